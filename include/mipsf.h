@@ -1,0 +1,190 @@
+/*
+ * mipsf.h -- C ABI of libmipsf_hip.so: the MI355X (gfx950) implementation of the MIPS-Fusion
+ * render-and-optimise hot path.
+ *
+ * Every entry point is a plain `extern "C"` function over raw device pointers and sizes.  All
+ * pointers are DEVICE pointers (HBM) unless the name ends in `_host`; the caller owns every buffer;
+ * kernels are enqueued on the `hipStream_t` passed as `void* stream` and never synchronise the
+ * device.  Return value: 0 = ok, non-zero = error (message via mipsf_last_error(), thread local).
+ * No exceptions cross this boundary.
+ *
+ * Reference interfaces replaced (paths under the upstream repository root):
+ *   mipsf_hashgrid_*      tinycudann.Encoding(HashGrid)   model/encodings.py:11-26, used model/scene_rep.py:40,122
+ *   mipsf_freq_*          tinycudann.Encoding(Frequency)  model/encodings.py:29-39, used model/scene_rep.py:37,123
+ *   mipsf_decoder_*       MLP_reg.forward (+autograd)     model/decoder.py:53-75 (layers :32-50)
+ *   mipsf_sample_rays     render_rays steps 1-2 + run_network normalisation
+ *                                                         model/scene_rep.py:156-179, 134-142
+ *   mipsf_render_*        sdf2weights / raw2outputs / forward losses
+ *                                                         model/scene_rep.py:58-103, 211-236;
+ *                                                         helper_functions/utils.py:21-111
+ *   mipsf_rays_bwd        autograd of pts = o + d*z and of the fp64 normalisation
+ *   mipsf_adam_step       torch.optim.Adam.step           mipsfusion.py:580-584, 190, 330-335
+ *   mipsf_ro_fitness      RandomOptimizer.get_fitness     RandomOptimizer.py:113-131
+ */
+#ifndef MIPSF_H
+#define MIPSF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIPSF_MAX_LEVELS 32
+#define MIPSF_ABI_VERSION 1
+
+/* ------------------------------------------------------------------ errors / info */
+const char* mipsf_last_error(void);
+int mipsf_abi_version(void);
+/* number of compute units of the current device (used to size persistent grids); <0 on error */
+int mipsf_device_cu_count(void);
+
+/* --------------------------------------------------------------- hash grid (a5) */
+typedef struct mipsf_grid_meta {
+    uint32_t n_levels;              /* L                                   */
+    uint32_t n_features;            /* F, only 2 is built                   */
+    uint32_t log2_hashmap_size;     /* T = 2^this                           */
+    uint32_t base_resolution;       /* N_min                                */
+    float per_level_scale;          /* b as fp32                            */
+    float log2_per_level_scale;     /* log2f(b)                             */
+    uint32_t n_params;              /* total floats = offsets[L] * F        */
+    uint32_t offsets[MIPSF_MAX_LEVELS + 1];   /* entry offset of each level */
+    uint32_t resolutions[MIPSF_MAX_LEVELS];
+    float scales[MIPSF_MAX_LEVELS];
+} mipsf_grid_meta;
+
+/* Host-only: fill the level table exactly as tiny-cuda-nn's GridEncodingTemplated constructor does. */
+int mipsf_hashgrid_meta_init(mipsf_grid_meta* meta_host, uint32_t n_levels, uint32_t n_features,
+                             uint32_t log2_hashmap_size, uint32_t base_resolution, double per_level_scale);
+
+/* Feature layouts.  AOS: out[i*L*F + level*F + f] (what tcnn.Encoding returns).
+ * LEVEL_MAJOR: out[(level*M + i)*F + f] (internal layout between the grid and the decoder). */
+#define MIPSF_FEAT_AOS 0
+#define MIPSF_FEAT_LEVEL_MAJOR 1
+
+/* x: [M,3] fp32 already normalised (scene_rep.py:140-142 + :119); params: [n_params]; out: [M,L*F]. */
+int mipsf_hashgrid_fwd(const float* x, const float* params, float* out, uint32_t M,
+                       const mipsf_grid_meta* meta_host, int layout, void* stream);
+/* dparams += scatter (fp32 atomics; caller zeroes or accumulates); dx (nullable) += dL/dx [M,3]. */
+int mipsf_hashgrid_bwd(const float* x, const float* params, const float* dout, float* dparams, float* dx,
+                       uint32_t M, const mipsf_grid_meta* meta_host, int layout, void* stream);
+/* parity probe: idx[(i*L + level)*8 + corner] = entry index inside the level (uint32). */
+int mipsf_hashgrid_indices(const float* x, uint32_t* idx, uint32_t M, const mipsf_grid_meta* meta_host,
+                           void* stream);
+
+/* --------------------------------------------------------------- frequency (a6) */
+int mipsf_freq_fwd(const float* x, float* out, uint32_t M, uint32_t n_dims, uint32_t n_freq, void* stream);
+int mipsf_freq_bwd(const float* x, const float* dout, float* dx, uint32_t M, uint32_t n_dims,
+                   uint32_t n_freq, void* stream);
+
+/* ------------------------------------------------------------------ decoder (a7) */
+/* Architecture is the reference's fixed one: e = [x(3), pe(48)] -> 128 -> 128 = [sdf_emb 64 | rgb_emb 64];
+ * rgb = L(115->3)([rgb_emb, e]); prob = softmax(L(128->5)(relu(L(96->128)([sdf_emb, grid32])))). */
+typedef struct mipsf_decoder_weights {   /* nn.Linear layout: weight [out,in] row-major, bias [out] */
+    const float* w_pts0; const float* b_pts0;   /* [128,51]  */
+    const float* w_pts2; const float* b_pts2;   /* [128,128] */
+    const float* w_rgb0; const float* b_rgb0;   /* [3,115]   */
+    const float* w_sdf0; const float* b_sdf0;   /* [128,96]  */
+    const float* w_sdf2; const float* b_sdf2;   /* [5,128]   */
+} mipsf_decoder_weights;
+
+typedef struct mipsf_decoder_grads {
+    float* w_pts0; float* b_pts0; float* w_pts2; float* b_pts2; float* w_rgb0; float* b_rgb0;
+    float* w_sdf0; float* b_sdf0; float* w_sdf2; float* b_sdf2;
+} mipsf_decoder_grads;
+
+/* sizes (in floats) of the scratch buffers the caller must provide */
+uint32_t mipsf_decoder_packed_floats(void);            /* MFMA operand images of the weights        */
+uint64_t mipsf_decoder_saved_floats(uint32_t M);       /* activations kept for backward              */
+uint64_t mipsf_decoder_dact_floats(uint32_t M);        /* pre-activation gradients (chain -> wgrad)  */
+uint64_t mipsf_decoder_wgrad_partial_floats(void);     /* per-block partial weight gradients         */
+
+/* repack nn.Linear weights into MFMA A-operand images (run after every optimiser step) */
+int mipsf_decoder_pack(const mipsf_decoder_weights* w_host_struct, float* packed, void* stream);
+/* host mirror of the same packing (plain CPU; used by the layout unit tests) */
+int mipsf_decoder_pack_host(const mipsf_decoder_weights* w_host_ptrs, float* packed_host);
+
+/* Forward.  pe_mode 0: positional encoding computed in-kernel from x (n_freq = 8) -- `embed_pos` ignored.
+ *           pe_mode 1: `embed_pos` [M,48] is an input (module API of MLP_reg.forward).
+ * feat: grid features in `feat_layout`; x: [M,3]; out: [M,10] = rgb(3) sdf entropy prob(5).
+ * saved: nullable; when given, activations for backward are stored (mipsf_decoder_saved_floats(M)). */
+int mipsf_decoder_fwd(const float* packed, const float* feat, int feat_layout, const float* x,
+                      const float* embed_pos, int pe_mode, float* out, float* saved, uint32_t M, void* stream);
+/* Backward.  dout [M,10].  Outputs: dfeat (layout as feat), dx [M,3] (pe_mode 0: includes the PE chain),
+ * dembed_pos [M,48] (pe_mode 1 only).  Weight gradients are ACCUMULATED into `grads`.
+ * dact / partial: scratch of the sizes above. */
+int mipsf_decoder_bwd(const float* packed, const float* feat, int feat_layout, const float* x,
+                      const float* embed_pos, int pe_mode, const float* out, const float* dout,
+                      const float* saved, float* dfeat, float* dx, float* dembed_pos,
+                      const mipsf_decoder_grads* grads_host_struct, float* dact, float* partial,
+                      uint32_t M, void* stream);
+
+/* -------------------------------------------------- sample placement (a3 + a4) */
+typedef struct mipsf_render_cfg {
+    uint32_t n_uniform;      /* training.n_samples_d (or n_samples when no depth guidance) */
+    uint32_t n_near;         /* training.n_range_d   (0 when no depth guidance)            */
+    int perturb;             /* training.perturb > 0                                       */
+    int use_bound;           /* grid.use_bound_normalize                                   */
+    double bound_min[3];     /* mapping.bound[:,0]   (fp64, mipsfusion.py:94-96)           */
+    double bound_max[3];
+    double half_len[3];      /* mapping.localMLP_max_len                                   */
+    double norm_factor;      /* training.norm_factor                                       */
+    float trunc;             /* training.trunc                                             */
+    float sc_factor;         /* data.sc_factor                                             */
+    float depth_trunc;       /* cam.depth_trunc                                            */
+    int rgb_missing_nonzero; /* training.rgb_missing != 0                                  */
+    float emd_w;             /* EMD_w of JointEncoding.forward                             */
+} mipsf_render_cfg;
+
+/* z_uniform [n_uniform], z_near_offsets [n_near], z_near_nodepth [n_near]: the three torch.linspace tables
+ * (computed once on the host by torch so that placement is bit-identical).  target_d nullable (then
+ * n_near must be 0).  noise [N,S] U[0,1) (nullable when !perturb).  Outputs: z_vals [N,S]; xn [N*S,3]
+ * normalised fp32 coordinates; counts[2] (uint32, zeroed by the caller) += {#front, #band} of
+ * helper_functions/utils.py:33-44 (only when target_d != NULL). */
+int mipsf_sample_rays(const float* rays_o, const float* rays_d, const float* target_d, const float* noise,
+                      const float* z_uniform, const float* z_near_offsets, const float* z_near_nodepth,
+                      const mipsf_render_cfg* cfg_host, float* z_vals, float* xn, uint32_t* counts,
+                      uint32_t N, void* stream);
+/* normalise arbitrary points (run_network, scene_rep.py:134-146): pts [M,3] fp32 -> xn [M,3] fp32 */
+int mipsf_normalise_points(const float* pts, const mipsf_render_cfg* cfg_host, float* xn, uint32_t M,
+                           void* stream);
+
+/* ------------------------------------------------ compositing + losses (a8, a9) */
+/* raw [N,S,10], z_vals [N,S] -> per-ray rgb[N,3], depth, depth_var, disp, acc [N], weights [N,S] (nullable).
+ * When `losses` != NULL (training): target_rgb [N,3], target_d [N,1], counts[2] from mipsf_sample_rays;
+ * losses[8] = {rgb_loss, depth_loss, sdf_loss, fs_loss, psnr, fs_weight, sdf_weight, n_valid_depth};
+ * partial: scratch [N*8]. */
+int mipsf_render_fwd(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
+                     const uint32_t* counts, const mipsf_render_cfg* cfg_host, float* rgb, float* depth,
+                     float* depth_var, float* disp, float* acc, float* weights, float* losses,
+                     float* partial, uint32_t N, uint32_t S, void* stream);
+/* Gradients wrt raw.  g_losses[4] (device): d total / d {rgb_loss, depth_loss, sdf_loss, fs_loss};
+ * g_rgb [N,3], g_depth [N] nullable extra gradients on the rendered maps.  draw [N,S,10] is written. */
+int mipsf_render_bwd(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
+                     const uint32_t* counts, const float* losses, const mipsf_render_cfg* cfg_host,
+                     const float* g_losses, const float* g_rgb, const float* g_depth, float* draw,
+                     uint32_t N, uint32_t S, void* stream);
+/* dxn [N*S,3] -> d_rays_o [N,3], d_rays_d [N,3] (written) */
+int mipsf_rays_bwd(const float* dxn, const float* z_vals, const mipsf_render_cfg* cfg_host, float* d_rays_o,
+                   float* d_rays_d, uint32_t N, uint32_t S, void* stream);
+/* dxn [M,3] -> dpts [M,3]: autograd of mipsf_normalise_points */
+int mipsf_normalise_bwd(const float* dxn, const mipsf_render_cfg* cfg_host, float* dpts, uint32_t M,
+                        void* stream);
+
+/* ------------------------------------------------------------------- Adam (a11) */
+/* One dense torch.optim.Adam step over n floats.  step = 1-based count after increment.
+ * zero_grad != 0 clears grad in the same pass. */
+int mipsf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, uint32_t step, int zero_grad,
+                    void* stream);
+
+/* -------------------------------------------------- RandomOptimizer fitness (a12) */
+/* sdf [P,n] (column 3 of run_network output, stride `sdf_stride` floats) , valid [n] ->
+ * mean_masked[P] = mean_j(valid_j * |sdf*trunc|)  (RandomOptimizer.py:125-129) */
+int mipsf_ro_fitness(const float* raw, uint32_t raw_stride, const float* target_d, float trunc,
+                     float* mean_masked, uint32_t P, uint32_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIPSF_H */

@@ -1,0 +1,127 @@
+"""ctypes binding of libmipsf_hip.so (C ABI: include/mipsf.h).
+
+The product path has no fallback: a missing library raises at first use, and every
+operator raises when its tensors are not on a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmipsf_hip.so")
+MAX_LEVELS = 32
+FEAT_AOS, FEAT_LEVEL_MAJOR = 0, 1
+
+
+class GridMeta(C.Structure):
+    _fields_ = [("n_levels", C.c_uint32), ("n_features", C.c_uint32), ("log2_hashmap_size", C.c_uint32),
+                ("base_resolution", C.c_uint32), ("per_level_scale", C.c_float),
+                ("log2_per_level_scale", C.c_float), ("n_params", C.c_uint32),
+                ("offsets", C.c_uint32 * (MAX_LEVELS + 1)), ("resolutions", C.c_uint32 * MAX_LEVELS),
+                ("scales", C.c_float * MAX_LEVELS)]
+
+
+class DecoderWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w_pts0", "b_pts0", "w_pts2", "b_pts2", "w_rgb0", "b_rgb0",
+                                          "w_sdf0", "b_sdf0", "w_sdf2", "b_sdf2")]
+
+
+DecoderGrads = DecoderWeights   # same field order, non-const pointers
+
+
+class RenderCfg(C.Structure):
+    _fields_ = [("n_uniform", C.c_uint32), ("n_near", C.c_uint32), ("perturb", C.c_int), ("use_bound", C.c_int),
+                ("bound_min", C.c_double * 3), ("bound_max", C.c_double * 3), ("half_len", C.c_double * 3),
+                ("norm_factor", C.c_double), ("trunc", C.c_float), ("sc_factor", C.c_float),
+                ("depth_trunc", C.c_float), ("rgb_missing_nonzero", C.c_int), ("emd_w", C.c_float)]
+
+
+_P = C.c_void_p
+_U32, _U64, _I, _F, _D = C.c_uint32, C.c_uint64, C.c_int, C.c_float, C.c_double
+
+# name -> (restype, argtypes); every symbol include/mipsf.h declares
+SIGNATURES = {
+    "mipsf_last_error": (C.c_char_p, []),
+    "mipsf_abi_version": (_I, []),
+    "mipsf_device_cu_count": (_I, []),
+    "mipsf_hashgrid_meta_init": (_I, [C.POINTER(GridMeta), _U32, _U32, _U32, _U32, _D]),
+    "mipsf_hashgrid_fwd": (_I, [_P, _P, _P, _U32, C.POINTER(GridMeta), _I, _P]),
+    "mipsf_hashgrid_bwd": (_I, [_P, _P, _P, _P, _P, _U32, C.POINTER(GridMeta), _I, _P]),
+    "mipsf_hashgrid_indices": (_I, [_P, _P, _U32, C.POINTER(GridMeta), _P]),
+    "mipsf_freq_fwd": (_I, [_P, _P, _U32, _U32, _U32, _P]),
+    "mipsf_freq_bwd": (_I, [_P, _P, _P, _U32, _U32, _U32, _P]),
+    "mipsf_decoder_packed_floats": (_U32, []),
+    "mipsf_decoder_saved_floats": (_U64, [_U32]),
+    "mipsf_decoder_dact_floats": (_U64, [_U32]),
+    "mipsf_decoder_wgrad_partial_floats": (_U64, []),
+    "mipsf_decoder_pack": (_I, [C.POINTER(DecoderWeights), _P, _P]),
+    "mipsf_decoder_pack_host": (_I, [C.POINTER(DecoderWeights), _P]),
+    "mipsf_decoder_fwd": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _U32, _P]),
+    "mipsf_decoder_bwd": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.POINTER(DecoderGrads), _P, _P,
+                               _U32, _P]),
+    "mipsf_sample_rays": (_I, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _U32, _P]),
+    "mipsf_normalise_points": (_I, [_P, C.POINTER(RenderCfg), _P, _U32, _P]),
+    "mipsf_render_fwd": (_I, [_P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _U32, _U32,
+                              _P]),
+    "mipsf_render_bwd": (_I, [_P, _P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _U32, _U32, _P]),
+    "mipsf_rays_bwd": (_I, [_P, _P, C.POINTER(RenderCfg), _P, _P, _U32, _U32, _P]),
+    "mipsf_normalise_bwd": (_I, [_P, C.POINTER(RenderCfg), _P, _U32, _P]),
+    "mipsf_adam_step": (_I, [_P, _P, _P, _P, _U64, _F, _F, _F, _F, _F, _U32, _I, _P]),
+    "mipsf_ro_fitness": (_I, [_P, _U32, _P, _F, _P, _U32, _U32, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C mipsfusion_amd/csrc`). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.mipsf_abi_version() != 1:
+            raise RuntimeError("libmipsf_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().mipsf_last_error().decode(errors="replace")
+        raise RuntimeError(f"libmipsf_hip {what} failed (code {rc}): {msg}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dptr(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[int]:
+    """Device pointer of a contiguous GPU tensor (None passes through as NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("mipsfusion_amd operators need GPU tensors (no CPU fallback exists)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def make_grid_meta(n_levels=16, n_features=2, log2_hashmap_size=19, base_resolution=16,
+                   per_level_scale=2.0) -> GridMeta:
+    m = GridMeta()
+    check(lib().mipsf_hashgrid_meta_init(C.byref(m), n_levels, n_features, log2_hashmap_size, base_resolution,
+                                         float(per_level_scale)), "hashgrid_meta_init")
+    return m

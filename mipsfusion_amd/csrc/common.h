@@ -1,0 +1,74 @@
+// Shared host/device helpers for libmipsf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/mipsf.h"
+
+#define MIPSF_WAVE 64
+
+namespace mipsf {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define MIPSF_REQUIRE(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            ::mipsf::set_error(__VA_ARGS__);     \
+            return 1;                            \
+        }                                        \
+    } while (0)
+
+// level table handed to kernels by value
+struct GridLevels {
+    uint32_t n_levels;
+    uint32_t offsets[MIPSF_MAX_LEVELS + 1];
+    uint32_t res[MIPSF_MAX_LEVELS];
+    float scale[MIPSF_MAX_LEVELS];
+};
+
+// normalisation constants handed to kernels by value (fp64 on purpose: mipsfusion.py:94-96 builds
+// the bounding box as a float64 tensor, so scene_rep.py:140/142 computes in float64)
+struct NormCfg {
+    double sub[3];   // x -> (x - sub) / div / norm_factor   (use_bound: sub = bmin, div = bmax - bmin;
+    double div[3];   //                                       else:      sub = -L,   div = 2L)
+    double norm_factor;
+};
+
+inline NormCfg make_norm(const mipsf_render_cfg& c) {
+    NormCfg n;
+    for (int d = 0; d < 3; ++d) {
+        if (c.use_bound) {
+            n.sub[d] = c.bound_min[d];
+            n.div[d] = c.bound_max[d] - c.bound_min[d];
+        } else {
+            n.sub[d] = -c.half_len[d];
+            n.div[d] = 2 * c.half_len[d];
+        }
+    }
+    n.norm_factor = c.norm_factor;
+    return n;
+}
+
+__device__ __forceinline__ float normalise1(float p, double sub, double div, double nf) {
+    return (float)((((double)p - sub) / div) / nf);
+}
+
+// ---- wave-level helpers (wave = 64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+}  // namespace mipsf

@@ -1,0 +1,694 @@
+// SDF/colour decoder MLP (model/decoder.py:32-75 of the reference) for gfx950, forward and backward,
+// on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, bitwise an fmaf chain).
+//
+// Kernels
+//   decoder_pack_kernel    nn.Linear weights -> MFMA A-operand images (decoder_layout.h)
+//   decoder_fwd_kernel     one wave = 32 samples; the 51->128->128->{115->3, 96->128->5} chain stays in
+//                          accumulator registers from the positional encoding to the softmax (no LDS).
+//   decoder_bwd_kernel     same structure for the activation-gradient chain; emits d(feat), d(x) and the
+//                          pre-activation gradients the weight-gradient kernel needs.
+//   decoder_wgrad_kernel   dW = dOut^T * In as MFMA GEMMs whose reduction index is the SAMPLE: a block of
+//                          4 waves transposes 128 samples through LDS, each wave owns 11 of the 44 output
+//                          tiles and keeps them in registers across its whole share of the batch.
+//   decoder_wgrad_reduce   sum of the per-block partials, accumulated into the .grad tensors.
+//
+// Roofline: MFMA-bound.  72 370 FLOP/sample forward, 217 110 forward+backward; the three big layers
+// are 138 k-steps x 4 row tiles = 552 MFMAs (64 cycles each) per 32 samples forward.
+#include "common.h"
+#include "decoder_layout.h"
+
+namespace mipsf {
+using namespace dl;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr float PI_F = 3.14159265358979323846f;
+constexpr float HALF_PI_F = 1.57079632679489661923f;
+constexpr int DEC_BLOCK = 256;
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// acc[rt] += A_image(rt, t) * B(t) for all k-steps; bfn(t) must fold to a register after unrolling
+template <int RT, int T, typename BFn>
+__device__ __forceinline__ void mfma_layer(const float4* __restrict__ img, int lane, f32x16 (&acc)[RT], BFn bfn) {
+    constexpr int T4 = T / 4;
+#pragma unroll
+    for (int t4 = 0; t4 < T4; ++t4) {
+        float4 a[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a[rt] = img[(rt * T4 + t4) * 64 + lane];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma(a[rt].x, bfn(t4 * 4 + 0), acc[rt]);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma(a[rt].y, bfn(t4 * 4 + 1), acc[rt]);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma(a[rt].z, bfn(t4 * 4 + 2), acc[rt]);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma(a[rt].w, bfn(t4 * 4 + 3), acc[rt]);
+    }
+}
+
+template <int RT>
+__device__ __forceinline__ void load_bias(const float* __restrict__ packed, int layer, int h, f32x16 (&acc)[RT]) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][r] = packed[OFF_BIAS + ((layer * 64 + rt * 16 + r) << 1) + h];
+}
+
+__device__ __forceinline__ void store_act(float* __restrict__ dst, int64_t tile, int mat, int lane,
+                                          const f32x16 (&acc)[4]) {
+    float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            d4[(tile * (ACT_SLOTS / 4) + mat * 16 + rt * 4 + g) * 64 + lane] =
+                make_float4(acc[rt][4 * g], acc[rt][4 * g + 1], acc[rt][4 * g + 2], acc[rt][4 * g + 3]);
+}
+
+__device__ __forceinline__ void load_act(const float* __restrict__ src, int64_t tile, int mat, int lane,
+                                         f32x16 (&acc)[4]) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = s4[(tile * (ACT_SLOTS / 4) + mat * 16 + rt * 4 + g) * 64 + lane];
+            acc[rt][4 * g] = v.x, acc[rt][4 * g + 1] = v.y, acc[rt][4 * g + 2] = v.z, acc[rt][4 * g + 3] = v.w;
+        }
+}
+
+// the 26 e values this lane feeds into layer 1 (its half of every k-step)
+template <bool PE_INTERNAL>
+__device__ __forceinline__ void load_e(const float* __restrict__ x, const float* __restrict__ embed_pos,
+                                       uint32_t s, int h, float (&ev)[E_SLOTS]) {
+    const float x0 = x[3 * (size_t)s], x1 = x[3 * (size_t)s + 1], x2 = x[3 * (size_t)s + 2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float xd = d == 0 ? x0 : (d == 1 ? x1 : x2);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (PE_INTERNAL)
+                ev[d * 8 + k] = sinf(fmaf(ldexpf(xd, k), PI_F, h ? HALF_PI_F : 0.0f));
+            else
+                ev[d * 8 + k] = embed_pos[(size_t)s * N_PE + d * 16 + 2 * k + h];
+        }
+    }
+    ev[24] = h ? x1 : x0;
+    ev[25] = h ? 0.0f : x2;
+}
+
+template <int LAYOUT>
+__device__ __forceinline__ float load_feat(const float* __restrict__ feat, uint32_t s, int level, int f, uint32_t M) {
+    return LAYOUT == MIPSF_FEAT_AOS ? feat[(size_t)s * N_GRID + 2 * level + f] : feat[((size_t)level * M + s) * 2 + f];
+}
+
+// ================================================================================ forward
+template <bool PE_INTERNAL, int LAYOUT, bool SAVE>
+__global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_fwd_kernel(const float* __restrict__ packed,
+                                                                const float* __restrict__ feat,
+                                                                const float* __restrict__ x,
+                                                                const float* __restrict__ embed_pos,
+                                                                float* __restrict__ out, float* __restrict__ saved,
+                                                                uint32_t M) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + (threadIdx.x >> 6);
+    if (tile * 32 >= (int64_t)M) return;
+    const uint32_t s_raw = (uint32_t)(tile * 32 + j);
+    const bool live = s_raw < M;
+    const uint32_t s = live ? s_raw : M - 1;   // tail lanes recompute the last sample (finite values, no stores)
+
+    float ev[E_SLOTS];
+    load_e<PE_INTERNAL>(x, embed_pos, s, h, ev);
+
+    // ---- layer 1: pts_linear.0 + ReLU
+    f32x16 H1[4];
+    load_bias(packed, 0, h, H1);
+    mfma_layer<RT_F1, T_F1>(reinterpret_cast<const float4*>(packed + OFF_F1), lane, H1,
+                            [&](int t) { return t < E_SLOTS ? ev[t] : 0.0f; });
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H1[rt][r] = fmaxf(H1[rt][r], 0.0f);
+    if (SAVE) store_act(saved, tile, 0, lane, H1);
+
+    // ---- layer 2: pts_linear.2 -> [sdf_emb | rgb_emb]
+    f32x16 H2[4];
+    load_bias(packed, 1, h, H2);
+    mfma_layer<RT_F2, T_F2>(reinterpret_cast<const float4*>(packed + OFF_F2), lane, H2,
+                            [&](int t) { return H1[t >> 4][t & 15]; });
+    if (SAVE) store_act(saved, tile, 1, lane, H2);
+
+    // ---- rgb_linear.0 on the vector ALU (3 outputs): this lane's half of every dot product, then one swap
+    float pr[3] = {0.f, 0.f, 0.f};
+    {
+        const float4* trgb = reinterpret_cast<const float4*>(packed + OFF_TRGB) + h * TRGB_SLOTS;
+#pragma unroll
+        for (int slot = 0; slot < 32; ++slot) {
+            const float4 wv = trgb[slot];
+            const float v = H2[2 + (slot >> 4)][slot & 15];
+            pr[0] = fmaf(wv.x, v, pr[0]), pr[1] = fmaf(wv.y, v, pr[1]), pr[2] = fmaf(wv.z, v, pr[2]);
+        }
+#pragma unroll
+        for (int t = 0; t < E_SLOTS; ++t) {
+            const float4 wv = trgb[32 + t];
+            pr[0] = fmaf(wv.x, ev[t], pr[0]), pr[1] = fmaf(wv.y, ev[t], pr[1]), pr[2] = fmaf(wv.z, ev[t], pr[2]);
+        }
+    }
+    float rgb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgb[c] = (pr[c] + __shfl_xor(pr[c], 32, 64)) + packed[OFF_BSMALL + c];
+
+    // ---- layer 3: sdf_linear.0 + ReLU on [sdf_emb (regs of H2 tiles 0,1) | grid features (loaded)]
+    float gf[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) gf[u] = load_feat<LAYOUT>(feat, s, u, h, M);
+    f32x16 H3[4];
+    load_bias(packed, 2, h, H3);
+    mfma_layer<RT_F3, T_F3>(reinterpret_cast<const float4*>(packed + OFF_F3), lane, H3,
+                            [&](int t) { return t < 32 ? H2[t >> 4][t & 15] : gf[t - 32]; });
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H3[rt][r] = fmaxf(H3[rt][r], 0.0f);
+    if (SAVE) store_act(saved, tile, 2, lane, H3);
+
+    // ---- sdf_linear.2 (5 logits) on the vector ALU, softmax, entropy, expected class -> SDF
+    float pl[N_CLASS] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    {
+        const float4* ts2 = reinterpret_cast<const float4*>(packed + OFF_TS2) + h * 128;
+#pragma unroll
+        for (int slot = 0; slot < 64; ++slot) {
+            const float4 w0 = ts2[2 * slot], w1 = ts2[2 * slot + 1];
+            const float v = H3[slot >> 4][slot & 15];
+            pl[0] = fmaf(w0.x, v, pl[0]), pl[1] = fmaf(w0.y, v, pl[1]), pl[2] = fmaf(w0.z, v, pl[2]);
+            pl[3] = fmaf(w0.w, v, pl[3]), pl[4] = fmaf(w1.x, v, pl[4]);
+        }
+    }
+    float lg[N_CLASS], mx = -3.0e38f;
+#pragma unroll
+    for (int c = 0; c < N_CLASS; ++c) {
+        lg[c] = (pl[c] + __shfl_xor(pl[c], 32, 64)) + packed[OFF_BSMALL + 4 + c];
+        mx = fmaxf(mx, lg[c]);
+    }
+    float p[N_CLASS], den = 0.f;
+#pragma unroll
+    for (int c = 0; c < N_CLASS; ++c) {
+        p[c] = expf(lg[c] - mx);
+        den += p[c];
+    }
+    float ent = 0.f, cls = 0.f;
+#pragma unroll
+    for (int c = 0; c < N_CLASS; ++c) {
+        p[c] = p[c] / den;
+        ent += p[c] * log2f(p[c] + 1e-5f);
+        cls += p[c] * (float)c;
+    }
+    const float sdf = (cls / 4.0f - 0.5f) * 2.0f;
+    if (live) {
+        float* o = out + (size_t)s * 10;
+        if (h == 0) {
+            o[0] = rgb[0], o[1] = rgb[1], o[2] = rgb[2], o[3] = sdf, o[4] = -1.0f * ent;
+        } else {
+            o[5] = p[0], o[6] = p[1], o[7] = p[2], o[8] = p[3], o[9] = p[4];
+        }
+    }
+}
+
+// ============================================================================ backward chain
+// dsmall[s*8 + {0..4}] = d logits, {5..7} = d rgb (inputs of the two small weight-gradient GEMMs)
+template <bool PE_INTERNAL, int LAYOUT>
+__global__ __launch_bounds__(DEC_BLOCK) void decoder_bwd_kernel(
+    const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ out,
+    const float* __restrict__ dout, const float* __restrict__ saved, float* __restrict__ dfeat,
+    float* __restrict__ dx, float* __restrict__ dembed_pos, float* __restrict__ dact, float* __restrict__ dsmall,
+    uint32_t M) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + (threadIdx.x >> 6);
+    if (tile * 32 >= (int64_t)M) return;
+    const uint32_t s_raw = (uint32_t)(tile * 32 + j);
+    const bool live = s_raw < M;
+    const uint32_t s = live ? s_raw : M - 1;
+
+    // ---- softmax / entropy / expected-class backward -> d logits; d rgb is the incoming gradient itself
+    float dlg[N_CLASS], drgb[3];
+    {
+        const float* o = out + (size_t)s * 10;
+        const float* g = dout + (size_t)s * 10;
+        const float g_sdf = live ? g[3] : 0.f, g_ent = live ? g[4] : 0.f;
+        float p[N_CLASS], dp[N_CLASS], dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < N_CLASS; ++c) {
+            p[c] = o[5 + c];
+            const float q = p[c] + 1e-5f;
+            const float dent = -1.0f * (log2f(q) + p[c] / (q * 0.69314718055994530942f));
+            dp[c] = (live ? g[5 + c] : 0.f) + g_sdf * (0.5f * (float)c) + g_ent * dent;
+            dot += p[c] * dp[c];
+        }
+#pragma unroll
+        for (int c = 0; c < N_CLASS; ++c) dlg[c] = p[c] * (dp[c] - dot);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) drgb[c] = live ? g[c] : 0.f;
+        if (h == 0) {
+            float4* d4 = reinterpret_cast<float4*>(dsmall + (size_t)(tile * 32 + j) * 8);
+            d4[0] = make_float4(dlg[0], dlg[1], dlg[2], dlg[3]);
+            d4[1] = make_float4(dlg[4], drgb[0], drgb[1], drgb[2]);
+        }
+    }
+
+    // ---- dG3 = relu'(H3) * (Ws2^T dlogits)   (vector ALU, K = 5)
+    f32x16 dG3[4];
+    {
+        f32x16 H3[4];
+        load_act(saved, tile, 2, lane, H3);
+        const float4* ts2 = reinterpret_cast<const float4*>(packed + OFF_TS2) + h * 128;
+#pragma unroll
+        for (int slot = 0; slot < 64; ++slot) {
+            const float4 w0 = ts2[2 * slot], w1 = ts2[2 * slot + 1];
+            float v = w0.x * dlg[0];
+            v = fmaf(w0.y, dlg[1], v), v = fmaf(w0.z, dlg[2], v), v = fmaf(w0.w, dlg[3], v), v = fmaf(w1.x, dlg[4], v);
+            dG3[slot >> 4][slot & 15] = H3[slot >> 4][slot & 15] > 0.0f ? v : 0.0f;
+        }
+    }
+    store_act(dact, tile, 2, lane, dG3);
+
+    // ---- d[sdf_emb | grid] = Ws1^T dG3   (3 row tiles: 0,1 -> d sdf_emb, 2 -> d grid features)
+    f32x16 dIn3[3];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dIn3[rt][r] = 0.0f;
+    mfma_layer<RT_B3, T_B3>(reinterpret_cast<const float4*>(packed + OFF_B3), lane, dIn3,
+                            [&](int t) { return dG3[t >> 4][t & 15]; });
+    if (live) {
+        // regs (r, r+1), r even, hold (level, f=0/1) of grid feature row rowmap(r,h) -> one 8-byte store each
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const int row = rowmap(r, h);
+            const float2 v = make_float2(dIn3[2][r], dIn3[2][r + 1]);
+            if (LAYOUT == MIPSF_FEAT_AOS)
+                *reinterpret_cast<float2*>(dfeat + (size_t)s * N_GRID + row) = v;
+            else
+                *reinterpret_cast<float2*>(dfeat + ((size_t)(row >> 1) * M + s) * 2) = v;
+        }
+    }
+
+    // ---- dH2 = [d sdf_emb (from above) | d rgb_emb = Wrgb^T drgb]; also the rgb branch's share of d e
+    f32x16 dH2[4];
+    dH2[0] = dIn3[0];
+    dH2[1] = dIn3[1];
+    float de[E_SLOTS];
+    {
+        const float4* trgb = reinterpret_cast<const float4*>(packed + OFF_TRGB) + h * TRGB_SLOTS;
+#pragma unroll
+        for (int slot = 0; slot < 32; ++slot) {
+            const float4 wv = trgb[slot];
+            dH2[2 + (slot >> 4)][slot & 15] = fmaf(wv.z, drgb[2], fmaf(wv.y, drgb[1], wv.x * drgb[0]));
+        }
+#pragma unroll
+        for (int t = 0; t < E_SLOTS; ++t) {
+            const float4 wv = trgb[32 + t];
+            de[t] = fmaf(wv.z, drgb[2], fmaf(wv.y, drgb[1], wv.x * drgb[0]));
+        }
+    }
+    store_act(dact, tile, 1, lane, dH2);
+
+    // ---- dG1 = relu'(H1) * (W2^T dH2)
+    f32x16 dG1[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dG1[rt][r] = 0.0f;
+    mfma_layer<RT_B2, T_B2>(reinterpret_cast<const float4*>(packed + OFF_B2), lane, dG1,
+                            [&](int t) { return dH2[t >> 4][t & 15]; });
+    {
+        f32x16 H1[4];
+        load_act(saved, tile, 0, lane, H1);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dG1[rt][r] = H1[rt][r] > 0.0f ? dG1[rt][r] : 0.0f;
+    }
+    store_act(dact, tile, 0, lane, dG1);
+
+    // ---- d e = W1^T dG1 (+ rgb share); rows are arranged so that e-slot (t, h) lands in THIS lane
+    f32x16 dE[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dE[rt][r] = 0.0f;
+    mfma_layer<RT_B1, T_B1>(reinterpret_cast<const float4*>(packed + OFF_B1), lane, dE,
+                            [&](int t) { return dG1[t >> 4][t & 15]; });
+#pragma unroll
+    for (int t = 0; t < E_SLOTS; ++t) de[t] = de[t] + dE[t >> 4][t & 15];
+
+    if (PE_INTERNAL) {
+        // chain through the frequency encoding: d sin(2^k pi x + phase)/dx = 2^k pi cos(.)
+        const float x0 = x[3 * (size_t)s], x1 = x[3 * (size_t)s + 1], x2 = x[3 * (size_t)s + 2];
+        float gx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float xd = d == 0 ? x0 : (d == 1 ? x1 : x2);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float arg = fmaf(ldexpf(xd, k), PI_F, h ? HALF_PI_F : 0.0f);
+                gx[d] = gx[d] + de[d * 8 + k] * ((ldexpf(1.0f, k) * PI_F) * cosf(arg));
+            }
+        }
+        gx[0] += h == 0 ? de[24] : 0.0f;   // slot 24 carries x0 (lower half) / x1 (upper half)
+        gx[1] += h == 1 ? de[24] : 0.0f;
+        gx[2] += h == 0 ? de[25] : 0.0f;   // slot 25 carries x2 (lower half only)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) gx[d] = gx[d] + __shfl_xor(gx[d], 32, 64);
+        if (live && h == 0) {
+            dx[3 * (size_t)s] = gx[0], dx[3 * (size_t)s + 1] = gx[1], dx[3 * (size_t)s + 2] = gx[2];
+        }
+    } else if (live) {
+#pragma unroll
+        for (int t = 0; t < 24; ++t) dembed_pos[(size_t)s * N_PE + (t >> 3) * 16 + 2 * (t & 7) + h] = de[t];
+        dx[3 * (size_t)s + h] = de[24];
+        if (h == 0) dx[3 * (size_t)s + 2] = de[25];
+    }
+}
+
+// ============================================================================ weight gradients
+constexpr int WG_LDW = 129;                         // odd row stride: conflict-free both ways
+constexpr int WG_ROWS = 128;
+constexpr int WG_LDS_FLOATS = 2 * WG_ROWS * WG_LDW;
+constexpr int WG_LDS_BYTES = WG_LDS_FLOATS * 4;
+
+// global (accumulator-image layout) -> LDS transposed [feature row][sample]; one row tile (16 regs) at a time
+__device__ __forceinline__ void stage_act(float* __restrict__ dstT, const float* __restrict__ src, int64_t tile,
+                                          int mat, int rt0, int nrt, int row_shift, bool live, int w, int lane) {
+    const int j = lane & 31, h = lane >> 5;
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    for (int rt = rt0; rt < rt0 + nrt; ++rt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) v = s4[(tile * (ACT_SLOTS / 4) + mat * 16 + rt * 4 + g) * 64 + lane];
+            float* d = dstT + (feat_of(rt, 4 * g, h) + row_shift) * WG_LDW + 32 * w + j;   // regs 4g..4g+3 -> rows +0..+3
+            d[0] = v.x, d[WG_LDW] = v.y, d[2 * WG_LDW] = v.z, d[3 * WG_LDW] = v.w;
+        }
+    }
+}
+
+// acc[ct] += X^T[row tile rtile] * Y^T[col tile ct0+ct]^T over the block's 128 samples
+template <int NCT>
+__device__ __forceinline__ void wgrad_mma(const float* __restrict__ XT, const float* __restrict__ YT, int rtile,
+                                          int ct0, int lane, f32x16 (&acc)[NCT], bool a_rows_lt8 = false) {
+    const int i = lane & 31, kk = lane >> 5;
+    const float* xa = XT + (32 * rtile + i) * WG_LDW + kk;
+    const float* yb = YT + (32 * ct0 + i) * WG_LDW + kk;
+#pragma unroll 4
+    for (int t = 0; t < 64; ++t) {
+        float a = xa[2 * t];
+        if (a_rows_lt8) a = i < 8 ? a : 0.0f;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = mfma(a, yb[ct * 32 * WG_LDW + 2 * t], acc[ct]);
+    }
+}
+
+template <int NCT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NCT]) {
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
+}
+
+// write one accumulator tile into the block's natural-layout partial record
+__device__ __forceinline__ void flush_tile(float* __restrict__ rec, int base, int out_dim, int in_dim, int rtile,
+                                           int ctile, int lane, const f32x16& acc) {
+    const int jj = lane & 31, hh = lane >> 5;
+    const int col = 32 * ctile + jj;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = 32 * rtile + rowmap(r, hh);
+        if (row < out_dim && col < in_dim) rec[base + row * in_dim + col] = acc[r];
+    }
+}
+
+template <bool PE_INTERNAL, int LAYOUT>
+__global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
+    const float* __restrict__ feat, const float* __restrict__ x, const float* __restrict__ embed_pos,
+    const float* __restrict__ saved, const float* __restrict__ dact, const float* __restrict__ dsmall,
+    float* __restrict__ partial, uint32_t M, uint32_t n_btiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* XT = lds;
+    float* YT = lds + WG_ROWS * WG_LDW;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+
+    f32x16 aS1[3], aW2[4], aW1[2], aS2[1], aRGB[1];
+    zero_acc(aS1), zero_acc(aW2), zero_acc(aW1), zero_acc(aS2), zero_acc(aRGB);
+    float db3 = 0.f, db2 = 0.f, db1 = 0.f, dbs = 0.f;
+    const int brow = tid & 127, bhalf = tid >> 7;
+
+    auto row_sum = [&](const float* T, int row, int c0, int n) {
+        float a = 0.f;
+        for (int c = 0; c < n; ++c) a += T[row * WG_LDW + c0 + c];
+        return a;
+    };
+
+    for (uint32_t bt = blockIdx.x; bt < n_btiles; bt += gridDim.x) {
+        const int64_t tile = (int64_t)bt * 4 + w;
+        const bool tile_live = tile * 32 < (int64_t)M;
+        const uint32_t s_raw = (uint32_t)(tile * 32 + j);
+        const uint32_t s = s_raw < M ? s_raw : M - 1;
+
+        // ---------------- phase sdf0: X = dG3, Y = [sdf_emb | grid]
+        stage_act(XT, dact, tile, 2, 0, 4, 0, tile_live, w, lane);
+        stage_act(YT, saved, tile, 1, 0, 2, 0, tile_live, w, lane);
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            YT[(64 + 2 * u + h) * WG_LDW + 32 * w + j] = tile_live ? load_feat<LAYOUT>(feat, s, u, h, M) : 0.0f;
+        __syncthreads();
+        wgrad_mma<3>(XT, YT, w, 0, lane, aS1);
+        db3 += row_sum(XT, brow, 64 * bhalf, 64);
+        __syncthreads();
+
+        // ---------------- phase pts2: X = dH2, Y = H1
+        stage_act(XT, dact, tile, 1, 0, 4, 0, tile_live, w, lane);
+        stage_act(YT, saved, tile, 0, 0, 4, 0, tile_live, w, lane);
+        __syncthreads();
+        wgrad_mma<4>(XT, YT, w, 0, lane, aW2);
+        db2 += row_sum(XT, brow, 64 * bhalf, 64);
+        __syncthreads();
+
+        // ---------------- phase pts0: X = dG1, Y = e (rows 0..50, rows 51..63 zero)
+        stage_act(XT, dact, tile, 0, 0, 4, 0, tile_live, w, lane);
+        float ev[E_SLOTS];
+        load_e<PE_INTERNAL>(x, embed_pos, s, h, ev);
+#pragma unroll
+        for (int t = 0; t < E_SLOTS; ++t) {
+            const int e = eidx(t, h);
+            if (e >= 0) YT[e * WG_LDW + 32 * w + j] = tile_live ? ev[t] : 0.0f;
+        }
+        for (int q = tid; q < 13 * 128; q += DEC_BLOCK) YT[(51 + q / 128) * WG_LDW + (q % 128)] = 0.0f;
+        __syncthreads();
+        wgrad_mma<2>(XT, YT, w, 0, lane, aW1);
+        db1 += row_sum(XT, brow, 64 * bhalf, 64);
+        __syncthreads();
+
+        // ---------------- phase sdf2: X = [dlogits(5) | drgb(3)] (8 rows), Y = H3
+        {
+            const int sl = tid & 127, half = tid >> 7;
+            const int64_t sg = (int64_t)bt * 128 + sl;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sg < (int64_t)M) v = reinterpret_cast<const float4*>(dsmall + sg * 8)[half];
+            XT[(4 * half + 0) * WG_LDW + sl] = v.x;
+            XT[(4 * half + 1) * WG_LDW + sl] = v.y;
+            XT[(4 * half + 2) * WG_LDW + sl] = v.z;
+            XT[(4 * half + 3) * WG_LDW + sl] = v.w;
+        }
+        stage_act(YT, saved, tile, 2, 0, 4, 0, tile_live, w, lane);
+        __syncthreads();
+        wgrad_mma<1>(XT, YT, 0, w, lane, aS2, true);
+        if (tid < 16) dbs += row_sum(XT, tid & 7, 64 * (tid >> 3), 64);
+        __syncthreads();
+
+        // ---------------- phase rgb0: X = same 8 rows, Y = [rgb_emb (64) | e (51) | 0]
+        stage_act(YT, saved, tile, 1, 2, 2, -64, tile_live, w, lane);
+#pragma unroll
+        for (int t = 0; t < E_SLOTS; ++t) {
+            const int e = eidx(t, h);
+            if (e >= 0) YT[(64 + e) * WG_LDW + 32 * w + j] = tile_live ? ev[t] : 0.0f;
+        }
+        for (int q = tid; q < 13 * 128; q += DEC_BLOCK) YT[(115 + q / 128) * WG_LDW + (q % 128)] = 0.0f;
+        __syncthreads();
+        wgrad_mma<1>(XT, YT, 0, w, lane, aRGB, true);
+        __syncthreads();
+    }
+
+    // ---------------- flush this block's partial record
+    float* rec = partial + (size_t)blockIdx.x * (G_STRIDE + 0);
+    for (int q = tid; q < G_STRIDE; q += DEC_BLOCK) rec[q] = 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) flush_tile(rec, G_W_SDF0, HID, N_SDF_IN, w, ct, lane, aS1[ct]);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) flush_tile(rec, G_W_PTS2, HID, HID, w, ct, lane, aW2[ct]);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) flush_tile(rec, G_W_PTS0, HID, N_E, w, ct, lane, aW1[ct]);
+    {
+        // rows 0..4 of aS2 = d w_sdf2[c][32w + col]; rows 5..7 of aRGB = d w_rgb0[c][32w + col]
+        const int jj = lane & 31, hh = lane >> 5;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rowmap(r, hh), col = 32 * w + jj;
+            if (row < N_CLASS) rec[G_W_SDF2 + row * HID + col] = aS2[0][r];
+            if (row >= 5 && row < 8 && col < N_RGB_IN) rec[G_W_RGB0 + (row - 5) * N_RGB_IN + col] = aRGB[0][r];
+        }
+    }
+    // bias partials: two column halves per row -> atomics inside the block's own record (LDS-free, 2 adders)
+    atomicAdd(&rec[G_B_SDF0 + brow], db3);
+    atomicAdd(&rec[G_B_PTS2 + brow], db2);
+    atomicAdd(&rec[G_B_PTS0 + brow], db1);
+    if (tid < 16) {
+        const int row = tid & 7;
+        if (row < N_CLASS) atomicAdd(&rec[G_B_SDF2 + row], dbs);
+        else atomicAdd(&rec[G_B_RGB0 + row - 5], dbs);
+    }
+}
+
+struct GradPtrs {
+    float* p[10];   // order of the G_* record: w_pts0 b_pts0 w_pts2 b_pts2 w_rgb0 b_rgb0 w_sdf0 b_sdf0 w_sdf2 b_sdf2
+};
+
+__global__ __launch_bounds__(256) void decoder_wgrad_reduce_kernel(const float* __restrict__ partial, uint32_t nrec,
+                                                                   GradPtrs g) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= G_TOTAL) return;
+    float a = 0.f;
+    for (uint32_t b = 0; b < nrec; ++b) a += partial[(size_t)b * G_STRIDE + q];
+    const int bounds[11] = {G_W_PTS0, G_B_PTS0, G_W_PTS2, G_B_PTS2, G_W_RGB0, G_B_RGB0,
+                            G_W_SDF0, G_B_SDF0, G_W_SDF2, G_B_SDF2, G_TOTAL};
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+        if (q >= bounds[k] && q < bounds[k + 1]) g.p[k][q - bounds[k]] += a;
+}
+
+__global__ __launch_bounds__(256) void decoder_pack_kernel(W w, float* __restrict__ packed) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < PACKED_FLOATS) packed[idx] = packed_value(w, idx);
+}
+
+static W to_w(const mipsf_decoder_weights& s) {
+    W w;
+    w.w_pts0 = s.w_pts0, w.b_pts0 = s.b_pts0, w.w_pts2 = s.w_pts2, w.b_pts2 = s.b_pts2, w.w_rgb0 = s.w_rgb0;
+    w.b_rgb0 = s.b_rgb0, w.w_sdf0 = s.w_sdf0, w.b_sdf0 = s.b_sdf0, w.w_sdf2 = s.w_sdf2, w.b_sdf2 = s.b_sdf2;
+    return w;
+}
+
+constexpr uint32_t WG_MAX_BLOCKS = 256;
+
+static inline uint64_t n_wave_tiles(uint32_t M) { return ((uint64_t)M + 31) / 32; }
+static inline uint64_t n_block_tiles(uint32_t M) { return ((uint64_t)M + 127) / 128; }
+
+}  // namespace mipsf
+
+using namespace mipsf;
+
+extern "C" {
+
+uint32_t mipsf_decoder_packed_floats(void) { return (uint32_t)PACKED_FLOATS; }
+// saved / dact are addressed per 128-sample block tile by the weight-gradient kernel -> round up to 4 wave tiles
+uint64_t mipsf_decoder_saved_floats(uint32_t M) { return n_block_tiles(M) * 4 * ACT_TILE_FLOATS; }
+uint64_t mipsf_decoder_dact_floats(uint32_t M) { return n_block_tiles(M) * 4 * ACT_TILE_FLOATS + n_block_tiles(M) * 128 * 8; }
+uint64_t mipsf_decoder_wgrad_partial_floats(void) { return (uint64_t)WG_MAX_BLOCKS * G_STRIDE; }
+
+int mipsf_decoder_pack(const mipsf_decoder_weights* w, float* packed, void* stream) {
+    MIPSF_REQUIRE(w && packed, "null pointer");
+    hipLaunchKernelGGL(decoder_pack_kernel, dim3((PACKED_FLOATS + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       to_w(*w), packed);
+    return check_launch("decoder_pack");
+}
+
+int mipsf_decoder_pack_host(const mipsf_decoder_weights* w, float* packed_host) {
+    MIPSF_REQUIRE(w && packed_host, "null pointer");
+    const W ww = to_w(*w);
+    for (int idx = 0; idx < PACKED_FLOATS; ++idx) packed_host[idx] = packed_value(ww, idx);
+    return 0;
+}
+
+int mipsf_decoder_fwd(const float* packed, const float* feat, int feat_layout, const float* x,
+                      const float* embed_pos, int pe_mode, float* out, float* saved, uint32_t M, void* stream) {
+    if (M == 0) return 0;
+    MIPSF_REQUIRE(packed && feat && x && out, "null pointer");
+    MIPSF_REQUIRE(pe_mode == 0 || embed_pos, "pe_mode 1 needs embed_pos");
+    MIPSF_REQUIRE(feat_layout == MIPSF_FEAT_AOS || feat_layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout");
+    const uint32_t blocks = (uint32_t)((n_wave_tiles(M) + 3) / 4);
+    hipStream_t s = (hipStream_t)stream;
+#define FWD(PE, LAY, SV) \
+    hipLaunchKernelGGL((decoder_fwd_kernel<PE, LAY, SV>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed, feat, x, embed_pos, out, saved, M)
+    const bool sv = saved != nullptr;
+    if (pe_mode == 0) {
+        if (feat_layout == MIPSF_FEAT_AOS) { if (sv) FWD(true, MIPSF_FEAT_AOS, true); else FWD(true, MIPSF_FEAT_AOS, false); }
+        else { if (sv) FWD(true, MIPSF_FEAT_LEVEL_MAJOR, true); else FWD(true, MIPSF_FEAT_LEVEL_MAJOR, false); }
+    } else {
+        if (feat_layout == MIPSF_FEAT_AOS) { if (sv) FWD(false, MIPSF_FEAT_AOS, true); else FWD(false, MIPSF_FEAT_AOS, false); }
+        else { if (sv) FWD(false, MIPSF_FEAT_LEVEL_MAJOR, true); else FWD(false, MIPSF_FEAT_LEVEL_MAJOR, false); }
+    }
+#undef FWD
+    return check_launch("decoder_fwd");
+}
+
+int mipsf_decoder_bwd(const float* packed, const float* feat, int feat_layout, const float* x,
+                      const float* embed_pos, int pe_mode, const float* out, const float* dout,
+                      const float* saved, float* dfeat, float* dx, float* dembed_pos,
+                      const mipsf_decoder_grads* grads, float* dact, float* partial, uint32_t M, void* stream) {
+    if (M == 0) return 0;
+    MIPSF_REQUIRE(packed && feat && x && out && dout && saved && dfeat && dx && dact && partial && grads,
+                  "null pointer");
+    MIPSF_REQUIRE(pe_mode == 0 || (embed_pos && dembed_pos), "pe_mode 1 needs embed_pos and dembed_pos");
+    MIPSF_REQUIRE(feat_layout == MIPSF_FEAT_AOS || feat_layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout");
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t blocks = (uint32_t)((n_wave_tiles(M) + 3) / 4);
+    const uint32_t n_bt = (uint32_t)n_block_tiles(M);
+    float* dsmall = dact + n_block_tiles(M) * 4 * ACT_TILE_FLOATS;
+#define BWD(PE, LAY) \
+    hipLaunchKernelGGL((decoder_bwd_kernel<PE, LAY>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed, x, out, dout, saved, dfeat, dx, dembed_pos, dact, dsmall, M)
+    if (pe_mode == 0) { if (feat_layout == MIPSF_FEAT_AOS) BWD(true, MIPSF_FEAT_AOS); else BWD(true, MIPSF_FEAT_LEVEL_MAJOR); }
+    else { if (feat_layout == MIPSF_FEAT_AOS) BWD(false, MIPSF_FEAT_AOS); else BWD(false, MIPSF_FEAT_LEVEL_MAJOR); }
+#undef BWD
+    if (int e = check_launch("decoder_bwd")) return e;
+
+    int cus = mipsf_device_cu_count();
+    if (cus <= 0) return 3;
+    uint32_t wg_blocks = n_bt < (uint32_t)cus ? n_bt : (uint32_t)cus;
+    if (wg_blocks > WG_MAX_BLOCKS) wg_blocks = WG_MAX_BLOCKS;
+#define WG(PE, LAY)                                                                                              \
+    do {                                                                                                         \
+        static bool attr_set = false;                                                                            \
+        if (!attr_set) {                                                                                         \
+            if (hipFuncSetAttribute((const void*)decoder_wgrad_kernel<PE, LAY>,                                  \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES) != hipSuccess) {   \
+                set_error("cannot raise dynamic LDS to %d bytes", WG_LDS_BYTES);                                 \
+                return 4;                                                                                        \
+            }                                                                                                    \
+            attr_set = true;                                                                                     \
+        }                                                                                                        \
+        hipLaunchKernelGGL((decoder_wgrad_kernel<PE, LAY>), dim3(wg_blocks), dim3(DEC_BLOCK), WG_LDS_BYTES, s,   \
+                           feat, x, embed_pos, saved, dact, dsmall, partial, M, n_bt);                           \
+    } while (0)
+    if (pe_mode == 0) { if (feat_layout == MIPSF_FEAT_AOS) WG(true, MIPSF_FEAT_AOS); else WG(true, MIPSF_FEAT_LEVEL_MAJOR); }
+    else { if (feat_layout == MIPSF_FEAT_AOS) WG(false, MIPSF_FEAT_AOS); else WG(false, MIPSF_FEAT_LEVEL_MAJOR); }
+#undef WG
+    if (int e = check_launch("decoder_wgrad")) return e;
+
+    GradPtrs g;
+    g.p[0] = grads->w_pts0, g.p[1] = grads->b_pts0, g.p[2] = grads->w_pts2, g.p[3] = grads->b_pts2;
+    g.p[4] = grads->w_rgb0, g.p[5] = grads->b_rgb0, g.p[6] = grads->w_sdf0, g.p[7] = grads->b_sdf0;
+    g.p[8] = grads->w_sdf2, g.p[9] = grads->b_sdf2;
+    for (int k = 0; k < 10; ++k) MIPSF_REQUIRE(g.p[k] != nullptr, "null gradient pointer %d", k);
+    hipLaunchKernelGGL(decoder_wgrad_reduce_kernel, dim3((G_TOTAL + 255) / 256), dim3(256), 0, s, partial, wg_blocks, g);
+    return check_launch("decoder_wgrad_reduce");
+}
+
+}  // extern "C"

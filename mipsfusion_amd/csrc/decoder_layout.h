@@ -1,0 +1,171 @@
+// Index maps of the register-chained MFMA decoder (shared by the device kernels, the device/host weight
+// packers and -- through mipsf_decoder_pack_host -- the CPU layout tests).
+//
+// The decoder is evaluated TRANSPOSED, one wavefront per 32 samples:
+//     Out^T[features x 32 samples] = W[features x K] * In^T[K x 32 samples]
+// with v_mfma_f32_32x32x2_f32 (exact fp32).  Lane l = (j = l & 31, h = l >> 5).
+//   A operand (weights):    lane holds A[row i = j][k = h]
+//   B operand (activations): lane holds B[k = h][col = sample j]
+//   C/D (16 regs):           reg r, lane (j,h) = D[row = (r&3) + 8*(r>>2) + 4*h][col = sample j]
+// Because the reduction index k may be visited in any order, accumulator register r of row-tile q of the
+// PREVIOUS layer is used directly as the B operand of k-step t = 16*q + r of the NEXT layer: the lower
+// half-wave contributes feature 32q + rowmap(r,0) and the upper half feature 32q + rowmap(r,1).  The weight
+// images below are laid out so that the matching A operand is one contiguous 16-byte-per-lane load.
+// Activations therefore never leave registers between layers (no LDS, no barriers in the chain kernels).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MIPSF_HD __host__ __device__ inline
+#else
+#define MIPSF_HD inline
+#endif
+
+namespace mipsf {
+namespace dl {
+
+constexpr int HID = 128;          // n_hidden = n_hidden_branch
+constexpr int N_PE = 48;          // 3 dims * 8 freqs * {sin,cos}
+constexpr int N_E = 51;           // [x(3), pe(48)]
+constexpr int N_GRID = 32;        // 16 levels * 2 features
+constexpr int N_EMB = 64;         // sdf_emb / rgb_emb width
+constexpr int N_RGB_IN = 115;     // rgb_emb(64) + e(51)
+constexpr int N_SDF_IN = 96;      // sdf_emb(64) + grid(32)
+constexpr int N_CLASS = 5;
+constexpr int E_SLOTS = 26;       // k-steps that carry e (52 half-slots, one pad)
+
+// k-steps (each = 2 reduction indices) per layer, padded to a multiple of 4 for 16-byte operand loads
+constexpr int T_F1 = 28, T_F2 = 64, T_F3 = 48;      // forward: pts0, pts2, sdf0
+constexpr int T_B3 = 64, T_B2 = 64, T_B1 = 64;      // backward chain: sdf0^T, pts2^T, pts0^T
+constexpr int RT_F1 = 4, RT_F2 = 4, RT_F3 = 4, RT_B3 = 3, RT_B2 = 4, RT_B1 = 2;
+
+MIPSF_HD int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+MIPSF_HD int feat_of(int q, int r, int h) { return 32 * q + rowmap(r, h); }
+// feature carried by half h at k-step t when the B operand is accumulator reg (t/16, t%16)
+MIPSF_HD int kfeat(int t, int h) { return feat_of(t >> 4, t & 15, h); }
+
+// e index (into [x0,x1,x2, pe0..pe47]) carried by half h at e-slot t; -1 = padding
+MIPSF_HD int eidx(int t, int h) {
+    if (t < 24) return 3 + (t >> 3) * 16 + 2 * (t & 7) + h;
+    if (t == 24) return h;
+    if (t == 25) return h == 0 ? 2 : -1;
+    return -1;
+}
+// inverse of rowmap for an A-operand row i in [0,32): which (reg, half) of an accumulator tile owns it
+MIPSF_HD void row_owner(int i, int& r, int& h) {
+    h = (i >> 2) & 1;
+    r = (i & 3) + 4 * (i >> 3);
+}
+
+// ------------------------------------------------------------------ packed buffer (floats)
+constexpr int img_floats(int rt, int T) { return rt * T * 64; }
+constexpr int OFF_F1 = 0;
+constexpr int OFF_F2 = OFF_F1 + img_floats(RT_F1, T_F1);
+constexpr int OFF_F3 = OFF_F2 + img_floats(RT_F2, T_F2);
+constexpr int OFF_B3 = OFF_F3 + img_floats(RT_F3, T_F3);
+constexpr int OFF_B2 = OFF_B3 + img_floats(RT_B3, T_B3);
+constexpr int OFF_B1 = OFF_B2 + img_floats(RT_B2, T_B2);
+constexpr int OFF_TRGB = OFF_B1 + img_floats(RT_B1, T_B1);   // [h][58 slots][4]   (c < 3)
+constexpr int TRGB_SLOTS = 32 + E_SLOTS;
+constexpr int OFF_TS2 = OFF_TRGB + 2 * TRGB_SLOTS * 4;      // [h][64 slots][8]   (c < 5)
+constexpr int OFF_BIAS = OFF_TS2 + 2 * 64 * 8;              // [layer 0..2][64 slots][h]
+constexpr int OFF_BSMALL = OFF_BIAS + 3 * 64 * 2;           // b_rgb0[0..2], pad, b_sdf2[0..4], pad*3
+constexpr int PACKED_FLOATS = OFF_BSMALL + 12;
+
+// element (rt, t, lane) of an A image; stored as [rt][t/4][lane][t%4]
+MIPSF_HD int img_index(int T, int rt, int t, int lane) { return ((rt * (T >> 2) + (t >> 2)) * 64 + lane) * 4 + (t & 3); }
+
+struct W {   // nn.Linear weights, row-major [out][in]
+    const float *w_pts0, *b_pts0, *w_pts2, *b_pts2, *w_rgb0, *b_rgb0, *w_sdf0, *b_sdf0, *w_sdf2, *b_sdf2;
+};
+
+// value of packed[idx]; every packed float is produced by exactly this function (device kernel: one thread
+// per idx; host mirror: a loop), so host tests exercise the very code the GPU runs.
+MIPSF_HD float packed_value(const W& w, int idx) {
+    if (idx < OFF_TRGB) {
+        int base, T, kind;
+        if (idx < OFF_F2) { base = OFF_F1; T = T_F1; kind = 0; }
+        else if (idx < OFF_F3) { base = OFF_F2; T = T_F2; kind = 1; }
+        else if (idx < OFF_B3) { base = OFF_F3; T = T_F3; kind = 2; }
+        else if (idx < OFF_B2) { base = OFF_B3; T = T_B3; kind = 3; }
+        else if (idx < OFF_B1) { base = OFF_B2; T = T_B2; kind = 4; }
+        else { base = OFF_B1; T = T_B1; kind = 5; }
+        const int rel = idx - base;
+        const int u = rel & 3, lane = (rel >> 2) & 63, g = rel >> 8;   // g = rt * (T/4) + t4
+        const int t4n = T >> 2;
+        const int rt = g / t4n, t = (g - rt * t4n) * 4 + u;
+        const int i = lane & 31, h = lane >> 5;
+        const int row = 32 * rt + i;
+        switch (kind) {
+            case 0: {   // pts0: H1^T = W1 * e^T
+                const int e = eidx(t, h);
+                return e < 0 ? 0.f : w.w_pts0[row * N_E + e];
+            }
+            case 1:     // pts2: H2^T = W2 * H1^T
+                return w.w_pts2[row * HID + kfeat(t, h)];
+            case 2: {   // sdf0: G3^T = Ws1 * [sdf_emb; grid]^T
+                const int src = t < 32 ? kfeat(t, h) : 64 + 2 * (t - 32) + h;
+                return w.w_sdf0[row * N_SDF_IN + src];
+            }
+            case 3:     // d[sdf_emb; grid]^T = Ws1^T * dG3^T      (row = input index 0..95)
+                return w.w_sdf0[kfeat(t, h) * N_SDF_IN + row];
+            case 4:     // dH1^T = W2^T * dH2^T
+                return w.w_pts2[kfeat(t, h) * HID + row];
+            default: {  // d e^T = W1^T * dG1^T; output row i of tile rt lands in e-slot (16*rt + r', h')
+                int r2, h2;
+                row_owner(i, r2, h2);
+                const int e = eidx(16 * rt + r2, h2);
+                return e < 0 ? 0.f : w.w_pts0[kfeat(t, h) * N_E + e];
+            }
+        }
+    }
+    if (idx < OFF_TS2) {            // rgb table: slots 0..31 = rgb_emb regs (q=2,3), 32..57 = e slots
+        const int rel = idx - OFF_TRGB;
+        const int c = rel & 3, slot = (rel >> 2) % TRGB_SLOTS, h = (rel >> 2) / TRGB_SLOTS;
+        if (c >= 3) return 0.f;
+        if (slot < 32) return w.w_rgb0[c * N_RGB_IN + (32 * (slot >> 4) + rowmap(slot & 15, h))];
+        const int e = eidx(slot - 32, h);
+        return e < 0 ? 0.f : w.w_rgb0[c * N_RGB_IN + N_EMB + e];
+    }
+    if (idx < OFF_BIAS) {           // sdf2 table: slot = q*16 + r
+        const int rel = idx - OFF_TS2;
+        const int c = rel & 7, slot = (rel >> 3) & 63, h = rel >> 9;
+        return c < N_CLASS ? w.w_sdf2[c * HID + kfeat(slot, h)] : 0.f;
+    }
+    if (idx < OFF_BSMALL) {         // hidden-layer biases in accumulator order
+        const int rel = idx - OFF_BIAS;
+        const int h = rel & 1, slot = (rel >> 1) & 63, layer = rel >> 7;
+        const float* b = layer == 0 ? w.b_pts0 : (layer == 1 ? w.b_pts2 : w.b_sdf0);
+        return b[kfeat(slot, h)];
+    }
+    const int rel = idx - OFF_BSMALL;
+    if (rel < 3) return w.b_rgb0[rel];
+    if (rel >= 4 && rel < 4 + N_CLASS) return w.b_sdf2[rel - 4];
+    return 0.f;
+}
+
+// --------------------------------------------------------- activations kept between kernels
+// one 32-sample wave tile = 192 accumulator registers x 64 lanes, stored [tile][g = slot/4][lane][4]
+constexpr int ACT_SLOTS = 192;                 // 3 matrices x 4 row tiles x 16 regs
+constexpr int ACT_TILE_FLOATS = ACT_SLOTS * 64;
+MIPSF_HD int64_t act_index(int64_t tile, int mat, int rt, int r, int lane) {
+    const int slot = mat * 64 + rt * 16 + r;
+    return (tile * (ACT_SLOTS / 4) + (slot >> 2)) * 256 + lane * 4 + (slot & 3);
+}
+
+// ---------------------------------------------- natural-layout gradient record (partials + reduce)
+constexpr int G_W_PTS0 = 0;
+constexpr int G_B_PTS0 = G_W_PTS0 + HID * N_E;
+constexpr int G_W_PTS2 = G_B_PTS0 + HID;
+constexpr int G_B_PTS2 = G_W_PTS2 + HID * HID;
+constexpr int G_W_RGB0 = G_B_PTS2 + HID;
+constexpr int G_B_RGB0 = G_W_RGB0 + 3 * N_RGB_IN;
+constexpr int G_W_SDF0 = G_B_RGB0 + 3;
+constexpr int G_B_SDF0 = G_W_SDF0 + HID * N_SDF_IN;
+constexpr int G_W_SDF2 = G_B_SDF0 + HID;
+constexpr int G_B_SDF2 = G_W_SDF2 + N_CLASS * HID;
+constexpr int G_TOTAL = G_B_SDF2 + N_CLASS;      // 36577 parameters
+constexpr int G_STRIDE = (G_TOTAL + 63) / 64 * 64;
+
+}  // namespace dl
+}  // namespace mipsf

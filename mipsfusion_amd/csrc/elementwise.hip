@@ -1,0 +1,207 @@
+// Small streaming kernels: frequency encoding (module API), point normalisation, dense Adam,
+// RandomOptimizer fitness.  All HBM-bound: coalesced, vectorised where the layout allows.
+#include "common.h"
+
+namespace mipsf {
+
+constexpr float PI_F = 3.14159265358979323846f;
+constexpr float HALF_PI_F = 1.57079632679489661923f;   // fp32(pi)/2 == fp32(pi/2)
+
+// ---------------------------------------------------------------- frequency (tcnn frequency.h)
+// out[i, d*2F + 2k + s] = sin(fma(ldexp(x_d, k), pi, s*pi/2)); one thread per (sample, dim).
+__global__ __launch_bounds__(256) void freq_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                       uint32_t n, uint32_t n_dims, uint32_t n_freq) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t i = t / n_dims, d = t - i * n_dims;
+    const float v = x[t];
+    float* o = out + ((size_t)i * n_dims + d) * 2 * n_freq;
+    for (uint32_t k = 0; k < n_freq; ++k) {
+        const float s = ldexpf(v, (int)k);
+        o[2 * k] = sinf(fmaf(s, PI_F, 0.0f));
+        o[2 * k + 1] = sinf(fmaf(s, PI_F, HALF_PI_F));
+    }
+}
+
+__global__ __launch_bounds__(256) void freq_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                                       float* __restrict__ dx, uint32_t n, uint32_t n_dims,
+                                                       uint32_t n_freq) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t i = t / n_dims, d = t - i * n_dims;
+    const float v = x[t];
+    const float* g = dout + ((size_t)i * n_dims + d) * 2 * n_freq;
+    float acc = 0.f;
+    for (uint32_t k = 0; k < n_freq; ++k) {
+        const float s = ldexpf(v, (int)k);
+        const float fpi = ldexpf(1.0f, (int)k) * PI_F;
+        acc = acc + g[2 * k] * (fpi * cosf(fmaf(s, PI_F, 0.0f)));
+        acc = acc + g[2 * k + 1] * (fpi * cosf(fmaf(s, PI_F, HALF_PI_F)));
+    }
+    dx[t] = acc;
+}
+
+// ------------------------------------------------------------- normalisation (scene_rep.py:134-142)
+__global__ __launch_bounds__(256) void normalise_kernel(const float* __restrict__ pts, float* __restrict__ xn,
+                                                        uint64_t n3, NormCfg nc) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n3) return;
+    const int d = (int)(t % 3);
+    xn[t] = normalise1(pts[t], nc.sub[d], nc.div[d], nc.norm_factor);
+}
+
+__global__ __launch_bounds__(256) void normalise_bwd_kernel(const float* __restrict__ dxn, float* __restrict__ dpts,
+                                                            uint64_t n3, NormCfg nc) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n3) return;
+    const int d = (int)(t % 3);
+    dpts[t] = (float)(((double)dxn[t] / nc.norm_factor) / nc.div[d]);
+}
+
+// ----------------------------------------------------------------- dense Adam (torch.optim.Adam)
+// p, g, m, v streamed once: 16 B read + 12 B write per parameter (28 B with the fused zero-grad).
+struct AdamK {
+    float lr_over_bc1, beta1, beta2, one_minus_b1, one_minus_b2, inv_sqrt_bc2, eps, wd;
+};
+
+__device__ __forceinline__ void adam1(float& p, float& g, float& m, float& v, const AdamK& k) {
+    float gg = g;
+    if (k.wd != 0.f) gg = gg + k.wd * p;
+    m = m + (gg - m) * k.one_minus_b1;            // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * k.beta2 + (k.one_minus_b2 * gg) * gg;   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+    const float denom = sqrtf(v) * k.inv_sqrt_bc2 + k.eps;
+    p = p - k.lr_over_bc1 * (m / denom);
+}
+
+template <bool ZERO>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, uint64_t n,
+                                                   AdamK k) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t n4 = n / 4;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    float4* g4 = reinterpret_cast<float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+        adam1(pp.x, gg.x, mm.x, vv.x, k);
+        adam1(pp.y, gg.y, mm.y, vv.y, k);
+        adam1(pp.z, gg.z, mm.z, vv.z, k);
+        adam1(pp.w, gg.w, mm.w, vv.w, k);
+        p4[i] = pp;
+        m4[i] = mm;
+        v4[i] = vv;
+        if (ZERO) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (uint64_t i = n4 * 4 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+        adam1(pp, gg, mm, vv, k);
+        p[i] = pp;
+        m[i] = mm;
+        v[i] = vv;
+        if (ZERO) g[i] = 0.f;
+    }
+}
+
+// ------------------------------------------------------ RandomOptimizer.get_fitness (RandomOptimizer.py:125-129)
+// one wave per particle: mean_j( (d_j > 0) * |sdf_pj * trunc| )
+__global__ __launch_bounds__(256) void ro_fitness_kernel(const float* __restrict__ raw, uint32_t stride,
+                                                         const float* __restrict__ target_d, float trunc,
+                                                         float* __restrict__ out, uint32_t P, uint32_t n) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / MIPSF_WAVE;
+    const uint32_t lane = threadIdx.x & (MIPSF_WAVE - 1);
+    if (wave >= P) return;
+    float acc = 0.f;
+    for (uint32_t j = lane; j < n; j += MIPSF_WAVE) {
+        const float s = raw[((size_t)wave * n + j) * stride + 3] * trunc;
+        acc += (target_d[j] > 0.f) ? fabsf(s) : 0.f;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[wave] = acc / (float)n;
+}
+
+}  // namespace mipsf
+
+using namespace mipsf;
+
+extern "C" {
+
+int mipsf_freq_fwd(const float* x, float* out, uint32_t M, uint32_t n_dims, uint32_t n_freq, void* stream) {
+    if (M == 0) return 0;
+    MIPSF_REQUIRE(x && out, "null pointer");
+    const uint32_t n = M * n_dims;
+    hipLaunchKernelGGL(freq_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, out, n, n_dims,
+                       n_freq);
+    return check_launch("freq_fwd");
+}
+
+int mipsf_freq_bwd(const float* x, const float* dout, float* dx, uint32_t M, uint32_t n_dims, uint32_t n_freq,
+                   void* stream) {
+    if (M == 0) return 0;
+    MIPSF_REQUIRE(x && dout && dx, "null pointer");
+    const uint32_t n = M * n_dims;
+    hipLaunchKernelGGL(freq_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, dout, dx, n,
+                       n_dims, n_freq);
+    return check_launch("freq_bwd");
+}
+
+int mipsf_normalise_points(const float* pts, const mipsf_render_cfg* cfg, float* xn, uint32_t M, void* stream) {
+    if (M == 0) return 0;
+    MIPSF_REQUIRE(pts && cfg && xn, "null pointer");
+    const uint64_t n3 = (uint64_t)M * 3;
+    hipLaunchKernelGGL(normalise_kernel, dim3((uint32_t)((n3 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pts,
+                       xn, n3, make_norm(*cfg));
+    return check_launch("normalise_points");
+}
+
+int mipsf_normalise_bwd(const float* dxn, const mipsf_render_cfg* cfg, float* dpts, uint32_t M, void* stream) {
+    if (M == 0) return 0;
+    MIPSF_REQUIRE(dxn && cfg && dpts, "null pointer");
+    const uint64_t n3 = (uint64_t)M * 3;
+    hipLaunchKernelGGL(normalise_bwd_kernel, dim3((uint32_t)((n3 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       dxn, dpts, n3, make_norm(*cfg));
+    return check_launch("normalise_bwd");
+}
+
+int mipsf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, uint32_t step, int zero_grad, void* stream) {
+    if (n == 0) return 0;
+    MIPSF_REQUIRE(param && grad && exp_avg && exp_avg_sq, "null pointer");
+    MIPSF_REQUIRE(step >= 1, "step must be >= 1");
+    MIPSF_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+                  "adam buffers must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    AdamK k;
+    k.lr_over_bc1 = (float)((double)lr / bc1);
+    k.beta1 = beta1;
+    k.beta2 = beta2;
+    k.one_minus_b1 = (float)(1.0 - (double)beta1);
+    k.one_minus_b2 = (float)(1.0 - (double)beta2);
+    k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    k.eps = eps;
+    k.wd = weight_decay;
+    uint64_t want = (n / 4 + 255) / 256;
+    uint32_t blocks = (uint32_t)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+    if (zero_grad)
+        hipLaunchKernelGGL(adam_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                           exp_avg_sq, n, k);
+    else
+        hipLaunchKernelGGL(adam_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                           exp_avg_sq, n, k);
+    return check_launch("adam_step");
+}
+
+int mipsf_ro_fitness(const float* raw, uint32_t raw_stride, const float* target_d, float trunc, float* mean_masked,
+                     uint32_t P, uint32_t n, void* stream) {
+    if (P == 0) return 0;
+    MIPSF_REQUIRE(raw && target_d && mean_masked, "null pointer");
+    MIPSF_REQUIRE(raw_stride >= 4, "raw_stride must cover the sdf column");
+    const uint32_t threads = P * MIPSF_WAVE;
+    hipLaunchKernelGGL(ro_fitness_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, raw,
+                       raw_stride, target_d, trunc, mean_masked, P, n);
+    return check_launch("ro_fitness");
+}
+
+}  // extern "C"

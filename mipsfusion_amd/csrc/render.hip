@@ -1,0 +1,506 @@
+// Per-ray kernels: depth-guided sample placement (+ fp64 normalisation), SDF-weight compositing with the
+// training losses, and their gradients.  One 64-lane wavefront owns one ray, lanes stride over the S samples
+// (S = 64 at the headline configuration = exactly one sample per lane); per-ray reductions are wave
+// shuffles, the "first sign change" search is a ballot + ffs.  HBM-bound streaming kernels.
+//
+// Reference: model/scene_rep.py:58-103 (sdf2weights, raw2outputs), :156-179 (placement), :211-236 (losses);
+// helper_functions/utils.py:21-49, 71-111 (get_masks, get_sdf_loss).
+#include "common.h"
+
+namespace mipsf {
+
+constexpr int RAYS_PER_BLOCK = 4;
+constexpr int MAX_S = 256;
+
+struct PlaceCfg {
+    uint32_t n_uniform, n_near;
+    int perturb;
+    float trunc_total;   // trunc * sc_factor as fp32
+};
+
+// --------------------------------------------------------------------- sample placement
+// The sorted concatenation of two already-sorted lists is a merge: every element's final slot is its own
+// index plus the number of elements of the other list that precede it.  Values (not indices) are all the
+// reference keeps from torch.sort (scene_rep.py:164), so tie order is irrelevant and the result is
+// bit-identical to a sort.
+__global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void sample_rays_kernel(
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ target_d,
+    const float* __restrict__ noise, const float* __restrict__ z_uniform, const float* __restrict__ z_near_off,
+    const float* __restrict__ z_near_nodepth, PlaceCfg pc, NormCfg nc, float* __restrict__ z_vals,
+    float* __restrict__ xn, uint32_t* __restrict__ counts, uint32_t N) {
+    __shared__ float zs[RAYS_PER_BLOCK][MAX_S];
+    const uint32_t w = threadIdx.x / MIPSF_WAVE, lane = threadIdx.x & (MIPSF_WAVE - 1);
+    const uint32_t n = blockIdx.x * RAYS_PER_BLOCK + w;
+    if (n >= N) return;   // whole wave exits together; no block-level barrier is used below
+    const uint32_t nu = pc.n_uniform, nn = pc.n_near, S = nu + nn;
+    const float d = target_d ? target_d[n] : 0.f;
+    const bool has_depth = d > 0.f;   // rows with d <= 0 fall back to linspace(near, far) (scene_rep.py:160)
+    float* row = zs[w];
+
+    for (uint32_t e = lane; e < S; e += MIPSF_WAVE) {
+        float val;
+        uint32_t slot;
+        if (e < nu) {
+            val = z_uniform[e];
+            uint32_t c = 0;
+            for (uint32_t j = 0; j < nn; ++j) {
+                const float b = has_depth ? z_near_off[j] + d : z_near_nodepth[j];
+                c += (b < val) ? 1u : 0u;
+            }
+            slot = e + c;
+        } else {
+            const uint32_t j = e - nu;
+            val = has_depth ? z_near_off[j] + d : z_near_nodepth[j];
+            uint32_t c = 0;
+            for (uint32_t i = 0; i < nu; ++i) c += (z_uniform[i] <= val) ? 1u : 0u;
+            slot = j + c;
+        }
+        row[slot] = val;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
+    const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
+    uint32_t n_front = 0, n_band = 0;
+    for (uint32_t k = lane; k < S; k += MIPSF_WAVE) {
+        float z = row[k];
+        if (pc.perturb) {
+            const float lo = k > 0 ? 0.5f * (z + row[k - 1]) : z;
+            const float hi = k + 1 < S ? 0.5f * (row[k + 1] + z) : z;
+            z = lo + (hi - lo) * noise[(size_t)n * S + k];
+        }
+        z_vals[(size_t)n * S + k] = z;
+        const float px = ox + dx * z, py = oy + dy * z, pz = oz + dz * z;
+        float* o = xn + ((size_t)n * S + k) * 3;
+        o[0] = normalise1(px, nc.sub[0], nc.div[0], nc.norm_factor);
+        o[1] = normalise1(py, nc.sub[1], nc.div[1], nc.norm_factor);
+        o[2] = normalise1(pz, nc.sub[2], nc.div[2], nc.norm_factor);
+        if (target_d) {
+            const bool front = z < d - pc.trunc_total;
+            const bool back = z > d + pc.trunc_total;
+            n_front += front ? 1u : 0u;
+            n_band += (!front && !back && has_depth) ? 1u : 0u;
+        }
+    }
+    if (target_d && counts) {
+        const float f = wave_sum((float)n_front), b = wave_sum((float)n_band);   // <= 256 each: exact in fp32
+        if (lane == 0) {
+            atomicAdd(&counts[0], (uint32_t)f);
+            atomicAdd(&counts[1], (uint32_t)b);
+        }
+    }
+}
+
+// ------------------------------------------------------------------- compositing helpers
+struct RenderCfg {
+    float trunc;          // training.trunc
+    float band;           // fp32(sc_factor * trunc): z < z_min + band
+    float trunc_total;    // fp32(trunc * sc_factor): loss truncation
+    float depth_trunc;
+    int rgb_missing_nonzero;
+    float emd_w;
+};
+
+struct RayState {   // per-lane, for up to MAX_S / 64 samples per lane
+    float z_min;
+    float usum;
+};
+
+// first k in [0, S-1) with s[k] * s[k+1] < 0, else 0 (torch.argmax of an all-zero row)
+__device__ __forceinline__ uint32_t first_crossing(const float* __restrict__ srow, uint32_t S, uint32_t lane) {
+    uint32_t found = 0xFFFFFFFFu;
+    for (uint32_t base = 0; base + 1 < S; base += MIPSF_WAVE) {
+        const uint32_t k = base + lane;
+        const bool hit = (k + 1 < S) && (srow[k] * srow[k + 1] < 0.0f);
+        const unsigned long long m = __ballot(hit);
+        if (m != 0ull) {
+            found = base + (uint32_t)(__ffsll((long long)m) - 1);
+            break;
+        }
+    }
+    return found == 0xFFFFFFFFu ? 0u : found;
+}
+
+// ------------------------------------------------------------------------ forward
+// partial[n*8 + {0..5}] = {rgb_sq, depth_sq(valid), fs_sq, sdf_sq, fs_emd, sdf_emd}; [6] = valid flag
+template <bool TRAIN>
+__global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void render_fwd_kernel(
+    const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ target_rgb,
+    const float* __restrict__ target_d, RenderCfg rc, float* __restrict__ rgb_out, float* __restrict__ depth_out,
+    float* __restrict__ var_out, float* __restrict__ disp_out, float* __restrict__ acc_out,
+    float* __restrict__ weights_out, float* __restrict__ partial, uint32_t N, uint32_t S) {
+    __shared__ float ssdf[RAYS_PER_BLOCK][MAX_S];
+    const uint32_t w = threadIdx.x / MIPSF_WAVE, lane = threadIdx.x & (MIPSF_WAVE - 1);
+    const uint32_t n = blockIdx.x * RAYS_PER_BLOCK + w;
+    if (n >= N) return;
+    const float* rraw = raw + (size_t)n * S * 10;
+    const float* rz = z_vals + (size_t)n * S;
+    float* srow = ssdf[w];
+    for (uint32_t k = lane; k < S; k += MIPSF_WAVE) srow[k] = rraw[k * 10 + 3];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t kc = first_crossing(srow, S, lane);
+    const float z_min = rz[kc];
+    const float z_cut = z_min + rc.band;
+
+    float usum = 0.f;
+    for (uint32_t k = lane; k < S; k += MIPSF_WAVE) {
+        const float q = srow[k] / rc.trunc;
+        const float u = sigmoidf_(q) * sigmoidf_(-q);
+        usum += (rz[k] < z_cut) ? u : 0.f;
+    }
+    usum = wave_sum(usum);
+    const float inv = 1.0f / (usum + 1e-8f);
+
+    float a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f, a_w = 0.f;
+    for (uint32_t k = lane; k < S; k += MIPSF_WAVE) {
+        const float q = srow[k] / rc.trunc;
+        const float u = (rz[k] < z_cut) ? sigmoidf_(q) * sigmoidf_(-q) : 0.f;
+        const float wn = u * inv;
+        if (weights_out) weights_out[(size_t)n * S + k] = wn;
+        a_r += wn * sigmoidf_(rraw[k * 10 + 0]);
+        a_g += wn * sigmoidf_(rraw[k * 10 + 1]);
+        a_b += wn * sigmoidf_(rraw[k * 10 + 2]);
+        a_d += wn * rz[k];
+        a_w += wn;
+    }
+    a_r = wave_sum(a_r), a_g = wave_sum(a_g), a_b = wave_sum(a_b), a_d = wave_sum(a_d), a_w = wave_sum(a_w);
+    float a_v = 0.f;
+    for (uint32_t k = lane; k < S; k += MIPSF_WAVE) {
+        const float q = srow[k] / rc.trunc;
+        const float u = (rz[k] < z_cut) ? sigmoidf_(q) * sigmoidf_(-q) : 0.f;
+        const float t = rz[k] - a_d;
+        a_v += (u * inv) * (t * t);
+    }
+    a_v = wave_sum(a_v);
+    if (lane == 0) {
+        rgb_out[3 * n] = a_r, rgb_out[3 * n + 1] = a_g, rgb_out[3 * n + 2] = a_b;
+        depth_out[n] = a_d;
+        if (var_out) var_out[n] = a_v;
+        if (disp_out) disp_out[n] = 1.0f / fmaxf(1e-10f, a_d / a_w);
+        if (acc_out) acc_out[n] = a_w;
+    }
+    if (!TRAIN) return;
+
+    const float d = target_d[n];
+    const bool valid = (d > 0.f) && (d < rc.depth_trunc);
+    const float cw = (valid || rc.rgb_missing_nonzero) ? 1.f : 0.f;
+    float p_fs = 0.f, p_sd = 0.f, p_fe = 0.f, p_se = 0.f;
+    const float T = rc.trunc_total;
+    const bool has_depth = d > 0.f;
+    for (uint32_t k = lane; k < S; k += MIPSF_WAVE) {
+        const float z = rz[k], s = srow[k];
+        const bool front = z < d - T;
+        const bool back = z > d + T;
+        const float fm = front ? 1.f : 0.f;
+        const float bm = (!front && !back && has_depth) ? 1.f : 0.f;
+        const float ef = s * fm - fm;
+        p_fs += ef * ef;
+        const float es = (z + s * T) * bm - d * bm;
+        p_sd += es * es;
+        if (rc.emd_w > 0.f) {
+            const float gt = (((d - z) + T) / (2.f * T)) * 4.f;
+            float fe = 0.f, se = 0.f;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                const float p = rraw[k * 10 + 5 + c];
+                fe += p * (float)(4 - c) * fm;
+                se += fabsf(gt - (float)c) * bm * p;
+            }
+            p_fe += fe;
+            p_se += se;
+        }
+    }
+    p_fs = wave_sum(p_fs), p_sd = wave_sum(p_sd), p_fe = wave_sum(p_fe), p_se = wave_sum(p_se);
+    if (lane == 0) {
+        float* p = partial + (size_t)n * 8;
+        const float e0 = a_r * cw - target_rgb[3 * n] * cw;
+        const float e1 = a_g * cw - target_rgb[3 * n + 1] * cw;
+        const float e2 = a_b * cw - target_rgb[3 * n + 2] * cw;
+        p[0] = e0 * e0 + e1 * e1 + e2 * e2;
+        const float ed = a_d - d;
+        p[1] = valid ? ed * ed : 0.f;
+        p[2] = p_fs, p[3] = p_sd, p[4] = p_fe, p[5] = p_se;
+        p[6] = valid ? 1.f : 0.f;
+        p[7] = 0.f;
+    }
+}
+
+// losses[8] = {rgb_loss, depth_loss, sdf_loss, fs_loss, psnr, fs_weight, sdf_weight, n_valid}
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ partial,
+                                                            const uint32_t* __restrict__ counts, float emd_w,
+                                                            float* __restrict__ losses, uint32_t N, uint32_t S) {
+    __shared__ double red[4][7];
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t n = threadIdx.x; n < N; n += 256) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[j] += (double)partial[(size_t)n * 8 + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc[j] = wave_sum_d(acc[j]);
+    const uint32_t w = threadIdx.x / MIPSF_WAVE, lane = threadIdx.x & (MIPSF_WAVE - 1);
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) red[w][j] = acc[j];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[7];
+        for (int j = 0; j < 7; ++j) t[j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+        const double NS = (double)N * (double)S;
+        const float n_front = (float)counts[0], n_band = (float)counts[1];
+        const float total = n_front + n_band;
+        const float fs_w = 1.0f - n_front / total;     // 0/0 -> NaN exactly like the reference
+        const float sdf_w = 1.0f - n_band / total;
+        const float rgb_loss = (float)(t[0] / (3.0 * (double)N));
+        const float depth_loss = (float)(t[1] / t[6]);   // no valid depth -> 0/0 = NaN (mse of an empty tensor)
+        float fs = (float)(t[2] / NS) * fs_w;
+        float sd = (float)(t[3] / NS) * sdf_w;
+        if (emd_w > 0.f) {
+            fs = fs + ((float)(t[4] / NS) / 250.f) * emd_w;
+            sd = sd + ((float)(t[5] / NS) / 5000.f) * emd_w;
+        }
+        losses[0] = rgb_loss;
+        losses[1] = depth_loss;
+        losses[2] = sd;
+        losses[3] = fs;
+        losses[4] = -10.f * logf(rgb_loss) / logf(10.f);
+        losses[5] = fs_w;
+        losses[6] = sdf_w;
+        losses[7] = (float)t[6];
+    }
+}
+
+// ------------------------------------------------------------------------ backward
+__global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void render_bwd_kernel(
+    const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ target_rgb,
+    const float* __restrict__ target_d, const float* __restrict__ losses, RenderCfg rc, int train,
+    const float* __restrict__ g_losses, const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
+    float* __restrict__ draw, uint32_t N, uint32_t S) {
+    __shared__ float ssdf[RAYS_PER_BLOCK][MAX_S];
+    const uint32_t w = threadIdx.x / MIPSF_WAVE, lane = threadIdx.x & (MIPSF_WAVE - 1);
+    const uint32_t n = blockIdx.x * RAYS_PER_BLOCK + w;
+    if (n >= N) return;
+    const float* rraw = raw + (size_t)n * S * 10;
+    const float* rz = z_vals + (size_t)n * S;
+    float* rdr = draw + (size_t)n * S * 10;
+    float* srow = ssdf[w];
+    for (uint32_t k = lane; k < S; k += MIPSF_WAVE) srow[k] = rraw[k * 10 + 3];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t kc = first_crossing(srow, S, lane);
+    const float z_cut = rz[kc] + rc.band;
+
+    // recompute the forward reductions
+    float usum = 0.f;
+    for (uint32_t k = lane; k < S; k += MIPSF_WAVE) {
+        const float q = srow[k] / rc.trunc;
+        usum += (rz[k] < z_cut) ? sigmoidf_(q) * sigmoidf_(-q) : 0.f;
+    }
+    usum = wave_sum(usum);
+    const float inv = 1.0f / (usum + 1e-8f);
+    float a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f;
+    for (uint32_t k = lane; k < S; k += MIPSF_WAVE) {
+        const float q = srow[k] / rc.trunc;
+        const float wn = ((rz[k] < z_cut) ? sigmoidf_(q) * sigmoidf_(-q) : 0.f) * inv;
+        a_r += wn * sigmoidf_(rraw[k * 10 + 0]);
+        a_g += wn * sigmoidf_(rraw[k * 10 + 1]);
+        a_b += wn * sigmoidf_(rraw[k * 10 + 2]);
+        a_d += wn * rz[k];
+    }
+    a_r = wave_sum(a_r), a_g = wave_sum(a_g), a_b = wave_sum(a_b), a_d = wave_sum(a_d);
+
+    // gradients reaching the rendered maps
+    float G_r = g_rgb ? g_rgb[3 * n] : 0.f, G_g = g_rgb ? g_rgb[3 * n + 1] : 0.f, G_b = g_rgb ? g_rgb[3 * n + 2] : 0.f;
+    float G_d = g_depth ? g_depth[n] : 0.f;
+    float d = 0.f, gS = 0.f, gF = 0.f, fs_w = 0.f, sdf_w = 0.f;
+    const float NS = (float)N * (float)S;
+    if (train) {
+        d = target_d[n];
+        const bool valid = (d > 0.f) && (d < rc.depth_trunc);
+        const float cw = (valid || rc.rgb_missing_nonzero) ? 1.f : 0.f;
+        const float gR = g_losses[0], gD = g_losses[1];
+        gS = g_losses[2], gF = g_losses[3];
+        fs_w = losses[5], sdf_w = losses[6];
+        const float k_rgb = gR * 2.f * cw * cw / (3.f * (float)N);
+        G_r += k_rgb * (a_r - target_rgb[3 * n]);
+        G_g += k_rgb * (a_g - target_rgb[3 * n + 1]);
+        G_b += k_rgb * (a_b - target_rgb[3 * n + 2]);
+        if (valid) G_d += gD * 2.f * (a_d - d) / losses[7];
+    }
+    // dot = sum_k G_k * wn_k
+    float dot = 0.f;
+    for (uint32_t k = lane; k < S; k += MIPSF_WAVE) {
+        const float q = srow[k] / rc.trunc;
+        const float wn = ((rz[k] < z_cut) ? sigmoidf_(q) * sigmoidf_(-q) : 0.f) * inv;
+        const float Gk = G_r * sigmoidf_(rraw[k * 10 + 0]) + G_g * sigmoidf_(rraw[k * 10 + 1]) +
+                         G_b * sigmoidf_(rraw[k * 10 + 2]) + G_d * rz[k];
+        dot += Gk * wn;
+    }
+    dot = wave_sum(dot);
+
+    const float T = rc.trunc_total;
+    const bool has_depth = d > 0.f;
+    for (uint32_t k = lane; k < S; k += MIPSF_WAVE) {
+        const float z = rz[k], s = srow[k];
+        const float q = s / rc.trunc;
+        const float sg = sigmoidf_(q);
+        const bool keep = z < z_cut;
+        const float a = sg * sigmoidf_(-q);
+        const float wn = (keep ? a : 0.f) * inv;
+        const float c0 = sigmoidf_(rraw[k * 10 + 0]), c1 = sigmoidf_(rraw[k * 10 + 1]), c2 = sigmoidf_(rraw[k * 10 + 2]);
+        const float Gk = G_r * c0 + G_g * c1 + G_b * c2 + G_d * z;
+        float ds = keep ? (Gk - dot) * inv * (a * (1.f - 2.f * sg) / rc.trunc) : 0.f;
+        float dp[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (train) {
+            const bool front = z < d - T;
+            const bool back = z > d + T;
+            const float fm = front ? 1.f : 0.f;
+            const float bm = (!front && !back && has_depth) ? 1.f : 0.f;
+            ds += gF * fs_w * (2.f / NS) * fm * (s * fm - fm);
+            ds += gS * sdf_w * (2.f / NS) * (bm * T) * ((z + s * T) * bm - d * bm);
+            if (rc.emd_w > 0.f) {
+                const float gt = (((d - z) + T) / (2.f * T)) * 4.f;
+                const float kf = gF * rc.emd_w / (250.f * NS), ks = gS * rc.emd_w / (5000.f * NS);
+#pragma unroll
+                for (int c = 0; c < 5; ++c) dp[c] = kf * fm * (float)(4 - c) + ks * bm * fabsf(gt - (float)c);
+            }
+        }
+        float* o = rdr + k * 10;
+        o[0] = G_r * wn * c0 * (1.f - c0);
+        o[1] = G_g * wn * c1 * (1.f - c1);
+        o[2] = G_b * wn * c2 * (1.f - c2);
+        o[3] = ds;
+        o[4] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) o[5 + c] = dp[c];
+    }
+}
+
+// d(xn) -> d(rays_o), d(rays_d): pts = o + d*z (scene_rep.py:179) then fp64 normalisation (:140/:142)
+__global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void rays_bwd_kernel(const float* __restrict__ dxn,
+                                                                              const float* __restrict__ z_vals,
+                                                                              NormCfg nc, float* __restrict__ d_o,
+                                                                              float* __restrict__ d_d, uint32_t N,
+                                                                              uint32_t S) {
+    const uint32_t w = threadIdx.x / MIPSF_WAVE, lane = threadIdx.x & (MIPSF_WAVE - 1);
+    const uint32_t n = blockIdx.x * RAYS_PER_BLOCK + w;
+    if (n >= N) return;
+    float so[3] = {0.f, 0.f, 0.f}, sd[3] = {0.f, 0.f, 0.f};
+    for (uint32_t k = lane; k < S; k += MIPSF_WAVE) {
+        const float z = z_vals[(size_t)n * S + k];
+        const float* g = dxn + ((size_t)n * S + k) * 3;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float gp = (float)(((double)g[d] / nc.norm_factor) / nc.div[d]);
+            so[d] += gp;
+            sd[d] += gp * z;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        so[d] = wave_sum(so[d]);
+        sd[d] = wave_sum(sd[d]);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            d_o[3 * n + d] = so[d];
+            d_d[3 * n + d] = sd[d];
+        }
+    }
+}
+
+static RenderCfg to_render_cfg(const mipsf_render_cfg& c) {
+    RenderCfg r;
+    r.trunc = c.trunc;
+    r.band = (float)((double)c.sc_factor * (double)c.trunc);
+    r.trunc_total = (float)((double)c.trunc * (double)c.sc_factor);
+    r.depth_trunc = c.depth_trunc;
+    r.rgb_missing_nonzero = c.rgb_missing_nonzero;
+    r.emd_w = c.emd_w;
+    return r;
+}
+
+}  // namespace mipsf
+
+using namespace mipsf;
+
+extern "C" {
+
+int mipsf_sample_rays(const float* rays_o, const float* rays_d, const float* target_d, const float* noise,
+                      const float* z_uniform, const float* z_near_offsets, const float* z_near_nodepth,
+                      const mipsf_render_cfg* cfg, float* z_vals, float* xn, uint32_t* counts, uint32_t N,
+                      void* stream) {
+    if (N == 0) return 0;
+    MIPSF_REQUIRE(cfg && rays_o && rays_d && z_uniform && z_vals && xn, "null pointer");
+    const uint32_t S = cfg->n_uniform + cfg->n_near;
+    MIPSF_REQUIRE(S >= 1 && S <= MAX_S, "samples per ray %u outside [1,%d]", S, MAX_S);
+    MIPSF_REQUIRE(cfg->n_near == 0 || (target_d && z_near_offsets && z_near_nodepth),
+                  "depth-guided samples need target_d and the near tables");
+    MIPSF_REQUIRE(!cfg->perturb || noise, "perturb needs the noise tensor");
+    PlaceCfg pc;
+    pc.n_uniform = cfg->n_uniform;
+    pc.n_near = cfg->n_near;
+    pc.perturb = cfg->perturb;
+    pc.trunc_total = (float)((double)cfg->trunc * (double)cfg->sc_factor);
+    hipLaunchKernelGGL(sample_rays_kernel, dim3((N + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK),
+                       dim3(RAYS_PER_BLOCK * MIPSF_WAVE), 0, (hipStream_t)stream, rays_o, rays_d, target_d, noise,
+                       z_uniform, z_near_offsets, z_near_nodepth, pc, make_norm(*cfg), z_vals, xn, counts, N);
+    return check_launch("sample_rays");
+}
+
+int mipsf_render_fwd(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
+                     const uint32_t* counts, const mipsf_render_cfg* cfg, float* rgb, float* depth,
+                     float* depth_var, float* disp, float* acc, float* weights, float* losses, float* partial,
+                     uint32_t N, uint32_t S, void* stream) {
+    if (N == 0) return 0;
+    MIPSF_REQUIRE(cfg && raw && z_vals && rgb && depth, "null pointer");
+    MIPSF_REQUIRE(S >= 1 && S <= MAX_S, "samples per ray %u outside [1,%d]", S, MAX_S);
+    const RenderCfg rc = to_render_cfg(*cfg);
+    const dim3 grid((N + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK), block(RAYS_PER_BLOCK * MIPSF_WAVE);
+    hipStream_t s = (hipStream_t)stream;
+    if (losses) {
+        MIPSF_REQUIRE(target_rgb && target_d && counts && partial, "training mode needs targets, counts, partial");
+        hipLaunchKernelGGL(render_fwd_kernel<true>, grid, block, 0, s, raw, z_vals, target_rgb, target_d, rc, rgb,
+                           depth, depth_var, disp, acc, weights, partial, N, S);
+        if (int e = check_launch("render_fwd")) return e;
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, partial, counts, rc.emd_w, losses, N, S);
+        return check_launch("loss_finalize");
+    }
+    hipLaunchKernelGGL(render_fwd_kernel<false>, grid, block, 0, s, raw, z_vals, target_rgb, target_d, rc, rgb, depth,
+                       depth_var, disp, acc, weights, partial, N, S);
+    return check_launch("render_fwd");
+}
+
+int mipsf_render_bwd(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
+                     const uint32_t* counts, const float* losses, const mipsf_render_cfg* cfg,
+                     const float* g_losses, const float* g_rgb, const float* g_depth, float* draw, uint32_t N,
+                     uint32_t S, void* stream) {
+    (void)counts;
+    if (N == 0) return 0;
+    MIPSF_REQUIRE(cfg && raw && z_vals && draw, "null pointer");
+    MIPSF_REQUIRE(S >= 1 && S <= MAX_S, "samples per ray %u outside [1,%d]", S, MAX_S);
+    const int train = g_losses != nullptr;
+    MIPSF_REQUIRE(!train || (target_rgb && target_d && losses), "training backward needs targets and losses");
+    hipLaunchKernelGGL(render_bwd_kernel, dim3((N + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK),
+                       dim3(RAYS_PER_BLOCK * MIPSF_WAVE), 0, (hipStream_t)stream, raw, z_vals, target_rgb, target_d,
+                       losses, to_render_cfg(*cfg), train, g_losses, g_rgb, g_depth, draw, N, S);
+    return check_launch("render_bwd");
+}
+
+int mipsf_rays_bwd(const float* dxn, const float* z_vals, const mipsf_render_cfg* cfg, float* d_rays_o,
+                   float* d_rays_d, uint32_t N, uint32_t S, void* stream) {
+    if (N == 0) return 0;
+    MIPSF_REQUIRE(cfg && dxn && z_vals && d_rays_o && d_rays_d, "null pointer");
+    hipLaunchKernelGGL(rays_bwd_kernel, dim3((N + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK),
+                       dim3(RAYS_PER_BLOCK * MIPSF_WAVE), 0, (hipStream_t)stream, dxn, z_vals, make_norm(*cfg),
+                       d_rays_o, d_rays_d, N, S);
+    return check_launch("rays_bwd");
+}
+
+}  // extern "C"
