@@ -1,0 +1,43 @@
+"""``MLP_reg`` with the reference's constructor, sub-module names and state-dict keys
+(model/decoder.py:6-75): pts_linear.{0,2}, rgb_linear.0, sdf_linear.{0,2}.  ``forward`` runs the fused
+MFMA decoder kernels (csrc/decoder.hip) instead of five nn.Linear calls; the nn.Linear modules only own the
+Parameters (and their default initialisation)."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class MLP_reg(nn.Module):
+    def __init__(self, cfg, input_ch=3, input_ch_pos=12, n_hidden=128, n_hidden_rgb=64, n_hidden_sdf=64,
+                 n_hidden_branch=128, n_class=5, beta=80.):
+        super().__init__()
+        self.cfg = cfg
+        self.input_ch = input_ch
+        self.input_ch_pos = input_ch_pos + 3
+        self.n_hidden = n_hidden
+        self.n_hidden_rgb = n_hidden_rgb
+        self.n_hidden_sdf = n_hidden_sdf
+        self.n_hidden_branch = n_hidden_branch
+        self.n_class = n_class
+        self.max_class_Id = n_class - 1
+        self.beta = beta
+        if (self.input_ch, self.input_ch_pos, n_hidden, n_hidden_rgb, n_hidden_sdf, n_hidden_branch, n_class) != \
+                (32, 51, 128, 64, 64, 128, 5):
+            raise ValueError("the HIP decoder is built for the reference architecture "
+                             "(grid 32, pos 48+3, hidden 128, rgb/sdf embedding 64, branch 128, 5 classes)")
+        self.pts_linear = nn.Sequential(nn.Linear(self.input_ch_pos, n_hidden), nn.ReLU(),
+                                        nn.Linear(n_hidden, n_hidden_sdf + n_hidden_rgb))
+        self.rgb_linear = nn.Sequential(nn.Linear(n_hidden_rgb + self.input_ch_pos, 3))
+        self.sdf_linear = nn.Sequential(nn.Linear(n_hidden_sdf + self.input_ch, n_hidden_branch), nn.ReLU(),
+                                        nn.Linear(n_hidden_branch, n_class), nn.Softmax(dim=-1))
+
+    def ordered_parameters(self):
+        named = dict(self.named_parameters())
+        return [named[k] for k in ops.DECODER_PARAM_ORDER]
+
+    def forward(self, embed, embed_pos, query_pts):
+        """embed [M,32], embed_pos [M,48], query_pts [M,3] -> [M,10] = rgb(3) sdf entropy prob(5)."""
+        if not query_pts.is_cuda:
+            raise RuntimeError("mipsfusion_amd decoder runs on the GPU only (no CPU fallback)")
+        return ops.DecoderFn.apply(embed, embed_pos, query_pts, *self.ordered_parameters())

@@ -1,0 +1,278 @@
+"""``JointEncoding`` -- the drop-in boundary of the hot path (reference: model/scene_rep.py:11-238).
+
+Same constructor, attributes (``embed_fn``, ``embedpos_fn``, ``decoder``), methods and state-dict keys as the
+reference class, so ``mipsfusion.py`` / ``InactiveMap.py`` / ``RandomOptimizer.py`` / ``Mesher.py`` can import it
+unchanged.  Internally the ~390 eager ops of one reference iteration become ten HIP kernels:
+
+    sample_rays -> hashgrid_fwd -> decoder_fwd -> render_fwd (+ loss_finalize)
+    render_bwd  -> decoder_bwd -> decoder_wgrad (+ reduce) -> hashgrid_bwd -> rays_bwd
+
+chained through three ``torch.autograd.Function`` objects (placement, query, render/loss) so that gradients
+reach the grid, the decoder and -- through ``rays_o`` / ``rays_d`` -- the pose parameters of the caller.
+"""
+import copy
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import FEAT_LEVEL_MAJOR
+from .decoder import MLP_reg
+from .encodings import get_encoder
+
+
+class _PlaceFn(torch.autograd.Function):
+    """scene_rep.py:156-179 + :134-142: (rays, depth, noise) -> z_vals, normalised sample coordinates."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, target_d, noise, tables, rc, N, S):
+        rays_o, rays_d = ops._f32c(rays_o), ops._f32c(rays_d)
+        z_vals, xn, counts = ops.sample_rays(rays_o, rays_d, target_d, noise, tables, rc, N, S)
+        ctx.rc, ctx.N, ctx.S = rc, N, S
+        ctx.save_for_backward(z_vals)
+        ctx.mark_non_differentiable(z_vals, counts)
+        return z_vals, xn, counts
+
+    @staticmethod
+    def backward(ctx, _dz, dxn, _dc):
+        (z_vals,) = ctx.saved_tensors
+        d_o, d_d = ops.rays_bwd(ops._f32c(dxn), z_vals, ctx.rc, ctx.N, ctx.S)
+        return d_o, d_d, None, None, None, None, None, None
+
+
+class _NormaliseFn(torch.autograd.Function):
+    """run_network's normalisation (scene_rep.py:138-142), float64 inside the kernel."""
+
+    @staticmethod
+    def forward(ctx, pts, rc):
+        ctx.rc = rc
+        return ops.normalise_points(ops._f32c(pts), rc)
+
+    @staticmethod
+    def backward(ctx, dxn):
+        return ops.normalise_bwd(ops._f32c(dxn), ctx.rc), None
+
+
+class _QueryFn(torch.autograd.Function):
+    """query_color_sdf (scene_rep.py:118-128) fused: hash grid (level-major features) -> decoder with the
+    frequency encoding computed in its prologue.  Parameter gradients are accumulated straight into ``.grad``
+    (dense 36 MB grid gradient: no extra zero-fill + add pass through autograd)."""
+
+    @staticmethod
+    def forward(ctx, xn, owner, grid_params, *weights):
+        xn = ops._f32c(xn)
+        M = xn.shape[0]
+        meta = owner.embed_fn.meta
+        feat = ops.hashgrid_fwd(xn, grid_params.detach(), meta, FEAT_LEVEL_MAJOR)
+        packed = ops.decoder_pack(weights)
+        need = any(ctx.needs_input_grad)
+        out, saved = ops.decoder_fwd(packed, feat, FEAT_LEVEL_MAJOR, xn, None, M, save=need)
+        ctx.owner, ctx.M, ctx.meta = owner, M, meta
+        ctx.save_for_backward(xn, feat, out, saved, packed, grid_params, *weights)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xn, feat, out, saved, packed, grid_params, *weights = ctx.saved_tensors
+        need_w = any(ctx.needs_input_grad[3:])
+        direct = ctx.owner.accumulate_param_grads_in_place
+        if direct and need_w:
+            grads = []
+            for w, need in zip(weights, ctx.needs_input_grad[3:]):
+                if need and w.grad is None:
+                    w.grad = torch.zeros_like(w)
+                grads.append(w.grad if need else torch.zeros_like(w))
+        else:
+            grads = [torch.zeros_like(w) for w in weights]
+        dfeat, dx, _ = ops.decoder_bwd(packed, feat, FEAT_LEVEL_MAJOR, xn, None, out, ops._f32c(dout), saved, grads,
+                                       ctx.M)
+        dparams = None
+        if ctx.needs_input_grad[2]:
+            if direct:
+                if grid_params.grad is None:
+                    grid_params.grad = torch.zeros_like(grid_params)
+                dparams = grid_params.grad
+            else:
+                dparams = torch.zeros_like(grid_params)
+        if dparams is not None or ctx.needs_input_grad[0]:
+            scratch = dparams if dparams is not None else torch.zeros_like(grid_params)
+            ops.hashgrid_bwd(xn, grid_params.detach(), dfeat, scratch, ctx.meta, FEAT_LEVEL_MAJOR,
+                             dx if ctx.needs_input_grad[0] else None)
+        if direct:
+            return (dx if ctx.needs_input_grad[0] else None, None, None, *([None] * len(weights)))
+        return (dx if ctx.needs_input_grad[0] else None, None, dparams, *(grads if need_w else [None] * len(weights)))
+
+
+class _RenderFn(torch.autograd.Function):
+    """raw2outputs / sdf2weights (+ the four training losses): scene_rep.py:58-103, 211-236."""
+
+    @staticmethod
+    def forward(ctx, raw, z_vals, target_rgb, target_d, counts, rc, N, S, train):
+        raw = ops._f32c(raw)
+        rgb, depth, var, disp, acc, _, losses = ops.render_fwd(raw, z_vals, target_rgb, target_d, counts, rc, N, S,
+                                                               train)
+        ctx.rc, ctx.N, ctx.S, ctx.train = rc, N, S, train
+        ctx.save_for_backward(raw, z_vals, target_rgb, target_d, counts, losses)
+        ctx.mark_non_differentiable(var, disp, acc)
+        if train:
+            return rgb, depth, var, disp, acc, losses
+        return rgb, depth, var, disp, acc
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, _gv, _gd, _ga, g_losses=None):
+        raw, z_vals, target_rgb, target_d, counts, losses = ctx.saved_tensors
+        g_rgb = ops._f32c(g_rgb) if g_rgb is not None else None
+        g_depth = ops._f32c(g_depth) if g_depth is not None else None
+        if ctx.train and g_losses is None:
+            g_losses = torch.zeros(8, dtype=torch.float32, device=raw.device)
+        draw = ops.render_bwd(raw, z_vals, target_rgb, target_d, counts, losses, ctx.rc,
+                              ops._f32c(g_losses) if ctx.train else None, g_rgb, g_depth, ctx.N, ctx.S)
+        return draw, None, None, None, None, None, None, None, None
+
+
+class JointEncoding(nn.Module):
+    def __init__(self, config, bound_box, coords_norm_factor):
+        super().__init__()
+        self.config = config
+        self.bounding_box = bound_box
+        self.coords_norm_factor = coords_norm_factor
+        self._bound64 = torch.as_tensor(bound_box).detach().to("cpu", torch.float64).tolist()
+        self._half64 = torch.as_tensor(coords_norm_factor).detach().to("cpu", torch.float64).reshape(-1).tolist()
+        # extensions (defaults reproduce the reference's observable behaviour)
+        self.accumulate_param_grads_in_place = True
+        self._tables = {}
+        self.get_resolution()
+        self.get_encoding(config)
+        self.get_decoder(config)
+        self.save_initial_param()
+
+    # ------------------------------------------------------------------ construction (scene_rep.py:22-55)
+    def get_resolution(self):
+        dim_max = max(b[1] - b[0] for b in self._bound64)
+        if self.config["grid"]["voxel_sdf"] > 10:
+            self.resolution_sdf = self.config["grid"]["voxel_sdf"]
+        else:
+            self.resolution_sdf = int(dim_max / self.config["grid"]["voxel_sdf"])
+
+    def get_encoding(self, config):
+        self.embedpos_fn, self.input_ch_pos = get_encoder(config["pos"]["enc"], n_bins=config["pos"]["n_bins"])
+        self.embed_fn, self.input_ch = get_encoder(config["grid"]["enc"],
+                                                   log2_hashmap_size=config["grid"]["hash_size"],
+                                                   desired_resolution=256)
+        if self.embed_fn.otype != "hashgrid" or self.embedpos_fn.otype != "frequency" or self.input_ch_pos != 48:
+            raise ValueError("the fused HIP path is built for grid.enc=HashGrid + pos.enc=Frequency(n_bins=8), "
+                             "the only combination the reference's configs use")
+
+    def get_decoder(self, config):
+        self.decoder = MLP_reg(config, input_ch=self.input_ch, input_ch_pos=self.input_ch_pos)
+
+    def save_initial_param(self):
+        self.initial_dict = copy.deepcopy(self.state_dict())
+
+    def recover_initial_param(self):
+        self.load_state_dict(self.initial_dict)
+
+    # --------------------------------------------------------------------------------- helpers
+    def _rc(self, n_uniform, n_near, emd_w=0.0):
+        return ops.make_render_cfg(self.config, self._bound64, self._half64, n_uniform, n_near, emd_w)
+
+    def _linspace_tables(self, device, guided: bool):
+        key = (str(device), guided)
+        if key not in self._tables:
+            tr, cam = self.config["training"], self.config["cam"]
+            if guided:
+                zu = torch.linspace(cam["near"], cam["far"], tr["n_samples_d"])
+                zoff = torch.linspace(-tr["range_d"], tr["range_d"], steps=tr["n_range_d"])
+                znd = torch.linspace(cam["near"], cam["far"], steps=tr["n_range_d"])
+                self._tables[key] = tuple(t.to(device=device, dtype=torch.float32).contiguous() for t in (zu, zoff, znd))
+            else:
+                zu = torch.linspace(cam["near"], cam["far"], tr["n_samples"]).to(device=device, dtype=torch.float32)
+                self._tables[key] = (zu.contiguous(), None, None)
+        return self._tables[key]
+
+    def _query(self, x32):
+        return _QueryFn.apply(x32, self, self.embed_fn.params, *self.decoder.ordered_parameters())
+
+    def __deepcopy__(self, memo):
+        new = JointEncoding(self.config, self.bounding_box, self.coords_norm_factor)
+        memo[id(self)] = new
+        dev = self.embed_fn.params.device
+        new.to(dev)
+        new.load_state_dict(self.state_dict())
+        new.initial_dict = copy.deepcopy(self.initial_dict)
+        new.accumulate_param_grads_in_place = self.accumulate_param_grads_in_place
+        new.train(self.training)
+        return new
+
+    # ---------------------------------------------------------------- queries (scene_rep.py:105-146)
+    def query_sdf(self, query_points):
+        return self.query_color_sdf(query_points)[..., 3:4]
+
+    def query_color(self, query_points):
+        return torch.sigmoid(self.query_color_sdf(query_points)[..., :3])
+
+    def query_sdf_entropy_prob(self, query_points):
+        return self.query_color_sdf(query_points)[..., 3:]
+
+    def query_color_sdf(self, query_points):
+        """query_points: ALREADY normalised coordinates [..., 3] -> [prod(...), 10]."""
+        flat = torch.reshape(query_points, [-1, query_points.shape[-1]]) / self.config["training"]["norm_factor"]
+        if not flat.is_cuda:
+            raise RuntimeError("JointEncoding runs on the GPU only (no CPU fallback)")
+        return self._query(flat.to(torch.float32))
+
+    def run_network(self, inputs):
+        """inputs: UN-normalised local coordinates [..., 3] -> [..., 10]."""
+        flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
+        if not flat.is_cuda:
+            raise RuntimeError("JointEncoding runs on the GPU only (no CPU fallback)")
+        rc = self._rc(1, 0)
+        # the kernel applies /norm_factor itself (query_color_sdf's division, scene_rep.py:119)
+        xn = _NormaliseFn.apply(flat, rc)
+        out = self._query(xn)
+        return torch.reshape(out, list(inputs.shape[:-1]) + [out.shape[-1]])
+
+    # -------------------------------------------------------------- rendering (scene_rep.py:153-187)
+    def _render(self, rays_o, rays_d, target_rgb, target_d, noise, train, emd_w):
+        if not rays_o.is_cuda:
+            raise RuntimeError("JointEncoding runs on the GPU only (no CPU fallback)")
+        tr = self.config["training"]
+        N = rays_o.shape[0]
+        guided = target_d is not None
+        if guided and tr["n_samples_d"] <= 0:
+            raise ValueError("training.n_samples_d must be > 0 (every reference config sets it)")
+        n_uniform = tr["n_samples_d"] if guided else tr["n_samples"]
+        n_near = tr["n_range_d"] if guided else 0
+        S = n_uniform + n_near
+        rc = self._rc(n_uniform, n_near, emd_w)
+        if rc.perturb:
+            if noise is None:
+                # the reference draws this on the CPU default generator (scene_rep.py:176); doing the same keeps
+                # the CPU RNG stream -- and therefore every later pixel-sampling call -- bit-identical
+                noise = torch.rand(N, S).to(rays_o)
+            noise = ops._f32c(noise)
+        else:
+            noise = None
+        tables = self._linspace_tables(rays_o.device, guided)
+        td = ops._f32c(target_d).reshape(N, 1) if guided else None
+        z_vals, xn, counts = _PlaceFn.apply(rays_o, rays_d, td, noise, tables, rc, N, S)
+        raw = self._query(xn)
+        trgb = ops._f32c(target_rgb) if train else None
+        res = _RenderFn.apply(raw, z_vals, trgb, td if train else None, counts if train else None, rc, N, S, train)
+        return res, z_vals, raw.reshape(N, S, 10)
+
+    def render_rays(self, rays_o, rays_d, target_d=None, noise=None):
+        (rgb, depth, var, disp, acc), z_vals, raw = self._render(rays_o, rays_d, None, target_d, noise, False, 0.0)
+        return {"rgb": rgb, "depth": depth, "disp_map": disp, "acc_map": acc, "depth_var": var, "z_vals": z_vals,
+                "raw": raw}
+
+    def forward(self, rays_o, rays_d, target_rgb, target_d, EMD_w=0.01, noise=None):
+        """Same contract as scene_rep.py:190-238.  ``noise`` (extension): an [N,S] U[0,1) tensor to use instead of
+        drawing torch.rand on the CPU."""
+        if not self.training:
+            return self.render_rays(rays_o, rays_d, target_d=target_d, noise=noise)
+        (rgb, depth, _var, _disp, _acc, losses), _z, _raw = self._render(rays_o, rays_d, target_rgb, target_d, noise,
+                                                                         True, float(EMD_w))
+        return {"rgb": rgb, "depth": depth, "rgb_loss": losses[0], "depth_loss": losses[1], "sdf_loss": losses[2],
+                "fs_loss": losses[3], "psnr": losses[4:5].detach()}

@@ -1,0 +1,255 @@
+"""Tensor-level wrappers of the C ABI and the autograd Functions built on them.
+
+Everything here launches HIP kernels on the caller's current stream through ``_lib``; outputs are
+torch-allocated and handed over by pointer (the kernels never allocate).  No CPU path exists.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import FEAT_AOS, FEAT_LEVEL_MAJOR, check, dptr, lib, stream_ptr
+
+DECODER_PARAM_ORDER = ("pts_linear.0.weight", "pts_linear.0.bias", "pts_linear.2.weight", "pts_linear.2.bias",
+                       "rgb_linear.0.weight", "rgb_linear.0.bias", "sdf_linear.0.weight", "sdf_linear.0.bias",
+                       "sdf_linear.2.weight", "sdf_linear.2.bias")
+_DEC_FIELDS = ("w_pts0", "b_pts0", "w_pts2", "b_pts2", "w_rgb0", "b_rgb0", "w_sdf0", "b_sdf0", "w_sdf2", "b_sdf2")
+_DEC_SHAPES = ((128, 51), (128,), (128, 128), (128,), (3, 115), (3,), (128, 96), (128,), (5, 128), (5,))
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------ hash grid
+def hashgrid_fwd(x: torch.Tensor, params: torch.Tensor, meta, layout=FEAT_AOS) -> torch.Tensor:
+    M = x.shape[0]
+    nf = meta.n_levels * meta.n_features
+    out = torch.empty((M, nf) if layout == FEAT_AOS else (meta.n_levels, M, meta.n_features),
+                      dtype=torch.float32, device=x.device)
+    check(lib().mipsf_hashgrid_fwd(dptr(x), dptr(params), dptr(out), M, C.byref(meta), layout, stream_ptr()),
+          "hashgrid_fwd")
+    return out
+
+
+def hashgrid_bwd(x, params, dout, dparams, meta, layout=FEAT_AOS, dx: Optional[torch.Tensor] = None):
+    """dparams (and dx when given) are accumulated into."""
+    check(lib().mipsf_hashgrid_bwd(dptr(x), dptr(params), dptr(dout), dptr(dparams), dptr(dx), x.shape[0],
+                                   C.byref(meta), layout, stream_ptr()), "hashgrid_bwd")
+
+
+def hashgrid_indices(x, meta) -> torch.Tensor:
+    M = x.shape[0]
+    idx = torch.empty((M, meta.n_levels, 8), dtype=torch.int32, device=x.device)
+    check(lib().mipsf_hashgrid_indices(dptr(x), dptr(idx, torch.int32), M, C.byref(meta), stream_ptr()),
+          "hashgrid_indices")
+    return idx
+
+
+class HashGridFn(torch.autograd.Function):
+    """tcnn.Encoding(HashGrid) forward/backward (dense fp32 parameter gradient, dL/dx)."""
+
+    @staticmethod
+    def forward(ctx, x, params, meta):
+        x = _f32c(x)
+        ctx.meta = meta
+        ctx.save_for_backward(x, params)
+        return hashgrid_fwd(x, params.detach(), meta, FEAT_AOS)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, params = ctx.saved_tensors          # saved tensors survive retain_graph=True re-entry
+        dout = _f32c(dout)
+        dparams = torch.zeros_like(params)
+        dx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
+        hashgrid_bwd(x, params.detach(), dout, dparams, ctx.meta, FEAT_AOS, dx)
+        return dx, dparams, None
+
+
+# ------------------------------------------------------------------------------ frequency
+class FrequencyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n_freq):
+        x = _f32c(x)
+        ctx.n_freq = n_freq
+        ctx.save_for_backward(x)
+        M, D = x.shape
+        out = torch.empty((M, D * 2 * n_freq), dtype=torch.float32, device=x.device)
+        check(lib().mipsf_freq_fwd(dptr(x), dptr(out), M, D, n_freq, stream_ptr()), "freq_fwd")
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        M, D = x.shape
+        dx = torch.empty_like(x)
+        check(lib().mipsf_freq_bwd(dptr(x), dptr(_f32c(dout)), dptr(dx), M, D, ctx.n_freq, stream_ptr()),
+              "freq_bwd")
+        return dx, None
+
+
+# -------------------------------------------------------------------------------- decoder
+def _decoder_struct(tensors, cls):
+    st = cls()
+    for field, t, shape in zip(_DEC_FIELDS, tensors, _DEC_SHAPES):
+        if tuple(t.shape) != shape:
+            raise RuntimeError(f"decoder tensor {field} has shape {tuple(t.shape)}, expected {shape}")
+        setattr(st, field, dptr(t))
+    return st
+
+
+def decoder_pack(weights, packed: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """weights: the 10 nn.Linear tensors in DECODER_PARAM_ORDER -> MFMA operand images."""
+    dev = weights[0].device
+    if packed is None:
+        packed = torch.empty(lib().mipsf_decoder_packed_floats(), dtype=torch.float32, device=dev)
+    ws = [w.detach() for w in weights]
+    st = _decoder_struct(ws, _lib.DecoderWeights)
+    check(lib().mipsf_decoder_pack(C.byref(st), dptr(packed), stream_ptr()), "decoder_pack")
+    return packed
+
+
+def decoder_fwd(packed, feat, layout, x, embed_pos, M, save: bool):
+    out = torch.empty((M, 10), dtype=torch.float32, device=x.device)
+    saved = None
+    if save:
+        saved = torch.empty(lib().mipsf_decoder_saved_floats(M), dtype=torch.float32, device=x.device)
+    pe_mode = 0 if embed_pos is None else 1
+    check(lib().mipsf_decoder_fwd(dptr(packed), dptr(feat), layout, dptr(x), dptr(embed_pos), pe_mode, dptr(out),
+                                  dptr(saved), M, stream_ptr()), "decoder_fwd")
+    return out, saved
+
+
+def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M):
+    """grads: 10 tensors in DECODER_PARAM_ORDER, accumulated into.  -> (dfeat, dx, dembed_pos|None)"""
+    dev = x.device
+    dfeat = torch.empty_like(feat)
+    dx = torch.empty((M, 3), dtype=torch.float32, device=dev)
+    dpe = torch.empty((M, 48), dtype=torch.float32, device=dev) if embed_pos is not None else None
+    dact = torch.empty(lib().mipsf_decoder_dact_floats(M), dtype=torch.float32, device=dev)
+    partial = torch.empty(lib().mipsf_decoder_wgrad_partial_floats(), dtype=torch.float32, device=dev)
+    st = _decoder_struct(grads, _lib.DecoderGrads)
+    pe_mode = 0 if embed_pos is None else 1
+    check(lib().mipsf_decoder_bwd(dptr(packed), dptr(feat), layout, dptr(x), dptr(embed_pos), pe_mode, dptr(out),
+                                  dptr(dout), dptr(saved), dptr(dfeat), dptr(dx), dptr(dpe), C.byref(st),
+                                  dptr(dact), dptr(partial), M, stream_ptr()), "decoder_bwd")
+    return dfeat, dx, dpe
+
+
+class DecoderFn(torch.autograd.Function):
+    """MLP_reg.forward(embed, embed_pos, query_pts) with all three inputs differentiable (module API)."""
+
+    @staticmethod
+    def forward(ctx, embed, embed_pos, x, *weights):
+        embed, embed_pos, x = _f32c(embed), _f32c(embed_pos), _f32c(x)
+        M = x.shape[0]
+        packed = decoder_pack(weights)
+        need = any(ctx.needs_input_grad)
+        out, saved = decoder_fwd(packed, embed, FEAT_AOS, x, embed_pos, M, save=need)
+        ctx.M = M
+        ctx.save_for_backward(embed, embed_pos, x, out, saved, packed, *weights)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        embed, embed_pos, x, out, saved, packed, *weights = ctx.saved_tensors
+        grads = [torch.zeros_like(w) for w in weights]
+        dfeat, dx, dpe = decoder_bwd(packed, embed, FEAT_AOS, x, embed_pos, out, _f32c(dout), saved, grads, ctx.M)
+        return (dfeat, dpe, dx, *grads)
+
+
+# ------------------------------------------------------------------------------- renderer
+def make_render_cfg(cfg: dict, bound64, half_len64, n_uniform: int, n_near: int, emd_w: float) -> _lib.RenderCfg:
+    tr, cam = cfg["training"], cfg["cam"]
+    rc = _lib.RenderCfg()
+    rc.n_uniform, rc.n_near = n_uniform, n_near
+    rc.perturb = 1 if tr["perturb"] > 0.0 else 0
+    rc.use_bound = 1 if cfg["grid"]["use_bound_normalize"] else 0
+    for d in range(3):
+        rc.bound_min[d] = float(bound64[d][0])
+        rc.bound_max[d] = float(bound64[d][1])
+        rc.half_len[d] = float(half_len64[d])
+    if not cfg["grid"]["tcnn_encoding"]:
+        raise RuntimeError("grid.tcnn_encoding = False is not a configuration the reference ships")
+    rc.norm_factor = float(tr["norm_factor"])
+    rc.trunc = float(tr["trunc"])
+    rc.sc_factor = float(cfg["data"]["sc_factor"])
+    rc.depth_trunc = float(cam["depth_trunc"])
+    rc.rgb_missing_nonzero = 1 if tr["rgb_missing"] != 0 else 0
+    rc.emd_w = float(emd_w)
+    return rc
+
+
+def normalise_points(pts: torch.Tensor, rc) -> torch.Tensor:
+    xn = torch.empty_like(pts)
+    check(lib().mipsf_normalise_points(dptr(pts), C.byref(rc), dptr(xn), pts.shape[0], stream_ptr()), "normalise")
+    return xn
+
+
+def normalise_bwd(dxn: torch.Tensor, rc) -> torch.Tensor:
+    dpts = torch.empty_like(dxn)
+    check(lib().mipsf_normalise_bwd(dptr(dxn), C.byref(rc), dptr(dpts), dxn.shape[0], stream_ptr()), "normalise_bwd")
+    return dpts
+
+
+def sample_rays(rays_o, rays_d, target_d, noise, tables, rc, N, S):
+    dev = rays_o.device
+    z_vals = torch.empty((N, S), dtype=torch.float32, device=dev)
+    xn = torch.empty((N * S, 3), dtype=torch.float32, device=dev)
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    zu, zoff, znd = tables
+    check(lib().mipsf_sample_rays(dptr(rays_o), dptr(rays_d), dptr(target_d), dptr(noise), dptr(zu), dptr(zoff),
+                                  dptr(znd), C.byref(rc), dptr(z_vals), dptr(xn), dptr(counts, torch.int32), N,
+                                  stream_ptr()), "sample_rays")
+    return z_vals, xn, counts
+
+
+def render_fwd(raw, z_vals, target_rgb, target_d, counts, rc, N, S, train: bool, want_weights=False):
+    dev = raw.device
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)   # noqa: E731
+    rgb, depth, var, disp, acc = f(N, 3), f(N), f(N), f(N), f(N)
+    weights = f(N, S) if want_weights else None
+    losses = f(8) if train else None
+    partial = f(N * 8) if train else None
+    check(lib().mipsf_render_fwd(dptr(raw), dptr(z_vals), dptr(target_rgb), dptr(target_d),
+                                 dptr(counts, torch.int32) if counts is not None else None, C.byref(rc), dptr(rgb),
+                                 dptr(depth), dptr(var), dptr(disp), dptr(acc), dptr(weights), dptr(losses),
+                                 dptr(partial), N, S, stream_ptr()), "render_fwd")
+    return rgb, depth, var, disp, acc, weights, losses
+
+
+def render_bwd(raw, z_vals, target_rgb, target_d, counts, losses, rc, g_losses, g_rgb, g_depth, N, S):
+    draw = torch.empty_like(raw)
+    check(lib().mipsf_render_bwd(dptr(raw), dptr(z_vals), dptr(target_rgb), dptr(target_d),
+                                 dptr(counts, torch.int32) if counts is not None else None, dptr(losses),
+                                 C.byref(rc), dptr(g_losses), dptr(g_rgb), dptr(g_depth), dptr(draw), N, S,
+                                 stream_ptr()), "render_bwd")
+    return draw
+
+
+def rays_bwd(dxn, z_vals, rc, N, S):
+    d_o = torch.empty((N, 3), dtype=torch.float32, device=dxn.device)
+    d_d = torch.empty((N, 3), dtype=torch.float32, device=dxn.device)
+    check(lib().mipsf_rays_bwd(dptr(dxn), dptr(z_vals), C.byref(rc), dptr(d_o), dptr(d_d), N, S, stream_ptr()),
+          "rays_bwd")
+    return d_o, d_d
+
+
+# ----------------------------------------------------------------------------------- Adam
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, zero_grad=False):
+    check(lib().mipsf_adam_step(dptr(param), dptr(grad), dptr(exp_avg), dptr(exp_avg_sq), param.numel(), lr, beta1,
+                                beta2, eps, weight_decay, step, 1 if zero_grad else 0, stream_ptr()), "adam_step")
+
+
+def ro_fitness(raw, target_d, trunc: float) -> torch.Tensor:
+    """raw [P,n,10] (run_network output), target_d [n] -> mean_masked_sdf [P] (RandomOptimizer.py:125-129)."""
+    P, n, stride = raw.shape
+    out = torch.empty(P, dtype=torch.float32, device=raw.device)
+    check(lib().mipsf_ro_fitness(dptr(raw), stride, dptr(target_d), trunc, dptr(out), P, n, stream_ptr()),
+          "ro_fitness")
+    return out

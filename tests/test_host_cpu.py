@@ -1,0 +1,130 @@
+"""CPU: the C-ABI library loads and exports everything include/mipsf.h declares, host-only entry points agree
+with the oracle, and the host-side mirrors (samplers, pose helpers) reproduce the reference's golden vectors.
+No compute kernel is launched here."""
+import ctypes as C
+import math
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from mipsfusion_amd import _lib
+from mipsfusion_amd.helper_functions import geometry_helper as gh
+from mipsfusion_amd.helper_functions import sampling_helper as sh
+from oracle import tcnn_cpu
+
+from .conftest import ROOT, load_golden
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "mipsf.h")).read()
+    declared = set(re.findall(r"\b(mipsf_[a-z0-9_]+)\s*\(", header))
+    declared -= {"mipsf_grid_meta", "mipsf_decoder_weights", "mipsf_decoder_grads", "mipsf_render_cfg"}
+    assert len(declared) >= 25
+    handle = C.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(handle, name), f"{name} declared in mipsf.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+
+
+def test_abi_version_and_error_channel():
+    lib = _lib.lib()
+    assert lib.mipsf_abi_version() == 1
+    m = _lib.GridMeta()
+    rc = lib.mipsf_hashgrid_meta_init(C.byref(m), 16, 4, 19, 16, 1.2)
+    assert rc != 0 and b"n_features" in lib.mipsf_last_error()
+    with pytest.raises(RuntimeError):
+        _lib.check(rc, "meta")
+
+
+@pytest.mark.parametrize("log2_t", [10, 16, 19])
+def test_level_table_equals_oracle(log2_t):
+    pls = float(2.0 ** (math.log2(256 / 16) / 15))
+    m = _lib.make_grid_meta(16, 2, log2_t, 16, pls)
+    o = tcnn_cpu.make_grid_meta(16, 2, log2_t, 16, pls)
+    assert list(m.offsets[:17]) == o.offsets
+    assert list(m.resolutions[:16]) == o.resolutions
+    assert np.array_equal(np.array(m.scales[:16], dtype=np.float32), np.array(o.scales, dtype=np.float32))
+    assert m.n_params == o.n_params
+    assert np.float32(m.log2_per_level_scale) == np.float32(o.log2_per_level_scale)
+
+
+def test_product_ops_refuse_cpu_tensors():
+    from mipsfusion_amd.model import get_encoder
+    enc, dim = get_encoder("HashGrid", log2_hashmap_size=10, desired_resolution=256)
+    assert dim == 32 and enc.params.numel() == 32768
+    with pytest.raises(RuntimeError, match="GPU"):
+        enc(torch.rand(4, 3))
+    freq, fdim = get_encoder("Frequency", n_bins=8)
+    assert fdim == 48 and freq.params.numel() == 0
+
+
+def test_state_dict_keys_match_reference_interface():
+    from mipsfusion_amd import synth
+    from mipsfusion_amd.model import JointEncoding
+    cfg = synth.config_plumbing()
+    bb = torch.from_numpy(np.array(cfg["mapping"]["bound"]))
+    m = JointEncoding(cfg, bb, torch.tensor([7.0, 7.0, 7.0], dtype=torch.float64))
+    g = load_golden("scene_cfg1.npz")
+    ref_keys = {k[2:] for k in g.files if k.startswith("w.")}
+    assert set(m.state_dict().keys()) == ref_keys
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == g["w." + k].shape, k
+    m.load_state_dict({k: torch.from_numpy(g["w." + k]) for k in ref_keys})     # reference checkpoint loads
+    m.recover_initial_param()
+
+
+# --------------------------------------------------------------------------- samplers (a1)
+def seed_all(s):
+    random.seed(s)
+    np.random.seed(s)
+    torch.manual_seed(s)
+
+
+def test_pixel_samplers_bit_exact():
+    g = load_golden("sampler.npz")
+    depth = torch.from_numpy(g["depth"])
+    H, W = depth.shape
+    r, c = sh.sample_pixels_uniformly(460, 620, 16, 24)
+    assert np.array_equal(r.numpy(), g["uniform_460x620_16x24_rows"])
+    assert np.array_equal(c.numpy(), g["uniform_460x620_16x24_cols"])
+    r, c = sh.sample_pixels_uniformly(H, W, 4, 6)
+    assert np.array_equal(r.numpy(), g["uniform_small_rows"]) and np.array_equal(c.numpy(), g["uniform_small_cols"])
+    seed_all(11)
+    assert np.array_equal(sh.sample_pixels_random(H, W, 100).numpy(), g["random_seed11_n100"])
+    seed_all(12)
+    assert np.array_equal(sh.sample_valid_pixels_random(depth, 64).numpy(), g["valid_random_seed12_n64"])
+    seed_all(13)
+    r, c = sh.sample_pixels_mix(H, W, 4, 6, depth, 120)
+    assert np.array_equal(r.numpy(), g["mix_seed13_rows"]) and np.array_equal(c.numpy(), g["mix_seed13_cols"])
+    assert np.array_equal(sh.pixel_rc_to_indices(r, c, H, W).numpy(), g["mix_seed13_indices"])
+    seed_all(14)
+    assert np.array_equal(sh.select_samples(H, W, 50).numpy(), g["select_samples_seed14_n50"])
+
+
+def test_pixel_sampler_edge_cases():
+    depth = torch.zeros(8, 8)
+    depth[2, 3] = 1.0
+    seed_all(0)
+    idx = sh.sample_valid_pixels_random(depth, 1)
+    assert idx.item() == 2 * 8 + 3                      # the only valid pixel wins the top-k
+    r, c = sh.sample_pixels_uniformly(8, 8, 8, 8)        # every pixel: gap 0
+    assert np.array_equal(sh.pixel_rc_to_indices(r, c, 8, 8).numpy(), np.arange(64))
+    rr, cc = sh.pixel_indices_to_rc(torch.tensor([0, 7, 8, 63]), 8, 8)
+    assert rr.tolist() == [0, 0, 1, 7] and cc.tolist() == [0, 7, 0, 7]
+
+
+def test_pose_helpers_match_golden():
+    g = load_golden("quaternion.npz")
+    rot = torch.from_numpy(g["rot"]).requires_grad_(True)
+    trans = torch.from_numpy(g["trans"]).requires_grad_(True)
+    T = gh.qt_to_transform_matrix(rot, trans)
+    np.testing.assert_allclose(T.detach().numpy(), g["T"], rtol=1e-6, atol=1e-7)
+    T.backward(torch.from_numpy(g["gT"]))
+    np.testing.assert_allclose(rot.grad.numpy(), g["d_rot"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(trans.grad.numpy(), g["d_trans"], rtol=1e-6)
+    np.testing.assert_allclose(gh.matrix_to_quaternion(torch.from_numpy(g["T"])[:, :3, :3]).numpy(), g["q_back"],
+                               rtol=1e-6, atol=1e-7)

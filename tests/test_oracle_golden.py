@@ -243,3 +243,23 @@ def test_oracle_equals_live_reference_on_fresh_seed():
     o = mine.train_forward(ro, rd, rgb, d, noise, 0.01)
     for k in ("rgb", "depth", "rgb_loss", "depth_loss", "sdf_loss", "fs_loss"):
         close(o[k].detach(), r[k].detach(), rtol=2e-5, atol=1e-7)
+
+
+def test_plain_c_restatement_agrees_bit_for_bit():
+    """oracle/c/hashgrid_ref.c (real uint32 wrap, real fmaf) == oracle/tcnn_cpu.py (int64-masked, fp64-emulated)."""
+    import subprocess
+    from oracle import c_ref
+    from .conftest import ROOT
+    import os
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle", "c")], check=True, capture_output=True)
+    meta = tcnn_cpu.make_grid_meta(16, 2, 19, 16, float(2.0 ** (math.log2(16) / 15)))
+    torch.manual_seed(0)
+    x = torch.rand(3000, 3)
+    x[0], x[1], x[2] = 0.0, 1.0, torch.tensor([-0.05, 1.07, 0.5])
+    params = torch.rand(meta.n_params) * 2 - 1
+    idx, y = c_ref.hashgrid(x.numpy(), params.numpy(), meta)
+    assert np.array_equal(idx.astype(np.int64), tcnn_cpu.hashgrid_indices(x, meta).numpy())
+    assert np.array_equal(y, tcnn_cpu.hashgrid_forward(x, params, meta).numpy())
+    g = load_golden("hashgrid.npz")
+    idx19, _ = c_ref.hashgrid(g["t19.x"], None, meta)
+    assert np.array_equal(idx19.astype(np.int32), g["t19.idx"])
