@@ -1,0 +1,365 @@
+#!/usr/bin/env python3
+"""Benchmark of the render-and-optimise hot path (BASELINE.json metric) on 1..N MI355X GPUs.
+
+    python bench.py --gpus 1 --steps 30 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one full mapping iteration of MIPSFusion.local_BA (mipsfusion.py:293-342) at BASELINE config 2:
+4096 rays x 64 samples (43 uniform + 21 depth-guided), hash grid 2^19, apartment_2 bound, 620x460 synthetic RGB-D:
+ray build from the keyframe pose Parameters -> sample placement -> hash grid -> decoder -> SDF compositing ->
+4 losses -> backward (grid, decoder, pose gradients) -> dense map Adam (+ pose Adam every pose_accum_step).
+Pixel sampling (a1) runs on the host before the timed region: ray batches and the jitter noise are resident in
+HBM when timing starts.  N > 1: one process per GPU, each optimising its OWN submap (weak scaling); the
+only exchange is an all-gather of the optimised keyframe poses once per BA round (mapping.iters steps).
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from mipsfusion_amd import ops, synth  # noqa: E402
+from mipsfusion_amd.helper_functions import sampling_helper as sh  # noqa: E402
+from mipsfusion_amd.helper_functions.geometry_helper import matrix_to_quaternion, qt_to_transform_matrix  # noqa: E402
+from mipsfusion_amd.helper_functions.utils import get_loss_from_ret  # noqa: E402
+from mipsfusion_amd.model import JointEncoding  # noqa: E402
+from mipsfusion_amd.optim import FusedAdam  # noqa: E402
+
+N_RAYS, N_SAMPLES = 4096, 64
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+N_GRID_PARAMS, N_DEC_PARAMS = 9014144, 36577
+
+# algorithmic cost per unit (SURVEY.md 8d / BASELINE.md 3); unit = 1 ray*sample unless noted
+KERNEL_COST = {
+    "hashgrid_fwd": ("hbm", 1164.0),
+    "hashgrid_bwd": ("hbm", 2188.0),
+    "decoder_fwd": ("mfma", 72370.0),
+    "decoder_bwd_chain": ("mfma", 72370.0),
+    "decoder_wgrad": ("mfma", 72370.0),
+    "sample_rays": ("hbm", 20.0),
+    "render_fwd": ("hbm", 44.0),
+    "render_bwd": ("hbm", 84.0),
+    "rays_bwd": ("hbm", 16.0),
+}
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=30)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--setup-iters", type=int, default=50, help="untimed mapping iterations so the SDF has sign changes")
+    p.add_argument("--cpu-rays", type=int, default=1024, help="rays of the bounded CPU-baseline sample (0 = skip)")
+    p.add_argument("--cpu-iters", type=int, default=3)
+    p.add_argument("--no-frame-estimate", action="store_true")
+    return p.parse_args()
+
+
+def build_submap(cfg, dev, seed):
+    """One submap's state: model, 4 keyframes + current frame, optimisable keyframe poses, host-sampled ray pool."""
+    random.seed(seed), np.random.seed(seed), torch.manual_seed(seed)
+    bb = torch.from_numpy(np.array(cfg["mapping"]["bound"]))
+    nf = torch.from_numpy(np.array(cfg["mapping"]["localMLP_max_len"]))
+    model = JointEncoding(cfg, bb, nf)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        model.embed_fn.params.copy_((torch.rand(model.embed_fn.params.shape, generator=g) * 2 - 1) * 1e-4)
+    model = model.to(dev).train()
+    # keyframes on a small arc + the current frame
+    frames, poses = [], []
+    for k in range(5):
+        c2w = synth.default_pose(cfg, yaw=0.3 + 0.12 * k, pitch=-0.1 + 0.02 * k)
+        c2w[:3, 3] += torch.tensor([0.05 * k, 0.08 * k, 0.0])
+        frames.append(synth.make_frame(cfg, c2w, seed=seed * 100 + k, frame_id=k))
+        poses.append(c2w)
+    poses = torch.stack(poses)
+    return model, frames, poses
+
+
+def sample_pool(cfg, frames, n_batches):
+    """Host pixel sampling exactly as local_BA does it (keyframe rays by random.sample, current frame by
+    sample_pixels_mix), gathered into [N,7] ray records + owning pose index."""
+    H, W = frames[0]["depth"].shape
+    n_kf = len(frames) - 1
+    n_cur = cfg["mapping"]["pixels_cur"]
+    n_from_kf = N_RAYS - n_cur
+    per_kf = n_from_kf // n_kf
+    pool = []
+    cur = frames[-1]
+    for _ in range(n_batches):
+        recs, owner = [], []
+        for k in range(n_kf):
+            idx = torch.tensor(random.sample(range(H * W), per_kf))
+            r, c = torch.div(idx, W, rounding_mode="floor"), torch.remainder(idx, W)
+            f = frames[k]
+            recs.append(torch.cat([f["direction"][r, c], f["rgb"][r, c], f["depth"][r, c][:, None]], -1))
+            owner.append(torch.full((per_kf,), k, dtype=torch.int64))
+        rows, cols = sh.sample_pixels_mix(H, W, cfg["tracking"]["RO"]["n_rows"], cfg["tracking"]["RO"]["n_cols"],
+                                          cur["depth"], n_cur)
+        recs.append(torch.cat([cur["direction"][rows, cols], cur["rgb"][rows, cols], cur["depth"][rows, cols][:, None]], -1))
+        owner.append(torch.full((n_cur,), n_kf, dtype=torch.int64))
+        pool.append((torch.cat(recs, 0), torch.cat(owner, 0)))
+    return pool
+
+
+class MappingLoop:
+    """The local-BA iteration of mipsfusion.py:293-342 against our JointEncoding."""
+
+    def __init__(self, cfg, model, poses, pool, dev):
+        self.cfg, self.model, self.dev = cfg, model, dev
+        self.map_opt = FusedAdam([{"params": model.decoder.parameters(), "weight_decay": 1e-6, "lr": cfg["mapping"]["lr_decoder"]},
+                                  {"params": model.embed_fn.parameters(), "eps": 1e-15, "lr": cfg["mapping"]["lr_embed"]}],
+                                 betas=(0.9, 0.99))
+        poses = poses.to(dev)
+        self.pose_fixed = poses[:1]                                  # first keyframe stays fixed
+        self.cur_trans = torch.nn.Parameter(poses[1:, :3, 3].clone())
+        self.cur_rot = torch.nn.Parameter(matrix_to_quaternion(poses[1:, :3, :3]))
+        self.pose_opt = torch.optim.Adam([{"params": self.cur_rot, "lr": cfg["mapping"]["lr_rot"]},
+                                          {"params": self.cur_trans, "lr": cfg["mapping"]["lr_trans"]}])
+        self.poses_all = torch.cat([self.pose_fixed, qt_to_transform_matrix(self.cur_rot, self.cur_trans)], 0)
+        self.pool = [(r.to(dev), o.to(dev)) for r, o in pool]
+        self.noise = [torch.rand(N_RAYS, N_SAMPLES, device=dev) for _ in pool]
+        self.i = 0
+
+    def step(self):
+        cfg = self.cfg
+        rays, owner = self.pool[self.i % len(self.pool)]
+        noise = self.noise[self.i % len(self.pool)]
+        rays_d_cam, target_s, target_d = rays[:, :3], rays[:, 3:6], rays[:, 6:7]
+        rays_d = torch.sum(rays_d_cam[..., None, :] * self.poses_all[owner, :3, :3], -1)
+        rays_o = self.poses_all[owner, :3, -1]
+        ret = self.model.forward(rays_o, rays_d, target_s, target_d, noise=noise)
+        loss = get_loss_from_ret(ret, cfg["training"])
+        loss.backward(retain_graph=True)
+        self.i += 1
+        if self.i % cfg["mapping"]["map_accum_step"] == 0:
+            self.map_opt.step(zero_grad=True)           # step + zero_grad (mipsfusion.py:330-335) in one pass
+        if self.i % cfg["mapping"]["pose_accum_step"] == 0:
+            self.pose_opt.step()
+            self.poses_all = torch.cat([self.pose_fixed, qt_to_transform_matrix(self.cur_rot, self.cur_trans)], 0)
+            self.pose_opt.zero_grad()
+        return loss
+
+
+def forward_only_rate(model, loop, dev, iters=10):
+    rays, owner = loop.pool[0]
+    with torch.no_grad():
+        rays_d = torch.sum(rays[:, :3][..., None, :] * loop.poses_all[owner, :3, :3], -1).contiguous()
+        rays_o = loop.poses_all[owner, :3, -1].contiguous()
+        model.eval()
+        for _ in range(3):
+            model.forward(rays_o, rays_d, None, rays[:, 6:7], noise=loop.noise[0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            model.forward(rays_o, rays_d, None, rays[:, 6:7], noise=loop.noise[0])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+    model.train()
+    return N_RAYS * N_SAMPLES / dt, dt * 1e3
+
+
+def frame_estimate(cfg, model, loop, dev, ba_ms):
+    """tracking+mapping ms/frame = iter_RO*RO + tracking.iter*GO + mapping.iters*BA/map_every."""
+    from mipsfusion_amd import ops as _ops
+    P, n = cfg["tracking"]["RO"]["particle_size"], cfg["tracking"]["RO"]["n_rows"] * cfg["tracking"]["RO"]["n_cols"]
+    b = np.array(cfg["mapping"]["bound"])
+    pts = (torch.rand(P, n, 3, device=dev) * torch.tensor(b[:, 1] - b[:, 0], device=dev, dtype=torch.float32)
+           + torch.tensor(b[:, 0], device=dev, dtype=torch.float32))
+    td = torch.rand(n, device=dev) + 0.5
+    with torch.no_grad():
+        for _ in range(2):
+            _ops.ro_fitness(model.run_network(pts), td, cfg["training"]["trunc"])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            _ops.ro_fitness(model.run_network(pts), td, cfg["training"]["trunc"])
+        torch.cuda.synchronize()
+        ro_ms = (time.perf_counter() - t0) / 5 * 1e3
+    # GO: tracking.sample rays, pose-only Adam on one pose
+    ns = cfg["tracking"]["sample"]
+    rays, _ = loop.pool[0]
+    rays = rays[:ns]
+    rot = torch.nn.Parameter(loop.cur_rot.detach()[-1:].clone())
+    trans = torch.nn.Parameter(loop.cur_trans.detach()[-1:].clone())
+    popt = torch.optim.Adam([{"params": rot, "lr": 1e-3}, {"params": trans, "lr": 1e-3}])
+    noise = loop.noise[0][:ns]
+
+    def go():
+        popt.zero_grad()
+        c2w = qt_to_transform_matrix(rot, trans)
+        rays_o = c2w[..., :3, -1].repeat(ns, 1)
+        rays_d = torch.sum(rays[:, :3][..., None, :] * c2w[:, :3, :3], -1)
+        ret = model.forward(rays_o, rays_d, rays[:, 3:6], rays[:, 6:7], EMD_w=0., noise=noise)
+        get_loss_from_ret(ret, cfg["training"]).backward()
+        popt.step()
+    for _ in range(3):
+        go()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        go()
+    torch.cuda.synchronize()
+    go_ms = (time.perf_counter() - t0) / 10 * 1e3
+    model.zero_grad()
+    tr, mp = cfg["tracking"], cfg["mapping"]
+    total = tr["iter_RO"] * ro_ms + tr["iter"] * go_ms + mp["iters"] * ba_ms / mp["map_every"]
+    return {"ro_iter_ms": round(ro_ms, 4), "go_iter_ms": round(go_ms, 4), "ba_iter_ms": round(ba_ms, 4),
+            "tracking_plus_mapping_ms_per_frame": round(total, 3),
+            "formula": "iter_RO*ro + tracking.iter*go + mapping.iters*ba/map_every (FastCaMo-synth cadence 5/10/15/3)"}
+
+
+def cpu_baseline(cfg, loop, n_rays, iters):
+    """The oracle (torch-CPU restatement of the reference path, oracle/path_cpu.py) on a bounded sample."""
+    from oracle import path_cpu
+    torch.set_num_threads(os.cpu_count() or 1)
+    cpu = path_cpu.CpuScene(cfg, cfg["mapping"]["bound"], cfg["mapping"]["localMLP_max_len"])
+    cpu.load_state_dict({k: v.cpu() for k, v in loop.model.state_dict().items()})
+    opt = torch.optim.Adam([{"params": cpu.decoder.parameters(), "weight_decay": 1e-6, "lr": 0.01},
+                            {"params": cpu.embed_fn.parameters(), "eps": 1e-15, "lr": 0.01}], betas=(0.9, 0.99))
+    rays, owner = loop.pool[0]
+    rays, owner = rays[:n_rays].cpu(), owner[:n_rays].cpu()
+    poses = loop.poses_all.detach().cpu()
+    noise = loop.noise[0][:n_rays].cpu()
+    rays_d = torch.sum(rays[:, :3][..., None, :] * poses[owner, :3, :3], -1)
+    rays_o = poses[owner, :3, -1]
+
+    def it():
+        opt.zero_grad()
+        ret = cpu.train_forward(rays_o, rays_d, rays[:, 3:6], rays[:, 6:7], noise, 0.01)
+        path_cpu.total_loss(ret, cfg["training"]).backward()
+        opt.step()
+    it()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        it()
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": n_rays * N_SAMPLES / dt, "unit": "rays*samples/s", "cores": torch.get_num_threads(),
+            "kind": "port", "s_per_iter": round(dt, 3),
+            "sample": f"{iters} full iterations (fwd+bwd+dense Adam over the 2^19 grid) of oracle/path_cpu.py on "
+                      f"{n_rays} of the 4096 rays x 64 samples of the same batch, torch CPU threads = cores"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg = synth.config_headline()
+    model, frames, poses = build_submap(cfg, dev, seed=rank)
+    pool = sample_pool(cfg, frames, n_batches=8)
+    loop = MappingLoop(cfg, model, poses, pool, dev)
+    for _ in range(args.setup_iters):
+        loop.step()
+    torch.cuda.synchronize()
+
+    def exchange_poses():
+        # after each BA round every submap publishes its optimised keyframe poses
+        if dist is not None:
+            mine = torch.cat([loop.cur_rot.detach(), loop.cur_trans.detach()], -1).contiguous()
+            out = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(out, mine)
+
+    for _ in range(args.warmup):
+        loop.step()
+    exchange_poses()
+    ba_round = cfg["mapping"]["iters"]
+
+    ops.PROFILE = {}
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        loop.step()
+        if (k + 1) % ba_round == 0:
+            exchange_poses()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ops.profile_summary()
+    ops.PROFILE = None
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    if rank != 0:
+        dist.barrier()              # rank 0 finishes its untimed extras, then everybody leaves together
+        dist.destroy_process_group()
+        return
+
+    M = N_RAYS * N_SAMPLES
+    ms_step = elapsed / args.steps * 1e3
+    value = M * args.steps * world / elapsed
+
+    kernels = {}
+    for name, (n_launch, ms) in prof.items():
+        if name in KERNEL_COST:
+            bound, per_unit = KERNEL_COST[name]
+            work = per_unit * M
+        elif name == "adam_step":
+            bound, work = "hbm", 28.0 * N_GRID_PARAMS
+        else:
+            continue
+        if bound == "hbm":
+            achieved, peak, unit = work / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            achieved, peak, unit = work / (ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+        kernels[name] = {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+                         "frac": round(achieved / peak, 4), "avg_ms": round(ms, 4),
+                         "launches": n_launch, "traffic": None}
+    dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"]) if kernels else None
+    roofline = dict(kernels[dominant], kernel=dominant) if dominant else None
+
+    fwd_rate, fwd_ms = forward_only_rate(model, loop, dev)
+    out = {
+        "metric": "rays*samples/s, full optimisation iteration (sample placement -> hash grid -> decoder -> SDF "
+                  "render -> losses -> backward -> pose+map Adam), 4096 rays x 64 samples, 640x480 RGB-D",
+        "value": round(value, 1), "unit": "rays*samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config 2: FastCaMo-synth apartment_2 bound, 1 active submap per GPU, "
+                               "4096 rays x 64 samples (43 uniform + 21 depth-guided), hash grid 2^19 x 16 levels x 2, "
+                               "620x460 synthetic RGB-D (640x480 cropped by 10)",
+                   "rays": N_RAYS, "samples_per_ray": N_SAMPLES, "hash_size": cfg["grid"]["hash_size"],
+                   "parallelism": f"submap-per-gpu x{world}" if world > 1 else "single gpu"},
+        "forward_only": {"value": round(fwd_rate, 1), "unit": "rays*samples/s", "ms": round(fwd_ms, 4)},
+        "roofline": roofline, "kernels": kernels,
+    }
+    if not args.no_frame_estimate:
+        out["frame"] = frame_estimate(cfg, model, loop, dev, ms_step)
+    if world == 1 and args.cpu_rays > 0:
+        out["cpu_baseline"] = cpu_baseline(cfg, loop, args.cpu_rays, args.cpu_iters)
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -118,6 +118,16 @@ int mipsf_decoder_bwd(const float* packed, const float* feat, int feat_layout, c
                       const float* saved, float* dfeat, float* dx, float* dembed_pos,
                       const mipsf_decoder_grads* grads_host_struct, float* dact, float* partial,
                       uint32_t M, void* stream);
+/* The two halves of mipsf_decoder_bwd as separate entry points (same arguments; used when the activation
+ * chain and the weight-gradient GEMMs are to be scheduled or timed separately):
+ *   _bwd_chain : d(out) -> dfeat, dx, dembed_pos, dact          (register-chained MFMA, no LDS)
+ *   _wgrad     : (saved, dact) -> weight/bias gradients          (LDS-transposed MFMA GEMMs + reduce) */
+int mipsf_decoder_bwd_chain(const float* packed, int feat_layout, const float* x, int pe_mode,
+                            const float* out, const float* dout, const float* saved, float* dfeat, float* dx,
+                            float* dembed_pos, float* dact, uint32_t M, void* stream);
+int mipsf_decoder_wgrad(const float* feat, int feat_layout, const float* x, const float* embed_pos, int pe_mode,
+                        const float* saved, const float* dact, const mipsf_decoder_grads* grads_host_struct,
+                        float* partial, uint32_t M, void* stream);
 
 /* -------------------------------------------------- sample placement (a3 + a4) */
 typedef struct mipsf_render_cfg {

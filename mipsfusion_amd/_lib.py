@@ -63,6 +63,8 @@ SIGNATURES = {
     "mipsf_decoder_fwd": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _U32, _P]),
     "mipsf_decoder_bwd": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.POINTER(DecoderGrads), _P, _P,
                                _U32, _P]),
+    "mipsf_decoder_bwd_chain": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _U32, _P]),
+    "mipsf_decoder_wgrad": (_I, [_P, _I, _P, _P, _I, _P, _P, C.POINTER(DecoderGrads), _P, _U32, _P]),
     "mipsf_sample_rays": (_I, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _U32, _P]),
     "mipsf_normalise_points": (_I, [_P, C.POINTER(RenderCfg), _P, _U32, _P]),
     "mipsf_render_fwd": (_I, [_P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _U32, _U32,

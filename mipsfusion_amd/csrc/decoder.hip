@@ -639,27 +639,41 @@ int mipsf_decoder_fwd(const float* packed, const float* feat, int feat_layout, c
     return check_launch("decoder_fwd");
 }
 
-int mipsf_decoder_bwd(const float* packed, const float* feat, int feat_layout, const float* x,
-                      const float* embed_pos, int pe_mode, const float* out, const float* dout,
-                      const float* saved, float* dfeat, float* dx, float* dembed_pos,
-                      const mipsf_decoder_grads* grads, float* dact, float* partial, uint32_t M, void* stream) {
+int mipsf_decoder_bwd_chain(const float* packed, int feat_layout, const float* x, int pe_mode, const float* out,
+                            const float* dout, const float* saved, float* dfeat, float* dx, float* dembed_pos,
+                            float* dact, uint32_t M, void* stream) {
     if (M == 0) return 0;
-    MIPSF_REQUIRE(packed && feat && x && out && dout && saved && dfeat && dx && dact && partial && grads,
-                  "null pointer");
-    MIPSF_REQUIRE(pe_mode == 0 || (embed_pos && dembed_pos), "pe_mode 1 needs embed_pos and dembed_pos");
+    MIPSF_REQUIRE(packed && x && out && dout && saved && dfeat && dx && dact, "null pointer");
+    MIPSF_REQUIRE(pe_mode == 0 || dembed_pos, "pe_mode 1 needs dembed_pos");
     MIPSF_REQUIRE(feat_layout == MIPSF_FEAT_AOS || feat_layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout");
     hipStream_t s = (hipStream_t)stream;
     const uint32_t blocks = (uint32_t)((n_wave_tiles(M) + 3) / 4);
-    const uint32_t n_bt = (uint32_t)n_block_tiles(M);
     float* dsmall = dact + n_block_tiles(M) * 4 * ACT_TILE_FLOATS;
 #define BWD(PE, LAY) \
     hipLaunchKernelGGL((decoder_bwd_kernel<PE, LAY>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed, x, out, dout, saved, dfeat, dx, dembed_pos, dact, dsmall, M)
     if (pe_mode == 0) { if (feat_layout == MIPSF_FEAT_AOS) BWD(true, MIPSF_FEAT_AOS); else BWD(true, MIPSF_FEAT_LEVEL_MAJOR); }
     else { if (feat_layout == MIPSF_FEAT_AOS) BWD(false, MIPSF_FEAT_AOS); else BWD(false, MIPSF_FEAT_LEVEL_MAJOR); }
 #undef BWD
-    if (int e = check_launch("decoder_bwd")) return e;
+    return check_launch("decoder_bwd_chain");
+}
 
-    int cus = mipsf_device_cu_count();
+int mipsf_decoder_wgrad(const float* feat, int feat_layout, const float* x, const float* embed_pos, int pe_mode,
+                        const float* saved, const float* dact, const mipsf_decoder_grads* grads, float* partial,
+                        uint32_t M, void* stream) {
+    if (M == 0) return 0;
+    MIPSF_REQUIRE(feat && x && saved && dact && partial && grads, "null pointer");
+    MIPSF_REQUIRE(pe_mode == 0 || embed_pos, "pe_mode 1 needs embed_pos");
+    MIPSF_REQUIRE(feat_layout == MIPSF_FEAT_AOS || feat_layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout");
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t n_bt = (uint32_t)n_block_tiles(M);
+    const float* dsmall = dact + n_block_tiles(M) * 4 * ACT_TILE_FLOATS;
+    GradPtrs g;
+    g.p[0] = grads->w_pts0, g.p[1] = grads->b_pts0, g.p[2] = grads->w_pts2, g.p[3] = grads->b_pts2;
+    g.p[4] = grads->w_rgb0, g.p[5] = grads->b_rgb0, g.p[6] = grads->w_sdf0, g.p[7] = grads->b_sdf0;
+    g.p[8] = grads->w_sdf2, g.p[9] = grads->b_sdf2;
+    for (int k = 0; k < 10; ++k) MIPSF_REQUIRE(g.p[k] != nullptr, "null gradient pointer %d", k);
+    static int cus = 0;
+    if (cus <= 0) cus = mipsf_device_cu_count();
     if (cus <= 0) return 3;
     uint32_t wg_blocks = n_bt < (uint32_t)cus ? n_bt : (uint32_t)cus;
     if (wg_blocks > WG_MAX_BLOCKS) wg_blocks = WG_MAX_BLOCKS;
@@ -681,14 +695,18 @@ int mipsf_decoder_bwd(const float* packed, const float* feat, int feat_layout, c
     else { if (feat_layout == MIPSF_FEAT_AOS) WG(false, MIPSF_FEAT_AOS); else WG(false, MIPSF_FEAT_LEVEL_MAJOR); }
 #undef WG
     if (int e = check_launch("decoder_wgrad")) return e;
-
-    GradPtrs g;
-    g.p[0] = grads->w_pts0, g.p[1] = grads->b_pts0, g.p[2] = grads->w_pts2, g.p[3] = grads->b_pts2;
-    g.p[4] = grads->w_rgb0, g.p[5] = grads->b_rgb0, g.p[6] = grads->w_sdf0, g.p[7] = grads->b_sdf0;
-    g.p[8] = grads->w_sdf2, g.p[9] = grads->b_sdf2;
-    for (int k = 0; k < 10; ++k) MIPSF_REQUIRE(g.p[k] != nullptr, "null gradient pointer %d", k);
     hipLaunchKernelGGL(decoder_wgrad_reduce_kernel, dim3((G_TOTAL + 255) / 256), dim3(256), 0, s, partial, wg_blocks, g);
     return check_launch("decoder_wgrad_reduce");
+}
+
+int mipsf_decoder_bwd(const float* packed, const float* feat, int feat_layout, const float* x,
+                      const float* embed_pos, int pe_mode, const float* out, const float* dout,
+                      const float* saved, float* dfeat, float* dx, float* dembed_pos,
+                      const mipsf_decoder_grads* grads, float* dact, float* partial, uint32_t M, void* stream) {
+    if (int e = mipsf_decoder_bwd_chain(packed, feat_layout, x, pe_mode, out, dout, saved, dfeat, dx, dembed_pos, dact,
+                                        M, stream))
+        return e;
+    return mipsf_decoder_wgrad(feat, feat_layout, x, embed_pos, pe_mode, saved, dact, grads, partial, M, stream);
 }
 
 }  // extern "C"

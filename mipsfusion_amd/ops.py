@@ -20,6 +20,36 @@ _DEC_FIELDS = ("w_pts0", "b_pts0", "w_pts2", "b_pts2", "w_rgb0", "b_rgb0", "w_sd
 _DEC_SHAPES = ((128, 51), (128,), (128, 128), (128,), (3, 115), (3,), (128, 96), (128,), (5, 128), (5,))
 
 
+# Optional per-kernel timing: set PROFILE = {} and every launch below is bracketed by a pair of events recorded
+# on the launch stream (torch's current stream IS the stream the kernels are enqueued on).
+PROFILE = None
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.b.record()
+            PROFILE.setdefault(self.name, []).append((self.a, self.b))
+
+
+def profile_summary():
+    """-> {kernel: (launches, mean_ms)} after a torch.cuda.synchronize()."""
+    out = {}
+    for k, pairs in (PROFILE or {}).items():
+        ms = [a.elapsed_time(b) for a, b in pairs]
+        out[k] = (len(ms), sum(ms) / max(1, len(ms)))
+    return out
+
+
 def _f32c(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         t = t.to(torch.float32)
@@ -32,15 +62,17 @@ def hashgrid_fwd(x: torch.Tensor, params: torch.Tensor, meta, layout=FEAT_AOS) -
     nf = meta.n_levels * meta.n_features
     out = torch.empty((M, nf) if layout == FEAT_AOS else (meta.n_levels, M, meta.n_features),
                       dtype=torch.float32, device=x.device)
-    check(lib().mipsf_hashgrid_fwd(dptr(x), dptr(params), dptr(out), M, C.byref(meta), layout, stream_ptr()),
-          "hashgrid_fwd")
+    with _timed("hashgrid_fwd"):
+        check(lib().mipsf_hashgrid_fwd(dptr(x), dptr(params), dptr(out), M, C.byref(meta), layout, stream_ptr()),
+              "hashgrid_fwd")
     return out
 
 
 def hashgrid_bwd(x, params, dout, dparams, meta, layout=FEAT_AOS, dx: Optional[torch.Tensor] = None):
     """dparams (and dx when given) are accumulated into."""
-    check(lib().mipsf_hashgrid_bwd(dptr(x), dptr(params), dptr(dout), dptr(dparams), dptr(dx), x.shape[0],
-                                   C.byref(meta), layout, stream_ptr()), "hashgrid_bwd")
+    with _timed("hashgrid_bwd"):
+        check(lib().mipsf_hashgrid_bwd(dptr(x), dptr(params), dptr(dout), dptr(dparams), dptr(dx), x.shape[0],
+                                       C.byref(meta), layout, stream_ptr()), "hashgrid_bwd")
 
 
 def hashgrid_indices(x, meta) -> torch.Tensor:
@@ -110,7 +142,8 @@ def decoder_pack(weights, packed: Optional[torch.Tensor] = None) -> torch.Tensor
         packed = torch.empty(lib().mipsf_decoder_packed_floats(), dtype=torch.float32, device=dev)
     ws = [w.detach() for w in weights]
     st = _decoder_struct(ws, _lib.DecoderWeights)
-    check(lib().mipsf_decoder_pack(C.byref(st), dptr(packed), stream_ptr()), "decoder_pack")
+    with _timed("decoder_pack"):
+        check(lib().mipsf_decoder_pack(C.byref(st), dptr(packed), stream_ptr()), "decoder_pack")
     return packed
 
 
@@ -120,8 +153,9 @@ def decoder_fwd(packed, feat, layout, x, embed_pos, M, save: bool):
     if save:
         saved = torch.empty(lib().mipsf_decoder_saved_floats(M), dtype=torch.float32, device=x.device)
     pe_mode = 0 if embed_pos is None else 1
-    check(lib().mipsf_decoder_fwd(dptr(packed), dptr(feat), layout, dptr(x), dptr(embed_pos), pe_mode, dptr(out),
-                                  dptr(saved), M, stream_ptr()), "decoder_fwd")
+    with _timed("decoder_fwd"):
+        check(lib().mipsf_decoder_fwd(dptr(packed), dptr(feat), layout, dptr(x), dptr(embed_pos), pe_mode, dptr(out),
+                                      dptr(saved), M, stream_ptr()), "decoder_fwd")
     return out, saved
 
 
@@ -135,9 +169,13 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M):
     partial = torch.empty(lib().mipsf_decoder_wgrad_partial_floats(), dtype=torch.float32, device=dev)
     st = _decoder_struct(grads, _lib.DecoderGrads)
     pe_mode = 0 if embed_pos is None else 1
-    check(lib().mipsf_decoder_bwd(dptr(packed), dptr(feat), layout, dptr(x), dptr(embed_pos), pe_mode, dptr(out),
-                                  dptr(dout), dptr(saved), dptr(dfeat), dptr(dx), dptr(dpe), C.byref(st),
-                                  dptr(dact), dptr(partial), M, stream_ptr()), "decoder_bwd")
+    with _timed("decoder_bwd_chain"):
+        check(lib().mipsf_decoder_bwd_chain(dptr(packed), layout, dptr(x), pe_mode, dptr(out), dptr(dout), dptr(saved),
+                                            dptr(dfeat), dptr(dx), dptr(dpe), dptr(dact), M, stream_ptr()),
+              "decoder_bwd_chain")
+    with _timed("decoder_wgrad"):
+        check(lib().mipsf_decoder_wgrad(dptr(feat), layout, dptr(x), dptr(embed_pos), pe_mode, dptr(saved),
+                                        dptr(dact), C.byref(st), dptr(partial), M, stream_ptr()), "decoder_wgrad")
     return dfeat, dx, dpe
 
 
@@ -203,9 +241,10 @@ def sample_rays(rays_o, rays_d, target_d, noise, tables, rc, N, S):
     xn = torch.empty((N * S, 3), dtype=torch.float32, device=dev)
     counts = torch.zeros(2, dtype=torch.int32, device=dev)
     zu, zoff, znd = tables
-    check(lib().mipsf_sample_rays(dptr(rays_o), dptr(rays_d), dptr(target_d), dptr(noise), dptr(zu), dptr(zoff),
-                                  dptr(znd), C.byref(rc), dptr(z_vals), dptr(xn), dptr(counts, torch.int32), N,
-                                  stream_ptr()), "sample_rays")
+    with _timed("sample_rays"):
+        check(lib().mipsf_sample_rays(dptr(rays_o), dptr(rays_d), dptr(target_d), dptr(noise), dptr(zu), dptr(zoff),
+                                      dptr(znd), C.byref(rc), dptr(z_vals), dptr(xn), dptr(counts, torch.int32), N,
+                                      stream_ptr()), "sample_rays")
     return z_vals, xn, counts
 
 
@@ -216,34 +255,38 @@ def render_fwd(raw, z_vals, target_rgb, target_d, counts, rc, N, S, train: bool,
     weights = f(N, S) if want_weights else None
     losses = f(8) if train else None
     partial = f(N * 8) if train else None
-    check(lib().mipsf_render_fwd(dptr(raw), dptr(z_vals), dptr(target_rgb), dptr(target_d),
-                                 dptr(counts, torch.int32) if counts is not None else None, C.byref(rc), dptr(rgb),
-                                 dptr(depth), dptr(var), dptr(disp), dptr(acc), dptr(weights), dptr(losses),
-                                 dptr(partial), N, S, stream_ptr()), "render_fwd")
+    with _timed("render_fwd"):
+        check(lib().mipsf_render_fwd(dptr(raw), dptr(z_vals), dptr(target_rgb), dptr(target_d),
+                                     dptr(counts, torch.int32) if counts is not None else None, C.byref(rc), dptr(rgb),
+                                     dptr(depth), dptr(var), dptr(disp), dptr(acc), dptr(weights), dptr(losses),
+                                     dptr(partial), N, S, stream_ptr()), "render_fwd")
     return rgb, depth, var, disp, acc, weights, losses
 
 
 def render_bwd(raw, z_vals, target_rgb, target_d, counts, losses, rc, g_losses, g_rgb, g_depth, N, S):
     draw = torch.empty_like(raw)
-    check(lib().mipsf_render_bwd(dptr(raw), dptr(z_vals), dptr(target_rgb), dptr(target_d),
-                                 dptr(counts, torch.int32) if counts is not None else None, dptr(losses),
-                                 C.byref(rc), dptr(g_losses), dptr(g_rgb), dptr(g_depth), dptr(draw), N, S,
-                                 stream_ptr()), "render_bwd")
+    with _timed("render_bwd"):
+        check(lib().mipsf_render_bwd(dptr(raw), dptr(z_vals), dptr(target_rgb), dptr(target_d),
+                                     dptr(counts, torch.int32) if counts is not None else None, dptr(losses),
+                                     C.byref(rc), dptr(g_losses), dptr(g_rgb), dptr(g_depth), dptr(draw), N, S,
+                                     stream_ptr()), "render_bwd")
     return draw
 
 
 def rays_bwd(dxn, z_vals, rc, N, S):
     d_o = torch.empty((N, 3), dtype=torch.float32, device=dxn.device)
     d_d = torch.empty((N, 3), dtype=torch.float32, device=dxn.device)
-    check(lib().mipsf_rays_bwd(dptr(dxn), dptr(z_vals), C.byref(rc), dptr(d_o), dptr(d_d), N, S, stream_ptr()),
-          "rays_bwd")
+    with _timed("rays_bwd"):
+        check(lib().mipsf_rays_bwd(dptr(dxn), dptr(z_vals), C.byref(rc), dptr(d_o), dptr(d_d), N, S, stream_ptr()),
+              "rays_bwd")
     return d_o, d_d
 
 
 # ----------------------------------------------------------------------------------- Adam
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, zero_grad=False):
-    check(lib().mipsf_adam_step(dptr(param), dptr(grad), dptr(exp_avg), dptr(exp_avg_sq), param.numel(), lr, beta1,
-                                beta2, eps, weight_decay, step, 1 if zero_grad else 0, stream_ptr()), "adam_step")
+    with _timed("adam_step" if param.numel() > (1 << 20) else "adam_step_small"):
+        check(lib().mipsf_adam_step(dptr(param), dptr(grad), dptr(exp_avg), dptr(exp_avg_sq), param.numel(), lr, beta1,
+                                    beta2, eps, weight_decay, step, 1 if zero_grad else 0, stream_ptr()), "adam_step")
 
 
 def ro_fitness(raw, target_d, trunc: float) -> torch.Tensor:
