@@ -54,6 +54,20 @@ KERNEL_COST = {
 }
 
 
+_T0 = time.time()
+
+
+def log(msg):
+    print(f"[bench +{time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -223,7 +237,7 @@ def frame_estimate(cfg, model, loop, dev, ba_ms):
 def cpu_baseline(cfg, loop, n_rays, iters):
     """The oracle (torch-CPU restatement of the reference path, oracle/path_cpu.py) on a bounded sample."""
     from oracle import path_cpu
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(usable_cores())
     cpu = path_cpu.CpuScene(cfg, cfg["mapping"]["bound"], cfg["mapping"]["localMLP_max_len"])
     cpu.load_state_dict({k: v.cpu() for k, v in loop.model.state_dict().items()})
     opt = torch.optim.Adam([{"params": cpu.decoder.parameters(), "weight_decay": 1e-6, "lr": 0.01},
@@ -240,10 +254,17 @@ def cpu_baseline(cfg, loop, n_rays, iters):
         ret = cpu.train_forward(rays_o, rays_d, rays[:, 3:6], rays[:, 6:7], noise, 0.01)
         path_cpu.total_loss(ret, cfg["training"]).backward()
         opt.step()
+    t_w = time.perf_counter()
     it()
+    log(f"cpu_baseline warm-up iteration {time.perf_counter() - t_w:.1f}s on {torch.get_num_threads()} threads")
     t0 = time.perf_counter()
+    done = 0
     for _ in range(iters):
         it()
+        done += 1
+        if time.perf_counter() - t0 > 45.0:          # keep the default run within minutes on slow hosts
+            break
+    iters = done
     dt = (time.perf_counter() - t0) / iters
     return {"value": n_rays * N_SAMPLES / dt, "unit": "rays*samples/s", "cores": torch.get_num_threads(),
             "kind": "port", "s_per_iter": round(dt, 3),
@@ -269,12 +290,15 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = synth.config_headline()
+    log(f"rank {rank}/{world} on {torch.cuda.get_device_name(local)}; building submap")
     model, frames, poses = build_submap(cfg, dev, seed=rank)
     pool = sample_pool(cfg, frames, n_batches=8)
     loop = MappingLoop(cfg, model, poses, pool, dev)
+    log("setup iterations")
     for _ in range(args.setup_iters):
         loop.step()
     torch.cuda.synchronize()
+    log("setup done")
 
     def exchange_poses():
         # after each BA round every submap publishes its optimised keyframe poses
@@ -301,6 +325,7 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    log(f"timed region: {args.steps} steps in {elapsed * 1e3:.1f} ms")
     prof = ops.profile_summary()
     ops.PROFILE = None
     if dist is not None:
@@ -337,6 +362,7 @@ def main():
     roofline = dict(kernels[dominant], kernel=dominant) if dominant else None
 
     fwd_rate, fwd_ms = forward_only_rate(model, loop, dev)
+    log(f"forward-only {fwd_ms:.3f} ms")
     out = {
         "metric": "rays*samples/s, full optimisation iteration (sample placement -> hash grid -> decoder -> SDF "
                   "render -> losses -> backward -> pose+map Adam), 4096 rays x 64 samples, 640x480 RGB-D",
@@ -353,6 +379,7 @@ def main():
     }
     if not args.no_frame_estimate:
         out["frame"] = frame_estimate(cfg, model, loop, dev, ms_step)
+        log("frame estimate done")
     if world == 1 and args.cpu_rays > 0:
         out["cpu_baseline"] = cpu_baseline(cfg, loop, args.cpu_rays, args.cpu_iters)
     print(json.dumps(out), flush=True)
