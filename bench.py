@@ -62,10 +62,18 @@ def log(msg):
 
 
 def usable_cores():
+    """CPU threads this process may really use: min(affinity mask, cgroup CPU quota)."""
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def parse():
@@ -74,8 +82,8 @@ def parse():
     p.add_argument("--steps", type=int, default=30)
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--setup-iters", type=int, default=50, help="untimed mapping iterations so the SDF has sign changes")
-    p.add_argument("--cpu-rays", type=int, default=1024, help="rays of the bounded CPU-baseline sample (0 = skip)")
-    p.add_argument("--cpu-iters", type=int, default=3)
+    p.add_argument("--cpu-rays", type=int, default=4096, help="rays of the bounded CPU-baseline sample (0 = skip)")
+    p.add_argument("--cpu-iters", type=int, default=4)
     p.add_argument("--no-frame-estimate", action="store_true")
     return p.parse_args()
 
