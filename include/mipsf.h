@@ -65,9 +65,11 @@ int mipsf_hashgrid_meta_init(mipsf_grid_meta* meta_host, uint32_t n_levels, uint
 /* x: [M,3] fp32 already normalised (scene_rep.py:140-142 + :119); params: [n_params]; out: [M,L*F]. */
 int mipsf_hashgrid_fwd(const float* x, const float* params, float* out, uint32_t M,
                        const mipsf_grid_meta* meta_host, int layout, void* stream);
-/* dparams += scatter (fp32 atomics; caller zeroes or accumulates); dx (nullable) += dL/dx [M,3]. */
+/* dparams += scatter of dL/dout (accumulated on chip in LDS slices, see hashgrid.hip); dx (nullable) += dL/dx [M,3].
+ * scratch: mipsf_hashgrid_bwd_scratch_floats(meta, M, dx != NULL) floats owned by the caller. */
+uint64_t mipsf_hashgrid_bwd_scratch_floats(const mipsf_grid_meta* meta_host, uint32_t M, int need_dx);
 int mipsf_hashgrid_bwd(const float* x, const float* params, const float* dout, float* dparams, float* dx,
-                       uint32_t M, const mipsf_grid_meta* meta_host, int layout, void* stream);
+                       float* scratch, uint32_t M, const mipsf_grid_meta* meta_host, int layout, void* stream);
 /* parity probe: idx[(i*L + level)*8 + corner] = entry index inside the level (uint32). */
 int mipsf_hashgrid_indices(const float* x, uint32_t* idx, uint32_t M, const mipsf_grid_meta* meta_host,
                            void* stream);

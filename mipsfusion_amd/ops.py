@@ -70,8 +70,11 @@ def hashgrid_fwd(x: torch.Tensor, params: torch.Tensor, meta, layout=FEAT_AOS) -
 
 def hashgrid_bwd(x, params, dout, dparams, meta, layout=FEAT_AOS, dx: Optional[torch.Tensor] = None):
     """dparams (and dx when given) are accumulated into."""
+    M = x.shape[0]
+    n = lib().mipsf_hashgrid_bwd_scratch_floats(C.byref(meta), M, 1 if dx is not None else 0)
+    scratch = torch.empty(n, dtype=torch.float32, device=x.device)
     with _timed("hashgrid_bwd"):
-        check(lib().mipsf_hashgrid_bwd(dptr(x), dptr(params), dptr(dout), dptr(dparams), dptr(dx), x.shape[0],
+        check(lib().mipsf_hashgrid_bwd(dptr(x), dptr(params), dptr(dout), dptr(dparams), dptr(dx), dptr(scratch), M,
                                        C.byref(meta), layout, stream_ptr()), "hashgrid_bwd")
 
 
