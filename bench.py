@@ -85,6 +85,8 @@ def parse():
     p.add_argument("--cpu-rays", type=int, default=4096, help="rays of the bounded CPU-baseline sample (0 = skip)")
     p.add_argument("--cpu-iters", type=int, default=4)
     p.add_argument("--no-frame-estimate", action="store_true")
+    p.add_argument("--torch-pose", action="store_true",
+                   help="build rays with the reference's eager torch ops (mipsfusion.py:320-322) instead of the fused op")
     return p.parse_args()
 
 
@@ -138,8 +140,8 @@ def sample_pool(cfg, frames, n_batches):
 class MappingLoop:
     """The local-BA iteration of mipsfusion.py:293-342 against our JointEncoding."""
 
-    def __init__(self, cfg, model, poses, pool, dev):
-        self.cfg, self.model, self.dev = cfg, model, dev
+    def __init__(self, cfg, model, poses, pool, dev, torch_pose=False):
+        self.cfg, self.model, self.dev, self.torch_pose = cfg, model, dev, torch_pose
         self.map_opt = FusedAdam([{"params": model.decoder.parameters(), "weight_decay": 1e-6, "lr": cfg["mapping"]["lr_decoder"]},
                                   {"params": model.embed_fn.parameters(), "eps": 1e-15, "lr": cfg["mapping"]["lr_embed"]}],
                                  betas=(0.9, 0.99))
@@ -151,34 +153,39 @@ class MappingLoop:
                                           {"params": self.cur_trans, "lr": cfg["mapping"]["lr_trans"]}])
         self.poses_all = torch.cat([self.pose_fixed, qt_to_transform_matrix(self.cur_rot, self.cur_trans)], 0)
         self.pool = [(r.to(dev), o.to(dev)) for r, o in pool]
+        self.pool = [(r, o, r[:, :3].contiguous(), r[:, 3:6].contiguous(), r[:, 6:7].contiguous()) for r, o in self.pool]
         self.noise = [torch.rand(N_RAYS, N_SAMPLES, device=dev) for _ in pool]
         self.i = 0
 
     def step(self):
         cfg = self.cfg
-        rays, owner = self.pool[self.i % len(self.pool)]
+        rays, owner, rays_d_cam, target_s, target_d = self.pool[self.i % len(self.pool)]
         noise = self.noise[self.i % len(self.pool)]
-        rays_d_cam, target_s, target_d = rays[:, :3], rays[:, 3:6], rays[:, 6:7]
-        rays_d = torch.sum(rays_d_cam[..., None, :] * self.poses_all[owner, :3, :3], -1)
-        rays_o = self.poses_all[owner, :3, -1]
+        if self.torch_pose:
+            rays_d = torch.sum(rays_d_cam[..., None, :] * self.poses_all[owner, :3, :3], -1)
+            rays_o = self.poses_all[owner, :3, -1]
+        else:   # same arithmetic, one kernel each way (gradients reach cur_rot / cur_trans through autograd)
+            rays_o, rays_d = ops.pose_rays(self.cur_rot, self.cur_trans, self.pose_fixed, owner, rays_d_cam)
         ret = self.model.forward(rays_o, rays_d, target_s, target_d, noise=noise)
         loss = get_loss_from_ret(ret, cfg["training"])
-        loss.backward(retain_graph=True)
+        loss.backward(retain_graph=self.torch_pose)
         self.i += 1
         if self.i % cfg["mapping"]["map_accum_step"] == 0:
             self.map_opt.step(zero_grad=True)           # step + zero_grad (mipsfusion.py:330-335) in one pass
         if self.i % cfg["mapping"]["pose_accum_step"] == 0:
             self.pose_opt.step()
-            self.poses_all = torch.cat([self.pose_fixed, qt_to_transform_matrix(self.cur_rot, self.cur_trans)], 0)
+            if self.torch_pose:
+                self.poses_all = torch.cat([self.pose_fixed, qt_to_transform_matrix(self.cur_rot, self.cur_trans)], 0)
             self.pose_opt.zero_grad()
         return loss
 
 
 def forward_only_rate(model, loop, dev, iters=10):
-    rays, owner = loop.pool[0]
+    rays, owner = loop.pool[0][:2]
+    poses_now = torch.cat([loop.pose_fixed, qt_to_transform_matrix(loop.cur_rot, loop.cur_trans)], 0).detach()
     with torch.no_grad():
-        rays_d = torch.sum(rays[:, :3][..., None, :] * loop.poses_all[owner, :3, :3], -1).contiguous()
-        rays_o = loop.poses_all[owner, :3, -1].contiguous()
+        rays_d = torch.sum(rays[:, :3][..., None, :] * poses_now[owner, :3, :3], -1).contiguous()
+        rays_o = poses_now[owner, :3, -1].contiguous()
         model.eval()
         for _ in range(3):
             model.forward(rays_o, rays_d, None, rays[:, 6:7], noise=loop.noise[0])
@@ -211,8 +218,7 @@ def frame_estimate(cfg, model, loop, dev, ba_ms):
         ro_ms = (time.perf_counter() - t0) / 5 * 1e3
     # GO: tracking.sample rays, pose-only Adam on one pose
     ns = cfg["tracking"]["sample"]
-    rays, _ = loop.pool[0]
-    rays = rays[:ns]
+    rays = loop.pool[0][0][:ns]
     rot = torch.nn.Parameter(loop.cur_rot.detach()[-1:].clone())
     trans = torch.nn.Parameter(loop.cur_trans.detach()[-1:].clone())
     popt = torch.optim.Adam([{"params": rot, "lr": 1e-3}, {"params": trans, "lr": 1e-3}])
@@ -250,9 +256,9 @@ def cpu_baseline(cfg, loop, n_rays, iters):
     cpu.load_state_dict({k: v.cpu() for k, v in loop.model.state_dict().items()})
     opt = torch.optim.Adam([{"params": cpu.decoder.parameters(), "weight_decay": 1e-6, "lr": 0.01},
                             {"params": cpu.embed_fn.parameters(), "eps": 1e-15, "lr": 0.01}], betas=(0.9, 0.99))
-    rays, owner = loop.pool[0]
+    rays, owner = loop.pool[0][:2]
     rays, owner = rays[:n_rays].cpu(), owner[:n_rays].cpu()
-    poses = loop.poses_all.detach().cpu()
+    poses = torch.cat([loop.pose_fixed, qt_to_transform_matrix(loop.cur_rot, loop.cur_trans)], 0).detach().cpu()
     noise = loop.noise[0][:n_rays].cpu()
     rays_d = torch.sum(rays[:, :3][..., None, :] * poses[owner, :3, :3], -1)
     rays_o = poses[owner, :3, -1]
@@ -301,7 +307,7 @@ def main():
     log(f"rank {rank}/{world} on {torch.cuda.get_device_name(local)}; building submap")
     model, frames, poses = build_submap(cfg, dev, seed=rank)
     pool = sample_pool(cfg, frames, n_batches=8)
-    loop = MappingLoop(cfg, model, poses, pool, dev)
+    loop = MappingLoop(cfg, model, poses, pool, dev, torch_pose=args.torch_pose)
     log("setup iterations")
     for _ in range(args.setup_iters):
         loop.step()
@@ -381,7 +387,8 @@ def main():
                                "4096 rays x 64 samples (43 uniform + 21 depth-guided), hash grid 2^19 x 16 levels x 2, "
                                "620x460 synthetic RGB-D (640x480 cropped by 10)",
                    "rays": N_RAYS, "samples_per_ray": N_SAMPLES, "hash_size": cfg["grid"]["hash_size"],
-                   "parallelism": f"submap-per-gpu x{world}" if world > 1 else "single gpu"},
+                   "parallelism": f"submap-per-gpu x{world}" if world > 1 else "single gpu",
+                   "ray_build": "torch eager ops" if args.torch_pose else "fused pose_rays kernel"},
         "forward_only": {"value": round(fwd_rate, 1), "unit": "rays*samples/s", "ms": round(fwd_ms, 4)},
         "roofline": roofline, "kernels": kernels,
     }

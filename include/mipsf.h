@@ -18,6 +18,7 @@
  *                                                         model/scene_rep.py:58-103, 211-236;
  *                                                         helper_functions/utils.py:21-111
  *   mipsf_rays_bwd        autograd of pts = o + d*z and of the fp64 normalisation
+ *   mipsf_pose_rays_*     per-ray pose gather + R*d     mipsfusion.py:320-322, 531-532; geometry_helper.py:11-17
  *   mipsf_adam_step       torch.optim.Adam.step           mipsfusion.py:580-584, 190, 330-335
  *   mipsf_ro_fitness      RandomOptimizer.get_fitness     RandomOptimizer.py:113-131
  */
@@ -151,8 +152,8 @@ typedef struct mipsf_render_cfg {
 /* z_uniform [n_uniform], z_near_offsets [n_near], z_near_nodepth [n_near]: the three torch.linspace tables
  * (computed once on the host by torch so that placement is bit-identical).  target_d nullable (then
  * n_near must be 0).  noise [N,S] U[0,1) (nullable when !perturb).  Outputs: z_vals [N,S]; xn [N*S,3]
- * normalised fp32 coordinates; counts[2] (uint32, zeroed by the caller) += {#front, #band} of
- * helper_functions/utils.py:33-44 (only when target_d != NULL). */
+ * normalised fp32 coordinates; counts[N,2] (uint32, written) = per-ray {#front, #band} of
+ * helper_functions/utils.py:33-44 (only when target_d != NULL); mipsf_render_fwd sums them. */
 int mipsf_sample_rays(const float* rays_o, const float* rays_d, const float* target_d, const float* noise,
                       const float* z_uniform, const float* z_near_offsets, const float* z_near_nodepth,
                       const mipsf_render_cfg* cfg_host, float* z_vals, float* xn, uint32_t* counts,
@@ -163,7 +164,7 @@ int mipsf_normalise_points(const float* pts, const mipsf_render_cfg* cfg_host, f
 
 /* ------------------------------------------------ compositing + losses (a8, a9) */
 /* raw [N,S,10], z_vals [N,S] -> per-ray rgb[N,3], depth, depth_var, disp, acc [N], weights [N,S] (nullable).
- * When `losses` != NULL (training): target_rgb [N,3], target_d [N,1], counts[2] from mipsf_sample_rays;
+ * When `losses` != NULL (training): target_rgb [N,3], target_d [N,1], counts[N,2] from mipsf_sample_rays;
  * losses[8] = {rgb_loss, depth_loss, sdf_loss, fs_loss, psnr, fs_weight, sdf_weight, n_valid_depth};
  * partial: scratch [N*8]. */
 int mipsf_render_fwd(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
@@ -183,12 +184,37 @@ int mipsf_rays_bwd(const float* dxn, const float* z_vals, const mipsf_render_cfg
 int mipsf_normalise_bwd(const float* dxn, const mipsf_render_cfg* cfg_host, float* dpts, uint32_t M,
                         void* stream);
 
+/* ---------------------------------------------------- rays from poses (a2) */
+/* poses_all = [fixed_poses (F x 4x4 row-major) | K optimisable poses given as quaternion (w,x,y,z) + translation];
+ * owner[n] indexes poses_all (negative = from the end, as mipsfusion.py:315 does with -1);
+ * rays_d[n] = R[owner[n]] * d_cam[n], rays_o[n] = t[owner[n]]   (mipsfusion.py:320-322, geometry_helper.py:11-17). */
+int mipsf_pose_rays_fwd(const float* fixed_poses, const float* rot, const float* trans, uint32_t F, uint32_t K,
+                        const int64_t* owner, const float* d_cam, float* rays_o, float* rays_d, uint32_t N,
+                        void* stream);
+/* d_rot [K,4], d_trans [K,3] are WRITTEN; scratch: 12*(F+K) floats. */
+int mipsf_pose_rays_bwd(const float* g_rays_o, const float* g_rays_d, const float* rot, uint32_t F, uint32_t K,
+                        const int64_t* owner, const float* d_cam, float* d_rot, float* d_trans, float* scratch,
+                        uint32_t N, void* stream);
+
 /* ------------------------------------------------------------------- Adam (a11) */
 /* One dense torch.optim.Adam step over n floats.  step = 1-based count after increment.
  * zero_grad != 0 clears grad in the same pass. */
 int mipsf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr,
                     float beta1, float beta2, float eps, float weight_decay, uint32_t step, int zero_grad,
                     void* stream);
+
+/* the same step over up to 16 small tensors that share one param group (one launch; used for the decoder) */
+#define MIPSF_ADAM_MAX_TENSORS 16
+typedef struct mipsf_adam_tensors {
+    uint32_t count;
+    float* param[MIPSF_ADAM_MAX_TENSORS];
+    float* grad[MIPSF_ADAM_MAX_TENSORS];
+    float* exp_avg[MIPSF_ADAM_MAX_TENSORS];
+    float* exp_avg_sq[MIPSF_ADAM_MAX_TENSORS];
+    uint64_t numel[MIPSF_ADAM_MAX_TENSORS];
+} mipsf_adam_tensors;
+int mipsf_adam_step_multi(const mipsf_adam_tensors* tensors_host_struct, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, uint32_t step, int zero_grad, void* stream);
 
 /* -------------------------------------------------- RandomOptimizer fitness (a12) */
 /* sdf [P,n] (column 3 of run_network output, stride `sdf_stride` floats) , valid [n] ->

@@ -40,6 +40,15 @@ class RenderCfg(C.Structure):
                 ("depth_trunc", C.c_float), ("rgb_missing_nonzero", C.c_int), ("emd_w", C.c_float)]
 
 
+ADAM_MAX_TENSORS = 16
+
+
+class AdamTensors(C.Structure):
+    _fields_ = [("count", C.c_uint32), ("param", C.c_void_p * ADAM_MAX_TENSORS), ("grad", C.c_void_p * ADAM_MAX_TENSORS),
+                ("exp_avg", C.c_void_p * ADAM_MAX_TENSORS), ("exp_avg_sq", C.c_void_p * ADAM_MAX_TENSORS),
+                ("numel", C.c_uint64 * ADAM_MAX_TENSORS)]
+
+
 _P = C.c_void_p
 _U32, _U64, _I, _F, _D = C.c_uint32, C.c_uint64, C.c_int, C.c_float, C.c_double
 
@@ -73,7 +82,10 @@ SIGNATURES = {
     "mipsf_render_bwd": (_I, [_P, _P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _U32, _U32, _P]),
     "mipsf_rays_bwd": (_I, [_P, _P, C.POINTER(RenderCfg), _P, _P, _U32, _U32, _P]),
     "mipsf_normalise_bwd": (_I, [_P, C.POINTER(RenderCfg), _P, _U32, _P]),
+    "mipsf_pose_rays_fwd": (_I, [_P, _P, _P, _U32, _U32, _P, _P, _P, _P, _U32, _P]),
+    "mipsf_pose_rays_bwd": (_I, [_P, _P, _P, _U32, _U32, _P, _P, _P, _P, _P, _U32, _P]),
     "mipsf_adam_step": (_I, [_P, _P, _P, _P, _U64, _F, _F, _F, _F, _F, _U32, _I, _P]),
+    "mipsf_adam_step_multi": (_I, [C.POINTER(AdamTensors), _F, _F, _F, _F, _F, _U32, _I, _P]),
     "mipsf_ro_fitness": (_I, [_P, _U32, _P, _F, _P, _U32, _U32, _P]),
 }
 

@@ -34,11 +34,17 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
 template <int RT, int T, typename BFn>
 __device__ __forceinline__ void mfma_layer(const float4* __restrict__ img, int lane, f32x16 (&acc)[RT], BFn bfn) {
     constexpr int T4 = T / 4;
+    // the A operands of group t4+1 are requested before the 4*RT MFMAs of group t4 issue, so an L2 round trip
+    // (~500-900 cycles) hides under 4*RT*64 cycles of matrix work instead of stalling in front of it
+    float4 a[RT], nxt[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a[rt] = img[(rt * T4) * 64 + lane];
 #pragma unroll
     for (int t4 = 0; t4 < T4; ++t4) {
-        float4 a[RT];
+        if (t4 + 1 < T4) {
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) a[rt] = img[(rt * T4 + t4) * 64 + lane];
+            for (int rt = 0; rt < RT; ++rt) nxt[rt] = img[(rt * T4 + t4 + 1) * 64 + lane];
+        }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma(a[rt].x, bfn(t4 * 4 + 0), acc[rt]);
 #pragma unroll
@@ -47,6 +53,10 @@ __device__ __forceinline__ void mfma_layer(const float4* __restrict__ img, int l
         for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma(a[rt].z, bfn(t4 * 4 + 2), acc[rt]);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma(a[rt].w, bfn(t4 * 4 + 3), acc[rt]);
+        if (t4 + 1 < T4) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) a[rt] = nxt[rt];
+        }
     }
 }
 
@@ -561,17 +571,26 @@ struct GradPtrs {
     float* p[10];   // order of the G_* record: w_pts0 b_pts0 w_pts2 b_pts2 w_rgb0 b_rgb0 w_sdf0 b_sdf0 w_sdf2 b_sdf2
 };
 
+constexpr int WG_REDUCE_SLICES = 8;
 __global__ __launch_bounds__(256) void decoder_wgrad_reduce_kernel(const float* __restrict__ partial, uint32_t nrec,
                                                                    GradPtrs g) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= G_TOTAL) return;
-    float a = 0.f;
-    for (uint32_t b = 0; b < nrec; ++b) a += partial[(size_t)b * G_STRIDE + q];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;          // independent chains keep 4 loads in flight
+    uint32_t b = blockIdx.y;
+    for (; b + 3 * WG_REDUCE_SLICES < nrec; b += 4 * WG_REDUCE_SLICES) {
+        a0 += partial[(size_t)b * G_STRIDE + q];
+        a1 += partial[(size_t)(b + WG_REDUCE_SLICES) * G_STRIDE + q];
+        a2 += partial[(size_t)(b + 2 * WG_REDUCE_SLICES) * G_STRIDE + q];
+        a3 += partial[(size_t)(b + 3 * WG_REDUCE_SLICES) * G_STRIDE + q];
+    }
+    for (; b < nrec; b += WG_REDUCE_SLICES) a0 += partial[(size_t)b * G_STRIDE + q];
+    const float a = (a0 + a1) + (a2 + a3);
     const int bounds[11] = {G_W_PTS0, G_B_PTS0, G_W_PTS2, G_B_PTS2, G_W_RGB0, G_B_RGB0,
                             G_W_SDF0, G_B_SDF0, G_W_SDF2, G_B_SDF2, G_TOTAL};
 #pragma unroll
     for (int k = 0; k < 10; ++k)
-        if (q >= bounds[k] && q < bounds[k + 1]) g.p[k][q - bounds[k]] += a;
+        if (q >= bounds[k] && q < bounds[k + 1]) unsafeAtomicAdd(&g.p[k][q - bounds[k]], a);
 }
 
 __global__ __launch_bounds__(256) void decoder_pack_kernel(W w, float* __restrict__ packed) {
@@ -695,7 +714,7 @@ int mipsf_decoder_wgrad(const float* feat, int feat_layout, const float* x, cons
     else { if (feat_layout == MIPSF_FEAT_AOS) WG(false, MIPSF_FEAT_AOS); else WG(false, MIPSF_FEAT_LEVEL_MAJOR); }
 #undef WG
     if (int e = check_launch("decoder_wgrad")) return e;
-    hipLaunchKernelGGL(decoder_wgrad_reduce_kernel, dim3((G_TOTAL + 255) / 256), dim3(256), 0, s, partial, wg_blocks, g);
+    hipLaunchKernelGGL(decoder_wgrad_reduce_kernel, dim3((G_TOTAL + 255) / 256, WG_REDUCE_SLICES), dim3(256), 0, s, partial, wg_blocks, g);
     return check_launch("decoder_wgrad_reduce");
 }
 

@@ -104,6 +104,28 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     }
 }
 
+// one launch for a group of small tensors (the decoder's 10 nn.Linear tensors): blockIdx.y = tensor
+struct AdamMulti {
+    float* p[MIPSF_ADAM_MAX_TENSORS];
+    float* g[MIPSF_ADAM_MAX_TENSORS];
+    float* m[MIPSF_ADAM_MAX_TENSORS];
+    float* v[MIPSF_ADAM_MAX_TENSORS];
+    uint64_t n[MIPSF_ADAM_MAX_TENSORS];
+};
+
+template <bool ZERO>
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamMulti t, AdamK k) {
+    const int ti = blockIdx.y;
+    float *p = t.p[ti], *g = t.g[ti], *m = t.m[ti], *v = t.v[ti];
+    const uint64_t n = t.n[ti];
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        float pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+        adam1(pp, gg, mm, vv, k);
+        p[i] = pp, m[i] = mm, v[i] = vv;
+        if (ZERO) g[i] = 0.f;
+    }
+}
+
 // ------------------------------------------------------ RandomOptimizer.get_fitness (RandomOptimizer.py:125-129)
 // one wave per particle: mean_j( (d_j > 0) * |sdf_pj * trunc| )
 __global__ __launch_bounds__(256) void ro_fitness_kernel(const float* __restrict__ raw, uint32_t stride,
@@ -191,6 +213,41 @@ int mipsf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq
         hipLaunchKernelGGL(adam_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                            exp_avg_sq, n, k);
     return check_launch("adam_step");
+}
+
+int mipsf_adam_step_multi(const mipsf_adam_tensors* t, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, uint32_t step, int zero_grad, void* stream) {
+    MIPSF_REQUIRE(t != nullptr, "null tensor table");
+    if (t->count == 0) return 0;
+    MIPSF_REQUIRE(t->count <= MIPSF_ADAM_MAX_TENSORS, "too many tensors (%u)", t->count);
+    MIPSF_REQUIRE(step >= 1, "step must be >= 1");
+    AdamMulti a;
+    uint64_t nmax = 0;
+    for (uint32_t i = 0; i < MIPSF_ADAM_MAX_TENSORS; ++i) {
+        const bool live = i < t->count;
+        a.p[i] = live ? t->param[i] : nullptr, a.g[i] = live ? t->grad[i] : nullptr;
+        a.m[i] = live ? t->exp_avg[i] : nullptr, a.v[i] = live ? t->exp_avg_sq[i] : nullptr;
+        a.n[i] = live ? t->numel[i] : 0;
+        if (live) {
+            MIPSF_REQUIRE(a.p[i] && a.g[i] && a.m[i] && a.v[i], "null pointer in tensor %u", i);
+            nmax = a.n[i] > nmax ? a.n[i] : nmax;
+        }
+    }
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    AdamK k;
+    k.lr_over_bc1 = (float)((double)lr / bc1);
+    k.beta1 = beta1, k.beta2 = beta2;
+    k.one_minus_b1 = (float)(1.0 - (double)beta1), k.one_minus_b2 = (float)(1.0 - (double)beta2);
+    k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    k.eps = eps, k.wd = weight_decay;
+    uint64_t bx = (nmax + 255) / 256;
+    if (bx > 64) bx = 64;
+    if (bx < 1) bx = 1;
+    const dim3 grid((uint32_t)bx, t->count);
+    if (zero_grad) hipLaunchKernelGGL(adam_multi_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a, k);
+    else hipLaunchKernelGGL(adam_multi_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a, k);
+    return check_launch("adam_step_multi");
 }
 
 int mipsf_ro_fitness(const float* raw, uint32_t raw_stride, const float* target_d, float trunc, float* mean_masked,

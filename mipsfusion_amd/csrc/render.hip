@@ -29,33 +29,45 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void sample_rays_kerne
     const float* __restrict__ z_near_nodepth, PlaceCfg pc, NormCfg nc, float* __restrict__ z_vals,
     float* __restrict__ xn, uint32_t* __restrict__ counts, uint32_t N) {
     __shared__ float zs[RAYS_PER_BLOCK][MAX_S];
+    __shared__ float sb[RAYS_PER_BLOCK][MAX_S];   // this ray's depth-guided list
+    __shared__ float sa[MAX_S];                   // the uniform list (shared by the block's rays)
     const uint32_t w = threadIdx.x / MIPSF_WAVE, lane = threadIdx.x & (MIPSF_WAVE - 1);
     const uint32_t n = blockIdx.x * RAYS_PER_BLOCK + w;
-    if (n >= N) return;   // whole wave exits together; no block-level barrier is used below
     const uint32_t nu = pc.n_uniform, nn = pc.n_near, S = nu + nn;
+    for (uint32_t e = threadIdx.x; e < nu; e += RAYS_PER_BLOCK * MIPSF_WAVE) sa[e] = z_uniform[e];
+    __syncthreads();
+    if (n >= N) return;   // whole wave exits together; no block-level barrier is used below
     const float d = target_d ? target_d[n] : 0.f;
     const bool has_depth = d > 0.f;   // rows with d <= 0 fall back to linspace(near, far) (scene_rep.py:160)
     float* row = zs[w];
+    float* rb = sb[w];
+    for (uint32_t j = lane; j < nn; j += MIPSF_WAVE) rb[j] = has_depth ? z_near_off[j] + d : z_near_nodepth[j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+    // merge by rank, ranks by binary search in the other (sorted) list
     for (uint32_t e = lane; e < S; e += MIPSF_WAVE) {
         float val;
-        uint32_t slot;
+        uint32_t lo = 0, hi;
         if (e < nu) {
-            val = z_uniform[e];
-            uint32_t c = 0;
-            for (uint32_t j = 0; j < nn; ++j) {
-                const float b = has_depth ? z_near_off[j] + d : z_near_nodepth[j];
-                c += (b < val) ? 1u : 0u;
+            val = sa[e];
+            hi = nn;                      // #{b : b < val}
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (rb[mid] < val) lo = mid + 1; else hi = mid;
             }
-            slot = e + c;
+            row[e + lo] = val;
         } else {
             const uint32_t j = e - nu;
-            val = has_depth ? z_near_off[j] + d : z_near_nodepth[j];
-            uint32_t c = 0;
-            for (uint32_t i = 0; i < nu; ++i) c += (z_uniform[i] <= val) ? 1u : 0u;
-            slot = j + c;
+            val = rb[j];
+            hi = nu;                      // #{a : a <= val}
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (sa[mid] <= val) lo = mid + 1; else hi = mid;
+            }
+            row[j + lo] = val;
         }
-        row[slot] = val;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -85,10 +97,12 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void sample_rays_kerne
         }
     }
     if (target_d && counts) {
+        // per-ray counts (summed by loss_finalize): two global atomics per ray on two shared words serialise at
+        // ~12 ns each -- 100 us for 4096 rays -- so nothing is accumulated here
         const float f = wave_sum((float)n_front), b = wave_sum((float)n_band);   // <= 256 each: exact in fp32
         if (lane == 0) {
-            atomicAdd(&counts[0], (uint32_t)f);
-            atomicAdd(&counts[1], (uint32_t)b);
+            counts[2 * n] = (uint32_t)f;
+            counts[2 * n + 1] = (uint32_t)b;
         }
     }
 }
@@ -233,25 +247,27 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void render_fwd_kernel
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ partial,
                                                             const uint32_t* __restrict__ counts, float emd_w,
                                                             float* __restrict__ losses, uint32_t N, uint32_t S) {
-    __shared__ double red[4][7];
-    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    __shared__ double red[4][9];
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t n = threadIdx.x; n < N; n += 256) {
 #pragma unroll
         for (int j = 0; j < 7; ++j) acc[j] += (double)partial[(size_t)n * 8 + j];
+        acc[7] += (double)counts[2 * n];          // integers < 2^53: exact
+        acc[8] += (double)counts[2 * n + 1];
     }
 #pragma unroll
-    for (int j = 0; j < 7; ++j) acc[j] = wave_sum_d(acc[j]);
+    for (int j = 0; j < 9; ++j) acc[j] = wave_sum_d(acc[j]);
     const uint32_t w = threadIdx.x / MIPSF_WAVE, lane = threadIdx.x & (MIPSF_WAVE - 1);
     if (lane == 0) {
 #pragma unroll
-        for (int j = 0; j < 7; ++j) red[w][j] = acc[j];
+        for (int j = 0; j < 9; ++j) red[w][j] = acc[j];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double t[7];
-        for (int j = 0; j < 7; ++j) t[j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+        double t[9];
+        for (int j = 0; j < 9; ++j) t[j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
         const double NS = (double)N * (double)S;
-        const float n_front = (float)counts[0], n_band = (float)counts[1];
+        const float n_front = (float)t[7], n_band = (float)t[8];
         const float total = n_front + n_band;
         const float fs_w = 1.0f - n_front / total;     // 0/0 -> NaN exactly like the reference
         const float sdf_w = 1.0f - n_band / total;

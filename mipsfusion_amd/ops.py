@@ -242,7 +242,7 @@ def sample_rays(rays_o, rays_d, target_d, noise, tables, rc, N, S):
     dev = rays_o.device
     z_vals = torch.empty((N, S), dtype=torch.float32, device=dev)
     xn = torch.empty((N * S, 3), dtype=torch.float32, device=dev)
-    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    counts = torch.empty((N, 2), dtype=torch.int32, device=dev)
     zu, zoff, znd = tables
     with _timed("sample_rays"):
         check(lib().mipsf_sample_rays(dptr(rays_o), dptr(rays_d), dptr(target_d), dptr(noise), dptr(zu), dptr(zoff),
@@ -285,11 +285,67 @@ def rays_bwd(dxn, z_vals, rc, N, S):
     return d_o, d_d
 
 
+# ------------------------------------------------------------------------- rays from poses
+class PoseRaysFn(torch.autograd.Function):
+    """(rot [K,4], trans [K,3]) -> rays_o, rays_d [N,3]; fused replacement of
+    ``qt_to_transform_matrix`` + ``poses_all[owner]`` gather + ``sum(d_cam * R, -1)`` (mipsfusion.py:320-322)."""
+
+    @staticmethod
+    def forward(ctx, rot, trans, fixed, owner, d_cam):
+        rot, trans, d_cam = _f32c(rot), _f32c(trans), _f32c(d_cam)
+        fixed = _f32c(fixed) if fixed is not None and fixed.numel() else None
+        owner = owner.to(torch.int64).contiguous()
+        F = 0 if fixed is None else fixed.shape[0]
+        K, N = rot.shape[0], d_cam.shape[0]
+        rays_o = torch.empty((N, 3), dtype=torch.float32, device=d_cam.device)
+        rays_d = torch.empty((N, 3), dtype=torch.float32, device=d_cam.device)
+        with _timed("pose_rays_fwd"):
+            check(lib().mipsf_pose_rays_fwd(dptr(fixed), dptr(rot), dptr(trans), F, K, dptr(owner, torch.int64),
+                                            dptr(d_cam), dptr(rays_o), dptr(rays_d), N, stream_ptr()), "pose_rays_fwd")
+        ctx.F, ctx.K, ctx.N = F, K, N
+        ctx.save_for_backward(rot, owner, d_cam)
+        return rays_o, rays_d
+
+    @staticmethod
+    def backward(ctx, g_o, g_d):
+        rot, owner, d_cam = ctx.saved_tensors
+        d_rot = torch.empty((ctx.K, 4), dtype=torch.float32, device=rot.device)
+        d_trans = torch.empty((ctx.K, 3), dtype=torch.float32, device=rot.device)
+        scratch = torch.empty(12 * (ctx.F + ctx.K), dtype=torch.float32, device=rot.device)
+        g_o = _f32c(g_o) if g_o is not None else None
+        g_d = _f32c(g_d) if g_d is not None else None
+        with _timed("pose_rays_bwd"):
+            check(lib().mipsf_pose_rays_bwd(dptr(g_o), dptr(g_d), dptr(rot), ctx.F, ctx.K, dptr(owner, torch.int64),
+                                            dptr(d_cam), dptr(d_rot), dptr(d_trans), dptr(scratch), ctx.N,
+                                            stream_ptr()), "pose_rays_bwd")
+        return d_rot, d_trans, None, None, None
+
+
+def pose_rays(rot, trans, fixed_poses, owner, d_cam):
+    """rays_o, rays_d for rays whose camera pose is poses_all[owner] with
+    poses_all = cat([fixed_poses, qt_to_transform_matrix(rot, trans)])."""
+    return PoseRaysFn.apply(rot, trans, fixed_poses, owner, d_cam)
+
+
 # ----------------------------------------------------------------------------------- Adam
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, zero_grad=False):
     with _timed("adam_step" if param.numel() > (1 << 20) else "adam_step_small"):
         check(lib().mipsf_adam_step(dptr(param), dptr(grad), dptr(exp_avg), dptr(exp_avg_sq), param.numel(), lr, beta1,
                                     beta2, eps, weight_decay, step, 1 if zero_grad else 0, stream_ptr()), "adam_step")
+
+
+def adam_step_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, weight_decay, step, zero_grad=False):
+    """One launch for a group of (small) tensors sharing hyper-parameters and step count."""
+    for i in range(0, len(params), _lib.ADAM_MAX_TENSORS):
+        chunk = slice(i, i + _lib.ADAM_MAX_TENSORS)
+        t = _lib.AdamTensors()
+        t.count = len(params[chunk])
+        for j, (p, g, m, v) in enumerate(zip(params[chunk], grads[chunk], exp_avgs[chunk], exp_avg_sqs[chunk])):
+            t.param[j], t.grad[j], t.exp_avg[j], t.exp_avg_sq[j] = dptr(p), dptr(g), dptr(m), dptr(v)
+            t.numel[j] = p.numel()
+        with _timed("adam_step_small"):
+            check(lib().mipsf_adam_step_multi(C.byref(t), lr, beta1, beta2, eps, weight_decay, step,
+                                              1 if zero_grad else 0, stream_ptr()), "adam_step_multi")
 
 
 def ro_fitness(raw, target_d, trunc: float) -> torch.Tensor:

@@ -21,6 +21,7 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            small = []
             for p in group["params"]:
                 if p.grad is None or p.numel() == 0:
                     continue
@@ -32,6 +33,17 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
+                if p.numel() < (1 << 18):
+                    small.append(p)
+                    continue
                 ops.adam_step(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"],
                               group["weight_decay"], st["step"], zero_grad)
+            # small tensors of a group (the decoder's ten nn.Linear tensors) share one launch per step count
+            by_step = {}
+            for p in small:
+                by_step.setdefault(self.state[p]["step"], []).append(p)
+            for step, ps in by_step.items():
+                ops.adam_step_multi([p.data for p in ps], [p.grad for p in ps],
+                                    [self.state[p]["exp_avg"] for p in ps], [self.state[p]["exp_avg_sq"] for p in ps],
+                                    group["lr"], b1, b2, group["eps"], group["weight_decay"], step, zero_grad)
         return loss

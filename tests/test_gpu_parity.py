@@ -333,6 +333,62 @@ def test_fused_adam_odd_sizes_vs_torch(dev):
         np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=2e-5, atol=1e-8)
 
 
+def test_fused_adam_multi_tensor_group_vs_torch(dev):
+    """The decoder's ten small tensors go through ONE launch; compare with torch.optim.Adam (weight decay on)."""
+    torch.manual_seed(2)
+    shapes = [(128, 51), (128,), (128, 128), (128,), (3, 115), (3,), (128, 96), (128,), (5, 128), (5,)]
+    ps = [torch.randn(*s) * 0.1 for s in shapes]
+    a = [torch.nn.Parameter(p.clone().to(dev)) for p in ps]
+    b = [torch.nn.Parameter(p.clone()) for p in ps]
+    oa = FusedAdam([{"params": a, "weight_decay": 1e-6, "lr": 0.01}], betas=(0.9, 0.99))
+    ob = torch.optim.Adam([{"params": b, "weight_decay": 1e-6, "lr": 0.01}], betas=(0.9, 0.99))
+    for _ in range(4):
+        for x, y in zip(a, b):
+            g = torch.randn_like(y) * 0.01
+            x.grad, y.grad = g.clone().to(dev), g
+        oa.step(), ob.step()
+    for x, y in zip(a, b):
+        np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().numpy(), rtol=2e-5, atol=1e-8)
+
+
+def test_pose_rays_matches_torch_composition(dev):
+    """Fused ray building == qt_to_transform_matrix + gather + sum(d_cam * R, -1) (mipsfusion.py:320-322), values
+    and gradients wrt quaternion / translation; includes python-style negative owner indices and mixed waves."""
+    from mipsfusion_amd.helper_functions.geometry_helper import qt_to_transform_matrix
+    g = load_golden("quaternion.npz")
+    torch.manual_seed(4)
+    N, F, K = 1000, 2, 9
+    rot0, trans0 = T(g["rot"]).to(dev), T(g["trans"]).to(dev)
+    fixed = qt_to_transform_matrix(torch.randn(F, 4, device=dev), torch.randn(F, 3, device=dev))
+    owner = torch.randint(-(F + K), F + K, (N,), device=dev)
+    owner[:300] = 3                                    # uniform waves take the shuffle path
+    d_cam = torch.randn(N, 3, device=dev)
+    go, gd = torch.randn(N, 3, device=dev), torch.randn(N, 3, device=dev)
+    rot_a, trans_a = rot0.clone().requires_grad_(True), trans0.clone().requires_grad_(True)
+    ro, rd = ops.pose_rays(rot_a, trans_a, fixed, owner, d_cam)
+    (ro * go).sum().add((rd * gd).sum()).backward()
+    rot_b, trans_b = rot0.clone().requires_grad_(True), trans0.clone().requires_grad_(True)
+    poses = torch.cat([fixed, qt_to_transform_matrix(rot_b, trans_b)], 0)
+    rd_ref = torch.sum(d_cam[..., None, :] * poses[owner, :3, :3], -1)
+    ro_ref = poses[owner, :3, -1]
+    (ro_ref * go).sum().add((rd_ref * gd).sum()).backward()
+    assert_close(ro, ro_ref, 1e-6, "rays_o")
+    assert_close(rd, rd_ref, 1e-6, "rays_d")
+    assert_close(rot_a.grad, rot_b.grad, 2e-5, "d quaternion")
+    assert_close(trans_a.grad, trans_b.grad, 2e-5, "d translation")
+    # and the chain alone against the reference's own autograd (golden)
+    rot_c, trans_c = T(g["rot"]).to(dev).requires_grad_(True), T(g["trans"]).to(dev).requires_grad_(True)
+    eye = torch.eye(3, device=dev)
+    own = torch.arange(9, device=dev).repeat_interleave(3)
+    ro3, rd3 = ops.pose_rays(rot_c, trans_c, None, own, eye.repeat(9, 1))      # rd rows = columns of R
+    R = rd3.reshape(9, 3, 3).transpose(1, 2)
+    assert_close(R, g["T"][:, :3, :3], 1e-6, "R from quaternion")
+    gT = T(g["gT"]).to(dev)
+    ((R * gT[:, :3, :3]).sum() + (ro3.reshape(9, 3, 3)[:, 0] * gT[:, :3, 3]).sum()).backward()
+    assert_close(rot_c.grad, g["d_rot"], 2e-5, "d_rot vs reference autograd")
+    assert_close(trans_c.grad, g["d_trans"], 2e-5, "d_trans vs reference autograd")
+
+
 # ---------------------------------------------------------------------- optimisation loop
 def test_ba_loop_trace_matches_reference(dev):
     """6 iterations of the mapping loop (mipsfusion.py:293-342) with pose + map optimisation: loss trace and final
