@@ -28,6 +28,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from mipsfusion_amd import dist as mdist  # noqa: E402
 from mipsfusion_amd import ops, synth  # noqa: E402
 from mipsfusion_amd.helper_functions import sampling_helper as sh  # noqa: E402
 from mipsfusion_amd.helper_functions.geometry_helper import matrix_to_quaternion, qt_to_transform_matrix  # noqa: E402
@@ -295,13 +296,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    backend = os.environ.get("MIPSF_BENCH_BACKEND", "nccl")      # "gloo" only to debug N>1 on a single GPU
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg = synth.config_headline()
     log(f"rank {rank}/{world} on {torch.cuda.get_device_name(local)}; building submap")
@@ -315,11 +322,8 @@ def main():
     log("setup done")
 
     def exchange_poses():
-        # after each BA round every submap publishes its optimised keyframe poses
-        if dist is not None:
-            mine = torch.cat([loop.cur_rot.detach(), loop.cur_trans.detach()], -1).contiguous()
-            out = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(out, mine)
+        # after each BA round every submap publishes its optimised keyframe poses (RCCL all_gather)
+        mdist.exchange_poses(loop.cur_rot, loop.cur_trans)
 
     for _ in range(args.warmup):
         loop.step()
@@ -342,10 +346,7 @@ def main():
     log(f"timed region: {args.steps} steps in {elapsed * 1e3:.1f} ms")
     prof = ops.profile_summary()
     ops.PROFILE = None
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+    elapsed = mdist.max_over_ranks(elapsed, dev)
 
     if rank != 0:
         dist.barrier()              # rank 0 finishes its untimed extras, then everybody leaves together
