@@ -392,18 +392,38 @@ constexpr int WG_ROWS = 128;
 constexpr int WG_LDS_FLOATS = 2 * WG_ROWS * WG_LDW;
 constexpr int WG_LDS_BYTES = WG_LDS_FLOATS * 4;
 
-// global (accumulator-image layout) -> LDS transposed [feature row][sample]; one row tile (16 regs) at a time
-__device__ __forceinline__ void stage_act(float* __restrict__ dstT, const float* __restrict__ src, int64_t tile,
-                                          int mat, int rt0, int nrt, int row_shift, bool live, int w, int lane) {
-    const int j = lane & 31, h = lane >> 5;
+// Staging is split in two so that HBM latency hides under matrix work (the kernel runs one wave per SIMD, nothing
+// else covers a stall): fetch_act issues the global loads of the NEXT phase into registers right before the MFMA
+// loop of the current phase; put_act writes them, transposed, into LDS after the loop's closing barrier.
+__device__ __forceinline__ void fetch_act(float4* __restrict__ regs, const float* __restrict__ src, int64_t tile,
+                                          int mat, int rt0, int nrt, bool live, int lane) {
     const float4* s4 = reinterpret_cast<const float4*>(src);
-    for (int rt = rt0; rt < rt0 + nrt; ++rt) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (live) v = s4[(tile * (ACT_SLOTS / 4) + mat * 16 + rt * 4 + g) * 64 + lane];
-            float* d = dstT + (feat_of(rt, 4 * g, h) + row_shift) * WG_LDW + 32 * w + j;   // regs 4g..4g+3 -> rows +0..+3
-            d[0] = v.x, d[WG_LDW] = v.y, d[2 * WG_LDW] = v.z, d[3 * WG_LDW] = v.w;
+    for (int q = 0; q < 4; ++q) {
+        if (q < nrt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live) v = s4[(tile * (ACT_SLOTS / 4) + mat * 16 + (rt0 + q) * 4 + g) * 64 + lane];
+                regs[q * 4 + g] = v;
+            }
+        }
+    }
+}
+
+// accumulator-image registers -> LDS transposed [feature row][sample]; regs 4g..4g+3 of a tile are rows +0..+3
+__device__ __forceinline__ void put_act(float* __restrict__ dstT, const float4* __restrict__ regs, int rt0, int nrt,
+                                        int row_shift, int w, int lane) {
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q < nrt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 v = regs[q * 4 + g];
+                float* d = dstT + (feat_of(rt0 + q, 4 * g, h) + row_shift) * WG_LDW + 32 * w + j;
+                d[0] = v.x, d[WG_LDW] = v.y, d[2 * WG_LDW] = v.z, d[3 * WG_LDW] = v.w;
+            }
         }
     }
 }
@@ -415,12 +435,37 @@ __device__ __forceinline__ void wgrad_mma(const float* __restrict__ XT, const fl
     const int i = lane & 31, kk = lane >> 5;
     const float* xa = XT + (32 * rtile + i) * WG_LDW + kk;
     const float* yb = YT + (32 * ct0 + i) * WG_LDW + kk;
-#pragma unroll 4
-    for (int t = 0; t < 64; ++t) {
-        float a = xa[2 * t];
-        if (a_rows_lt8) a = i < 8 ? a : 0.0f;
+    const bool keep = !a_rows_lt8 || i < 8;
+    // operands of k-step group g+1 are read from LDS while the 4*NCT MFMAs of group g execute
+    constexpr int G = 4;
+    float a[G], b[G][NCT], na[G], nb[G][NCT];
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) acc[ct] = mfma(a, yb[ct * 32 * WG_LDW + 2 * t], acc[ct]);
+    for (int u = 0; u < G; ++u) {
+        a[u] = xa[2 * u];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) b[u][ct] = yb[ct * 32 * WG_LDW + 2 * u];
+    }
+    for (int t0 = 0; t0 < 64; t0 += G) {
+        if (t0 + G < 64) {
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                na[u] = xa[2 * (t0 + G + u)];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) nb[u][ct] = yb[ct * 32 * WG_LDW + 2 * (t0 + G + u)];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const float av = keep ? a[u] : 0.0f;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[ct] = mfma(av, b[u][ct], acc[ct]);
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            a[u] = na[u];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) b[u][ct] = nb[u][ct];
+        }
     }
 }
 
@@ -466,35 +511,57 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
         return a;
     };
 
+    // prefetch registers: X / Y operands of the next phase (+ grid features, coordinates, small gradients)
+    float4 nx[16], ny[16], nsm;
+    float ngf[16], npx[3];
+    auto tile_of = [&](uint32_t bt) { return (int64_t)bt * 4 + w; };
+    auto live_of = [&](uint32_t bt) { return bt < n_btiles && tile_of(bt) * 32 < (int64_t)M; };
+    auto sample_of = [&](uint32_t bt) {
+        const uint32_t s_raw = (uint32_t)(tile_of(bt) * 32 + j);
+        return s_raw < M ? s_raw : M - 1;
+    };
+    auto fetch_phase0 = [&](uint32_t bt) {          // X = dG3, Y = [sdf_emb | grid]
+        const bool lv = live_of(bt);
+        fetch_act(nx, dact, tile_of(bt), 2, 0, 4, lv, lane);
+        fetch_act(ny, saved, tile_of(bt), 1, 0, 2, lv, lane);
+        const uint32_t s = lv ? sample_of(bt) : 0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) ngf[u] = lv ? load_feat<LAYOUT>(feat, s, u, h, M) : 0.0f;
+    };
+
+    fetch_phase0(blockIdx.x);
     for (uint32_t bt = blockIdx.x; bt < n_btiles; bt += gridDim.x) {
-        const int64_t tile = (int64_t)bt * 4 + w;
-        const bool tile_live = tile * 32 < (int64_t)M;
-        const uint32_t s_raw = (uint32_t)(tile * 32 + j);
-        const uint32_t s = s_raw < M ? s_raw : M - 1;
+        const int64_t tile = tile_of(bt);
+        const bool tile_live = live_of(bt);
+        const uint32_t s = sample_of(bt);
 
         // ---------------- phase sdf0: X = dG3, Y = [sdf_emb | grid]
-        stage_act(XT, dact, tile, 2, 0, 4, 0, tile_live, w, lane);
-        stage_act(YT, saved, tile, 1, 0, 2, 0, tile_live, w, lane);
+        put_act(XT, nx, 0, 4, 0, w, lane);
+        put_act(YT, ny, 0, 2, 0, w, lane);
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
-            YT[(64 + 2 * u + h) * WG_LDW + 32 * w + j] = tile_live ? load_feat<LAYOUT>(feat, s, u, h, M) : 0.0f;
+        for (int u = 0; u < 16; ++u) YT[(64 + 2 * u + h) * WG_LDW + 32 * w + j] = ngf[u];
         __syncthreads();
+        fetch_act(nx, dact, tile, 1, 0, 4, tile_live, lane);      // next: X = dH2, Y = H1
+        fetch_act(ny, saved, tile, 0, 0, 4, tile_live, lane);
         wgrad_mma<3>(XT, YT, w, 0, lane, aS1);
         db3 += row_sum(XT, brow, 64 * bhalf, 64);
         __syncthreads();
 
         // ---------------- phase pts2: X = dH2, Y = H1
-        stage_act(XT, dact, tile, 1, 0, 4, 0, tile_live, w, lane);
-        stage_act(YT, saved, tile, 0, 0, 4, 0, tile_live, w, lane);
+        put_act(XT, nx, 0, 4, 0, w, lane);
+        put_act(YT, ny, 0, 4, 0, w, lane);
         __syncthreads();
+        fetch_act(nx, dact, tile, 0, 0, 4, tile_live, lane);      // next: X = dG1, Y = e (from x)
+        npx[0] = x[3 * (size_t)s], npx[1] = x[3 * (size_t)s + 1], npx[2] = x[3 * (size_t)s + 2];
         wgrad_mma<4>(XT, YT, w, 0, lane, aW2);
         db2 += row_sum(XT, brow, 64 * bhalf, 64);
         __syncthreads();
 
         // ---------------- phase pts0: X = dG1, Y = e (rows 0..50, rows 51..63 zero)
-        stage_act(XT, dact, tile, 0, 0, 4, 0, tile_live, w, lane);
+        put_act(XT, nx, 0, 4, 0, w, lane);
         float ev[E_SLOTS];
         load_e<PE_INTERNAL>(x, embed_pos, s, h, ev);
+        (void)npx;
 #pragma unroll
         for (int t = 0; t < E_SLOTS; ++t) {
             const int e = eidx(t, h);
@@ -502,6 +569,13 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
         }
         for (int q = tid; q < 13 * 128; q += DEC_BLOCK) YT[(51 + q / 128) * WG_LDW + (q % 128)] = 0.0f;
         __syncthreads();
+        {                                                          // next: X = [dlogits | drgb], Y = H3
+            const int sl = tid & 127, half = tid >> 7;
+            const int64_t sg = (int64_t)bt * 128 + sl;
+            nsm = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sg < (int64_t)M) nsm = reinterpret_cast<const float4*>(dsmall + sg * 8)[half];
+        }
+        fetch_act(ny, saved, tile, 2, 0, 4, tile_live, lane);
         wgrad_mma<2>(XT, YT, w, 0, lane, aW1);
         db1 += row_sum(XT, brow, 64 * bhalf, 64);
         __syncthreads();
@@ -509,22 +583,20 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
         // ---------------- phase sdf2: X = [dlogits(5) | drgb(3)] (8 rows), Y = H3
         {
             const int sl = tid & 127, half = tid >> 7;
-            const int64_t sg = (int64_t)bt * 128 + sl;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (sg < (int64_t)M) v = reinterpret_cast<const float4*>(dsmall + sg * 8)[half];
-            XT[(4 * half + 0) * WG_LDW + sl] = v.x;
-            XT[(4 * half + 1) * WG_LDW + sl] = v.y;
-            XT[(4 * half + 2) * WG_LDW + sl] = v.z;
-            XT[(4 * half + 3) * WG_LDW + sl] = v.w;
+            XT[(4 * half + 0) * WG_LDW + sl] = nsm.x;
+            XT[(4 * half + 1) * WG_LDW + sl] = nsm.y;
+            XT[(4 * half + 2) * WG_LDW + sl] = nsm.z;
+            XT[(4 * half + 3) * WG_LDW + sl] = nsm.w;
         }
-        stage_act(YT, saved, tile, 2, 0, 4, 0, tile_live, w, lane);
+        put_act(YT, ny, 0, 4, 0, w, lane);
         __syncthreads();
+        fetch_act(ny, saved, tile, 1, 2, 2, tile_live, lane);     // next: Y = [rgb_emb | e]
         wgrad_mma<1>(XT, YT, 0, w, lane, aS2, true);
         if (tid < 16) dbs += row_sum(XT, tid & 7, 64 * (tid >> 3), 64);
         __syncthreads();
 
         // ---------------- phase rgb0: X = same 8 rows, Y = [rgb_emb (64) | e (51) | 0]
-        stage_act(YT, saved, tile, 1, 2, 2, -64, tile_live, w, lane);
+        put_act(YT, ny, 2, 2, -64, w, lane);
 #pragma unroll
         for (int t = 0; t < E_SLOTS; ++t) {
             const int e = eidx(t, h);
@@ -532,6 +604,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
         }
         for (int q = tid; q < 13 * 128; q += DEC_BLOCK) YT[(115 + q / 128) * WG_LDW + (q % 128)] = 0.0f;
         __syncthreads();
+        fetch_phase0(bt + gridDim.x);                              // next block tile's first phase
         wgrad_mma<1>(XT, YT, 0, w, lane, aRGB, true);
         __syncthreads();
     }
