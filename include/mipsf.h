@@ -66,7 +66,8 @@ int mipsf_hashgrid_meta_init(mipsf_grid_meta* meta_host, uint32_t n_levels, uint
 /* x: [M,3] fp32 already normalised (scene_rep.py:140-142 + :119); params: [n_params]; out: [M,L*F]. */
 int mipsf_hashgrid_fwd(const float* x, const float* params, float* out, uint32_t M,
                        const mipsf_grid_meta* meta_host, int layout, void* stream);
-/* dparams += scatter of dL/dout (accumulated on chip in LDS slices, see hashgrid.hip); dx (nullable) += dL/dx [M,3].
+/* dparams (nullable: frozen grid) += scatter of dL/dout (accumulated on chip in LDS slices, see hashgrid.hip);
+ * dx (nullable) += dL/dx [M,3].
  * scratch: mipsf_hashgrid_bwd_scratch_floats(meta, M, dx != NULL) floats owned by the caller. */
 uint64_t mipsf_hashgrid_bwd_scratch_floats(const mipsf_grid_meta* meta_host, uint32_t M, int need_dx);
 int mipsf_hashgrid_bwd(const float* x, const float* params, const float* dout, float* dparams, float* dx,

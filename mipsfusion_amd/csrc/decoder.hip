@@ -31,8 +31,22 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
 }
 
 // acc[rt] += A_image(rt, t) * B(t) for all k-steps; bfn(t) must fold to a register after unrolling
-template <int RT, int T, typename BFn>
-__device__ __forceinline__ void mfma_layer(const float4* __restrict__ img, int lane, f32x16 (&acc)[RT], BFn bfn) {
+// PLACEMENT PIN.  The chain kernels take an always-zero kernel argument `pin`; the trickled stores below are
+// wrapped in `if (pin == 0)`.  The branch is never taken, but because the compiler cannot prove that, it cannot
+// sink/hoist those stores back into one burst in front of the next layer's operand loads (which it does otherwise:
+// measured 410 us vs 313 us for the backward chain at 4096x64).
+struct NoSide {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+
+// acc[rt] += A_image(rt, t) * B(t) for all k-steps; bfn(t) must fold to a register after unrolling.
+// side(t4) is invoked once per group of 4 k-steps AFTER the next group's operand loads have been issued: callers
+// use it to trickle out stores (saved activations / pre-activation gradients) and reloads.  vmcnt retires in order
+// on gfx9, so a burst of stores in front of the next layer's first loads stalls the matrix pipe for a full
+// store round trip; one 16-byte store per group behind the loads costs nothing.
+template <int RT, int T, typename BFn, typename SideFn = NoSide>
+__device__ __forceinline__ void mfma_layer(const float4* __restrict__ img, int lane, f32x16 (&acc)[RT], BFn bfn,
+                                           SideFn side = SideFn()) {
     constexpr int T4 = T / 4;
     // the A operands of group t4+1 are requested before the 4*RT MFMAs of group t4 issue, so an L2 round trip
     // (~500-900 cycles) hides under 4*RT*64 cycles of matrix work instead of stalling in front of it
@@ -45,6 +59,7 @@ __device__ __forceinline__ void mfma_layer(const float4* __restrict__ img, int l
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) nxt[rt] = img[(rt * T4 + t4 + 1) * 64 + lane];
         }
+        side(t4);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma(a[rt].x, bfn(t4 * 4 + 0), acc[rt]);
 #pragma unroll
@@ -77,6 +92,21 @@ __device__ __forceinline__ void store_act(float* __restrict__ dst, int64_t tile,
         for (int g = 0; g < 4; ++g)
             d4[(tile * (ACT_SLOTS / 4) + mat * 16 + rt * 4 + g) * 64 + lane] =
                 make_float4(acc[rt][4 * g], acc[rt][4 * g + 1], acc[rt][4 * g + 2], acc[rt][4 * g + 3]);
+}
+
+// group q in [0,16): row tile q>>2, registers 4*(q&3) .. +3
+__device__ __forceinline__ void store_act_piece(float* __restrict__ dst, int64_t tile, int mat, int lane,
+                                                const f32x16 (&acc)[4], int q) {
+    const int rt = q >> 2, g = q & 3;
+    reinterpret_cast<float4*>(dst)[(tile * (ACT_SLOTS / 4) + mat * 16 + q) * 64 + lane] =
+        make_float4(acc[rt][4 * g], acc[rt][4 * g + 1], acc[rt][4 * g + 2], acc[rt][4 * g + 3]);
+}
+
+__device__ __forceinline__ void load_act_piece(const float* __restrict__ src, int64_t tile, int mat, int lane,
+                                               f32x16 (&acc)[4], int q) {
+    const int rt = q >> 2, g = q & 3;
+    const float4 v = reinterpret_cast<const float4*>(src)[(tile * (ACT_SLOTS / 4) + mat * 16 + q) * 64 + lane];
+    acc[rt][4 * g] = v.x, acc[rt][4 * g + 1] = v.y, acc[rt][4 * g + 2] = v.z, acc[rt][4 * g + 3] = v.w;
 }
 
 __device__ __forceinline__ void load_act(const float* __restrict__ src, int64_t tile, int mat, int lane,
@@ -123,7 +153,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_fwd_kernel(const float* 
                                                                 const float* __restrict__ x,
                                                                 const float* __restrict__ embed_pos,
                                                                 float* __restrict__ out, float* __restrict__ saved,
-                                                                uint32_t M) {
+                                                                uint32_t M, int pin) {
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + (threadIdx.x >> 6);
@@ -144,14 +174,13 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_fwd_kernel(const float* 
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) H1[rt][r] = fmaxf(H1[rt][r], 0.0f);
-    if (SAVE) store_act(saved, tile, 0, lane, H1);
 
-    // ---- layer 2: pts_linear.2 -> [sdf_emb | rgb_emb]
+    // ---- layer 2: pts_linear.2 -> [sdf_emb | rgb_emb]   (H1 is written out one 16-byte group per k-group)
     f32x16 H2[4];
     load_bias(packed, 1, h, H2);
     mfma_layer<RT_F2, T_F2>(reinterpret_cast<const float4*>(packed + OFF_F2), lane, H2,
-                            [&](int t) { return H1[t >> 4][t & 15]; });
-    if (SAVE) store_act(saved, tile, 1, lane, H2);
+                            [&](int t) { return H1[t >> 4][t & 15]; },
+                            [&](int t4) { if (SAVE && pin == 0) store_act_piece(saved, tile, 0, lane, H1, t4); });
 
     // ---- rgb_linear.0 on the vector ALU (3 outputs): this lane's half of every dot product, then one swap
     float pr[3] = {0.f, 0.f, 0.f};
@@ -180,7 +209,13 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_fwd_kernel(const float* 
     f32x16 H3[4];
     load_bias(packed, 2, h, H3);
     mfma_layer<RT_F3, T_F3>(reinterpret_cast<const float4*>(packed + OFF_F3), lane, H3,
-                            [&](int t) { return t < 32 ? H2[t >> 4][t & 15] : gf[t - 32]; });
+                            [&](int t) { return t < 32 ? H2[t >> 4][t & 15] : gf[t - 32]; },
+                            [&](int t4) {                       // 16 groups of H2 over 12 k-groups
+                                if (SAVE && pin == 0) {
+                                    store_act_piece(saved, tile, 1, lane, H2, t4);
+                                    if (t4 < 4) store_act_piece(saved, tile, 1, lane, H2, 12 + t4);
+                                }
+                            });
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -236,7 +271,7 @@ __global__ __launch_bounds__(DEC_BLOCK) void decoder_bwd_kernel(
     const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ out,
     const float* __restrict__ dout, const float* __restrict__ saved, float* __restrict__ dfeat,
     float* __restrict__ dx, float* __restrict__ dembed_pos, float* __restrict__ dact, float* __restrict__ dsmall,
-    uint32_t M) {
+    uint32_t M, int pin) {
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + (threadIdx.x >> 6);
@@ -285,7 +320,6 @@ __global__ __launch_bounds__(DEC_BLOCK) void decoder_bwd_kernel(
             dG3[slot >> 4][slot & 15] = H3[slot >> 4][slot & 15] > 0.0f ? v : 0.0f;
         }
     }
-    store_act(dact, tile, 2, lane, dG3);
 
     // ---- d[sdf_emb | grid] = Ws1^T dG3   (3 row tiles: 0,1 -> d sdf_emb, 2 -> d grid features)
     f32x16 dIn3[3];
@@ -294,7 +328,8 @@ __global__ __launch_bounds__(DEC_BLOCK) void decoder_bwd_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) dIn3[rt][r] = 0.0f;
     mfma_layer<RT_B3, T_B3>(reinterpret_cast<const float4*>(packed + OFF_B3), lane, dIn3,
-                            [&](int t) { return dG3[t >> 4][t & 15]; });
+                            [&](int t) { return dG3[t >> 4][t & 15]; },
+                            [&](int t4) { if (pin == 0) store_act_piece(dact, tile, 2, lane, dG3, t4); });
     if (live) {
         // regs (r, r+1), r even, hold (level, f=0/1) of grid feature row rowmap(r,h) -> one 8-byte store each
 #pragma unroll
@@ -326,25 +361,24 @@ __global__ __launch_bounds__(DEC_BLOCK) void decoder_bwd_kernel(
             de[t] = fmaf(wv.z, drgb[2], fmaf(wv.y, drgb[1], wv.x * drgb[0]));
         }
     }
-    store_act(dact, tile, 1, lane, dH2);
 
-    // ---- dG1 = relu'(H1) * (W2^T dH2)
+    // ---- dG1 = relu'(H1) * (W2^T dH2)   (dH2 goes out, H1 comes in, one 16-byte group per k-group)
     f32x16 dG1[4];
+    f32x16 H1[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dG1[rt][r] = 0.0f;
     mfma_layer<RT_B2, T_B2>(reinterpret_cast<const float4*>(packed + OFF_B2), lane, dG1,
-                            [&](int t) { return dH2[t >> 4][t & 15]; });
-    {
-        f32x16 H1[4];
-        load_act(saved, tile, 0, lane, H1);
+                            [&](int t) { return dH2[t >> 4][t & 15]; },
+                            [&](int t4) {
+                                load_act_piece(saved, tile, 0, lane, H1, t4);
+                                if (pin == 0) store_act_piece(dact, tile, 1, lane, dH2, t4);
+                            });
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dG1[rt][r] = H1[rt][r] > 0.0f ? dG1[rt][r] : 0.0f;
-    }
-    store_act(dact, tile, 0, lane, dG1);
+        for (int r = 0; r < 16; ++r) dG1[rt][r] = H1[rt][r] > 0.0f ? dG1[rt][r] : 0.0f;
 
     // ---- d e = W1^T dG1 (+ rgb share); rows are arranged so that e-slot (t, h) lands in THIS lane
     f32x16 dE[2];
@@ -353,7 +387,8 @@ __global__ __launch_bounds__(DEC_BLOCK) void decoder_bwd_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) dE[rt][r] = 0.0f;
     mfma_layer<RT_B1, T_B1>(reinterpret_cast<const float4*>(packed + OFF_B1), lane, dE,
-                            [&](int t) { return dG1[t >> 4][t & 15]; });
+                            [&](int t) { return dG1[t >> 4][t & 15]; },
+                            [&](int t4) { if (pin == 0) store_act_piece(dact, tile, 0, lane, dG1, t4); });
 #pragma unroll
     for (int t = 0; t < E_SLOTS; ++t) de[t] = de[t] + dE[t >> 4][t & 15];
 
@@ -718,7 +753,7 @@ int mipsf_decoder_fwd(const float* packed, const float* feat, int feat_layout, c
     const uint32_t blocks = (uint32_t)((n_wave_tiles(M) + 3) / 4);
     hipStream_t s = (hipStream_t)stream;
 #define FWD(PE, LAY, SV) \
-    hipLaunchKernelGGL((decoder_fwd_kernel<PE, LAY, SV>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed, feat, x, embed_pos, out, saved, M)
+    hipLaunchKernelGGL((decoder_fwd_kernel<PE, LAY, SV>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed, feat, x, embed_pos, out, saved, M, 0)
     const bool sv = saved != nullptr;
     if (pe_mode == 0) {
         if (feat_layout == MIPSF_FEAT_AOS) { if (sv) FWD(true, MIPSF_FEAT_AOS, true); else FWD(true, MIPSF_FEAT_AOS, false); }
@@ -742,7 +777,7 @@ int mipsf_decoder_bwd_chain(const float* packed, int feat_layout, const float* x
     const uint32_t blocks = (uint32_t)((n_wave_tiles(M) + 3) / 4);
     float* dsmall = dact + n_block_tiles(M) * 4 * ACT_TILE_FLOATS;
 #define BWD(PE, LAY) \
-    hipLaunchKernelGGL((decoder_bwd_kernel<PE, LAY>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed, x, out, dout, saved, dfeat, dx, dembed_pos, dact, dsmall, M)
+    hipLaunchKernelGGL((decoder_bwd_kernel<PE, LAY>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed, x, out, dout, saved, dfeat, dx, dembed_pos, dact, dsmall, M, 0)
     if (pe_mode == 0) { if (feat_layout == MIPSF_FEAT_AOS) BWD(true, MIPSF_FEAT_AOS); else BWD(true, MIPSF_FEAT_LEVEL_MAJOR); }
     else { if (feat_layout == MIPSF_FEAT_AOS) BWD(false, MIPSF_FEAT_AOS); else BWD(false, MIPSF_FEAT_LEVEL_MAJOR); }
 #undef BWD

@@ -477,7 +477,8 @@ int mipsf_hashgrid_bwd(const float* x, const float* params, const float* dout, f
     GridLevels g;
     if (int rc = to_levels(meta, g)) return rc;
     if (M == 0) return 0;
-    MIPSF_REQUIRE(x && params && dout && dparams && scratch, "null pointer");
+    MIPSF_REQUIRE(x && params && dout && scratch, "null pointer");
+    MIPSF_REQUIRE(dparams || dx, "nothing to compute: dparams and dx are both null");
     MIPSF_REQUIRE(layout == MIPSF_FEAT_AOS || layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout %d", layout);
     hipStream_t s = (hipStream_t)stream;
     const ScatterPlan plan = make_plan(g, M);
@@ -500,10 +501,12 @@ int mipsf_hashgrid_bwd(const float* x, const float* params, const float* dout, f
         hipLaunchKernelGGL((hashgrid_scatter_kernel<LAY>), dim3(plan.total_blocks), dim3(SC_BLOCK), lds_bytes, s, \
                            x, dout, dparams, partial, M, g, plan);                                               \
     } while (0)
-    if (layout == MIPSF_FEAT_AOS) SCATTER(MIPSF_FEAT_AOS); else SCATTER(MIPSF_FEAT_LEVEL_MAJOR);
+    if (dparams) {   // a frozen grid (tracking) skips the scatter altogether
+        if (layout == MIPSF_FEAT_AOS) SCATTER(MIPSF_FEAT_AOS); else SCATTER(MIPSF_FEAT_LEVEL_MAJOR);
+        if (int e = check_launch("hashgrid_scatter")) return e;
+    }
 #undef SCATTER
-    if (int e = check_launch("hashgrid_scatter")) return e;
-    if (plan.split_entries) {
+    if (dparams && plan.split_entries) {
         hipLaunchKernelGGL(hashgrid_scatter_reduce_kernel, dim3((plan.split_entries + 255) / 256), dim3(256), 0, s,
                            partial, dparams, g, plan);
         if (int e = check_launch("hashgrid_scatter_reduce")) return e;

@@ -76,32 +76,37 @@ class _QueryFn(torch.autograd.Function):
     def backward(ctx, dout):
         xn, feat, out, saved, packed, grid_params, *weights = ctx.saved_tensors
         need_w = any(ctx.needs_input_grad[3:])
+        need_g = ctx.needs_input_grad[2]
+        need_x = ctx.needs_input_grad[0]
         direct = ctx.owner.accumulate_param_grads_in_place
-        if direct and need_w:
+        # frozen parameters (requires_grad False, e.g. the map during tracking) skip their kernels entirely
+        grads = None
+        if need_w:
             grads = []
             for w, need in zip(weights, ctx.needs_input_grad[3:]):
-                if need and w.grad is None:
-                    w.grad = torch.zeros_like(w)
-                grads.append(w.grad if need else torch.zeros_like(w))
-        else:
-            grads = [torch.zeros_like(w) for w in weights]
+                if direct and need:
+                    if w.grad is None:
+                        w.grad = torch.zeros_like(w)
+                    grads.append(w.grad)
+                else:
+                    grads.append(torch.zeros_like(w))
         dfeat, dx, _ = ops.decoder_bwd(packed, feat, FEAT_LEVEL_MAJOR, xn, None, out, ops._f32c(dout), saved, grads,
                                        ctx.M)
         dparams = None
-        if ctx.needs_input_grad[2]:
+        if need_g:
             if direct:
                 if grid_params.grad is None:
                     grid_params.grad = torch.zeros_like(grid_params)
                 dparams = grid_params.grad
             else:
                 dparams = torch.zeros_like(grid_params)
-        if dparams is not None or ctx.needs_input_grad[0]:
-            scratch = dparams if dparams is not None else torch.zeros_like(grid_params)
-            ops.hashgrid_bwd(xn, grid_params.detach(), dfeat, scratch, ctx.meta, FEAT_LEVEL_MAJOR,
-                             dx if ctx.needs_input_grad[0] else None)
-        if direct:
-            return (dx if ctx.needs_input_grad[0] else None, None, None, *([None] * len(weights)))
-        return (dx if ctx.needs_input_grad[0] else None, None, dparams, *(grads if need_w else [None] * len(weights)))
+        if need_g or need_x:
+            ops.hashgrid_bwd(xn, grid_params.detach(), dfeat, dparams, ctx.meta, FEAT_LEVEL_MAJOR,
+                             dx if need_x else None)
+        w_out = [None] * len(weights)
+        if need_w and not direct:
+            w_out = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[3:])]
+        return (dx if need_x else None, None, None if direct else dparams, *w_out)
 
 
 class _RenderFn(torch.autograd.Function):

@@ -100,9 +100,10 @@ class HashGridFn(torch.autograd.Function):
     def backward(ctx, dout):
         x, params = ctx.saved_tensors          # saved tensors survive retain_graph=True re-entry
         dout = _f32c(dout)
-        dparams = torch.zeros_like(params)
+        dparams = torch.zeros_like(params) if ctx.needs_input_grad[1] else None
         dx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
-        hashgrid_bwd(x, params.detach(), dout, dparams, ctx.meta, FEAT_AOS, dx)
+        if dparams is not None or dx is not None:
+            hashgrid_bwd(x, params.detach(), dout, dparams, ctx.meta, FEAT_AOS, dx)
         return dx, dparams, None
 
 
@@ -163,22 +164,24 @@ def decoder_fwd(packed, feat, layout, x, embed_pos, M, save: bool):
 
 
 def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M):
-    """grads: 10 tensors in DECODER_PARAM_ORDER, accumulated into.  -> (dfeat, dx, dembed_pos|None)"""
+    """grads: 10 tensors in DECODER_PARAM_ORDER, accumulated into, or None (frozen decoder: the weight-gradient
+    GEMMs are skipped).  -> (dfeat, dx, dembed_pos|None)"""
     dev = x.device
     dfeat = torch.empty_like(feat)
     dx = torch.empty((M, 3), dtype=torch.float32, device=dev)
     dpe = torch.empty((M, 48), dtype=torch.float32, device=dev) if embed_pos is not None else None
     dact = torch.empty(lib().mipsf_decoder_dact_floats(M), dtype=torch.float32, device=dev)
-    partial = torch.empty(lib().mipsf_decoder_wgrad_partial_floats(), dtype=torch.float32, device=dev)
-    st = _decoder_struct(grads, _lib.DecoderGrads)
     pe_mode = 0 if embed_pos is None else 1
     with _timed("decoder_bwd_chain"):
         check(lib().mipsf_decoder_bwd_chain(dptr(packed), layout, dptr(x), pe_mode, dptr(out), dptr(dout), dptr(saved),
                                             dptr(dfeat), dptr(dx), dptr(dpe), dptr(dact), M, stream_ptr()),
               "decoder_bwd_chain")
-    with _timed("decoder_wgrad"):
-        check(lib().mipsf_decoder_wgrad(dptr(feat), layout, dptr(x), dptr(embed_pos), pe_mode, dptr(saved),
-                                        dptr(dact), C.byref(st), dptr(partial), M, stream_ptr()), "decoder_wgrad")
+    if grads is not None:
+        partial = torch.empty(lib().mipsf_decoder_wgrad_partial_floats(), dtype=torch.float32, device=dev)
+        st = _decoder_struct(grads, _lib.DecoderGrads)
+        with _timed("decoder_wgrad"):
+            check(lib().mipsf_decoder_wgrad(dptr(feat), layout, dptr(x), dptr(embed_pos), pe_mode, dptr(saved),
+                                            dptr(dact), C.byref(st), dptr(partial), M, stream_ptr()), "decoder_wgrad")
     return dfeat, dx, dpe
 
 
@@ -199,9 +202,10 @@ class DecoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         embed, embed_pos, x, out, saved, packed, *weights = ctx.saved_tensors
-        grads = [torch.zeros_like(w) for w in weights]
+        need_w = any(ctx.needs_input_grad[3:])
+        grads = [torch.zeros_like(w) for w in weights] if need_w else None
         dfeat, dx, dpe = decoder_bwd(packed, embed, FEAT_AOS, x, embed_pos, out, _f32c(dout), saved, grads, ctx.M)
-        return (dfeat, dpe, dx, *grads)
+        return (dfeat, dpe, dx, *(grads if need_w else [None] * len(weights)))
 
 
 # ------------------------------------------------------------------------------- renderer

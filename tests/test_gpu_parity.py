@@ -292,6 +292,23 @@ def test_default_noise_draw_keeps_cpu_rng_stream(dev):
     assert torch.equal(out["z_vals"], out2["z_vals"])
 
 
+def test_frozen_map_skips_param_grads_but_keeps_pose_grads(dev):
+    """Tracking (mipsfusion.py:470-577) optimises the pose only.  With requires_grad False on the map the wgrad and
+    scatter kernels are skipped; d(rays) must be unchanged and no parameter gradient may appear."""
+    g = load_golden("scene_cfg1.npz")
+    cfg = cfg_for("scene_cfg1.npz")
+    m = make_scene(g, cfg, dev).train()
+    for prm in m.parameters():
+        prm.requires_grad_(False)
+    ro = T(g["rays_o"]).to(dev).requires_grad_(True)
+    rd = T(g["rays_d"]).to(dev).requires_grad_(True)
+    ret = m.forward(ro, rd, T(g["target_rgb"]).to(dev), T(g["target_d"]).to(dev), EMD_w=0.0, noise=T(g["noise"]).to(dev))
+    path_cpu.total_loss(ret, cfg["training"]).backward()
+    assert_close(ro.grad, g["noemd.d_rays_o"], 5e-4, "d rays_o (frozen map)")
+    assert_close(rd.grad, g["noemd.d_rays_d"], 5e-4, "d rays_d (frozen map)")
+    assert all(prm.grad is None for prm in m.parameters())
+
+
 def test_no_valid_depth_gives_nan_losses_like_reference(dev):
     g = load_golden("scene_cfg1.npz")
     m = make_scene(g, cfg_for("scene_cfg1.npz"), dev).train()
