@@ -225,12 +225,18 @@ def frame_estimate(cfg, model, loop, dev, ba_ms):
     popt = torch.optim.Adam([{"params": rot, "lr": 1e-3}, {"params": trans, "lr": 1e-3}])
     noise = loop.noise[0][:ns]
 
+    d_cam, t_rgb, t_d = rays[:, :3].contiguous(), rays[:, 3:6].contiguous(), rays[:, 6:7].contiguous()
+    own = torch.zeros(ns, dtype=torch.int64, device=dev)
+
     def go():
         popt.zero_grad()
-        c2w = qt_to_transform_matrix(rot, trans)
-        rays_o = c2w[..., :3, -1].repeat(ns, 1)
-        rays_d = torch.sum(rays[:, :3][..., None, :] * c2w[:, :3, :3], -1)
-        ret = model.forward(rays_o, rays_d, rays[:, 3:6], rays[:, 6:7], EMD_w=0., noise=noise)
+        if loop.torch_pose:
+            c2w = qt_to_transform_matrix(rot, trans)
+            rays_o = c2w[..., :3, -1].repeat(ns, 1)
+            rays_d = torch.sum(d_cam[..., None, :] * c2w[:, :3, :3], -1)
+        else:
+            rays_o, rays_d = ops.pose_rays(rot, trans, None, own, d_cam)
+        ret = model.forward(rays_o, rays_d, t_rgb, t_d, EMD_w=0., noise=noise)
         get_loss_from_ret(ret, cfg["training"]).backward()
         popt.step()
     def time_go():
@@ -293,6 +299,17 @@ def cpu_baseline(cfg, loop, n_rays, iters):
             "kind": "port", "s_per_iter": round(dt, 3),
             "sample": f"{iters} full iterations (fwd+bwd+dense Adam over the 2^19 grid) of oracle/path_cpu.py on "
                       f"{n_rays} of the 4096 rays x 64 samples of the same batch, torch CPU threads = cores"}
+
+
+def pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_latest.json, written by
+    tools/pmc_to_json.py from `tools/pmc.sh`): FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE is NOT doubled here
+    because these kernels read 4-12 B per lane, not the 16 B/lane streams the x2 gfx950 correction was calibrated on."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f).get("traffic_bytes_per_launch", {})
 
 
 def main():
@@ -366,6 +383,7 @@ def main():
     value = M * args.steps * world / elapsed
 
     kernels = {}
+    traffic = pmc_traffic()
     for name, (n_launch, ms) in prof.items():
         if name in KERNEL_COST:
             bound, per_unit = KERNEL_COST[name]
@@ -380,7 +398,7 @@ def main():
             achieved, peak, unit = work / (ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
         kernels[name] = {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
                          "frac": round(achieved / peak, 4), "avg_ms": round(ms, 4),
-                         "launches": n_launch, "traffic": None}
+                         "launches": n_launch, "traffic": traffic.get(name)}
     dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"]) if kernels else None
     roofline = dict(kernels[dominant], kernel=dominant) if dominant else None
 

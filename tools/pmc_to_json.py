@@ -1,0 +1,32 @@
+"""gpurun_out/pmc_<tag>/pass*_summary.txt -> profiles/pmc_latest.json (+ a readable copy of the summaries)."""
+import json, os, re, sys, glob
+tag = sys.argv[1]
+src = f"gpurun_out/pmc_{tag}"
+vals = {}
+for f in sorted(glob.glob(os.path.join(src, "pass*_summary.txt"))):
+    for line in open(f):
+        m = re.match(r"(\S+?)(<[^>]*>)?\s+n=\s*(\d+)\s+(.*)", line)
+        if not m:
+            continue
+        k = m.group(1)
+        for kv in m.group(4).split():
+            c, v = kv.split("=")
+            vals.setdefault(k, {})[c] = float(v)
+# map rocprof kernel names -> bench kernel groups (a group = one C-ABI call)
+groups = {"hashgrid_fwd": ["hashgrid_fwd_kernel"], "hashgrid_bwd": ["hashgrid_scatter_kernel", "hashgrid_scatter_reduce_kernel", "hashgrid_dx_kernel", "hashgrid_dx_reduce_kernel"],
+          "decoder_fwd": ["decoder_fwd_kernel"], "decoder_bwd_chain": ["decoder_bwd_kernel"], "decoder_wgrad": ["decoder_wgrad_kernel", "decoder_wgrad_reduce_kernel"],
+          "adam_step": ["adam_kernel"], "sample_rays": ["sample_rays_kernel"], "render_fwd": ["render_fwd_kernel", "loss_finalize_kernel"],
+          "render_bwd": ["render_bwd_kernel"], "rays_bwd": ["rays_bwd_kernel"]}
+traffic = {}
+for g, ks in groups.items():
+    tot = 0.0
+    for k in ks:
+        tot += (vals.get(k, {}).get("FETCH_SIZE", 0.0) + vals.get(k, {}).get("WRITE_SIZE", 0.0)) * 1024.0
+    traffic[g] = round(tot)
+out = {"source": f"rocprofv3 --pmc passes, tools/pmc.sh {tag}", "traffic_bytes_per_launch": traffic, "counters": vals}
+os.makedirs("profiles", exist_ok=True)
+json.dump(out, open("profiles/pmc_latest.json", "w"), indent=1)
+with open(f"profiles/r01_{tag}_pmc_summary.txt", "w") as o:
+    for f in sorted(glob.glob(os.path.join(src, "pass*_summary.txt"))):
+        o.write(open(f).read())
+print(json.dumps(traffic, indent=1))
