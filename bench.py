@@ -33,6 +33,7 @@ from mipsfusion_amd import ops, synth  # noqa: E402
 from mipsfusion_amd.helper_functions import sampling_helper as sh  # noqa: E402
 from mipsfusion_amd.helper_functions.geometry_helper import matrix_to_quaternion, qt_to_transform_matrix  # noqa: E402
 from mipsfusion_amd.helper_functions.utils import get_loss_from_ret  # noqa: E402
+from mipsfusion_amd.graph import GraphedSteps, work_stream  # noqa: E402
 from mipsfusion_amd.model import JointEncoding  # noqa: E402
 from mipsfusion_amd.optim import FusedAdam  # noqa: E402
 
@@ -86,6 +87,8 @@ def parse():
     p.add_argument("--cpu-rays", type=int, default=4096, help="rays of the bounded CPU-baseline sample (0 = skip)")
     p.add_argument("--cpu-iters", type=int, default=4)
     p.add_argument("--no-frame-estimate", action="store_true")
+    p.add_argument("--no-graph", action="store_true",
+                   help="time eager launches instead of hipGraph replays of pose_accum_step iterations")
     p.add_argument("--torch-pose", action="store_true",
                    help="build rays with the reference's eager torch ops (mipsfusion.py:320-322) instead of the fused op")
     return p.parse_args()
@@ -141,27 +144,50 @@ def sample_pool(cfg, frames, n_batches):
 class MappingLoop:
     """The local-BA iteration of mipsfusion.py:293-342 against our JointEncoding."""
 
-    def __init__(self, cfg, model, poses, pool, dev, torch_pose=False):
+    def __init__(self, cfg, model, poses, pool, dev, torch_pose=False, capturable=False):
         self.cfg, self.model, self.dev, self.torch_pose = cfg, model, dev, torch_pose
         self.map_opt = FusedAdam([{"params": model.decoder.parameters(), "weight_decay": 1e-6, "lr": cfg["mapping"]["lr_decoder"]},
                                   {"params": model.embed_fn.parameters(), "eps": 1e-15, "lr": cfg["mapping"]["lr_embed"]}],
-                                 betas=(0.9, 0.99))
+                                 betas=(0.9, 0.99), capturable=capturable)
         poses = poses.to(dev)
         self.pose_fixed = poses[:1]                                  # first keyframe stays fixed
         self.cur_trans = torch.nn.Parameter(poses[1:, :3, 3].clone())
         self.cur_rot = torch.nn.Parameter(matrix_to_quaternion(poses[1:, :3, :3]))
         self.pose_opt = torch.optim.Adam([{"params": self.cur_rot, "lr": cfg["mapping"]["lr_rot"]},
-                                          {"params": self.cur_trans, "lr": cfg["mapping"]["lr_trans"]}])
+                                          {"params": self.cur_trans, "lr": cfg["mapping"]["lr_trans"]}],
+                                         capturable=capturable)
         self.poses_all = torch.cat([self.pose_fixed, qt_to_transform_matrix(self.cur_rot, self.cur_trans)], 0)
         self.pool = [(r.to(dev), o.to(dev)) for r, o in pool]
         self.pool = [(r, o, r[:, :3].contiguous(), r[:, 3:6].contiguous(), r[:, 6:7].contiguous()) for r, o in self.pool]
         self.noise = [torch.rand(N_RAYS, N_SAMPLES, device=dev) for _ in pool]
         self.i = 0
 
+    def make_static(self, n_inner):
+        """Static input buffers for a captured group of n_inner iterations + stacked pool to refill them from."""
+        P = len(self.pool)
+        self.stk = [torch.stack([e[c] for e in self.pool]) for c in (1, 2, 3, 4)]      # owner, d_cam, rgb, depth
+        self.stk.append(torch.stack(self.noise))
+        self.static = [t[:n_inner].clone() for t in self.stk]
+        self.n_inner, self.cursor = n_inner, 0
+        self._arange = torch.arange(n_inner, device=self.dev)
+
+    def refill_static(self):
+        idx = (self._arange + self.cursor) % len(self.pool)
+        for dst, src in zip(self.static, self.stk):
+            torch.index_select(src, 0, idx, out=dst)
+        self.cursor += self.n_inner
+
+    def step_static(self, k):
+        owner, rays_d_cam, target_s, target_d, noise = (t[k] for t in self.static)
+        return self._iterate(owner, rays_d_cam, target_s, target_d, noise, set_to_none=False)
+
     def step(self):
-        cfg = self.cfg
         rays, owner, rays_d_cam, target_s, target_d = self.pool[self.i % len(self.pool)]
         noise = self.noise[self.i % len(self.pool)]
+        return self._iterate(owner, rays_d_cam, target_s, target_d, noise, set_to_none=True)
+
+    def _iterate(self, owner, rays_d_cam, target_s, target_d, noise, set_to_none):
+        cfg = self.cfg
         if self.torch_pose:
             rays_d = torch.sum(rays_d_cam[..., None, :] * self.poses_all[owner, :3, :3], -1)
             rays_o = self.poses_all[owner, :3, -1]
@@ -177,7 +203,7 @@ class MappingLoop:
             self.pose_opt.step()
             if self.torch_pose:
                 self.poses_all = torch.cat([self.pose_fixed, qt_to_transform_matrix(self.cur_rot, self.cur_trans)], 0)
-            self.pose_opt.zero_grad()
+            self.pose_opt.zero_grad(set_to_none=set_to_none)
         return loss
 
 
@@ -200,7 +226,7 @@ def forward_only_rate(model, loop, dev, iters=10):
     return N_RAYS * N_SAMPLES / dt, dt * 1e3
 
 
-def frame_estimate(cfg, model, loop, dev, ba_ms):
+def frame_estimate(cfg, model, loop, dev, ba_ms, stream=None):
     """tracking+mapping ms/frame = iter_RO*RO + tracking.iter*GO + mapping.iters*BA/map_every."""
     from mipsfusion_amd import ops as _ops
     P, n = cfg["tracking"]["RO"]["particle_size"], cfg["tracking"]["RO"]["n_rows"] * cfg["tracking"]["RO"]["n_cols"]
@@ -222,14 +248,14 @@ def frame_estimate(cfg, model, loop, dev, ba_ms):
     rays = loop.pool[0][0][:ns]
     rot = torch.nn.Parameter(loop.cur_rot.detach()[-1:].clone())
     trans = torch.nn.Parameter(loop.cur_trans.detach()[-1:].clone())
-    popt = torch.optim.Adam([{"params": rot, "lr": 1e-3}, {"params": trans, "lr": 1e-3}])
+    popt = torch.optim.Adam([{"params": rot, "lr": 1e-3}, {"params": trans, "lr": 1e-3}], capturable=stream is not None)
     noise = loop.noise[0][:ns]
 
     d_cam, t_rgb, t_d = rays[:, :3].contiguous(), rays[:, 3:6].contiguous(), rays[:, 6:7].contiguous()
     own = torch.zeros(ns, dtype=torch.int64, device=dev)
 
     def go():
-        popt.zero_grad()
+        popt.zero_grad(set_to_none=False)
         if loop.torch_pose:
             c2w = qt_to_transform_matrix(rot, trans)
             rays_o = c2w[..., :3, -1].repeat(ns, 1)
@@ -252,12 +278,27 @@ def frame_estimate(cfg, model, loop, dev, ba_ms):
     for prm in model.parameters():      # what freeze_model (mipsfusion.py:226-230) intends; pose results identical
         prm.requires_grad_(False)
     go_ms = time_go()
+    go_graph_ms = None
+    if stream is not None and not loop.torch_pose:      # the same iteration as one hipGraph replay
+        g = GraphedSteps(lambda k: go(), 1, stream=stream)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            g.replay()
+        torch.cuda.synchronize()
+        go_graph_ms = (time.perf_counter() - t0) / 20 * 1e3
     for prm in model.parameters():
         prm.requires_grad_(True)
     model.zero_grad()
+    go_eager_ms = go_ms
+    if go_graph_ms is not None:
+        go_ms = go_graph_ms
     tr, mp = cfg["tracking"], cfg["mapping"]
     total = tr["iter_RO"] * ro_ms + tr["iter"] * go_ms + mp["iters"] * ba_ms / mp["map_every"]
     return {"ro_iter_ms": round(ro_ms, 4), "go_iter_ms": round(go_ms, 4),
+            "go_iter_ms_eager": round(go_eager_ms, 4),
             "go_iter_ms_map_grads_computed_and_discarded": round(go_ms_unfrozen, 4), "ba_iter_ms": round(ba_ms, 4),
             "tracking_plus_mapping_ms_per_frame": round(total, 3),
             "formula": "iter_RO*ro + tracking.iter*go + mapping.iters*ba/map_every (FastCaMo-synth cadence 5/10/15/3)"}
@@ -335,11 +376,13 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    stream = work_stream(dev)        # everything (setup, eager pass, capture, replays) runs on this one stream
     cfg = synth.config_headline()
     log(f"rank {rank}/{world} on {torch.cuda.get_device_name(local)}; building submap")
     model, frames, poses = build_submap(cfg, dev, seed=rank)
     pool = sample_pool(cfg, frames, n_batches=8)
-    loop = MappingLoop(cfg, model, poses, pool, dev, torch_pose=args.torch_pose)
+    use_graph = not args.no_graph and not args.torch_pose and args.steps % cfg["mapping"]["pose_accum_step"] == 0
+    loop = MappingLoop(cfg, model, poses, pool, dev, torch_pose=args.torch_pose, capturable=use_graph)
     log("setup iterations")
     for _ in range(args.setup_iters):
         loop.step()
@@ -355,22 +398,46 @@ def main():
     exchange_poses()
     ba_round = cfg["mapping"]["iters"]
 
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- eager pass: K steps with per-kernel event pairs on the launch stream (kernel durations for the roofline)
     ops.PROFILE = {}
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         loop.step()
         if (k + 1) % ba_round == 0:
             exchange_poses()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    log(f"timed region: {args.steps} steps in {elapsed * 1e3:.1f} ms")
+    barrier()
+    eager_elapsed = time.perf_counter() - t0
     prof = ops.profile_summary()
     ops.PROFILE = None
+    log(f"eager timed region: {args.steps} steps in {eager_elapsed * 1e3:.1f} ms")
+    elapsed = eager_elapsed
+
+    # ---- graph pass (the number reported as `value`): the same K steps as hipGraph replays of pose_accum_step
+    #      iterations; fresh ray batches are copied into the static input buffers before every replay
+    if use_graph:
+        n_inner = cfg["mapping"]["pose_accum_step"]
+        loop.make_static(n_inner)
+        loop.refill_static()
+        graphed = GraphedSteps(loop.step_static, n_inner, stream=stream)
+        for _ in range(max(1, args.warmup // n_inner)):
+            loop.refill_static()
+            graphed.replay()
+        barrier()
+        t0 = time.perf_counter()
+        for r in range(args.steps // n_inner):
+            loop.refill_static()
+            graphed.replay()
+            if ((r + 1) * n_inner) % ba_round == 0:
+                exchange_poses()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        log(f"graph timed region: {args.steps} steps in {elapsed * 1e3:.1f} ms")
     elapsed = mdist.max_over_ranks(elapsed, dev)
 
     if rank != 0:
@@ -408,7 +475,9 @@ def main():
         "metric": "rays*samples/s, full optimisation iteration (sample placement -> hash grid -> decoder -> SDF "
                   "render -> losses -> backward -> pose+map Adam), 4096 rays x 64 samples, 640x480 RGB-D",
         "value": round(value, 1), "unit": "rays*samples/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+        "launch": "hipGraph replay of pose_accum_step iterations" if use_graph else "eager",
+        "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE config 2: FastCaMo-synth apartment_2 bound, 1 active submap per GPU, "
                                "4096 rays x 64 samples (43 uniform + 21 depth-guided), hash grid 2^19 x 16 levels x 2, "
@@ -420,7 +489,7 @@ def main():
         "roofline": roofline, "kernels": kernels,
     }
     if not args.no_frame_estimate:
-        out["frame"] = frame_estimate(cfg, model, loop, dev, ms_step)
+        out["frame"] = frame_estimate(cfg, model, loop, dev, ms_step, stream if use_graph else None)
         log("frame estimate done")
     if world == 1 and args.cpu_rays > 0:
         out["cpu_baseline"] = cpu_baseline(cfg, loop, args.cpu_rays, args.cpu_iters)

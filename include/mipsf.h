@@ -204,6 +204,14 @@ int mipsf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq
                     float beta1, float beta2, float eps, float weight_decay, uint32_t step, int zero_grad,
                     void* stream);
 
+/* hipGraph-capturable form: the two step-dependent scalars {lr/bc1, 1/sqrt(bc2)} are read from `hyper_dev` (device,
+ * 2 floats) instead of being baked into the launch; mipsf_adam_advance increments the device step counter and
+ * refreshes them (enqueue it once per optimiser step, before the _ex calls). */
+int mipsf_adam_advance(int32_t* step_dev, float* hyper_dev, float lr, float beta1, float beta2, void* stream);
+int mipsf_adam_step_ex(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, uint32_t step,
+                       const float* hyper_dev, int zero_grad, void* stream);
+
 /* the same step over up to 16 small tensors that share one param group (one launch; used for the decoder) */
 #define MIPSF_ADAM_MAX_TENSORS 16
 typedef struct mipsf_adam_tensors {
@@ -216,6 +224,9 @@ typedef struct mipsf_adam_tensors {
 } mipsf_adam_tensors;
 int mipsf_adam_step_multi(const mipsf_adam_tensors* tensors_host_struct, float lr, float beta1, float beta2,
                           float eps, float weight_decay, uint32_t step, int zero_grad, void* stream);
+int mipsf_adam_step_multi_ex(const mipsf_adam_tensors* tensors_host_struct, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, uint32_t step, const float* hyper_dev, int zero_grad,
+                             void* stream);
 
 /* -------------------------------------------------- RandomOptimizer fitness (a12) */
 /* sdf [P,n] (column 3 of run_network output, stride `sdf_stride` floats) , valid [n] ->

@@ -62,7 +62,29 @@ __global__ __launch_bounds__(256) void normalise_bwd_kernel(const float* __restr
 // p, g, m, v streamed once: 16 B read + 12 B write per parameter (28 B with the fused zero-grad).
 struct AdamK {
     float lr_over_bc1, beta1, beta2, one_minus_b1, one_minus_b2, inv_sqrt_bc2, eps, wd;
+    const float* dev_hyper;   // when non-null: {lr/bc1, 1/sqrt(bc2)} are read from device memory (graph capture)
 };
+
+__device__ __forceinline__ AdamK resolve(AdamK k) {
+    if (k.dev_hyper) {
+        k.lr_over_bc1 = k.dev_hyper[0];
+        k.inv_sqrt_bc2 = k.dev_hyper[1];
+    }
+    return k;
+}
+
+// advances a device-resident step counter and refreshes the two step-dependent scalars (captured into hipGraphs)
+__global__ void adam_advance_kernel(int* __restrict__ step, float* __restrict__ hyper, float lr, float beta1,
+                                    float beta2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int t = step[0] + 1;
+        step[0] = t;
+        const double bc1 = 1.0 - pow((double)beta1, (double)t);
+        const double bc2 = 1.0 - pow((double)beta2, (double)t);
+        hyper[0] = (float)((double)lr / bc1);
+        hyper[1] = (float)(1.0 / sqrt(bc2));
+    }
+}
 
 __device__ __forceinline__ void adam1(float& p, float& g, float& m, float& v, const AdamK& k) {
     float gg = g;
@@ -76,7 +98,8 @@ __device__ __forceinline__ void adam1(float& p, float& g, float& m, float& v, co
 template <bool ZERO>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, uint64_t n,
-                                                   AdamK k) {
+                                                   AdamK k_in) {
+    const AdamK k = resolve(k_in);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t n4 = n / 4;
     float4* p4 = reinterpret_cast<float4*>(p);
@@ -114,7 +137,8 @@ struct AdamMulti {
 };
 
 template <bool ZERO>
-__global__ __launch_bounds__(256) void adam_multi_kernel(AdamMulti t, AdamK k) {
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamMulti t, AdamK k_in) {
+    const AdamK k = resolve(k_in);
     const int ti = blockIdx.y;
     float *p = t.p[ti], *g = t.g[ti], *m = t.m[ti], *v = t.v[ti];
     const uint64_t n = t.n[ti];
@@ -186,16 +210,11 @@ int mipsf_normalise_bwd(const float* dxn, const mipsf_render_cfg* cfg, float* dp
     return check_launch("normalise_bwd");
 }
 
-int mipsf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1,
-                    float beta2, float eps, float weight_decay, uint32_t step, int zero_grad, void* stream) {
-    if (n == 0) return 0;
-    MIPSF_REQUIRE(param && grad && exp_avg && exp_avg_sq, "null pointer");
-    MIPSF_REQUIRE(step >= 1, "step must be >= 1");
-    MIPSF_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
-                  "adam buffers must be 16-byte aligned");
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+static AdamK make_adam(float lr, float beta1, float beta2, float eps, float weight_decay, uint32_t step,
+                       const float* dev_hyper) {
     AdamK k;
+    const double bc1 = 1.0 - pow((double)beta1, (double)(step ? step : 1));
+    const double bc2 = 1.0 - pow((double)beta2, (double)(step ? step : 1));
     k.lr_over_bc1 = (float)((double)lr / bc1);
     k.beta1 = beta1;
     k.beta2 = beta2;
@@ -204,6 +223,32 @@ int mipsf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq
     k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     k.eps = eps;
     k.wd = weight_decay;
+    k.dev_hyper = dev_hyper;
+    return k;
+}
+
+int mipsf_adam_advance(int32_t* step_dev, float* hyper_dev, float lr, float beta1, float beta2, void* stream) {
+    MIPSF_REQUIRE(step_dev && hyper_dev, "null pointer");
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev, hyper_dev, lr, beta1,
+                       beta2);
+    return check_launch("adam_advance");
+}
+
+int mipsf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, uint32_t step, int zero_grad, void* stream) {
+    return mipsf_adam_step_ex(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, nullptr,
+                              zero_grad, stream);
+}
+
+int mipsf_adam_step_ex(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, uint32_t step, const float* hyper_dev,
+                       int zero_grad, void* stream) {
+    if (n == 0) return 0;
+    MIPSF_REQUIRE(param && grad && exp_avg && exp_avg_sq, "null pointer");
+    MIPSF_REQUIRE(step >= 1 || hyper_dev, "step must be >= 1 (or hyper_dev given)");
+    MIPSF_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+                  "adam buffers must be 16-byte aligned");
+    const AdamK k = make_adam(lr, beta1, beta2, eps, weight_decay, step, hyper_dev);
     uint64_t want = (n / 4 + 255) / 256;
     uint32_t blocks = (uint32_t)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
     if (zero_grad)
@@ -217,10 +262,15 @@ int mipsf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq
 
 int mipsf_adam_step_multi(const mipsf_adam_tensors* t, float lr, float beta1, float beta2, float eps,
                           float weight_decay, uint32_t step, int zero_grad, void* stream) {
+    return mipsf_adam_step_multi_ex(t, lr, beta1, beta2, eps, weight_decay, step, nullptr, zero_grad, stream);
+}
+
+int mipsf_adam_step_multi_ex(const mipsf_adam_tensors* t, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, uint32_t step, const float* hyper_dev, int zero_grad, void* stream) {
     MIPSF_REQUIRE(t != nullptr, "null tensor table");
     if (t->count == 0) return 0;
     MIPSF_REQUIRE(t->count <= MIPSF_ADAM_MAX_TENSORS, "too many tensors (%u)", t->count);
-    MIPSF_REQUIRE(step >= 1, "step must be >= 1");
+    MIPSF_REQUIRE(step >= 1 || hyper_dev, "step must be >= 1 (or hyper_dev given)");
     AdamMulti a;
     uint64_t nmax = 0;
     for (uint32_t i = 0; i < MIPSF_ADAM_MAX_TENSORS; ++i) {
@@ -233,14 +283,7 @@ int mipsf_adam_step_multi(const mipsf_adam_tensors* t, float lr, float beta1, fl
             nmax = a.n[i] > nmax ? a.n[i] : nmax;
         }
     }
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    AdamK k;
-    k.lr_over_bc1 = (float)((double)lr / bc1);
-    k.beta1 = beta1, k.beta2 = beta2;
-    k.one_minus_b1 = (float)(1.0 - (double)beta1), k.one_minus_b2 = (float)(1.0 - (double)beta2);
-    k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    k.eps = eps, k.wd = weight_decay;
+    const AdamK k = make_adam(lr, beta1, beta2, eps, weight_decay, step, hyper_dev);
     uint64_t bx = (nmax + 255) / 256;
     if (bx > 64) bx = 64;
     if (bx < 1) bx = 1;

@@ -107,6 +107,11 @@ __global__ __launch_bounds__(PR_BLOCK) void pose_rays_bwd_kernel(const float* __
     }
 }
 
+__global__ void pose_zero_kernel(float* __restrict__ p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
 // chain through R(q) = I + s A(q), s = 2/|q|^2 (pytorch3d quaternion_to_matrix, not assuming unit norm)
 __global__ void pose_chain_kernel(const float* __restrict__ rot, const float* __restrict__ acc, int F, int K,
                                   float* __restrict__ d_rot, float* __restrict__ d_trans) {
@@ -159,10 +164,9 @@ int mipsf_pose_rays_bwd(const float* g_rays_o, const float* g_rays_d, const floa
     MIPSF_REQUIRE(F + K <= PR_MAX_POSES, "number of poses %u above %d", F + K, PR_MAX_POSES);
     hipStream_t s = (hipStream_t)stream;
     const int P = (int)(F + K);
-    if (hipMemsetAsync(scratch, 0, sizeof(float) * 12 * P, s) != hipSuccess) {
-        set_error("hipMemsetAsync failed");
-        return 2;
-    }
+    // (a kernel, not hipMemsetAsync: memset nodes recorded from the autograd thread crash hipStreamEndCapture on ROCm 7.2)
+    hipLaunchKernelGGL(pose_zero_kernel, dim3((12 * P + 255) / 256), dim3(256), 0, s, scratch, 12 * P);
+    if (int e = check_launch("pose_zero")) return e;
     if (N > 0) {
         hipLaunchKernelGGL(pose_rays_bwd_kernel, dim3((N + PR_BLOCK - 1) / PR_BLOCK), dim3(PR_BLOCK), 0, s, g_rays_o,
                            g_rays_d, d_cam, owner, P, scratch, N);

@@ -332,13 +332,21 @@ def pose_rays(rot, trans, fixed_poses, owner, d_cam):
 
 
 # ----------------------------------------------------------------------------------- Adam
-def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, zero_grad=False):
+def adam_advance(step_dev, hyper_dev, lr, beta1, beta2):
+    check(lib().mipsf_adam_advance(dptr(step_dev, torch.int32), dptr(hyper_dev), lr, beta1, beta2, stream_ptr()),
+          "adam_advance")
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, zero_grad=False,
+              hyper_dev=None):
     with _timed("adam_step" if param.numel() > (1 << 20) else "adam_step_small"):
-        check(lib().mipsf_adam_step(dptr(param), dptr(grad), dptr(exp_avg), dptr(exp_avg_sq), param.numel(), lr, beta1,
-                                    beta2, eps, weight_decay, step, 1 if zero_grad else 0, stream_ptr()), "adam_step")
+        check(lib().mipsf_adam_step_ex(dptr(param), dptr(grad), dptr(exp_avg), dptr(exp_avg_sq), param.numel(), lr,
+                                       beta1, beta2, eps, weight_decay, step, dptr(hyper_dev),
+                                       1 if zero_grad else 0, stream_ptr()), "adam_step")
 
 
-def adam_step_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, weight_decay, step, zero_grad=False):
+def adam_step_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, weight_decay, step, zero_grad=False,
+                    hyper_dev=None):
     """One launch for a group of (small) tensors sharing hyper-parameters and step count."""
     for i in range(0, len(params), _lib.ADAM_MAX_TENSORS):
         chunk = slice(i, i + _lib.ADAM_MAX_TENSORS)
@@ -348,8 +356,9 @@ def adam_step_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps,
             t.param[j], t.grad[j], t.exp_avg[j], t.exp_avg_sq[j] = dptr(p), dptr(g), dptr(m), dptr(v)
             t.numel[j] = p.numel()
         with _timed("adam_step_small"):
-            check(lib().mipsf_adam_step_multi(C.byref(t), lr, beta1, beta2, eps, weight_decay, step,
-                                              1 if zero_grad else 0, stream_ptr()), "adam_step_multi")
+            check(lib().mipsf_adam_step_multi_ex(C.byref(t), lr, beta1, beta2, eps, weight_decay, step,
+                                                 dptr(hyper_dev), 1 if zero_grad else 0, stream_ptr()),
+                  "adam_step_multi")
 
 
 def ro_fitness(raw, target_d, trunc: float) -> torch.Tensor:

@@ -1,15 +1,28 @@
 """``FusedAdam``: drop-in for ``torch.optim.Adam`` as the reference configures it (mipsfusion.py:580-584,
 InactiveMap.py:53-57): per-group lr / eps / weight_decay (L2 added to the gradient, not AdamW), betas, DENSE
-semantics (moments decay and parameters move where the gradient is zero).  One HIP kernel per parameter tensor
-streams p, g, m, v once (28 B per parameter with the fused zero-grad)."""
+semantics (moments decay and parameters move where the gradient is zero).  One HIP kernel per large tensor streams
+p, g, m, v once (28 B per parameter with the fused zero-grad); a group's small tensors share one launch.
+
+``capturable=True`` keeps the step counter and the two step-dependent scalars in device memory so that
+``step()`` can be captured into a hipGraph (``torch.cuda.graph``) and replayed."""
 import torch
 
 from . import ops
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.capturable = capturable
+        self._dev = {}          # group index -> (step int32[1], hyper float[2]) when capturable
+
+    def _ensure_state(self, p):
+        st = self.state[p]
+        if not st:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        return st
 
     @torch.no_grad()
     def step(self, closure=None, zero_grad=False):
@@ -19,25 +32,33 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
-            small = []
-            for p in group["params"]:
-                if p.grad is None or p.numel() == 0:
-                    continue
+            live = [p for p in group["params"] if p.grad is not None and p.numel() > 0]
+            if not live:
+                continue
+            for p in live:
                 if not p.is_cuda:
                     raise RuntimeError("FusedAdam runs on GPU parameters only (no CPU fallback)")
+                self._ensure_state(p)["step"] += 1
+            hyper = None
+            if self.capturable:
+                # one device-resident counter per group (all its tensors step together)
+                if gi not in self._dev:
+                    dev = live[0].device
+                    start = self.state[live[0]]["step"] - 1
+                    self._dev[gi] = (torch.full((1,), start, dtype=torch.int32, device=dev),
+                                     torch.zeros(2, dtype=torch.float32, device=dev))
+                step_dev, hyper = self._dev[gi]
+                ops.adam_advance(step_dev, hyper, group["lr"], b1, b2)
+            small = []
+            for p in live:
                 st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st["step"] += 1
                 if p.numel() < (1 << 18):
                     small.append(p)
                     continue
                 ops.adam_step(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"],
-                              group["weight_decay"], st["step"], zero_grad)
+                              group["weight_decay"], st["step"], zero_grad, hyper_dev=hyper)
             # small tensors of a group (the decoder's ten nn.Linear tensors) share one launch per step count
             by_step = {}
             for p in small:
@@ -45,5 +66,6 @@ class FusedAdam(torch.optim.Optimizer):
             for step, ps in by_step.items():
                 ops.adam_step_multi([p.data for p in ps], [p.grad for p in ps],
                                     [self.state[p]["exp_avg"] for p in ps], [self.state[p]["exp_avg_sq"] for p in ps],
-                                    group["lr"], b1, b2, group["eps"], group["weight_decay"], step, zero_grad)
+                                    group["lr"], b1, b2, group["eps"], group["weight_decay"], step, zero_grad,
+                                    hyper_dev=hyper)
         return loss

@@ -455,6 +455,41 @@ def test_ba_loop_trace_matches_reference(dev):
     assert_close(m.decoder.pts_linear[2].weight, g["w1.decoder.pts_linear.2.weight"], 5e-3, "decoder after 6 steps")
 
 
+def test_hipgraph_replay_matches_eager_iterations(dev):
+    """Capturing fwd+bwd+FusedAdam(capturable) into a hipGraph and replaying it must give the parameters eager
+    execution gives (same inputs, same number of steps)."""
+    from mipsfusion_amd.graph import GraphedSteps
+    g = load_golden("scene_cfg1.npz")
+    cfg = cfg_for("scene_cfg1.npz")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        inputs = [T(g[k]).to(dev) for k in ("rays_o", "rays_d", "target_rgb", "target_d", "noise")]
+
+        def make():
+            m = make_scene(g, cfg, dev).train()
+            opt = FusedAdam([{"params": m.decoder.parameters(), "weight_decay": 1e-6, "lr": 0.01},
+                             {"params": m.embed_fn.parameters(), "eps": 1e-15, "lr": 0.01}], betas=(0.9, 0.99),
+                            capturable=True)
+
+            def step(_k=0):
+                ret = m.forward(*inputs[:4], noise=inputs[4])
+                path_cpu.total_loss(ret, cfg["training"]).backward()
+                opt.step(zero_grad=True)
+            return m, step
+
+        m_eager, step_eager = make()
+        for _ in range(5):
+            step_eager()
+        m_graph, step_graph = make()
+        graphed = GraphedSteps(step_graph, 1, warmup=2, stream=side)      # 2 warm-up steps ran; capture only records
+        for _ in range(3):
+            graphed.replay()                                               # 5 steps in total
+        torch.cuda.synchronize()
+    for (k, a), (_, b) in zip(m_graph.named_parameters(), m_eager.named_parameters()):
+        if a.numel():
+            assert_grad_close(a, b, 1e-5, "after 5 steps: " + k)
+
+
 # ------------------------------------------------------------- full-size property checks
 def headline_scene(dev, hash_size=19):
     cfg = synth.config_headline()
