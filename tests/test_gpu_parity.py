@@ -309,6 +309,100 @@ def test_frozen_map_skips_param_grads_but_keeps_pose_grads(dev):
     assert all(prm.grad is None for prm in m.parameters())
 
 
+def test_random_optimizer_fitness_slice(dev):
+    """a12: RandomOptimizer.get_fitness (RandomOptimizer.py:113-131): P particles x n surface points, forward-only
+    run_network, masked mean |sdf * trunc| * 1000 -- against the oracle."""
+    g = load_golden("scene_cfg1.npz")
+    cfg = cfg_for("scene_cfg1.npz")
+    m = make_scene(g, cfg, dev).eval()
+    cpu = path_cpu.CpuScene(cfg, g["bound"], g["half_len"])
+    cpu.load_state_dict({k[2:]: T(g[k]) for k in g.files if k.startswith("w.")})
+    torch.manual_seed(3)
+    P, n = 37, 100                                   # ragged on purpose
+    world = torch.rand(P, n, 3) * 1.6 - 0.8
+    td = torch.rand(n, 1) * 2
+    td[::9] = 0.0                                    # invalid depth pixels are masked out
+    trunc = cfg["training"]["trunc"]
+    with torch.no_grad():
+        ref_sdf = cpu.run_network(world)[..., 3:4].squeeze(-1) * trunc
+        valid = (td > 0).float().squeeze(-1)[None]
+        ref = torch.mean(valid * ref_sdf.abs(), dim=-1)
+        got = ops.ro_fitness(m.run_network(world.to(dev)), td.squeeze(-1).to(dev), trunc)
+    assert_close(got * 1000.0, ref * 1000.0, 1e-4, "fitness")
+
+
+def test_centre_length_normalisation_and_hash16_vs_oracle(dev):
+    """FastCaMo-large style submap (BASELINE config 4): hash 2^16, use_bound_normalize False -> (x + L) / 2L
+    (scene_rep.py:142), one training iteration against the oracle."""
+    cfg = synth.config_large_submap()
+    cfg["training"].update(n_samples_d=11, n_range_d=5, n_samples=16)
+    bb = torch.from_numpy(np.array(cfg["mapping"]["bound"]))
+    nf = torch.from_numpy(np.array(cfg["mapping"]["localMLP_max_len"]))
+    torch.manual_seed(5)
+    m = JointEncoding(cfg, bb, nf).to(dev).train()
+    with torch.no_grad():
+        m.embed_fn.params.copy_((torch.randn(m.embed_fn.params.shape) * 0.2).to(dev))
+    cpu = path_cpu.CpuScene(cfg, bb, nf)
+    cpu.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    frame = synth.make_frame(cfg, seed=2)
+    H, W = frame["depth"].shape
+    idx = torch.randperm(H * W)[:333]                # ragged ray count
+    ro, rd, rgb, d = synth.ray_batch(frame, idx, frame["c2w"])
+    noise = torch.rand(333, 16)
+    ret = m.forward(ro.to(dev), rd.to(dev), rgb.to(dev), d.to(dev), noise=noise.to(dev))
+    ref = cpu.train_forward(ro, rd, rgb, d, noise, 0.01)
+    for k in ("rgb", "depth", "rgb_loss", "depth_loss", "sdf_loss", "fs_loss"):
+        assert_close(ret[k], ref[k], 1e-4, k)
+    path_cpu.total_loss(ret, cfg["training"]).backward()
+    path_cpu.total_loss(ref, cfg["training"]).backward()
+    assert_grad_close(m.embed_fn.params.grad, cpu.embed_fn.params.grad, 5e-4, "grid gradient (hash 2^16)")
+
+
+@pytest.mark.parametrize("n_rays", [1, 3, 65])
+def test_ragged_ray_counts_and_empty_batch(dev, n_rays):
+    g = load_golden("scene_cfg1.npz")
+    cfg = cfg_for("scene_cfg1.npz")
+    m = make_scene(g, cfg, dev).train()
+    cpu = path_cpu.CpuScene(cfg, g["bound"], g["half_len"])
+    cpu.load_state_dict({k[2:]: T(g[k]) for k in g.files if k.startswith("w.")})
+    sl = slice(0, n_rays)
+    args = [T(g[k])[sl] for k in ("rays_o", "rays_d", "target_rgb", "target_d")]
+    noise = T(g["noise"])[sl]
+    ret = m.forward(*[a.to(dev) for a in args], noise=noise.to(dev))
+    ref = cpu.train_forward(*args, noise, 0.01)
+    for k in ("rgb", "depth", "rgb_loss", "sdf_loss", "fs_loss"):
+        assert_close(ret[k], ref[k], 1e-4, f"{k} (N={n_rays})")
+    path_cpu.total_loss(ret, cfg["training"]).backward()
+    assert torch.isfinite(m.embed_fn.params.grad).all()
+    # empty batch: every entry point returns without launching
+    empty = [a[:0].to(dev) for a in args]
+    m.eval()
+    with torch.no_grad():
+        out = m.forward(empty[0], empty[1], None, empty[3], noise=noise[:0].to(dev))
+    assert out["rgb"].shape == (0, 3) and out["raw"].shape == (0, 16, 10)
+
+
+def test_maximum_samples_per_ray(dev):
+    """S = 256 is the most a ray kernel accepts (4 samples per lane); S = 257 is refused with an error."""
+    g = load_golden("scene_cfg1.npz")
+    cfg = cfg_for("scene_cfg1.npz")
+    cfg["training"].update(n_samples_d=200, n_range_d=56, n_samples=256)
+    m = make_scene(g, cfg, dev).eval()
+    cpu = path_cpu.CpuScene(cfg, g["bound"], g["half_len"])
+    cpu.load_state_dict({k[2:]: T(g[k]) for k in g.files if k.startswith("w.")})
+    ro, rd, td = (T(g[k])[:40] for k in ("rays_o", "rays_d", "target_d"))
+    noise = torch.rand(40, 256)
+    with torch.no_grad():
+        out = m.forward(ro.to(dev), rd.to(dev), None, td.to(dev), noise=noise.to(dev))
+        ref = cpu.render_rays(ro, rd, td, noise)
+    assert np.array_equal(out["z_vals"].cpu().numpy(), ref["z_vals"].numpy())
+    assert_close(out["depth"], ref["depth"], 1e-4, "depth at S=256")
+    cfg["training"].update(n_samples_d=201)
+    m2 = make_scene(g, cfg, dev).eval()
+    with pytest.raises(RuntimeError, match="samples per ray"):
+        m2.forward(ro.to(dev), rd.to(dev), None, td.to(dev), noise=torch.rand(40, 257, device=dev))
+
+
 def test_no_valid_depth_gives_nan_losses_like_reference(dev):
     g = load_golden("scene_cfg1.npz")
     m = make_scene(g, cfg_for("scene_cfg1.npz"), dev).train()
