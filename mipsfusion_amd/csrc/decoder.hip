@@ -5,8 +5,9 @@
 //   decoder_pack_kernel    nn.Linear weights -> MFMA A-operand images (decoder_layout.h)
 //   decoder_fwd_kernel     one wave = 32 samples; the 51->128->128->{115->3, 96->128->5} chain stays in
 //                          accumulator registers from the positional encoding to the softmax (no LDS).
-//   decoder_bwd_kernel     same structure for the activation-gradient chain; emits d(feat), d(x) and the
-//                          pre-activation gradients the weight-gradient kernel needs.
+//   decoder_bwd_lds_kernel activation-gradient chain; each gradient tile is staged in a per-wave LDS buffer that
+//                          feeds the next layer's B operand; emits d(feat), d(x) and the pre-activation
+//                          gradients the weight-gradient kernel needs.
 //   decoder_wgrad_kernel   dW = dOut^T * In as MFMA GEMMs whose reduction index is the SAMPLE: a block of
 //                          4 waves transposes 128 samples through LDS, each wave owns 11 of the 44 output
 //                          tiles and keeps them in registers across its whole share of the batch.
@@ -25,6 +26,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr float PI_F = 3.14159265358979323846f;
 constexpr float HALF_PI_F = 1.57079632679489661923f;
 constexpr int DEC_BLOCK = 256;
+#ifndef MIPSF_PIN_ARG
+#define MIPSF_PIN_ARG 0          // experiments only: 1 skips the trickled stores (wrong results, timing)
+#endif
+
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -94,12 +99,18 @@ __device__ __forceinline__ void store_act(float* __restrict__ dst, int64_t tile,
                 make_float4(acc[rt][4 * g], acc[rt][4 * g + 1], acc[rt][4 * g + 2], acc[rt][4 * g + 3]);
 }
 
+// 16-byte activation store (non-temporal stores were tried: no change)
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16(float4* p, const float4& v) {
+    *p = v;
+}
+
 // group q in [0,16): row tile q>>2, registers 4*(q&3) .. +3
 __device__ __forceinline__ void store_act_piece(float* __restrict__ dst, int64_t tile, int mat, int lane,
                                                 const f32x16 (&acc)[4], int q) {
     const int rt = q >> 2, g = q & 3;
-    reinterpret_cast<float4*>(dst)[(tile * (ACT_SLOTS / 4) + mat * 16 + q) * 64 + lane] =
-        make_float4(acc[rt][4 * g], acc[rt][4 * g + 1], acc[rt][4 * g + 2], acc[rt][4 * g + 3]);
+    store16(reinterpret_cast<float4*>(dst) + (tile * (ACT_SLOTS / 4) + mat * 16 + q) * 64 + lane,
+            make_float4(acc[rt][4 * g], acc[rt][4 * g + 1], acc[rt][4 * g + 2], acc[rt][4 * g + 3]));
 }
 
 __device__ __forceinline__ void load_act_piece(const float* __restrict__ src, int64_t tile, int mat, int lane,
@@ -266,19 +277,77 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_fwd_kernel(const float* 
 
 // ============================================================================ backward chain
 // dsmall[s*8 + {0..4}] = d logits, {5..7} = d rgb (inputs of the two small weight-gradient GEMMs)
+__device__ __forceinline__ void zero_acc3(f32x16 (&a)[3]) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[q][r] = 0.0f;
+}
+__device__ __forceinline__ void zero_acc4(f32x16 (&a)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[q][r] = 0.0f;
+}
+
+// ---------------------------------------------------------------------------- backward chain (LDS-staged)
+// Every pre-activation gradient tile goes through a per-wave LDS buffer instead of staying in registers (the first
+// version chained accumulators register-to-register like the forward kernel and needed 460 registers): the B
+// operand of k-step group t4 is ONE ds_read_b128 (rows 8*t4 + 4h + {0..3} of this lane's sample), which is also
+// exactly the 16-byte piece the weight-gradient kernel wants in `dact`.  196 registers -> two blocks share a CU and
+// one wave's scalar sections (softmax backward, frequency chain, HBM latency at tile start) hide under the other
+// wave's matrix work.  Measured on MI355X (4096x64 samples): 297 us register-chained -> 251 us.
+constexpr int XB_ENTRIES = 32 * 32;                  // float4 entries per wave: [group 2*t4+h][sample j]
+
+template <int RT, int T, typename SideFn>
+__device__ __forceinline__ void mfma_layer_b4(const float4* __restrict__ img, int lane, f32x16 (&acc)[RT],
+                                              const float4* xb, SideFn side) {
+    constexpr int T4 = T / 4;
+    float4 a[RT], nxt[RT], b, nb;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a[rt] = img[(rt * T4) * 64 + lane];
+    b = xb[0];
+#pragma unroll
+    for (int t4 = 0; t4 < T4; ++t4) {
+        if (t4 + 1 < T4) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) nxt[rt] = img[(rt * T4 + t4 + 1) * 64 + lane];
+            nb = xb[(t4 + 1) * 64];
+        }
+        side(t4, b);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma(a[rt].x, b.x, acc[rt]);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma(a[rt].y, b.y, acc[rt]);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma(a[rt].z, b.z, acc[rt]);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma(a[rt].w, b.w, acc[rt]);
+        if (t4 + 1 < T4) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) a[rt] = nxt[rt];
+            b = nb;
+        }
+    }
+}
+
 template <bool PE_INTERNAL, int LAYOUT>
-__global__ __launch_bounds__(DEC_BLOCK) void decoder_bwd_kernel(
+__global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
     const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ out,
     const float* __restrict__ dout, const float* __restrict__ saved, float* __restrict__ dfeat,
     float* __restrict__ dx, float* __restrict__ dembed_pos, float* __restrict__ dact, float* __restrict__ dsmall,
     uint32_t M, int pin) {
+    __shared__ float4 xb_all[(DEC_BLOCK / 64) * XB_ENTRIES];
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + (threadIdx.x >> 6);
     if (tile * 32 >= (int64_t)M) return;
+    float4* xb = xb_all + (threadIdx.x >> 6) * XB_ENTRIES + h * 32 + j;      // piece p of this lane: xb[p * 64]
     const uint32_t s_raw = (uint32_t)(tile * 32 + j);
     const bool live = s_raw < M;
     const uint32_t s = live ? s_raw : M - 1;
+    const float4* sv4 = reinterpret_cast<const float4*>(saved) + (size_t)tile * (ACT_SLOTS / 4) * 64 + lane;
+    float4* da4 = reinterpret_cast<float4*>(dact) + (size_t)tile * (ACT_SLOTS / 4) * 64 + lane;
 
     // ---- softmax / entropy / expected-class backward -> d logits; d rgb is the incoming gradient itself
     float dlg[N_CLASS], drgb[3];
@@ -306,32 +375,32 @@ __global__ __launch_bounds__(DEC_BLOCK) void decoder_bwd_kernel(
         }
     }
 
-    // ---- dG3 = relu'(H3) * (Ws2^T dlogits)   (vector ALU, K = 5)
-    f32x16 dG3[4];
+    // ---- dG3 = relu'(H3) * (Ws2^T dlogits)   (vector ALU, K = 5), one 16-byte piece at a time into LDS
     {
-        f32x16 H3[4];
-        load_act(saved, tile, 2, lane, H3);
         const float4* ts2 = reinterpret_cast<const float4*>(packed + OFF_TS2) + h * 128;
 #pragma unroll
-        for (int slot = 0; slot < 64; ++slot) {
-            const float4 w0 = ts2[2 * slot], w1 = ts2[2 * slot + 1];
-            float v = w0.x * dlg[0];
-            v = fmaf(w0.y, dlg[1], v), v = fmaf(w0.z, dlg[2], v), v = fmaf(w0.w, dlg[3], v), v = fmaf(w1.x, dlg[4], v);
-            dG3[slot >> 4][slot & 15] = H3[slot >> 4][slot & 15] > 0.0f ? v : 0.0f;
+        for (int p = 0; p < 16; ++p) {
+            const float4 hm = sv4[(2 * 16 + p) * 64];
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int slot = 4 * p + i;
+                const float4 w0 = ts2[2 * slot], w1 = ts2[2 * slot + 1];
+                float t = w0.x * dlg[0];
+                t = fmaf(w0.y, dlg[1], t), t = fmaf(w0.z, dlg[2], t), t = fmaf(w0.w, dlg[3], t), t = fmaf(w1.x, dlg[4], t);
+                v[i] = t;
+            }
+            xb[p * 64] = make_float4(hm.x > 0.0f ? v[0] : 0.0f, hm.y > 0.0f ? v[1] : 0.0f, hm.z > 0.0f ? v[2] : 0.0f,
+                                     hm.w > 0.0f ? v[3] : 0.0f);
         }
     }
 
     // ---- d[sdf_emb | grid] = Ws1^T dG3   (3 row tiles: 0,1 -> d sdf_emb, 2 -> d grid features)
     f32x16 dIn3[3];
-#pragma unroll
-    for (int rt = 0; rt < 3; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dIn3[rt][r] = 0.0f;
-    mfma_layer<RT_B3, T_B3>(reinterpret_cast<const float4*>(packed + OFF_B3), lane, dIn3,
-                            [&](int t) { return dG3[t >> 4][t & 15]; },
-                            [&](int t4) { if (pin == 0) store_act_piece(dact, tile, 2, lane, dG3, t4); });
+    zero_acc3(dIn3);
+    mfma_layer_b4<RT_B3, T_B3>(reinterpret_cast<const float4*>(packed + OFF_B3), lane, dIn3, xb,
+                               [&](int t4, const float4& b) { if (pin == 0) store16(da4 + (2 * 16 + t4) * 64, b); });
     if (live) {
-        // regs (r, r+1), r even, hold (level, f=0/1) of grid feature row rowmap(r,h) -> one 8-byte store each
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             const int row = rowmap(r, h);
@@ -343,42 +412,42 @@ __global__ __launch_bounds__(DEC_BLOCK) void decoder_bwd_kernel(
         }
     }
 
-    // ---- dH2 = [d sdf_emb (from above) | d rgb_emb = Wrgb^T drgb]; also the rgb branch's share of d e
-    f32x16 dH2[4];
-    dH2[0] = dIn3[0];
-    dH2[1] = dIn3[1];
-    float de[E_SLOTS];
-    {
-        const float4* trgb = reinterpret_cast<const float4*>(packed + OFF_TRGB) + h * TRGB_SLOTS;
+    // ---- dH2 = [d sdf_emb (from above) | d rgb_emb = Wrgb^T drgb] -> LDS
+    const float4* trgb = reinterpret_cast<const float4*>(packed + OFF_TRGB) + h * TRGB_SLOTS;
 #pragma unroll
-        for (int slot = 0; slot < 32; ++slot) {
-            const float4 wv = trgb[slot];
-            dH2[2 + (slot >> 4)][slot & 15] = fmaf(wv.z, drgb[2], fmaf(wv.y, drgb[1], wv.x * drgb[0]));
-        }
+    for (int p = 0; p < 8; ++p) {
+        const int rt = p >> 2, g = p & 3;
+        xb[p * 64] = make_float4(dIn3[rt][4 * g], dIn3[rt][4 * g + 1], dIn3[rt][4 * g + 2], dIn3[rt][4 * g + 3]);
+    }
 #pragma unroll
-        for (int t = 0; t < E_SLOTS; ++t) {
-            const float4 wv = trgb[32 + t];
-            de[t] = fmaf(wv.z, drgb[2], fmaf(wv.y, drgb[1], wv.x * drgb[0]));
+    for (int p = 8; p < 16; ++p) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 wv = trgb[4 * (p - 8) + i];
+            v[i] = fmaf(wv.z, drgb[2], fmaf(wv.y, drgb[1], wv.x * drgb[0]));
         }
+        xb[p * 64] = make_float4(v[0], v[1], v[2], v[3]);
     }
 
     // ---- dG1 = relu'(H1) * (W2^T dH2)   (dH2 goes out, H1 comes in, one 16-byte group per k-group)
-    f32x16 dG1[4];
-    f32x16 H1[4];
+    {
+        f32x16 dG1[4];
+        float4 H1p[16];
+        zero_acc4(dG1);
+        mfma_layer_b4<RT_B2, T_B2>(reinterpret_cast<const float4*>(packed + OFF_B2), lane, dG1, xb,
+                                   [&](int t4, const float4& b) {
+                                       H1p[t4] = sv4[(0 * 16 + t4) * 64];
+                                       if (pin == 0) store16(da4 + (1 * 16 + t4) * 64, b);
+                                   });
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dG1[rt][r] = 0.0f;
-    mfma_layer<RT_B2, T_B2>(reinterpret_cast<const float4*>(packed + OFF_B2), lane, dG1,
-                            [&](int t) { return dH2[t >> 4][t & 15]; },
-                            [&](int t4) {
-                                load_act_piece(saved, tile, 0, lane, H1, t4);
-                                if (pin == 0) store_act_piece(dact, tile, 1, lane, dH2, t4);
-                            });
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dG1[rt][r] = H1[rt][r] > 0.0f ? dG1[rt][r] : 0.0f;
+        for (int p = 0; p < 16; ++p) {
+            const int rt = p >> 2, g = p & 3;
+            xb[p * 64] = make_float4(H1p[p].x > 0.0f ? dG1[rt][4 * g] : 0.0f, H1p[p].y > 0.0f ? dG1[rt][4 * g + 1] : 0.0f,
+                                     H1p[p].z > 0.0f ? dG1[rt][4 * g + 2] : 0.0f,
+                                     H1p[p].w > 0.0f ? dG1[rt][4 * g + 3] : 0.0f);
+        }
+    }
 
     // ---- d e = W1^T dG1 (+ rgb share); rows are arranged so that e-slot (t, h) lands in THIS lane
     f32x16 dE[2];
@@ -386,14 +455,16 @@ __global__ __launch_bounds__(DEC_BLOCK) void decoder_bwd_kernel(
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dE[rt][r] = 0.0f;
-    mfma_layer<RT_B1, T_B1>(reinterpret_cast<const float4*>(packed + OFF_B1), lane, dE,
-                            [&](int t) { return dG1[t >> 4][t & 15]; },
-                            [&](int t4) { if (pin == 0) store_act_piece(dact, tile, 0, lane, dG1, t4); });
+    mfma_layer_b4<RT_B1, T_B1>(reinterpret_cast<const float4*>(packed + OFF_B1), lane, dE, xb,
+                               [&](int t4, const float4& b) { if (pin == 0) store16(da4 + (0 * 16 + t4) * 64, b); });
+    float de[E_SLOTS];
 #pragma unroll
-    for (int t = 0; t < E_SLOTS; ++t) de[t] = de[t] + dE[t >> 4][t & 15];
+    for (int t = 0; t < E_SLOTS; ++t) {
+        const float4 wv = trgb[32 + t];
+        de[t] = fmaf(wv.z, drgb[2], fmaf(wv.y, drgb[1], wv.x * drgb[0])) + dE[t >> 4][t & 15];
+    }
 
     if (PE_INTERNAL) {
-        // chain through the frequency encoding: d sin(2^k pi x + phase)/dx = 2^k pi cos(.)
         const float x0 = x[3 * (size_t)s], x1 = x[3 * (size_t)s + 1], x2 = x[3 * (size_t)s + 2];
         float gx[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -675,6 +746,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
     }
 }
 
+
 struct GradPtrs {
     float* p[10];   // order of the G_* record: w_pts0 b_pts0 w_pts2 b_pts2 w_rgb0 b_rgb0 w_sdf0 b_sdf0 w_sdf2 b_sdf2
 };
@@ -777,7 +849,7 @@ int mipsf_decoder_bwd_chain(const float* packed, int feat_layout, const float* x
     const uint32_t blocks = (uint32_t)((n_wave_tiles(M) + 3) / 4);
     float* dsmall = dact + n_block_tiles(M) * 4 * ACT_TILE_FLOATS;
 #define BWD(PE, LAY) \
-    hipLaunchKernelGGL((decoder_bwd_kernel<PE, LAY>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed, x, out, dout, saved, dfeat, dx, dembed_pos, dact, dsmall, M, 0)
+    hipLaunchKernelGGL((decoder_bwd_lds_kernel<PE, LAY>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed, x, out, dout, saved, dfeat, dx, dembed_pos, dact, dsmall, M, MIPSF_PIN_ARG)
     if (pe_mode == 0) { if (feat_layout == MIPSF_FEAT_AOS) BWD(true, MIPSF_FEAT_AOS); else BWD(true, MIPSF_FEAT_LEVEL_MAJOR); }
     else { if (feat_layout == MIPSF_FEAT_AOS) BWD(false, MIPSF_FEAT_AOS); else BWD(false, MIPSF_FEAT_LEVEL_MAJOR); }
 #undef BWD
