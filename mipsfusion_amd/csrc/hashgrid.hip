@@ -152,87 +152,208 @@ __global__ __launch_bounds__(HG_BLOCK) void hashgrid_fwd_kernel(const float* __r
 // ----------------------------------------------------------------------------- backward
 // dL/dparams is a scatter of 16 floats per (sample, level).  Global fp32 atomics top out at ~18 G atomics/s on
 // MI355X whatever the access pattern (measured: 4.0 ms for the 67 M atomics of a 4096x64 batch), so the scatter
-// target is moved ON CHIP: the 256 CUs own 40 MiB of LDS, more than the whole 34.4 MiB gradient table.
-//   * a level's table is cut into slices of <= 20480 entries (160 KiB of float2);
-//   * one workgroup owns one slice: it scans the samples of that level, recomputes the 8 corner indices and
-//     accumulates the contributions that fall into its slice with LDS atomics (ds_add_f32);
-//   * it then adds its slice to dparams with coalesced read-modify-writes -- no global atomics, no inter-workgroup
-//     communication, nothing placement dependent;
-//   * coarse levels (few slices, every sample hits, long same-cell runs => LDS conflicts) are additionally split
-//     over the SAMPLES; such workgroups write partial slices to scratch and a reduce kernel folds them in.
-// Redundant index computation (each sample is visited by every slice owner of its level) is ALU work the chip has
-// to spare; HBM traffic stays at x + dL/dy + one read-modify-write of the table.
+// target is moved ON CHIP: the 256 CUs own 40 MiB of LDS.
+//   * a level's table is cut into slices of <= 10240 entries (160 KiB of fp64 pairs) -- one "bin" per slice;
+//   * ROUTE: every (sample, level) is sent to the bins its 8 corners fall into (count -> scan -> fill; a record
+//     is the sample index, duplicates inside a bin are merged), so that no workgroup ever looks at a sample
+//     that does not touch its slice.  (The first version let every slice owner scan ALL samples of its level:
+//     52 x redundant index arithmetic on the hashed levels, 640 us.)
+//   * ACCUMULATE: one workgroup per (bin, part of <= 32768 records) re-derives the corners of its samples and
+//     adds the contributions that fall into its slice with LDS atomics in fp64.  ds_add_f64 runs at ~0.33 cycles
+//     per lane-op per CU on gfx950, ds_add_f32 at 3.0 (serialised lane by lane; tools/micro/lds_atomic.hip), and
+//     fp64 sums make the result independent of the arrival order to fp32 precision;
+//   * the slice is added to dparams with coalesced read-modify-writes; bins with several parts go through
+//     partial slices and a reduce kernel.  No global float atomics, no inter-workgroup communication.
 constexpr int SC_BLOCK = 1024;
-constexpr uint32_t SC_MAX_SLICE = 20480;            // entries: 20480 * 8 B = 163840 B = all of a CU's LDS
-constexpr uint32_t SC_MAX_SPLIT = 32;
+constexpr uint32_t SC_MAX_SLICE = 10240;            // entries: 10240 * 2 doubles = 163840 B = all of a CU's LDS
+constexpr uint32_t SC_PART = 32768;                 // records per accumulate workgroup
+constexpr uint32_t SC_RUN = 8;                      // consecutive records merged per thread in the accumulate kernel
+constexpr uint32_t SC_ROUTE_UNR = 4;                // samples per thread in the routing kernels
+constexpr uint32_t SC_MAX_NS = 512;                 // slices per level (2^22-entry levels)
+constexpr uint32_t SC_MAX_BINS = 8192;
 
 struct ScatterPlan {
     uint32_t n_levels;
-    uint32_t first_block[MIPSF_MAX_LEVELS + 1];   // blocks are ordered finest level first: order[k] = level
     // NB: every array is uint32_t on purpose.  With sub-dword arrays in a kernel-argument struct hipcc (ROCm 7.2)
     // folds `base + 2*level` into the SBASE of a scalar dword load; the hardware ignores SBASE's low two bits, so
     // odd levels silently read element [level-1].
-    uint32_t order[MIPSF_MAX_LEVELS];
     uint32_t n_slices[MIPSF_MAX_LEVELS];
-    uint32_t n_split[MIPSF_MAX_LEVELS];
     uint32_t slice_entries[MIPSF_MAX_LEVELS];
-    uint32_t partial_off[MIPSF_MAX_LEVELS];       // float offset into the partial scratch (levels with n_split > 1)
-    uint32_t total_blocks;
-    uint32_t partial_floats;
-    uint32_t split_entries;                       // sum of level sizes over split levels (reduce kernel extent)
+    uint32_t bin0[MIPSF_MAX_LEVELS + 1];          // first bin of each level
+    uint32_t n_bins;
+    uint32_t max_items;                           // upper bound on accumulate work items for this M
+    // scratch layout, in 4-byte words from the start of the scratch buffer
+    uint32_t w_count, w_cursor, w_offset, w_first, w_parts, w_nitems, w_items;
+    uint64_t w_records, w_partial, w_end;
 };
 
 static ScatterPlan make_plan(const GridLevels& g, uint32_t M) {
     ScatterPlan p = {};
     p.n_levels = g.n_levels;
-    uint32_t blocks = 0, poff = 0, split_entries = 0;
-    for (uint32_t k = 0; k < g.n_levels; ++k) {
-        const uint32_t l = g.n_levels - 1 - k;
+    uint32_t bins = 0;
+    for (uint32_t l = 0; l < g.n_levels; ++l) {
         const uint32_t size = g.offsets[l + 1] - g.offsets[l];
         const uint32_t ns = (size + SC_MAX_SLICE - 1) / SC_MAX_SLICE;
-        const uint32_t se = (size + ns - 1) / ns;
-        // Measured cost of one workgroup scanning all M samples of a level (units of a hashed-level workgroup at
-        // M = 262144, ~300 us): hashed levels 1.0 (hits are scattered, ~2.5 hit-loop trips per wave iteration);
-        // dense levels 1 + 33/n_slices (a sample has all 8 corners in the slice or none: 8 sparse trips, plus
-        // same-address conflicts on coherent rays).  Split the samples so that no workgroup exceeds ~1 unit.
-        const bool dense = !level_is_hashed(g.res[l], size);
-        const double unit = (double)M / 262144.0 * (dense ? 1.0 + 33.0 / ns : 1.0);
-        uint32_t split = (uint32_t)(unit + 0.999);
-        if (split < 1) split = 1;
-        if (split > SC_MAX_SPLIT) split = SC_MAX_SPLIT;
-        p.order[k] = l;
-        p.first_block[k] = blocks;
         p.n_slices[l] = ns;
-        p.n_split[l] = split;
-        p.slice_entries[l] = se;
-        p.partial_off[l] = poff;
-        if (split > 1) {
-            poff += split * size * 2;
-            split_entries += size;
-        }
-        blocks += ns * split;
+        p.slice_entries[l] = (size + ns - 1) / ns;
+        p.bin0[l] = bins;
+        bins += ns;
     }
-    p.first_block[g.n_levels] = blocks;
-    p.total_blocks = blocks;
-    p.partial_floats = poff;
-    p.split_entries = split_entries;
+    p.bin0[g.n_levels] = bins;
+    p.n_bins = bins;
+    const uint64_t max_records = 8ull * g.n_levels * M;
+    p.max_items = (uint32_t)((max_records + SC_PART - 1) / SC_PART) + bins;
+    uint64_t w = 0;
+    p.w_count = (uint32_t)w, w += bins;
+    p.w_cursor = (uint32_t)w, w += bins;
+    p.w_nitems = (uint32_t)w, w += 4;
+    p.w_offset = (uint32_t)w, w += bins;
+    p.w_first = (uint32_t)w, w += bins;
+    p.w_parts = (uint32_t)w, w += bins;
+    p.w_items = (uint32_t)w, w += p.max_items;
+    w = (w + 15) / 16 * 16;
+    p.w_records = w, w += max_records;
+    w = (w + 15) / 16 * 16;
+    p.w_partial = w, w += (uint64_t)p.max_items * SC_MAX_SLICE * 2;
+    p.w_end = w;
     return p;
+}
+
+__global__ void scatter_zero_kernel(uint32_t* __restrict__ ws, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ws[i] = 0u;
+}
+
+// slice of every corner of one (sample, level); lead = bit c set when corner c is the first one in its slice
+__device__ __forceinline__ uint32_t corner_slices(int mode, const float* __restrict__ x, uint32_t i, float scale,
+                                                  uint32_t res, uint32_t size, uint32_t se, float inv_se,
+                                                  uint32_t sl[8]) {
+    const Cell cell = locate(x, i, scale);
+    uint32_t idx[8];
+    corner_indices(mode, cell, res, size, idx);
+    uint32_t lead = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        uint32_t q = (uint32_t)((float)idx[c] * inv_se);          // idx < 2^24: within one of the true quotient
+        if (q * se > idx[c]) --q;
+        if ((q + 1u) * se <= idx[c]) ++q;
+        sl[c] = q;
+        bool first = true;
+#pragma unroll
+        for (int k = 0; k < c; ++k) first = first && (sl[k] != q);
+        lead |= first ? (1u << c) : 0u;
+    }
+    return lead;
+}
+
+// FILL = false: count the records of every bin.  FILL = true: write them (sample indices) at the scanned offsets.
+// One workgroup = one level x 4096 consecutive samples; LDS counters keep the global atomics at one per bin per
+// workgroup.
+template <bool FILL>
+__global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __restrict__ x, uint32_t M, GridLevels g,
+                                                                ScatterPlan plan, uint32_t* __restrict__ ws) {
+    __shared__ uint32_t cnt[SC_MAX_NS];
+    __shared__ uint32_t base[SC_MAX_NS];
+    const uint32_t level = blockIdx.x % plan.n_levels;
+    const uint32_t chunk = blockIdx.x / plan.n_levels;
+    const uint32_t size = g.offsets[level + 1] - g.offsets[level];
+    const uint32_t res = g.res[level];
+    const float scale = g.scale[level];
+    const uint32_t ns = plan.n_slices[level], se = plan.slice_entries[level], bin0 = plan.bin0[level];
+    const float inv_se = 1.0f / (float)se;
+    const int mode = level_mode(res, size);
+    for (uint32_t q = threadIdx.x; q < ns; q += SC_BLOCK) cnt[q] = 0u;
+    __syncthreads();
+    const uint32_t s0 = chunk * (SC_BLOCK * SC_ROUTE_UNR);
+    uint32_t sl[SC_ROUTE_UNR][8], lead[SC_ROUTE_UNR];
+#pragma unroll
+    for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u) {
+        const uint32_t i = s0 + u * SC_BLOCK + threadIdx.x;
+        lead[u] = 0;
+        if (i < M) lead[u] = corner_slices(mode, x, i, scale, res, size, se, inv_se, sl[u]);
+    }
+    if (!FILL) {
+#pragma unroll
+        for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u)
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (lead[u] >> c & 1u) atomicAdd(&cnt[sl[u][c]], 1u);
+        __syncthreads();
+        for (uint32_t q = threadIdx.x; q < ns; q += SC_BLOCK)
+            if (cnt[q]) atomicAdd(&ws[plan.w_count + bin0 + q], cnt[q]);
+    } else {
+        // rank inside the workgroup first, then one reservation per bin, then the writes
+        uint32_t rank[SC_ROUTE_UNR][8];
+#pragma unroll
+        for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u)
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (lead[u] >> c & 1u) rank[u][c] = atomicAdd(&cnt[sl[u][c]], 1u);
+        __syncthreads();
+        for (uint32_t q = threadIdx.x; q < ns; q += SC_BLOCK)
+            base[q] = cnt[q] ? ws[plan.w_offset + bin0 + q] + atomicAdd(&ws[plan.w_cursor + bin0 + q], cnt[q]) : 0u;
+        __syncthreads();
+        uint32_t* rec = ws + plan.w_records;
+#pragma unroll
+        for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u) {
+            const uint32_t i = s0 + u * SC_BLOCK + threadIdx.x;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (lead[u] >> c & 1u) rec[base[sl[u][c]] + rank[u][c]] = i;
+        }
+    }
+}
+
+// one workgroup: exclusive scan of the bin counts -> record offsets, and the (bin, part) work-item table
+__global__ __launch_bounds__(1024) void scatter_scan_kernel(ScatterPlan plan, uint32_t* __restrict__ ws) {
+    __shared__ uint32_t srec[1024], sitm[1024];
+    constexpr uint32_t PER = SC_MAX_BINS / 1024;
+    const uint32_t t = threadIdx.x;
+    uint32_t cnt[PER], lrec = 0, litm = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+        const uint32_t b = t * PER + k;
+        cnt[k] = b < plan.n_bins ? ws[plan.w_count + b] : 0u;
+        lrec += cnt[k];
+        litm += (cnt[k] + SC_PART - 1) / SC_PART;
+    }
+    srec[t] = lrec, sitm[t] = litm;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t a = t >= d ? srec[t - d] : 0u, c = t >= d ? sitm[t - d] : 0u;
+        __syncthreads();
+        srec[t] += a, sitm[t] += c;
+        __syncthreads();
+    }
+    uint32_t orec = srec[t] - lrec, oitm = sitm[t] - litm;
+    if (t == 1023) ws[plan.w_nitems] = sitm[t];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+        const uint32_t b = t * PER + k;
+        if (b < plan.n_bins) {
+            const uint32_t parts = (cnt[k] + SC_PART - 1) / SC_PART;
+            ws[plan.w_offset + b] = orec;
+            ws[plan.w_first + b] = oitm;
+            ws[plan.w_parts + b] = parts;
+            for (uint32_t q = 0; q < parts; ++q) ws[plan.w_items + oitm + q] = b | (q << 16);
+            orec += cnt[k], oitm += parts;
+        }
+    }
 }
 
 template <int LAYOUT>
 __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float* __restrict__ x,
                                                                    const float* __restrict__ dout,
-                                                                   float* __restrict__ dparams,
-                                                                   float* __restrict__ partial, uint32_t M,
-                                                                   GridLevels g, ScatterPlan plan) {
-    extern __shared__ __attribute__((aligned(16))) float acc[];   // [slice entries][2]
-    // ---- which (level, slice, sample split) is this workgroup?
-    uint32_t k = 0;
-    while (k + 1 < plan.n_levels && blockIdx.x >= plan.first_block[k + 1]) ++k;
-    const uint32_t level = plan.order[k];
-    const uint32_t rel = blockIdx.x - plan.first_block[k];
-    const uint32_t n_split = plan.n_split[level];
-    const uint32_t slice = rel / n_split, split = rel - slice * n_split;
+                                                                   float* __restrict__ dparams, uint32_t M,
+                                                                   GridLevels g, ScatterPlan plan,
+                                                                   uint32_t* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) double acc[];   // [slice entries][2]
+    if (blockIdx.x >= ws[plan.w_nitems]) return;
+    const uint32_t item = ws[plan.w_items + blockIdx.x];
+    const uint32_t bin = item & 0xffffu, part = item >> 16;
+    uint32_t level = 0;
+    while (level + 1 < plan.n_levels && bin >= plan.bin0[level + 1]) ++level;
+    const uint32_t slice = bin - plan.bin0[level];
     const uint32_t off = g.offsets[level];
     const uint32_t size = g.offsets[level + 1] - off;
     const uint32_t se = plan.slice_entries[level];
@@ -240,30 +361,68 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
     const uint32_t count = begin + se <= size ? se : size - begin;
     const uint32_t res = g.res[level];
     const float scale = g.scale[level];
+    const uint32_t n_rec_bin = ws[plan.w_count + bin];
+    const uint32_t r0 = part * SC_PART;
+    const uint32_t n_rec = n_rec_bin - r0 < SC_PART ? n_rec_bin - r0 : SC_PART;
+    const uint32_t* __restrict__ rec = ws + plan.w_records + ws[plan.w_offset + bin] + r0;
 
-    for (uint32_t e = threadIdx.x; e < 2 * count; e += SC_BLOCK) acc[e] = 0.0f;
+    for (uint32_t e = threadIdx.x; e < 2 * count; e += SC_BLOCK) acc[e] = 0.0;
     __syncthreads();
 
-    const uint32_t per = (M + n_split - 1) / n_split;
-    const uint32_t s0 = split * per;
-    const uint32_t s1 = s0 + per < M ? s0 + per : M;
     const int mode = level_mode(res, size);
-    constexpr int UNR = 4;   // independent x loads in flight per thread: the scan is latency-bound otherwise
-    for (uint32_t base = s0 + threadIdx.x; base < s1; base += UNR * SC_BLOCK) {
+    // Every thread takes SC_RUN consecutive records at a time (records are in sample order, so they are a
+    // stretch of one ray) and merges the ones that sit in the same cell in registers; the atomics go out when the
+    // cell changes.  On the coarse levels a ray spends ~10 samples per cell: up to SC_RUN x fewer atomics, and the
+    // lanes of a wave mostly hold different cells -- same-address ds_add_f64 degrades from 0.33 to 3 cycles per
+    // lane-op (tools/micro/lds_atomic.hip).  A wave still reads 64 x SC_RUN consecutive records (coalesced).
+    uint32_t cc[3] = {0u, 0u, 0u};
+    float sum[8][2];
+    bool open = false;
+    auto flush = [&]() {
+        Cell cell;
+        cell.c[0] = cc[0], cell.c[1] = cc[1], cell.c[2] = cc[2];
+        uint32_t idx[8];
+        corner_indices(mode, cell, res, size, idx);
+        uint32_t hit = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            idx[c] -= begin;
+            hit |= (idx[c] < count) ? (1u << c) : 0u;
+        }
+        // each lane walks ITS OWN hit list, so the wave issues max-over-lanes(hits) dense atomic pairs instead of 8
+        // sparse ones (an LDS atomic instruction has a fixed cost of ~20 cycles however few lanes are active)
+        while (hit) {
+            const int c = __ffs((int)hit) - 1;
+            hit &= hit - 1u;
+            uint32_t e = idx[0];
+            float v0 = sum[0][0], v1 = sum[0][1];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) {
+                e = (c == k) ? idx[k] : e;
+                v0 = (c == k) ? sum[k][0] : v0;
+                v1 = (c == k) ? sum[k][1] : v1;
+            }
+            atomicAdd(&acc[2 * e], (double)v0);
+            atomicAdd(&acc[2 * e + 1], (double)v1);
+        }
+    };
+    constexpr int UNR = (int)SC_RUN;   // independent record -> x chains in flight per thread
+    for (uint32_t r = threadIdx.x * SC_RUN; r < n_rec; r += SC_BLOCK * SC_RUN) {
+        const uint32_t re = r + SC_RUN < n_rec ? r + SC_RUN : n_rec;
+        uint32_t si[UNR];
         float px[UNR][3];
-        float2 pg[UNR];     // dL/dy is fetched up front too: a load issued inside the hit branch exposes a full
-                            // L2 round trip per iteration (the dominant cost of the first version)
+        float2 pg[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) si[u] = rec[r + u < re ? r + u : re - 1];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const uint32_t i = base + u * SC_BLOCK;
-            const uint32_t ii = i < s1 ? i : s1 - 1;
+            const uint32_t ii = si[u];
             px[u][0] = x[3 * (size_t)ii], px[u][1] = x[3 * (size_t)ii + 1], px[u][2] = x[3 * (size_t)ii + 2];
             pg[u] = *reinterpret_cast<const float2*>(dout + feat_index<LAYOUT>(ii, level, M, g.n_levels));
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const uint32_t i = base + u * SC_BLOCK;
-            if (i >= s1) break;
+            if (r + u >= re) break;
             Cell cell;
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
@@ -272,41 +431,34 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
                 cell.c[d] = (uint32_t)(int)fl;
                 cell.f[d] = pos - fl;
             }
-            uint32_t idx[8];
-            corner_indices(mode, cell, res, size, idx);
-            uint32_t hit = 0;
+            const bool same = open && cell.c[0] == cc[0] && cell.c[1] == cc[1] && cell.c[2] == cc[2];
+            if (!same) {
+                if (open) flush();
+                cc[0] = cell.c[0], cc[1] = cell.c[1], cc[2] = cell.c[2];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) sum[c][0] = 0.0f, sum[c][1] = 0.0f;
+                open = true;
+            }
+            const float2 gy = pg[u];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                idx[c] -= begin;
-                hit |= (idx[c] < count) ? (1u << c) : 0u;
-            }
-            if (hit) {
-                // each lane walks ITS OWN hit list (mean 8/n_slices hits per lane), so the wave issues
-                // max-over-lanes(hits) dense atomic pairs instead of 8 sparse ones: an LDS atomic instruction costs
-                // ~18 cycles however few lanes are active
-                const float2 gy = pg[u];
-                do {
-                    const int c = __ffs((int)hit) - 1;
-                    hit &= hit - 1u;
-                    uint32_t e = idx[0];
-#pragma unroll
-                    for (int k = 1; k < 8; ++k) e = (c == k) ? idx[k] : e;
-                    float wgt = (c & 1) ? cell.f[0] : 1.0f - cell.f[0];
-                    wgt = wgt * ((c & 2) ? cell.f[1] : 1.0f - cell.f[1]);
-                    wgt = wgt * ((c & 4) ? cell.f[2] : 1.0f - cell.f[2]);
-                    atomicAdd(&acc[2 * e], wgt * gy.x);
-                    atomicAdd(&acc[2 * e + 1], wgt * gy.y);
-                } while (hit);
+                float wgt = (c & 1) ? cell.f[0] : 1.0f - cell.f[0];
+                wgt = wgt * ((c & 2) ? cell.f[1] : 1.0f - cell.f[1]);
+                wgt = wgt * ((c & 4) ? cell.f[2] : 1.0f - cell.f[2]);
+                sum[c][0] = sum[c][0] + wgt * gy.x;
+                sum[c][1] = sum[c][1] + wgt * gy.y;
             }
         }
+        if (open) flush();
+        open = false;
     }
     __syncthreads();
 
-    if (n_split == 1) {
+    const double2* a2 = reinterpret_cast<const double2*>(acc);
+    if (ws[plan.w_parts + bin] == 1) {
         float2* dst = reinterpret_cast<float2*>(dparams) + off + begin;
-        const float2* a2 = reinterpret_cast<const float2*>(acc);
         for (uint32_t e = threadIdx.x; e < count; e += SC_BLOCK) {
-            const float2 v = a2[e];
+            const float2 v = make_float2((float)a2[e].x, (float)a2[e].y);
             if (v.x != 0.0f || v.y != 0.0f) {
                 float2 d = dst[e];
                 d.x += v.x, d.y += v.y;
@@ -314,36 +466,38 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
             }
         }
     } else {
-        float2* dst = reinterpret_cast<float2*>(partial + plan.partial_off[level]) + (size_t)split * size + begin;
-        const float2* a2 = reinterpret_cast<const float2*>(acc);
-        for (uint32_t e = threadIdx.x; e < count; e += SC_BLOCK) dst[e] = a2[e];
+        float2* dst = reinterpret_cast<float2*>(reinterpret_cast<float*>(ws) + plan.w_partial) +
+                      (size_t)blockIdx.x * SC_MAX_SLICE;
+        for (uint32_t e = threadIdx.x; e < count; e += SC_BLOCK) dst[e] = make_float2((float)a2[e].x, (float)a2[e].y);
     }
 }
 
-// folds the sample-split partial slices of the coarse levels into dparams
-__global__ __launch_bounds__(256) void hashgrid_scatter_reduce_kernel(const float* __restrict__ partial,
-                                                                      float* __restrict__ dparams, GridLevels g,
-                                                                      ScatterPlan plan) {
-    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;     // float2 entry index over the split levels
-    for (uint32_t l = 0; l < g.n_levels; ++l) {
-        const uint32_t ns = plan.n_split[l];
-        if (ns <= 1) continue;
-        const uint32_t size = g.offsets[l + 1] - g.offsets[l];
-        if (q < size) {
-            const float2* p2 = reinterpret_cast<const float2*>(partial + plan.partial_off[l]);
-            float2 a = make_float2(0.f, 0.f);
-            for (uint32_t s = 0; s < ns; ++s) {
-                const float2 v = p2[(size_t)s * size + q];
-                a.x += v.x, a.y += v.y;
-            }
-            float2* d = reinterpret_cast<float2*>(dparams) + g.offsets[l] + q;
-            float2 cur = *d;
-            cur.x += a.x, cur.y += a.y;
-            *d = cur;
-            return;
-        }
-        q -= size;
+// folds the partial slices of bins that were split over several workgroups into dparams
+__global__ __launch_bounds__(256) void hashgrid_scatter_reduce_kernel(float* __restrict__ dparams, GridLevels g,
+                                                                      ScatterPlan plan,
+                                                                      const uint32_t* __restrict__ ws) {
+    const uint32_t bin = blockIdx.x;
+    const uint32_t parts = ws[plan.w_parts + bin];
+    if (parts <= 1) return;
+    uint32_t level = 0;
+    while (level + 1 < plan.n_levels && bin >= plan.bin0[level + 1]) ++level;
+    const uint32_t size = g.offsets[level + 1] - g.offsets[level];
+    const uint32_t se = plan.slice_entries[level];
+    const uint32_t begin = (bin - plan.bin0[level]) * se;
+    const uint32_t count = begin + se <= size ? se : size - begin;
+    const uint32_t e = blockIdx.y * 256 + threadIdx.x;
+    if (e >= count) return;
+    const float2* p2 = reinterpret_cast<const float2*>(reinterpret_cast<const float*>(ws) + plan.w_partial) +
+                       (size_t)ws[plan.w_first + bin] * SC_MAX_SLICE + e;
+    float2 a = make_float2(0.f, 0.f);
+    for (uint32_t q = 0; q < parts; ++q) {
+        const float2 v = p2[(size_t)q * SC_MAX_SLICE];
+        a.x += v.x, a.y += v.y;
     }
+    float2* d = reinterpret_cast<float2*>(dparams) + g.offsets[level] + begin + e;
+    float2 cur = *d;
+    cur.x += a.x, cur.y += a.y;
+    *d = cur;
 }
 
 // dL/dx of one level per thread (tcnn kernel_grid_backward_input); written to per-level partials, no atomics
@@ -469,7 +623,7 @@ uint64_t mipsf_hashgrid_bwd_scratch_floats(const mipsf_grid_meta* meta, uint32_t
     GridLevels g;
     if (to_levels(meta, g)) return 0;
     const ScatterPlan p = make_plan(g, M);
-    return (uint64_t)p.partial_floats + (need_dx ? (uint64_t)g.n_levels * M * 3 : 0) + 64;
+    return p.w_end + (need_dx ? (uint64_t)g.n_levels * M * 3 : 0) + 64;
 }
 
 int mipsf_hashgrid_bwd(const float* x, const float* params, const float* dout, float* dparams, float* dx,
@@ -482,11 +636,24 @@ int mipsf_hashgrid_bwd(const float* x, const float* params, const float* dout, f
     MIPSF_REQUIRE(layout == MIPSF_FEAT_AOS || layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout %d", layout);
     hipStream_t s = (hipStream_t)stream;
     const ScatterPlan plan = make_plan(g, M);
-    float* partial = scratch;
-    float* dxl = scratch + ((plan.partial_floats + 15) / 16) * 16;
-    uint32_t max_slice = 0;
-    for (uint32_t l = 0; l < g.n_levels; ++l) max_slice = plan.slice_entries[l] > max_slice ? plan.slice_entries[l] : max_slice;
-    const uint32_t lds_bytes = max_slice * 8;
+    MIPSF_REQUIRE(plan.n_bins <= SC_MAX_BINS && plan.n_bins <= 0xffffu, "grid too large: %u table slices", plan.n_bins);
+    for (uint32_t l = 0; l < g.n_levels; ++l)
+        MIPSF_REQUIRE(plan.n_slices[l] <= SC_MAX_NS, "level %u too large: %u slices", l, plan.n_slices[l]);
+    MIPSF_REQUIRE(plan.w_end < (1ull << 32), "batch too large for 32-bit scratch offsets (M = %u)", M);
+    MIPSF_REQUIRE(((uint64_t)M + SC_PART - 1) / SC_PART < (1u << 16), "batch too large (M = %u)", M);
+    uint32_t* ws = reinterpret_cast<uint32_t*>(scratch);
+    float* dxl = scratch + ((plan.w_end + 15) / 16) * 16;
+    if (dparams) {   // a frozen grid (tracking) skips the scatter altogether
+        const uint32_t nz = plan.w_nitems + 4;   // counts, cursors, item count
+        hipLaunchKernelGGL(scatter_zero_kernel, dim3((nz + 255) / 256), dim3(256), 0, s, ws, nz);
+        const uint32_t rb = g.n_levels * ((M + SC_BLOCK * SC_ROUTE_UNR - 1) / (SC_BLOCK * SC_ROUTE_UNR));
+        hipLaunchKernelGGL(scatter_route_kernel<false>, dim3(rb), dim3(SC_BLOCK), 0, s, x, M, g, plan, ws);
+        hipLaunchKernelGGL(scatter_scan_kernel, dim3(1), dim3(1024), 0, s, plan, ws);
+        hipLaunchKernelGGL(scatter_route_kernel<true>, dim3(rb), dim3(SC_BLOCK), 0, s, x, M, g, plan, ws);
+        if (int e = check_launch("hashgrid_route")) return e;
+        uint32_t max_slice = 0;
+        for (uint32_t l = 0; l < g.n_levels; ++l) max_slice = plan.slice_entries[l] > max_slice ? plan.slice_entries[l] : max_slice;
+        const uint32_t lds_bytes = max_slice * 16;
 #define SCATTER(LAY)                                                                                             \
     do {                                                                                                         \
         static uint32_t attr_bytes = 0;                                                                          \
@@ -498,17 +665,14 @@ int mipsf_hashgrid_bwd(const float* x, const float* params, const float* dout, f
             }                                                                                                    \
             attr_bytes = lds_bytes;                                                                              \
         }                                                                                                        \
-        hipLaunchKernelGGL((hashgrid_scatter_kernel<LAY>), dim3(plan.total_blocks), dim3(SC_BLOCK), lds_bytes, s, \
-                           x, dout, dparams, partial, M, g, plan);                                               \
+        hipLaunchKernelGGL((hashgrid_scatter_kernel<LAY>), dim3(plan.max_items), dim3(SC_BLOCK), lds_bytes, s,   \
+                           x, dout, dparams, M, g, plan, ws);                                                    \
     } while (0)
-    if (dparams) {   // a frozen grid (tracking) skips the scatter altogether
         if (layout == MIPSF_FEAT_AOS) SCATTER(MIPSF_FEAT_AOS); else SCATTER(MIPSF_FEAT_LEVEL_MAJOR);
-        if (int e = check_launch("hashgrid_scatter")) return e;
-    }
 #undef SCATTER
-    if (dparams && plan.split_entries) {
-        hipLaunchKernelGGL(hashgrid_scatter_reduce_kernel, dim3((plan.split_entries + 255) / 256), dim3(256), 0, s,
-                           partial, dparams, g, plan);
+        if (int e = check_launch("hashgrid_scatter")) return e;
+        hipLaunchKernelGGL(hashgrid_scatter_reduce_kernel, dim3(plan.n_bins, (SC_MAX_SLICE + 255) / 256), dim3(256), 0, s,
+                           dparams, g, plan, ws);
         if (int e = check_launch("hashgrid_scatter_reduce")) return e;
     }
     if (dx) {

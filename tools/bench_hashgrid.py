@@ -26,7 +26,9 @@ def timeit(fn, n=20):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
 
+only = sys.argv[1] if len(sys.argv) > 1 else None
 for name, x in (("ray", x_ray), ("random", x_rnd)):
+    if only and name != only: continue
     dp = torch.zeros_like(params); dx = torch.zeros(M, 3, device=dev)
     t_f = timeit(lambda: ops.hashgrid_fwd(x, params, meta, _lib.FEAT_LEVEL_MAJOR))
     t_b = timeit(lambda: ops.hashgrid_bwd(x, params, dy, dp, meta, _lib.FEAT_LEVEL_MAJOR, None))
