@@ -45,7 +45,8 @@ N_GRID_PARAMS, N_DEC_PARAMS = 9014144, 36577
 # algorithmic cost per unit (SURVEY.md 8d / BASELINE.md 3); unit = 1 ray*sample unless noted
 KERNEL_COST = {
     "hashgrid_fwd": ("hbm", 1164.0),
-    "hashgrid_bwd": ("hbm", 2188.0),
+    "hashgrid_bwd": ("hbm", 2188.0),          # scatter: x + dL/dy + read-modify-write of the touched entries
+    "hashgrid_dx": ("hbm", 536.0),            # saved Jacobian (384) + dL/dy (128) + dx read-modify-write (24)
     "decoder_fwd": ("mfma", 72370.0),
     "decoder_bwd_chain": ("mfma", 72370.0),
     "decoder_wgrad": ("mfma", 72370.0),

@@ -66,6 +66,14 @@ int mipsf_hashgrid_meta_init(mipsf_grid_meta* meta_host, uint32_t n_levels, uint
 /* x: [M,3] fp32 already normalised (scene_rep.py:140-142 + :119); params: [n_params]; out: [M,L*F]. */
 int mipsf_hashgrid_fwd(const float* x, const float* params, float* out, uint32_t M,
                        const mipsf_grid_meta* meta_host, int layout, void* stream);
+/* Same, and also stores the Jacobian d out / d x: jac[(level*M + i)*6 + 2*d + f] = d out_f(level) / d x_d (the
+ * quantity tcnn's kernel_grid_backward_input recomputes from the table).  With it the backward obtains dL/dx from a
+ * streaming pass (mipsf_hashgrid_dx_from_jac) instead of gathering 8 table entries per level again. */
+int mipsf_hashgrid_fwd_jac(const float* x, const float* params, float* out, float* jac, uint32_t M,
+                           const mipsf_grid_meta* meta_host, int layout, void* stream);
+/* dx [M,3] += sum over levels of jac . dL/dout   (bit-identical to the dx part of mipsf_hashgrid_bwd) */
+int mipsf_hashgrid_dx_from_jac(const float* jac, const float* dout, float* dx, uint32_t M,
+                               const mipsf_grid_meta* meta_host, int layout, void* stream);
 /* dparams (nullable: frozen grid) += scatter of dL/dout (accumulated on chip in LDS slices, see hashgrid.hip);
  * dx (nullable) += dL/dx [M,3].
  * scratch: mipsf_hashgrid_bwd_scratch_floats(meta, M, dx != NULL) floats owned by the caller. */

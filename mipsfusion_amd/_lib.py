@@ -59,6 +59,8 @@ SIGNATURES = {
     "mipsf_device_cu_count": (_I, []),
     "mipsf_hashgrid_meta_init": (_I, [C.POINTER(GridMeta), _U32, _U32, _U32, _U32, _D]),
     "mipsf_hashgrid_fwd": (_I, [_P, _P, _P, _U32, C.POINTER(GridMeta), _I, _P]),
+    "mipsf_hashgrid_fwd_jac": (_I, [_P, _P, _P, _P, _U32, C.POINTER(GridMeta), _I, _P]),
+    "mipsf_hashgrid_dx_from_jac": (_I, [_P, _P, _P, _U32, C.POINTER(GridMeta), _I, _P]),
     "mipsf_hashgrid_bwd_scratch_floats": (_U64, [C.POINTER(GridMeta), _U32, _I]),
     "mipsf_hashgrid_bwd": (_I, [_P, _P, _P, _P, _P, _P, _U32, C.POINTER(GridMeta), _I, _P]),
     "mipsf_hashgrid_indices": (_I, [_P, _P, _U32, C.POINTER(GridMeta), _P]),

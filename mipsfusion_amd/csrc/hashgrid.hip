@@ -114,12 +114,34 @@ __device__ __forceinline__ size_t feat_index(uint32_t i, uint32_t level, uint32_
     return LAYOUT == MIPSF_FEAT_AOS ? ((size_t)i * L + level) * 2 : ((size_t)level * M + i) * 2;
 }
 
+// d f0 / d x_d (s0) and d f1 / d x_d (s1) of one level from its 8 corner values (tcnn kernel_grid_backward_input):
+// scale * sum over the 4 corner pairs along d of w_other * (right - left)
+__device__ __forceinline__ void level_jacobian(const Cell& cell, const float2 (&v)[8], float scale, int d, float& s0,
+                                               float& s1) {
+    s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+        const int d0 = d == 0 ? 1 : 0;
+        const int d1 = d == 2 ? 1 : 2;
+        const int b0 = sub & 1, b1 = (sub >> 1) & 1;
+        float wgt = scale;
+        wgt = wgt * (b0 ? cell.f[d0] : 1.0f - cell.f[d0]);
+        wgt = wgt * (b1 ? cell.f[d1] : 1.0f - cell.f[d1]);
+        const int left = (b0 << d0) | (b1 << d1);
+        const int right = left | (1 << d);
+        s0 = s0 + wgt * (v[right].x - v[left].x);
+        s1 = s1 + wgt * (v[right].y - v[left].y);
+    }
+}
+
 // ------------------------------------------------------------------------------ forward
-template <int LAYOUT>
+// JAC: also store d out / d x of this (sample, level) -- 3 x (d f0/d x_d, d f1/d x_d), level-major [L][M][6] -- so that
+// the backward gets dL/dx from a streaming pass (hashgrid_dx_jac_kernel) instead of gathering the table again.
+template <int LAYOUT, bool JAC>
 __global__ __launch_bounds__(HG_BLOCK) void hashgrid_fwd_kernel(const float* __restrict__ x,
                                                                 const float2* __restrict__ table,
-                                                                float* __restrict__ out, uint32_t M,
-                                                                GridLevels g, uint32_t nchunk) {
+                                                                float* __restrict__ out, float* __restrict__ jac,
+                                                                uint32_t M, GridLevels g, uint32_t nchunk) {
     uint32_t chunk;
     const int level = decode_level(g.n_levels, nchunk, chunk);
     if (level >= (int)g.n_levels) return;
@@ -147,6 +169,16 @@ __global__ __launch_bounds__(HG_BLOCK) void hashgrid_fwd_kernel(const float* __r
     float2* dst = reinterpret_cast<float2*>(out + feat_index<LAYOUT>(i, level, M, g.n_levels));
     __builtin_nontemporal_store(a0, &dst->x);
     __builtin_nontemporal_store(a1, &dst->y);
+    if (JAC) {
+        float2* j2 = reinterpret_cast<float2*>(jac) + ((size_t)level * M + i) * 3;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float s0, s1;
+            level_jacobian(cell, v, g.scale[level], d, s0, s1);
+            __builtin_nontemporal_store(s0, &j2[d].x);
+            __builtin_nontemporal_store(s1, &j2[d].y);
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------- backward
@@ -154,9 +186,10 @@ __global__ __launch_bounds__(HG_BLOCK) void hashgrid_fwd_kernel(const float* __r
 // MI355X whatever the access pattern (measured: 4.0 ms for the 67 M atomics of a 4096x64 batch), so the scatter
 // target is moved ON CHIP: the 256 CUs own 40 MiB of LDS.
 //   * a level's table is cut into slices of <= 10240 entries (160 KiB of fp64 pairs) -- one "bin" per slice;
-//   * ROUTE: every (sample, level) is sent to the bins its 8 corners fall into (count -> scan -> fill; a record
-//     is the sample index, duplicates inside a bin are merged), so that no workgroup ever looks at a sample
-//     that does not touch its slice.  (The first version let every slice owner scan ALL samples of its level:
+//   * ROUTE: every (sample, level) is sent to the bins its 8 corners fall into (a record is the sample index,
+//     duplicates inside a bin are merged, so a bin holds at most M records and gets a fixed M-record region of
+//     scratch: one pass, no counting pre-pass), so that no workgroup ever looks at a sample that does not touch
+//     its slice.  (The first version let every slice owner scan ALL samples of its level:
 //     52 x redundant index arithmetic on the hashed levels, 640 us.)
 //   * ACCUMULATE: one workgroup per (bin, part of <= 32768 records) re-derives the corners of its samples and
 //     adds the contributions that fall into its slice with LDS atomics in fp64.  ds_add_f64 runs at ~0.33 cycles
@@ -183,8 +216,8 @@ struct ScatterPlan {
     uint32_t n_bins;
     uint32_t max_items;                           // upper bound on accumulate work items for this M
     // scratch layout, in 4-byte words from the start of the scratch buffer
-    uint32_t w_count, w_cursor, w_offset, w_first, w_parts, w_nitems, w_items;
-    uint64_t w_records, w_partial, w_end;
+    uint32_t w_count, w_first, w_parts, w_nitems, w_items;
+    uint64_t w_records, w_partial, w_end;         // records: n_bins regions of bin_cap words
 };
 
 static ScatterPlan make_plan(const GridLevels& g, uint32_t M) {
@@ -205,14 +238,12 @@ static ScatterPlan make_plan(const GridLevels& g, uint32_t M) {
     p.max_items = (uint32_t)((max_records + SC_PART - 1) / SC_PART) + bins;
     uint64_t w = 0;
     p.w_count = (uint32_t)w, w += bins;
-    p.w_cursor = (uint32_t)w, w += bins;
     p.w_nitems = (uint32_t)w, w += 4;
-    p.w_offset = (uint32_t)w, w += bins;
     p.w_first = (uint32_t)w, w += bins;
     p.w_parts = (uint32_t)w, w += bins;
     p.w_items = (uint32_t)w, w += p.max_items;
     w = (w + 15) / 16 * 16;
-    p.w_records = w, w += max_records;
+    p.w_records = w, w += (uint64_t)bins * M;
     w = (w + 15) / 16 * 16;
     p.w_partial = w, w += (uint64_t)p.max_items * SC_MAX_SLICE * 2;
     p.w_end = w;
@@ -246,10 +277,8 @@ __device__ __forceinline__ uint32_t corner_slices(int mode, const float* __restr
     return lead;
 }
 
-// FILL = false: count the records of every bin.  FILL = true: write them (sample indices) at the scanned offsets.
-// One workgroup = one level x 4096 consecutive samples; LDS counters keep the global atomics at one per bin per
-// workgroup.
-template <bool FILL>
+// One workgroup = one level x 4096 consecutive samples: rank the records inside the workgroup with LDS counters,
+// reserve room in every bin with ONE global atomic per bin, write the sample indices.
 __global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __restrict__ x, uint32_t M, GridLevels g,
                                                                 ScatterPlan plan, uint32_t* __restrict__ ws) {
     __shared__ uint32_t cnt[SC_MAX_NS];
@@ -265,78 +294,65 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __
     for (uint32_t q = threadIdx.x; q < ns; q += SC_BLOCK) cnt[q] = 0u;
     __syncthreads();
     const uint32_t s0 = chunk * (SC_BLOCK * SC_ROUTE_UNR);
-    uint32_t sl[SC_ROUTE_UNR][8], lead[SC_ROUTE_UNR];
+    uint32_t sl[SC_ROUTE_UNR][8], lead[SC_ROUTE_UNR], rank[SC_ROUTE_UNR][8];
 #pragma unroll
     for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u) {
         const uint32_t i = s0 + u * SC_BLOCK + threadIdx.x;
         lead[u] = 0;
         if (i < M) lead[u] = corner_slices(mode, x, i, scale, res, size, se, inv_se, sl[u]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (lead[u] >> c & 1u) rank[u][c] = atomicAdd(&cnt[sl[u][c]], 1u);
     }
-    if (!FILL) {
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < ns; q += SC_BLOCK)
+        base[q] = cnt[q] ? atomicAdd(&ws[plan.w_count + bin0 + q], cnt[q]) : 0u;
+    __syncthreads();
+    uint32_t* rec = ws + plan.w_records;
 #pragma unroll
-        for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u)
+    for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u) {
+        const uint32_t i = s0 + u * SC_BLOCK + threadIdx.x;
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
-                if (lead[u] >> c & 1u) atomicAdd(&cnt[sl[u][c]], 1u);
-        __syncthreads();
-        for (uint32_t q = threadIdx.x; q < ns; q += SC_BLOCK)
-            if (cnt[q]) atomicAdd(&ws[plan.w_count + bin0 + q], cnt[q]);
-    } else {
-        // rank inside the workgroup first, then one reservation per bin, then the writes
-        uint32_t rank[SC_ROUTE_UNR][8];
-#pragma unroll
-        for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u)
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                if (lead[u] >> c & 1u) rank[u][c] = atomicAdd(&cnt[sl[u][c]], 1u);
-        __syncthreads();
-        for (uint32_t q = threadIdx.x; q < ns; q += SC_BLOCK)
-            base[q] = cnt[q] ? ws[plan.w_offset + bin0 + q] + atomicAdd(&ws[plan.w_cursor + bin0 + q], cnt[q]) : 0u;
-        __syncthreads();
-        uint32_t* rec = ws + plan.w_records;
-#pragma unroll
-        for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u) {
-            const uint32_t i = s0 + u * SC_BLOCK + threadIdx.x;
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                if (lead[u] >> c & 1u) rec[base[sl[u][c]] + rank[u][c]] = i;
-        }
+        for (int c = 0; c < 8; ++c)
+#ifdef MIPSF_EXP_NOWRITE
+            if ((lead[u] >> c & 1u) && base[sl[u][c]] == 0xffffffffu) rec[(size_t)(bin0 + sl[u][c]) * M + base[sl[u][c]] + rank[u][c]] = i;
+#else
+            if (lead[u] >> c & 1u) rec[(size_t)(bin0 + sl[u][c]) * M + base[sl[u][c]] + rank[u][c]] = i;
+#endif
     }
 }
 
-// one workgroup: exclusive scan of the bin counts -> record offsets, and the (bin, part) work-item table
+// one workgroup: the (bin, part) work-item table from the bin counts
 __global__ __launch_bounds__(1024) void scatter_scan_kernel(ScatterPlan plan, uint32_t* __restrict__ ws) {
-    __shared__ uint32_t srec[1024], sitm[1024];
+    __shared__ uint32_t sitm[1024];
     constexpr uint32_t PER = SC_MAX_BINS / 1024;
     const uint32_t t = threadIdx.x;
-    uint32_t cnt[PER], lrec = 0, litm = 0;
+    uint32_t cnt[PER], litm = 0;
 #pragma unroll
     for (uint32_t k = 0; k < PER; ++k) {
         const uint32_t b = t * PER + k;
         cnt[k] = b < plan.n_bins ? ws[plan.w_count + b] : 0u;
-        lrec += cnt[k];
         litm += (cnt[k] + SC_PART - 1) / SC_PART;
     }
-    srec[t] = lrec, sitm[t] = litm;
+    sitm[t] = litm;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
-        const uint32_t a = t >= d ? srec[t - d] : 0u, c = t >= d ? sitm[t - d] : 0u;
+        const uint32_t c = t >= d ? sitm[t - d] : 0u;
         __syncthreads();
-        srec[t] += a, sitm[t] += c;
+        sitm[t] += c;
         __syncthreads();
     }
-    uint32_t orec = srec[t] - lrec, oitm = sitm[t] - litm;
+    uint32_t oitm = sitm[t] - litm;
     if (t == 1023) ws[plan.w_nitems] = sitm[t];
 #pragma unroll
     for (uint32_t k = 0; k < PER; ++k) {
         const uint32_t b = t * PER + k;
         if (b < plan.n_bins) {
             const uint32_t parts = (cnt[k] + SC_PART - 1) / SC_PART;
-            ws[plan.w_offset + b] = orec;
             ws[plan.w_first + b] = oitm;
             ws[plan.w_parts + b] = parts;
             for (uint32_t q = 0; q < parts; ++q) ws[plan.w_items + oitm + q] = b | (q << 16);
-            orec += cnt[k], oitm += parts;
+            oitm += parts;
         }
     }
 }
@@ -364,7 +380,7 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
     const uint32_t n_rec_bin = ws[plan.w_count + bin];
     const uint32_t r0 = part * SC_PART;
     const uint32_t n_rec = n_rec_bin - r0 < SC_PART ? n_rec_bin - r0 : SC_PART;
-    const uint32_t* __restrict__ rec = ws + plan.w_records + ws[plan.w_offset + bin] + r0;
+    const uint32_t* __restrict__ rec = ws + plan.w_records + (size_t)bin * M + r0;
 
     for (uint32_t e = threadIdx.x; e < 2 * count; e += SC_BLOCK) acc[e] = 0.0;
     __syncthreads();
@@ -524,24 +540,11 @@ __global__ __launch_bounds__(HG_BLOCK) void hashgrid_dx_kernel(const float* __re
     float2 v[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) v[c] = lvl[idx[c]];
-    // dy_f/dx_d = scale * sum over the 4 corner pairs along d of w_other * (right - left)
     float gx[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-            const int d0 = d == 0 ? 1 : 0;
-            const int d1 = d == 2 ? 1 : 2;
-            const int b0 = sub & 1, b1 = (sub >> 1) & 1;
-            float wgt = scale;
-            wgt = wgt * (b0 ? cell.f[d0] : 1.0f - cell.f[d0]);
-            wgt = wgt * (b1 ? cell.f[d1] : 1.0f - cell.f[d1]);
-            const int left = (b0 << d0) | (b1 << d1);
-            const int right = left | (1 << d);
-            s0 = s0 + wgt * (v[right].x - v[left].x);
-            s1 = s1 + wgt * (v[right].y - v[left].y);
-        }
+        float s0, s1;
+        level_jacobian(cell, v, scale, d, s0, s1);
         gx[d] = s0 * gy.x + s1 * gy.y;
     }
     float* o = dxl + ((size_t)level * M + i) * 3;
@@ -555,6 +558,27 @@ __global__ __launch_bounds__(256) void hashgrid_dx_reduce_kernel(const float* __
     float a = 0.f;
     for (uint32_t l = 0; l < L; ++l) a += dxl[(uint64_t)l * n3 + t];
     dx[t] += a;
+}
+
+// dx += sum over levels of J_l . dL/dy_l with the Jacobian saved by the forward (same arithmetic and the same
+// level order as hashgrid_dx_kernel + hashgrid_dx_reduce_kernel: bit-identical results)
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void hashgrid_dx_jac_kernel(const float* __restrict__ jac,
+                                                              const float* __restrict__ dout, float* __restrict__ dx,
+                                                              uint32_t M, uint32_t L) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    float a[3] = {0.f, 0.f, 0.f};
+    for (uint32_t l = 0; l < L; ++l) {
+        const float2* j2 = reinterpret_cast<const float2*>(jac) + ((size_t)l * M + i) * 3;
+        const float2 gy = *reinterpret_cast<const float2*>(dout + feat_index<LAYOUT>(i, l, M, L));
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float2 j = j2[d];
+            a[d] += j.x * gy.x + j.y * gy.y;
+        }
+    }
+    dx[3 * (size_t)i] += a[0], dx[3 * (size_t)i + 1] += a[1], dx[3 * (size_t)i + 2] += a[2];
 }
 
 __global__ __launch_bounds__(HG_BLOCK) void hashgrid_indices_kernel(const float* __restrict__ x,
@@ -598,25 +622,48 @@ using namespace mipsf;
 
 extern "C" {
 
-int mipsf_hashgrid_fwd(const float* x, const float* params, float* out, uint32_t M,
-                       const mipsf_grid_meta* meta, int layout, void* stream) {
+static int hashgrid_fwd_impl(const float* x, const float* params, float* out, float* jac, uint32_t M,
+                             const mipsf_grid_meta* meta, int layout, void* stream) {
     GridLevels g;
     if (int rc = to_levels(meta, g)) return rc;
     if (M == 0) return 0;
     MIPSF_REQUIRE(x && params && out, "null pointer");
+    MIPSF_REQUIRE(layout == MIPSF_FEAT_AOS || layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout %d", layout);
     uint32_t nchunk;
     const uint32_t nb = grid_blocks(M, g.n_levels, nchunk);
     hipStream_t s = (hipStream_t)stream;
     const float2* table = reinterpret_cast<const float2*>(params);
-    if (layout == MIPSF_FEAT_AOS)
-        hipLaunchKernelGGL(hashgrid_fwd_kernel<MIPSF_FEAT_AOS>, dim3(nb), dim3(HG_BLOCK), 0, s, x, table, out, M, g,
-                           nchunk);
-    else if (layout == MIPSF_FEAT_LEVEL_MAJOR)
-        hipLaunchKernelGGL(hashgrid_fwd_kernel<MIPSF_FEAT_LEVEL_MAJOR>, dim3(nb), dim3(HG_BLOCK), 0, s, x, table,
-                           out, M, g, nchunk);
-    else
-        MIPSF_REQUIRE(false, "bad layout %d", layout);
+#define FWD(LAY, J) hipLaunchKernelGGL((hashgrid_fwd_kernel<LAY, J>), dim3(nb), dim3(HG_BLOCK), 0, s, x, table, out, jac, M, g, nchunk)
+    if (layout == MIPSF_FEAT_AOS) { if (jac) FWD(MIPSF_FEAT_AOS, true); else FWD(MIPSF_FEAT_AOS, false); }
+    else { if (jac) FWD(MIPSF_FEAT_LEVEL_MAJOR, true); else FWD(MIPSF_FEAT_LEVEL_MAJOR, false); }
+#undef FWD
     return check_launch("hashgrid_fwd");
+}
+
+int mipsf_hashgrid_fwd(const float* x, const float* params, float* out, uint32_t M,
+                       const mipsf_grid_meta* meta, int layout, void* stream) {
+    return hashgrid_fwd_impl(x, params, out, nullptr, M, meta, layout, stream);
+}
+
+int mipsf_hashgrid_fwd_jac(const float* x, const float* params, float* out, float* jac, uint32_t M,
+                           const mipsf_grid_meta* meta, int layout, void* stream) {
+    MIPSF_REQUIRE(jac != nullptr || M == 0, "jac is null");
+    return hashgrid_fwd_impl(x, params, out, jac, M, meta, layout, stream);
+}
+
+int mipsf_hashgrid_dx_from_jac(const float* jac, const float* dout, float* dx, uint32_t M,
+                               const mipsf_grid_meta* meta, int layout, void* stream) {
+    GridLevels g;
+    if (int rc = to_levels(meta, g)) return rc;
+    if (M == 0) return 0;
+    MIPSF_REQUIRE(jac && dout && dx, "null pointer");
+    MIPSF_REQUIRE(layout == MIPSF_FEAT_AOS || layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout %d", layout);
+    hipStream_t s = (hipStream_t)stream;
+    if (layout == MIPSF_FEAT_AOS)
+        hipLaunchKernelGGL(hashgrid_dx_jac_kernel<MIPSF_FEAT_AOS>, dim3((M + 255) / 256), dim3(256), 0, s, jac, dout, dx, M, g.n_levels);
+    else
+        hipLaunchKernelGGL(hashgrid_dx_jac_kernel<MIPSF_FEAT_LEVEL_MAJOR>, dim3((M + 255) / 256), dim3(256), 0, s, jac, dout, dx, M, g.n_levels);
+    return check_launch("hashgrid_dx_from_jac");
 }
 
 uint64_t mipsf_hashgrid_bwd_scratch_floats(const mipsf_grid_meta* meta, uint32_t M, int need_dx) {
@@ -644,12 +691,11 @@ int mipsf_hashgrid_bwd(const float* x, const float* params, const float* dout, f
     uint32_t* ws = reinterpret_cast<uint32_t*>(scratch);
     float* dxl = scratch + ((plan.w_end + 15) / 16) * 16;
     if (dparams) {   // a frozen grid (tracking) skips the scatter altogether
-        const uint32_t nz = plan.w_nitems + 4;   // counts, cursors, item count
+        const uint32_t nz = plan.w_nitems + 4;   // bin counts, item count
         hipLaunchKernelGGL(scatter_zero_kernel, dim3((nz + 255) / 256), dim3(256), 0, s, ws, nz);
         const uint32_t rb = g.n_levels * ((M + SC_BLOCK * SC_ROUTE_UNR - 1) / (SC_BLOCK * SC_ROUTE_UNR));
-        hipLaunchKernelGGL(scatter_route_kernel<false>, dim3(rb), dim3(SC_BLOCK), 0, s, x, M, g, plan, ws);
+        hipLaunchKernelGGL(scatter_route_kernel, dim3(rb), dim3(SC_BLOCK), 0, s, x, M, g, plan, ws);
         hipLaunchKernelGGL(scatter_scan_kernel, dim3(1), dim3(1024), 0, s, plan, ws);
-        hipLaunchKernelGGL(scatter_route_kernel<true>, dim3(rb), dim3(SC_BLOCK), 0, s, x, M, g, plan, ws);
         if (int e = check_launch("hashgrid_route")) return e;
         uint32_t max_slice = 0;
         for (uint32_t l = 0; l < g.n_levels; ++l) max_slice = plan.slice_entries[l] > max_slice ? plan.slice_entries[l] : max_slice;

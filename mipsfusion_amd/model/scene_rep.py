@@ -64,17 +64,24 @@ class _QueryFn(torch.autograd.Function):
         xn = ops._f32c(xn)
         M = xn.shape[0]
         meta = owner.embed_fn.meta
-        feat = ops.hashgrid_fwd(xn, grid_params.detach(), meta, FEAT_LEVEL_MAJOR)
+        # when the points need a gradient (pose optimisation) the forward also keeps d feat / d x, so the backward
+        # never gathers the table a second time
+        jac = None
+        if ctx.needs_input_grad[0]:
+            feat, jac = ops.hashgrid_fwd(xn, grid_params.detach(), meta, FEAT_LEVEL_MAJOR, with_jac=True)
+        else:
+            feat = ops.hashgrid_fwd(xn, grid_params.detach(), meta, FEAT_LEVEL_MAJOR)
         packed = ops.decoder_pack(weights)
         need = any(ctx.needs_input_grad)
         out, saved = ops.decoder_fwd(packed, feat, FEAT_LEVEL_MAJOR, xn, None, M, save=need)
-        ctx.owner, ctx.M, ctx.meta = owner, M, meta
-        ctx.save_for_backward(xn, feat, out, saved, packed, grid_params, *weights)
+        ctx.owner, ctx.M, ctx.meta, ctx.has_jac = owner, M, meta, jac is not None
+        ctx.save_for_backward(xn, feat, out, saved, packed, grid_params, *weights, *([jac] if jac is not None else []))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         xn, feat, out, saved, packed, grid_params, *weights = ctx.saved_tensors
+        jac = weights.pop() if ctx.has_jac else None
         need_w = any(ctx.needs_input_grad[3:])
         need_g = ctx.needs_input_grad[2]
         need_x = ctx.needs_input_grad[0]
@@ -100,9 +107,10 @@ class _QueryFn(torch.autograd.Function):
                 dparams = grid_params.grad
             else:
                 dparams = torch.zeros_like(grid_params)
-        if need_g or need_x:
-            ops.hashgrid_bwd(xn, grid_params.detach(), dfeat, dparams, ctx.meta, FEAT_LEVEL_MAJOR,
-                             dx if need_x else None)
+        if need_g:
+            ops.hashgrid_bwd(xn, grid_params.detach(), dfeat, dparams, ctx.meta, FEAT_LEVEL_MAJOR, None)
+        if need_x:
+            ops.hashgrid_dx_from_jac(jac, dfeat, dx, ctx.meta, FEAT_LEVEL_MAJOR)
         w_out = [None] * len(weights)
         if need_w and not direct:
             w_out = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[3:])]

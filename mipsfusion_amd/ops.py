@@ -57,15 +57,30 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------ hash grid
-def hashgrid_fwd(x: torch.Tensor, params: torch.Tensor, meta, layout=FEAT_AOS) -> torch.Tensor:
+def hashgrid_fwd(x: torch.Tensor, params: torch.Tensor, meta, layout=FEAT_AOS, with_jac: bool = False):
+    """with_jac: also return d out / d x ([L, M, 3, 2]) for `hashgrid_dx_from_jac` (use when x needs a gradient)."""
     M = x.shape[0]
     nf = meta.n_levels * meta.n_features
     out = torch.empty((M, nf) if layout == FEAT_AOS else (meta.n_levels, M, meta.n_features),
                       dtype=torch.float32, device=x.device)
+    if with_jac:
+        jac = torch.empty((meta.n_levels, M, 3, 2), dtype=torch.float32, device=x.device)
+        with _timed("hashgrid_fwd"):
+            check(lib().mipsf_hashgrid_fwd_jac(dptr(x), dptr(params), dptr(out), dptr(jac), M, C.byref(meta), layout,
+                                               stream_ptr()), "hashgrid_fwd_jac")
+        return out, jac
     with _timed("hashgrid_fwd"):
         check(lib().mipsf_hashgrid_fwd(dptr(x), dptr(params), dptr(out), M, C.byref(meta), layout, stream_ptr()),
               "hashgrid_fwd")
     return out
+
+
+def hashgrid_dx_from_jac(jac, dout, dx, meta, layout=FEAT_AOS):
+    """dx += J . dout with the Jacobian saved by hashgrid_fwd(with_jac=True)."""
+    M = dx.shape[0]
+    with _timed("hashgrid_dx"):
+        check(lib().mipsf_hashgrid_dx_from_jac(dptr(jac), dptr(dout), dptr(dx), M, C.byref(meta), layout,
+                                               stream_ptr()), "hashgrid_dx_from_jac")
 
 
 def hashgrid_bwd(x, params, dout, dparams, meta, layout=FEAT_AOS, dx: Optional[torch.Tensor] = None):
@@ -93,17 +108,23 @@ class HashGridFn(torch.autograd.Function):
     def forward(ctx, x, params, meta):
         x = _f32c(x)
         ctx.meta = meta
+        if ctx.needs_input_grad[0]:
+            out, jac = hashgrid_fwd(x, params.detach(), meta, FEAT_AOS, with_jac=True)
+            ctx.save_for_backward(x, params, jac)
+            return out
         ctx.save_for_backward(x, params)
         return hashgrid_fwd(x, params.detach(), meta, FEAT_AOS)
 
     @staticmethod
     def backward(ctx, dout):
-        x, params = ctx.saved_tensors          # saved tensors survive retain_graph=True re-entry
+        x, params, *jac = ctx.saved_tensors    # saved tensors survive retain_graph=True re-entry
         dout = _f32c(dout)
         dparams = torch.zeros_like(params) if ctx.needs_input_grad[1] else None
         dx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
-        if dparams is not None or dx is not None:
-            hashgrid_bwd(x, params.detach(), dout, dparams, ctx.meta, FEAT_AOS, dx)
+        if dparams is not None:
+            hashgrid_bwd(x, params.detach(), dout, dparams, ctx.meta, FEAT_AOS, None)
+        if dx is not None:
+            hashgrid_dx_from_jac(jac[0], dout, dx, ctx.meta, FEAT_AOS)
         return dx, dparams, None
 
 

@@ -92,6 +92,14 @@ def test_hashgrid_golden(dev, tag, log2_t):
                      _lib.FEAT_LEVEL_MAJOR, dx2)
     assert_close(dparams2, dparams, 1e-5, "level-major dparams")
     assert_close(dx2, dx, 1e-5, "level-major dx")
+    # Jacobian-saving forward: same features, and dL/dx from the saved Jacobian is bit-identical to the gather path
+    for layout, dyl, ref in ((_lib.FEAT_AOS, dy, dx), (_lib.FEAT_LEVEL_MAJOR,
+                                                       dy.reshape(-1, 16, 2).permute(1, 0, 2).contiguous(), dx2)):
+        yj, jac = ops.hashgrid_fwd(x, params, meta, layout, with_jac=True)
+        assert torch.equal(yj, y if layout == _lib.FEAT_AOS else ylm), "fwd_jac features"
+        dxj = torch.zeros_like(x)
+        ops.hashgrid_dx_from_jac(jac, dyl, dxj, meta, layout)
+        assert torch.equal(dxj, ref), "dx from the saved Jacobian must equal the gather path bit for bit"
 
 
 def test_hashgrid_vs_oracle_fresh(dev):

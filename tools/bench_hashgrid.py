@@ -3,6 +3,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import math, numpy as np, torch
 from mipsfusion_amd import _lib, ops, synth
+if os.environ.get("MIPSF_LIB_VARIANT"): _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "micro", "libmipsf_%s.so" % os.environ["MIPSF_LIB_VARIANT"])
 dev = torch.device("cuda:0")
 PLS = float(2.0 ** (math.log2(16) / 15))
 meta = _lib.make_grid_meta(16, 2, 19, 16, PLS)
