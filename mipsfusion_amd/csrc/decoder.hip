@@ -26,6 +26,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr float PI_F = 3.14159265358979323846f;
 constexpr float HALF_PI_F = 1.57079632679489661923f;
 constexpr int DEC_BLOCK = 256;
+#ifndef MIPSF_FWD_LDS_MIN_ROUNDS
+#define MIPSF_FWD_LDS_MIN_ROUNDS 2u   // experiments: a huge value disables the persistent forward kernel
+#endif
 #ifndef MIPSF_PIN_ARG
 #define MIPSF_PIN_ARG 0          // experiments only: 1 skips the trickled stores (wrong results, timing)
 #endif
@@ -50,7 +53,7 @@ struct NoSide {
 // on gfx9, so a burst of stores in front of the next layer's first loads stalls the matrix pipe for a full
 // store round trip; one 16-byte store per group behind the loads costs nothing.
 template <int RT, int T, typename BFn, typename SideFn = NoSide>
-__device__ __forceinline__ void mfma_layer(const float4* __restrict__ img, int lane, f32x16 (&acc)[RT], BFn bfn,
+__device__ __forceinline__ void mfma_layer(const float4* img, int lane, f32x16 (&acc)[RT], BFn bfn,
                                            SideFn side = SideFn()) {
     constexpr int T4 = T / 4;
     // the A operands of group t4+1 are requested before the 4*RT MFMAs of group t4 issue, so an L2 round trip
@@ -158,17 +161,15 @@ __device__ __forceinline__ float load_feat(const float* __restrict__ feat, uint3
 }
 
 // ================================================================================ forward
+// one wave, one tile of 32 samples; img1/2/3 = A-operand images of the three big layers (global or LDS)
 template <bool PE_INTERNAL, int LAYOUT, bool SAVE>
-__global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_fwd_kernel(const float* __restrict__ packed,
-                                                                const float* __restrict__ feat,
-                                                                const float* __restrict__ x,
-                                                                const float* __restrict__ embed_pos,
-                                                                float* __restrict__ out, float* __restrict__ saved,
-                                                                uint32_t M, int pin) {
-    const int lane = threadIdx.x & 63;
+__device__ __forceinline__ void decoder_fwd_tile(const float* __restrict__ packed, const float4* img1,
+                                                 const float4* img2, const float4* img3,
+                                                 const float* __restrict__ feat, const float* __restrict__ x,
+                                                 const float* __restrict__ embed_pos, float* __restrict__ out,
+                                                 float* __restrict__ saved, uint32_t M, int pin, int64_t tile,
+                                                 int lane) {
     const int j = lane & 31, h = lane >> 5;
-    const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + (threadIdx.x >> 6);
-    if (tile * 32 >= (int64_t)M) return;
     const uint32_t s_raw = (uint32_t)(tile * 32 + j);
     const bool live = s_raw < M;
     const uint32_t s = live ? s_raw : M - 1;   // tail lanes recompute the last sample (finite values, no stores)
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_fwd_kernel(const float* 
     // ---- layer 1: pts_linear.0 + ReLU
     f32x16 H1[4];
     load_bias(packed, 0, h, H1);
-    mfma_layer<RT_F1, T_F1>(reinterpret_cast<const float4*>(packed + OFF_F1), lane, H1,
+    mfma_layer<RT_F1, T_F1>(img1, lane, H1,
                             [&](int t) { return t < E_SLOTS ? ev[t] : 0.0f; });
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_fwd_kernel(const float* 
     // ---- layer 2: pts_linear.2 -> [sdf_emb | rgb_emb]   (H1 is written out one 16-byte group per k-group)
     f32x16 H2[4];
     load_bias(packed, 1, h, H2);
-    mfma_layer<RT_F2, T_F2>(reinterpret_cast<const float4*>(packed + OFF_F2), lane, H2,
+    mfma_layer<RT_F2, T_F2>(img2, lane, H2,
                             [&](int t) { return H1[t >> 4][t & 15]; },
                             [&](int t4) { if (SAVE && pin == 0) store_act_piece(saved, tile, 0, lane, H1, t4); });
 
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_fwd_kernel(const float* 
     for (int u = 0; u < 16; ++u) gf[u] = load_feat<LAYOUT>(feat, s, u, h, M);
     f32x16 H3[4];
     load_bias(packed, 2, h, H3);
-    mfma_layer<RT_F3, T_F3>(reinterpret_cast<const float4*>(packed + OFF_F3), lane, H3,
+    mfma_layer<RT_F3, T_F3>(img3, lane, H3,
                             [&](int t) { return t < 32 ? H2[t >> 4][t & 15] : gf[t - 32]; },
                             [&](int t4) {                       // 16 groups of H2 over 12 k-groups
                                 if (SAVE && pin == 0) {
@@ -272,6 +273,58 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_fwd_kernel(const float* 
         } else {
             o[5] = p[0], o[6] = p[1], o[7] = p[2], o[8] = p[3], o[9] = p[4];
         }
+    }
+}
+
+template <bool PE_INTERNAL, int LAYOUT, bool SAVE>
+__global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_fwd_kernel(const float* __restrict__ packed,
+                                                                const float* __restrict__ feat,
+                                                                const float* __restrict__ x,
+                                                                const float* __restrict__ embed_pos,
+                                                                float* __restrict__ out, float* __restrict__ saved,
+                                                                uint32_t M, int pin) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + (threadIdx.x >> 6);
+    if (tile * 32 >= (int64_t)M) return;
+    decoder_fwd_tile<PE_INTERNAL, LAYOUT, SAVE>(packed, reinterpret_cast<const float4*>(packed + OFF_F1),
+                                                reinterpret_cast<const float4*>(packed + OFF_F2),
+                                                reinterpret_cast<const float4*>(packed + OFF_F3), feat, x, embed_pos,
+                                                out, saved, M, pin, tile, lane);
+}
+
+// Persistent variant for large batches: one workgroup of 8 waves per CU keeps the three forward weight images
+// (140 KB) in LDS for its whole share of the batch.  The A operands then arrive over the LDS path, so the trickled
+// activation stores are alone in the vector-memory queue: on gfx9 loads and stores retire through ONE in-order
+// counter (vmcnt), and an L2 weight load queued behind a store to HBM waits for that store.
+constexpr int FWD_LDS_FLOATS = OFF_B3 - OFF_F1;
+constexpr int FWD_LDS_BYTES = FWD_LDS_FLOATS * 4;
+constexpr int FWD_LDS_BLOCK = 512;
+template <bool PE_INTERNAL, int LAYOUT, bool SAVE>
+__global__ __launch_bounds__(FWD_LDS_BLOCK, 1) void decoder_fwd_lds_kernel(const float* __restrict__ packed,
+                                                                        const float* __restrict__ feat,
+                                                                        const float* __restrict__ x,
+                                                                        const float* __restrict__ embed_pos,
+                                                                        float* __restrict__ out,
+                                                                        float* __restrict__ saved, uint32_t M,
+                                                                        int pin, uint32_t n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float4 wimg[];
+    {
+        const float4* src = reinterpret_cast<const float4*>(packed + OFF_F1);
+        for (int q = threadIdx.x; q < FWD_LDS_FLOATS / 4; q += FWD_LDS_BLOCK) wimg[q] = src[q];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (uint32_t tile = blockIdx.x * (FWD_LDS_BLOCK / 64) + (threadIdx.x >> 6); tile < n_tiles;
+         tile += gridDim.x * (FWD_LDS_BLOCK / 64)) {
+        // the images are loop invariant: an opaque zero keeps the compiler from hoisting ~550 LDS reads out of the loop
+        // (same for the small per-lane tables read from `packed`)
+        uint32_t z = 0, zs = 0;
+        asm volatile("" : "+v"(z));
+        asm volatile("" : "+s"(zs));
+        const float4* w4 = wimg + z;
+        decoder_fwd_tile<PE_INTERNAL, LAYOUT, SAVE>(packed + zs, w4 + (OFF_F1 - OFF_F1) / 4, w4 + (OFF_F2 - OFF_F1) / 4,
+                                                    w4 + (OFF_F3 - OFF_F1) / 4, feat, x, embed_pos, out, saved, M, pin,
+                                                    (int64_t)tile, lane);
     }
 }
 
@@ -822,10 +875,33 @@ int mipsf_decoder_fwd(const float* packed, const float* feat, int feat_layout, c
     MIPSF_REQUIRE(packed && feat && x && out, "null pointer");
     MIPSF_REQUIRE(pe_mode == 0 || embed_pos, "pe_mode 1 needs embed_pos");
     MIPSF_REQUIRE(feat_layout == MIPSF_FEAT_AOS || feat_layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout");
-    const uint32_t blocks = (uint32_t)((n_wave_tiles(M) + 3) / 4);
+    const uint32_t n_tiles = (uint32_t)n_wave_tiles(M);
+    const uint32_t blocks = (n_tiles + 3) / 4;
     hipStream_t s = (hipStream_t)stream;
-#define FWD(PE, LAY, SV) \
-    hipLaunchKernelGGL((decoder_fwd_kernel<PE, LAY, SV>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed, feat, x, embed_pos, out, saved, M, 0)
+    static int cus = 0;
+    if (cus <= 0) cus = mipsf_device_cu_count();
+    if (cus <= 0) return 3;
+    // persistent LDS-resident weights pay off once every CU has several rounds of tiles to amortise the 140 KB fill
+    const bool persistent = n_tiles >= (uint32_t)cus * 8u * MIPSF_FWD_LDS_MIN_ROUNDS;
+#define FWD(PE, LAY, SV)                                                                                         \
+    do {                                                                                                         \
+        if (persistent) {                                                                                        \
+            static bool attr_set = false;                                                                        \
+            if (!attr_set) {                                                                                     \
+                if (hipFuncSetAttribute((const void*)decoder_fwd_lds_kernel<PE, LAY, SV>,                        \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS_BYTES) != hipSuccess) { \
+                    set_error("cannot raise dynamic LDS to %d bytes", FWD_LDS_BYTES);                            \
+                    return 4;                                                                                    \
+                }                                                                                                \
+                attr_set = true;                                                                                 \
+            }                                                                                                    \
+            hipLaunchKernelGGL((decoder_fwd_lds_kernel<PE, LAY, SV>), dim3(cus), dim3(FWD_LDS_BLOCK), FWD_LDS_BYTES, s, \
+                               packed, feat, x, embed_pos, out, saved, M, 0, n_tiles);                           \
+        } else {                                                                                                 \
+            hipLaunchKernelGGL((decoder_fwd_kernel<PE, LAY, SV>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed, feat, x, \
+                               embed_pos, out, saved, M, 0);                                                     \
+        }                                                                                                        \
+    } while (0)
     const bool sv = saved != nullptr;
     if (pe_mode == 0) {
         if (feat_layout == MIPSF_FEAT_AOS) { if (sv) FWD(true, MIPSF_FEAT_AOS, true); else FWD(true, MIPSF_FEAT_AOS, false); }
