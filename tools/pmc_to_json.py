@@ -13,8 +13,11 @@ for f in sorted(glob.glob(os.path.join(src, "pass*_summary.txt"))):
             c, v = kv.split("=")
             vals.setdefault(k, {})[c] = float(v)
 # map rocprof kernel names -> bench kernel groups (a group = one C-ABI call)
-groups = {"hashgrid_fwd": ["hashgrid_fwd_kernel"], "hashgrid_bwd": ["hashgrid_scatter_kernel", "hashgrid_scatter_reduce_kernel", "hashgrid_dx_kernel", "hashgrid_dx_reduce_kernel"],
-          "decoder_fwd": ["decoder_fwd_kernel"], "decoder_bwd_chain": ["decoder_bwd_kernel"], "decoder_wgrad": ["decoder_wgrad_kernel", "decoder_wgrad_reduce_kernel"],
+groups = {"hashgrid_fwd": ["hashgrid_fwd_kernel"],
+          "hashgrid_bwd": ["scatter_zero_kernel", "scatter_route_kernel", "scatter_scan_kernel", "hashgrid_scatter_kernel", "hashgrid_scatter_reduce_kernel"],
+          "hashgrid_dx": ["hashgrid_dx_jac_kernel"],
+          "decoder_fwd": ["decoder_fwd_kernel", "decoder_fwd_lds_kernel"], "decoder_bwd_chain": ["decoder_bwd_lds_kernel"],
+          "decoder_wgrad": ["decoder_wgrad_kernel", "decoder_wgrad_reduce_kernel"],
           "adam_step": ["adam_kernel"], "sample_rays": ["sample_rays_kernel"], "render_fwd": ["render_fwd_kernel", "loss_finalize_kernel"],
           "render_bwd": ["render_bwd_kernel"], "rays_bwd": ["rays_bwd_kernel"]}
 traffic = {}
