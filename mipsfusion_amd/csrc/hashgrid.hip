@@ -199,8 +199,14 @@ __global__ __launch_bounds__(HG_BLOCK) void hashgrid_fwd_kernel(const float* __r
 //     partial slices and a reduce kernel.  No global float atomics, no inter-workgroup communication.
 constexpr int SC_BLOCK = 1024;
 constexpr uint32_t SC_MAX_SLICE = 10240;            // entries: 10240 * 2 doubles = 163840 B = all of a CU's LDS
-constexpr uint32_t SC_PART = 32768;                 // records per accumulate workgroup
-constexpr uint32_t SC_RUN = 8;                      // consecutive records merged per thread in the accumulate kernel
+#ifndef MIPSF_SC_PART
+#define MIPSF_SC_PART 32768
+#endif
+#ifndef MIPSF_SC_RUN
+#define MIPSF_SC_RUN 4
+#endif
+constexpr uint32_t SC_PART = MIPSF_SC_PART;           // records per accumulate workgroup
+constexpr uint32_t SC_RUN = MIPSF_SC_RUN;                   // consecutive records merged per thread in the accumulate kernel
 constexpr uint32_t SC_ROUTE_UNR = 4;                // samples per thread in the routing kernels
 constexpr uint32_t SC_MAX_NS = 512;                 // slices per level (2^22-entry levels)
 constexpr uint32_t SC_MAX_BINS = 8192;
@@ -391,6 +397,9 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
     // cell changes.  On the coarse levels a ray spends ~10 samples per cell: up to SC_RUN x fewer atomics, and the
     // lanes of a wave mostly hold different cells -- same-address ds_add_f64 degrades from 0.33 to 3 cycles per
     // lane-op (tools/micro/lds_atomic.hip).  A wave still reads 64 x SC_RUN consecutive records (coalesced).
+#ifdef MIPSF_EXP_NOATOM
+    double dummy = 0.0;
+#endif
     uint32_t cc[3] = {0u, 0u, 0u};
     float sum[8][2];
     bool open = false;
@@ -407,6 +416,18 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
         }
         // each lane walks ITS OWN hit list, so the wave issues max-over-lanes(hits) dense atomic pairs instead of 8
         // sparse ones (an LDS atomic instruction has a fixed cost of ~20 cycles however few lanes are active)
+        if (mode == 0) {
+            // dense level: a cell is inside the slice with all 8 corners or (almost always) with none, so the
+            // straight-line form has full lanes and needs no per-lane selects
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (hit >> c & 1u) {
+                    atomicAdd(&acc[2 * idx[c]], (double)sum[c][0]);
+                    atomicAdd(&acc[2 * idx[c] + 1], (double)sum[c][1]);
+                }
+            }
+            return;
+        }
         while (hit) {
             const int c = __ffs((int)hit) - 1;
             hit &= hit - 1u;
@@ -418,12 +439,19 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
                 v0 = (c == k) ? sum[k][0] : v0;
                 v1 = (c == k) ? sum[k][1] : v1;
             }
+#ifdef MIPSF_EXP_NOATOM
+            dummy += (double)v0 * (double)e + (double)v1;
+#else
             atomicAdd(&acc[2 * e], (double)v0);
             atomicAdd(&acc[2 * e + 1], (double)v1);
+#endif
         }
     };
     constexpr int UNR = (int)SC_RUN;   // independent record -> x chains in flight per thread
-    for (uint32_t r = threadIdx.x * SC_RUN; r < n_rec; r += SC_BLOCK * SC_RUN) {
+    // (a transposed assignment -- neighbouring lanes one ray apart, so that they never meet in a coarse cell -- was
+    // measured 25 % slower: the locality of the record / x / dL/dy reads matters more than the residual conflicts)
+    const uint32_t chunk_id = threadIdx.x;
+    for (uint32_t r = chunk_id * SC_RUN; r < n_rec; r += SC_BLOCK * SC_RUN) {
         const uint32_t re = r + SC_RUN < n_rec ? r + SC_RUN : n_rec;
         uint32_t si[UNR];
         float px[UNR][3];
@@ -470,16 +498,25 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
     }
     __syncthreads();
 
+#ifdef MIPSF_EXP_NOATOM
+    if (dummy == 1.2345) acc[0] = dummy;
+#endif
     const double2* a2 = reinterpret_cast<const double2*>(acc);
     if (ws[plan.w_parts + bin] == 1) {
+        // read-modify-write of the whole slice; all loads are issued before the first add (a load -> add -> store
+        // chain per iteration costs one HBM round trip each, ~10 us per workgroup)
         float2* dst = reinterpret_cast<float2*>(dparams) + off + begin;
-        for (uint32_t e = threadIdx.x; e < count; e += SC_BLOCK) {
-            const float2 v = make_float2((float)a2[e].x, (float)a2[e].y);
-            if (v.x != 0.0f || v.y != 0.0f) {
-                float2 d = dst[e];
-                d.x += v.x, d.y += v.y;
-                dst[e] = d;
-            }
+        constexpr uint32_t FL = SC_MAX_SLICE / SC_BLOCK;
+        float2 cur[FL];
+#pragma unroll
+        for (uint32_t k = 0; k < FL; ++k) {
+            const uint32_t e = threadIdx.x + k * SC_BLOCK;
+            cur[k] = e < count ? dst[e] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < FL; ++k) {
+            const uint32_t e = threadIdx.x + k * SC_BLOCK;
+            if (e < count) dst[e] = make_float2(cur[k].x + (float)a2[e].x, cur[k].y + (float)a2[e].y);
         }
     } else {
         float2* dst = reinterpret_cast<float2*>(reinterpret_cast<float*>(ws) + plan.w_partial) +
