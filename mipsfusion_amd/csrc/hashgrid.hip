@@ -308,7 +308,11 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __
         if (i < M) lead[u] = corner_slices(mode, x, i, scale, res, size, se, inv_se, sl[u]);
 #pragma unroll
         for (int c = 0; c < 8; ++c)
+#ifdef MIPSF_EXP_NORANK
+            if (lead[u] >> c & 1u) rank[u][c] = threadIdx.x & 7u;
+#else
             if (lead[u] >> c & 1u) rank[u][c] = atomicAdd(&cnt[sl[u][c]], 1u);
+#endif
     }
     __syncthreads();
     for (uint32_t q = threadIdx.x; q < ns; q += SC_BLOCK)

@@ -329,6 +329,7 @@ class PoseRaysFn(torch.autograd.Function):
                                             dptr(d_cam), dptr(rays_o), dptr(rays_d), N, stream_ptr()), "pose_rays_fwd")
         ctx.F, ctx.K, ctx.N = F, K, N
         ctx.save_for_backward(rot, owner, d_cam)
+        ctx.set_materialize_grads(False)
         return rays_o, rays_d
 
     @staticmethod
