@@ -229,21 +229,32 @@ def forward_only_rate(model, loop, dev, iters=10):
 
 def frame_estimate(cfg, model, loop, dev, ba_ms, stream=None):
     """tracking+mapping ms/frame = iter_RO*RO + tracking.iter*GO + mapping.iters*BA/map_every."""
-    from mipsfusion_amd import ops as _ops
-    P, n = cfg["tracking"]["RO"]["particle_size"], cfg["tracking"]["RO"]["n_rows"] * cfg["tracking"]["RO"]["n_cols"]
-    b = np.array(cfg["mapping"]["bound"])
-    pts = (torch.rand(P, n, 3, device=dev) * torch.tensor(b[:, 1] - b[:, 0], device=dev, dtype=torch.float32)
-           + torch.tensor(b[:, 0], device=dev, dtype=torch.float32))
-    td = torch.rand(n, device=dev) + 0.5
-    with torch.no_grad():
-        for _ in range(2):
-            _ops.ro_fitness(model.run_network(pts), td, cfg["training"]["trunc"])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            _ops.ro_fitness(model.run_network(pts), td, cfg["training"]["trunc"])
-        torch.cuda.synchronize()
-        ro_ms = (time.perf_counter() - t0) / 5 * 1e3
+    # RO: the whole RandomOptimizer.optimize call of one frame (iter_RO fused rounds: particles -> grid -> decoder ->
+    # fitness -> swarm update, search state on the device, one read-back at the end), divided by iter_RO
+    import types
+    from mipsfusion_amd.RandomOptimizer import RandomOptimizer
+    rcfg = cfg["tracking"]["RO"]
+    rcfg.setdefault("initial_scaling_factor", 0.02)
+    rcfg.setdefault("rescaling_factor", 0.5)
+    cfg["tracking"].setdefault("ignore_edge_W", 20)
+    cfg["tracking"].setdefault("ignore_edge_H", 20)
+    H, W, fx, fy, cx, cy = synth.intrinsics_after_crop(cfg)
+    frame = synth.make_frame(cfg, seed=1)
+    ds = types.SimpleNamespace(H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy, rays_d=frame["direction"])
+    ro = RandomOptimizer(cfg, types.SimpleNamespace(dataset=ds, device=dev))
+    n_ro = max(1, cfg["tracking"]["iter_RO"])
+    init = frame["c2w"].clone()
+    was_training = model.training
+    model.eval()
+    for _ in range(2):
+        ro.optimize(model, frame["depth"], init, None, n_iter=n_ro)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ro.optimize(model, frame["depth"], init, None, n_iter=n_ro)
+    torch.cuda.synchronize()
+    ro_ms = (time.perf_counter() - t0) / 5 / n_ro * 1e3
+    model.train(was_training)
     # GO: tracking.sample rays, pose-only Adam on one pose
     ns = cfg["tracking"]["sample"]
     rays = loop.pool[0][0][:ns]

@@ -21,6 +21,7 @@
  *   mipsf_pose_rays_*     per-ray pose gather + R*d     mipsfusion.py:320-322, 531-532; geometry_helper.py:11-17
  *   mipsf_adam_step       torch.optim.Adam.step           mipsfusion.py:580-584, 190, 330-335
  *   mipsf_ro_fitness      RandomOptimizer.get_fitness     RandomOptimizer.py:113-131
+ *   mipsf_ro_particles/_update  one RandomOptimizer round  RandomOptimizer.py:184-224
  */
 #ifndef MIPSF_H
 #define MIPSF_H
@@ -241,6 +242,25 @@ int mipsf_adam_step_multi_ex(const mipsf_adam_tensors* tensors_host_struct, floa
  * mean_masked[P] = mean_j(valid_j * |sdf*trunc|)  (RandomOptimizer.py:125-129) */
 int mipsf_ro_fitness(const float* raw, uint32_t raw_stride, const float* target_d, float trunc,
                      float* mean_masked, uint32_t P, uint32_t n, void* stream);
+
+/* -------------------------------------- RandomOptimizer particle step */
+/* The search state lives on the device so that a tracking round needs no host round trip (the reference
+ * synchronises on `if success_flag:` every round, RandomOptimizer.py:204,211).  state[MIPSF_RO_STATE_FLOATS]:
+ *   [0..8] rot_cur (row-major 3x3)   [9..11] trans_cur   [12..17] search size (initial_scaling_factor x 6 at start)
+ *   written by _ro_update: [18] success flag, [19] mean SDF of the advanced particles, [20] fitness of particle 0,
+ *   [21..27] weighted mean transform (qw qx qy qz tx ty tz), [28] number of advanced particles. */
+#define MIPSF_RO_STATE_FLOATS 32
+/* pst [P,6] pre-sampled particle template; rays_d_cam [n,3], target_d [n] of the lattice pixels ->
+ * pst7 [P,7] rescaled 7-D particle poses (pose_6D_to_7D, RandomOptimizer.py:57-63) and
+ * xn [P*n,3]: lattice points moved by every particle's absolute pose (get_abs_pose :72-76, batch_points_trans
+ * :84-88) and normalised like run_network (scene_rep.py:134-142), ready for mipsf_hashgrid_fwd. */
+int mipsf_ro_particles(const float* pst, const float* state, const float* rays_d_cam, const float* target_d,
+                       const mipsf_render_cfg* cfg_host, float* xn, float* pst7, uint32_t P, uint32_t n,
+                       void* stream);
+/* mean_masked [P] from mipsf_ro_fitness -> advanced-particle weights, weighted mean transform, new rot/trans and
+ * search size in `state` (RandomOptimizer.py:196-224; sdf_weight = 1000, rescale = tracking.RO.rescaling_factor). */
+int mipsf_ro_update(const float* mean_masked, const float* pst7, float* state, float sdf_weight, float rescale,
+                    uint32_t P, void* stream);
 
 #ifdef __cplusplus
 }

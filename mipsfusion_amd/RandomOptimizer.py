@@ -1,0 +1,108 @@
+"""Particle-swarm pre-tracker with the reference's interface (RandomOptimizer.py:10-227).
+
+``RandomOptimizer(cfg, mipsfusion)`` and ``optimize(model, depth_img, initial_pose, last_frame_pose, n_iter)``
+take and return what the reference's do.  The difference is where a round runs: the search state (rotation,
+translation, search size) stays in a 32-float device buffer, a round is five kernel launches
+(ro_particles -> hashgrid_fwd -> decoder_fwd -> ro_fitness -> ro_update) and nothing is read back until the last
+round, whereas the reference issues ~25 eager ops and one device->host synchronisation (``if success_flag``) per
+round.  The small helper methods keep their reference semantics for callers that use them directly.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import FEAT_LEVEL_MAJOR
+from .helper_functions.geometry_helper import quaternion_to_matrix
+from .helper_functions.sampling_helper import sample_pixels_uniformly
+
+
+class RandomOptimizer:
+    def __init__(self, cfg, mipsfusion):
+        self.cfg = cfg
+        self.slam = mipsfusion
+        self.dataset = self.slam.dataset
+        self.device = self.slam.device
+        ro = cfg["tracking"]["RO"]
+        self.particle_size = ro["particle_size"]
+        self.scaling_coefficient1 = ro["initial_scaling_factor"]
+        self.scaling_coefficient2 = ro["rescaling_factor"]
+        self.sdf_weight = 1000.
+        self.trunc_value = cfg["training"]["trunc"]
+
+        # particle swarm template, same draw as RandomOptimizer.py:26-33 (numpy global RNG)
+        pst = np.random.multivariate_normal(np.zeros(6), np.eye(6), self.particle_size).astype(np.float32)
+        pst = torch.from_numpy(pst)
+        pst[0, :] = 0
+        self.pre_sampled_particle = torch.clamp(pst, -2., 2.).to(self.device).contiguous()
+        self.no_rel_trans = torch.tensor([1., 0., 0., 0., 0., 0., 0.]).to(self.device)
+
+        self.iW = cfg["tracking"]["ignore_edge_W"]
+        self.iH = cfg["tracking"]["ignore_edge_H"]
+        self.rays_dir = self.dataset.rays_d
+        self.row_indices, self.col_indices = sample_pixels_uniformly(self.dataset.H, self.dataset.W, ro["n_rows"],
+                                                                     ro["n_cols"])
+        self.fx, self.fy, self.cx, self.cy = self.dataset.fx, self.dataset.fy, self.dataset.cx, self.dataset.cy
+        self.intrinsic = torch.tensor([[self.fx, 0., self.cx], [0., self.fy, self.cy], [0., 0., 1.]]).to(self.device)
+        # the five lattice offsets of optimize() never change: their camera-frame directions live on the device
+        rows, cols = self.row_indices, self.col_indices
+        self._dirs = torch.stack([self.rays_dir[rows + o, cols + o, :] for o in range(5)]).to(
+            self.device, torch.float32).contiguous()
+
+    # ------------------------------------------------------------- reference helpers (same semantics, torch)
+    def pose_6D_to_7D(self, batch_pose):
+        s = batch_pose[:, 0] ** 2 + batch_pose[:, 1] ** 2 + batch_pose[:, 2] ** 2
+        qw = torch.where(s <= 1., torch.sqrt(1 - s), torch.zeros_like(s)).unsqueeze(1)
+        return torch.cat([qw, batch_pose], dim=-1)
+
+    def get_abs_pose(self, ref_pose_rot, ref_pose_trans, particle_template):
+        return ref_pose_rot @ quaternion_to_matrix(particle_template[:, :4]), \
+            ref_pose_trans + particle_template[:, 4:, None]
+
+    def batch_points_trans(self, points, pose_rot, pose_trans):
+        return torch.transpose(pose_rot @ torch.transpose(points, 0, 1) + pose_trans, 1, 2)
+
+    def get_fitness(self, model, abs_rot, abs_trans, last_frame_pose, target_d, rays_d_cam):
+        world = self.batch_points_trans(rays_d_cam * target_d, abs_rot, abs_trans)
+        mean_masked_sdf = ops.ro_fitness(model.run_network(world), target_d.reshape(-1).contiguous(), self.trunc_value)
+        return mean_masked_sdf * self.sdf_weight, mean_masked_sdf
+
+    def update_cur_pose(self, rot_cur, trans_cur, mean_transform):
+        return rot_cur @ quaternion_to_matrix(mean_transform[:4]), trans_cur + mean_transform[4:][..., None]
+
+    def update_search_size(self, mean_pred_sdf, mean_transform):
+        s = torch.abs(mean_transform) + 0.0001
+        return (self.scaling_coefficient2 * mean_pred_sdf * s / s.norm() + 0.0001)[None, ...]
+
+    # ------------------------------------------------------------------------------------------ the fused loop
+    def _enqueue_round(self, model, state, target_d, dirs, rc, packed):
+        """One round (RandomOptimizer.py:177-224) on the current stream; no host synchronisation."""
+        P, n = self.particle_size, dirs.shape[0]
+        xn, pst7 = ops.ro_particles(self.pre_sampled_particle, state, dirs, target_d, rc)
+        feat = ops.hashgrid_fwd(xn, model.embed_fn.params.detach(), model.embed_fn.meta, FEAT_LEVEL_MAJOR)
+        raw, _ = ops.decoder_fwd(packed, feat, FEAT_LEVEL_MAJOR, xn, None, P * n, save=False)
+        mean_masked = ops.ro_fitness(raw.view(P, n, raw.shape[-1]), target_d, self.trunc_value)
+        ops.ro_update(mean_masked, pst7, state, self.sdf_weight, self.scaling_coefficient2)
+        return mean_masked
+
+    @torch.no_grad()
+    def optimize(self, model, depth_img, initial_pose, last_frame_pose, n_iter=10, return_state=False):
+        if n_iter <= 0:
+            return initial_pose
+        dev = self.device
+        rows, cols = self.row_indices, self.col_indices
+        # depth of the five lattice offsets: one small upload per frame instead of one per round
+        td5 = torch.stack([depth_img[rows + o, cols + o] for o in range(5)]).to(dev, torch.float32).contiguous()
+        state = torch.zeros(ops.RO_STATE_FLOATS, dtype=torch.float32, device=dev)
+        init = initial_pose.to(dev, torch.float32)
+        state[0:9] = init[:3, :3].reshape(9)
+        state[9:12] = init[:3, 3]
+        state[12:18] = float(self.scaling_coefficient1)
+        rc = model._rc(1, 0)
+        packed = ops.decoder_pack(model.decoder.ordered_parameters())
+        for i in range(n_iter):
+            o = i % 5
+            self._enqueue_round(model, state, td5[o], self._dirs[o], rc, packed)
+        pose = torch.eye(4, dtype=torch.float32, device=dev)
+        pose[:3, :3] = state[0:9].view(3, 3)
+        pose[:3, 3] = state[9:12]
+        return (pose, state) if return_state else pose

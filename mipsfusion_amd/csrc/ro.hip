@@ -1,0 +1,173 @@
+// RandomOptimizer particle step (reference RandomOptimizer.py:54-88, 113-131, 137-224).
+//
+// One tracking round of the reference is ~25 eager torch ops, a [P,3,3] @ [3,n] batched matmul, a device->host
+// synchronisation (`if success_flag:`) and two small host->device copies.  Here the state of the search (rotation,
+// translation, search size) lives in a 32-float device buffer and a round is five launches with no host round
+// trip, so that all rounds of a frame can be captured in one hipGraph:
+//   ro_particles   PST rescale -> 7-D pose -> R(q) -> absolute pose -> lattice points to world -> fp64 normalisation
+//   hashgrid_fwd, decoder_fwd (forward only), ro_fitness   (existing kernels)
+//   ro_update      advanced-particle weights, weighted mean transform, pose and search-size update (one workgroup)
+#include "common.h"
+
+namespace mipsf {
+
+// state layout (floats): see MIPSF_RO_* in include/mipsf.h
+constexpr int RO_ROT = 0, RO_TRANS = 9, RO_SEARCH = 12, RO_SUCCESS = 18, RO_MEAN_SDF = 19, RO_FIT0 = 20,
+              RO_MEAN_T = 21, RO_NBETTER = 28;
+
+// pytorch3d.transforms.quaternion_to_matrix for a real-first, not necessarily unit quaternion
+__device__ __forceinline__ void quat_to_mat(float w, float x, float y, float z, float (&m)[9]) {
+    const float two_s = 2.0f / (((w * w + x * x) + y * y) + z * z);
+    m[0] = 1 - two_s * (y * y + z * z), m[1] = two_s * (x * y - z * w), m[2] = two_s * (x * z + y * w);
+    m[3] = two_s * (x * y + z * w), m[4] = 1 - two_s * (x * x + z * z), m[5] = two_s * (y * z - x * w);
+    m[6] = two_s * (x * z - y * w), m[7] = two_s * (y * z + x * w), m[8] = 1 - two_s * (x * x + y * y);
+}
+
+__device__ __forceinline__ void mat_mul3(const float (&a)[9], const float (&b)[9], float (&c)[9]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c[3 * i + j] = (a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j]) + a[3 * i + 2] * b[6 + j];
+}
+
+// one wave per particle; every lane derives the particle's pose (60 flops) and then walks the lattice points
+__global__ __launch_bounds__(256) void ro_particles_kernel(const float* __restrict__ pst,
+                                                           const float* __restrict__ state,
+                                                           const float* __restrict__ rays_d_cam,
+                                                           const float* __restrict__ target_d, NormCfg nc,
+                                                           float* __restrict__ xn, float* __restrict__ pst7,
+                                                           uint32_t P, uint32_t n) {
+    const uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) / MIPSF_WAVE;
+    const uint32_t lane = threadIdx.x & (MIPSF_WAVE - 1);
+    if (p >= P) return;
+    float r[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r[k] = pst[6 * (size_t)p + k] * state[RO_SEARCH + k];
+    const float s = (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2];
+    const float qw = s <= 1.0f ? sqrtf(1.0f - s) : 0.0f;             // pose_6D_to_7D
+    if (lane == 0) {
+        float* o = pst7 + 7 * (size_t)p;
+        o[0] = qw;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[1 + k] = r[k];
+    }
+    float rot[9], dR[9], aR[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rot[k] = state[RO_ROT + k];
+    quat_to_mat(qw, r[0], r[1], r[2], dR);
+    mat_mul3(rot, dR, aR);                                            // get_abs_pose
+    const float t0 = state[RO_TRANS] + r[3], t1 = state[RO_TRANS + 1] + r[4], t2 = state[RO_TRANS + 2] + r[5];
+    for (uint32_t i = lane; i < n; i += MIPSF_WAVE) {
+        const float d = target_d[i];
+        const float c0 = rays_d_cam[3 * i] * d, c1 = rays_d_cam[3 * i + 1] * d, c2 = rays_d_cam[3 * i + 2] * d;
+        const float w0 = ((aR[0] * c0 + aR[1] * c1) + aR[2] * c2) + t0;     // batch_points_trans
+        const float w1 = ((aR[3] * c0 + aR[4] * c1) + aR[5] * c2) + t1;
+        const float w2 = ((aR[6] * c0 + aR[7] * c1) + aR[8] * c2) + t2;
+        float* o = xn + 3 * ((size_t)p * n + i);
+        o[0] = normalise1(w0, nc.sub[0], nc.div[0], nc.norm_factor);          // run_network's fp64 normalisation
+        o[1] = normalise1(w1, nc.sub[1], nc.div[1], nc.norm_factor);
+        o[2] = normalise1(w2, nc.sub[2], nc.div[2], nc.norm_factor);
+    }
+}
+
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+    v = wave_sum_d(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += sh[k];
+    return t;
+}
+
+// RandomOptimizer.py:196-224, one workgroup.  Sums are accumulated in fp64 (any fp32 summation order of the
+// reference is within one rounding of them).
+__global__ __launch_bounds__(256) void ro_update_kernel(const float* __restrict__ mean_masked,
+                                                        const float* __restrict__ pst7, float* __restrict__ state,
+                                                        float sdf_weight, float rescale, uint32_t P) {
+    __shared__ double sh[4];
+    const float f0 = mean_masked[0] * sdf_weight;
+    double s_w = 0.0, s_wm = 0.0, s_t[7] = {0, 0, 0, 0, 0, 0, 0}, s_n = 0.0;
+    for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) {
+        const float mm = mean_masked[p];
+        const float f = mm * sdf_weight;
+        const float w = f < f0 ? f0 - f : 0.0f;
+        s_n += f < f0 ? 1.0 : 0.0;
+        s_w += (double)w;
+        s_wm += (double)(w * mm);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) s_t[k] += (double)(pst7[7 * (size_t)p + k] * w);
+    }
+    s_n = block_sum_d(s_n, sh);
+    s_w = block_sum_d(s_w, sh);
+    s_wm = block_sum_d(s_wm, sh);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s_t[k] = block_sum_d(s_t[k], sh);
+    if (threadIdx.x != 0) return;
+    const float wsum = (float)s_w + 0.00001f;
+    const bool ok = s_n > 0.0;
+    float mt[7] = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, mean_sdf = mean_masked[0];
+    if (ok) {
+        mean_sdf = (float)s_wm / wsum;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) mt[k] = (float)s_t[k] / wsum;
+        const float nq = sqrtf(((mt[0] * mt[0] + mt[1] * mt[1]) + mt[2] * mt[2]) + mt[3] * mt[3]) + 1e-5f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mt[k] = mt[k] / nq;
+        float rot[9], dR[9], nr[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) rot[k] = state[RO_ROT + k];
+        quat_to_mat(mt[0], mt[1], mt[2], mt[3], dR);
+        mat_mul3(rot, dR, nr);                                        // update_cur_pose
+#pragma unroll
+        for (int k = 0; k < 9; ++k) state[RO_ROT + k] = nr[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) state[RO_TRANS + k] = state[RO_TRANS + k] + mt[4 + k];
+    }
+    float sz[6], n2 = 0.f;                                            // update_search_size
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        sz[k] = fabsf(mt[1 + k]) + 0.0001f;
+        n2 = n2 + sz[k] * sz[k];
+    }
+    const float nrm = sqrtf(n2);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float v = rescale * mean_sdf * sz[k] / nrm + 0.0001f;
+        state[RO_SEARCH + k] = ok ? v : v * 2.0f;
+    }
+    state[RO_SUCCESS] = ok ? 1.0f : 0.0f;
+    state[RO_MEAN_SDF] = mean_sdf;
+    state[RO_FIT0] = f0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) state[RO_MEAN_T + k] = mt[k];
+    state[RO_NBETTER] = (float)s_n;
+}
+
+}  // namespace mipsf
+
+using namespace mipsf;
+
+extern "C" {
+
+int mipsf_ro_particles(const float* pst, const float* state, const float* rays_d_cam, const float* target_d,
+                       const mipsf_render_cfg* cfg, float* xn, float* pst7, uint32_t P, uint32_t n, void* stream) {
+    if (P == 0 || n == 0) return 0;
+    MIPSF_REQUIRE(pst && state && rays_d_cam && target_d && cfg && xn && pst7, "null pointer");
+    const uint32_t threads = P * MIPSF_WAVE;
+    hipLaunchKernelGGL(ro_particles_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, pst, state,
+                       rays_d_cam, target_d, make_norm(*cfg), xn, pst7, P, n);
+    return check_launch("ro_particles");
+}
+
+int mipsf_ro_update(const float* mean_masked, const float* pst7, float* state, float sdf_weight, float rescale,
+                    uint32_t P, void* stream) {
+    MIPSF_REQUIRE(P >= 1, "empty particle swarm");
+    MIPSF_REQUIRE(mean_masked && pst7 && state, "null pointer");
+    hipLaunchKernelGGL(ro_update_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mean_masked, pst7, state,
+                       sdf_weight, rescale, P);
+    return check_launch("ro_update");
+}
+
+}  // extern "C"

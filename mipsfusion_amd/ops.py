@@ -390,3 +390,24 @@ def ro_fitness(raw, target_d, trunc: float) -> torch.Tensor:
     check(lib().mipsf_ro_fitness(dptr(raw), stride, dptr(target_d), trunc, dptr(out), P, n, stream_ptr()),
           "ro_fitness")
     return out
+
+
+RO_STATE_FLOATS = 32
+
+
+def ro_particles(pst, state, rays_d_cam, target_d, rc):
+    """One RandomOptimizer round, first half (RandomOptimizer.py:184-190, 117-121): -> xn [P*n,3], pst7 [P,7]."""
+    P, n = pst.shape[0], rays_d_cam.shape[0]
+    xn = torch.empty((P * n, 3), dtype=torch.float32, device=pst.device)
+    pst7 = torch.empty((P, 7), dtype=torch.float32, device=pst.device)
+    with _timed("ro_particles"):
+        check(lib().mipsf_ro_particles(dptr(pst), dptr(state), dptr(rays_d_cam), dptr(target_d), C.byref(rc),
+                                       dptr(xn), dptr(pst7), P, n, stream_ptr()), "ro_particles")
+    return xn, pst7
+
+
+def ro_update(mean_masked, pst7, state, sdf_weight: float, rescale: float):
+    """Second half (RandomOptimizer.py:196-224): updates ``state`` (rot, trans, search size) in place on the device."""
+    with _timed("ro_update"):
+        check(lib().mipsf_ro_update(dptr(mean_masked), dptr(pst7), dptr(state), sdf_weight, rescale,
+                                    mean_masked.shape[0], stream_ptr()), "ro_update")

@@ -16,6 +16,7 @@ Files written
   adam.npz           torch.optim.Adam with the two param groups of mipsfusion.py:580-584
   quaternion.npz     geometry_helper.py:11-17 qt_to_transform_matrix (+ grads) [pytorch3d unpinned]
   ba_trace.npz       loss-per-iteration trace of a 6-iteration local-BA-style loop (mipsfusion.py:293-342)
+  ro.npz             RandomOptimizer.py:164-227 optimize (6 iterations, pose after each) + one get_fitness
   hashgrid.npz       ORACLE-generated (tinycudann absent => parity unpinned): hash-grid indices,
                      features and gradients at hash 2^10 and a sparse probe at hash 2^19
 """
@@ -334,6 +335,56 @@ def gen_hashgrid():
     save("hashgrid.npz", **out)
 
 
+# ------------------------------------------------------------------- RandomOptimizer
+def gen_ro():
+    """RandomOptimizer.optimize (RandomOptimizer.py:164-227) on BASELINE config 1 with a small particle swarm.
+    The reference's class is imported unmodified (pytorch3d.transforms -> oracle/p3d_cpu, see ref_import)."""
+    import importlib
+    import types
+    RO = importlib.import_module("RandomOptimizer")
+    seed_all(11)
+    cfg = synth.config_plumbing()
+    cfg["tracking"]["RO"] = dict(cfg["tracking"].get("RO", {}), particle_size=96, n_rows=4, n_cols=6,
+                                 initial_scaling_factor=0.02, rescaling_factor=0.5)
+    cfg["tracking"].setdefault("ignore_edge_W", 2)
+    cfg["tracking"].setdefault("ignore_edge_H", 2)
+    bb = torch.from_numpy(np.array(cfg["mapping"]["bound"]))
+    nf = torch.from_numpy(np.array(cfg["mapping"]["localMLP_max_len"]))
+    model = ref.scene_rep.JointEncoding(cfg, bb, nf)
+    with torch.no_grad():
+        model.embed_fn.params.copy_(torch.randn_like(model.embed_fn.params) * 0.3)
+        model.decoder.sdf_linear[2].weight.mul_(6.0)
+    model.eval()
+    frame = synth.make_frame(cfg, seed=11)
+    H, W, fx, fy, cx, cy = synth.intrinsics_after_crop(cfg)
+    depth = frame["depth"].clone()
+    dataset = types.SimpleNamespace(H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy, rays_d=frame["direction"])
+    slam = types.SimpleNamespace(dataset=dataset, device=torch.device("cpu"))
+    ro = RO.RandomOptimizer(cfg, slam)
+    depth[ro.row_indices[3] + 1, ro.col_indices[3] + 1] = 0.0   # an invalid lattice pixel (valid_mask branch, offset 1)
+    depth[ro.row_indices[7], ro.col_indices[7]] = 0.0
+    c2w = frame["c2w"].clone()
+    # start a little away from the true pose so that the swarm finds better particles
+    init = c2w.clone()
+    init[:3, 3] += torch.tensor([0.03, -0.02, 0.025])
+    arrays = dict(pst=ro.pre_sampled_particle, rows=ro.row_indices, cols=ro.col_indices, depth=depth,
+                  rays_dir=dataset.rays_d, init_pose=init, bound=bb, half_len=nf,
+                  particle_size=96, n_rows=4, n_cols=6, c1=0.02, c2=0.5, trunc=cfg["training"]["trunc"])
+    for k, v in model.state_dict().items():
+        arrays["w." + k] = v
+    for n_iter in range(0, 7):
+        arrays[f"pose_after_{n_iter}"] = ro.optimize(model, depth, init.clone(), c2w, n_iter=n_iter)
+    # one fitness evaluation in isolation (RandomOptimizer.py:113-131)
+    pst7 = ro.pose_6D_to_7D(ro.pre_sampled_particle * 0.02)
+    rot, trans = ro.get_abs_pose(init[:3, :3], init[:3, 3:], pst7)
+    td = depth[ro.row_indices, ro.col_indices].unsqueeze(-1)
+    rd = dataset.rays_d[ro.row_indices, ro.col_indices, :]
+    with torch.no_grad():
+        fit, mms = ro.get_fitness(model, rot, trans, c2w, td, rd)
+    arrays.update(fit0=fit, mean_masked0=mms, pst7_0=pst7, abs_rot0=rot, abs_trans0=trans)
+    save("ro.npz", **arrays)
+
+
 if __name__ == "__main__":
     gen_sampler()
     gen_losses()
@@ -346,3 +397,4 @@ if __name__ == "__main__":
     gen_quaternion()
     gen_ba_trace()
     gen_hashgrid()
+    gen_ro()

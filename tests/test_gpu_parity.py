@@ -676,3 +676,79 @@ def test_full_size_training_step_vs_oracle_subset(dev):
     assert_grad_close(m.embed_fn.params.grad, cpu.embed_fn.params.grad, 5e-4, "grid gradient")
     assert_grad_close(m.decoder.sdf_linear[0].weight.grad, cpu.decoder.sdf_linear[0].weight.grad, 5e-4,
                       "decoder gradient")
+
+
+# ------------------------------------------------------------------------ RandomOptimizer
+def _ro_setup(g, dev, particle_size=None):
+    import types
+    from mipsfusion_amd.RandomOptimizer import RandomOptimizer
+    cfg = synth.config_plumbing()
+    P = int(g["particle_size"]) if particle_size is None else particle_size
+    cfg["tracking"]["RO"] = dict(particle_size=P, n_rows=int(g["n_rows"]), n_cols=int(g["n_cols"]),
+                                 initial_scaling_factor=float(g["c1"]), rescaling_factor=float(g["c2"]))
+    cfg["tracking"]["ignore_edge_W"] = cfg["tracking"]["ignore_edge_H"] = 2
+    H, W, fx, fy, cx, cy = synth.intrinsics_after_crop(cfg)
+    ds = types.SimpleNamespace(H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy, rays_d=T(g["rays_dir"]))
+    ro = RandomOptimizer(cfg, types.SimpleNamespace(dataset=ds, device=dev))
+    return cfg, ro
+
+
+@pytest.mark.gpu
+def test_random_optimizer_matches_reference_golden(dev):
+    """Fused particle rounds (ro_particles -> hashgrid -> decoder -> ro_fitness -> ro_update) vs the poses the
+    reference's own RandomOptimizer.optimize produced (tests/golden/ro.npz), round by round."""
+    g = load_golden("ro.npz")
+    cfg, ro = _ro_setup(g, dev)
+    assert np.array_equal(ro.row_indices.numpy(), g["rows"]) and np.array_equal(ro.col_indices.numpy(), g["cols"])
+    ro.pre_sampled_particle = T(g["pst"]).to(dev).contiguous()
+    m = make_scene(g, cfg, dev)
+    m.eval()
+    depth, init = T(g["depth"]), T(g["init_pose"])
+    # first half of a round against the reference's intermediate tensors
+    state = torch.zeros(ops.RO_STATE_FLOATS, device=dev)
+    state[0:9], state[9:12], state[12:18] = init[:3, :3].reshape(9).to(dev), init[:3, 3].to(dev), float(g["c1"])
+    td = depth[ro.row_indices, ro.col_indices].to(dev).contiguous()
+    xn, pst7 = ops.ro_particles(ro.pre_sampled_particle, state, ro._dirs[0], td, m._rc(1, 0))
+    assert_close(pst7, g["pst7_0"], 1e-7, "7-D particle poses")
+    world = (T(g["abs_rot0"]) @ (T(g["rays_dir"])[ro.row_indices, ro.col_indices] * td.cpu()[:, None]).T
+             + T(g["abs_trans0"])).transpose(1, 2)
+    bound = T(g["bound"]).double()
+    xn_ref = ((world.double() - bound[:, 0]) / (bound[:, 1] - bound[:, 0])).float().reshape(-1, 3)
+    assert_close(xn, xn_ref, 2e-6, "normalised particle points")
+    mm = ops.ro_fitness(m.query_color_sdf(xn).view(pst7.shape[0], -1, 10), td, float(g["trunc"]))
+    assert_close(mm, g["mean_masked0"], 1e-4, "mean masked |sdf| per particle")
+    # whole optimisation
+    for n_iter in range(0, 7):
+        pose = ro.optimize(m, depth, init.clone(), None, n_iter=n_iter)
+        assert_close(pose, g[f"pose_after_{n_iter}"], 1e-4, f"tracked pose after {n_iter} rounds")
+
+
+@pytest.mark.gpu
+def test_random_optimizer_full_size_vs_oracle(dev):
+    """2000 particles x (16 x 24) lattice points at the headline grid: three fused rounds vs oracle/ro_cpu.py fed
+    with the same network (the oracle queries the GPU model so that only the particle logic is compared)."""
+    import types
+    from oracle import ro_cpu
+    from mipsfusion_amd.RandomOptimizer import RandomOptimizer
+    cfg, m, _ = headline_scene(dev, hash_size=16)
+    cfg["tracking"]["RO"].update(initial_scaling_factor=0.02, rescaling_factor=0.5)
+    cfg["tracking"]["ignore_edge_W"] = cfg["tracking"]["ignore_edge_H"] = 20
+    frame = synth.make_frame(cfg, seed=3)
+    H, W, fx, fy, cx, cy = synth.intrinsics_after_crop(cfg)
+    ds = types.SimpleNamespace(H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy, rays_d=frame["direction"])
+    np.random.seed(5)
+    ro = RandomOptimizer(cfg, types.SimpleNamespace(dataset=ds, device=dev))
+    m.eval()
+    init = frame["c2w"].clone()
+    init[:3, 3] += torch.tensor([0.02, -0.015, 0.01])
+    pose, state = ro.optimize(m, frame["depth"], init, None, n_iter=3, return_state=True)
+
+    def net(world):
+        with torch.no_grad():
+            return m.run_network(world.to(dev)).cpu()
+    ref_pose, trace = ro_cpu.optimize(net, ro.pre_sampled_particle.cpu(), ro.row_indices, ro.col_indices,
+                                      frame["depth"], frame["direction"], init, 3, 0.02, 0.5,
+                                      cfg["training"]["trunc"])
+    assert_close(pose, ref_pose, 1e-4, "tracked pose, 3 rounds, 2000 particles")
+    assert_close(state[12:18], trace[-1]["search"].reshape(6), 1e-3, "search size")
+    assert bool(state[18] > 0) == trace[-1]["success"]

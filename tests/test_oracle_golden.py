@@ -263,3 +263,30 @@ def test_plain_c_restatement_agrees_bit_for_bit():
     g = load_golden("hashgrid.npz")
     idx19, _ = c_ref.hashgrid(g["t19.x"], None, meta)
     assert np.array_equal(idx19.astype(np.int32), g["t19.idx"])
+
+
+# ------------------------------------------------------------------------------ RandomOptimizer
+def test_random_optimizer_restatement_matches_reference():
+    """oracle/ro_cpu.py vs poses produced by the reference's own RandomOptimizer.optimize (tests/golden/ro.npz)."""
+    from oracle import ro_cpu
+    g = load_golden("ro.npz")
+    m = scene_from(g, synth.config_plumbing())
+    m.eval()
+    pst, rows, cols = T(g["pst"]), T(g["rows"]).long(), T(g["cols"]).long()
+    depth, rays_dir, init = T(g["depth"]), T(g["rays_dir"]), T(g["init_pose"])
+    c1, c2, trunc = float(g["c1"]), float(g["c2"]), float(g["trunc"])
+    # one fitness evaluation
+    pst7 = ro_cpu.pose_6d_to_7d(pst * c1)
+    close(pst7, g["pst7_0"], rtol=0, atol=0)
+    td = depth[rows, cols][:, None]
+    world, a_rot, a_trans = ro_cpu.particle_points(init[:3, :3], init[:3, 3:], pst7, rays_dir[rows, cols, :] * td)
+    close(a_rot, g["abs_rot0"], rtol=1e-6, atol=1e-7)
+    close(a_trans, g["abs_trans0"], rtol=1e-6, atol=1e-7)
+    with torch.no_grad():
+        mms = ro_cpu.mean_masked_sdf(m.run_network, world, td, trunc)
+    close(mms, g["mean_masked0"], rtol=2e-5, atol=1e-7)
+    # whole optimisation, pose after every round
+    for n_iter in range(0, 7):
+        pose, trace = ro_cpu.optimize(m.run_network, pst, rows, cols, depth, rays_dir, init, n_iter, c1, c2, trunc)
+        close(pose, g[f"pose_after_{n_iter}"], rtol=1e-4, atol=2e-6)
+        assert len(trace) == n_iter

@@ -6,6 +6,6 @@ cd "$(dirname "$0")/../.."
 SRC=mipsfusion_amd/csrc
 SUF=$1; shift
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -w "$@" \
-    -Iinclude -shared $SRC/capi.hip $SRC/hashgrid.hip $SRC/elementwise.hip $SRC/render.hip $SRC/decoder.hip $SRC/pose.hip \
+    -Iinclude -shared $SRC/capi.hip $SRC/hashgrid.hip $SRC/elementwise.hip $SRC/render.hip $SRC/decoder.hip $SRC/pose.hip $SRC/ro.hip \
     -o tools/micro/libmipsf_$SUF.so
 echo built tools/micro/libmipsf_$SUF.so
