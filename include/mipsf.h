@@ -262,6 +262,15 @@ int mipsf_ro_particles(const float* pst, const float* state, const float* rays_d
 int mipsf_ro_update(const float* mean_masked, const float* pst7, float* state, float sdf_weight, float rescale,
                     uint32_t P, void* stream);
 
+/* ---------------------------------------- keyframe ray database gather */
+/* db [n_rows,7] = rows [direction(3) | rgb(3) | depth] of the device-resident keyframe database
+ * (model/keyframeSet.py:25); idx [N] int64 flat row indices generated on the host (python `random.sample`, so the
+ * index stream is the reference's; negative = from the end).  Any of the outputs may be NULL:
+ * rays7 [N,7] (what sample_rays_in_submap returns, keyframeSet.py:386-436), d_cam [N,3], rgb [N,3], depth [N]
+ * (the three slices mipsfusion.py:315-317 uploads every iteration). */
+int mipsf_gather_rays(const float* db, uint64_t n_rows, const int64_t* idx, uint32_t N, float* rays7, float* d_cam,
+                      float* rgb, float* depth, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,6 +94,7 @@ SIGNATURES = {
     "mipsf_ro_fitness": (_I, [_P, _U32, _P, _F, _P, _U32, _U32, _P]),
     "mipsf_ro_particles": (_I, [_P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _U32, _U32, _P]),
     "mipsf_ro_update": (_I, [_P, _P, _P, _F, _F, _U32, _P]),
+    "mipsf_gather_rays": (_I, [_P, _U64, _P, _U32, _P, _P, _P, _P, _P]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -171,3 +171,41 @@ int mipsf_ro_update(const float* mean_masked, const float* pst7, float* state, f
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Keyframe ray database gather (reference model/keyframeSet.py:264-290, 386-455 and
+// mipsfusion.py:296-317): rows [direction(3) | rgb(3) | depth(1)] of the device-resident database are gathered by
+// host-generated flat indices (the index stream stays on the host so that python's `random.sample` draws are the
+// reference's) and split straight into the three tensors the iteration consumes.
+namespace mipsf {
+__global__ __launch_bounds__(256) void gather_rays_kernel(const float* __restrict__ db, const int64_t* __restrict__ idx,
+                                                          uint64_t n_rows, uint32_t N, float* __restrict__ rays7,
+                                                          float* __restrict__ d_cam, float* __restrict__ rgb,
+                                                          float* __restrict__ depth) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    int64_t r = idx[t];
+    if (r < 0) r += (int64_t)n_rows;
+    const float* s = db + 7 * (size_t)r;
+    float v[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v[k] = s[k];
+    if (rays7) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) rays7[7 * (size_t)t + k] = v[k];
+    }
+    if (d_cam) d_cam[3 * (size_t)t] = v[0], d_cam[3 * (size_t)t + 1] = v[1], d_cam[3 * (size_t)t + 2] = v[2];
+    if (rgb) rgb[3 * (size_t)t] = v[3], rgb[3 * (size_t)t + 1] = v[4], rgb[3 * (size_t)t + 2] = v[5];
+    if (depth) depth[t] = v[6];
+}
+}  // namespace mipsf
+
+extern "C" int mipsf_gather_rays(const float* db, uint64_t n_rows, const int64_t* idx, uint32_t N, float* rays7,
+                                 float* d_cam, float* rgb, float* depth, void* stream) {
+    if (N == 0) return 0;
+    MIPSF_REQUIRE(db && idx, "null pointer");
+    MIPSF_REQUIRE(rays7 || d_cam || rgb || depth, "no output requested");
+    hipLaunchKernelGGL(mipsf::gather_rays_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, db, idx,
+                       n_rows, N, rays7, d_cam, rgb, depth);
+    return mipsf::check_launch("gather_rays");
+}

@@ -411,3 +411,21 @@ def ro_update(mean_masked, pst7, state, sdf_weight: float, rescale: float):
     with _timed("ro_update"):
         check(lib().mipsf_ro_update(dptr(mean_masked), dptr(pst7), dptr(state), sdf_weight, rescale,
                                     mean_masked.shape[0], stream_ptr()), "ro_update")
+
+
+def gather_rays(db, idx, split: bool = False):
+    """db [..., 7] device-resident ray rows, idx int64 [N] (device) -> rays [N,7], or (d_cam, rgb, depth[N,1])."""
+    flat = db.reshape(-1, 7)
+    N = idx.shape[0]
+    dev = flat.device
+    if split:
+        d_cam = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        rgb = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        depth = torch.empty((N, 1), dtype=torch.float32, device=dev)
+        check(lib().mipsf_gather_rays(dptr(flat), flat.shape[0], dptr(idx, torch.int64), N, None, dptr(d_cam),
+                                      dptr(rgb), dptr(depth), stream_ptr()), "gather_rays")
+        return d_cam, rgb, depth
+    out = torch.empty((N, 7), dtype=torch.float32, device=dev)
+    check(lib().mipsf_gather_rays(dptr(flat), flat.shape[0], dptr(idx, torch.int64), N, dptr(out), None, None, None,
+                                  stream_ptr()), "gather_rays")
+    return out

@@ -17,6 +17,7 @@ Files written
   quaternion.npz     geometry_helper.py:11-17 qt_to_transform_matrix (+ grads) [pytorch3d unpinned]
   ba_trace.npz       loss-per-iteration trace of a 6-iteration local-BA-style loop (mipsfusion.py:293-342)
   ro.npz             RandomOptimizer.py:164-227 optimize (6 iterations, pose after each) + one get_fitness
+  keyframe_rays.npz  model/keyframeSet.py:268-290, 386-455 ray samplers of the reference's KeyframeSet (seeded)
   hashgrid.npz       ORACLE-generated (tinycudann absent => parity unpinned): hash-grid indices,
                      features and gradients at hash 2^10 and a sparse probe at hash 2^19
 """
@@ -385,6 +386,39 @@ def gen_ro():
     save("ro.npz", **arrays)
 
 
+# ------------------------------------------------------------------- keyframe ray sampling
+def gen_keyframe_rays():
+    """model/keyframeSet.py ray samplers (:268-290, :386-455) of the reference's own KeyframeSet: for a seeded
+    python RNG and a random ray database, which rows come out (rays, kf_ids, kf_indices)."""
+    import importlib
+    KF = importlib.import_module("model.keyframeSet")
+    cfg = {"sampling": {"kf_n_rays_h": 6, "kf_n_rays_w": 8},
+           "mapping": {"localMLP_num": 2, "localMLP_max_len": [7.0, 7.0, 7.0], "overlapping": {"n_rays_h": 2, "n_rays_w": 2}}}
+    num_kf = 7
+    kfs = KF.KeyframeSet(cfg, 32, 32, num_kf, torch.device("cpu"))
+    seed_all(21)
+    kfs.rays = torch.randn(num_kf, kfs.num_rays_to_save, 7)
+    kfs.frame_ids = torch.arange(num_kf, dtype=torch.float32) * 5
+    arrays = dict(db=kfs.rays, num_rays_to_save=kfs.num_rays_to_save)
+    cases = {"sub1": (torch.tensor(2), torch.tensor([2]), 40), "sub2": (torch.tensor(1), torch.tensor([1, 4]), 40),
+             "sub5": (torch.tensor(0), torch.tensor([0, 2, 3, 5, 6]), 45)}
+    for name, (first, rel, n) in cases.items():
+        random.seed(100 + n)
+        rays, kf_ids, kf_indices = kfs.sample_rays_in_submap(first, rel, n)
+        arrays.update({f"{name}.first": first, f"{name}.related": rel, f"{name}.n": n, f"{name}.seed": 100 + n,
+                       f"{name}.rays": rays, f"{name}.kf_ids": kf_ids, f"{name}.kf_indices": kf_indices})
+    random.seed(7)
+    rays, kf_ids, kf_indices = kfs.sample_rays_in_given_kf(torch.tensor([6, 1, 3]), 30)
+    arrays.update({"given.rays": rays, "given.kf_ids": kf_ids, "given.kf_indices": kf_indices})
+    random.seed(8)
+    rays, kf_ids = kfs.sample_global_rays(25)
+    arrays.update({"global.rays": rays, "global.kf_ids": kf_ids})
+    random.seed(9)
+    rays, kf_indices = kfs.sample_rays_from_given(torch.tensor([5, 0]), 20)
+    arrays.update({"from_given.rays": rays, "from_given.kf_indices": kf_indices})
+    save("keyframe_rays.npz", **arrays)
+
+
 if __name__ == "__main__":
     gen_sampler()
     gen_losses()
@@ -398,3 +432,4 @@ if __name__ == "__main__":
     gen_ba_trace()
     gen_hashgrid()
     gen_ro()
+    gen_keyframe_rays()

@@ -752,3 +752,41 @@ def test_random_optimizer_full_size_vs_oracle(dev):
     assert_close(pose, ref_pose, 1e-4, "tracked pose, 3 rounds, 2000 particles")
     assert_close(state[12:18], trace[-1]["search"].reshape(6), 1e-3, "search size")
     assert bool(state[18] > 0) == trace[-1]["success"]
+
+
+# --------------------------------------------------------------- device-resident keyframe rays
+@pytest.mark.gpu
+def test_keyframe_ray_sampling_matches_reference_bit_for_bit(dev):
+    """DeviceRayDB (HBM database, host index stream, gather kernel) vs the rows the reference's own KeyframeSet
+    sampled for the same python RNG seeds (tests/golden/keyframe_rays.npz)."""
+    from mipsfusion_amd.keyframe_rays import DeviceRayDB
+    g = load_golden("keyframe_rays.npz")
+    db = DeviceRayDB(g["db"].shape[0], int(g["num_rays_to_save"]), dev)
+    for k in range(g["db"].shape[0]):
+        db.store(k, T(g["db"][k]))
+    for name in ("sub1", "sub2", "sub5"):
+        random.seed(int(g[f"{name}.seed"]))
+        rays, kf_ids, kf_indices = db.sample_rays_in_submap(T(g[f"{name}.first"]), T(g[f"{name}.related"]).long(),
+                                                            int(g[f"{name}.n"]))
+        assert rays.is_cuda and np.array_equal(rays.cpu().numpy(), g[f"{name}.rays"]), name
+        assert np.array_equal(kf_ids.numpy(), g[f"{name}.kf_ids"]) and np.array_equal(kf_indices.numpy(),
+                                                                                      g[f"{name}.kf_indices"])
+    random.seed(7)
+    rays, kf_ids, kf_indices = db.sample_rays_in_given_kf(torch.tensor([6, 1, 3]), 30)
+    assert np.array_equal(rays.cpu().numpy(), g["given.rays"]) and np.array_equal(kf_ids.numpy(), g["given.kf_ids"])
+    assert np.array_equal(kf_indices.numpy(), g["given.kf_indices"])
+    random.seed(8)
+    rays, kf_ids = db.sample_global_rays(25, g["db"].shape[0])
+    assert np.array_equal(rays.cpu().numpy(), g["global.rays"]) and np.array_equal(kf_ids.numpy(), g["global.kf_ids"])
+    random.seed(9)
+    rays, kf_indices = db.sample_rays_from_given(torch.tensor([5, 0]), 20)
+    assert np.array_equal(rays.cpu().numpy(), g["from_given.rays"])
+    assert np.array_equal(kf_indices.numpy(), g["from_given.kf_indices"])
+    # split form (what mipsfusion.py:315-317 slices and uploads), negative and empty index lists
+    idx = torch.tensor([0, 5, -1, 17], device=dev)
+    d_cam, rgb, depth = ops.gather_rays(db.rays, idx, split=True)
+    flat = T(g["db"]).reshape(-1, 7)
+    ref = flat[[0, 5, flat.shape[0] - 1, 17]]
+    assert torch.equal(d_cam.cpu(), ref[:, :3]) and torch.equal(rgb.cpu(), ref[:, 3:6])
+    assert torch.equal(depth.cpu(), ref[:, 6:7])
+    assert ops.gather_rays(db.rays, torch.empty(0, dtype=torch.int64, device=dev)).shape == (0, 7)
