@@ -227,6 +227,45 @@ def forward_only_rate(model, loop, dev, iters=10):
     return N_RAYS * N_SAMPLES / dt, dt * 1e3
 
 
+def inference_rates(cfg, model, dev):
+    """Logger.render_full_img-style full-frame render (10 000-ray chunks) and Mesher-style dense grid
+    queries (16 384-point batches) through the eval / query_* entry points."""
+    from mipsfusion_amd import inference
+    frame = synth.make_frame(cfg, seed=2)
+    H, W = frame["depth"].shape
+    S = cfg["training"]["n_samples_d"] + cfg["training"]["n_range_d"]
+    noise = torch.rand(H * W, S, device=dev)
+    was_training = model.training
+    model.eval()
+    d_cam, c2w, depth = frame["direction"].to(dev), frame["c2w"].to(dev), frame["depth"].to(dev)
+
+    def render():
+        return inference.render_full_img(model, d_cam, c2w, depth, H, W, 10000, noise=noise)
+    render()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        render()
+    torch.cuda.synchronize()
+    img_ms = (time.perf_counter() - t0) / 3 * 1e3
+    pts = torch.rand(128 ** 3, 3, device=dev)
+    inference.query_in_batches(model.query_sdf, pts[:65536])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    inference.query_in_batches(model.query_sdf, pts, batch_size=1024 * 16)
+    torch.cuda.synchronize()
+    q16k_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    inference.query_in_batches(model.query_sdf, pts, batch_size=1024 * 1024)
+    torch.cuda.synchronize()
+    q1m_ms = (time.perf_counter() - t0) * 1e3
+    model.train(was_training)
+    return {"full_image_ms": round(img_ms, 3), "image": f"{W}x{H} rays x {S} samples, 10000-ray chunks",
+            "full_image_rays_samples_per_s": round(H * W * S / (img_ms * 1e-3), 1),
+            "grid_query_128cubed_ms_batch16k": round(q16k_ms, 3), "grid_query_128cubed_ms_batch1M": round(q1m_ms, 3),
+            "grid_query_points_per_s_batch1M": round(128 ** 3 / (q1m_ms * 1e-3), 1)}
+
+
 def frame_estimate(cfg, model, loop, dev, ba_ms, stream=None):
     """tracking+mapping ms/frame = iter_RO*RO + tracking.iter*GO + mapping.iters*BA/map_every."""
     # RO: the whole RandomOptimizer.optimize call of one frame (iter_RO fused rounds: particles -> grid -> decoder ->
@@ -503,6 +542,8 @@ def main():
     if not args.no_frame_estimate:
         out["frame"] = frame_estimate(cfg, model, loop, dev, ms_step, stream if use_graph else None)
         log("frame estimate done")
+        out["inference"] = inference_rates(cfg, model, dev)
+        log("inference consumers done")
     if world == 1 and args.cpu_rays > 0:
         out["cpu_baseline"] = cpu_baseline(cfg, loop, args.cpu_rays, args.cpu_iters)
     print(json.dumps(out), flush=True)

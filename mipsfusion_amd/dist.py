@@ -40,3 +40,22 @@ def max_over_ranks(seconds: float, device, group=None) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t)
+
+
+def all_gather_ragged(mine: torch.Tensor, n_total: int, world: int, group=None) -> torch.Tensor:
+    """Contiguous shares of an [n_total, ...] tensor (share sizes differ by at most one, see
+    inference.share_of) -> the whole tensor on every rank.  One all_gather of equal-size padded blocks."""
+    if not (dist.is_available() and dist.is_initialized()) or world == 1:
+        return mine
+    base, extra = divmod(n_total, world)
+    block = base + (1 if extra else 0)
+    dev = mine.device
+    buf = mine
+    if dist.get_backend(group) == "gloo" and buf.is_cuda:
+        buf = buf.cpu()
+    pad = torch.zeros((block,) + tuple(buf.shape[1:]), dtype=buf.dtype, device=buf.device)
+    pad[:buf.shape[0]] = buf
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad, group=group)
+    parts = [out[r][:base + (1 if r < extra else 0)] for r in range(world)]
+    return torch.cat(parts, 0).to(dev)

@@ -18,6 +18,8 @@ Files written
   ba_trace.npz       loss-per-iteration trace of a 6-iteration local-BA-style loop (mipsfusion.py:293-342)
   ro.npz             RandomOptimizer.py:164-227 optimize (6 iterations, pose after each) + one get_fitness
   keyframe_rays.npz  model/keyframeSet.py:268-290, 386-455 ray samplers of the reference's KeyframeSet (seeded)
+  ref_model_0.pth    a checkpoint as the reference writes it (Logger.py:33-34: torch.save(model.state_dict()))
+  checkpoint_probe.npz  points + the reference model's query_color_sdf output for that checkpoint
   hashgrid.npz       ORACLE-generated (tinycudann absent => parity unpinned): hash-grid indices,
                      features and gradients at hash 2^10 and a sparse probe at hash 2^19
 """
@@ -419,6 +421,25 @@ def gen_keyframe_rays():
     save("keyframe_rays.npz", **arrays)
 
 
+# ------------------------------------------------------------------- checkpoint format
+def gen_checkpoint():
+    """A checkpoint exactly as the reference writes it (Logger.py:33-34, 267-277: torch.save(model.state_dict())),
+    from the reference's own JointEncoding at BASELINE config 1, plus the eval output it must reproduce."""
+    seed_all(31)
+    cfg = synth.config_plumbing()
+    bb = torch.from_numpy(np.array(cfg["mapping"]["bound"]))
+    nf = torch.from_numpy(np.array(cfg["mapping"]["localMLP_max_len"]))
+    model = ref.scene_rep.JointEncoding(cfg, bb, nf)
+    with torch.no_grad():
+        model.embed_fn.params.copy_(torch.randn_like(model.embed_fn.params) * 0.3)
+    torch.save(model.state_dict(), os.path.join(HERE, "ref_model_0.pth"))
+    pts = torch.rand(64, 3)
+    with torch.no_grad():
+        out = model.query_color_sdf(pts)
+    save("checkpoint_probe.npz", pts=pts, out=out, bound=bb, half_len=nf)
+    print("ref_model_0.pth:", os.path.getsize(os.path.join(HERE, "ref_model_0.pth")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     gen_sampler()
     gen_losses()
@@ -433,3 +454,4 @@ if __name__ == "__main__":
     gen_hashgrid()
     gen_ro()
     gen_keyframe_rays()
+    gen_checkpoint()

@@ -27,7 +27,12 @@ def _worker(rank, world, port, q):
         trans = torch.full((K, 3), 10.0 * rank)
         allp = mdist.exchange_poses(rot, trans)
         t = mdist.max_over_ranks(0.5 + rank, torch.device("cpu"))
-        q.put((rank, allp.clone(), t, mdist.submaps_of_rank(8, world, rank)))
+        # ray-data-parallel inference: contiguous shares of 11 rays, gathered back in order
+        from mipsfusion_amd.inference import share_of
+        b, e = share_of(11, rank, world)
+        whole = torch.arange(11 * 3, dtype=torch.float32).reshape(11, 3)
+        gathered = mdist.all_gather_ragged(whole[b:e].clone(), 11, world)
+        q.put((rank, allp.clone(), t, mdist.submaps_of_rank(8, world, rank), gathered.clone(), (b, e)))
     finally:
         dist.destroy_process_group()
 
@@ -43,7 +48,9 @@ def test_pose_exchange_and_ownership_world2():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, allp, t, owned in res:
+    for rank, allp, t, owned, gathered, share in res:
+        assert torch.equal(gathered, torch.arange(33, dtype=torch.float32).reshape(11, 3))
+        assert share == ((0, 6) if rank == 0 else (6, 11))
         assert allp.shape == (2, 4, 7)
         for src in range(2):
             assert torch.equal(allp[src, :, :4], torch.full((4, 4), float(src)) + torch.arange(4)[:, None])

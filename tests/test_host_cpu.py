@@ -128,3 +128,36 @@ def test_pose_helpers_match_golden():
     np.testing.assert_allclose(trans.grad.numpy(), g["d_trans"], rtol=1e-6)
     np.testing.assert_allclose(gh.matrix_to_quaternion(torch.from_numpy(g["T"])[:, :3, :3]).numpy(), g["q_back"],
                                rtol=1e-6, atol=1e-7)
+
+
+def test_reference_checkpoint_file_loads_and_round_trips(tmp_path):
+    """tests/golden/ref_model_0.pth was written by the reference's own JointEncoding with
+    torch.save(model.state_dict()) (Logger.py:33-34).  It must load into this package's JointEncoding with strict
+    keys, and a checkpoint written here must have exactly the reference's keys, shapes and dtypes."""
+    import os
+    import numpy as np
+    from mipsfusion_amd import checkpoint, synth
+    from mipsfusion_amd.model import JointEncoding
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ref_sd = torch.load(os.path.join(here, "ref_model_0.pth"))
+    assert tuple(ref_sd.keys()) == checkpoint.EXPECTED_KEYS
+    cfg = synth.config_plumbing()
+    bb = torch.from_numpy(np.array(cfg["mapping"]["bound"]))
+    nf = torch.from_numpy(np.array(cfg["mapping"]["localMLP_max_len"]))
+    m = JointEncoding(cfg, bb, nf)
+    checkpoint.load_state_dict(m, os.path.join(here, "ref_model_0.pth"))
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, ref_sd[k]), k
+    out = tmp_path / "model_0.pth"
+    checkpoint.save_state_dict(m, out)
+    mine = torch.load(out)
+    assert list(mine.keys()) == list(ref_sd.keys())
+    for k in mine:
+        assert mine[k].shape == ref_sd[k].shape and mine[k].dtype == ref_sd[k].dtype and torch.equal(mine[k], ref_sd[k])
+    m2 = JointEncoding(cfg, bb, nf)
+    checkpoint.copy_parameters_(m2, m)
+    for (k, a), (_, b) in zip(m.named_parameters(), m2.named_parameters()):
+        assert torch.equal(a, b), k
+    with pytest.raises(RuntimeError):
+        torch.save({"x": torch.zeros(1)}, tmp_path / "bad.pth")
+        checkpoint.load_state_dict(m, tmp_path / "bad.pth")
