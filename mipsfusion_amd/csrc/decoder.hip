@@ -548,7 +548,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
 // ============================================================================ weight gradients
 constexpr int WG_LDW = 129;                         // odd row stride: conflict-free both ways
 constexpr int WG_ROWS = 128;
-constexpr int WG_LDS_FLOATS = 2 * WG_ROWS * WG_LDW;
+constexpr int WG_LDS_FLOATS = (2 * WG_ROWS + 32) * WG_LDW;   // X^T, Y^T and the 8 (padded to 32) small-gradient rows
 constexpr int WG_LDS_BYTES = WG_LDS_FLOATS * 4;
 
 // Staging is split in two so that HBM latency hides under matrix work (the kernel runs one wave per SIMD, nothing
@@ -656,6 +656,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* XT = lds;
     float* YT = lds + WG_ROWS * WG_LDW;
+    float* X8 = lds + 2 * WG_ROWS * WG_LDW;       // [dlogits(5) | drgb(3)] rows; rows 8..31 are read but masked
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
 
@@ -666,13 +667,24 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
 
     auto row_sum = [&](const float* T, int row, int c0, int n) {
         float a = 0.f;
-        for (int c = 0; c < n; ++c) a += T[row * WG_LDW + c0 + c];
+        // 8 loads in flight at a time.  Fully unrolled, the 64 loads of a row sum are all hoisted in front of the adds;
+        // their 64 registers (on top of the 128 prefetch registers in flight) pushed ~40 loop invariants into scratch,
+        // and every scratch reload waits on vmcnt -- i.e. for the whole prefetch it was meant to overlap (370 -> see
+        // DESIGN.md 4b).
+#pragma unroll 1
+        for (int c = 0; c < n; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = T[row * WG_LDW + c0 + c + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
         return a;
     };
 
     // prefetch registers: X / Y operands of the next phase (+ grid features, coordinates, small gradients)
     float4 nx[16], ny[16], nsm;
-    float ngf[16], npx[3];
+    float ngf[16];
     auto tile_of = [&](uint32_t bt) { return (int64_t)bt * 4 + w; };
     auto live_of = [&](uint32_t bt) { return bt < n_btiles && tile_of(bt) * 32 < (int64_t)M; };
     auto sample_of = [&](uint32_t bt) {
@@ -710,61 +722,52 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
         put_act(XT, nx, 0, 4, 0, w, lane);
         put_act(YT, ny, 0, 4, 0, w, lane);
         __syncthreads();
-        fetch_act(nx, dact, tile, 0, 0, 4, tile_live, lane);      // next: X = dG1, Y = e (from x)
-        npx[0] = x[3 * (size_t)s], npx[1] = x[3 * (size_t)s + 1], npx[2] = x[3 * (size_t)s + 2];
-        wgrad_mma<4>(XT, YT, w, 0, lane, aW2);
-        db2 += row_sum(XT, brow, 64 * bhalf, 64);
-        __syncthreads();
-
-        // ---------------- phase pts0: X = dG1, Y = e (rows 0..50, rows 51..63 zero)
-        put_act(XT, nx, 0, 4, 0, w, lane);
-        float ev[E_SLOTS];
-        load_e<PE_INTERNAL>(x, embed_pos, s, h, ev);
-        (void)npx;
-#pragma unroll
-        for (int t = 0; t < E_SLOTS; ++t) {
-            const int e = eidx(t, h);
-            if (e >= 0) YT[e * WG_LDW + 32 * w + j] = tile_live ? ev[t] : 0.0f;
-        }
-        for (int q = tid; q < 13 * 128; q += DEC_BLOCK) YT[(51 + q / 128) * WG_LDW + (q % 128)] = 0.0f;
-        __syncthreads();
-        {                                                          // next: X = [dlogits | drgb], Y = H3
+        fetch_act(nx, dact, tile, 0, 0, 4, tile_live, lane);      // next: X = dG1 (+ the 8 small rows), Y = [e | rgb_emb]
+        fetch_act(ny, saved, tile, 1, 2, 2, tile_live, lane);
+        {
             const int sl = tid & 127, half = tid >> 7;
             const int64_t sg = (int64_t)bt * 128 + sl;
             nsm = make_float4(0.f, 0.f, 0.f, 0.f);
             if (sg < (int64_t)M) nsm = reinterpret_cast<const float4*>(dsmall + sg * 8)[half];
         }
-        fetch_act(ny, saved, tile, 2, 0, 4, tile_live, lane);
-        wgrad_mma<2>(XT, YT, w, 0, lane, aW1);
-        db1 += row_sum(XT, brow, 64 * bhalf, 64);
+        wgrad_mma<4>(XT, YT, w, 0, lane, aW2);
+        db2 += row_sum(XT, brow, 64 * bhalf, 64);
         __syncthreads();
 
-        // ---------------- phase sdf2: X = [dlogits(5) | drgb(3)] (8 rows), Y = H3
+        // ---------------- phase pts0 + rgb0: X = dG1 and the 8 small rows, Y = [e (rows 0..50, 51..63 zero) | rgb_emb (64..127)]
+        // (d w_rgb0 = drgb^T [rgb_emb | e] rides on the staging of e: one phase, two barriers and one e-staging less)
+        put_act(XT, nx, 0, 4, 0, w, lane);
+        put_act(YT, ny, 2, 2, 0, w, lane);
+        {
+            float ev[E_SLOTS];
+            load_e<PE_INTERNAL>(x, embed_pos, s, h, ev);
+#pragma unroll
+            for (int t = 0; t < E_SLOTS; ++t) {
+                const int e = eidx(t, h);
+                if (e >= 0) YT[e * WG_LDW + 32 * w + j] = tile_live ? ev[t] : 0.0f;
+            }
+        }
+        for (int q = tid; q < 13 * 128; q += DEC_BLOCK) YT[(51 + q / 128) * WG_LDW + (q % 128)] = 0.0f;
         {
             const int sl = tid & 127, half = tid >> 7;
-            XT[(4 * half + 0) * WG_LDW + sl] = nsm.x;
-            XT[(4 * half + 1) * WG_LDW + sl] = nsm.y;
-            XT[(4 * half + 2) * WG_LDW + sl] = nsm.z;
-            XT[(4 * half + 3) * WG_LDW + sl] = nsm.w;
+            X8[(4 * half + 0) * WG_LDW + sl] = nsm.x;
+            X8[(4 * half + 1) * WG_LDW + sl] = nsm.y;
+            X8[(4 * half + 2) * WG_LDW + sl] = nsm.z;
+            X8[(4 * half + 3) * WG_LDW + sl] = nsm.w;
         }
-        put_act(YT, ny, 0, 4, 0, w, lane);
         __syncthreads();
-        fetch_act(ny, saved, tile, 1, 2, 2, tile_live, lane);     // next: Y = [rgb_emb | e]
-        wgrad_mma<1>(XT, YT, 0, w, lane, aS2, true);
-        if (tid < 16) dbs += row_sum(XT, tid & 7, 64 * (tid >> 3), 64);
+        fetch_act(ny, saved, tile, 2, 0, 4, tile_live, lane);      // next: Y = H3
+        wgrad_mma<2>(XT, YT, w, 0, lane, aW1);
+        wgrad_mma<1>(X8, YT, 0, w, lane, aRGB, true);
+        db1 += row_sum(XT, brow, 64 * bhalf, 64);
+        if (tid < 16) dbs += row_sum(X8, tid & 7, 64 * (tid >> 3), 64);
         __syncthreads();
 
-        // ---------------- phase rgb0: X = same 8 rows, Y = [rgb_emb (64) | e (51) | 0]
-        put_act(YT, ny, 2, 2, -64, w, lane);
-#pragma unroll
-        for (int t = 0; t < E_SLOTS; ++t) {
-            const int e = eidx(t, h);
-            if (e >= 0) YT[(64 + e) * WG_LDW + 32 * w + j] = tile_live ? ev[t] : 0.0f;
-        }
-        for (int q = tid; q < 13 * 128; q += DEC_BLOCK) YT[(115 + q / 128) * WG_LDW + (q % 128)] = 0.0f;
+        // ---------------- phase sdf2: X = the 8 small rows (still in X8), Y = H3
+        put_act(YT, ny, 0, 4, 0, w, lane);
         __syncthreads();
         fetch_phase0(bt + gridDim.x);                              // next block tile's first phase
-        wgrad_mma<1>(XT, YT, 0, w, lane, aRGB, true);
+        wgrad_mma<1>(X8, YT, 0, w, lane, aS2, true);
         __syncthreads();
     }
 
@@ -785,7 +788,9 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
         for (int r = 0; r < 16; ++r) {
             const int row = rowmap(r, hh), col = 32 * w + jj;
             if (row < N_CLASS) rec[G_W_SDF2 + row * HID + col] = aS2[0][r];
-            if (row >= 5 && row < 8 && col < N_RGB_IN) rec[G_W_RGB0 + (row - 5) * N_RGB_IN + col] = aRGB[0][r];
+            // aRGB columns follow the phase's Y rows: [e (0..50) | pad | rgb_emb (64..127)] -> w_rgb0 columns [64 + e | rgb_emb]
+            const int rc = col < N_E ? 64 + col : (col >= 64 ? col - 64 : -1);
+            if (row >= 5 && row < 8 && rc >= 0) rec[G_W_RGB0 + (row - 5) * N_RGB_IN + rc] = aRGB[0][r];
         }
     }
     // bias partials: two column halves per row -> atomics inside the block's own record (LDS-free, 2 adders)

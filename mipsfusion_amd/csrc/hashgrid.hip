@@ -415,9 +415,6 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
     // cell changes.  On the coarse levels a ray spends ~10 samples per cell: up to SC_RUN x fewer atomics, and the
     // lanes of a wave mostly hold different cells -- same-address ds_add_f64 degrades from 0.33 to 3 cycles per
     // lane-op (tools/micro/lds_atomic.hip).  A wave still reads 64 x SC_RUN consecutive records (coalesced).
-#ifdef MIPSF_EXP_NOATOM
-    double dummy = 0.0;
-#endif
     uint32_t cc[3] = {0u, 0u, 0u};
     float sum[8][2];
     bool open = false;
@@ -457,12 +454,8 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
                 v0 = (c == k) ? sum[k][0] : v0;
                 v1 = (c == k) ? sum[k][1] : v1;
             }
-#ifdef MIPSF_EXP_NOATOM
-            dummy += (double)v0 * (double)e + (double)v1;
-#else
             atomicAdd(&acc[2 * e], (double)v0);
             atomicAdd(&acc[2 * e + 1], (double)v1);
-#endif
         }
     };
     constexpr int UNR = (int)SC_RUN;   // independent record -> x chains in flight per thread
@@ -516,9 +509,6 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
     }
     __syncthreads();
 
-#ifdef MIPSF_EXP_NOATOM
-    if (dummy == 1.2345) acc[0] = dummy;
-#endif
     const double2* a2 = reinterpret_cast<const double2*>(acc);
     if (ws[plan.w_parts + bin] == 1) {
         // read-modify-write of the whole slice; all loads are issued before the first add (a load -> add -> store

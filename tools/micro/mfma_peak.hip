@@ -52,7 +52,16 @@ int main() {
     run<4>(2, 256);
     run<8>(1, 256);
     run<4>(1, 512);
-    // sustained: ~50 ms of work
-    for (int r = 0; r < 3; ++r) run<4>(1, 256);
+    // sustained: back-to-back launches for ~0.5 s -- does the clock hold?
+    for (int r = 0; r < 300; ++r) {
+        if (r % 30 == 0) run<4>(1, 256);
+        else {
+            float* out;
+            (void)hipMalloc(&out, 256 * 16 * 1024 * 4);
+            hipLaunchKernelGGL(k<4>, dim3(256), dim3(256), 0, 0, out, 2000, 1.f, 2.f);
+            (void)hipDeviceSynchronize();
+            (void)hipFree(out);
+        }
+    }
     return 0;
 }
