@@ -319,7 +319,10 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __
     const uint32_t ns = plan.n_slices[level], se = plan.slice_entries[level], bin0 = plan.bin0[level];
     const float inv_se = 1.0f / (float)se;
     const int mode = level_mode(res, size);
-    const bool aggregate = ns <= 8;
+#ifndef MIPSF_SC_AGG_MAX
+#define MIPSF_SC_AGG_MAX 1   // measured on the mapping workload: 65 us (<= 1 bin), 67 (<= 2), 88 (<= 8)
+#endif
+    const bool aggregate = ns <= MIPSF_SC_AGG_MAX;
     for (uint32_t q = threadIdx.x; q < ns; q += SC_BLOCK) cnt[q] = 0u;
     __syncthreads();
     const uint32_t s0 = chunk * (SC_BLOCK * SC_ROUTE_UNR);
