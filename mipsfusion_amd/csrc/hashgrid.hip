@@ -203,7 +203,7 @@ constexpr uint32_t SC_MAX_SLICE = 10240;            // entries: 10240 * 2 double
 #define MIPSF_SC_PART 32768
 #endif
 #ifndef MIPSF_SC_RUN
-#define MIPSF_SC_RUN 4
+#define MIPSF_SC_RUN 3
 #endif
 constexpr uint32_t SC_PART = MIPSF_SC_PART;           // records per accumulate workgroup
 constexpr uint32_t SC_RUN = MIPSF_SC_RUN;                   // consecutive records merged per thread in the accumulate kernel
