@@ -685,7 +685,8 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
     // prefetch registers: X / Y operands of the next phase (+ grid features, coordinates, small gradients)
     float4 nx[16], ny[16], nsm;
     float ngf[16];
-    auto tile_of = [&](uint32_t bt) { return (int64_t)bt * 4 + w; };
+    // reversed tile order: the tiles the chain kernel wrote last are still in the 256 MB Infinity Cache (318 -> 310 us)
+    auto tile_of = [&](uint32_t bt) { return (int64_t)(n_btiles - 1u - (bt < n_btiles ? bt : n_btiles - 1u)) * 4 + w; };
     auto live_of = [&](uint32_t bt) { return bt < n_btiles && tile_of(bt) * 32 < (int64_t)M; };
     auto sample_of = [&](uint32_t bt) {
         const uint32_t s_raw = (uint32_t)(tile_of(bt) * 32 + j);
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
         fetch_act(ny, saved, tile, 1, 2, 2, tile_live, lane);
         {
             const int sl = tid & 127, half = tid >> 7;
-            const int64_t sg = (int64_t)bt * 128 + sl;
+            const int64_t sg = (tile_of(bt) - w) * 32 + sl;
             nsm = make_float4(0.f, 0.f, 0.f, 0.f);
             if (sg < (int64_t)M) nsm = reinterpret_cast<const float4*>(dsmall + sg * 8)[half];
         }
