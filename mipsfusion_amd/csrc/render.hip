@@ -244,14 +244,17 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void render_fwd_kernel
 }
 
 // losses[8] = {rgb_loss, depth_loss, sdf_loss, fs_loss, psnr, fs_weight, sdf_weight, n_valid}
-__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ partial,
+constexpr int LF_BLOCK = 1024;
+__global__ __launch_bounds__(LF_BLOCK) void loss_finalize_kernel(const float* __restrict__ partial,
                                                             const uint32_t* __restrict__ counts, float emd_w,
                                                             float* __restrict__ losses, uint32_t N, uint32_t S) {
-    __shared__ double red[4][9];
+    __shared__ double red[LF_BLOCK / MIPSF_WAVE][9];
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t n = threadIdx.x; n < N; n += 256) {
-#pragma unroll
-        for (int j = 0; j < 7; ++j) acc[j] += (double)partial[(size_t)n * 8 + j];
+    for (uint32_t n = threadIdx.x; n < N; n += LF_BLOCK) {
+        const float4 p0 = reinterpret_cast<const float4*>(partial)[2 * (size_t)n];
+        const float4 p1 = reinterpret_cast<const float4*>(partial)[2 * (size_t)n + 1];
+        acc[0] += (double)p0.x, acc[1] += (double)p0.y, acc[2] += (double)p0.z, acc[3] += (double)p0.w;
+        acc[4] += (double)p1.x, acc[5] += (double)p1.y, acc[6] += (double)p1.z;
         acc[7] += (double)counts[2 * n];          // integers < 2^53: exact
         acc[8] += (double)counts[2 * n + 1];
     }
@@ -265,7 +268,10 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     __syncthreads();
     if (threadIdx.x == 0) {
         double t[9];
-        for (int j = 0; j < 9; ++j) t[j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+        for (int j = 0; j < 9; ++j) {
+            t[j] = 0.0;
+            for (int k = 0; k < LF_BLOCK / MIPSF_WAVE; ++k) t[j] += red[k][j];
+        }
         const double NS = (double)N * (double)S;
         const float n_front = (float)t[7], n_band = (float)t[8];
         const float total = n_front + n_band;
@@ -485,7 +491,7 @@ int mipsf_render_fwd(const float* raw, const float* z_vals, const float* target_
         hipLaunchKernelGGL(render_fwd_kernel<true>, grid, block, 0, s, raw, z_vals, target_rgb, target_d, rc, rgb,
                            depth, depth_var, disp, acc, weights, partial, N, S);
         if (int e = check_launch("render_fwd")) return e;
-        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, partial, counts, rc.emd_w, losses, N, S);
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(LF_BLOCK), 0, s, partial, counts, rc.emd_w, losses, N, S);
         return check_launch("loss_finalize");
     }
     hipLaunchKernelGGL(render_fwd_kernel<false>, grid, block, 0, s, raw, z_vals, target_rgb, target_d, rc, rgb, depth,

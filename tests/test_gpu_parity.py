@@ -125,6 +125,30 @@ def test_hashgrid_vs_oracle_fresh(dev):
     assert_close(dx, dx_ref, 1e-4, "dx")
 
 
+@pytest.mark.parametrize("log2_t,M", [(16, 1), (16, 70000), (22, 3001)])
+def test_hashgrid_backward_routing_edge_sizes(dev, log2_t, M):
+    """The routed scatter at its edges: a single sample; a batch larger than one 32768-record part on a 2^16 table
+    (every bin multi-part -> partial slices + reduce); a 2^22 table (410 slices per level, 3000 bins) -- all against
+    the oracle, with a degenerate cluster (many samples in one cell: run merging + same-address atomics)."""
+    torch.manual_seed(30 + log2_t)
+    meta = _lib.make_grid_meta(16, 2, log2_t, 16, PLS)
+    ometa = tcnn_cpu.make_grid_meta(16, 2, log2_t, 16, PLS)
+    x = torch.rand(M, 3)
+    if M > 2000:
+        x[100:1100] = torch.tensor([0.4312, 0.2521, 0.8133]) + torch.rand(1000, 3) * 1e-4     # one fine cell
+    dy = torch.randn(M, 32)
+    params = torch.zeros(ometa.n_params)
+    dp_ref, _ = tcnn_cpu.hashgrid_backward(x, params, dy, ometa, need_dx=False)
+    dp = torch.zeros(ometa.n_params, device=dev)
+    ops.hashgrid_bwd(x.to(dev), params.to(dev), dy.to(dev), dp, meta, _lib.FEAT_AOS, None)
+    assert_close(dp, dp_ref, 2e-5, f"dparams T=2^{log2_t} M={M}")
+    touched = dp_ref != 0
+    assert float(dp.cpu()[~touched].abs().max()) == 0.0
+    # accumulate semantics: a second call adds on top
+    ops.hashgrid_bwd(x.to(dev), params.to(dev), dy.to(dev), dp, meta, _lib.FEAT_AOS, None)
+    assert_close(dp, 2 * dp_ref, 2e-5, "accumulation into dparams")
+
+
 def test_hashgrid_empty_and_single(dev):
     meta = _lib.make_grid_meta(16, 2, 10, 16, PLS)
     params = torch.rand(meta.n_params, device=dev)
