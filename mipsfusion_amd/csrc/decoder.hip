@@ -26,6 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr float PI_F = 3.14159265358979323846f;
 constexpr float HALF_PI_F = 1.57079632679489661923f;
 constexpr int DEC_BLOCK = 256;
+constexpr int TAIL_F4 = (PACKED_FLOATS - OFF_TRGB) / 4;  // rgb / sdf2 head tables, biases (contiguous tail of `packed`)
 #ifndef MIPSF_FWD_LDS_MIN_ROUNDS
 #define MIPSF_FWD_LDS_MIN_ROUNDS 2u   // experiments: a huge value disables the persistent forward kernel
 #endif
@@ -84,11 +85,11 @@ __device__ __forceinline__ void mfma_layer(const float4* img, int lane, f32x16 (
 }
 
 template <int RT>
-__device__ __forceinline__ void load_bias(const float* __restrict__ packed, int layer, int h, f32x16 (&acc)[RT]) {
+__device__ __forceinline__ void load_bias(const float* tail, int layer, int h, f32x16 (&acc)[RT]) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rt][r] = packed[OFF_BIAS + ((layer * 64 + rt * 16 + r) << 1) + h];
+        for (int r = 0; r < 16; ++r) acc[rt][r] = tail[(OFF_BIAS - OFF_TRGB) + ((layer * 64 + rt * 16 + r) << 1) + h];
 }
 
 __device__ __forceinline__ void store_act(float* __restrict__ dst, int64_t tile, int mat, int lane,
@@ -163,7 +164,7 @@ __device__ __forceinline__ float load_feat(const float* __restrict__ feat, uint3
 // ================================================================================ forward
 // one wave, one tile of 32 samples; img1/2/3 = A-operand images of the three big layers (global or LDS)
 template <bool PE_INTERNAL, int LAYOUT, bool SAVE>
-__device__ __forceinline__ void decoder_fwd_tile(const float* __restrict__ packed, const float4* img1,
+__device__ __forceinline__ void decoder_fwd_tile(const float* tail, const float4* img1,
                                                  const float4* img2, const float4* img3,
                                                  const float* __restrict__ feat, const float* __restrict__ x,
                                                  const float* __restrict__ embed_pos, float* __restrict__ out,
@@ -179,7 +180,7 @@ __device__ __forceinline__ void decoder_fwd_tile(const float* __restrict__ packe
 
     // ---- layer 1: pts_linear.0 + ReLU
     f32x16 H1[4];
-    load_bias(packed, 0, h, H1);
+    load_bias(tail, 0, h, H1);
     mfma_layer<RT_F1, T_F1>(img1, lane, H1,
                             [&](int t) { return t < E_SLOTS ? ev[t] : 0.0f; });
 #pragma unroll
@@ -189,7 +190,7 @@ __device__ __forceinline__ void decoder_fwd_tile(const float* __restrict__ packe
 
     // ---- layer 2: pts_linear.2 -> [sdf_emb | rgb_emb]   (H1 is written out one 16-byte group per k-group)
     f32x16 H2[4];
-    load_bias(packed, 1, h, H2);
+    load_bias(tail, 1, h, H2);
     mfma_layer<RT_F2, T_F2>(img2, lane, H2,
                             [&](int t) { return H1[t >> 4][t & 15]; },
                             [&](int t4) { if (SAVE && pin == 0) store_act_piece(saved, tile, 0, lane, H1, t4); });
@@ -197,7 +198,7 @@ __device__ __forceinline__ void decoder_fwd_tile(const float* __restrict__ packe
     // ---- rgb_linear.0 on the vector ALU (3 outputs): this lane's half of every dot product, then one swap
     float pr[3] = {0.f, 0.f, 0.f};
     {
-        const float4* trgb = reinterpret_cast<const float4*>(packed + OFF_TRGB) + h * TRGB_SLOTS;
+        const float4* trgb = reinterpret_cast<const float4*>(tail) + h * TRGB_SLOTS;
 #pragma unroll
         for (int slot = 0; slot < 32; ++slot) {
             const float4 wv = trgb[slot];
@@ -212,14 +213,14 @@ __device__ __forceinline__ void decoder_fwd_tile(const float* __restrict__ packe
     }
     float rgb[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) rgb[c] = (pr[c] + __shfl_xor(pr[c], 32, 64)) + packed[OFF_BSMALL + c];
+    for (int c = 0; c < 3; ++c) rgb[c] = (pr[c] + __shfl_xor(pr[c], 32, 64)) + tail[OFF_BSMALL - OFF_TRGB + c];
 
     // ---- layer 3: sdf_linear.0 + ReLU on [sdf_emb (regs of H2 tiles 0,1) | grid features (loaded)]
     float gf[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) gf[u] = load_feat<LAYOUT>(feat, s, u, h, M);
     f32x16 H3[4];
-    load_bias(packed, 2, h, H3);
+    load_bias(tail, 2, h, H3);
     mfma_layer<RT_F3, T_F3>(img3, lane, H3,
                             [&](int t) { return t < 32 ? H2[t >> 4][t & 15] : gf[t - 32]; },
                             [&](int t4) {                       // 16 groups of H2 over 12 k-groups
@@ -237,7 +238,7 @@ __device__ __forceinline__ void decoder_fwd_tile(const float* __restrict__ packe
     // ---- sdf_linear.2 (5 logits) on the vector ALU, softmax, entropy, expected class -> SDF
     float pl[N_CLASS] = {0.f, 0.f, 0.f, 0.f, 0.f};
     {
-        const float4* ts2 = reinterpret_cast<const float4*>(packed + OFF_TS2) + h * 128;
+        const float4* ts2 = reinterpret_cast<const float4*>(tail) + (OFF_TS2 - OFF_TRGB) / 4 + h * 128;
 #pragma unroll
         for (int slot = 0; slot < 64; ++slot) {
             const float4 w0 = ts2[2 * slot], w1 = ts2[2 * slot + 1];
@@ -249,7 +250,7 @@ __device__ __forceinline__ void decoder_fwd_tile(const float* __restrict__ packe
     float lg[N_CLASS], mx = -3.0e38f;
 #pragma unroll
     for (int c = 0; c < N_CLASS; ++c) {
-        lg[c] = (pl[c] + __shfl_xor(pl[c], 32, 64)) + packed[OFF_BSMALL + 4 + c];
+        lg[c] = (pl[c] + __shfl_xor(pl[c], 32, 64)) + tail[OFF_BSMALL - OFF_TRGB + 4 + c];
         mx = fmaxf(mx, lg[c]);
     }
     float p[N_CLASS], den = 0.f;
@@ -283,10 +284,14 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_fwd_kernel(const float* 
                                                                 const float* __restrict__ embed_pos,
                                                                 float* __restrict__ out, float* __restrict__ saved,
                                                                 uint32_t M, int pin) {
+    // biases and the two small head tables (7.5 KB): broadcast LDS reads instead of ~380 L2 loads per lane and tile
+    __shared__ float4 tailbuf[TAIL_F4];
+    for (int q = threadIdx.x; q < TAIL_F4; q += DEC_BLOCK) tailbuf[q] = reinterpret_cast<const float4*>(packed + OFF_TRGB)[q];
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + (threadIdx.x >> 6);
     if (tile * 32 >= (int64_t)M) return;
-    decoder_fwd_tile<PE_INTERNAL, LAYOUT, SAVE>(packed, reinterpret_cast<const float4*>(packed + OFF_F1),
+    decoder_fwd_tile<PE_INTERNAL, LAYOUT, SAVE>(reinterpret_cast<const float*>(tailbuf), reinterpret_cast<const float4*>(packed + OFF_F1),
                                                 reinterpret_cast<const float4*>(packed + OFF_F2),
                                                 reinterpret_cast<const float4*>(packed + OFF_F3), feat, x, embed_pos,
                                                 out, saved, M, pin, tile, lane);
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_fwd_kernel(const float* 
 // activation stores are alone in the vector-memory queue: on gfx9 loads and stores retire through ONE in-order
 // counter (vmcnt), and an L2 weight load queued behind a store to HBM waits for that store.
 constexpr int FWD_LDS_FLOATS = OFF_B3 - OFF_F1;
-constexpr int FWD_LDS_BYTES = FWD_LDS_FLOATS * 4;
+constexpr int FWD_LDS_BYTES = FWD_LDS_FLOATS * 4 + TAIL_F4 * 16;
 constexpr int FWD_LDS_BLOCK = 512;
 template <bool PE_INTERNAL, int LAYOUT, bool SAVE>
 __global__ __launch_bounds__(FWD_LDS_BLOCK, 1) void decoder_fwd_lds_kernel(const float* __restrict__ packed,
@@ -311,6 +316,8 @@ __global__ __launch_bounds__(FWD_LDS_BLOCK, 1) void decoder_fwd_lds_kernel(const
     {
         const float4* src = reinterpret_cast<const float4*>(packed + OFF_F1);
         for (int q = threadIdx.x; q < FWD_LDS_FLOATS / 4; q += FWD_LDS_BLOCK) wimg[q] = src[q];
+        const float4* tsrc = reinterpret_cast<const float4*>(packed + OFF_TRGB);
+        for (int q = threadIdx.x; q < TAIL_F4; q += FWD_LDS_BLOCK) wimg[FWD_LDS_FLOATS / 4 + q] = tsrc[q];
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -322,7 +329,9 @@ __global__ __launch_bounds__(FWD_LDS_BLOCK, 1) void decoder_fwd_lds_kernel(const
         asm volatile("" : "+v"(z));
         asm volatile("" : "+s"(zs));
         const float4* w4 = wimg + z;
-        decoder_fwd_tile<PE_INTERNAL, LAYOUT, SAVE>(packed + zs, w4 + (OFF_F1 - OFF_F1) / 4, w4 + (OFF_F2 - OFF_F1) / 4,
+        (void)zs;
+        decoder_fwd_tile<PE_INTERNAL, LAYOUT, SAVE>(reinterpret_cast<const float*>(w4 + FWD_LDS_FLOATS / 4),
+                                                    w4 + (OFF_F1 - OFF_F1) / 4, w4 + (OFF_F2 - OFF_F1) / 4,
                                                     w4 + (OFF_F3 - OFF_F1) / 4, feat, x, embed_pos, out, saved, M, pin,
                                                     (int64_t)tile, lane);
     }
@@ -350,6 +359,7 @@ __device__ __forceinline__ void zero_acc4(f32x16 (&a)[4]) {
 // exactly the 16-byte piece the weight-gradient kernel wants in `dact`.  196 registers -> two blocks share a CU and
 // one wave's scalar sections (softmax backward, frequency chain, HBM latency at tile start) hide under the other
 // wave's matrix work.  Measured on MI355X (4096x64 samples): 297 us register-chained -> 251 us.
+constexpr int TAB_F4 = (OFF_BIAS - OFF_TRGB) / 4;      // rgb-head and sdf2-head tables, contiguous in `packed`
 constexpr int XB_ENTRIES = 32 * 32;                  // float4 entries per wave: [group 2*t4+h][sample j]
 
 template <int RT, int T, typename SideFn>
@@ -391,6 +401,11 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
     float* __restrict__ dx, float* __restrict__ dembed_pos, float* __restrict__ dact, float* __restrict__ dsmall,
     uint32_t M, int pin) {
     __shared__ float4 xb_all[(DEC_BLOCK / 64) * XB_ENTRIES];
+    // the two small per-half-wave weight tables (rgb head, sdf2 head: 6 KB) are read 186 x 16 B per lane and tile;
+    // from LDS that is a broadcast ds_read_b128 instead of an L2 round trip
+    __shared__ float4 tab[TAB_F4];
+    for (int q = threadIdx.x; q < TAB_F4; q += DEC_BLOCK) tab[q] = reinterpret_cast<const float4*>(packed + OFF_TRGB)[q];
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + (threadIdx.x >> 6);
@@ -430,7 +445,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
 
     // ---- dG3 = relu'(H3) * (Ws2^T dlogits)   (vector ALU, K = 5), one 16-byte piece at a time into LDS
     {
-        const float4* ts2 = reinterpret_cast<const float4*>(packed + OFF_TS2) + h * 128;
+        const float4* ts2 = tab + (OFF_TS2 - OFF_TRGB) / 4 + h * 128;
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             const float4 hm = sv4[(2 * 16 + p) * 64];
@@ -466,7 +481,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
     }
 
     // ---- dH2 = [d sdf_emb (from above) | d rgb_emb = Wrgb^T drgb] -> LDS
-    const float4* trgb = reinterpret_cast<const float4*>(packed + OFF_TRGB) + h * TRGB_SLOTS;
+    const float4* trgb = tab + h * TRGB_SLOTS;
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const int rt = p >> 2, g = p & 3;
