@@ -461,6 +461,61 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
             atomicAdd(&acc[2 * e + 1], (double)v1);
         }
     };
+    if (mode != 0) {
+        // Hashed (fine) levels: a record has ~2 of its 8 corners in this slice and consecutive samples seldom share a
+        // cell, so run merging would only add work.  Direct form: membership first, weights and atomics for the hits
+        // only (each lane walks its own hit list).
+        constexpr int UD = 4;
+        for (uint32_t r = threadIdx.x; r < n_rec; r += UD * SC_BLOCK) {
+            uint32_t si[UD];
+            float px[UD][3];
+            float2 pg[UD];
+#pragma unroll
+            for (int u = 0; u < UD; ++u) {
+                const uint32_t q = r + u * SC_BLOCK;
+                si[u] = rec[q < n_rec ? q : n_rec - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < UD; ++u) {
+                const uint32_t ii = si[u];
+                px[u][0] = x[3 * (size_t)ii], px[u][1] = x[3 * (size_t)ii + 1], px[u][2] = x[3 * (size_t)ii + 2];
+                pg[u] = *reinterpret_cast<const float2*>(dout + feat_index<LAYOUT>(ii, level, M, g.n_levels));
+            }
+#pragma unroll
+            for (int u = 0; u < UD; ++u) {
+                if (r + u * SC_BLOCK >= n_rec) break;
+                Cell cell;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const float pos = fmaf(scale, px[u][d], 0.5f);
+                    const float fl = floorf(pos);
+                    cell.c[d] = (uint32_t)(int)fl;
+                    cell.f[d] = pos - fl;
+                }
+                uint32_t idx[8];
+                corner_indices(mode, cell, res, size, idx);
+                uint32_t hit = 0;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    idx[c] -= begin;
+                    hit |= (idx[c] < count) ? (1u << c) : 0u;
+                }
+                const float2 gy = pg[u];
+                while (hit) {
+                    const int c = __ffs((int)hit) - 1;
+                    hit &= hit - 1u;
+                    uint32_t e = idx[0];
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) e = (c == k) ? idx[k] : e;
+                    float wgt = (c & 1) ? cell.f[0] : 1.0f - cell.f[0];
+                    wgt = wgt * ((c & 2) ? cell.f[1] : 1.0f - cell.f[1]);
+                    wgt = wgt * ((c & 4) ? cell.f[2] : 1.0f - cell.f[2]);
+                    atomicAdd(&acc[2 * e], (double)(wgt * gy.x));
+                    atomicAdd(&acc[2 * e + 1], (double)(wgt * gy.y));
+                }
+            }
+        }
+    } else {
     constexpr int UNR = (int)SC_RUN;   // independent record -> x chains in flight per thread
     // (a transposed assignment -- neighbouring lanes one ray apart, so that they never meet in a coarse cell -- was
     // measured 25 % slower: the locality of the record / x / dL/dy reads matters more than the residual conflicts)
@@ -509,6 +564,7 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
         }
         if (open) flush();
         open = false;
+    }
     }
     __syncthreads();
 
