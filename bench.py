@@ -154,9 +154,11 @@ class MappingLoop:
         self.pose_fixed = poses[:1]                                  # first keyframe stays fixed
         self.cur_trans = torch.nn.Parameter(poses[1:, :3, 3].clone())
         self.cur_rot = torch.nn.Parameter(matrix_to_quaternion(poses[1:, :3, :3]))
-        self.pose_opt = torch.optim.Adam([{"params": self.cur_rot, "lr": cfg["mapping"]["lr_rot"]},
-                                          {"params": self.cur_trans, "lr": cfg["mapping"]["lr_trans"]}],
-                                         capturable=capturable)
+        # pose Adam: same fused kernel as the map (dense torch.optim.Adam semantics, tests/test_gpu_parity.py); the
+        # torch optimiser costs ~12 tiny launches per pose step
+        self.pose_opt = FusedAdam([{"params": self.cur_rot, "lr": cfg["mapping"]["lr_rot"]},
+                                   {"params": self.cur_trans, "lr": cfg["mapping"]["lr_trans"]}],
+                                  capturable=capturable)
         self.poses_all = torch.cat([self.pose_fixed, qt_to_transform_matrix(self.cur_rot, self.cur_trans)], 0)
         self.pool = [(r.to(dev), o.to(dev)) for r, o in pool]
         self.pool = [(r, o, r[:, :3].contiguous(), r[:, 3:6].contiguous(), r[:, 6:7].contiguous()) for r, o in self.pool]
@@ -299,7 +301,7 @@ def frame_estimate(cfg, model, loop, dev, ba_ms, stream=None):
     rays = loop.pool[0][0][:ns]
     rot = torch.nn.Parameter(loop.cur_rot.detach()[-1:].clone())
     trans = torch.nn.Parameter(loop.cur_trans.detach()[-1:].clone())
-    popt = torch.optim.Adam([{"params": rot, "lr": 1e-3}, {"params": trans, "lr": 1e-3}], capturable=stream is not None)
+    popt = FusedAdam([{"params": rot, "lr": 1e-3}, {"params": trans, "lr": 1e-3}], capturable=stream is not None)
     noise = loop.noise[0][:ns]
 
     d_cam, t_rgb, t_d = rays[:, :3].contiguous(), rays[:, 3:6].contiguous(), rays[:, 6:7].contiguous()
