@@ -217,6 +217,10 @@ int mipsf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq
  * 2 floats) instead of being baked into the launch; mipsf_adam_advance increments the device step counter and
  * refreshes them (enqueue it once per optimiser step, before the _ex calls). */
 int mipsf_adam_advance(int32_t* step_dev, float* hyper_dev, float lr, float beta1, float beta2, void* stream);
+/* the same for up to MIPSF_ADAM_MAX_GROUPS parameter groups in one launch (host arrays of device pointers / scalars) */
+#define MIPSF_ADAM_MAX_GROUPS 8
+int mipsf_adam_advance_n(int32_t* const* step_dev, float* const* hyper_dev, const float* lr, const float* beta1,
+                         const float* beta2, uint32_t n_groups, void* stream);
 int mipsf_adam_step_ex(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr,
                        float beta1, float beta2, float eps, float weight_decay, uint32_t step,
                        const float* hyper_dev, int zero_grad, void* stream);

@@ -88,6 +88,7 @@ SIGNATURES = {
     "mipsf_pose_rays_bwd": (_I, [_P, _P, _P, _U32, _U32, _P, _P, _P, _P, _P, _U32, _P]),
     "mipsf_adam_step": (_I, [_P, _P, _P, _P, _U64, _F, _F, _F, _F, _F, _U32, _I, _P]),
     "mipsf_adam_advance": (_I, [_P, _P, _F, _F, _F, _P]),
+    "mipsf_adam_advance_n": (_I, [_P, _P, _P, _P, _P, _U32, _P]),
     "mipsf_adam_step_ex": (_I, [_P, _P, _P, _P, _U64, _F, _F, _F, _F, _F, _U32, _P, _I, _P]),
     "mipsf_adam_step_multi_ex": (_I, [C.POINTER(AdamTensors), _F, _F, _F, _F, _F, _U32, _P, _I, _P]),
     "mipsf_adam_step_multi": (_I, [C.POINTER(AdamTensors), _F, _F, _F, _F, _F, _U32, _I, _P]),

@@ -86,6 +86,24 @@ __global__ void adam_advance_kernel(int* __restrict__ step, float* __restrict__ 
     }
 }
 
+struct AdvanceN {
+    int* step[MIPSF_ADAM_MAX_GROUPS];
+    float* hyper[MIPSF_ADAM_MAX_GROUPS];
+    float lr[MIPSF_ADAM_MAX_GROUPS], beta1[MIPSF_ADAM_MAX_GROUPS], beta2[MIPSF_ADAM_MAX_GROUPS];
+    uint32_t n;
+};
+// the same for all parameter groups of an optimiser in one launch (one thread per group)
+__global__ void adam_advance_n_kernel(AdvanceN a) {
+    const uint32_t i = threadIdx.x;
+    if (i >= a.n) return;
+    const int t = a.step[i][0] + 1;
+    a.step[i][0] = t;
+    const double bc1 = 1.0 - pow((double)a.beta1[i], (double)t);
+    const double bc2 = 1.0 - pow((double)a.beta2[i], (double)t);
+    a.hyper[i][0] = (float)((double)a.lr[i] / bc1);
+    a.hyper[i][1] = (float)(1.0 / sqrt(bc2));
+}
+
 __device__ __forceinline__ void adam1(float& p, float& g, float& m, float& v, const AdamK& k) {
     float gg = g;
     if (k.wd != 0.f) gg = gg + k.wd * p;
@@ -232,6 +250,21 @@ int mipsf_adam_advance(int32_t* step_dev, float* hyper_dev, float lr, float beta
     hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev, hyper_dev, lr, beta1,
                        beta2);
     return check_launch("adam_advance");
+}
+
+int mipsf_adam_advance_n(int32_t* const* step_dev, float* const* hyper_dev, const float* lr, const float* beta1,
+                         const float* beta2, uint32_t n_groups, void* stream) {
+    if (n_groups == 0) return 0;
+    MIPSF_REQUIRE(step_dev && hyper_dev && lr && beta1 && beta2, "null pointer");
+    MIPSF_REQUIRE(n_groups <= MIPSF_ADAM_MAX_GROUPS, "at most %d groups per call", MIPSF_ADAM_MAX_GROUPS);
+    AdvanceN a;
+    a.n = n_groups;
+    for (uint32_t i = 0; i < n_groups; ++i) {
+        MIPSF_REQUIRE(step_dev[i] && hyper_dev[i], "null pointer in group %u", i);
+        a.step[i] = step_dev[i], a.hyper[i] = hyper_dev[i], a.lr[i] = lr[i], a.beta1[i] = beta1[i], a.beta2[i] = beta2[i];
+    }
+    hipLaunchKernelGGL(adam_advance_n_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+    return check_launch("adam_advance_n");
 }
 
 int mipsf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1,

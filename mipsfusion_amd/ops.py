@@ -359,6 +359,17 @@ def adam_advance(step_dev, hyper_dev, lr, beta1, beta2):
           "adam_advance")
 
 
+def adam_advance_n(groups):
+    """groups: list of (step_dev int32[1], hyper_dev float[2], lr, beta1, beta2) -- one launch for all of them."""
+    n = len(groups)
+    steps = (C.c_void_p * n)(*[dptr(g[0], torch.int32) for g in groups])
+    hypers = (C.c_void_p * n)(*[dptr(g[1]) for g in groups])
+    lr = (C.c_float * n)(*[g[2] for g in groups])
+    b1 = (C.c_float * n)(*[g[3] for g in groups])
+    b2 = (C.c_float * n)(*[g[4] for g in groups])
+    check(lib().mipsf_adam_advance_n(steps, hypers, lr, b1, b2, n, stream_ptr()), "adam_advance_n")
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, zero_grad=False,
               hyper_dev=None):
     with _timed("adam_step" if param.numel() > (1 << 20) else "adam_step_small"):

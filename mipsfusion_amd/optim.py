@@ -32,6 +32,7 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        work = []
         for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
             live = [p for p in group["params"] if p.grad is not None and p.numel() > 0]
@@ -49,8 +50,15 @@ class FusedAdam(torch.optim.Optimizer):
                     start = self.state[live[0]]["step"] - 1
                     self._dev[gi] = (torch.full((1,), start, dtype=torch.int32, device=dev),
                                      torch.zeros(2, dtype=torch.float32, device=dev))
-                step_dev, hyper = self._dev[gi]
-                ops.adam_advance(step_dev, hyper, group["lr"], b1, b2)
+                hyper = self._dev[gi][1]
+            work.append((gi, group, live, hyper))
+        if self.capturable and work:       # all groups' step counters / bias corrections in ONE launch
+            adv = [(self._dev[gi][0], self._dev[gi][1], group["lr"], group["betas"][0], group["betas"][1])
+                   for gi, group, _, _ in work]
+            for i in range(0, len(adv), 8):
+                ops.adam_advance_n(adv[i:i + 8])
+        for gi, group, live, hyper in work:
+            b1, b2 = group["betas"]
             small = []
             for p in live:
                 st = self.state[p]
