@@ -257,6 +257,8 @@ def inference_rates(cfg, model, dev):
     inference.query_in_batches(model.query_sdf, pts, batch_size=1024 * 16)
     torch.cuda.synchronize()
     q16k_ms = (time.perf_counter() - t0) * 1e3
+    inference.query_in_batches(model.query_sdf, pts, batch_size=1024 * 1024)      # warm the allocator at this batch size
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     inference.query_in_batches(model.query_sdf, pts, batch_size=1024 * 1024)
     torch.cuda.synchronize()
