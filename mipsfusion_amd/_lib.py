@@ -127,7 +127,9 @@ def check(rc: int, what: str = "") -> None:
 
 
 def stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """hipStream_t of torch's current stream on the current device (raw query: 0.2 us instead of 2.6 us for
+    torch.cuda.current_stream().cuda_stream -- it is called once per launch)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def dptr(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[int]:
