@@ -18,10 +18,17 @@ from . import ops
 
 
 class DeviceRayDB:
-    def __init__(self, num_kf: int, num_rays_to_save: int, device):
+    def __init__(self, num_kf: int, num_rays_to_save: int, device, storage: torch.Tensor = None):
+        """storage: optional caller-owned device buffer of >= num_kf*num_rays_to_save*7 floats to keep the rows in (lets
+        a caller put the database and the current frame's rays in ONE table that a captured iteration gathers from)."""
         self.num_rays_to_save = num_rays_to_save
         self.device = torch.device(device)
-        self.rays = torch.zeros((num_kf, num_rays_to_save, 7), dtype=torch.float32, device=self.device)
+        if storage is None:
+            self.rays = torch.zeros((num_kf, num_rays_to_save, 7), dtype=torch.float32, device=self.device)
+        else:
+            if storage.dtype != torch.float32 or not storage.is_contiguous() or storage.device.type != self.device.type:
+                raise ValueError("storage must be a contiguous float32 tensor on the database's device")
+            self.rays = storage.reshape(-1)[:num_kf * num_rays_to_save * 7].view(num_kf, num_rays_to_save, 7)
 
     # keyframeSet.py:170-175 -- the down-sampled rays of a new keyframe go straight to HBM (one 7 x R x 4 B upload)
     def store(self, kf_index: int, rays) -> None:

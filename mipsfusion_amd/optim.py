@@ -25,6 +25,19 @@ class FusedAdam(torch.optim.Optimizer):
         return st
 
     @torch.no_grad()
+    def reset(self):
+        """Back to the state of a freshly constructed optimiser (moments and step counters zero), IN PLACE: the
+        reference builds a new pose optimiser for every frame / BA round (mipsfusion.py:472-475, 300-303); a
+        captured iteration keeps reading the same state tensors, so they are cleared instead of replaced."""
+        for st in self.state.values():
+            if st:
+                st["step"] = 0
+                st["exp_avg"].zero_()
+                st["exp_avg_sq"].zero_()
+        for step_dev, _ in self._dev.values():
+            step_dev.zero_()
+
+    @torch.no_grad()
     def step(self, closure=None, zero_grad=False):
         """zero_grad=True (extension) clears each gradient in the same pass (the reference calls
         ``zero_grad()`` right after ``step()``, mipsfusion.py:330-335)."""

@@ -495,6 +495,28 @@ def test_fused_adam_multi_tensor_group_vs_torch(dev):
         np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().numpy(), rtol=2e-5, atol=1e-8)
 
 
+def test_fused_adam_reset_equals_fresh_optimizer(dev):
+    """FusedAdam.reset() (in place, also under capturable=True) must continue exactly like a newly built
+    torch.optim.Adam -- the reference rebuilds its pose optimiser every frame (mipsfusion.py:472-475)."""
+    torch.manual_seed(4)
+    for capturable in (False, True):
+        p0 = torch.randn(7, 4)
+        a, b = torch.nn.Parameter(p0.clone().to(dev)), torch.nn.Parameter(p0.clone())
+        oa = FusedAdam([{"params": a, "lr": 0.01}], capturable=capturable)
+        moments = None
+        for rnd in range(3):
+            ob = torch.optim.Adam([{"params": b, "lr": 0.01}])          # fresh every round
+            if rnd:
+                oa.reset()
+                assert oa.state[a]["exp_avg"] is moments                 # cleared, not replaced
+            for _ in range(4):
+                g = torch.randn(7, 4)
+                a.grad, b.grad = g.clone().to(dev), g
+                oa.step(), ob.step()
+            moments = oa.state[a]["exp_avg"]
+            np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=2e-5, atol=1e-8)
+
+
 def test_pose_rays_matches_torch_composition(dev):
     """Fused ray building == qt_to_transform_matrix + gather + sum(d_cam * R, -1) (mipsfusion.py:320-322), values
     and gradients wrt quaternion / translation; includes python-style negative owner indices and mixed waves."""
@@ -815,6 +837,15 @@ def test_keyframe_ray_sampling_matches_reference_bit_for_bit(dev):
     assert torch.equal(d_cam.cpu(), ref[:, :3]) and torch.equal(rgb.cpu(), ref[:, 3:6])
     assert torch.equal(depth.cpu(), ref[:, 6:7])
     assert ops.gather_rays(db.rays, torch.empty(0, dtype=torch.int64, device=dev)).shape == (0, 7)
+    # caller-owned storage: database rows and extra rows (a current frame) in one table, gathered by one index list
+    K, R = g["db"].shape[0], int(g["num_rays_to_save"])
+    table = torch.zeros(K * R + 4, 7, device=dev)
+    db2 = DeviceRayDB(K, R, dev, storage=table)
+    db2.store(2, T(g["db"][2]))
+    table[K * R:] = 5.0
+    rows = ops.gather_rays(table, torch.tensor([2 * R + 1, K * R + 3], device=dev))
+    assert torch.equal(rows[0].cpu(), T(g["db"][2][1])) and bool((rows[1] == 5.0).all())
+    assert db2.rays.data_ptr() == table.data_ptr()
 
 
 @pytest.mark.gpu
