@@ -17,6 +17,7 @@
 // are 138 k-steps x 4 row tiles = 552 MFMAs (64 cycles each) per 32 samples forward.
 #include "common.h"
 #include "decoder_layout.h"
+#include <type_traits>
 
 namespace mipsf {
 using namespace dl;
@@ -137,7 +138,10 @@ __device__ __forceinline__ void load_act(const float* __restrict__ src, int64_t 
 }
 
 // the 26 e values this lane feeds into layer 1 (its half of every k-step)
-template <bool PE_INTERNAL>
+// FAST (weight gradients only, where e is an operand of a 262144-term sum): sin(2^k pi x + h pi/2) evaluated as
+// v_sin_f32(fract(2^(k-1) x) + h/4) -- the argument in revolutions is exact, 3 instructions instead of the ~45 of
+// sinf's range reduction, and with one wave per SIMD every one of them is exposed
+template <bool PE_INTERNAL, bool FAST = false>
 __device__ __forceinline__ void load_e(const float* __restrict__ x, const float* __restrict__ embed_pos,
                                        uint32_t s, int h, float (&ev)[E_SLOTS]) {
     const float x0 = x[3 * (size_t)s], x1 = x[3 * (size_t)s + 1], x2 = x[3 * (size_t)s + 2];
@@ -146,7 +150,9 @@ __device__ __forceinline__ void load_e(const float* __restrict__ x, const float*
         const float xd = d == 0 ? x0 : (d == 1 ? x1 : x2);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            if (PE_INTERNAL)
+            if (PE_INTERNAL && FAST)
+                ev[d * 8 + k] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(ldexpf(xd, k - 1)) + (h ? 0.25f : 0.0f));
+            else if (PE_INTERNAL)
                 ev[d * 8 + k] = sinf(fmaf(ldexpf(xd, k), PI_F, h ? HALF_PI_F : 0.0f));
             else
                 ev[d * 8 + k] = embed_pos[(size_t)s * N_PE + d * 16 + 2 * k + h];
@@ -567,22 +573,16 @@ constexpr int WG_LDS_FLOATS = (2 * WG_ROWS + 32) * WG_LDW;   // X^T, Y^T and the
 constexpr int WG_LDS_BYTES = WG_LDS_FLOATS * 4;
 
 // Staging is split in two so that HBM latency hides under matrix work (the kernel runs one wave per SIMD, nothing
-// else covers a stall): fetch_act issues the global loads of the NEXT phase into registers right before the MFMA
-// loop of the current phase; put_act writes them, transposed, into LDS after the loop's closing barrier.
-__device__ __forceinline__ void fetch_act(float4* __restrict__ regs, const float* __restrict__ src, int64_t tile,
-                                          int mat, int rt0, int nrt, bool live, int lane) {
-    const float4* s4 = reinterpret_cast<const float4*>(src);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (q < nrt) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (live) v = s4[(tile * (ACT_SLOTS / 4) + mat * 16 + (rt0 + q) * 4 + g) * 64 + lane];
-                regs[q * 4 + g] = v;
-            }
-        }
-    }
+// else covers a stall): the global loads of the NEXT phase are issued into registers from inside the MFMA loop of the
+// current phase; put_act writes them, transposed, into LDS after the loop's closing barrier.
+// act_base = wave-uniform pointer to the tile's (matrix, first row tile) + lane, so that a 16-byte piece costs one
+// load with an immediate (or scalar) offset and no vector address arithmetic
+__device__ __forceinline__ const char* act_base(const float* __restrict__ src, int tile_u, int mat, int rt0) {
+    return reinterpret_cast<const char*>(src) + ((size_t)tile_u * (ACT_SLOTS / 4) + mat * 16 + rt0 * 4) * 1024;
+}
+// piece k of a staged matrix: scalar base + 32-bit lane offset + immediate
+__device__ __forceinline__ float4 act_piece(const char* base_u, int k, uint32_t lane16) {
+    return *reinterpret_cast<const float4*>(base_u + (size_t)(k * 1024) + lane16);
 }
 
 // accumulator-image registers -> LDS transposed [feature row][sample]; regs 4g..4g+3 of a tile are rows +0..+3
@@ -603,14 +603,20 @@ __device__ __forceinline__ void put_act(float* __restrict__ dstT, const float4* 
 }
 
 // acc[ct] += X^T[row tile rtile] * Y^T[col tile ct0+ct]^T over the block's 128 samples
-template <int NCT>
+struct NoFetch {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+
+// acc[ct] += X^T[row tile rtile] * Y^T[col tile ct0+ct]^T over the block's 128 samples
+template <int NCT, typename SideFn = NoFetch>
 __device__ __forceinline__ void wgrad_mma(const float* __restrict__ XT, const float* __restrict__ YT, int rtile,
-                                          int ct0, int lane, f32x16 (&acc)[NCT], bool a_rows_lt8 = false) {
+                                          int ct0, int lane, f32x16 (&acc)[NCT], SideFn side = NoFetch()) {
     const int i = lane & 31, kk = lane >> 5;
     const float* xa = XT + (32 * rtile + i) * WG_LDW + kk;
     const float* yb = YT + (32 * ct0 + i) * WG_LDW + kk;
-    const bool keep = !a_rows_lt8 || i < 8;
-    // operands of k-step group g+1 are read from LDS while the 4*NCT MFMAs of group g execute
+    // operands of k-step group g+1 are read from LDS while the 4*NCT MFMAs of group g execute; side(g), g = 0..15,
+    // issues the g-th slice of the NEXT phase's global loads: spread over the loop, the wave never sits in a full
+    // memory-instruction queue before its first MFMA (308 -> 297 us)
     constexpr int G = 4;
     float a[G], b[G][NCT], na[G], nb[G][NCT];
 #pragma unroll
@@ -619,6 +625,7 @@ __device__ __forceinline__ void wgrad_mma(const float* __restrict__ XT, const fl
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) b[u][ct] = yb[ct * 32 * WG_LDW + 2 * u];
     }
+#pragma unroll
     for (int t0 = 0; t0 < 64; t0 += G) {
         if (t0 + G < 64) {
 #pragma unroll
@@ -628,11 +635,11 @@ __device__ __forceinline__ void wgrad_mma(const float* __restrict__ XT, const fl
                 for (int ct = 0; ct < NCT; ++ct) nb[u][ct] = yb[ct * 32 * WG_LDW + 2 * (t0 + G + u)];
             }
         }
+        side(t0 / G);
 #pragma unroll
         for (int u = 0; u < G; ++u) {
-            const float av = keep ? a[u] : 0.0f;
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) acc[ct] = mfma(av, b[u][ct], acc[ct]);
+            for (int ct = 0; ct < NCT; ++ct) acc[ct] = mfma(a[u], b[u][ct], acc[ct]);
         }
 #pragma unroll
         for (int u = 0; u < G; ++u) {
@@ -640,6 +647,8 @@ __device__ __forceinline__ void wgrad_mma(const float* __restrict__ XT, const fl
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) b[u][ct] = nb[u][ct];
         }
+        // without the fence the scheduler gathers all sixteen slices at the end of the loop
+        if (!std::is_same<SideFn, NoFetch>::value) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -671,13 +680,14 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* XT = lds;
     float* YT = lds + WG_ROWS * WG_LDW;
-    float* X8 = lds + 2 * WG_ROWS * WG_LDW;       // [dlogits(5) | drgb(3)] rows; rows 8..31 are read but masked
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float* X8 = lds + 2 * WG_ROWS * WG_LDW;       // [dlogits(5) | drgb(3)] rows; rows 8..31 are zero
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
 
+    for (int q = tid; q < 24 * WG_LDW; q += DEC_BLOCK) X8[8 * WG_LDW + q] = 0.0f;      // rows 8..31 stay zero
     f32x16 aS1[3], aW2[4], aW1[2], aS2[1], aRGB[1];
     zero_acc(aS1), zero_acc(aW2), zero_acc(aW1), zero_acc(aS2), zero_acc(aRGB);
-    float db3 = 0.f, db2 = 0.f, db1 = 0.f, dbs = 0.f;
+    float db3 = 0.f, db2 = 0.f;
     const int brow = tid & 127, bhalf = tid >> 7;
 
     auto row_sum = [&](const float* T, int row, int c0, int n) {
@@ -700,90 +710,130 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
     // prefetch registers: X / Y operands of the next phase (+ grid features, coordinates, small gradients)
     float4 nx[16], ny[16], nsm;
     float ngf[16];
+    // Everything that selects a tile is kept in scalar registers (w is wave-uniform): with one wave per SIMD a
+    // vector instruction is never hidden behind this wave's own MFMAs, so per-load address
+    // arithmetic, per-load liveness selects and zero-fills were costing as much as the matrix work they fed.
+    // Loads are unconditional from a tile that exists; a dead wave tile (tail of M) zeroes its X operand instead.
+    const int n_wtiles = (int)((M + 31u) / 32u);
+    const uint32_t lane16 = 16u * (uint32_t)lane;
     // reversed tile order: the tiles the chain kernel wrote last are still in the 256 MB Infinity Cache (318 -> 310 us)
-    auto tile_of = [&](uint32_t bt) { return (int64_t)(n_btiles - 1u - (bt < n_btiles ? bt : n_btiles - 1u)) * 4 + w; };
-    auto live_of = [&](uint32_t bt) { return bt < n_btiles && tile_of(bt) * 32 < (int64_t)M; };
+    auto tile_of = [&](uint32_t bt) { return (int)(n_btiles - 1u - (bt < n_btiles ? bt : n_btiles - 1u)) * 4 + w; };
+    auto live_of = [&](uint32_t bt) { return bt < n_btiles && tile_of(bt) < n_wtiles; };
+    auto src_tile = [&](uint32_t bt) { const int t = tile_of(bt); return t < n_wtiles ? t : n_wtiles - 1; };
     auto sample_of = [&](uint32_t bt) {
-        const uint32_t s_raw = (uint32_t)(tile_of(bt) * 32 + j);
+        const uint32_t s_raw = (uint32_t)(src_tile(bt) * 32 + j);
         return s_raw < M ? s_raw : M - 1;
     };
-    auto fetch_phase0 = [&](uint32_t bt) {          // X = dG3, Y = [sdf_emb | grid]
-        const bool lv = live_of(bt);
-        fetch_act(nx, dact, tile_of(bt), 2, 0, 4, lv, lane);
-        fetch_act(ny, saved, tile_of(bt), 1, 0, 2, lv, lane);
-        const uint32_t s = lv ? sample_of(bt) : 0;
+    auto zero16 = [&](float4* r) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) ngf[u] = lv ? load_feat<LAYOUT>(feat, s, u, h, M) : 0.0f;
+        for (int q = 0; q < 16; ++q) r[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     };
 
-    fetch_phase0(blockIdx.x);
+    {   // first block tile's first phase: X = dG3, Y = [sdf_emb | grid]
+        const int t0 = src_tile(blockIdx.x);
+        const char* bx = act_base(dact, t0, 2, 0);
+        const char* by = act_base(saved, t0, 1, 0);
+        const uint32_t s0 = sample_of(blockIdx.x);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) nx[k] = act_piece(bx, k, lane16);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ny[k] = act_piece(by, k, lane16);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) ngf[u] = load_feat<LAYOUT>(feat, s0, u, h, M);
+    }
     for (uint32_t bt = blockIdx.x; bt < n_btiles; bt += gridDim.x) {
-        const int64_t tile = tile_of(bt);
         const bool tile_live = live_of(bt);
+        const int tile = src_tile(bt);
         const uint32_t s = sample_of(bt);
 
         // ---------------- phase sdf0: X = dG3, Y = [sdf_emb | grid]
+        if (!tile_live) zero16(nx);
         put_act(XT, nx, 0, 4, 0, w, lane);
         put_act(YT, ny, 0, 2, 0, w, lane);
 #pragma unroll
         for (int u = 0; u < 16; ++u) YT[(64 + 2 * u + h) * WG_LDW + 32 * w + j] = ngf[u];
         __syncthreads();
-        fetch_act(nx, dact, tile, 1, 0, 4, tile_live, lane);      // next: X = dH2, Y = H1
-        fetch_act(ny, saved, tile, 0, 0, 4, tile_live, lane);
-        wgrad_mma<3>(XT, YT, w, 0, lane, aS1);
+        {                                                                        // next: X = dH2, Y = H1
+            const char* bx = act_base(dact, tile, 1, 0);
+            const char* by = act_base(saved, tile, 0, 0);
+            wgrad_mma<3>(XT, YT, w, 0, lane, aS1, [&](int g) {
+                nx[g] = act_piece(bx, g, lane16);
+                ny[g] = act_piece(by, g, lane16);
+            });
+        }
         db3 += row_sum(XT, brow, 64 * bhalf, 64);
         __syncthreads();
 
         // ---------------- phase pts2: X = dH2, Y = H1
+        if (!tile_live) zero16(nx);
         put_act(XT, nx, 0, 4, 0, w, lane);
         put_act(YT, ny, 0, 4, 0, w, lane);
         __syncthreads();
-        fetch_act(nx, dact, tile, 0, 0, 4, tile_live, lane);      // next: X = dG1 (+ the 8 small rows), Y = [e | rgb_emb]
-        fetch_act(ny, saved, tile, 1, 2, 2, tile_live, lane);
-        {
-            const int sl = tid & 127, half = tid >> 7;
-            const int64_t sg = (tile_of(bt) - w) * 32 + sl;
-            nsm = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (sg < (int64_t)M) nsm = reinterpret_cast<const float4*>(dsmall + sg * 8)[half];
+        {                                                    // next: X = dG1 (+ the 8 small rows), Y = [e | rgb_emb]
+            const char* bx = act_base(dact, tile, 0, 0);
+            const char* by = act_base(saved, tile, 1, 2);
+            wgrad_mma<4>(XT, YT, w, 0, lane, aW2, [&](int g) {
+                nx[g] = act_piece(bx, g, lane16);
+                if (g < 8) ny[g] = act_piece(by, g, lane16);
+                if (g == 8) {
+                    const int64_t sg = (int64_t)(tile_of(bt) - w) * 32 + brow;
+                    nsm = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (sg < (int64_t)M) nsm = reinterpret_cast<const float4*>(dsmall + sg * 8)[bhalf];
+                }
+            });
         }
-        wgrad_mma<4>(XT, YT, w, 0, lane, aW2);
         db2 += row_sum(XT, brow, 64 * bhalf, 64);
         __syncthreads();
 
-        // ---------------- phase pts0 + rgb0: X = dG1 and the 8 small rows, Y = [e (rows 0..50, 51..63 zero) | rgb_emb (64..127)]
-        // (d w_rgb0 = drgb^T [rgb_emb | e] rides on the staging of e: one phase, two barriers and one e-staging less)
+        // ---------------- phase pts0 + rgb0: X = dG1 and the 8 small rows,
+        // Y = [e (rows 0..50) | ONES (row 51) | zero (52..63) | rgb_emb (64..127)]
+        // (d w_rgb0 = drgb^T [rgb_emb | e] rides on the staging of e: one phase, two barriers and one e-staging less;
+        //  the ones row makes column 51 of both products the bias gradients: sums over samples of dG1 / dlogits / drgb)
+        if (!tile_live) zero16(nx);
         put_act(XT, nx, 0, 4, 0, w, lane);
         put_act(YT, ny, 2, 2, 0, w, lane);
         {
             float ev[E_SLOTS];
-            load_e<PE_INTERNAL>(x, embed_pos, s, h, ev);
+            load_e<PE_INTERNAL, true>(x, embed_pos, s, h, ev);
 #pragma unroll
             for (int t = 0; t < E_SLOTS; ++t) {
                 const int e = eidx(t, h);
-                if (e >= 0) YT[e * WG_LDW + 32 * w + j] = tile_live ? ev[t] : 0.0f;
+                if (e >= 0) YT[e * WG_LDW + 32 * w + j] = ev[t];
             }
         }
-        for (int q = tid; q < 13 * 128; q += DEC_BLOCK) YT[(51 + q / 128) * WG_LDW + (q % 128)] = 0.0f;
         {
-            const int sl = tid & 127, half = tid >> 7;
-            X8[(4 * half + 0) * WG_LDW + sl] = nsm.x;
-            X8[(4 * half + 1) * WG_LDW + sl] = nsm.y;
-            X8[(4 * half + 2) * WG_LDW + sl] = nsm.z;
-            X8[(4 * half + 3) * WG_LDW + sl] = nsm.w;
+            float* pad = YT + (51 + bhalf) * WG_LDW + brow;          // rows 51..63, two rows per pass
+#pragma unroll
+            for (int i = 0; i < 7; ++i)
+                if (bhalf + 2 * i < 13) pad[2 * i * WG_LDW] = (bhalf + 2 * i == 0) ? 1.0f : 0.0f;
         }
+        X8[(4 * bhalf + 0) * WG_LDW + brow] = nsm.x;
+        X8[(4 * bhalf + 1) * WG_LDW + brow] = nsm.y;
+        X8[(4 * bhalf + 2) * WG_LDW + brow] = nsm.z;
+        X8[(4 * bhalf + 3) * WG_LDW + brow] = nsm.w;
         __syncthreads();
-        fetch_act(ny, saved, tile, 2, 0, 4, tile_live, lane);      // next: Y = H3
-        wgrad_mma<2>(XT, YT, w, 0, lane, aW1);
-        wgrad_mma<1>(X8, YT, 0, w, lane, aRGB, true);
-        db1 += row_sum(XT, brow, 64 * bhalf, 64);
-        if (tid < 16) dbs += row_sum(X8, tid & 7, 64 * (tid >> 3), 64);
+        {                                                                        // next: Y = H3
+            const char* by = act_base(saved, tile, 2, 0);
+            wgrad_mma<2>(XT, YT, w, 0, lane, aW1, [&](int g) { ny[g] = act_piece(by, g, lane16); });
+        }
+        wgrad_mma<1>(X8, YT, 0, w, lane, aRGB);
         __syncthreads();
 
         // ---------------- phase sdf2: X = the 8 small rows (still in X8), Y = H3
         put_act(YT, ny, 0, 4, 0, w, lane);
         __syncthreads();
-        fetch_phase0(bt + gridDim.x);                              // next block tile's first phase
-        wgrad_mma<1>(X8, YT, 0, w, lane, aS2, true);
+        {                                                                        // next block tile's first phase
+            const uint32_t nb = bt + gridDim.x;
+            const int nt = src_tile(nb);
+            const char* bx = act_base(dact, nt, 2, 0);
+            const char* by = act_base(saved, nt, 1, 0);
+            const uint32_t ns = sample_of(nb);
+            wgrad_mma<1>(X8, YT, 0, w, lane, aS2, [&](int g) {
+                nx[g] = act_piece(bx, g, lane16);
+                if (g < 8) ny[g] = act_piece(by, g, lane16);
+                ngf[g] = load_feat<LAYOUT>(feat, ns, g, h, M);
+            });
+        }
         __syncthreads();
     }
 
@@ -809,15 +859,22 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
             if (row >= 5 && row < 8 && rc >= 0) rec[G_W_RGB0 + (row - 5) * N_RGB_IN + rc] = aRGB[0][r];
         }
     }
-    // bias partials: two column halves per row -> atomics inside the block's own record (LDS-free, 2 adders)
+    {
+        // column 51 of the pts0 / rgb0 products is the ones row: d b_pts0 (rows of aW1[1]), d b_sdf2 and d b_rgb0
+        const int jj = lane & 31, hh = lane >> 5;
+        if (jj == N_E - 32) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rowmap(r, hh);
+                rec[G_B_PTS0 + 32 * w + row] = aW1[1][r];
+                if (w == 1 && row < N_CLASS) rec[G_B_SDF2 + row] = aRGB[0][r];
+                if (w == 1 && row >= 5 && row < 8) rec[G_B_RGB0 + row - 5] = aRGB[0][r];
+            }
+        }
+    }
+    // remaining bias partials: two column halves per row -> atomics inside the block's own record
     atomicAdd(&rec[G_B_SDF0 + brow], db3);
     atomicAdd(&rec[G_B_PTS2 + brow], db2);
-    atomicAdd(&rec[G_B_PTS0 + brow], db1);
-    if (tid < 16) {
-        const int row = tid & 7;
-        if (row < N_CLASS) atomicAdd(&rec[G_B_SDF2 + row], dbs);
-        else atomicAdd(&rec[G_B_RGB0 + row - 5], dbs);
-    }
 }
 
 
