@@ -110,6 +110,25 @@ __device__ __forceinline__ void store16(float4* p, const float4& v) {
     *p = v;
 }
 
+// Buffer addressing: one 128-bit resource (scalar) + a 32-bit lane offset (vector, computed once) + a scalar /
+// immediate offset per access.  A flat `ptr[const + lane]` costs one or two 64-bit vector adds per access as soon as
+// the constant leaves the 4 KB immediate range -- 350 vector instructions per tile in the backward chain, and vector
+// instructions are what the matrix pipe waits for.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t srd_t;
+__device__ __forceinline__ srd_t make_srd(const void* base_u, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base_u), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load16(srd_t r, uint32_t lane16, uint32_t off_u) {
+    const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, lane16, off_u, 0);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+}
+__device__ __forceinline__ void buf_store16(srd_t r, uint32_t lane16, uint32_t off_u, const float4& v) {
+    u32x4 u;
+    u.x = __float_as_uint(v.x), u.y = __float_as_uint(v.y), u.z = __float_as_uint(v.z), u.w = __float_as_uint(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, lane16, off_u, 0);
+}
+
 // group q in [0,16): row tile q>>2, registers 4*(q&3) .. +3
 __device__ __forceinline__ void store_act_piece(float* __restrict__ dst, int64_t tile, int mat, int lane,
                                                 const f32x16 (&acc)[4], int q) {
@@ -369,18 +388,18 @@ constexpr int TAB_F4 = (OFF_BIAS - OFF_TRGB) / 4;      // rgb-head and sdf2-head
 constexpr int XB_ENTRIES = 32 * 32;                  // float4 entries per wave: [group 2*t4+h][sample j]
 
 template <int RT, int T, typename SideFn>
-__device__ __forceinline__ void mfma_layer_b4(const float4* __restrict__ img, int lane, f32x16 (&acc)[RT],
+__device__ __forceinline__ void mfma_layer_b4(srd_t wsrd, uint32_t img_off, uint32_t lane16, f32x16 (&acc)[RT],
                                               const float4* xb, SideFn side) {
     constexpr int T4 = T / 4;
     float4 a[RT], nxt[RT], b, nb;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) a[rt] = img[(rt * T4) * 64 + lane];
+    for (int rt = 0; rt < RT; ++rt) a[rt] = buf_load16(wsrd, lane16, img_off + (rt * T4) * 1024);
     b = xb[0];
 #pragma unroll
     for (int t4 = 0; t4 < T4; ++t4) {
         if (t4 + 1 < T4) {
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) nxt[rt] = img[(rt * T4 + t4 + 1) * 64 + lane];
+            for (int rt = 0; rt < RT; ++rt) nxt[rt] = buf_load16(wsrd, lane16, img_off + (rt * T4 + t4 + 1) * 1024);
             nb = xb[(t4 + 1) * 64];
         }
         side(t4, b);
@@ -414,14 +433,19 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
-    const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + (threadIdx.x >> 6);
+    // the wave index is made a scalar so that every per-tile base address below is scalar arithmetic: vector
+    // instructions are only partly hidden behind the other wave's MFMAs
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + wv;
     if (tile * 32 >= (int64_t)M) return;
-    float4* xb = xb_all + (threadIdx.x >> 6) * XB_ENTRIES + h * 32 + j;      // piece p of this lane: xb[p * 64]
+    float4* xb = xb_all + wv * XB_ENTRIES + h * 32 + j;      // piece p of this lane: xb[p * 64]
     const uint32_t s_raw = (uint32_t)(tile * 32 + j);
     const bool live = s_raw < M;
     const uint32_t s = live ? s_raw : M - 1;
-    const float4* sv4 = reinterpret_cast<const float4*>(saved) + (size_t)tile * (ACT_SLOTS / 4) * 64 + lane;
-    float4* da4 = reinterpret_cast<float4*>(dact) + (size_t)tile * (ACT_SLOTS / 4) * 64 + lane;
+    const uint32_t lane16 = 16u * (uint32_t)lane;
+    const srd_t wsrd = make_srd(packed, PACKED_FLOATS * 4);
+    const srd_t sv = make_srd(saved + (size_t)tile * ACT_TILE_FLOATS, ACT_TILE_FLOATS * 4);     // this tile's saved activations
+    const srd_t da = make_srd(dact + (size_t)tile * ACT_TILE_FLOATS, ACT_TILE_FLOATS * 4);      // ... and gradients
 
     // ---- softmax / entropy / expected-class backward -> d logits; d rgb is the incoming gradient itself
     float dlg[N_CLASS], drgb[3];
@@ -454,7 +478,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
         const float4* ts2 = tab + (OFF_TS2 - OFF_TRGB) / 4 + h * 128;
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
-            const float4 hm = sv4[(2 * 16 + p) * 64];
+            const float4 hm = buf_load16(sv, lane16, (2 * 16 + p) * 1024);
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -472,8 +496,8 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
     // ---- d[sdf_emb | grid] = Ws1^T dG3   (3 row tiles: 0,1 -> d sdf_emb, 2 -> d grid features)
     f32x16 dIn3[3];
     zero_acc3(dIn3);
-    mfma_layer_b4<RT_B3, T_B3>(reinterpret_cast<const float4*>(packed + OFF_B3), lane, dIn3, xb,
-                               [&](int t4, const float4& b) { if (pin == 0) store16(da4 + (2 * 16 + t4) * 64, b); });
+    mfma_layer_b4<RT_B3, T_B3>(wsrd, OFF_B3 * 4, lane16, dIn3, xb,
+                               [&](int t4, const float4& b) { if (pin == 0) buf_store16(da, lane16, (2 * 16 + t4) * 1024, b); });
     if (live) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
@@ -509,10 +533,10 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
         f32x16 dG1[4];
         float4 H1p[16];
         zero_acc4(dG1);
-        mfma_layer_b4<RT_B2, T_B2>(reinterpret_cast<const float4*>(packed + OFF_B2), lane, dG1, xb,
+        mfma_layer_b4<RT_B2, T_B2>(wsrd, OFF_B2 * 4, lane16, dG1, xb,
                                    [&](int t4, const float4& b) {
-                                       H1p[t4] = sv4[(0 * 16 + t4) * 64];
-                                       if (pin == 0) store16(da4 + (1 * 16 + t4) * 64, b);
+                                       H1p[t4] = buf_load16(sv, lane16, (0 * 16 + t4) * 1024);
+                                       if (pin == 0) buf_store16(da, lane16, (1 * 16 + t4) * 1024, b);
                                    });
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
@@ -529,8 +553,8 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dE[rt][r] = 0.0f;
-    mfma_layer_b4<RT_B1, T_B1>(reinterpret_cast<const float4*>(packed + OFF_B1), lane, dE, xb,
-                               [&](int t4, const float4& b) { if (pin == 0) store16(da4 + (0 * 16 + t4) * 64, b); });
+    mfma_layer_b4<RT_B1, T_B1>(wsrd, OFF_B1 * 4, lane16, dE, xb,
+                               [&](int t4, const float4& b) { if (pin == 0) buf_store16(da, lane16, (0 * 16 + t4) * 1024, b); });
     float de[E_SLOTS];
 #pragma unroll
     for (int t = 0; t < E_SLOTS; ++t) {
@@ -546,8 +570,10 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
             const float xd = d == 0 ? x0 : (d == 1 ? x1 : x2);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float arg = fmaf(ldexpf(xd, k), PI_F, h ? HALF_PI_F : 0.0f);
-                gx[d] = gx[d] + de[d * 8 + k] * ((ldexpf(1.0f, k) * PI_F) * cosf(arg));
+                // cos(2^k pi x + h pi/2) = v_cos_f32(fract(2^(k-1) x) + h/4): exact argument in revolutions, 3
+                // instructions instead of cosf's ~45 (24 of them per lane were a tenth of this kernel's instructions)
+                const float c = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(ldexpf(xd, k - 1)) + (h ? 0.25f : 0.0f));
+                gx[d] = gx[d] + de[d * 8 + k] * ((ldexpf(1.0f, k) * PI_F) * c);
             }
         }
         gx[0] += h == 0 ? de[24] : 0.0f;   // slot 24 carries x0 (lower half) / x1 (upper half)
