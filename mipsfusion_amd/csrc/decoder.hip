@@ -157,10 +157,26 @@ __device__ __forceinline__ void load_act(const float* __restrict__ src, int64_t 
 }
 
 // the 26 e values this lane feeds into layer 1 (its half of every k-step)
-// FAST (weight gradients only, where e is an operand of a 262144-term sum): sin(2^k pi x + h pi/2) evaluated as
-// v_sin_f32(fract(2^(k-1) x) + h/4) -- the argument in revolutions is exact, 3 instructions instead of the ~45 of
-// sinf's range reduction, and with one wave per SIMD every one of them is exposed
-template <bool PE_INTERNAL, bool FAST = false>
+// sin of an fp32 argument |a| < ~2^10 as the oracle's sinf sees it, without libm's Payne-Hanek path (~65 vector
+// instructions per value, 24 values per lane: a third of the forward kernel's non-matrix instructions).  The
+// argument is reduced to revolutions with 1/(2 pi) split in two (the fma recovers the product's low bits, error
+// < 1e-7 revolutions), then v_sin_f32.  The forward must see the oracle's ROUNDED argument: evaluating the exact
+// argument instead moves e by up to 3e-5 and flips enough ReLUs to fail the scene gradient fixtures.
+__device__ __forceinline__ float sin_reduced(float a) {
+    const float C_HI = 0x1.45f306p-3f, C_LO = 0x1.b9391p-28f;
+    const float n = rintf(a * C_HI);
+    float f = fmaf(a, C_HI, -n);
+    f = fmaf(a, C_LO, f);
+    return __builtin_amdgcn_sinf(f);
+}
+__device__ __forceinline__ float cos_reduced(float a) {
+    const float C_HI = 0x1.45f306p-3f, C_LO = 0x1.b9391p-28f;
+    const float n = rintf(a * C_HI);
+    float f = fmaf(a, C_HI, -n);
+    f = fmaf(a, C_LO, f);
+    return __builtin_amdgcn_cosf(f);
+}
+template <bool PE_INTERNAL>
 __device__ __forceinline__ void load_e(const float* __restrict__ x, const float* __restrict__ embed_pos,
                                        uint32_t s, int h, float (&ev)[E_SLOTS]) {
     const float x0 = x[3 * (size_t)s], x1 = x[3 * (size_t)s + 1], x2 = x[3 * (size_t)s + 2];
@@ -169,10 +185,8 @@ __device__ __forceinline__ void load_e(const float* __restrict__ x, const float*
         const float xd = d == 0 ? x0 : (d == 1 ? x1 : x2);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            if (PE_INTERNAL && FAST)
-                ev[d * 8 + k] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(ldexpf(xd, k - 1)) + (h ? 0.25f : 0.0f));
-            else if (PE_INTERNAL)
-                ev[d * 8 + k] = sinf(fmaf(ldexpf(xd, k), PI_F, h ? HALF_PI_F : 0.0f));
+            if (PE_INTERNAL)
+                ev[d * 8 + k] = sin_reduced(fmaf(ldexpf(xd, k), PI_F, h ? HALF_PI_F : 0.0f));
             else
                 ev[d * 8 + k] = embed_pos[(size_t)s * N_PE + d * 16 + 2 * k + h];
         }
@@ -387,13 +401,19 @@ __device__ __forceinline__ void zero_acc4(f32x16 (&a)[4]) {
 constexpr int TAB_F4 = (OFF_BIAS - OFF_TRGB) / 4;      // rgb-head and sdf2-head tables, contiguous in `packed`
 constexpr int XB_ENTRIES = 32 * 32;                  // float4 entries per wave: [group 2*t4+h][sample j]
 
+// first k-group of a layer's A image: requested BEFORE the vector section that precedes the layer, so that the
+// layer's first MFMA does not start with an L2 round trip
+template <int RT, int T>
+__device__ __forceinline__ void preload_a(srd_t wsrd, uint32_t img_off, uint32_t lane16, float4 (&a)[RT]) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a[rt] = buf_load16(wsrd, lane16, img_off + (rt * (T / 4)) * 1024);
+}
+
 template <int RT, int T, typename SideFn>
 __device__ __forceinline__ void mfma_layer_b4(srd_t wsrd, uint32_t img_off, uint32_t lane16, f32x16 (&acc)[RT],
-                                              const float4* xb, SideFn side) {
+                                              const float4* xb, float4 (&a)[RT], SideFn side) {
     constexpr int T4 = T / 4;
-    float4 a[RT], nxt[RT], b, nb;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) a[rt] = buf_load16(wsrd, lane16, img_off + (rt * T4) * 1024);
+    float4 nxt[RT], b, nb;
     b = xb[0];
 #pragma unroll
     for (int t4 = 0; t4 < T4; ++t4) {
@@ -447,25 +467,43 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
     const srd_t sv = make_srd(saved + (size_t)tile * ACT_TILE_FLOATS, ACT_TILE_FLOATS * 4);     // this tile's saved activations
     const srd_t da = make_srd(dact + (size_t)tile * ACT_TILE_FLOATS, ACT_TILE_FLOATS * 4);      // ... and gradients
 
+    // The whole H3 tile (relu mask of the first gradient) and the two 40-byte rows of out / dout are requested
+    // before anything is computed: this wave has no earlier tile whose matrix work could cover them, and left to the
+    // compiler the sixteen H3 pieces were fetched two at a time in front of their uses -- eight exposed round trips
+    // per tile (ablation: 28 us of the kernel's 221).
+    float2 o2[5], g2[5];
+    {
+        const float2* o = reinterpret_cast<const float2*>(out + (size_t)s * 10);
+        const float2* g = reinterpret_cast<const float2*>(dout + (size_t)s * 10);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) o2[c] = o[c], g2[c] = g[c];
+    }
+    __builtin_amdgcn_sched_barrier(0);      // vmcnt retires in order: the softmax below waits for these rows only
+    float4 hm3[16], a3[RT_B3];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) hm3[p] = buf_load16(sv, lane16, (2 * 16 + p) * 1024);
+    preload_a<RT_B3, T_B3>(wsrd, OFF_B3 * 4, lane16, a3);
+    __builtin_amdgcn_sched_barrier(0);
+
     // ---- softmax / entropy / expected-class backward -> d logits; d rgb is the incoming gradient itself
     float dlg[N_CLASS], drgb[3];
     {
-        const float* o = out + (size_t)s * 10;
-        const float* g = dout + (size_t)s * 10;
-        const float g_sdf = live ? g[3] : 0.f, g_ent = live ? g[4] : 0.f;
+        const float gv[10] = {g2[0].x, g2[0].y, g2[1].x, g2[1].y, g2[2].x, g2[2].y, g2[3].x, g2[3].y, g2[4].x, g2[4].y};
+        const float ov[10] = {o2[0].x, o2[0].y, o2[1].x, o2[1].y, o2[2].x, o2[2].y, o2[3].x, o2[3].y, o2[4].x, o2[4].y};
+        const float g_sdf = live ? gv[3] : 0.f, g_ent = live ? gv[4] : 0.f;
         float p[N_CLASS], dp[N_CLASS], dot = 0.f;
 #pragma unroll
         for (int c = 0; c < N_CLASS; ++c) {
-            p[c] = o[5 + c];
+            p[c] = ov[5 + c];
             const float q = p[c] + 1e-5f;
             const float dent = -1.0f * (log2f(q) + p[c] / (q * 0.69314718055994530942f));
-            dp[c] = (live ? g[5 + c] : 0.f) + g_sdf * (0.5f * (float)c) + g_ent * dent;
+            dp[c] = (live ? gv[5 + c] : 0.f) + g_sdf * (0.5f * (float)c) + g_ent * dent;
             dot += p[c] * dp[c];
         }
 #pragma unroll
         for (int c = 0; c < N_CLASS; ++c) dlg[c] = p[c] * (dp[c] - dot);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) drgb[c] = live ? g[c] : 0.f;
+        for (int c = 0; c < 3; ++c) drgb[c] = live ? gv[c] : 0.f;
         if (h == 0) {
             float4* d4 = reinterpret_cast<float4*>(dsmall + (size_t)(tile * 32 + j) * 8);
             d4[0] = make_float4(dlg[0], dlg[1], dlg[2], dlg[3]);
@@ -478,7 +516,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
         const float4* ts2 = tab + (OFF_TS2 - OFF_TRGB) / 4 + h * 128;
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
-            const float4 hm = buf_load16(sv, lane16, (2 * 16 + p) * 1024);
+            const float4 hm = hm3[p];
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -496,7 +534,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
     // ---- d[sdf_emb | grid] = Ws1^T dG3   (3 row tiles: 0,1 -> d sdf_emb, 2 -> d grid features)
     f32x16 dIn3[3];
     zero_acc3(dIn3);
-    mfma_layer_b4<RT_B3, T_B3>(wsrd, OFF_B3 * 4, lane16, dIn3, xb,
+    mfma_layer_b4<RT_B3, T_B3>(wsrd, OFF_B3 * 4, lane16, dIn3, xb, a3,
                                [&](int t4, const float4& b) { if (pin == 0) buf_store16(da, lane16, (2 * 16 + t4) * 1024, b); });
     if (live) {
 #pragma unroll
@@ -511,6 +549,8 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
     }
 
     // ---- dH2 = [d sdf_emb (from above) | d rgb_emb = Wrgb^T drgb] -> LDS
+    float4 a2[RT_B2];
+    preload_a<RT_B2, T_B2>(wsrd, OFF_B2 * 4, lane16, a2);
     const float4* trgb = tab + h * TRGB_SLOTS;
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
@@ -529,15 +569,17 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
     }
 
     // ---- dG1 = relu'(H1) * (W2^T dH2)   (dH2 goes out, H1 comes in, one 16-byte group per k-group)
+    float4 a1[RT_B1];
     {
         f32x16 dG1[4];
         float4 H1p[16];
         zero_acc4(dG1);
-        mfma_layer_b4<RT_B2, T_B2>(wsrd, OFF_B2 * 4, lane16, dG1, xb,
+        mfma_layer_b4<RT_B2, T_B2>(wsrd, OFF_B2 * 4, lane16, dG1, xb, a2,
                                    [&](int t4, const float4& b) {
                                        H1p[t4] = buf_load16(sv, lane16, (0 * 16 + t4) * 1024);
                                        if (pin == 0) buf_store16(da, lane16, (1 * 16 + t4) * 1024, b);
                                    });
+        preload_a<RT_B1, T_B1>(wsrd, OFF_B1 * 4, lane16, a1);
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             const int rt = p >> 2, g = p & 3;
@@ -553,7 +595,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dE[rt][r] = 0.0f;
-    mfma_layer_b4<RT_B1, T_B1>(wsrd, OFF_B1 * 4, lane16, dE, xb,
+    mfma_layer_b4<RT_B1, T_B1>(wsrd, OFF_B1 * 4, lane16, dE, xb, a1,
                                [&](int t4, const float4& b) { if (pin == 0) buf_store16(da, lane16, (0 * 16 + t4) * 1024, b); });
     float de[E_SLOTS];
 #pragma unroll
@@ -570,10 +612,10 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
             const float xd = d == 0 ? x0 : (d == 1 ? x1 : x2);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                // cos(2^k pi x + h pi/2) = v_cos_f32(fract(2^(k-1) x) + h/4): exact argument in revolutions, 3
-                // instructions instead of cosf's ~45 (24 of them per lane were a tenth of this kernel's instructions)
-                const float c = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(ldexpf(xd, k - 1)) + (h ? 0.25f : 0.0f));
-                gx[d] = gx[d] + de[d * 8 + k] * ((ldexpf(1.0f, k) * PI_F) * c);
+                // derivative at the argument the forward used; cos_reduced = 6 instructions instead of cosf's ~65
+                // (24 of them per lane were a quarter of this kernel's vector instructions)
+                const float arg = fmaf(ldexpf(xd, k), PI_F, h ? HALF_PI_F : 0.0f);
+                gx[d] = gx[d] + de[d * 8 + k] * ((ldexpf(1.0f, k) * PI_F) * cos_reduced(arg));
             }
         }
         gx[0] += h == 0 ? de[24] : 0.0f;   // slot 24 carries x0 (lower half) / x1 (upper half)
@@ -820,7 +862,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
         put_act(YT, ny, 2, 2, 0, w, lane);
         {
             float ev[E_SLOTS];
-            load_e<PE_INTERNAL, true>(x, embed_pos, s, h, ev);
+            load_e<PE_INTERNAL>(x, embed_pos, s, h, ev);
 #pragma unroll
             for (int t = 0; t < E_SLOTS; ++t) {
                 const int e = eidx(t, h);
