@@ -635,7 +635,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
 }
 
 // ============================================================================ weight gradients
-constexpr int WG_LDW = 129;                         // odd row stride: conflict-free both ways
+constexpr int WG_LDW = 132;                         // row stride: 16-byte aligned rows, 4 banks apart (b128 reads conflict-free)
 constexpr int WG_ROWS = 128;
 constexpr int WG_LDS_FLOATS = (2 * WG_ROWS + 32) * WG_LDW;   // X^T, Y^T and the 8 (padded to 32) small-gradient rows
 constexpr int WG_LDS_BYTES = WG_LDS_FLOATS * 4;
@@ -679,42 +679,38 @@ struct NoFetch {
 template <int NCT, typename SideFn = NoFetch>
 __device__ __forceinline__ void wgrad_mma(const float* __restrict__ XT, const float* __restrict__ YT, int rtile,
                                           int ct0, int lane, f32x16 (&acc)[NCT], SideFn side = NoFetch()) {
+    // MFMA k-step t multiplies samples t (lanes 0..31) and t + 64 (lanes 32..63) -- any pairing is valid as long as
+    // both operands use it -- so that four consecutive k-steps of one operand are ONE ds_read_b128 (256 operand reads per
+    // block tile instead of 512 ds_read2_b32; measured neutral, kept for the simpler loop)
     const int i = lane & 31, kk = lane >> 5;
-    const float* xa = XT + (32 * rtile + i) * WG_LDW + kk;
-    const float* yb = YT + (32 * ct0 + i) * WG_LDW + kk;
+    const float4* xa = reinterpret_cast<const float4*>(XT + (32 * rtile + i) * WG_LDW + 64 * kk);
+    const float4* yb = reinterpret_cast<const float4*>(YT + (32 * ct0 + i) * WG_LDW + 64 * kk);
     // operands of k-step group g+1 are read from LDS while the 4*NCT MFMAs of group g execute; side(g), g = 0..15,
     // issues the g-th slice of the NEXT phase's global loads: spread over the loop, the wave never sits in a full
     // memory-instruction queue before its first MFMA (308 -> 297 us)
-    constexpr int G = 4;
-    float a[G], b[G][NCT], na[G], nb[G][NCT];
+    float4 a, b[NCT], na, nb[NCT];
+    a = xa[0];
 #pragma unroll
-    for (int u = 0; u < G; ++u) {
-        a[u] = xa[2 * u];
+    for (int ct = 0; ct < NCT; ++ct) b[ct] = yb[ct * 8 * WG_LDW];
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) b[u][ct] = yb[ct * 32 * WG_LDW + 2 * u];
-    }
+    for (int g = 0; g < 16; ++g) {
+        if (g + 1 < 16) {
+            na = xa[g + 1];
 #pragma unroll
-    for (int t0 = 0; t0 < 64; t0 += G) {
-        if (t0 + G < 64) {
-#pragma unroll
-            for (int u = 0; u < G; ++u) {
-                na[u] = xa[2 * (t0 + G + u)];
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) nb[u][ct] = yb[ct * 32 * WG_LDW + 2 * (t0 + G + u)];
-            }
+            for (int ct = 0; ct < NCT; ++ct) nb[ct] = yb[ct * 8 * WG_LDW + g + 1];
         }
-        side(t0 / G);
+        side(g);
 #pragma unroll
-        for (int u = 0; u < G; ++u) {
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = mfma(a.x, b[ct].x, acc[ct]);
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) acc[ct] = mfma(a[u], b[u][ct], acc[ct]);
-        }
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = mfma(a.y, b[ct].y, acc[ct]);
 #pragma unroll
-        for (int u = 0; u < G; ++u) {
-            a[u] = na[u];
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = mfma(a.z, b[ct].z, acc[ct]);
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) b[u][ct] = nb[u][ct];
-        }
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = mfma(a.w, b[ct].w, acc[ct]);
+        a = na;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) b[ct] = nb[ct];
         // without the fence the scheduler gathers all sixteen slices at the end of the loop
         if (!std::is_same<SideFn, NoFetch>::value) __builtin_amdgcn_sched_barrier(0);
     }
@@ -759,20 +755,20 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
     const int brow = tid & 127, bhalf = tid >> 7;
 
     auto row_sum = [&](const float* T, int row, int c0, int n) {
-        float a = 0.f;
-        // 8 loads in flight at a time.  Fully unrolled, the 64 loads of a row sum are all hoisted in front of the adds;
-        // their 64 registers (on top of the 128 prefetch registers in flight) pushed ~40 loop invariants into scratch,
-        // and every scratch reload waits on vmcnt -- i.e. for the whole prefetch it was meant to overlap (370 -> see
-        // DESIGN.md 4b).
+        // four 16-byte reads in flight at a time (fully unrolled, the loads of a row sum are all hoisted in front of the
+        // adds and their registers, on top of the 128 prefetch registers, push loop invariants into scratch -- and
+        // every scratch reload waits on vmcnt, i.e. for the whole prefetch it was meant to overlap)
+        const float4* T4 = reinterpret_cast<const float4*>(T + row * WG_LDW + c0);
+        float s0 = 0.f, s1 = 0.f;
 #pragma unroll 1
-        for (int c = 0; c < n; c += 8) {
-            float v[8];
+        for (int c = 0; c < n / 4; c += 4) {
+            float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = T[row * WG_LDW + c0 + c + u];
+            for (int u = 0; u < 4; ++u) v[u] = T4[c + u];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a += v[u];
+            for (int u = 0; u < 4; ++u) s0 += v[u].x + v[u].z, s1 += v[u].y + v[u].w;
         }
-        return a;
+        return s0 + s1;
     };
 
     // prefetch registers: X / Y operands of the next phase (+ grid features, coordinates, small gradients)
