@@ -185,13 +185,14 @@ __global__ __launch_bounds__(HG_BLOCK) void hashgrid_fwd_kernel(const float* __r
 // dL/dparams is a scatter of 16 floats per (sample, level).  Global fp32 atomics top out at ~18 G atomics/s on
 // MI355X whatever the access pattern (measured: 4.0 ms for the 67 M atomics of a 4096x64 batch), so the scatter
 // target is moved ON CHIP: the 256 CUs own 40 MiB of LDS.
-//   * a level's table is cut into slices of <= 10240 entries (160 KiB of fp64 pairs) -- one "bin" per slice;
+//   * a level that fits 10240 entries (160 KiB of fp64 pairs) is one slice, a larger one is cut into 8192-entry
+//     slices (power of two: slice = index >> 13) -- one "bin" per slice;
 //   * ROUTE: every (sample, level) is sent to the bins its 8 corners fall into (a record is the sample index,
 //     duplicates inside a bin are merged, so a bin holds at most M records and gets a fixed M-record region of
 //     scratch: one pass, no counting pre-pass), so that no workgroup ever looks at a sample that does not touch
 //     its slice.  (The first version let every slice owner scan ALL samples of its level:
 //     52 x redundant index arithmetic on the hashed levels, 640 us.)
-//   * ACCUMULATE: one workgroup per (bin, part of <= 32768 records) re-derives the corners of its samples and
+//   * ACCUMULATE: one workgroup per (bin, part of <= 24576 records) re-derives the corners of its samples and
 //     adds the contributions that fall into its slice with LDS atomics in fp64.  ds_add_f64 runs at ~0.33 cycles
 //     per lane-op per CU on gfx950, ds_add_f32 at 3.0 (serialised lane by lane; tools/micro/lds_atomic.hip), and
 //     fp64 sums make the result independent of the arrival order to fp32 precision;
@@ -199,8 +200,12 @@ __global__ __launch_bounds__(HG_BLOCK) void hashgrid_fwd_kernel(const float* __r
 //     partial slices and a reduce kernel.  No global float atomics, no inter-workgroup communication.
 constexpr int SC_BLOCK = 1024;
 constexpr uint32_t SC_MAX_SLICE = 10240;            // entries: 10240 * 2 doubles = 163840 B = all of a CU's LDS
+#ifndef MIPSF_SC_SLICE_LOG2
+#define MIPSF_SC_SLICE_LOG2 13
+#endif
+constexpr uint32_t SC_SLICE_LOG2 = MIPSF_SC_SLICE_LOG2;   // slices of multi-slice levels: 8192 entries
 #ifndef MIPSF_SC_PART
-#define MIPSF_SC_PART 32768
+#define MIPSF_SC_PART 24576
 #endif
 #ifndef MIPSF_SC_RUN
 #define MIPSF_SC_RUN 3
@@ -218,6 +223,7 @@ struct ScatterPlan {
     // odd levels silently read element [level-1].
     uint32_t n_slices[MIPSF_MAX_LEVELS];
     uint32_t slice_entries[MIPSF_MAX_LEVELS];
+    uint32_t slice_shift[MIPSF_MAX_LEVELS];       // slice of table index i = i >> slice_shift (31: one slice)
     uint32_t bin0[MIPSF_MAX_LEVELS + 1];          // first bin of each level
     uint32_t n_bins;
     uint32_t max_items;                           // upper bound on accumulate work items for this M
@@ -232,9 +238,13 @@ static ScatterPlan make_plan(const GridLevels& g, uint32_t M) {
     uint32_t bins = 0;
     for (uint32_t l = 0; l < g.n_levels; ++l) {
         const uint32_t size = g.offsets[l + 1] - g.offsets[l];
-        const uint32_t ns = (size + SC_MAX_SLICE - 1) / SC_MAX_SLICE;
+        // a level that does not fit one slice is cut into power-of-two slices: the routing kernel finds the slice of
+        // a corner with one shift instead of a float division + two fix-ups per corner (8 corners x 4.2 M records)
+        const bool one = size <= SC_MAX_SLICE;
+        const uint32_t ns = one ? 1u : (size + (1u << SC_SLICE_LOG2) - 1) >> SC_SLICE_LOG2;
         p.n_slices[l] = ns;
-        p.slice_entries[l] = (size + ns - 1) / ns;
+        p.slice_entries[l] = one ? size : (1u << SC_SLICE_LOG2);
+        p.slice_shift[l] = one ? 31u : SC_SLICE_LOG2;
         p.bin0[l] = bins;
         bins += ns;
     }
@@ -263,17 +273,14 @@ __global__ void scatter_zero_kernel(uint32_t* __restrict__ ws, uint32_t n) {
 
 // slice of every corner of one (sample, level); lead = bit c set when corner c is the first one in its slice
 __device__ __forceinline__ uint32_t corner_slices(int mode, const float* __restrict__ x, uint32_t i, float scale,
-                                                  uint32_t res, uint32_t size, uint32_t se, float inv_se,
-                                                  uint32_t sl[8]) {
+                                                  uint32_t res, uint32_t size, uint32_t shift, uint32_t sl[8]) {
     const Cell cell = locate(x, i, scale);
     uint32_t idx[8];
     corner_indices(mode, cell, res, size, idx);
     uint32_t lead = 0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        uint32_t q = (uint32_t)((float)idx[c] * inv_se);          // idx < 2^24: within one of the true quotient
-        if (q * se > idx[c]) --q;
-        if ((q + 1u) * se <= idx[c]) ++q;
+        const uint32_t q = idx[c] >> shift;          // power-of-two slices (shift 31 = the level is one slice)
         sl[c] = q;
         bool first = true;
 #pragma unroll
@@ -316,8 +323,8 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __
     const uint32_t size = g.offsets[level + 1] - g.offsets[level];
     const uint32_t res = g.res[level];
     const float scale = g.scale[level];
-    const uint32_t ns = plan.n_slices[level], se = plan.slice_entries[level], bin0 = plan.bin0[level];
-    const float inv_se = 1.0f / (float)se;
+    const uint32_t ns = plan.n_slices[level], bin0 = plan.bin0[level];
+    const uint32_t shift = plan.slice_shift[level];
     const int mode = level_mode(res, size);
 #ifndef MIPSF_SC_AGG_MAX
 #define MIPSF_SC_AGG_MAX 1   // measured on the mapping workload: 65 us (<= 1 bin), 67 (<= 2), 88 (<= 8)
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __
     for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u) {
         const uint32_t i = s0 + u * SC_BLOCK + threadIdx.x;
         lead[u] = 0;
-        if (i < M) lead[u] = corner_slices(mode, x, i, scale, res, size, se, inv_se, sl[u]);
+        if (i < M) lead[u] = corner_slices(mode, x, i, scale, res, size, shift, sl[u]);
 #pragma unroll
         for (int c = 0; c < 8; ++c) rank[u][c] = ranked_add(cnt, sl[u][c], (lead[u] >> c & 1u) != 0u, aggregate);
     }
