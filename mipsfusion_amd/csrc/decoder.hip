@@ -36,6 +36,7 @@ constexpr int TAIL_F4 = (PACKED_FLOATS - OFF_TRGB) / 4;  // rgb / sdf2 head tabl
 #endif
 
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -93,23 +94,6 @@ __device__ __forceinline__ void load_bias(const float* tail, int layer, int h, f
         for (int r = 0; r < 16; ++r) acc[rt][r] = tail[(OFF_BIAS - OFF_TRGB) + ((layer * 64 + rt * 16 + r) << 1) + h];
 }
 
-__device__ __forceinline__ void store_act(float* __restrict__ dst, int64_t tile, int mat, int lane,
-                                          const f32x16 (&acc)[4]) {
-    float4* d4 = reinterpret_cast<float4*>(dst);
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            d4[(tile * (ACT_SLOTS / 4) + mat * 16 + rt * 4 + g) * 64 + lane] =
-                make_float4(acc[rt][4 * g], acc[rt][4 * g + 1], acc[rt][4 * g + 2], acc[rt][4 * g + 3]);
-}
-
-// 16-byte activation store (non-temporal stores were tried: no change)
-typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store16(float4* p, const float4& v) {
-    *p = v;
-}
-
 // Buffer addressing: one 128-bit resource (scalar) + a 32-bit lane offset (vector, computed once) + a scalar /
 // immediate offset per access.  A flat `ptr[const + lane]` costs one or two 64-bit vector adds per access as soon as
 // the constant leaves the 4 KB immediate range -- 350 vector instructions per tile in the backward chain, and vector
@@ -128,6 +112,39 @@ __device__ __forceinline__ void buf_store16(srd_t r, uint32_t lane16, uint32_t o
     u.x = __float_as_uint(v.x), u.y = __float_as_uint(v.y), u.z = __float_as_uint(v.z), u.w = __float_as_uint(v.w);
     __builtin_amdgcn_raw_buffer_store_b128(u, r, lane16, off_u, 0);
 }
+
+// the same two stores against the tile's own buffer resource (forward kernels: no vector address arithmetic)
+__device__ __forceinline__ void buf_store_act(srd_t sv, uint32_t lane16, int mat, const f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            buf_store16(sv, lane16, (mat * 16 + rt * 4 + g) * 1024,
+                        make_float4(acc[rt][4 * g], acc[rt][4 * g + 1], acc[rt][4 * g + 2], acc[rt][4 * g + 3]));
+}
+__device__ __forceinline__ void buf_store_act_piece(srd_t sv, uint32_t lane16, int mat, const f32x16 (&acc)[4], int q) {
+    const int rt = q >> 2, g = q & 3;
+    buf_store16(sv, lane16, (mat * 16 + q) * 1024,
+                make_float4(acc[rt][4 * g], acc[rt][4 * g + 1], acc[rt][4 * g + 2], acc[rt][4 * g + 3]));
+}
+
+__device__ __forceinline__ void store_act(float* __restrict__ dst, int64_t tile, int mat, int lane,
+                                          const f32x16 (&acc)[4]) {
+    float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            d4[(tile * (ACT_SLOTS / 4) + mat * 16 + rt * 4 + g) * 64 + lane] =
+                make_float4(acc[rt][4 * g], acc[rt][4 * g + 1], acc[rt][4 * g + 2], acc[rt][4 * g + 3]);
+}
+
+// 16-byte activation store (non-temporal stores were tried: no change)
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16(float4* p, const float4& v) {
+    *p = v;
+}
+
 
 // group q in [0,16): row tile q>>2, registers 4*(q&3) .. +3
 __device__ __forceinline__ void store_act_piece(float* __restrict__ dst, int64_t tile, int mat, int lane,
@@ -213,6 +230,10 @@ __device__ __forceinline__ void decoder_fwd_tile(const float* tail, const float4
     const uint32_t s_raw = (uint32_t)(tile * 32 + j);
     const bool live = s_raw < M;
     const uint32_t s = live ? s_raw : M - 1;   // tail lanes recompute the last sample (finite values, no stores)
+    // `tile` is wave-uniform (the callers pass it through readfirstlane): the saved-activation tile gets its own
+    // buffer resource, its 48 stores need no vector address arithmetic
+    const uint32_t lane16 = 16u * (uint32_t)lane;
+    const srd_t sv = make_srd(SAVE ? saved + (size_t)tile * ACT_TILE_FLOATS : saved, SAVE ? ACT_TILE_FLOATS * 4 : 0);
 
     float ev[E_SLOTS];
     load_e<PE_INTERNAL>(x, embed_pos, s, h, ev);
@@ -232,23 +253,30 @@ __device__ __forceinline__ void decoder_fwd_tile(const float* tail, const float4
     load_bias(tail, 1, h, H2);
     mfma_layer<RT_F2, T_F2>(img2, lane, H2,
                             [&](int t) { return H1[t >> 4][t & 15]; },
-                            [&](int t4) { if (SAVE && pin == 0) store_act_piece(saved, tile, 0, lane, H1, t4); });
+                            [&](int t4) { if (SAVE && pin == 0) buf_store_act_piece(sv, lane16, 0, H1, t4); });
 
     // ---- rgb_linear.0 on the vector ALU (3 outputs): this lane's half of every dot product, then one swap
-    float pr[3] = {0.f, 0.f, 0.f};
+    // (two of the three / four of the five running sums advance with one packed v_pk_fma_f32 each: same fmaf per
+    //  component, a third fewer vector instructions in the two heads)
+    float pr[3];
     {
         const float4* trgb = reinterpret_cast<const float4*>(tail) + h * TRGB_SLOTS;
+        f32x2 p01 = {0.f, 0.f};
+        float p2 = 0.f;
 #pragma unroll
         for (int slot = 0; slot < 32; ++slot) {
             const float4 wv = trgb[slot];
             const float v = H2[2 + (slot >> 4)][slot & 15];
-            pr[0] = fmaf(wv.x, v, pr[0]), pr[1] = fmaf(wv.y, v, pr[1]), pr[2] = fmaf(wv.z, v, pr[2]);
+            p01 = __builtin_elementwise_fma(f32x2{wv.x, wv.y}, f32x2{v, v}, p01);
+            p2 = fmaf(wv.z, v, p2);
         }
 #pragma unroll
         for (int t = 0; t < E_SLOTS; ++t) {
             const float4 wv = trgb[32 + t];
-            pr[0] = fmaf(wv.x, ev[t], pr[0]), pr[1] = fmaf(wv.y, ev[t], pr[1]), pr[2] = fmaf(wv.z, ev[t], pr[2]);
+            p01 = __builtin_elementwise_fma(f32x2{wv.x, wv.y}, f32x2{ev[t], ev[t]}, p01);
+            p2 = fmaf(wv.z, ev[t], p2);
         }
+        pr[0] = p01.x, pr[1] = p01.y, pr[2] = p2;
     }
     float rgb[3];
 #pragma unroll
@@ -256,35 +284,47 @@ __device__ __forceinline__ void decoder_fwd_tile(const float* tail, const float4
 
     // ---- layer 3: sdf_linear.0 + ReLU on [sdf_emb (regs of H2 tiles 0,1) | grid features (loaded)]
     float gf[16];
+    if (LAYOUT == MIPSF_FEAT_LEVEL_MAJOR && M < (1u << 24)) {       // 16 levels x M x 8 B within one 4 GB resource
+        const srd_t fs = make_srd(feat, M * 128u);
+        const uint32_t voff = (2u * s + (uint32_t)h) * 4u;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) gf[u] = load_feat<LAYOUT>(feat, s, u, h, M);
+        for (int u = 0; u < 16; ++u)
+            gf[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(fs, voff, (uint32_t)u * M * 8u, 0));
+    } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) gf[u] = load_feat<LAYOUT>(feat, s, u, h, M);
+    }
     f32x16 H3[4];
     load_bias(tail, 2, h, H3);
     mfma_layer<RT_F3, T_F3>(img3, lane, H3,
                             [&](int t) { return t < 32 ? H2[t >> 4][t & 15] : gf[t - 32]; },
                             [&](int t4) {                       // 16 groups of H2 over 12 k-groups
                                 if (SAVE && pin == 0) {
-                                    store_act_piece(saved, tile, 1, lane, H2, t4);
-                                    if (t4 < 4) store_act_piece(saved, tile, 1, lane, H2, 12 + t4);
+                                    buf_store_act_piece(sv, lane16, 1, H2, t4);
+                                    if (t4 < 4) buf_store_act_piece(sv, lane16, 1, H2, 12 + t4);
                                 }
                             });
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) H3[rt][r] = fmaxf(H3[rt][r], 0.0f);
-    if (SAVE) store_act(saved, tile, 2, lane, H3);
+    if (SAVE) buf_store_act(sv, lane16, 2, H3);
 
     // ---- sdf_linear.2 (5 logits) on the vector ALU, softmax, entropy, expected class -> SDF
-    float pl[N_CLASS] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float pl[N_CLASS];
     {
         const float4* ts2 = reinterpret_cast<const float4*>(tail) + (OFF_TS2 - OFF_TRGB) / 4 + h * 128;
+        f32x2 q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
+        float q4 = 0.f;
 #pragma unroll
         for (int slot = 0; slot < 64; ++slot) {
             const float4 w0 = ts2[2 * slot], w1 = ts2[2 * slot + 1];
             const float v = H3[slot >> 4][slot & 15];
-            pl[0] = fmaf(w0.x, v, pl[0]), pl[1] = fmaf(w0.y, v, pl[1]), pl[2] = fmaf(w0.z, v, pl[2]);
-            pl[3] = fmaf(w0.w, v, pl[3]), pl[4] = fmaf(w1.x, v, pl[4]);
+            q01 = __builtin_elementwise_fma(f32x2{w0.x, w0.y}, f32x2{v, v}, q01);
+            q23 = __builtin_elementwise_fma(f32x2{w0.z, w0.w}, f32x2{v, v}, q23);
+            q4 = fmaf(w1.x, v, q4);
         }
+        pl[0] = q01.x, pl[1] = q01.y, pl[2] = q23.x, pl[3] = q23.y, pl[4] = q4;
     }
     float lg[N_CLASS], mx = -3.0e38f;
 #pragma unroll
@@ -328,7 +368,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_fwd_kernel(const float* 
     for (int q = threadIdx.x; q < TAIL_F4; q += DEC_BLOCK) tailbuf[q] = reinterpret_cast<const float4*>(packed + OFF_TRGB)[q];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (tile * 32 >= (int64_t)M) return;
     decoder_fwd_tile<PE_INTERNAL, LAYOUT, SAVE>(reinterpret_cast<const float*>(tailbuf), reinterpret_cast<const float4*>(packed + OFF_F1),
                                                 reinterpret_cast<const float4*>(packed + OFF_F2),
@@ -360,7 +400,7 @@ __global__ __launch_bounds__(FWD_LDS_BLOCK, 1) void decoder_fwd_lds_kernel(const
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    for (uint32_t tile = blockIdx.x * (FWD_LDS_BLOCK / 64) + (threadIdx.x >> 6); tile < n_tiles;
+    for (uint32_t tile = blockIdx.x * (FWD_LDS_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); tile < n_tiles;
          tile += gridDim.x * (FWD_LDS_BLOCK / 64)) {
         // the images are loop invariant: an opaque zero keeps the compiler from hoisting ~550 LDS reads out of the loop
         // (same for the small per-lane tables read from `packed`)
