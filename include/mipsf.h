@@ -201,7 +201,10 @@ int mipsf_normalise_bwd(const float* dxn, const mipsf_render_cfg* cfg_host, floa
 int mipsf_pose_rays_fwd(const float* fixed_poses, const float* rot, const float* trans, uint32_t F, uint32_t K,
                         const int64_t* owner, const float* d_cam, float* rays_o, float* rays_d, uint32_t N,
                         void* stream);
-/* d_rot [K,4], d_trans [K,3] are WRITTEN; scratch: 12*(F+K) floats. */
+/* d_rot [K,4], d_trans [K,3] are WRITTEN.  scratch: mipsf_pose_rays_scratch_floats(F, K, N) floats whose FIRST word
+ * must be zero on entry (clear it once after allocating) and is zero again on return -- it is the ticket that lets
+ * the last workgroup finish the reduction and the quaternion chain in the same launch; the rest needs no init. */
+uint64_t mipsf_pose_rays_scratch_floats(uint32_t F, uint32_t K, uint32_t N);
 int mipsf_pose_rays_bwd(const float* g_rays_o, const float* g_rays_d, const float* rot, uint32_t F, uint32_t K,
                         const int64_t* owner, const float* d_cam, float* d_rot, float* d_trans, float* scratch,
                         uint32_t N, void* stream);

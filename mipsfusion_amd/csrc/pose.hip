@@ -64,13 +64,45 @@ __global__ __launch_bounds__(PR_BLOCK) void pose_rays_fwd_kernel(const float* __
     }
 }
 
-// acc[(F+K)*12]: per pose {dR (9, row-major), dt (3)}; zeroed by the launcher
+// chain through R(q) = I + s A(q), s = 2/|q|^2 (pytorch3d quaternion_to_matrix, not assuming unit norm);
+// G = {dR (9, row-major), dt (3)} of optimisable pose k
+__device__ __forceinline__ void pose_chain(const float* __restrict__ rot, const float* G, int k,
+                                           float* __restrict__ d_rot, float* __restrict__ d_trans) {
+    const float w = rot[4 * k], x = rot[4 * k + 1], y = rot[4 * k + 2], z = rot[4 * k + 3];
+    const float n = w * w + x * x + y * y + z * z;
+    const float s = 2.0f / n;
+    const float A[9] = {-(y * y + z * z), x * y - z * w, x * z + y * w, x * y + z * w, -(x * x + z * z),
+                        y * z - x * w,    x * z - y * w, y * z + x * w, -(x * x + y * y)};
+    float GA = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) GA += G[i] * A[i];
+    const float dAw = (-z * G[1] + y * G[2]) + (z * G[3] - x * G[5]) + (-y * G[6] + x * G[7]);
+    const float dAx = (y * G[1] + z * G[2]) + (y * G[3] - 2 * x * G[4] - w * G[5]) + (z * G[6] + w * G[7] - 2 * x * G[8]);
+    const float dAy = (-2 * y * G[0] + x * G[1] + w * G[2]) + (x * G[3] + z * G[5]) + (-w * G[6] + z * G[7] - 2 * y * G[8]);
+    const float dAz = (-2 * z * G[0] - w * G[1] + x * G[2]) + (w * G[3] - 2 * z * G[4] + y * G[5]) + (x * G[6] + y * G[7]);
+    const float c = s * GA * 2.0f / n;
+    d_rot[4 * k] = s * dAw - c * w;
+    d_rot[4 * k + 1] = s * dAx - c * x;
+    d_rot[4 * k + 2] = s * dAy - c * y;
+    d_rot[4 * k + 3] = s * dAz - c * z;
+    d_trans[3 * k] = G[9], d_trans[3 * k + 1] = G[10], d_trans[3 * k + 2] = G[11];
+}
+
+// ONE launch (it used to be zero-fill + accumulate-with-atomics + chain = three, ~5 us each in a captured iteration):
+// every workgroup writes its per-pose partial {dR, dt} to its own row of `part`, the LAST one to finish (ticket
+// counter) sums the rows in workgroup order -- no float atomics on global memory --, runs the
+// quaternion chain and puts the ticket back to zero for the next call.
 __global__ __launch_bounds__(PR_BLOCK) void pose_rays_bwd_kernel(const float* __restrict__ g_o,
                                                                  const float* __restrict__ g_d,
                                                                  const float* __restrict__ d_cam,
-                                                                 const int64_t* __restrict__ owner, int P,
-                                                                 float* __restrict__ acc, uint32_t N) {
+                                                                 const int64_t* __restrict__ owner,
+                                                                 const float* __restrict__ rot, int F, int K,
+                                                                 float* __restrict__ part, uint32_t* __restrict__ ticket,
+                                                                 float* __restrict__ d_rot, float* __restrict__ d_trans,
+                                                                 uint32_t N) {
     __shared__ float sacc[PR_MAX_POSES * 12];
+    __shared__ bool is_last;
+    const int P = F + K;
     for (int q = threadIdx.x; q < P * 12; q += PR_BLOCK) sacc[q] = 0.f;
     __syncthreads();
     const uint32_t n = blockIdx.x * PR_BLOCK + threadIdx.x;
@@ -101,41 +133,28 @@ __global__ __launch_bounds__(PR_BLOCK) void pose_rays_bwd_kernel(const float* __
         for (int q = 0; q < 12; ++q) atomicAdd(&sacc[(int)p * 12 + q], v[q]);
     }
     __syncthreads();
+    for (int q = threadIdx.x; q < P * 12; q += PR_BLOCK)
+        __hip_atomic_store(&part[(size_t)blockIdx.x * (P * 12) + q], sacc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
     for (int q = threadIdx.x; q < P * 12; q += PR_BLOCK) {
-        const float s = sacc[q];
-        if (s != 0.f) unsafeAtomicAdd(&acc[q], s);
+        float s = 0.f;
+        for (uint32_t b = 0; b < gridDim.x; ++b)
+            s += __hip_atomic_load(&part[(size_t)b * (P * 12) + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sacc[q] = s;
     }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += PR_BLOCK) pose_chain(rot, sacc + 12 * (F + k), k, d_rot, d_trans);
+    if (threadIdx.x == 0) *ticket = 0u;
 }
 
 __global__ void pose_zero_kernel(float* __restrict__ p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.f;
-}
-
-// chain through R(q) = I + s A(q), s = 2/|q|^2 (pytorch3d quaternion_to_matrix, not assuming unit norm)
-__global__ void pose_chain_kernel(const float* __restrict__ rot, const float* __restrict__ acc, int F, int K,
-                                  float* __restrict__ d_rot, float* __restrict__ d_trans) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
-    const float* G = acc + 12 * (F + k);
-    const float w = rot[4 * k], x = rot[4 * k + 1], y = rot[4 * k + 2], z = rot[4 * k + 3];
-    const float n = w * w + x * x + y * y + z * z;
-    const float s = 2.0f / n;
-    const float A[9] = {-(y * y + z * z), x * y - z * w, x * z + y * w, x * y + z * w, -(x * x + z * z),
-                        y * z - x * w,    x * z - y * w, y * z + x * w, -(x * x + y * y)};
-    float GA = 0.f;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) GA += G[i] * A[i];
-    const float dAw = (-z * G[1] + y * G[2]) + (z * G[3] - x * G[5]) + (-y * G[6] + x * G[7]);
-    const float dAx = (y * G[1] + z * G[2]) + (y * G[3] - 2 * x * G[4] - w * G[5]) + (z * G[6] + w * G[7] - 2 * x * G[8]);
-    const float dAy = (-2 * y * G[0] + x * G[1] + w * G[2]) + (x * G[3] + z * G[5]) + (-w * G[6] + z * G[7] - 2 * y * G[8]);
-    const float dAz = (-2 * z * G[0] - w * G[1] + x * G[2]) + (w * G[3] - 2 * z * G[4] + y * G[5]) + (x * G[6] + y * G[7]);
-    const float c = s * GA * 2.0f / n;
-    d_rot[4 * k] = s * dAw - c * w;
-    d_rot[4 * k + 1] = s * dAx - c * x;
-    d_rot[4 * k + 2] = s * dAy - c * y;
-    d_rot[4 * k + 3] = s * dAz - c * z;
-    d_trans[3 * k] = G[9], d_trans[3 * k + 1] = G[10], d_trans[3 * k + 2] = G[11];
 }
 
 }  // namespace mipsf
@@ -156,6 +175,10 @@ int mipsf_pose_rays_fwd(const float* fixed_poses, const float* rot, const float*
     return check_launch("pose_rays_fwd");
 }
 
+uint64_t mipsf_pose_rays_scratch_floats(uint32_t F, uint32_t K, uint32_t N) {
+    return 1ull + 12ull * (F + K) * ((N + PR_BLOCK - 1) / PR_BLOCK);
+}
+
 int mipsf_pose_rays_bwd(const float* g_rays_o, const float* g_rays_d, const float* rot, uint32_t F, uint32_t K,
                         const int64_t* owner, const float* d_cam, float* d_rot, float* d_trans, float* scratch,
                         uint32_t N, void* stream) {
@@ -163,18 +186,16 @@ int mipsf_pose_rays_bwd(const float* g_rays_o, const float* g_rays_d, const floa
     MIPSF_REQUIRE(rot && owner && d_cam && d_rot && d_trans && scratch, "null pointer");
     MIPSF_REQUIRE(F + K <= PR_MAX_POSES, "number of poses %u above %d", F + K, PR_MAX_POSES);
     hipStream_t s = (hipStream_t)stream;
-    const int P = (int)(F + K);
-    // (a kernel, not hipMemsetAsync: memset nodes recorded from the autograd thread crash hipStreamEndCapture on ROCm 7.2)
-    hipLaunchKernelGGL(pose_zero_kernel, dim3((12 * P + 255) / 256), dim3(256), 0, s, scratch, 12 * P);
-    if (int e = check_launch("pose_zero")) return e;
-    if (N > 0) {
-        hipLaunchKernelGGL(pose_rays_bwd_kernel, dim3((N + PR_BLOCK - 1) / PR_BLOCK), dim3(PR_BLOCK), 0, s, g_rays_o,
-                           g_rays_d, d_cam, owner, P, scratch, N);
-        if (int e = check_launch("pose_rays_bwd")) return e;
+    if (N == 0) {       // no rays: zero gradients
+        hipLaunchKernelGGL(pose_zero_kernel, dim3(1), dim3(256), 0, s, d_rot, (int)(4 * K));
+        hipLaunchKernelGGL(pose_zero_kernel, dim3(1), dim3(256), 0, s, d_trans, (int)(3 * K));
+        return check_launch("pose_zero");
     }
-    hipLaunchKernelGGL(pose_chain_kernel, dim3((K + 63) / 64), dim3(64), 0, s, rot, scratch, (int)F, (int)K, d_rot,
-                       d_trans);
-    return check_launch("pose_chain");
+    // scratch[0] = ticket (zero on entry, zero again on return), then one row of partials per workgroup
+    hipLaunchKernelGGL(pose_rays_bwd_kernel, dim3((N + PR_BLOCK - 1) / PR_BLOCK), dim3(PR_BLOCK), 0, s, g_rays_o,
+                       g_rays_d, d_cam, owner, rot, (int)F, (int)K, scratch + 1, reinterpret_cast<uint32_t*>(scratch),
+                       d_rot, d_trans, N);
+    return check_launch("pose_rays_bwd");
 }
 
 }  // extern "C"

@@ -311,6 +311,21 @@ def rays_bwd(dxn, z_vals, rc, N, S):
 
 
 # ------------------------------------------------------------------------- rays from poses
+_POSE_SCRATCH = {}
+
+
+def _pose_scratch(device, F, K, N):
+    """Scratch of mipsf_pose_rays_bwd: its first word is a ticket that must be zero on entry and is left zero by the
+    kernel, so one zero-initialised buffer per (device, stream, size) is kept and reused (calls on one stream are
+    ordered; no per-call memset launch)."""
+    n = int(lib().mipsf_pose_rays_scratch_floats(F, K, N))
+    key = (device.index, stream_ptr(), n)
+    buf = _POSE_SCRATCH.get(key)
+    if buf is None:
+        buf = _POSE_SCRATCH[key] = torch.zeros(n, dtype=torch.float32, device=device)
+    return buf
+
+
 class PoseRaysFn(torch.autograd.Function):
     """(rot [K,4], trans [K,3]) -> rays_o, rays_d [N,3]; fused replacement of
     ``qt_to_transform_matrix`` + ``poses_all[owner]`` gather + ``sum(d_cam * R, -1)`` (mipsfusion.py:320-322)."""
@@ -337,7 +352,7 @@ class PoseRaysFn(torch.autograd.Function):
         rot, owner, d_cam = ctx.saved_tensors
         d_rot = torch.empty((ctx.K, 4), dtype=torch.float32, device=rot.device)
         d_trans = torch.empty((ctx.K, 3), dtype=torch.float32, device=rot.device)
-        scratch = torch.empty(12 * (ctx.F + ctx.K), dtype=torch.float32, device=rot.device)
+        scratch = _pose_scratch(rot.device, ctx.F, ctx.K, ctx.N)
         g_o = _f32c(g_o) if g_o is not None else None
         g_d = _f32c(g_d) if g_d is not None else None
         with _timed("pose_rays_bwd"):

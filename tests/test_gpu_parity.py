@@ -542,6 +542,18 @@ def test_pose_rays_matches_torch_composition(dev):
     assert_close(rd, rd_ref, 1e-6, "rays_d")
     assert_close(rot_a.grad, rot_b.grad, 2e-5, "d quaternion")
     assert_close(trans_a.grad, trans_b.grad, 2e-5, "d translation")
+    # the backward is ONE launch whose scratch carries a ticket it must leave at zero: repeated calls (same and other
+    # sizes, several workgroups) have to keep giving the same gradients
+    for _ in range(3):
+        rot_r, trans_r = rot0.clone().requires_grad_(True), trans0.clone().requires_grad_(True)
+        ro2, rd2 = ops.pose_rays(rot_r, trans_r, fixed, owner, d_cam)
+        (ro2 * go).sum().add((rd2 * gd).sum()).backward()
+        assert_close(rot_r.grad, rot_b.grad, 2e-5, "d quaternion, repeated call")
+        assert_close(trans_r.grad, trans_b.grad, 2e-5, "d translation, repeated call")
+        rot_s, trans_s = rot0.clone().requires_grad_(True), trans0.clone().requires_grad_(True)
+        ro4, rd4 = ops.pose_rays(rot_s, trans_s, fixed, owner[:70], d_cam[:70])
+        (ro4 * go[:70]).sum().add((rd4 * gd[:70]).sum()).backward()
+        assert torch.isfinite(rot_s.grad).all()
     # and the chain alone against the reference's own autograd (golden)
     rot_c, trans_c = T(g["rot"]).to(dev).requires_grad_(True), T(g["trans"]).to(dev).requires_grad_(True)
     eye = torch.eye(3, device=dev)
