@@ -37,6 +37,29 @@ constexpr int TAIL_F4 = (PACKED_FLOATS - OFF_TRGB) / 4;  // rgb / sdf2 head tabl
 
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ReLU masks for the backward chain.  The chain needs only the SIGN of H1 and H3, but used to read both tiles back
+// (2 x 16 KB per 32 samples = 268 MB per launch, ~28 us of its 215).  The forward now appends two 64-bit words per
+// lane and layer to `saved` (8 MB): bit 31-k of word w is "H > 0" for accumulator element (row tile 2w + (k >> 4),
+// register k & 15).  Building a bit = v_cmp + v_addc (m = 2m + carry), using it = v_bfe_i32 + v_and.
+constexpr int MASK_TILE_WORDS = 256;                 // [layer H1, H3][lane][2 words]
+__device__ __forceinline__ uint32_t mask_push(uint32_t m, float h) {
+    asm("v_cmp_lt_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(h) : "vcc");
+    return m;
+}
+__device__ __forceinline__ void relu_masks(const f32x16 (&H)[4], uint32_t (&m)[2]) {
+    m[0] = 0u, m[1] = 0u;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m[rt >> 1] = mask_push(m[rt >> 1], H[rt][r]);
+}
+// g where element (rt, r) was active in the forward, 0 elsewhere
+__device__ __forceinline__ float mask_apply(const uint32_t (&m)[2], int rt, int r, float g) {
+    const int k = (rt & 1) * 16 + r;
+    return __uint_as_float(__float_as_uint(g) & (uint32_t)__builtin_amdgcn_sbfe((int)m[rt >> 1], 31 - k, 1));
+}
+
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -248,6 +271,9 @@ __device__ __forceinline__ void decoder_fwd_tile(const float* tail, const float4
 #pragma unroll
         for (int r = 0; r < 16; ++r) H1[rt][r] = fmaxf(H1[rt][r], 0.0f);
 
+    uint32_t m1[2] = {0u, 0u};
+    if (SAVE) relu_masks(H1, m1);
+
     // ---- layer 2: pts_linear.2 -> [sdf_emb | rgb_emb]   (H1 is written out one 16-byte group per k-group)
     f32x16 H2[4];
     load_bias(tail, 1, h, H2);
@@ -308,7 +334,15 @@ __device__ __forceinline__ void decoder_fwd_tile(const float* tail, const float4
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) H3[rt][r] = fmaxf(H3[rt][r], 0.0f);
-    if (SAVE) buf_store_act(sv, lane16, 2, H3);
+    if (SAVE) {
+        buf_store_act(sv, lane16, 2, H3);
+        uint32_t m3[2];
+        relu_masks(H3, m3);
+        uint2* mk = reinterpret_cast<uint2*>(saved + (((size_t)M + 127) / 128) * 4 * ACT_TILE_FLOATS) +
+                    (size_t)tile * (MASK_TILE_WORDS / 2) + lane;
+        mk[0] = make_uint2(m1[0], m1[1]);
+        mk[64] = make_uint2(m3[0], m3[1]);
+    }
 
     // ---- sdf_linear.2 (5 logits) on the vector ALU, softmax, entropy, expected class -> SDF
     float pl[N_CLASS];
@@ -504,13 +538,10 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
     const uint32_t s = live ? s_raw : M - 1;
     const uint32_t lane16 = 16u * (uint32_t)lane;
     const srd_t wsrd = make_srd(packed, PACKED_FLOATS * 4);
-    const srd_t sv = make_srd(saved + (size_t)tile * ACT_TILE_FLOATS, ACT_TILE_FLOATS * 4);     // this tile's saved activations
     const srd_t da = make_srd(dact + (size_t)tile * ACT_TILE_FLOATS, ACT_TILE_FLOATS * 4);      // ... and gradients
 
-    // The whole H3 tile (relu mask of the first gradient) and the two 40-byte rows of out / dout are requested
-    // before anything is computed: this wave has no earlier tile whose matrix work could cover them, and left to the
-    // compiler the sixteen H3 pieces were fetched two at a time in front of their uses -- eight exposed round trips
-    // per tile (ablation: 28 us of the kernel's 221).
+    // The two 40-byte rows of out / dout, the ReLU mask words and the first weight group are requested before anything
+    // is computed: this wave has no earlier tile whose matrix work could cover them.
     float2 o2[5], g2[5];
     {
         const float2* o = reinterpret_cast<const float2*>(out + (size_t)s * 10);
@@ -519,9 +550,11 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
         for (int c = 0; c < 5; ++c) o2[c] = o[c], g2[c] = g[c];
     }
     __builtin_amdgcn_sched_barrier(0);      // vmcnt retires in order: the softmax below waits for these rows only
-    float4 hm3[16], a3[RT_B3];
-#pragma unroll
-    for (int p = 0; p < 16; ++p) hm3[p] = buf_load16(sv, lane16, (2 * 16 + p) * 1024);
+    float4 a3[RT_B3];
+    const uint2* mk = reinterpret_cast<const uint2*>(saved + (((size_t)M + 127) / 128) * 4 * ACT_TILE_FLOATS) +
+                      (size_t)tile * (MASK_TILE_WORDS / 2) + lane;
+    const uint2 mk1 = mk[0], mk3 = mk[64];
+    const uint32_t m1[2] = {mk1.x, mk1.y}, m3[2] = {mk3.x, mk3.y};
     preload_a<RT_B3, T_B3>(wsrd, OFF_B3 * 4, lane16, a3);
     __builtin_amdgcn_sched_barrier(0);
 
@@ -556,7 +589,6 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
         const float4* ts2 = tab + (OFF_TS2 - OFF_TRGB) / 4 + h * 128;
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
-            const float4 hm = hm3[p];
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -566,8 +598,8 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
                 t = fmaf(w0.y, dlg[1], t), t = fmaf(w0.z, dlg[2], t), t = fmaf(w0.w, dlg[3], t), t = fmaf(w1.x, dlg[4], t);
                 v[i] = t;
             }
-            xb[p * 64] = make_float4(hm.x > 0.0f ? v[0] : 0.0f, hm.y > 0.0f ? v[1] : 0.0f, hm.z > 0.0f ? v[2] : 0.0f,
-                                     hm.w > 0.0f ? v[3] : 0.0f);
+            xb[p * 64] = make_float4(mask_apply(m3, p >> 2, 4 * (p & 3) + 0, v[0]), mask_apply(m3, p >> 2, 4 * (p & 3) + 1, v[1]),
+                                     mask_apply(m3, p >> 2, 4 * (p & 3) + 2, v[2]), mask_apply(m3, p >> 2, 4 * (p & 3) + 3, v[3]));
         }
     }
 
@@ -612,20 +644,18 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
     float4 a1[RT_B1];
     {
         f32x16 dG1[4];
-        float4 H1p[16];
         zero_acc4(dG1);
         mfma_layer_b4<RT_B2, T_B2>(wsrd, OFF_B2 * 4, lane16, dG1, xb, a2,
                                    [&](int t4, const float4& b) {
-                                       H1p[t4] = buf_load16(sv, lane16, (0 * 16 + t4) * 1024);
                                        if (pin == 0) buf_store16(da, lane16, (1 * 16 + t4) * 1024, b);
                                    });
         preload_a<RT_B1, T_B1>(wsrd, OFF_B1 * 4, lane16, a1);
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             const int rt = p >> 2, g = p & 3;
-            xb[p * 64] = make_float4(H1p[p].x > 0.0f ? dG1[rt][4 * g] : 0.0f, H1p[p].y > 0.0f ? dG1[rt][4 * g + 1] : 0.0f,
-                                     H1p[p].z > 0.0f ? dG1[rt][4 * g + 2] : 0.0f,
-                                     H1p[p].w > 0.0f ? dG1[rt][4 * g + 3] : 0.0f);
+            xb[p * 64] = make_float4(mask_apply(m1, rt, 4 * g + 0, dG1[rt][4 * g]), mask_apply(m1, rt, 4 * g + 1, dG1[rt][4 * g + 1]),
+                                     mask_apply(m1, rt, 4 * g + 2, dG1[rt][4 * g + 2]),
+                                     mask_apply(m1, rt, 4 * g + 3, dG1[rt][4 * g + 3]));
         }
     }
 
@@ -1033,7 +1063,7 @@ extern "C" {
 
 uint32_t mipsf_decoder_packed_floats(void) { return (uint32_t)PACKED_FLOATS; }
 // saved / dact are addressed per 128-sample block tile by the weight-gradient kernel -> round up to 4 wave tiles
-uint64_t mipsf_decoder_saved_floats(uint32_t M) { return n_block_tiles(M) * 4 * ACT_TILE_FLOATS; }
+uint64_t mipsf_decoder_saved_floats(uint32_t M) { return n_block_tiles(M) * 4 * (ACT_TILE_FLOATS + MASK_TILE_WORDS); }
 uint64_t mipsf_decoder_dact_floats(uint32_t M) { return n_block_tiles(M) * 4 * ACT_TILE_FLOATS + n_block_tiles(M) * 128 * 8; }
 uint64_t mipsf_decoder_wgrad_partial_floats(void) { return (uint64_t)WG_MAX_BLOCKS * G_STRIDE; }
 
