@@ -123,6 +123,11 @@ int mipsf_decoder_pack_host(const mipsf_decoder_weights* w_host_ptrs, float* pac
  * saved: nullable; when given, activations for backward are stored (mipsf_decoder_saved_floats(M)). */
 int mipsf_decoder_fwd(const float* packed, const float* feat, int feat_layout, const float* x,
                       const float* embed_pos, int pe_mode, float* out, float* saved, uint32_t M, void* stream);
+/* SDF branch only: MLP_reg.get_raw_sdf as reached through JointEncoding.query_sdf (model/decoder.py:60-72,
+ * model/scene_rep.py:105-108; callers: RandomOptimizer.get_fitness RandomOptimizer.py:113-131, Mesher SDF grids).
+ * sdf: [M].  Bit-identical to column 3 of mipsf_decoder_fwd; layer 2 computes its sdf_emb half only, no rgb head. */
+int mipsf_decoder_fwd_sdf(const float* packed, const float* feat, int feat_layout, const float* x,
+                          const float* embed_pos, int pe_mode, float* sdf, uint32_t M, void* stream);
 /* Backward.  dout [M,10].  Outputs: dfeat (layout as feat), dx [M,3] (pe_mode 0: includes the PE chain),
  * dembed_pos [M,48] (pe_mode 1 only).  Weight gradients are ACCUMULATED into `grads`.
  * dact / partial: scratch of the sizes above. */
@@ -249,6 +254,9 @@ int mipsf_adam_step_multi_ex(const mipsf_adam_tensors* tensors_host_struct, floa
  * mean_masked[P] = mean_j(valid_j * |sdf*trunc|)  (RandomOptimizer.py:125-129) */
 int mipsf_ro_fitness(const float* raw, uint32_t raw_stride, const float* target_d, float trunc,
                      float* mean_masked, uint32_t P, uint32_t n, void* stream);
+/* the same on the [P,n] output of mipsf_decoder_fwd_sdf */
+int mipsf_ro_fitness_sdf(const float* sdf, const float* target_d, float trunc, float* mean_masked, uint32_t P,
+                         uint32_t n, void* stream);
 
 /* -------------------------------------- RandomOptimizer particle step */
 /* The search state lives on the device so that a tracking round needs no host round trip (the reference

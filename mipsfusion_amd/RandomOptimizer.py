@@ -79,8 +79,8 @@ class RandomOptimizer:
         P, n = self.particle_size, dirs.shape[0]
         xn, pst7 = ops.ro_particles(self.pre_sampled_particle, state, dirs, target_d, rc)
         feat = ops.hashgrid_fwd(xn, model.embed_fn.params.detach(), model.embed_fn.meta, FEAT_LEVEL_MAJOR)
-        raw, _ = ops.decoder_fwd(packed, feat, FEAT_LEVEL_MAJOR, xn, None, P * n, save=False)
-        mean_masked = ops.ro_fitness(raw.view(P, n, raw.shape[-1]), target_d, self.trunc_value)
+        sdf = ops.decoder_fwd_sdf(packed, feat, FEAT_LEVEL_MAJOR, xn, None, P * n)      # the get_raw_sdf branch only
+        mean_masked = ops.ro_fitness(sdf.view(P, n, 1), target_d, self.trunc_value)
         ops.ro_update(mean_masked, pst7, state, self.sdf_weight, self.scaling_coefficient2)
         return mean_masked
 

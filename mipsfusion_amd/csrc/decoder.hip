@@ -242,7 +242,10 @@ __device__ __forceinline__ float load_feat(const float* __restrict__ feat, uint3
 
 // ================================================================================ forward
 // one wave, one tile of 32 samples; img1/2/3 = A-operand images of the three big layers (global or LDS)
-template <bool PE_INTERNAL, int LAYOUT, bool SAVE>
+// SDF_ONLY: the branch of MLP_reg.get_raw_sdf / JointEncoding.query_sdf (decoder.py:60-72, scene_rep.py:105-108):
+// layer 2 only produces its sdf_emb half (2 of 4 row tiles), no rgb head, no entropy; out = sdf [M].  This is what
+// RandomOptimizer.get_fitness and the mesher's SDF grid queries call -- 23 % fewer MFMAs, a tenth of the output.
+template <bool PE_INTERNAL, int LAYOUT, bool SAVE, bool SDF_ONLY = false>
 __device__ __forceinline__ void decoder_fwd_tile(const float* tail, const float4* img1,
                                                  const float4* img2, const float4* img3,
                                                  const float* __restrict__ feat, const float* __restrict__ x,
@@ -275,17 +278,19 @@ __device__ __forceinline__ void decoder_fwd_tile(const float* tail, const float4
     if (SAVE) relu_masks(H1, m1);
 
     // ---- layer 2: pts_linear.2 -> [sdf_emb | rgb_emb]   (H1 is written out one 16-byte group per k-group)
-    f32x16 H2[4];
+    constexpr int RT2 = SDF_ONLY ? 2 : RT_F2;
+    f32x16 H2[RT2];
     load_bias(tail, 1, h, H2);
-    mfma_layer<RT_F2, T_F2>(img2, lane, H2,
-                            [&](int t) { return H1[t >> 4][t & 15]; },
-                            [&](int t4) { if (SAVE && pin == 0) buf_store_act_piece(sv, lane16, 0, H1, t4); });
+    mfma_layer<RT2, T_F2>(img2, lane, H2,
+                          [&](int t) { return H1[t >> 4][t & 15]; },
+                          [&](int t4) { if constexpr (SAVE) { if (pin == 0) buf_store_act_piece(sv, lane16, 0, H1, t4); } });
 
     // ---- rgb_linear.0 on the vector ALU (3 outputs): this lane's half of every dot product, then one swap
     // (two of the three / four of the five running sums advance with one packed v_pk_fma_f32 each: same fmaf per
     //  component, a third fewer vector instructions in the two heads)
-    float pr[3];
-    {
+    float rgb[3] = {0.f, 0.f, 0.f};
+    if constexpr (!SDF_ONLY) {
+        float pr[3];
         const float4* trgb = reinterpret_cast<const float4*>(tail) + h * TRGB_SLOTS;
         f32x2 p01 = {0.f, 0.f};
         float p2 = 0.f;
@@ -303,10 +308,9 @@ __device__ __forceinline__ void decoder_fwd_tile(const float* tail, const float4
             p2 = fmaf(wv.z, ev[t], p2);
         }
         pr[0] = p01.x, pr[1] = p01.y, pr[2] = p2;
-    }
-    float rgb[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) rgb[c] = (pr[c] + __shfl_xor(pr[c], 32, 64)) + tail[OFF_BSMALL - OFF_TRGB + c];
+        for (int c = 0; c < 3; ++c) rgb[c] = (pr[c] + __shfl_xor(pr[c], 32, 64)) + tail[OFF_BSMALL - OFF_TRGB + c];
+    }
 
     // ---- layer 3: sdf_linear.0 + ReLU on [sdf_emb (regs of H2 tiles 0,1) | grid features (loaded)]
     float gf[16];
@@ -325,9 +329,11 @@ __device__ __forceinline__ void decoder_fwd_tile(const float* tail, const float4
     mfma_layer<RT_F3, T_F3>(img3, lane, H3,
                             [&](int t) { return t < 32 ? H2[t >> 4][t & 15] : gf[t - 32]; },
                             [&](int t4) {                       // 16 groups of H2 over 12 k-groups
-                                if (SAVE && pin == 0) {
-                                    buf_store_act_piece(sv, lane16, 1, H2, t4);
-                                    if (t4 < 4) buf_store_act_piece(sv, lane16, 1, H2, 12 + t4);
+                                if constexpr (SAVE) {
+                                    if (pin == 0) {
+                                        buf_store_act_piece(sv, lane16, 1, H2, t4);
+                                        if (t4 < 4) buf_store_act_piece(sv, lane16, 1, H2, 12 + t4);
+                                    }
                                 }
                             });
 #pragma unroll
@@ -380,6 +386,10 @@ __device__ __forceinline__ void decoder_fwd_tile(const float* tail, const float4
         cls += p[c] * (float)c;
     }
     const float sdf = (cls / 4.0f - 0.5f) * 2.0f;
+    if (SDF_ONLY) {
+        if (live && h == 0) out[s] = sdf;
+        return;
+    }
     if (live) {
         float* o = out + (size_t)s * 10;
         if (h == 0) {
@@ -390,7 +400,7 @@ __device__ __forceinline__ void decoder_fwd_tile(const float* tail, const float4
     }
 }
 
-template <bool PE_INTERNAL, int LAYOUT, bool SAVE>
+template <bool PE_INTERNAL, int LAYOUT, bool SAVE, bool SDF_ONLY = false>
 __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_fwd_kernel(const float* __restrict__ packed,
                                                                 const float* __restrict__ feat,
                                                                 const float* __restrict__ x,
@@ -404,7 +414,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_fwd_kernel(const float* 
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (tile * 32 >= (int64_t)M) return;
-    decoder_fwd_tile<PE_INTERNAL, LAYOUT, SAVE>(reinterpret_cast<const float*>(tailbuf), reinterpret_cast<const float4*>(packed + OFF_F1),
+    decoder_fwd_tile<PE_INTERNAL, LAYOUT, SAVE, SDF_ONLY>(reinterpret_cast<const float*>(tailbuf), reinterpret_cast<const float4*>(packed + OFF_F1),
                                                 reinterpret_cast<const float4*>(packed + OFF_F2),
                                                 reinterpret_cast<const float4*>(packed + OFF_F3), feat, x, embed_pos,
                                                 out, saved, M, pin, tile, lane);
@@ -417,7 +427,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_fwd_kernel(const float* 
 constexpr int FWD_LDS_FLOATS = OFF_B3 - OFF_F1;
 constexpr int FWD_LDS_BYTES = FWD_LDS_FLOATS * 4 + TAIL_F4 * 16;
 constexpr int FWD_LDS_BLOCK = 512;
-template <bool PE_INTERNAL, int LAYOUT, bool SAVE>
+template <bool PE_INTERNAL, int LAYOUT, bool SAVE, bool SDF_ONLY = false>
 __global__ __launch_bounds__(FWD_LDS_BLOCK, 1) void decoder_fwd_lds_kernel(const float* __restrict__ packed,
                                                                         const float* __restrict__ feat,
                                                                         const float* __restrict__ x,
@@ -443,7 +453,7 @@ __global__ __launch_bounds__(FWD_LDS_BLOCK, 1) void decoder_fwd_lds_kernel(const
         asm volatile("" : "+s"(zs));
         const float4* w4 = wimg + z;
         (void)zs;
-        decoder_fwd_tile<PE_INTERNAL, LAYOUT, SAVE>(reinterpret_cast<const float*>(w4 + FWD_LDS_FLOATS / 4),
+        decoder_fwd_tile<PE_INTERNAL, LAYOUT, SAVE, SDF_ONLY>(reinterpret_cast<const float*>(w4 + FWD_LDS_FLOATS / 4),
                                                     w4 + (OFF_F1 - OFF_F1) / 4, w4 + (OFF_F2 - OFF_F1) / 4,
                                                     w4 + (OFF_F3 - OFF_F1) / 4, feat, x, embed_pos, out, saved, M, pin,
                                                     (int64_t)tile, lane);
@@ -1081,8 +1091,9 @@ int mipsf_decoder_pack_host(const mipsf_decoder_weights* w, float* packed_host) 
     return 0;
 }
 
-int mipsf_decoder_fwd(const float* packed, const float* feat, int feat_layout, const float* x,
-                      const float* embed_pos, int pe_mode, float* out, float* saved, uint32_t M, void* stream) {
+static int decoder_fwd_launch(const float* packed, const float* feat, int feat_layout, const float* x,
+                              const float* embed_pos, int pe_mode, float* out, float* saved, bool sdf_only, uint32_t M,
+                              void* stream) {
     if (M == 0) return 0;
     MIPSF_REQUIRE(packed && feat && x && out, "null pointer");
     MIPSF_REQUIRE(pe_mode == 0 || embed_pos, "pe_mode 1 needs embed_pos");
@@ -1095,35 +1106,49 @@ int mipsf_decoder_fwd(const float* packed, const float* feat, int feat_layout, c
     if (cus <= 0) return 3;
     // persistent LDS-resident weights pay off once every CU has several rounds of tiles to amortise the 140 KB fill
     const bool persistent = n_tiles >= (uint32_t)cus * 8u * MIPSF_FWD_LDS_MIN_ROUNDS;
-#define FWD(PE, LAY, SV)                                                                                         \
+#define FWD(PE, LAY, SV, SDF)                                                                                    \
     do {                                                                                                         \
         if (persistent) {                                                                                        \
             static bool attr_set = false;                                                                        \
             if (!attr_set) {                                                                                     \
-                if (hipFuncSetAttribute((const void*)decoder_fwd_lds_kernel<PE, LAY, SV>,                        \
+                if (hipFuncSetAttribute((const void*)decoder_fwd_lds_kernel<PE, LAY, SV, SDF>,                   \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS_BYTES) != hipSuccess) { \
                     set_error("cannot raise dynamic LDS to %d bytes", FWD_LDS_BYTES);                            \
                     return 4;                                                                                    \
                 }                                                                                                \
                 attr_set = true;                                                                                 \
             }                                                                                                    \
-            hipLaunchKernelGGL((decoder_fwd_lds_kernel<PE, LAY, SV>), dim3(cus), dim3(FWD_LDS_BLOCK), FWD_LDS_BYTES, s, \
+            hipLaunchKernelGGL((decoder_fwd_lds_kernel<PE, LAY, SV, SDF>), dim3(cus), dim3(FWD_LDS_BLOCK), FWD_LDS_BYTES, s, \
                                packed, feat, x, embed_pos, out, saved, M, 0, n_tiles);                           \
         } else {                                                                                                 \
-            hipLaunchKernelGGL((decoder_fwd_kernel<PE, LAY, SV>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed, feat, x, \
+            hipLaunchKernelGGL((decoder_fwd_kernel<PE, LAY, SV, SDF>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed, feat, x, \
                                embed_pos, out, saved, M, 0);                                                     \
         }                                                                                                        \
     } while (0)
-    const bool sv = saved != nullptr;
+#define FWD_SV(PE, LAY)                                  \
+    do {                                                 \
+        if (sdf_only) FWD(PE, LAY, false, true);         \
+        else if (saved != nullptr) FWD(PE, LAY, true, false); \
+        else FWD(PE, LAY, false, false);                 \
+    } while (0)
     if (pe_mode == 0) {
-        if (feat_layout == MIPSF_FEAT_AOS) { if (sv) FWD(true, MIPSF_FEAT_AOS, true); else FWD(true, MIPSF_FEAT_AOS, false); }
-        else { if (sv) FWD(true, MIPSF_FEAT_LEVEL_MAJOR, true); else FWD(true, MIPSF_FEAT_LEVEL_MAJOR, false); }
+        if (feat_layout == MIPSF_FEAT_AOS) FWD_SV(true, MIPSF_FEAT_AOS); else FWD_SV(true, MIPSF_FEAT_LEVEL_MAJOR);
     } else {
-        if (feat_layout == MIPSF_FEAT_AOS) { if (sv) FWD(false, MIPSF_FEAT_AOS, true); else FWD(false, MIPSF_FEAT_AOS, false); }
-        else { if (sv) FWD(false, MIPSF_FEAT_LEVEL_MAJOR, true); else FWD(false, MIPSF_FEAT_LEVEL_MAJOR, false); }
+        if (feat_layout == MIPSF_FEAT_AOS) FWD_SV(false, MIPSF_FEAT_AOS); else FWD_SV(false, MIPSF_FEAT_LEVEL_MAJOR);
     }
+#undef FWD_SV
 #undef FWD
     return check_launch("decoder_fwd");
+}
+
+int mipsf_decoder_fwd(const float* packed, const float* feat, int feat_layout, const float* x,
+                      const float* embed_pos, int pe_mode, float* out, float* saved, uint32_t M, void* stream) {
+    return decoder_fwd_launch(packed, feat, feat_layout, x, embed_pos, pe_mode, out, saved, false, M, stream);
+}
+
+int mipsf_decoder_fwd_sdf(const float* packed, const float* feat, int feat_layout, const float* x,
+                          const float* embed_pos, int pe_mode, float* sdf, uint32_t M, void* stream) {
+    return decoder_fwd_launch(packed, feat, feat_layout, x, embed_pos, pe_mode, sdf, nullptr, true, M, stream);
 }
 
 int mipsf_decoder_bwd_chain(const float* packed, int feat_layout, const float* x, int pe_mode, const float* out,

@@ -337,4 +337,15 @@ int mipsf_ro_fitness(const float* raw, uint32_t raw_stride, const float* target_
     return check_launch("ro_fitness");
 }
 
+int mipsf_ro_fitness_sdf(const float* sdf, const float* target_d, float trunc, float* mean_masked, uint32_t P,
+                         uint32_t n, void* stream) {
+    if (P == 0) return 0;
+    MIPSF_REQUIRE(sdf && target_d && mean_masked, "null pointer");
+    const uint32_t threads = P * MIPSF_WAVE;
+    // the kernel reads element 3 of rows `stride` floats apart: a dense [P*n] SDF array is that table shifted by 3
+    hipLaunchKernelGGL(ro_fitness_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, sdf - 3, 1u,
+                       target_d, trunc, mean_masked, P, n);
+    return check_launch("ro_fitness");
+}
+
 }  // extern "C"

@@ -266,12 +266,13 @@ __global__ __launch_bounds__(LF_BLOCK) void loss_finalize_kernel(const float* __
         for (int j = 0; j < 9; ++j) red[w][j] = acc[j];
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double t[9];
-        for (int j = 0; j < 9; ++j) {
-            t[j] = 0.0;
-            for (int k = 0; k < LF_BLOCK / MIPSF_WAVE; ++k) t[j] += red[k][j];
-        }
+    if (w != 0) return;
+    // second stage in the first wave (lane k holds wave k's partial): a single thread walking the 16 x 9 doubles
+    // through LDS was a third of this kernel's 12 us
+    double t[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) t[j] = wave_sum_d(lane < LF_BLOCK / MIPSF_WAVE ? red[lane][j] : 0.0);
+    if (lane == 0) {
         const double NS = (double)N * (double)S;
         const float n_front = (float)t[7], n_band = (float)t[8];
         const float total = n_front + n_band;

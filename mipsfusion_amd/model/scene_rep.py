@@ -224,7 +224,19 @@ class JointEncoding(nn.Module):
 
     # ---------------------------------------------------------------- queries (scene_rep.py:105-146)
     def query_sdf(self, query_points):
-        return self.query_color_sdf(query_points)[..., 3:4]
+        """scene_rep.py:105-108.  Without autograd (mesher grids, fitness probes) only the SDF branch of the decoder
+        runs (MLP_reg.get_raw_sdf): same values as column 3 of query_color_sdf, bit for bit."""
+        needs_grad = torch.is_grad_enabled() and (query_points.requires_grad or
+                                                  any(p.requires_grad for p in self.parameters()))
+        if needs_grad:
+            return self.query_color_sdf(query_points)[..., 3:4]
+        flat = torch.reshape(query_points, [-1, query_points.shape[-1]]) / self.config["training"]["norm_factor"]
+        if not flat.is_cuda:
+            raise RuntimeError("JointEncoding runs on the GPU only (no CPU fallback)")
+        xn = ops._f32c(flat)
+        feat = ops.hashgrid_fwd(xn, self.embed_fn.params.detach(), self.embed_fn.meta, FEAT_LEVEL_MAJOR)
+        packed = ops.decoder_pack(self.decoder.ordered_parameters())
+        return ops.decoder_fwd_sdf(packed, feat, FEAT_LEVEL_MAJOR, xn, None, xn.shape[0])[:, None]
 
     def query_color(self, query_points):
         return torch.sigmoid(self.query_color_sdf(query_points)[..., :3])

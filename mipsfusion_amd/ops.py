@@ -206,6 +206,17 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M):
     return dfeat, dx, dpe
 
 
+def decoder_fwd_sdf(packed, feat, layout, x, embed_pos, M) -> torch.Tensor:
+    """SDF branch only (MLP_reg.get_raw_sdf / JointEncoding.query_sdf): [M] floats, bit-identical to column 3 of
+    decoder_fwd, without the rgb half of layer 2, the rgb head and nine tenths of the output."""
+    sdf = torch.empty((M,), dtype=torch.float32, device=x.device)
+    pe_mode = 0 if embed_pos is None else 1
+    with _timed("decoder_fwd"):
+        check(lib().mipsf_decoder_fwd_sdf(dptr(packed), dptr(feat), layout, dptr(x), dptr(embed_pos), pe_mode, dptr(sdf),
+                                          M, stream_ptr()), "decoder_fwd_sdf")
+    return sdf
+
+
 class DecoderFn(torch.autograd.Function):
     """MLP_reg.forward(embed, embed_pos, query_pts) with all three inputs differentiable (module API)."""
 
@@ -410,11 +421,15 @@ def adam_step_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps,
 
 
 def ro_fitness(raw, target_d, trunc: float) -> torch.Tensor:
-    """raw [P,n,10] (run_network output), target_d [n] -> mean_masked_sdf [P] (RandomOptimizer.py:125-129)."""
+    """raw [P,n,10] (run_network output) or [P,n,1] (SDF only), target_d [n] -> mean_masked_sdf [P]
+    (RandomOptimizer.py:125-129)."""
     P, n, stride = raw.shape
     out = torch.empty(P, dtype=torch.float32, device=raw.device)
-    check(lib().mipsf_ro_fitness(dptr(raw), stride, dptr(target_d), trunc, dptr(out), P, n, stream_ptr()),
-          "ro_fitness")
+    if stride == 1:
+        check(lib().mipsf_ro_fitness_sdf(dptr(raw), dptr(target_d), trunc, dptr(out), P, n, stream_ptr()), "ro_fitness")
+    else:
+        check(lib().mipsf_ro_fitness(dptr(raw), stride, dptr(target_d), trunc, dptr(out), P, n, stream_ptr()),
+              "ro_fitness")
     return out
 
 

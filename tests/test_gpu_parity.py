@@ -860,6 +860,29 @@ def test_keyframe_ray_sampling_matches_reference_bit_for_bit(dev):
     assert db2.rays.data_ptr() == table.data_ptr()
 
 
+def test_sdf_only_forward_is_column_3_bit_for_bit(dev):
+    """mipsf_decoder_fwd_sdf (MLP_reg.get_raw_sdf branch: half of layer 2, no rgb head) vs column 3 of the full
+    forward, on the small-batch kernel and on the persistent LDS kernel, ragged sizes; and JointEncoding.query_sdf
+    (no-grad path) vs query_color_sdf."""
+    torch.manual_seed(11)
+    cfg = synth.config_plumbing()
+    m = JointEncoding(cfg, T(np.array(cfg["mapping"]["bound"])), T(np.array(cfg["mapping"]["localMLP_max_len"]))).to(dev)
+    with torch.no_grad():
+        m.embed_fn.params.uniform_(-0.5, 0.5)
+        for p in m.decoder.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    packed = ops.decoder_pack(m.decoder.ordered_parameters())
+    for M in (1, 33, 1000, 70001, 300000):
+        xn = torch.rand(M, 3, device=dev)
+        feat = ops.hashgrid_fwd(xn, m.embed_fn.params.detach(), m.embed_fn.meta, ops.FEAT_LEVEL_MAJOR)
+        full, _ = ops.decoder_fwd(packed, feat, ops.FEAT_LEVEL_MAJOR, xn, None, M, save=False)
+        sdf = ops.decoder_fwd_sdf(packed, feat, ops.FEAT_LEVEL_MAJOR, xn, None, M)
+        assert torch.equal(sdf, full[:, 3]), M
+    pts = torch.rand(5000, 3, device=dev) * 2 - 1
+    with torch.no_grad():
+        assert torch.equal(m.query_sdf(pts), m.query_color_sdf(pts)[..., 3:4])
+
+
 @pytest.mark.gpu
 def test_reference_checkpoint_reproduces_reference_outputs(dev):
     """the checkpoint file written by the reference (tests/golden/ref_model_0.pth) loaded into the GPU
