@@ -883,6 +883,30 @@ def test_sdf_only_forward_is_column_3_bit_for_bit(dev):
         assert torch.equal(m.query_sdf(pts), m.query_color_sdf(pts)[..., 3:4])
 
 
+def test_forward_above_16m_samples_matches_chunked_evaluation(dev):
+    """Maximum sizes: above 2^24 samples the forward leaves the single 4 GB buffer resource for the grid features and
+    takes its 64-bit addressing branch; a batch of 2^24 + 77 samples must equal the same points evaluated in chunks
+    (hash grid + full decoder forward + SDF-only forward), bit for bit."""
+    torch.manual_seed(12)
+    cfg = synth.config_plumbing()
+    m = JointEncoding(cfg, T(np.array(cfg["mapping"]["bound"])), T(np.array(cfg["mapping"]["localMLP_max_len"]))).to(dev)
+    with torch.no_grad():
+        m.embed_fn.params.uniform_(-0.5, 0.5)
+    packed = ops.decoder_pack(m.decoder.ordered_parameters())
+    M = (1 << 24) + 77
+    xn = torch.rand(M, 3, device=dev)
+    feat = ops.hashgrid_fwd(xn, m.embed_fn.params.detach(), m.embed_fn.meta, ops.FEAT_LEVEL_MAJOR)
+    sdf = ops.decoder_fwd_sdf(packed, feat, ops.FEAT_LEVEL_MAJOR, xn, None, M)
+    full, _ = ops.decoder_fwd(packed, feat, ops.FEAT_LEVEL_MAJOR, xn, None, M, save=False)
+    assert torch.equal(sdf, full[:, 3])
+    del feat
+    for lo, hi in ((0, 100000), (M - 100077, M)):
+        xc = xn[lo:hi].contiguous()
+        fc = ops.hashgrid_fwd(xc, m.embed_fn.params.detach(), m.embed_fn.meta, ops.FEAT_LEVEL_MAJOR)
+        oc, _ = ops.decoder_fwd(packed, fc, ops.FEAT_LEVEL_MAJOR, xc, None, hi - lo, save=False)
+        assert torch.equal(oc, full[lo:hi]), (lo, hi)
+
+
 @pytest.mark.gpu
 def test_reference_checkpoint_reproduces_reference_outputs(dev):
     """the checkpoint file written by the reference (tests/golden/ref_model_0.pth) loaded into the GPU
