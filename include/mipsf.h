@@ -254,9 +254,10 @@ int mipsf_adam_step_multi_ex(const mipsf_adam_tensors* tensors_host_struct, floa
  * mean_masked[P] = mean_j(valid_j * |sdf*trunc|)  (RandomOptimizer.py:125-129) */
 int mipsf_ro_fitness(const float* raw, uint32_t raw_stride, const float* target_d, float trunc,
                      float* mean_masked, uint32_t P, uint32_t n, void* stream);
-/* the same on the [P,n] output of mipsf_decoder_fwd_sdf */
+/* the same on the output of mipsf_decoder_fwd_sdf: sdf[p*n + j], or sdf[j*P + p] when point_major != 0
+ * (the order mipsf_ro_particles_pm writes) */
 int mipsf_ro_fitness_sdf(const float* sdf, const float* target_d, float trunc, float* mean_masked, uint32_t P,
-                         uint32_t n, void* stream);
+                         uint32_t n, int point_major, void* stream);
 
 /* -------------------------------------- RandomOptimizer particle step */
 /* The search state lives on the device so that a tracking round needs no host round trip (the reference
@@ -272,6 +273,10 @@ int mipsf_ro_fitness_sdf(const float* sdf, const float* target_d, float trunc, f
 int mipsf_ro_particles(const float* pst, const float* state, const float* rays_d_cam, const float* target_d,
                        const mipsf_render_cfg* cfg_host, float* xn, float* pst7, uint32_t P, uint32_t n,
                        void* stream);
+/* same, samples written point-major (xn[(j*P + p)*3 ..]): the 64 samples of a hash-grid wavefront are then 64
+ * particles' copies of one lattice point, i.e. the same few table cells -- 2-3x faster grid lookups for the round */
+int mipsf_ro_particles_pm(const float* pst, const float* state, const float* rays_d_cam, const float* target_d,
+                          const mipsf_render_cfg* cfg, float* xn, float* pst7, uint32_t P, uint32_t n, void* stream);
 /* mean_masked [P] from mipsf_ro_fitness -> advanced-particle weights, weighted mean transform, new rot/trans and
  * search size in `state` (RandomOptimizer.py:196-224; sdf_weight = 1000, rescale = tracking.RO.rescaling_factor). */
 int mipsf_ro_update(const float* mean_masked, const float* pst7, float* state, float sdf_weight, float rescale,

@@ -16,6 +16,10 @@ from .helper_functions.geometry_helper import quaternion_to_matrix
 from .helper_functions.sampling_helper import sample_pixels_uniformly
 
 
+# sample order of a round: point-major (hash-grid lookups 144 -> 77 us per round; see mipsf_ro_particles_pm)
+_POINT_MAJOR = True
+
+
 class RandomOptimizer:
     def __init__(self, cfg, mipsfusion):
         self.cfg = cfg
@@ -77,10 +81,11 @@ class RandomOptimizer:
     def _enqueue_round(self, model, state, target_d, dirs, rc, packed):
         """One round (RandomOptimizer.py:177-224) on the current stream; no host synchronisation."""
         P, n = self.particle_size, dirs.shape[0]
-        xn, pst7 = ops.ro_particles(self.pre_sampled_particle, state, dirs, target_d, rc)
+        # point-major sample order: a hash-grid wavefront = 64 particles' copies of one lattice point (same cells)
+        xn, pst7 = ops.ro_particles(self.pre_sampled_particle, state, dirs, target_d, rc, point_major=_POINT_MAJOR)
         feat = ops.hashgrid_fwd(xn, model.embed_fn.params.detach(), model.embed_fn.meta, FEAT_LEVEL_MAJOR)
         sdf = ops.decoder_fwd_sdf(packed, feat, FEAT_LEVEL_MAJOR, xn, None, P * n)      # the get_raw_sdf branch only
-        mean_masked = ops.ro_fitness(sdf.view(P, n, 1), target_d, self.trunc_value)
+        mean_masked = ops.ro_fitness(sdf.view(P, n, 1), target_d, self.trunc_value, point_major=_POINT_MAJOR)
         ops.ro_update(mean_masked, pst7, state, self.sdf_weight, self.scaling_coefficient2)
         return mean_masked
 

@@ -95,8 +95,9 @@ SIGNATURES = {
     "mipsf_adam_step_multi_ex": (_I, [C.POINTER(AdamTensors), _F, _F, _F, _F, _F, _U32, _P, _I, _P]),
     "mipsf_adam_step_multi": (_I, [C.POINTER(AdamTensors), _F, _F, _F, _F, _F, _U32, _I, _P]),
     "mipsf_ro_fitness": (_I, [_P, _U32, _P, _F, _P, _U32, _U32, _P]),
-    "mipsf_ro_fitness_sdf": (_I, [_P, _P, _F, _P, _U32, _U32, _P]),
+    "mipsf_ro_fitness_sdf": (_I, [_P, _P, _F, _P, _U32, _U32, _I, _P]),
     "mipsf_ro_particles": (_I, [_P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _U32, _U32, _P]),
+    "mipsf_ro_particles_pm": (_I, [_P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _U32, _U32, _P]),
     "mipsf_ro_update": (_I, [_P, _P, _P, _F, _F, _U32, _P]),
     "mipsf_gather_rays": (_I, [_P, _U64, _P, _U32, _P, _P, _P, _P, _P]),
 }

@@ -170,15 +170,17 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamMulti t, AdamK k_in
 
 // ------------------------------------------------------ RandomOptimizer.get_fitness (RandomOptimizer.py:125-129)
 // one wave per particle: mean_j( (d_j > 0) * |sdf_pj * trunc| )
+// row of (particle, point) = particle * row_p + point * row_j, `stride` floats per row, SDF in column 3
 __global__ __launch_bounds__(256) void ro_fitness_kernel(const float* __restrict__ raw, uint32_t stride,
                                                          const float* __restrict__ target_d, float trunc,
-                                                         float* __restrict__ out, uint32_t P, uint32_t n) {
+                                                         float* __restrict__ out, uint32_t P, uint32_t n,
+                                                         uint32_t row_p, uint32_t row_j) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / MIPSF_WAVE;
     const uint32_t lane = threadIdx.x & (MIPSF_WAVE - 1);
     if (wave >= P) return;
     float acc = 0.f;
     for (uint32_t j = lane; j < n; j += MIPSF_WAVE) {
-        const float s = raw[((size_t)wave * n + j) * stride + 3] * trunc;
+        const float s = raw[((size_t)wave * row_p + (size_t)j * row_j) * stride + 3] * trunc;
         acc += (target_d[j] > 0.f) ? fabsf(s) : 0.f;
     }
     acc = wave_sum(acc);
@@ -333,18 +335,18 @@ int mipsf_ro_fitness(const float* raw, uint32_t raw_stride, const float* target_
     MIPSF_REQUIRE(raw_stride >= 4, "raw_stride must cover the sdf column");
     const uint32_t threads = P * MIPSF_WAVE;
     hipLaunchKernelGGL(ro_fitness_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, raw,
-                       raw_stride, target_d, trunc, mean_masked, P, n);
+                       raw_stride, target_d, trunc, mean_masked, P, n, n, 1u);
     return check_launch("ro_fitness");
 }
 
 int mipsf_ro_fitness_sdf(const float* sdf, const float* target_d, float trunc, float* mean_masked, uint32_t P,
-                         uint32_t n, void* stream) {
+                         uint32_t n, int point_major, void* stream) {
     if (P == 0) return 0;
     MIPSF_REQUIRE(sdf && target_d && mean_masked, "null pointer");
     const uint32_t threads = P * MIPSF_WAVE;
     // the kernel reads element 3 of rows `stride` floats apart: a dense [P*n] SDF array is that table shifted by 3
     hipLaunchKernelGGL(ro_fitness_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, sdf - 3, 1u,
-                       target_d, trunc, mean_masked, P, n);
+                       target_d, trunc, mean_masked, P, n, point_major ? 1u : n, point_major ? P : 1u);
     return check_launch("ro_fitness");
 }
 

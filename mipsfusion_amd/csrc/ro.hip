@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void ro_particles_kernel(const float* __restri
                                                            const float* __restrict__ rays_d_cam,
                                                            const float* __restrict__ target_d, NormCfg nc,
                                                            float* __restrict__ xn, float* __restrict__ pst7,
-                                                           uint32_t P, uint32_t n) {
+                                                           uint32_t P, uint32_t n, int point_major) {
     const uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) / MIPSF_WAVE;
     const uint32_t lane = threadIdx.x & (MIPSF_WAVE - 1);
     if (p >= P) return;
@@ -63,7 +63,10 @@ __global__ __launch_bounds__(256) void ro_particles_kernel(const float* __restri
         const float w0 = ((aR[0] * c0 + aR[1] * c1) + aR[2] * c2) + t0;     // batch_points_trans
         const float w1 = ((aR[3] * c0 + aR[4] * c1) + aR[5] * c2) + t1;
         const float w2 = ((aR[6] * c0 + aR[7] * c1) + aR[8] * c2) + t2;
-        float* o = xn + 3 * ((size_t)p * n + i);
+        // point_major: sample index = point * P + particle -- the 64 samples of a hash-grid wavefront are then 64
+        // particles' copies of ONE lattice point (a few cm apart: same or neighbouring cells on every level)
+        // instead of 64 lattice points scattered over the depth image
+        float* o = xn + 3 * (point_major ? (size_t)i * P + p : (size_t)p * n + i);
         o[0] = normalise1(w0, nc.sub[0], nc.div[0], nc.norm_factor);          // run_network's fp64 normalisation
         o[1] = normalise1(w1, nc.sub[1], nc.div[1], nc.norm_factor);
         o[2] = normalise1(w2, nc.sub[2], nc.div[2], nc.norm_factor);
@@ -157,7 +160,17 @@ int mipsf_ro_particles(const float* pst, const float* state, const float* rays_d
     MIPSF_REQUIRE(pst && state && rays_d_cam && target_d && cfg && xn && pst7, "null pointer");
     const uint32_t threads = P * MIPSF_WAVE;
     hipLaunchKernelGGL(ro_particles_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, pst, state,
-                       rays_d_cam, target_d, make_norm(*cfg), xn, pst7, P, n);
+                       rays_d_cam, target_d, make_norm(*cfg), xn, pst7, P, n, 0);
+    return check_launch("ro_particles");
+}
+
+int mipsf_ro_particles_pm(const float* pst, const float* state, const float* rays_d_cam, const float* target_d,
+                          const mipsf_render_cfg* cfg, float* xn, float* pst7, uint32_t P, uint32_t n, void* stream) {
+    if (P == 0 || n == 0) return 0;
+    MIPSF_REQUIRE(pst && state && rays_d_cam && target_d && cfg && xn && pst7, "null pointer");
+    const uint32_t threads = P * MIPSF_WAVE;
+    hipLaunchKernelGGL(ro_particles_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, pst, state,
+                       rays_d_cam, target_d, make_norm(*cfg), xn, pst7, P, n, 1);
     return check_launch("ro_particles");
 }
 

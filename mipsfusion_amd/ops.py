@@ -420,13 +420,14 @@ def adam_step_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps,
                   "adam_step_multi")
 
 
-def ro_fitness(raw, target_d, trunc: float) -> torch.Tensor:
-    """raw [P,n,10] (run_network output) or [P,n,1] (SDF only), target_d [n] -> mean_masked_sdf [P]
-    (RandomOptimizer.py:125-129)."""
+def ro_fitness(raw, target_d, trunc: float, point_major: bool = False) -> torch.Tensor:
+    """raw [P,n,10] (run_network output) or [P,n,1] (SDF only; with point_major the memory order is [n,P] and raw is
+    passed as sdf.view(P, n, 1) all the same), target_d [n] -> mean_masked_sdf [P] (RandomOptimizer.py:125-129)."""
     P, n, stride = raw.shape
     out = torch.empty(P, dtype=torch.float32, device=raw.device)
     if stride == 1:
-        check(lib().mipsf_ro_fitness_sdf(dptr(raw), dptr(target_d), trunc, dptr(out), P, n, stream_ptr()), "ro_fitness")
+        check(lib().mipsf_ro_fitness_sdf(dptr(raw), dptr(target_d), trunc, dptr(out), P, n, 1 if point_major else 0,
+                                         stream_ptr()), "ro_fitness")
     else:
         check(lib().mipsf_ro_fitness(dptr(raw), stride, dptr(target_d), trunc, dptr(out), P, n, stream_ptr()),
               "ro_fitness")
@@ -436,14 +437,16 @@ def ro_fitness(raw, target_d, trunc: float) -> torch.Tensor:
 RO_STATE_FLOATS = 32
 
 
-def ro_particles(pst, state, rays_d_cam, target_d, rc):
-    """One RandomOptimizer round, first half (RandomOptimizer.py:184-190, 117-121): -> xn [P*n,3], pst7 [P,7]."""
+def ro_particles(pst, state, rays_d_cam, target_d, rc, point_major: bool = False):
+    """One RandomOptimizer round, first half (RandomOptimizer.py:184-190, 117-121): -> xn [P*n,3], pst7 [P,7].
+    point_major: sample (particle p, lattice point j) is row j*P + p instead of p*n + j."""
     P, n = pst.shape[0], rays_d_cam.shape[0]
     xn = torch.empty((P * n, 3), dtype=torch.float32, device=pst.device)
     pst7 = torch.empty((P, 7), dtype=torch.float32, device=pst.device)
+    fn = lib().mipsf_ro_particles_pm if point_major else lib().mipsf_ro_particles
     with _timed("ro_particles"):
-        check(lib().mipsf_ro_particles(dptr(pst), dptr(state), dptr(rays_d_cam), dptr(target_d), C.byref(rc),
-                                       dptr(xn), dptr(pst7), P, n, stream_ptr()), "ro_particles")
+        check(fn(dptr(pst), dptr(state), dptr(rays_d_cam), dptr(target_d), C.byref(rc), dptr(xn), dptr(pst7), P, n,
+                 stream_ptr()), "ro_particles")
     return xn, pst7
 
 

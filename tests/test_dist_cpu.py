@@ -32,7 +32,9 @@ def _worker(rank, world, port, q):
         b, e = share_of(11, rank, world)
         whole = torch.arange(11 * 3, dtype=torch.float32).reshape(11, 3)
         gathered = mdist.all_gather_ragged(whole[b:e].clone(), 11, world)
-        q.put((rank, allp.clone(), t, mdist.submaps_of_rank(8, world, rank), gathered.clone(), (b, e)))
+        # numpy, not torch tensors: a tensor travels through the queue as a file descriptor owned by THIS process,
+        # and the parent may only open it after the worker has exited (FileNotFoundError, seen once in ~50 runs)
+        q.put((rank, allp.numpy().copy(), t, mdist.submaps_of_rank(8, world, rank), gathered.numpy().copy(), (b, e)))
     finally:
         dist.destroy_process_group()
 
@@ -49,6 +51,7 @@ def test_pose_exchange_and_ownership_world2():
         p.join(60)
         assert p.exitcode == 0
     for rank, allp, t, owned, gathered, share in res:
+        allp, gathered = torch.from_numpy(allp), torch.from_numpy(gathered)
         assert torch.equal(gathered, torch.arange(33, dtype=torch.float32).reshape(11, 3))
         assert share == ((0, 6) if rank == 0 else (6, 11))
         assert allp.shape == (2, 4, 7)
