@@ -796,6 +796,37 @@ __device__ __forceinline__ void wgrad_mma(const float* __restrict__ XT, const fl
     }
 }
 
+// The two products whose X operand is the 8 small-gradient rows (rgb0: drgb, sdf2: dlogits) on 16x16x4 tiles: a
+// 32x32x2 tile spends 32 output rows on them, a 16x16x4 one 16 -- half the matrix time of these two phases (4096 ->
+// 2048 cycles per wave and phase, 9 % of the kernel's MFMA cycles).  acc[ct] += X8[rows 0..15] * Y^T[cols 16*(2w+ct)
+// .. +15]^T; MFMA k-step t multiplies samples {t, t+32, t+64, t+96} (lane groups of 16), so four consecutive k-steps
+// of an operand are again one ds_read_b128.  side(g), g = 0..15, as in wgrad_mma.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <typename SideFn = NoFetch>
+__device__ __forceinline__ void wgrad_mma_small(const float* __restrict__ X8, const float* __restrict__ YT, int w,
+                                                int lane, f32x4 (&acc)[2], SideFn side = NoFetch()) {
+    const int i = lane & 15, g4 = lane >> 4;
+    const float4* xa = reinterpret_cast<const float4*>(X8 + i * WG_LDW + 32 * g4);
+    const float4* yb = reinterpret_cast<const float4*>(YT + (32 * w + i) * WG_LDW + 32 * g4);
+    float4 a = xa[0], b0 = yb[0], b1 = yb[4 * WG_LDW], na, nb0, nb1;
+#pragma unroll
+    for (int t4 = 0; t4 < 8; ++t4) {
+        if (t4 + 1 < 8) na = xa[t4 + 1], nb0 = yb[t4 + 1], nb1 = yb[4 * WG_LDW + t4 + 1];
+        side(2 * t4);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc[1], 0, 0, 0);
+        side(2 * t4 + 1);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc[1], 0, 0, 0);
+        a = na, b0 = nb0, b1 = nb1;
+        if (!std::is_same<SideFn, NoFetch>::value) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int NCT>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NCT]) {
 #pragma unroll
@@ -829,8 +860,13 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
     const int j = lane & 31, h = lane >> 5;
 
     for (int q = tid; q < 24 * WG_LDW; q += DEC_BLOCK) X8[8 * WG_LDW + q] = 0.0f;      // rows 8..31 stay zero
-    f32x16 aS1[3], aW2[4], aW1[2], aS2[1], aRGB[1];
-    zero_acc(aS1), zero_acc(aW2), zero_acc(aW1), zero_acc(aS2), zero_acc(aRGB);
+    f32x16 aS1[3], aW2[4], aW1[2];
+    f32x4 aS2[2], aRGB[2];              // 16x16 tiles: rows 0..7 = the 8 small-gradient rows, columns 32w + 16ct + (lane & 15)
+    zero_acc(aS1), zero_acc(aW2), zero_acc(aW1);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) aS2[ct][r] = 0.0f, aRGB[ct][r] = 0.0f;
     float db3 = 0.f, db2 = 0.f;
     const int brow = tid & 127, bhalf = tid >> 7;
 
@@ -960,7 +996,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
             const char* by = act_base(saved, tile, 2, 0);
             wgrad_mma<2>(XT, YT, w, 0, lane, aW1, [&](int g) { ny[g] = act_piece(by, g, lane16); });
         }
-        wgrad_mma<1>(X8, YT, 0, w, lane, aRGB);
+        wgrad_mma_small(X8, YT, w, lane, aRGB);
         __syncthreads();
 
         // ---------------- phase sdf2: X = the 8 small rows (still in X8), Y = H3
@@ -972,7 +1008,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
             const char* bx = act_base(dact, nt, 2, 0);
             const char* by = act_base(saved, nt, 1, 0);
             const uint32_t ns = sample_of(nb);
-            wgrad_mma<1>(X8, YT, 0, w, lane, aS2, [&](int g) {
+            wgrad_mma_small(X8, YT, w, lane, aS2, [&](int g) {
                 nx[g] = act_piece(bx, g, lane16);
                 if (g < 8) ny[g] = act_piece(by, g, lane16);
                 ngf[g] = load_feat<LAYOUT>(feat, ns, g, h, M);
@@ -992,28 +1028,28 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) flush_tile(rec, G_W_PTS0, HID, N_E, w, ct, lane, aW1[ct]);
     {
-        // rows 0..4 of aS2 = d w_sdf2[c][32w + col]; rows 5..7 of aRGB = d w_rgb0[c][32w + col]
-        const int jj = lane & 31, hh = lane >> 5;
+        // 16x16 accumulator: register r of lane l = row 4*(l >> 4) + r, column l & 15 of its tile.
+        // rows 0..4 of aS2 = d w_sdf2[c][col]; rows 5..7 of aRGB = d w_rgb0[c][..]; column 51 of aRGB (ones row of the
+        // pts0 phase's Y) = d b_sdf2 (rows 0..4) and d b_rgb0 (rows 5..7)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rowmap(r, hh), col = 32 * w + jj;
-            if (row < N_CLASS) rec[G_W_SDF2 + row * HID + col] = aS2[0][r];
-            // aRGB columns follow the phase's Y rows: [e (0..50) | pad | rgb_emb (64..127)] -> w_rgb0 columns [64 + e | rgb_emb]
-            const int rc = col < N_E ? 64 + col : (col >= 64 ? col - 64 : -1);
-            if (row >= 5 && row < 8 && rc >= 0) rec[G_W_RGB0 + (row - 5) * N_RGB_IN + rc] = aRGB[0][r];
-        }
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * (lane >> 4) + r, col = 32 * w + 16 * ct + (lane & 15);
+                if (row < N_CLASS) rec[G_W_SDF2 + row * HID + col] = aS2[ct][r];
+                // aRGB columns follow the phase's Y rows: [e (0..50) | ones | pad | rgb_emb (64..127)] -> w_rgb0 columns [64 + e | rgb_emb]
+                const int rc = col < N_E ? 64 + col : (col >= 64 ? col - 64 : -1);
+                if (row >= 5 && row < 8 && rc >= 0) rec[G_W_RGB0 + (row - 5) * N_RGB_IN + rc] = aRGB[ct][r];
+                if (col == N_E && row < N_CLASS) rec[G_B_SDF2 + row] = aRGB[ct][r];
+                if (col == N_E && row >= 5 && row < 8) rec[G_B_RGB0 + row - 5] = aRGB[ct][r];
+            }
     }
     {
-        // column 51 of the pts0 / rgb0 products is the ones row: d b_pts0 (rows of aW1[1]), d b_sdf2 and d b_rgb0
+        // column 51 of the pts0 product is the ones row: d b_pts0 (rows of aW1[1])
         const int jj = lane & 31, hh = lane >> 5;
         if (jj == N_E - 32) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rowmap(r, hh);
-                rec[G_B_PTS0 + 32 * w + row] = aW1[1][r];
-                if (w == 1 && row < N_CLASS) rec[G_B_SDF2 + row] = aRGB[0][r];
-                if (w == 1 && row >= 5 && row < 8) rec[G_B_RGB0 + row - 5] = aRGB[0][r];
-            }
+            for (int r = 0; r < 16; ++r) rec[G_B_PTS0 + 32 * w + rowmap(r, hh)] = aW1[1][r];
         }
     }
     // remaining bias partials: two column halves per row -> atomics inside the block's own record
