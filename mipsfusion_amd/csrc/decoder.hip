@@ -12,6 +12,13 @@
 //                          4 waves transposes 128 samples through LDS, each wave owns 11 of the 44 output
 //                          tiles and keeps them in registers across its whole share of the batch.
 //   decoder_wgrad_reduce   sum of the per-block partials, accumulated into the .grad tensors.
+//   (decoder_fwd_lds_kernel: persistent forward with the weight images in LDS for large batches; both forward
+//    kernels also exist as the SDF-only branch of MLP_reg.get_raw_sdf, see decoder_fwd_tile.)
+//
+// What these kernels are written around: a wave's vector instructions are NOT hidden behind its own
+// MFMAs (5.7 cycles of kernel time each at one wave per SIMD, 2.5 at two), so everything between the MFMAs is kept
+// to as few instructions as possible: scalar tile bases, buffer addressing, ReLU masks as bits, hardware sin/cos
+// after a two-constant range reduction, packed fp32 fma in the narrow heads, bias gradients from a ones row.
 //
 // Roofline: MFMA-bound.  72 370 FLOP/sample forward, 217 110 forward+backward; the three big layers
 // are 138 k-steps x 4 row tiles = 552 MFMAs (64 cycles each) per 32 samples forward.
@@ -149,51 +156,6 @@ __device__ __forceinline__ void buf_store_act_piece(srd_t sv, uint32_t lane16, i
     const int rt = q >> 2, g = q & 3;
     buf_store16(sv, lane16, (mat * 16 + q) * 1024,
                 make_float4(acc[rt][4 * g], acc[rt][4 * g + 1], acc[rt][4 * g + 2], acc[rt][4 * g + 3]));
-}
-
-__device__ __forceinline__ void store_act(float* __restrict__ dst, int64_t tile, int mat, int lane,
-                                          const f32x16 (&acc)[4]) {
-    float4* d4 = reinterpret_cast<float4*>(dst);
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            d4[(tile * (ACT_SLOTS / 4) + mat * 16 + rt * 4 + g) * 64 + lane] =
-                make_float4(acc[rt][4 * g], acc[rt][4 * g + 1], acc[rt][4 * g + 2], acc[rt][4 * g + 3]);
-}
-
-// 16-byte activation store (non-temporal stores were tried: no change)
-typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store16(float4* p, const float4& v) {
-    *p = v;
-}
-
-
-// group q in [0,16): row tile q>>2, registers 4*(q&3) .. +3
-__device__ __forceinline__ void store_act_piece(float* __restrict__ dst, int64_t tile, int mat, int lane,
-                                                const f32x16 (&acc)[4], int q) {
-    const int rt = q >> 2, g = q & 3;
-    store16(reinterpret_cast<float4*>(dst) + (tile * (ACT_SLOTS / 4) + mat * 16 + q) * 64 + lane,
-            make_float4(acc[rt][4 * g], acc[rt][4 * g + 1], acc[rt][4 * g + 2], acc[rt][4 * g + 3]));
-}
-
-__device__ __forceinline__ void load_act_piece(const float* __restrict__ src, int64_t tile, int mat, int lane,
-                                               f32x16 (&acc)[4], int q) {
-    const int rt = q >> 2, g = q & 3;
-    const float4 v = reinterpret_cast<const float4*>(src)[(tile * (ACT_SLOTS / 4) + mat * 16 + q) * 64 + lane];
-    acc[rt][4 * g] = v.x, acc[rt][4 * g + 1] = v.y, acc[rt][4 * g + 2] = v.z, acc[rt][4 * g + 3] = v.w;
-}
-
-__device__ __forceinline__ void load_act(const float* __restrict__ src, int64_t tile, int mat, int lane,
-                                         f32x16 (&acc)[4]) {
-    const float4* s4 = reinterpret_cast<const float4*>(src);
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 v = s4[(tile * (ACT_SLOTS / 4) + mat * 16 + rt * 4 + g) * 64 + lane];
-            acc[rt][4 * g] = v.x, acc[rt][4 * g + 1] = v.y, acc[rt][4 * g + 2] = v.z, acc[rt][4 * g + 3] = v.w;
-        }
 }
 
 // the 26 e values this lane feeds into layer 1 (its half of every k-step)
