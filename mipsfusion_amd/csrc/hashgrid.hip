@@ -208,7 +208,7 @@ constexpr uint32_t SC_SLICE_LOG2 = MIPSF_SC_SLICE_LOG2;   // slices of multi-sli
 #define MIPSF_SC_PART 24576
 #endif
 #ifndef MIPSF_SC_RUN
-#define MIPSF_SC_RUN 3
+#define MIPSF_SC_RUN 4
 #endif
 constexpr uint32_t SC_PART = MIPSF_SC_PART;           // records per accumulate workgroup
 constexpr uint32_t SC_RUN = MIPSF_SC_RUN;                   // consecutive records merged per thread in the accumulate kernel
