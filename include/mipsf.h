@@ -249,6 +249,26 @@ int mipsf_adam_step_multi_ex(const mipsf_adam_tensors* tensors_host_struct, floa
                              float eps, float weight_decay, uint32_t step, const float* hyper_dev, int zero_grad,
                              void* stream);
 
+/* A whole optimiser step in ONE launch when every tensor is tiny (the pose optimisers of tracking / local BA: a [K,4]
+ * and a [K,3] tensor in two param groups with their own lr): one workgroup advances each group's device step counter,
+ * refreshes its {lr/bc1, 1/sqrt(bc2)} pair and applies the step to all tensors -- three launches (advance + one
+ * multi-step per group) become one.  Arithmetic identical to mipsf_adam_advance_n + mipsf_adam_step_multi_ex. */
+#define MIPSF_ADAM_SMALL_MAX_NUMEL 16384
+typedef struct mipsf_adam_small {
+    uint32_t n_groups, n_tensors;
+    int32_t* step_dev[MIPSF_ADAM_MAX_GROUPS];
+    float* hyper_dev[MIPSF_ADAM_MAX_GROUPS];
+    float lr[MIPSF_ADAM_MAX_GROUPS], beta1[MIPSF_ADAM_MAX_GROUPS], beta2[MIPSF_ADAM_MAX_GROUPS];
+    float eps[MIPSF_ADAM_MAX_GROUPS], weight_decay[MIPSF_ADAM_MAX_GROUPS];
+    float* param[MIPSF_ADAM_MAX_TENSORS];
+    float* grad[MIPSF_ADAM_MAX_TENSORS];
+    float* exp_avg[MIPSF_ADAM_MAX_TENSORS];
+    float* exp_avg_sq[MIPSF_ADAM_MAX_TENSORS];
+    uint32_t numel[MIPSF_ADAM_MAX_TENSORS];
+    uint32_t group_of[MIPSF_ADAM_MAX_TENSORS];
+} mipsf_adam_small;
+int mipsf_adam_step_small(const mipsf_adam_small* desc_host_struct, int zero_grad, void* stream);
+
 /* -------------------------------------------------- RandomOptimizer fitness (a12) */
 /* sdf [P,n] (column 3 of run_network output, stride `sdf_stride` floats) , valid [n] ->
  * mean_masked[P] = mean_j(valid_j * |sdf*trunc|)  (RandomOptimizer.py:125-129) */

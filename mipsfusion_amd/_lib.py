@@ -49,6 +49,21 @@ class AdamTensors(C.Structure):
                 ("numel", C.c_uint64 * ADAM_MAX_TENSORS)]
 
 
+ADAM_MAX_GROUPS = 8
+ADAM_SMALL_MAX_NUMEL = 16384
+
+
+class AdamSmall(C.Structure):
+    _fields_ = [("n_groups", C.c_uint32), ("n_tensors", C.c_uint32),
+                ("step_dev", C.c_void_p * ADAM_MAX_GROUPS), ("hyper_dev", C.c_void_p * ADAM_MAX_GROUPS),
+                ("lr", C.c_float * ADAM_MAX_GROUPS), ("beta1", C.c_float * ADAM_MAX_GROUPS),
+                ("beta2", C.c_float * ADAM_MAX_GROUPS), ("eps", C.c_float * ADAM_MAX_GROUPS),
+                ("weight_decay", C.c_float * ADAM_MAX_GROUPS),
+                ("param", C.c_void_p * ADAM_MAX_TENSORS), ("grad", C.c_void_p * ADAM_MAX_TENSORS),
+                ("exp_avg", C.c_void_p * ADAM_MAX_TENSORS), ("exp_avg_sq", C.c_void_p * ADAM_MAX_TENSORS),
+                ("numel", C.c_uint32 * ADAM_MAX_TENSORS), ("group_of", C.c_uint32 * ADAM_MAX_TENSORS)]
+
+
 _P = C.c_void_p
 _U32, _U64, _I, _F, _D = C.c_uint32, C.c_uint64, C.c_int, C.c_float, C.c_double
 
@@ -94,6 +109,7 @@ SIGNATURES = {
     "mipsf_adam_step_ex": (_I, [_P, _P, _P, _P, _U64, _F, _F, _F, _F, _F, _U32, _P, _I, _P]),
     "mipsf_adam_step_multi_ex": (_I, [C.POINTER(AdamTensors), _F, _F, _F, _F, _F, _U32, _P, _I, _P]),
     "mipsf_adam_step_multi": (_I, [C.POINTER(AdamTensors), _F, _F, _F, _F, _F, _U32, _I, _P]),
+    "mipsf_adam_step_small": (_I, [C.POINTER(AdamSmall), _I, _P]),
     "mipsf_ro_fitness": (_I, [_P, _U32, _P, _F, _P, _U32, _U32, _P]),
     "mipsf_ro_fitness_sdf": (_I, [_P, _P, _F, _P, _U32, _U32, _I, _P]),
     "mipsf_ro_particles": (_I, [_P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _U32, _U32, _P]),

@@ -168,6 +168,38 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamMulti t, AdamK k_in
     }
 }
 
+// whole step of an optimiser with tiny tensors only: one workgroup = advance of every group + all element updates
+template <bool ZERO>
+__global__ __launch_bounds__(256) void adam_small_kernel(mipsf_adam_small d) {
+    __shared__ float hyp[MIPSF_ADAM_MAX_GROUPS][2];
+    if (threadIdx.x < d.n_groups) {
+        const uint32_t i = threadIdx.x;
+        const int t = d.step_dev[i][0] + 1;
+        d.step_dev[i][0] = t;
+        const double bc1 = 1.0 - pow((double)d.beta1[i], (double)t);
+        const double bc2 = 1.0 - pow((double)d.beta2[i], (double)t);
+        const float h0 = (float)((double)d.lr[i] / bc1), h1 = (float)(1.0 / sqrt(bc2));
+        hyp[i][0] = h0, hyp[i][1] = h1;
+        d.hyper_dev[i][0] = h0, d.hyper_dev[i][1] = h1;
+    }
+    __syncthreads();
+    for (uint32_t ti = 0; ti < d.n_tensors; ++ti) {
+        const uint32_t gi = d.group_of[ti];
+        AdamK k;
+        k.lr_over_bc1 = hyp[gi][0], k.inv_sqrt_bc2 = hyp[gi][1];
+        k.beta1 = d.beta1[gi], k.beta2 = d.beta2[gi];
+        k.one_minus_b1 = (float)(1.0 - (double)d.beta1[gi]), k.one_minus_b2 = (float)(1.0 - (double)d.beta2[gi]);
+        k.eps = d.eps[gi], k.wd = d.weight_decay[gi], k.dev_hyper = nullptr;
+        float *p = d.param[ti], *g = d.grad[ti], *m = d.exp_avg[ti], *v = d.exp_avg_sq[ti];
+        for (uint32_t i = threadIdx.x; i < d.numel[ti]; i += blockDim.x) {
+            float pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+            adam1(pp, gg, mm, vv, k);
+            p[i] = pp, m[i] = mm, v[i] = vv;
+            if (ZERO) g[i] = 0.f;
+        }
+    }
+}
+
 // ------------------------------------------------------ RandomOptimizer.get_fitness (RandomOptimizer.py:125-129)
 // one wave per particle: mean_j( (d_j > 0) * |sdf_pj * trunc| )
 // row of (particle, point) = particle * row_p + point * row_j, `stride` floats per row, SDF in column 3
@@ -326,6 +358,20 @@ int mipsf_adam_step_multi_ex(const mipsf_adam_tensors* t, float lr, float beta1,
     if (zero_grad) hipLaunchKernelGGL(adam_multi_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a, k);
     else hipLaunchKernelGGL(adam_multi_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a, k);
     return check_launch("adam_step_multi");
+}
+
+int mipsf_adam_step_small(const mipsf_adam_small* d, int zero_grad, void* stream) {
+    MIPSF_REQUIRE(d, "null descriptor");
+    MIPSF_REQUIRE(d->n_groups >= 1 && d->n_groups <= MIPSF_ADAM_MAX_GROUPS, "bad group count %u", d->n_groups);
+    MIPSF_REQUIRE(d->n_tensors >= 1 && d->n_tensors <= MIPSF_ADAM_MAX_TENSORS, "bad tensor count %u", d->n_tensors);
+    for (uint32_t i = 0; i < d->n_groups; ++i) MIPSF_REQUIRE(d->step_dev[i] && d->hyper_dev[i], "null pointer in group %u", i);
+    for (uint32_t i = 0; i < d->n_tensors; ++i) {
+        MIPSF_REQUIRE(d->param[i] && d->grad[i] && d->exp_avg[i] && d->exp_avg_sq[i], "null pointer in tensor %u", i);
+        MIPSF_REQUIRE(d->numel[i] <= MIPSF_ADAM_SMALL_MAX_NUMEL && d->group_of[i] < d->n_groups, "tensor %u out of range", i);
+    }
+    if (zero_grad) hipLaunchKernelGGL(adam_small_kernel<true>, dim3(1), dim3(256), 0, (hipStream_t)stream, *d);
+    else hipLaunchKernelGGL(adam_small_kernel<false>, dim3(1), dim3(256), 0, (hipStream_t)stream, *d);
+    return check_launch("adam_step_small");
 }
 
 int mipsf_ro_fitness(const float* raw, uint32_t raw_stride, const float* target_d, float trunc, float* mean_masked,

@@ -420,6 +420,24 @@ def adam_step_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps,
                   "adam_step_multi")
 
 
+def adam_step_small(groups, zero_grad=False):
+    """groups: list of (step_dev int32[1], hyper_dev float[2], lr, beta1, beta2, eps, weight_decay,
+    [(param, grad, exp_avg, exp_avg_sq), ...]) with tiny tensors only -- the whole optimiser step in one launch."""
+    d = _lib.AdamSmall()
+    d.n_groups = len(groups)
+    ti = 0
+    for gi, (step_dev, hyper_dev, lr, b1, b2, eps, wd, tensors) in enumerate(groups):
+        d.step_dev[gi], d.hyper_dev[gi] = dptr(step_dev, torch.int32), dptr(hyper_dev)
+        d.lr[gi], d.beta1[gi], d.beta2[gi], d.eps[gi], d.weight_decay[gi] = lr, b1, b2, eps, wd
+        for p, g, m, v in tensors:
+            d.param[ti], d.grad[ti], d.exp_avg[ti], d.exp_avg_sq[ti] = dptr(p), dptr(g), dptr(m), dptr(v)
+            d.numel[ti], d.group_of[ti] = p.numel(), gi
+            ti += 1
+    d.n_tensors = ti
+    with _timed("adam_step_small"):
+        check(lib().mipsf_adam_step_small(C.byref(d), 1 if zero_grad else 0, stream_ptr()), "adam_step_small")
+
+
 def ro_fitness(raw, target_d, trunc: float, point_major: bool = False) -> torch.Tensor:
     """raw [P,n,10] (run_network output) or [P,n,1] (SDF only; with point_major the memory order is [n,P] and raw is
     passed as sdf.view(P, n, 1) all the same), target_d [n] -> mean_masked_sdf [P] (RandomOptimizer.py:125-129)."""

@@ -7,7 +7,7 @@ p, g, m, v once (28 B per parameter with the fused zero-grad); a group's small t
 ``step()`` can be captured into a hipGraph (``torch.cuda.graph``) and replayed."""
 import torch
 
-from . import ops
+from . import _lib, ops
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -23,6 +23,12 @@ class FusedAdam(torch.optim.Optimizer):
             st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
         return st
+
+    @staticmethod
+    def _all_small(work):
+        n_t = sum(len(live) for _, _, live, _ in work)
+        return (len(work) <= _lib.ADAM_MAX_GROUPS and n_t <= _lib.ADAM_MAX_TENSORS and
+                all(p.numel() <= _lib.ADAM_SMALL_MAX_NUMEL for _, _, live, _ in work for p in live))
 
     @torch.no_grad()
     def reset(self):
@@ -65,6 +71,14 @@ class FusedAdam(torch.optim.Optimizer):
                                      torch.zeros(2, dtype=torch.float32, device=dev))
                 hyper = self._dev[gi][1]
             work.append((gi, group, live, hyper))
+        if self.capturable and work and self._all_small(work):
+            # an optimiser of tiny tensors only (pose optimisers): counters, bias corrections and every update in ONE
+            # launch instead of advance + one multi-tensor step per group
+            ops.adam_step_small([(self._dev[gi][0], self._dev[gi][1], group["lr"], group["betas"][0], group["betas"][1],
+                                  group["eps"], group["weight_decay"],
+                                  [(p.data, p.grad, self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"]) for p in live])
+                                 for gi, group, live, _ in work], zero_grad)
+            return loss
         if self.capturable and work:       # all groups' step counters / bias corrections in ONE launch
             adv = [(self._dev[gi][0], self._dev[gi][1], group["lr"], group["betas"][0], group["betas"][1])
                    for gi, group, _, _ in work]

@@ -495,6 +495,30 @@ def test_fused_adam_multi_tensor_group_vs_torch(dev):
         np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().numpy(), rtol=2e-5, atol=1e-8)
 
 
+def test_fused_adam_small_groups_one_launch(dev):
+    """Optimisers of tiny tensors only (the pose optimisers) take the one-launch path (device step counters, bias
+    corrections and all updates in one workgroup): two groups with their own lr / eps / weight decay against
+    torch.optim.Adam, and bit for bit against the multi-launch path (capturable=False)."""
+    torch.manual_seed(5)
+    r0, t0 = torch.randn(9, 4), torch.randn(9, 3)
+    mk = lambda dev_: (torch.nn.Parameter(r0.clone().to(dev_)), torch.nn.Parameter(t0.clone().to(dev_)))
+    (ra, ta), (rb, tb), (rc_, tc) = mk(dev), mk(dev), mk("cpu")
+    groups = lambda r, t: [{"params": r, "lr": 1e-3}, {"params": t, "lr": 1e-2, "eps": 1e-10, "weight_decay": 1e-4}]
+    oa = FusedAdam(groups(ra, ta), betas=(0.9, 0.99), capturable=True)
+    ob = FusedAdam(groups(rb, tb), betas=(0.9, 0.99), capturable=False)
+    oc = torch.optim.Adam(groups(rc_, tc), betas=(0.9, 0.99))
+    for _ in range(6):
+        gr, gt = torch.randn(9, 4), torch.randn(9, 3)
+        ra.grad, ta.grad = gr.clone().to(dev), gt.clone().to(dev)
+        rb.grad, tb.grad = gr.clone().to(dev), gt.clone().to(dev)
+        rc_.grad, tc.grad = gr.clone(), gt.clone()
+        oa.step(zero_grad=True), ob.step(), oc.step()
+        assert float(ra.grad.abs().max()) == 0.0 and float(ta.grad.abs().max()) == 0.0       # fused zero_grad
+    assert torch.equal(ra, rb) and torch.equal(ta, tb)
+    np.testing.assert_allclose(ra.detach().cpu().numpy(), rc_.detach().numpy(), rtol=2e-5, atol=1e-8)
+    np.testing.assert_allclose(ta.detach().cpu().numpy(), tc.detach().numpy(), rtol=2e-5, atol=1e-8)
+
+
 def test_fused_adam_reset_equals_fresh_optimizer(dev):
     """FusedAdam.reset() (in place, also under capturable=True) must continue exactly like a newly built
     torch.optim.Adam -- the reference rebuilds its pose optimiser every frame (mipsfusion.py:472-475)."""
