@@ -105,6 +105,7 @@ def build_submap(cfg, dev, seed):
     with torch.no_grad():
         model.embed_fn.params.copy_((torch.rand(model.embed_fn.params.shape, generator=g) * 2 - 1) * 1e-4)
     model = model.to(dev).train()
+    model.accumulate_param_grads_in_place = True      # plain loss.backward() loop: opt in (scene_rep._QueryFn)
     # keyframes on a small arc + the current frame
     frames, poses = [], []
     for k in range(5):

@@ -123,8 +123,8 @@ int mipsf_decoder_pack_host(const mipsf_decoder_weights* w_host_ptrs, float* pac
  * saved: nullable; when given, activations for backward are stored (mipsf_decoder_saved_floats(M)). */
 int mipsf_decoder_fwd(const float* packed, const float* feat, int feat_layout, const float* x,
                       const float* embed_pos, int pe_mode, float* out, float* saved, uint32_t M, void* stream);
-/* SDF branch only: MLP_reg.get_raw_sdf as reached through JointEncoding.query_sdf (model/decoder.py:60-72,
- * model/scene_rep.py:105-108; callers: RandomOptimizer.get_fitness RandomOptimizer.py:113-131, Mesher SDF grids).
+/* SDF column only: what JointEncoding.query_sdf keeps of MLP_reg.forward (model/scene_rep.py:106-107,
+ * model/decoder.py:53-75; callers: RandomOptimizer.get_fitness RandomOptimizer.py:113-131, Mesher SDF grids).
  * sdf: [M].  Bit-identical to column 3 of mipsf_decoder_fwd; layer 2 computes its sdf_emb half only, no rgb head. */
 int mipsf_decoder_fwd_sdf(const float* packed, const float* feat, int feat_layout, const float* x,
                           const float* embed_pos, int pe_mode, float* sdf, uint32_t M, void* stream);

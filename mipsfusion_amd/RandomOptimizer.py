@@ -84,7 +84,7 @@ class RandomOptimizer:
         # point-major sample order: a hash-grid wavefront = 64 particles' copies of one lattice point (same cells)
         xn, pst7 = ops.ro_particles(self.pre_sampled_particle, state, dirs, target_d, rc, point_major=_POINT_MAJOR)
         feat = ops.hashgrid_fwd(xn, model.embed_fn.params.detach(), model.embed_fn.meta, FEAT_LEVEL_MAJOR)
-        sdf = ops.decoder_fwd_sdf(packed, feat, FEAT_LEVEL_MAJOR, xn, None, P * n)      # the get_raw_sdf branch only
+        sdf = ops.decoder_fwd_sdf(packed, feat, FEAT_LEVEL_MAJOR, xn, None, P * n)      # SDF column only (scene_rep.py:106-107)
         mean_masked = ops.ro_fitness(sdf.view(P, n, 1), target_d, self.trunc_value, point_major=_POINT_MAJOR)
         ops.ro_update(mean_masked, pst7, state, self.sdf_weight, self.scaling_coefficient2)
         return mean_masked

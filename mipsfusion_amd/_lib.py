@@ -158,6 +158,11 @@ def dptr(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[int]:
         return None
     if not t.is_cuda:
         raise RuntimeError("mipsfusion_amd operators need GPU tensors (no CPU fallback exists)")
+    if t.device.index != torch._C._cuda_getDevice():
+        # launches go to the CURRENT device's current stream (stream_ptr): a tensor of another GPU would be a foreign
+        # pointer there.  One process per GPU with torch.cuda.set_device(local_rank) is the supported arrangement.
+        raise RuntimeError(f"tensor lives on cuda:{t.device.index} but the current device is "
+                           f"cuda:{torch._C._cuda_getDevice()}; wrap the call in torch.cuda.device(tensor.device)")
     if t.dtype != dtype:
         raise RuntimeError(f"expected {dtype}, got {t.dtype}")
     if not t.is_contiguous():

@@ -24,6 +24,13 @@ int check_launch(const char* what) {
     return 0;
 }
 
+int device_cus() {
+    static int cus[MAX_DEVICES] = {0};
+    const int d = device_slot();
+    if (cus[d] <= 0) cus[d] = mipsf_device_cu_count();
+    return cus[d];
+}
+
 }  // namespace mipsf
 
 extern "C" {

@@ -14,6 +14,17 @@ namespace mipsf {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// Per-device host-side caches (CU count, opted-in dynamic-LDS sizes): function attributes and device properties
+// belong to ONE device, a process may drive several.
+constexpr int MAX_DEVICES = 64;
+inline int device_slot() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES) return 0;
+    return d;
+}
+// CU count of the calling thread's current device (cached per device); <= 0 on error
+int device_cus();
+
 #define MIPSF_REQUIRE(cond, ...)                 \
     do {                                         \
         if (!(cond)) {                           \

@@ -13,7 +13,7 @@
 //                          tiles and keeps them in registers across its whole share of the batch.
 //   decoder_wgrad_reduce   sum of the per-block partials, accumulated into the .grad tensors.
 //   (decoder_fwd_lds_kernel: persistent forward with the weight images in LDS for large batches; both forward
-//    kernels also exist as the SDF-only branch of MLP_reg.get_raw_sdf, see decoder_fwd_tile.)
+//    kernels also exist in an SDF-only form (JointEncoding.query_sdf, scene_rep.py:106-107), see decoder_fwd_tile.)
 //
 // What these kernels are written around: a wave's vector instructions are NOT hidden behind its own
 // MFMAs (5.7 cycles of kernel time each at one wave per SIMD, 2.5 at two), so everything between the MFMAs is kept
@@ -204,7 +204,7 @@ __device__ __forceinline__ float load_feat(const float* __restrict__ feat, uint3
 
 // ================================================================================ forward
 // one wave, one tile of 32 samples; img1/2/3 = A-operand images of the three big layers (global or LDS)
-// SDF_ONLY: the branch of MLP_reg.get_raw_sdf / JointEncoding.query_sdf (decoder.py:60-72, scene_rep.py:105-108):
+// SDF_ONLY: what JointEncoding.query_sdf keeps of the decoder output (column 3, scene_rep.py:106-107; decoder.py:53-75):
 // layer 2 only produces its sdf_emb half (2 of 4 row tiles), no rgb head, no entropy; out = sdf [M].  This is what
 // RandomOptimizer.get_fitness and the mesher's SDF grid queries call -- 23 % fewer MFMAs, a tenth of the output.
 template <bool PE_INTERNAL, int LAYOUT, bool SAVE, bool SDF_ONLY = false>
@@ -1099,15 +1099,15 @@ static int decoder_fwd_launch(const float* packed, const float* feat, int feat_l
     const uint32_t n_tiles = (uint32_t)n_wave_tiles(M);
     const uint32_t blocks = (n_tiles + 3) / 4;
     hipStream_t s = (hipStream_t)stream;
-    static int cus = 0;
-    if (cus <= 0) cus = mipsf_device_cu_count();
+    const int cus = device_cus();
     if (cus <= 0) return 3;
     // persistent LDS-resident weights pay off once every CU has several rounds of tiles to amortise the 140 KB fill
     const bool persistent = n_tiles >= (uint32_t)cus * 8u * MIPSF_FWD_LDS_MIN_ROUNDS;
 #define FWD(PE, LAY, SV, SDF)                                                                                    \
     do {                                                                                                         \
         if (persistent) {                                                                                        \
-            static bool attr_set = false;                                                                        \
+            static bool attr_set_dev[MAX_DEVICES] = {false};                                                     \
+            bool& attr_set = attr_set_dev[device_slot()];                                                        \
             if (!attr_set) {                                                                                     \
                 if (hipFuncSetAttribute((const void*)decoder_fwd_lds_kernel<PE, LAY, SV, SDF>,                   \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS_BYTES) != hipSuccess) { \
@@ -1182,14 +1182,14 @@ int mipsf_decoder_wgrad(const float* feat, int feat_layout, const float* x, cons
     g.p[4] = grads->w_rgb0, g.p[5] = grads->b_rgb0, g.p[6] = grads->w_sdf0, g.p[7] = grads->b_sdf0;
     g.p[8] = grads->w_sdf2, g.p[9] = grads->b_sdf2;
     for (int k = 0; k < 10; ++k) MIPSF_REQUIRE(g.p[k] != nullptr, "null gradient pointer %d", k);
-    static int cus = 0;
-    if (cus <= 0) cus = mipsf_device_cu_count();
+    const int cus = device_cus();
     if (cus <= 0) return 3;
     uint32_t wg_blocks = n_bt < (uint32_t)cus ? n_bt : (uint32_t)cus;
     if (wg_blocks > WG_MAX_BLOCKS) wg_blocks = WG_MAX_BLOCKS;
 #define WG(PE, LAY)                                                                                              \
     do {                                                                                                         \
-        static bool attr_set = false;                                                                            \
+        static bool attr_set_dev[MAX_DEVICES] = {false};                                                         \
+        bool& attr_set = attr_set_dev[device_slot()];                                                            \
         if (!attr_set) {                                                                                         \
             if (hipFuncSetAttribute((const void*)decoder_wgrad_kernel<PE, LAY>,                                  \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES) != hipSuccess) {   \

@@ -813,7 +813,8 @@ int mipsf_hashgrid_bwd(const float* x, const float* params, const float* dout, f
         const uint32_t lds_bytes = max_slice * 16;
 #define SCATTER(LAY)                                                                                             \
     do {                                                                                                         \
-        static uint32_t attr_bytes = 0;                                                                          \
+        static uint32_t attr_bytes_dev[MAX_DEVICES] = {0};                                                       \
+        uint32_t& attr_bytes = attr_bytes_dev[device_slot()];                                                    \
         if (lds_bytes > attr_bytes) {                                                                            \
             if (hipFuncSetAttribute((const void*)hashgrid_scatter_kernel<LAY>,                                   \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {      \

@@ -55,8 +55,9 @@ __global__ __launch_bounds__(PR_BLOCK) void pose_rays_fwd_kernel(const float* __
     if (n >= N) return;
     int64_t p = owner[n];
     if (p < 0) p += F + K;                       // python-style negative index (local_BA uses -1 = current frame)
-    const Mat34 m = load_pose(fixed, rot, trans, F, (int)p);
-    const float dx = d_cam[3 * n], dy = d_cam[3 * n + 1], dz = d_cam[3 * n + 2];
+    const bool in_range = p >= 0 && p < F + K;   // a bad owner gives NaN rays instead of reading a foreign pose
+    const Mat34 m = load_pose(fixed, rot, trans, F, in_range ? (int)p : 0);
+    const float dx = in_range ? d_cam[3 * n] : __builtin_nanf(""), dy = d_cam[3 * n + 1], dz = d_cam[3 * n + 2];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         rays_d[3 * n + j] = (dx * m.r[3 * j] + dy * m.r[3 * j + 1]) + dz * m.r[3 * j + 2];
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(PR_BLOCK) void pose_rays_bwd_kernel(const float* __
     const uint32_t nn = valid ? n : N - 1;
     int64_t p = owner[nn];
     if (p < 0) p += P;
+    if (p < 0 || p >= P) p = 0;                  // forward already produced NaN rays for this owner
     float v[12];
     const float dx = d_cam[3 * nn], dy = d_cam[3 * nn + 1], dz = d_cam[3 * nn + 2];
 #pragma unroll

@@ -199,10 +199,13 @@ __global__ __launch_bounds__(256) void gather_rays_kernel(const float* __restric
     if (t >= N) return;
     int64_t r = idx[t];
     if (r < 0) r += (int64_t)n_rows;
-    const float* s = db + 7 * (size_t)r;
+    // the reference's torch indexing raises IndexError; a device-resident index cannot raise, so a row outside the
+    // database reads nothing and yields NaN rays (every loss of the iteration turns NaN: loud, never a foreign read)
+    const bool in_range = r >= 0 && (uint64_t)r < n_rows;
+    const float* s = db + 7 * (size_t)(in_range ? r : 0);
     float v[7];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) v[k] = s[k];
+    for (int k = 0; k < 7; ++k) v[k] = in_range ? s[k] : __builtin_nanf("");
     if (rays7) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) rays7[7 * (size_t)t + k] = v[k];

@@ -35,6 +35,11 @@ class DeviceRayDB:
         self.rays[kf_index].copy_(rays.reshape(self.num_rays_to_save, 7), non_blocking=True)
 
     def _gather(self, flat_idx: torch.Tensor):
+        n_rows = self.rays.shape[0] * self.rays.shape[1]
+        if flat_idx.numel() and not flat_idx.is_cuda:      # host index stream: check before it becomes an HBM address
+            lo, hi = int(flat_idx.min()), int(flat_idx.max())
+            if lo < -n_rows or hi >= n_rows:
+                raise IndexError(f"ray index out of range: [{lo}, {hi}] for a database of {n_rows} rows")
         return ops.gather_rays(self.rays, flat_idx.to(self.device, torch.int64, non_blocking=True))
 
     # ------------------------------------------------------------------ keyframeSet.py:268-275

@@ -59,8 +59,13 @@ class _NormaliseFn(torch.autograd.Function):
 
 class _QueryFn(torch.autograd.Function):
     """query_color_sdf (scene_rep.py:118-128) fused: hash grid (level-major features) -> decoder with the
-    frequency encoding computed in its prologue.  Parameter gradients are accumulated straight into ``.grad``
-    (dense 36 MB grid gradient: no extra zero-fill + add pass through autograd)."""
+    frequency encoding computed in its prologue.
+
+    Parameter gradients are returned through autograd by default (``torch.autograd.grad``, hooks, retain_graph and
+    partial backwards all behave as for any torch module).  ``JointEncoding.accumulate_param_grads_in_place = True``
+    (opt-in, used by bench.py and the captured training loops) makes the backward add them straight into ``.grad``
+    instead -- no 36 MB zero-fill + add pass per iteration -- which is only valid for plain ``loss.backward()``
+    accumulation loops; it is ignored for a parameter that is not a leaf or carries tensor hooks."""
 
     @staticmethod
     def forward(ctx, xn, owner, grid_params, *weights):
@@ -88,7 +93,8 @@ class _QueryFn(torch.autograd.Function):
         need_w = any(ctx.needs_input_grad[3:])
         need_g = ctx.needs_input_grad[2]
         need_x = ctx.needs_input_grad[0]
-        direct = ctx.owner.accumulate_param_grads_in_place
+        direct = ctx.owner.accumulate_param_grads_in_place and all(
+            p.is_leaf and not p._backward_hooks for p in (grid_params, *weights))
         # frozen parameters (requires_grad False, e.g. the map during tracking) skip their kernels entirely
         grads = None
         if need_w:
@@ -156,8 +162,8 @@ class JointEncoding(nn.Module):
         self.coords_norm_factor = coords_norm_factor
         self._bound64 = torch.as_tensor(bound_box).detach().to("cpu", torch.float64).tolist()
         self._half64 = torch.as_tensor(coords_norm_factor).detach().to("cpu", torch.float64).reshape(-1).tolist()
-        # extensions (defaults reproduce the reference's observable behaviour)
-        self.accumulate_param_grads_in_place = True
+        # extension, off by default: see _QueryFn (plain `loss.backward()` loops may opt in)
+        self.accumulate_param_grads_in_place = False
         self._tables = {}
         self.get_resolution()
         self.get_encoding(config)
@@ -225,7 +231,7 @@ class JointEncoding(nn.Module):
     # ---------------------------------------------------------------- queries (scene_rep.py:105-146)
     def query_sdf(self, query_points):
         """scene_rep.py:105-108.  Without autograd (mesher grids, fitness probes) only the SDF branch of the decoder
-        runs (MLP_reg.get_raw_sdf): same values as column 3 of query_color_sdf, bit for bit."""
+        runs (the `[..., 3:4]` slice of scene_rep.py:106-107 computed alone): same values as column 3 of query_color_sdf, bit for bit."""
         needs_grad = torch.is_grad_enabled() and (query_points.requires_grad or
                                                   any(p.requires_grad for p in self.parameters()))
         if needs_grad:

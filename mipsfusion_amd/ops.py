@@ -207,7 +207,7 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M):
 
 
 def decoder_fwd_sdf(packed, feat, layout, x, embed_pos, M) -> torch.Tensor:
-    """SDF branch only (MLP_reg.get_raw_sdf / JointEncoding.query_sdf): [M] floats, bit-identical to column 3 of
+    """SDF column only (JointEncoding.query_sdf, model/scene_rep.py:106-107): [M] floats, bit-identical to column 3 of
     decoder_fwd, without the rgb half of layer 2, the rgb head and nine tenths of the output."""
     sdf = torch.empty((M,), dtype=torch.float32, device=x.device)
     pe_mode = 0 if embed_pos is None else 1

@@ -43,6 +43,32 @@ class FusedAdam(torch.optim.Optimizer):
         for step_dev, _ in self._dev.values():
             step_dev.zero_()
 
+    # ---- checkpointing: with capturable=True the live step counters are the per-group device tensors (graph replays
+    # advance them without the host seeing it), so they are read back / re-seeded around (load_)state_dict
+    def _sync_steps_from_device(self):
+        for gi, (step_dev, _) in self._dev.items():
+            n = int(step_dev.item())
+            for p in self.param_groups[gi]["params"]:
+                if self.state.get(p):
+                    self.state[p]["step"] = n
+
+    def state_dict(self):
+        self._sync_steps_from_device()
+        return super().state_dict()
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for st in self.state.values():          # torch casts a saved int step to a tensor of the param's dtype
+            if st and torch.is_tensor(st.get("step")):
+                st["step"] = int(st["step"].item())
+        for gi, (step_dev, _) in self._dev.items():     # keep the tensors a captured graph reads, refresh their value
+            steps = {self.state[p]["step"] for p in self.param_groups[gi]["params"] if self.state.get(p)}
+            if len(steps) > 1:
+                raise RuntimeError(f"capturable FusedAdam: group {gi} has parameters at different steps {sorted(steps)}")
+            if steps:
+                step_dev.fill_(steps.pop())
+
     @torch.no_grad()
     def step(self, closure=None, zero_grad=False):
         """zero_grad=True (extension) clears each gradient in the same pass (the reference calls
@@ -64,6 +90,9 @@ class FusedAdam(torch.optim.Optimizer):
             hyper = None
             if self.capturable:
                 # one device-resident counter per group (all its tensors step together)
+                if len({self.state[p]["step"] for p in live}) > 1:
+                    raise RuntimeError(f"capturable FusedAdam: the parameters of group {gi} are at different steps "
+                                       "(some had no gradient in an earlier step); use capturable=False for that")
                 if gi not in self._dev:
                     dev = live[0].device
                     start = self.state[live[0]]["step"] - 1

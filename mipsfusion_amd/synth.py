@@ -106,6 +106,21 @@ def config_large_submap() -> dict:
     return c
 
 
+def config_scannet() -> dict:
+    """BASELINE config 5 workload: ScanNet scene0000_00 (configs/ScanNet/scannet.yaml, scene0000.yaml:4,21-22):
+    the scene bound, far = 7, S = 50 + 25, pose_accum_step 2, and the intrinsics AFTER the reference's floor-division
+    quirk (datasets/dataset.py:29-30: ``cfg["cam"]["fx"] // downsample`` floors 577.59 -> 577.0 etc.).  The reference
+    itself sets iter_RO 0 for ScanNet; the RandomOptimizer shape [2000, 16 x 24] is kept for the build-side
+    stress of the forward-only slice that BASELINE config 5 names."""
+    c = copy.deepcopy(_BASE)
+    c["cam"].update(fx=577.590698 // 1, fy=578.729797 // 1, cx=318.905426 // 1, cy=242.683609 // 1, far=7)
+    c["mapping"].update(bound=[[-0.1, 8.6], [-0.1, 8.9], [-0.3, 3.3]], localMLP_max_len=[7.0, 7.0, 4.0],
+                        pose_accum_step=2, map_every=3, iters=10, sample=2000, pixels_cur=500)
+    c["tracking"].update(iter_RO=0, iter=10, sample=1000, ignore_edge_W=20, ignore_edge_H=20)
+    c["tracking"]["RO"].update(initial_scaling_factor=0.02, rescaling_factor=0.5)
+    return c
+
+
 def intrinsics_after_crop(cfg: dict):
     cam = cfg["cam"]
     e = cam["crop_edge"]

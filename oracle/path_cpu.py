@@ -4,7 +4,7 @@ TEST INFRASTRUCTURE (checker + cpu_baseline only; never imported by the product)
 
 Pinned: every function here is compared, on seeded inputs, with the reference's own
 Python imported in the build container (oracle/ref_import.py) by
-tests/test_oracle_vs_reference.py, and the resulting vectors are committed under
+tests/test_oracle_golden.py (test_oracle_equals_live_reference_on_fresh_seed), and the resulting vectors are committed under
 tests/golden/ (generator: tests/golden/make_golden.py).  The hash-grid / frequency
 arithmetic underneath (oracle/tcnn_cpu.py) is third-party and *parity unpinned*.
 

@@ -440,7 +440,51 @@ def gen_checkpoint():
     print("ref_model_0.pth:", os.path.getsize(os.path.join(HERE, "ref_model_0.pth")) // 1024, "KiB")
 
 
+# ------------------------------------------------------------------- two-submap sequence (BASELINE config 3)
+def reference_backend():
+    """tests/seq_harness.py Backend over the REFERENCE's own classes (CPU)."""
+    import copy
+    import importlib
+    import types
+    KF = importlib.import_module("model.keyframeSet")
+    RO = importlib.import_module("RandomOptimizer")
+    gh = ref.geometry_helper
+
+    def make_model(cfg, bb, nf):
+        return ref.scene_rep.JointEncoding(cfg, bb, nf)
+
+    return types.SimpleNamespace(
+        device=torch.device("cpu"), make_model=make_model, deepcopy=copy.deepcopy, Adam=torch.optim.Adam,
+        sh=ref.sampling_helper, qt_to_transform_matrix=gh.qt_to_transform_matrix,
+        matrix_to_quaternion=gh.matrix_to_quaternion,
+        make_kfset=lambda cfg, H, W, n: KF.KeyframeSet(cfg, H, W, n, torch.device("cpu")),
+        make_ro=lambda cfg, slam: RO.RandomOptimizer(cfg, slam),
+        ro_optimize=lambda ro, model, depth, init, last, n: ro.optimize(model, depth, init, last, n_iter=n))
+
+
+def gen_sequence():
+    """tests/seq_harness.run_sequence over the reference's classes: index stream, loss trace, poses, both sub-maps'
+    final weights (mipsfusion.py:661-735 loop with a switch to a new sub-map and a switch back)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import seq_harness
+    out = seq_harness.run_sequence(reference_backend())
+    arrays = dict(losses=out["losses"], est=out["est"], tags=np.array(out["tags"]),
+                  idx_flat=torch.cat(out["idx"]), idx_len=np.array([t.numel() for t in out["idx"]]))
+    keep = ("decoder.pts_linear.0.weight", "decoder.sdf_linear.2.weight", "decoder.rgb_linear.0.bias", "embed_fn.params")
+    for sm, sd in out["models"].items():
+        for k in keep:
+            arrays[f"m{sm}.{k}"] = sd[k]
+    for k in keep[:2]:
+        arrays[f"copy.{k}"] = out["active_copy"][k]
+    save("sequence.npz", **arrays)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                       # python make_golden.py gen_sequence  -> only that fixture
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
+    gen_sequence()
     gen_sampler()
     gen_losses()
     gen_decoder()

@@ -885,7 +885,7 @@ def test_keyframe_ray_sampling_matches_reference_bit_for_bit(dev):
 
 
 def test_sdf_only_forward_is_column_3_bit_for_bit(dev):
-    """mipsf_decoder_fwd_sdf (MLP_reg.get_raw_sdf branch: half of layer 2, no rgb head) vs column 3 of the full
+    """mipsf_decoder_fwd_sdf (the query_sdf column, scene_rep.py:106-107: half of layer 2, no rgb head) vs column 3 of the full
     forward, on the small-batch kernel and on the persistent LDS kernel, ragged sizes; and JointEncoding.query_sdf
     (no-grad path) vs query_color_sdf."""
     torch.manual_seed(11)
@@ -993,3 +993,82 @@ def test_full_image_render_and_grid_queries(dev):
         assert_close(out, refq[:, sl], 1e-4, name)
     assert_close(inference.query_in_batches(m.query_color, grid.to(dev), batch_size=700), torch.sigmoid(refq[:, :3]),
                  1e-4, "query_color")
+
+
+def test_autograd_grad_and_partial_backward_with_trainable_params(dev):
+    """by default parameter gradients flow THROUGH autograd, so torch.autograd.grad(sdf, pts) with
+    trainable parameters leaves every .grad untouched, autograd.grad(loss, params) returns the gradients, tensor
+    hooks fire; the opt-in in-place accumulation gives the same .grad values for a plain backward()."""
+    g = load_golden("scene_cfg1.npz")
+    cfg = cfg_for("scene_cfg1.npz")
+    m = make_scene(g, cfg, dev).train()
+    assert m.accumulate_param_grads_in_place is False
+    pts = torch.rand(200, 3, device=dev, requires_grad=True)
+    sdf = m.query_sdf(pts)
+    (normals,) = torch.autograd.grad(sdf.sum(), pts)                 # eikonal / normal style call
+    assert normals.shape == pts.shape and torch.isfinite(normals).all() and normals.abs().max() > 0
+    assert all(p.grad is None for p in m.parameters()), "autograd.grad wrt the points must not touch parameter .grad"
+    inputs = [T(g[k]).to(dev) for k in ("rays_o", "rays_d", "target_rgb", "target_d", "noise")]
+    ret = m.forward(*inputs[:4], noise=inputs[4])
+    loss = path_cpu.total_loss(ret, cfg["training"])
+    params = [p for p in m.parameters() if p.numel()]
+    hits = []
+    h = m.embed_fn.params.register_hook(lambda gr: hits.append(float(gr.abs().sum())))
+    grads = torch.autograd.grad(loss, params, retain_graph=True)
+    assert all(gr is not None and torch.isfinite(gr).all() for gr in grads)
+    assert all(p.grad is None for p in params)
+    loss.backward()
+    h.remove()
+    assert len(hits) == 1 and hits[0] > 0, "tensor hook on the grid parameters fires on backward()"
+    for p, gr in zip(params, grads):
+        assert_grad_close(p.grad, gr, 1e-6, "backward() vs autograd.grad")
+    # opt-in in-place accumulation: same values
+    m2 = make_scene(g, cfg, dev).train()
+    m2.accumulate_param_grads_in_place = True
+    ret2 = m2.forward(*inputs[:4], noise=inputs[4])
+    path_cpu.total_loss(ret2, cfg["training"]).backward()
+    for p, q in zip(params, [q for q in m2.parameters() if q.numel()]):
+        assert_grad_close(q.grad, p.grad, 1e-6, "in-place accumulation vs autograd path")
+
+
+def test_out_of_range_ray_index_is_loud(dev):
+    """a bad keyframe id must not become a silent out-of-bounds read -- host index tensors raise
+    IndexError like the reference's torch indexing, device-resident indices yield NaN rays."""
+    from mipsfusion_amd.keyframe_rays import DeviceRayDB
+    db = DeviceRayDB(2, 10, dev)
+    db.store(0, torch.ones(10, 7))
+    with pytest.raises(IndexError):
+        db._gather(torch.tensor([0, 25]))
+    out = ops.gather_rays(db.rays, torch.tensor([3, 20, -1, -21], device=dev))
+    assert torch.isfinite(out[0]).all() and torch.isnan(out[1]).all() and torch.isfinite(out[2]).all() \
+        and torch.isnan(out[3]).all()
+    rot = torch.tensor([[1., 0, 0, 0]], device=dev)
+    ro_, rd_ = ops.pose_rays(rot, torch.zeros(1, 3, device=dev), None, torch.tensor([0, 1, -1, -2], device=dev),
+                             torch.ones(4, 3, device=dev))
+    assert torch.isfinite(rd_[0]).all() and torch.isnan(rd_[1]).all() and torch.isfinite(rd_[2]).all() \
+        and torch.isnan(rd_[3]).all()
+
+
+def test_fused_adam_capturable_state_dict_roundtrip(dev):
+    """with capturable=True the live step counter is a device tensor; state_dict() must carry it and
+    load_state_dict() must restore it (bias correction after a restore equals an uninterrupted run)."""
+    torch.manual_seed(0)
+    p0 = torch.randn(5000, device=dev)
+    grads = [torch.randn(5000, device=dev) for _ in range(6)]
+
+    def run(n_first, reload):
+        p = torch.nn.Parameter(p0.clone())
+        opt = FusedAdam([p], lr=1e-2, betas=(0.9, 0.99), capturable=True)
+        for k in range(n_first):
+            p.grad = grads[k].clone()
+            opt.step()
+        if reload:
+            sd = opt.state_dict()
+            assert sd["state"][0]["step"] == n_first
+            opt = FusedAdam([p], lr=1e-2, betas=(0.9, 0.99), capturable=True)
+            opt.load_state_dict(sd)
+        for k in range(n_first, 6):
+            p.grad = grads[k].clone()
+            opt.step()
+        return p.detach().clone()
+    assert torch.equal(run(3, False), run(3, True))

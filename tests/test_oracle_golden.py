@@ -290,3 +290,87 @@ def test_random_optimizer_restatement_matches_reference():
         pose, trace = ro_cpu.optimize(m.run_network, pst, rows, cols, depth, rays_dir, init, n_iter, c1, c2, trunc)
         close(pose, g[f"pose_after_{n_iter}"], rtol=1e-4, atol=2e-6)
         assert len(trace) == n_iter
+
+
+# --------------------------------------------------------------------- BASELINE config 3 in miniature (CPU)
+def oracle_backend():
+    """tests/seq_harness.py Backend over the ORACLE (path_cpu.CpuScene, ro_cpu, p3d_cpu) and the product's
+    host-side samplers / keyframe-ray index logic (CPU tensors only; nothing is launched)."""
+    import copy
+    import types
+    from oracle import ro_cpu
+    from mipsfusion_amd.helper_functions import sampling_helper as sh
+
+    class OracleModel(path_cpu.CpuScene):
+        def __init__(self, cfg, bb, nf):
+            super().__init__(cfg, bb, nf)
+            self.initial_dict = copy.deepcopy(self.state_dict())
+
+        def recover_initial_param(self):
+            self.load_state_dict(self.initial_dict)
+
+        def forward(self, rays_o, rays_d, target_rgb, target_d, EMD_w=0.01):
+            S = self.cfg["training"]["n_samples_d"] + self.cfg["training"]["n_range_d"]
+            return self.train_forward(rays_o, rays_d, target_rgb, target_d, torch.rand(rays_o.shape[0], S), EMD_w)
+
+    class KfSet:      # model/keyframeSet.py:25, 76-79, 170-175, 386-455 on CPU tensors
+        def __init__(self, cfg, H, W, num_kf):
+            s = cfg["sampling"]
+            self.rows, self.cols = sh.sample_pixels_uniformly(H, W, s["kf_n_rays_h"], s["kf_n_rays_w"])
+            self.R = s["kf_n_rays_h"] * s["kf_n_rays_w"]
+            self.rays = torch.zeros(num_kf, self.R, 7)
+            self.n = 0
+
+        def add_keyframe(self, frame):
+            rays = torch.cat([frame["direction"], frame["rgb"], frame["depth"][..., None]], -1)
+            self.rays[self.n] = rays[self.rows, self.cols]
+            self.n += 1
+
+        def _db(self):
+            from mipsfusion_amd.keyframe_rays import DeviceRayDB
+            db = DeviceRayDB.__new__(DeviceRayDB)
+            db.num_rays_to_save, db.device, db.rays = self.R, torch.device("cpu"), self.rays
+            db._gather = lambda flat: self.rays.reshape(-1, 7)[flat]       # the gather kernel's job, on the host
+            return db
+
+        def sample_rays_in_submap(self, *a):
+            return self._db().sample_rays_in_submap(*a)
+
+        def sample_rays_in_given_kf(self, *a):
+            return self._db().sample_rays_in_given_kf(*a)
+
+    def make_ro(cfg, slam):
+        r = cfg["tracking"]["RO"]
+        pst = torch.from_numpy(np.random.multivariate_normal(np.zeros(6), np.eye(6), r["particle_size"]).astype(np.float32))
+        pst[0, :] = 0
+        rows, cols = sh.sample_pixels_uniformly(slam.dataset.H, slam.dataset.W, r["n_rows"], r["n_cols"])
+        return types.SimpleNamespace(pst=torch.clamp(pst, -2., 2.), rows=rows, cols=cols, dirs=slam.dataset.rays_d,
+                                     c1=r["initial_scaling_factor"], c2=r["rescaling_factor"], trunc=cfg["training"]["trunc"])
+
+    def ro_optimize(ro, model, depth, init, last, n):
+        return ro_cpu.optimize(model.run_network, ro.pst, ro.rows, ro.cols, depth, ro.dirs, init, n, ro.c1, ro.c2,
+                               ro.trunc)[0]
+
+    return types.SimpleNamespace(
+        device=torch.device("cpu"), make_model=OracleModel, deepcopy=copy.deepcopy, Adam=torch.optim.Adam, sh=sh,
+        qt_to_transform_matrix=p3d_cpu.qt_to_transform_matrix if hasattr(p3d_cpu, "qt_to_transform_matrix") else None,
+        matrix_to_quaternion=p3d_cpu.matrix_to_quaternion, make_kfset=KfSet, make_ro=make_ro, ro_optimize=ro_optimize)
+
+
+def test_two_submap_sequence_oracle_matches_reference_run():
+    """The oracle + the product's HOST logic (pixel samplers, keyframe-ray index generation) driven through the
+    config-3 loop of tests/seq_harness.py reproduce the run over the reference's own classes (sequence.npz):
+    index stream bit for bit, losses and poses to fp32 round-off."""
+    from mipsfusion_amd.helper_functions import geometry_helper as gh
+    from . import seq_harness
+    g = load_golden("sequence.npz")
+    B = oracle_backend()
+    B.qt_to_transform_matrix = gh.qt_to_transform_matrix
+    out = seq_harness.run_sequence(B)
+    assert list(out["tags"]) == [str(t) for t in g["tags"]]
+    assert np.array_equal(torch.cat(out["idx"]).numpy(), g["idx_flat"])
+    np.testing.assert_allclose(out["losses"], g["losses"], rtol=2e-3)
+    np.testing.assert_allclose(out["est"], g["est"], atol=2e-4)
+    for sm in (0, 1):
+        close(out["models"][sm]["decoder.sdf_linear.2.weight"], g[f"m{sm}.decoder.sdf_linear.2.weight"], rtol=2e-2,
+              atol=2e-3)

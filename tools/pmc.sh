@@ -9,7 +9,7 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU
            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32"; do
   i=$((i+1))
-  rm -rf /tmp/pmc_$TAG_$i
+  rm -rf /tmp/pmc_${TAG}_$i
   timeout 300 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d /tmp/pmc_${TAG}_$i -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --setup-iters 4 --cpu-rays 0 --no-frame-estimate > $OUT/pass$i.log 2>&1
   echo "pass $i ($SET) rc=$?"
   f=$(find /tmp/pmc_${TAG}_$i -name "*counter_collection.csv" | head -1)

@@ -78,6 +78,7 @@ def main():
     bb = torch.from_numpy(np.array(mp["bound"]))
     nf = torch.from_numpy(np.array(mp["localMLP_max_len"]))
     model = JointEncoding(cfg, bb, nf).to(dev).train()
+    model.accumulate_param_grads_in_place = True
     gt = trajectory(cfg, a.frames)
     frames = [synth.make_frame(cfg, gt[k], seed=k, frame_id=k) for k in range(a.frames)]
     ds = types.SimpleNamespace(H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy, rays_d=frames[0]["direction"])
@@ -247,6 +248,7 @@ def main_graphed(a):
     bb = torch.from_numpy(np.array(mp["bound"]))
     nf = torch.from_numpy(np.array(mp["localMLP_max_len"]))
     model = JointEncoding(cfg, bb, nf).to(dev).train()
+    model.accumulate_param_grads_in_place = True
     gt = trajectory(cfg, a.frames)
     frames = [synth.make_frame(cfg, gt[k], seed=k, frame_id=k) for k in range(a.frames)]
     host_rays = [frame_rays(f).pin_memory() for f in frames]      # what a capture thread would hand over
