@@ -360,6 +360,90 @@ def frame_estimate(cfg, model, loop, dev, ba_ms, stream=None):
             "formula": "iter_RO*ro + tracking.iter*go + mapping.iters*ba/map_every (FastCaMo-synth cadence 5/10/15/3)"}
 
 
+def multi_gpu_checks(cfg, model, dev, rank, world):
+    """N > 1 only (every rank calls this): the two other shardings of SURVEY 8e, exercised over the real process group.
+    (row 3) RandomOptimizer particle split: a replica of one sub-map on every rank, 2000 particles / world per rank, one
+    all_gather of [2000, 8] per round -- must reproduce the unsplit pose exactly.  (row 1) cross-sub-map global BA
+    (InactiveMap.py:375-474) over the ranks' OWN sub-maps: prediction-table all-reduce + the (n-1) x 7 pose-gradient
+    all-reduce per pose step -- every rank must end with the same anchors."""
+    import types
+    import torch.distributed as dist
+    from mipsfusion_amd.RandomOptimizer import RandomOptimizer
+    from mipsfusion_amd.global_ba import PairTerm, ShardedGlobalBA, frozen, model_query
+    out = {}
+    # ---- row 3: particle split
+    rcfg = cfg["tracking"]["RO"]
+    rcfg.setdefault("initial_scaling_factor", 0.02)
+    rcfg.setdefault("rescaling_factor", 0.5)
+    cfg["tracking"].setdefault("ignore_edge_W", 20), cfg["tracking"].setdefault("ignore_edge_H", 20)
+    H, W, fx, fy, cx, cy = synth.intrinsics_after_crop(cfg)
+    frame = synth.make_frame(cfg, seed=1)
+    ds = types.SimpleNamespace(H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy, rays_d=frame["direction"])
+    replica, _, _ = build_submap(cfg, dev, seed=0)              # the same sub-map on every rank
+    replica.eval()
+    np.random.seed(0)
+    ro = RandomOptimizer(cfg, types.SimpleNamespace(dataset=ds, device=dev))
+    init = frame["c2w"].clone()
+    init[:3, 3] += torch.tensor([0.02, -0.015, 0.01])
+    n_ro = max(1, cfg["tracking"]["iter_RO"])
+
+    def timed_ro(split):
+        ro.particle_split = split
+        for _ in range(2):
+            pose = ro.optimize(replica, frame["depth"], init, None, n_iter=n_ro)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            pose = ro.optimize(replica, frame["depth"], init, None, n_iter=n_ro)
+        torch.cuda.synchronize()
+        return pose, (time.perf_counter() - t0) / 5 / n_ro * 1e3
+    pose_one, ms_one = timed_ro(False)
+    pose_split, ms_split = timed_ro(True)
+    out["ro_round_ms_unsplit"] = round(mdist.max_over_ranks(ms_one, dev), 4)
+    out["ro_round_ms_particle_split"] = round(mdist.max_over_ranks(ms_split, dev), 4)
+    out["ro_split_pose_equals_unsplit"] = bool(torch.equal(pose_one, pose_split))
+    out["ro_particles_per_rank"] = ro.particle_size // world
+    del replica
+    # ---- row 1: global BA over the ranks' own sub-maps (sub-map id = rank), chain of adjacent pairs
+    anchors = torch.eye(4, device=dev)[None].repeat(world, 1, 1)
+    for s in range(1, world):
+        anchors[s, :3, 3] = torch.tensor([0.03 * s, -0.02 * s, 0.01 * s], device=dev)
+    g = torch.Generator().manual_seed(1234)                     # the same term batches on every rank
+    bs = max(cfg["mapping"]["sample"] // max(1, world - 1), cfg["mapping"]["sample"] // 4)
+    f7 = torch.cat([frame["direction"], frame["rgb"], frame["depth"][..., None]], -1).reshape(-1, 7)
+    n_iter = 20                                                 # InactiveMap.py:408
+    batches = []
+    for _ in range(n_iter):
+        terms = []
+        for i in range(world - 1):
+            idx = torch.randint(0, f7.shape[0], (bs,), generator=g)
+            terms.append(PairTerm(i, i + 1, f7[idx].to(dev), frame["c2w"][None].to(dev), 5.0))
+        batches.append(terms)
+    model.eval()
+    with frozen([model]):
+        ba = ShardedGlobalBA(model_query({rank: model}), [rank], anchors, cfg["training"]["trunc"],
+                             cfg["mapping"]["lr_rot"], cfg["mapping"]["lr_trans"], cfg["mapping"]["pose_accum_step"])
+        ba.iteration(batches[0])
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for terms in batches[1:]:
+            loss = ba.iteration(terms)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / (n_iter - 1) * 1e3
+    model.train()
+    res = ba.result()
+    spread = mdist.exchange_poses(res[:, :3, :3].reshape(world, 9)[:, :4], res[:, :3, 3])   # any 7 numbers per anchor
+    out["global_ba_iter_ms"] = round(mdist.max_over_ranks(ms, dev), 4)
+    out["global_ba_final_loss"] = float(loss)
+    out["global_ba_anchor_spread_over_ranks"] = float((spread - spread[0:1]).abs().max())
+    out["global_ba_anchors_moved"] = bool((res[1:] - anchors[1:]).abs().max() > 1e-5)
+    out["global_ba_collectives_per_pose_step"] = (f"{cfg['mapping']['pose_accum_step']} x all_reduce[{world - 1} pairs, 2, {bs}] "
+                                                  f"+ 1 x all_reduce[{world - 1} x 7]")
+    return out
+
+
 def cpu_baseline(cfg, loop, n_rays, iters):
     """The oracle (torch-CPU restatement of the reference path, oracle/path_cpu.py) on a bounded sample."""
     from oracle import path_cpu
@@ -495,6 +579,7 @@ def main():
         elapsed = time.perf_counter() - t0
         log(f"graph timed region: {args.steps} steps in {elapsed * 1e3:.1f} ms")
     elapsed = mdist.max_over_ranks(elapsed, dev)
+    multi = multi_gpu_checks(cfg, model, dev, rank, world) if world > 1 else None
 
     if rank != 0:
         dist.barrier()              # rank 0 finishes its untimed extras, then everybody leaves together
@@ -549,6 +634,8 @@ def main():
         log("frame estimate done")
         out["inference"] = inference_rates(cfg, model, dev)
         log("inference consumers done")
+    if multi is not None:
+        out["multi_gpu"] = multi
     if world == 1 and args.cpu_rays > 0:
         out["cpu_baseline"] = cpu_baseline(cfg, loop, args.cpu_rays, args.cpu_iters)
     print(json.dumps(out), flush=True)

@@ -10,6 +10,7 @@ round.  The small helper methods keep their reference semantics for callers that
 import numpy as np
 import torch
 
+from . import dist as mdist
 from . import ops
 from ._lib import FEAT_LEVEL_MAJOR
 from .helper_functions.geometry_helper import quaternion_to_matrix
@@ -32,6 +33,8 @@ class RandomOptimizer:
         self.scaling_coefficient2 = ro["rescaling_factor"]
         self.sdf_weight = 1000.
         self.trunc_value = cfg["training"]["trunc"]
+        # extension: split the swarm over the ranks of the default process group (each holds a replica of the sub-map)
+        self.particle_split = False
 
         # particle swarm template, same draw as RandomOptimizer.py:26-33 (numpy global RNG)
         pst = np.random.multivariate_normal(np.zeros(6), np.eye(6), self.particle_size).astype(np.float32)
@@ -78,14 +81,26 @@ class RandomOptimizer:
         return (self.scaling_coefficient2 * mean_pred_sdf * s / s.norm() + 0.0001)[None, ...]
 
     # ------------------------------------------------------------------------------------------ the fused loop
-    def _enqueue_round(self, model, state, target_d, dirs, rc, packed):
-        """One round (RandomOptimizer.py:177-224) on the current stream; no host synchronisation."""
-        P, n = self.particle_size, dirs.shape[0]
+    def _enqueue_round(self, model, state, target_d, dirs, rc, packed, group=None):
+        """One round (RandomOptimizer.py:177-224) on the current stream; no host synchronisation.
+
+        With ``self.particle_split`` and an initialised process group the swarm is cut into contiguous shares
+        (SURVEY 8e row 3): every rank holds a replica of the sub-map, evaluates its share's fitness, one all_gather
+        (RCCL) reassembles [P, 8] = (mean masked |sdf|, 7-D pose) and every rank applies the identical update --
+        fitness values are per-particle quantities, so the result equals the unsplit round bit for bit."""
+        P_all, n = self.particle_size, dirs.shape[0]
+        rank, world = mdist.rank_world(group) if self.particle_split else (0, 1)
+        lo, hi = mdist.share_of(P_all, rank, world)
+        P = hi - lo
+        pst = self.pre_sampled_particle if world == 1 else self.pre_sampled_particle[lo:hi]
         # point-major sample order: a hash-grid wavefront = 64 particles' copies of one lattice point (same cells)
-        xn, pst7 = ops.ro_particles(self.pre_sampled_particle, state, dirs, target_d, rc, point_major=_POINT_MAJOR)
+        xn, pst7 = ops.ro_particles(pst, state, dirs, target_d, rc, point_major=_POINT_MAJOR)
         feat = ops.hashgrid_fwd(xn, model.embed_fn.params.detach(), model.embed_fn.meta, FEAT_LEVEL_MAJOR)
         sdf = ops.decoder_fwd_sdf(packed, feat, FEAT_LEVEL_MAJOR, xn, None, P * n)      # SDF column only (scene_rep.py:106-107)
         mean_masked = ops.ro_fitness(sdf.view(P, n, 1), target_d, self.trunc_value, point_major=_POINT_MAJOR)
+        if world > 1:
+            rows = mdist.gather_particle_results(torch.cat([mean_masked[:, None], pst7], 1), P_all, group)
+            mean_masked, pst7 = rows[:, 0].contiguous(), rows[:, 1:].contiguous()
         ops.ro_update(mean_masked, pst7, state, self.sdf_weight, self.scaling_coefficient2)
         return mean_masked
 

@@ -11,6 +11,34 @@ import torch
 import torch.distributed as dist
 
 
+def share_of(n: int, rank: int, world: int):
+    """Contiguous share [begin, end) of n items for `rank` of `world` (sizes differ by at most one)."""
+    base, extra = divmod(n, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def rank_world(group=None):
+    """(rank, world) of the default / given process group; (0, 1) when torch.distributed is not initialised."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def all_reduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place SUM all-reduce of a small tensor (pose gradients, prediction tables).  RCCL on GPU tensors; with the
+    gloo debugging backend a GPU tensor takes a host round trip.  No-op without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return t
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def submaps_of_rank(n_submaps: int, world: int, rank: int) -> List[int]:
     """Round-robin ownership (the reference's inactive-map loop is round-robin too, InactiveMap.py:207-210)."""
     return [s for s in range(n_submaps) if s % world == rank]
@@ -59,3 +87,14 @@ def all_gather_ragged(mine: torch.Tensor, n_total: int, world: int, group=None) 
     dist.all_gather(out, pad, group=group)
     parts = [out[r][:base + (1 if r < extra else 0)] for r in range(world)]
     return torch.cat(parts, 0).to(dev)
+
+
+def gather_particle_results(local_rows: torch.Tensor, n_particles: int, group=None) -> torch.Tensor:
+    """RandomOptimizer particle split (RandomOptimizer.py:113-131, 196-224): every rank evaluated the
+    fitness of its contiguous share of the swarm (`share_of(n_particles, rank, world)`), `local_rows` = [share, C]
+    (mean masked |sdf| and the 7-D particle pose per particle); -> [n_particles, C] on every rank, in particle order,
+    so that every rank performs the identical swarm update.  One all_gather of n_particles*C floats (64 KB at 2000 x 8)."""
+    rank, world = rank_world(group)
+    if world == 1:
+        return local_rows
+    return all_gather_ragged(local_rows.contiguous(), n_particles, world, group=group)

@@ -23,11 +23,7 @@ def rays_camera_to_world(rays_d_cam: torch.Tensor, c2w: torch.Tensor) -> Tuple[t
     return rays_d, rays_o
 
 
-def share_of(n: int, rank: int, world: int) -> Tuple[int, int]:
-    """Contiguous share [begin, end) of n items for `rank` of `world` (sizes differ by at most one)."""
-    base, extra = divmod(n, world)
-    begin = rank * base + min(rank, extra)
-    return begin, begin + base + (1 if rank < extra else 0)
+share_of = mdist.share_of
 
 
 @torch.no_grad()

@@ -218,7 +218,11 @@ class JointEncoding(nn.Module):
         return _QueryFn.apply(x32, self, self.embed_fn.params, *self.decoder.ordered_parameters())
 
     def __deepcopy__(self, memo):
-        new = JointEncoding(self.config, self.bounding_box, self.coords_norm_factor)
+        # a copy must not advance the CPU RNG (the constructor's nn.Linear initialisation would): the reference's
+        # copy.deepcopy(model) (InactiveMap.py:67,81,107) draws nothing, and every later pixel-sampling call depends
+        # on the generator state
+        with torch.random.fork_rng(devices=[]):
+            new = JointEncoding(self.config, self.bounding_box, self.coords_norm_factor)
         memo[id(self)] = new
         dev = self.embed_fn.params.device
         new.to(dev)

@@ -68,3 +68,104 @@ def test_single_process_is_a_noop():
     assert out.shape == (1, 3, 7)
     assert mdist.max_over_ranks(2.0, torch.device("cpu")) == 2.0
     assert mdist.submaps_of_rank(5, 1, 0) == [0, 1, 2, 3, 4]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SURVEY 8e rows 1 and 3 (VERDICT r1 missing-2): sharded cross-sub-map global BA with the (n-1) x 7 pose-gradient
+# all-reduce, and the RandomOptimizer particle split.  The arithmetic core of mipsfusion_amd.global_ba is plain torch
+# and its network query is injected, so the collective logic runs here on CPU tensors with the ORACLE's sub-map models.
+def _gba_problem(seed=0, n_sub=3, n_iter=4, bs=48):
+    """Three small sub-maps (hash 2^10) with perturbed anchors, pair terms (0,1), (1,2) + one loop-closing term."""
+    import numpy as np
+    from mipsfusion_amd import synth
+    from oracle import path_cpu
+    cfg = synth.config_plumbing()
+    g = torch.Generator().manual_seed(seed)
+    models = []
+    for s in range(n_sub):
+        torch.manual_seed(100 + s)
+        m = path_cpu.CpuScene(cfg, cfg["mapping"]["bound"], cfg["mapping"]["localMLP_max_len"])
+        with torch.no_grad():
+            m.embed_fn.params.copy_(torch.randn(m.embed_fn.params.shape, generator=g) * 0.3)
+        models.append(m)
+    anchors = torch.eye(4)[None].repeat(n_sub, 1, 1)
+    for s in range(1, n_sub):
+        anchors[s] = synth.default_pose(cfg, yaw=0.1 * s, pitch=0.02 * s)
+        anchors[s, :3, 3] = torch.tensor([0.2 * s, -0.1 * s, 0.05 * s])
+    f = synth.make_frame(cfg, seed=3)
+    H, W = f["depth"].shape
+    batches = []
+    for it in range(n_iter):
+        terms = []
+        for (i, j) in ((0, 1), (1, 2)):
+            idx = torch.randint(0, H * W, (bs,), generator=g)
+            r, c = idx // W, idx % W
+            rays = torch.cat([f["direction"][r, c], f["rgb"][r, c], f["depth"][r, c][:, None]], -1)
+            kf = anchors[j][None].repeat(bs, 1, 1).clone()
+            kf[:, :3, 3] += 0.01 * torch.randn(bs, 3, generator=g)
+            terms.append((i, j, rays, kf, 5.0, None))
+        idx = torch.randint(0, H * W, (bs // 2,), generator=g)
+        r, c = idx // W, idx % W
+        rays = torch.cat([f["direction"][r, c], f["rgb"][r, c], f["depth"][r, c][:, None]], -1)
+        mask = (torch.rand(bs // 2, 1, generator=g) > 0.3).float()
+        terms.append((2, 0, rays, anchors[2][None].clone(), 100.0, mask))          # get_SDF_dif2-style term
+        batches.append(terms)
+    return cfg, models, anchors, batches
+
+
+def _gba_run(models, anchors, batches, trunc, owned, accum, group=None):
+    from mipsfusion_amd.global_ba import PairTerm, ShardedGlobalBA
+    ba = ShardedGlobalBA(lambda sid, pts: models[sid].run_network(pts)[..., 3], owned, anchors, trunc,
+                         pose_accum_step=accum, group=group)
+    trace = []
+    for terms in batches:
+        trace.append(float(ba.iteration([PairTerm(i, j, rays, kf, w, mask) for (i, j, rays, kf, w, mask) in terms])))
+    return ba.result(), trace
+
+
+def _gba_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        cfg, models, anchors, batches = _gba_problem()
+        owned = mdist.submaps_of_rank(len(models), world, rank)                 # rank 0: {0, 2}, rank 1: {1}
+        poses, trace = _gba_run(models, anchors, batches, cfg["training"]["trunc"], owned, accum=2)
+        # particle split (row 3): each rank contributes its share of [P, 8] rows
+        P = 11
+        lo, hi = mdist.share_of(P, rank, world)
+        rows = torch.arange(P * 8, dtype=torch.float32).reshape(P, 8)
+        full = mdist.gather_particle_results(rows[lo:hi].clone(), P)
+        q.put((rank, poses.numpy().copy(), trace, full.numpy().copy(), sorted(owned)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_global_ba_world2_equals_single_process_and_oracle():
+    """World-2 sharded global BA (prediction-table + (n-1)x7 pose-gradient all-reduces) == the single-process run of
+    the same class == oracle/global_ba_cpu.py's restatement of InactiveMap.global_BA_overlapping."""
+    from oracle import global_ba_cpu
+    cfg, models, anchors, batches = _gba_problem()
+    trunc = cfg["training"]["trunc"]
+    ref_poses, ref_trace = global_ba_cpu.optimise(models, anchors, batches, trunc, pose_accum_step=2)
+    one_poses, one_trace = _gba_run(models, anchors, batches, trunc, owned=range(len(models)), accum=2)
+    assert torch.allclose(one_poses, ref_poses, atol=1e-6) and torch.allclose(torch.tensor(one_trace),
+                                                                             torch.tensor(ref_trace), rtol=1e-5)
+    assert not torch.allclose(ref_poses[1:], anchors[1:], atol=1e-4), "the anchors must actually move"
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gba_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][4] == [0, 2] and res[1][4] == [1]
+    for rank, poses, trace, full, _ in res:
+        assert torch.allclose(torch.from_numpy(poses), ref_poses, atol=2e-6), f"rank {rank} anchors"
+        assert torch.allclose(torch.tensor(trace), torch.tensor(ref_trace), rtol=1e-5), f"rank {rank} loss trace"
+        assert torch.equal(torch.from_numpy(full), torch.arange(88, dtype=torch.float32).reshape(11, 8))
+    assert (res[0][1] == res[1][1]).all(), "every rank must hold bit-identical anchors (same all-reduced gradient)"

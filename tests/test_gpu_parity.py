@@ -1012,11 +1012,11 @@ def test_autograd_grad_and_partial_backward_with_trainable_params(dev):
     ret = m.forward(*inputs[:4], noise=inputs[4])
     loss = path_cpu.total_loss(ret, cfg["training"])
     params = [p for p in m.parameters() if p.numel()]
-    hits = []
-    h = m.embed_fn.params.register_hook(lambda gr: hits.append(float(gr.abs().sum())))
     grads = torch.autograd.grad(loss, params, retain_graph=True)
     assert all(gr is not None and torch.isfinite(gr).all() for gr in grads)
     assert all(p.grad is None for p in params)
+    hits = []
+    h = m.embed_fn.params.register_hook(lambda gr: hits.append(float(gr.abs().sum())))
     loss.backward()
     h.remove()
     assert len(hits) == 1 and hits[0] > 0, "tensor hook on the grid parameters fires on backward()"

@@ -75,7 +75,12 @@ def test_two_submap_sequence_matches_reference_run(fused_adam, in_place):
     assert list(out["tags"]) == [str(t) for t in g["tags"]]
     assert [t.numel() for t in out["idx"]] == list(g["idx_len"])
     got = torch.cat(out["idx"]).numpy()
-    assert np.array_equal(got, g["idx_flat"]), "index stream differs from the reference's"
+    if not np.array_equal(got, g["idx_flat"]):
+        off = np.concatenate([[0], np.cumsum(g["idx_len"])])
+        first = next(k for k in range(len(out["idx"])) if not np.array_equal(out["idx"][k].numpy(),
+                                                                             g["idx_flat"][off[k]:off[k + 1]]))
+        pytest.fail(f"index stream differs from the reference's, first at record {first} ({out['tags'][first]}); "
+                    f"losses so far {out['losses'][:8]} vs {g['losses'][:8]}")
     # ---- loss trace (51 model iterations across init / tracking / BA / switch phases)
     lo, lr = out["losses"], g["losses"]
     assert lo.shape == lr.shape

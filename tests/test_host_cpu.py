@@ -161,3 +161,23 @@ def test_reference_checkpoint_file_loads_and_round_trips(tmp_path):
     with pytest.raises(RuntimeError):
         torch.save({"x": torch.zeros(1)}, tmp_path / "bad.pth")
         checkpoint.load_state_dict(m, tmp_path / "bad.pth")
+
+
+def test_deepcopy_of_the_model_draws_no_random_numbers():
+    """copy.deepcopy(model) (InactiveMap.py:67,81,107) must leave the CPU RNG where it was: the reference's copy
+    draws nothing, and the pixel-sampling index stream depends on the generator state (found by the config-3
+    sequence test)."""
+    import copy
+    import numpy as np
+    from mipsfusion_amd import synth
+    from mipsfusion_amd.model import JointEncoding
+    cfg = synth.config_plumbing()
+    bb = torch.from_numpy(np.array(cfg["mapping"]["bound"]))
+    nf = torch.from_numpy(np.array(cfg["mapping"]["localMLP_max_len"]))
+    torch.manual_seed(3)
+    m = JointEncoding(cfg, bb, nf)
+    state = torch.get_rng_state()
+    m2 = copy.deepcopy(m)
+    assert torch.equal(torch.get_rng_state(), state)
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
