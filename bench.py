@@ -9,9 +9,17 @@ One "step" = one full mapping iteration of MIPSFusion.local_BA (mipsfusion.py:29
 4096 rays x 64 samples (43 uniform + 21 depth-guided), hash grid 2^19, apartment_2 bound, 620x460 synthetic RGB-D:
 ray build from the keyframe pose Parameters -> sample placement -> hash grid -> decoder -> SDF compositing ->
 4 losses -> backward (grid, decoder, pose gradients) -> dense map Adam (+ pose Adam every pose_accum_step).
-Pixel sampling (a1) runs on the host before the timed region: ray batches and the jitter noise are resident in
-HBM when timing starts.  N > 1: one process per GPU, each optimising its OWN submap (weak scaling); the
-only exchange is an all-gather of the optimised keyframe poses once per BA round (mapping.iters steps).
+Every step processes a FRESH ray batch: the keyframe ray database (4 keyframes x 30 000 rays) and the current frame
+live in one HBM table, the index sets are drawn on the host BEFORE the timed region with the reference's own samplers
+(python random.sample per keyframeSet.py:386-436, sample_pixels_mix for the current frame) and resident in HBM with
+the jitter when timing starts; the rows are gathered inside the step.  N > 1: one process per GPU, each optimising its
+OWN submap (weak scaling); the only exchange of the timed region is an all-gather of the optimised keyframe
+poses once per BA round (mapping.iters steps); the other shardings are exercised after it (`multi_gpu`).
+
+Besides the contract fields the line carries: `step_ms_stats` (min / median / p95 over >= 200 further steps),
+`kernels` (per-kernel roofline from event pairs on the launch stream), `frame` (MEASURED tracking+mapping ms/frame of a
+31-frame sequence with the reference's host sampling run ahead by producer threads, and with device sampling),
+`roofline`, `cpu_baseline`.
 
 Prints ONE JSON line (rank 0).
 """
@@ -82,12 +90,14 @@ def usable_cores():
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=30)
+    p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--setup-iters", type=int, default=50, help="untimed mapping iterations so the SDF has sign changes")
     p.add_argument("--cpu-rays", type=int, default=4096, help="rays of the bounded CPU-baseline sample (0 = skip)")
     p.add_argument("--cpu-iters", type=int, default=4)
     p.add_argument("--no-frame-estimate", action="store_true")
+    p.add_argument("--stats-steps", type=int, default=200, help="further steps timed one replay at a time (min/median/p95)")
+    p.add_argument("--seq-frames", type=int, default=31, help="frames of the measured tracking+mapping sequence (0 = skip)")
     p.add_argument("--no-graph", action="store_true",
                    help="time eager launches instead of hipGraph replays of pose_accum_step iterations")
     p.add_argument("--torch-pose", action="store_true",
@@ -117,36 +127,44 @@ def build_submap(cfg, dev, seed):
     return model, frames, poses
 
 
-def sample_pool(cfg, frames, n_batches):
-    """Host pixel sampling exactly as local_BA does it (keyframe rays by random.sample, current frame by
-    sample_pixels_mix), gathered into [N,7] ray records + owning pose index."""
+def build_ray_table(cfg, frames, dev):
+    """[4 keyframes x R rows | H*W rows of the current frame] in ONE device table (DeviceRayDB storage)."""
+    from mipsfusion_amd.keyframe_rays import DeviceRayDB
+    H, W = frames[0]["depth"].shape
+    rows, cols = sh.sample_pixels_uniformly(H, W, 100, 300)              # kf_n_rays_h x kf_n_rays_w (scaled: 30 000)
+    R, n_kf = rows.shape[0], len(frames) - 1
+    table = torch.zeros(n_kf * R + H * W, 7, device=dev)
+    db = DeviceRayDB(n_kf, R, dev, storage=table)
+    for k in range(n_kf):
+        f = frames[k]
+        db.store(k, torch.cat([f["direction"], f["rgb"], f["depth"][..., None]], -1)[rows, cols].to(dev))
+    cur = frames[-1]
+    table[n_kf * R:].copy_(torch.cat([cur["direction"], cur["rgb"], cur["depth"][..., None]], -1).reshape(-1, 7))
+    return table, db, R
+
+
+def draw_index_sets(cfg, frames, db, R, n_sets):
+    """Host pixel sampling exactly as local_BA does it (mipsfusion.py:295-317): keyframe rays by the python
+    random.sample calls of sample_rays_in_submap, current-frame pixels by sample_pixels_mix -> [n_sets, N] table rows
+    and the index of the owning pose."""
     H, W = frames[0]["depth"].shape
     n_kf = len(frames) - 1
-    n_cur = cfg["mapping"]["pixels_cur"]
-    n_from_kf = N_RAYS - n_cur
-    per_kf = n_from_kf // n_kf
-    pool = []
-    cur = frames[-1]
-    for _ in range(n_batches):
-        recs, owner = [], []
-        for k in range(n_kf):
-            idx = torch.tensor(random.sample(range(H * W), per_kf))
-            r, c = torch.div(idx, W, rounding_mode="floor"), torch.remainder(idx, W)
-            f = frames[k]
-            recs.append(torch.cat([f["direction"][r, c], f["rgb"][r, c], f["depth"][r, c][:, None]], -1))
-            owner.append(torch.full((per_kf,), k, dtype=torch.int64))
-        rows, cols = sh.sample_pixels_mix(H, W, cfg["tracking"]["RO"]["n_rows"], cfg["tracking"]["RO"]["n_cols"],
-                                          cur["depth"], n_cur)
-        recs.append(torch.cat([cur["direction"][rows, cols], cur["rgb"][rows, cols], cur["depth"][rows, cols][:, None]], -1))
-        owner.append(torch.full((n_cur,), n_kf, dtype=torch.int64))
-        pool.append((torch.cat(recs, 0), torch.cat(owner, 0)))
-    return pool
+    n_cur, n_from_kf = cfg["mapping"]["pixels_cur"], N_RAYS - cfg["mapping"]["pixels_cur"]
+    related = torch.arange(n_kf)
+    rows_l, own_l = [], []
+    for _ in range(n_sets):
+        flat, _, kf_indices = db.indices_in_submap(related[0], related, n_from_kf)
+        r, c = sh.sample_pixels_mix(H, W, cfg["tracking"]["RO"]["n_rows"], cfg["tracking"]["RO"]["n_cols"],
+                                    frames[-1]["depth"], n_cur)
+        rows_l.append(torch.cat([flat, n_kf * R + r * W + c]))
+        own_l.append(torch.cat([kf_indices, torch.full((n_cur,), n_kf, dtype=torch.int64)]))
+    return torch.stack(rows_l), torch.stack(own_l)
 
 
 class MappingLoop:
     """The local-BA iteration of mipsfusion.py:293-342 against our JointEncoding."""
 
-    def __init__(self, cfg, model, poses, pool, dev, torch_pose=False, capturable=False):
+    def __init__(self, cfg, model, poses, table, idx_rows, idx_owner, dev, torch_pose=False, capturable=False):
         self.cfg, self.model, self.dev, self.torch_pose = cfg, model, dev, torch_pose
         self.map_opt = FusedAdam([{"params": model.decoder.parameters(), "weight_decay": 1e-6, "lr": cfg["mapping"]["lr_decoder"]},
                                   {"params": model.embed_fn.parameters(), "eps": 1e-15, "lr": cfg["mapping"]["lr_embed"]}],
@@ -161,37 +179,40 @@ class MappingLoop:
                                    {"params": self.cur_trans, "lr": cfg["mapping"]["lr_trans"]}],
                                   capturable=capturable)
         self.poses_all = torch.cat([self.pose_fixed, qt_to_transform_matrix(self.cur_rot, self.cur_trans)], 0)
-        self.pool = [(r.to(dev), o.to(dev)) for r, o in pool]
-        self.pool = [(r, o, r[:, :3].contiguous(), r[:, 3:6].contiguous(), r[:, 6:7].contiguous()) for r, o in self.pool]
-        self.noise = [torch.rand(N_RAYS, N_SAMPLES, device=dev) for _ in pool]
+        self.table = table
+        self.idx_rows, self.idx_owner = idx_rows.to(dev), idx_owner.to(dev)          # [n_sets, N]: one FRESH batch per step
+        self.n_sets = self.idx_rows.shape[0]
+        self.noise = torch.rand(self.n_sets, N_RAYS, N_SAMPLES, device=dev)
         self.i = 0
 
     def make_static(self, n_inner):
-        """Static input buffers for a captured group of n_inner iterations + stacked pool to refill them from."""
-        P = len(self.pool)
-        self.stk = [torch.stack([e[c] for e in self.pool]) for c in (1, 2, 3, 4)]      # owner, d_cam, rgb, depth
-        self.stk.append(torch.stack(self.noise))
+        """Static input buffers (table rows, owner, jitter) of a captured group of n_inner iterations."""
+        self.stk = [self.idx_rows, self.idx_owner, self.noise]
         self.static = [t[:n_inner].clone() for t in self.stk]
-        self.n_inner, self.cursor = n_inner, 0
+        self.n_inner = n_inner
         self._arange = torch.arange(n_inner, device=self.dev)
 
     def refill_static(self):
-        idx = (self._arange + self.cursor) % len(self.pool)
+        """the next n_inner UNUSED batches -> the graph's static inputs (three device-to-device copies)"""
+        idx = (self._arange + self.i) % self.n_sets
         for dst, src in zip(self.static, self.stk):
             torch.index_select(src, 0, idx, out=dst)
-        self.cursor += self.n_inner
 
     def step_static(self, k):
-        owner, rays_d_cam, target_s, target_d, noise = (t[k] for t in self.static)
-        return self._iterate(owner, rays_d_cam, target_s, target_d, noise, set_to_none=False)
+        rows, owner, noise = (t[k] for t in self.static)
+        return self._iterate(rows, owner, noise, set_to_none=False)
 
     def step(self):
-        rays, owner, rays_d_cam, target_s, target_d = self.pool[self.i % len(self.pool)]
-        noise = self.noise[self.i % len(self.pool)]
-        return self._iterate(owner, rays_d_cam, target_s, target_d, noise, set_to_none=True)
+        b = self.i % self.n_sets
+        return self._iterate(self.idx_rows[b], self.idx_owner[b], self.noise[b], set_to_none=True)
 
-    def _iterate(self, owner, rays_d_cam, target_s, target_d, noise, set_to_none):
+    def batch(self, b):
+        """(rays [N,7], owner) of index set b, for the forward-only / CPU legs"""
+        return ops.gather_rays(self.table, self.idx_rows[b]), self.idx_owner[b]
+
+    def _iterate(self, rows, owner, noise, set_to_none):
         cfg = self.cfg
+        rays_d_cam, target_s, target_d = ops.gather_rays(self.table, rows, split=True)      # fresh rows of the ray table
         if self.torch_pose:
             rays_d = torch.sum(rays_d_cam[..., None, :] * self.poses_all[owner, :3, :3], -1)
             rays_o = self.poses_all[owner, :3, -1]
@@ -212,7 +233,7 @@ class MappingLoop:
 
 
 def forward_only_rate(model, loop, dev, iters=10):
-    rays, owner = loop.pool[0][:2]
+    rays, owner = loop.batch(0)
     poses_now = torch.cat([loop.pose_fixed, qt_to_transform_matrix(loop.cur_rot, loop.cur_trans)], 0).detach()
     with torch.no_grad():
         rays_d = torch.sum(rays[:, :3][..., None, :] * poses_now[owner, :3, :3], -1).contiguous()
@@ -301,7 +322,7 @@ def frame_estimate(cfg, model, loop, dev, ba_ms, stream=None):
     model.train(was_training)
     # GO: tracking.sample rays, pose-only Adam on one pose
     ns = cfg["tracking"]["sample"]
-    rays = loop.pool[0][0][:ns]
+    rays = loop.batch(0)[0][:ns]
     rot = torch.nn.Parameter(loop.cur_rot.detach()[-1:].clone())
     trans = torch.nn.Parameter(loop.cur_trans.detach()[-1:].clone())
     popt = FusedAdam([{"params": rot, "lr": 1e-3}, {"params": trans, "lr": 1e-3}], capturable=stream is not None)
@@ -356,8 +377,30 @@ def frame_estimate(cfg, model, loop, dev, ba_ms, stream=None):
     return {"ro_iter_ms": round(ro_ms, 4), "go_iter_ms": round(go_ms, 4),
             "go_iter_ms_eager": round(go_eager_ms, 4),
             "go_iter_ms_map_grads_computed_and_discarded": round(go_ms_unfrozen, 4), "ba_iter_ms": round(ba_ms, 4),
-            "tracking_plus_mapping_ms_per_frame": round(total, 3),
+            "ms_per_frame_from_iteration_times": round(total, 3),
             "formula": "iter_RO*ro + tracking.iter*go + mapping.iters*ba/map_every (FastCaMo-synth cadence 5/10/15/3)"}
+
+
+def measured_sequence(n_frames, dev, stream):
+    """tracking + mapping ms/frame MEASURED over a synthetic sequence at the reference cadence (5 RO rounds, 10
+    tracking iterations, 15 mapping iterations every 3rd frame, keyframe every 15th): mipsfusion_amd/sequence.py.
+    `reference`: pixel / keyframe-ray indices and jitter from the reference's own host generators (bit-identical
+    index stream, drawn one frame ahead by producer threads); `device`: the same draws made on the GPU."""
+    from mipsfusion_amd import sequence
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from run_sequence import trajectory
+    out = {}
+    for sampler in ("reference", "device"):
+        random.seed(0), np.random.seed(0), torch.manual_seed(0)
+        cfg = synth.config_reference_defaults()                   # S = 50 + 25, sample 1800 + pixels_cur 800: as shipped
+        gt = trajectory(cfg, n_frames)
+        frames = [synth.make_frame(cfg, gt[k], seed=k, frame_id=k) for k in range(n_frames)]
+        seq = sequence.GraphedSequence(cfg, dev, frames, kf_every=15, sampler=sampler, first_iters=200, stream=stream)
+        res = seq.run(gt)
+        out[sampler] = sequence.summarise(res, gt, cfg, "hipGraph replay per tracking frame / per BA round; RO eager")
+        del seq
+        torch.cuda.empty_cache()
+    return out
 
 
 def multi_gpu_checks(cfg, model, dev, rank, world):
@@ -452,7 +495,7 @@ def cpu_baseline(cfg, loop, n_rays, iters):
     cpu.load_state_dict({k: v.cpu() for k, v in loop.model.state_dict().items()})
     opt = torch.optim.Adam([{"params": cpu.decoder.parameters(), "weight_decay": 1e-6, "lr": 0.01},
                             {"params": cpu.embed_fn.parameters(), "eps": 1e-15, "lr": 0.01}], betas=(0.9, 0.99))
-    rays, owner = loop.pool[0][:2]
+    rays, owner = loop.batch(0)
     rays, owner = rays[:n_rays].cpu(), owner[:n_rays].cpu()
     poses = torch.cat([loop.pose_fixed, qt_to_transform_matrix(loop.cur_rot, loop.cur_trans)], 0).detach().cpu()
     noise = loop.noise[0][:n_rays].cpu()
@@ -462,11 +505,30 @@ def cpu_baseline(cfg, loop, n_rays, iters):
     def it():
         opt.zero_grad()
         ret = cpu.train_forward(rays_o, rays_d, rays[:, 3:6], rays[:, 6:7], noise, 0.01)
-        path_cpu.total_loss(ret, cfg["training"]).backward()
+        loss = path_cpu.total_loss(ret, cfg["training"])
+        loss.backward()
+        grid_grad = cpu.embed_fn.params.grad.clone()
         opt.step()
+        return ret, loss.detach(), grid_grad
+    # the same iteration on the GPU from the same parameters: the checker's verdict next to its speed
+    dev = loop.dev
+    m = loop.model
+    m.zero_grad(set_to_none=True)
+    g_ret = m.forward(rays_o.to(dev), rays_d.to(dev), rays[:, 3:6].contiguous().to(dev), rays[:, 6:7].contiguous().to(dev),
+                      EMD_w=0.01, noise=noise.to(dev))
+    g_loss = path_cpu.total_loss(g_ret, cfg["training"])
+    g_loss.backward()
     t_w = time.perf_counter()
-    it()
+    c_ret, c_loss, c_grad = it()
     log(f"cpu_baseline warm-up iteration {time.perf_counter() - t_w:.1f}s on {torch.get_num_threads()} threads")
+
+    def rel(a, b):
+        return float((a.detach().cpu().double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+    parity = {"loss_rel_err": abs(float(g_loss) - float(c_loss)) / abs(float(c_loss)),
+              "depth_map_rel_err": rel(g_ret["depth"], c_ret["depth"]), "rgb_map_rel_err": rel(g_ret["rgb"], c_ret["rgb"]),
+              "grid_grad_rel_err": rel(m.embed_fn.params.grad, c_grad)}
+    log("cpu_baseline: GPU vs oracle on this batch " + ", ".join(f"{k} {v:.2e}" for k, v in parity.items()))
+    m.zero_grad(set_to_none=False)
     t0 = time.perf_counter()
     done = 0
     for _ in range(iters):
@@ -478,6 +540,7 @@ def cpu_baseline(cfg, loop, n_rays, iters):
     dt = (time.perf_counter() - t0) / iters
     return {"value": n_rays * N_SAMPLES / dt, "unit": "rays*samples/s", "cores": torch.get_num_threads(),
             "kind": "port", "s_per_iter": round(dt, 3),
+            "gpu_vs_oracle_same_batch": {k: float(f"{v:.3e}") for k, v in parity.items()},
             "sample": f"{iters} full iterations (fwd+bwd+dense Adam over the 2^19 grid) of oracle/path_cpu.py on "
                       f"{n_rays} of the 4096 rays x 64 samples of the same batch, torch CPU threads = cores"}
 
@@ -520,9 +583,16 @@ def main():
     cfg = synth.config_headline()
     log(f"rank {rank}/{world} on {torch.cuda.get_device_name(local)}; building submap")
     model, frames, poses = build_submap(cfg, dev, seed=rank)
-    pool = sample_pool(cfg, frames, n_batches=8)
+    table, db, R = build_ray_table(cfg, frames, dev)
     use_graph = not args.no_graph and not args.torch_pose and args.steps % cfg["mapping"]["pose_accum_step"] == 0
-    loop = MappingLoop(cfg, model, poses, pool, dev, torch_pose=args.torch_pose, capturable=use_graph)
+    # one fresh batch for every step of every pass (setup, warm-ups, eager pass, graph pass, stats pass); beyond 1024
+    # sets the sequence wraps around (a 4 ms host draw per set would otherwise dominate the run time of long benches)
+    n_sets = min(1024, args.setup_iters + 3 * args.warmup + 2 * args.steps + args.stats_steps + 16)
+    t_draw = time.perf_counter()
+    idx_rows, idx_owner = draw_index_sets(cfg, frames, db, R, n_sets)
+    log(f"{n_sets} index sets drawn on the host with the reference samplers in {time.perf_counter() - t_draw:.1f}s")
+    loop = MappingLoop(cfg, model, poses, table, idx_rows, idx_owner, dev, torch_pose=args.torch_pose,
+                       capturable=use_graph)
     log("setup iterations")
     for _ in range(args.setup_iters):
         loop.step()
@@ -556,7 +626,7 @@ def main():
     prof = ops.profile_summary()
     ops.PROFILE = None
     log(f"eager timed region: {args.steps} steps in {eager_elapsed * 1e3:.1f} ms")
-    elapsed = eager_elapsed
+    elapsed, step_stats = eager_elapsed, None
 
     # ---- graph pass (the number reported as `value`): the same K steps as hipGraph replays of pose_accum_step
     #      iterations; fresh ray batches are copied into the static input buffers before every replay
@@ -578,6 +648,19 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         log(f"graph timed region: {args.steps} steps in {elapsed * 1e3:.1f} ms")
+        # ---- spread: further steps, every replay (= n_inner steps incl. its input refill) bracketed by an event pair
+        n_rep = max(1, args.stats_steps // n_inner)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_rep)]
+        for a, b in ev:
+            a.record()
+            loop.refill_static()
+            graphed.replay()
+            b.record()
+        torch.cuda.synchronize()
+        per_step = np.array([a.elapsed_time(b) / n_inner for a, b in ev])
+        step_stats = {"steps": n_rep * n_inner, "granularity": f"one replay of {n_inner} steps incl. its input refill",
+                      "min": round(float(per_step.min()), 4), "median": round(float(np.median(per_step)), 4),
+                      "p95": round(float(np.percentile(per_step, 95)), 4), "max": round(float(per_step.max()), 4)}
     elapsed = mdist.max_over_ranks(elapsed, dev)
     multi = multi_gpu_checks(cfg, model, dev, rank, world) if world > 1 else None
 
@@ -618,6 +701,9 @@ def main():
         "value": round(value, 1), "unit": "rays*samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
         "launch": "hipGraph replay of pose_accum_step iterations" if use_graph else "eager",
+        "step_ms_stats": step_stats,
+        "batches": "a fresh ray batch every step: rows gathered in-step from the HBM ray table (4 keyframes x 30 000 rays "
+                   "+ current frame) by host-drawn index sets (reference samplers), indices and jitter resident in HBM",
         "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE config 2: FastCaMo-synth apartment_2 bound, 1 active submap per GPU, "
@@ -631,7 +717,14 @@ def main():
     }
     if not args.no_frame_estimate:
         out["frame"] = frame_estimate(cfg, model, loop, dev, ms_step, stream if use_graph else None)
-        log("frame estimate done")
+        log("iteration-level frame numbers done")
+        if args.seq_frames > 1 and use_graph:
+            seq = measured_sequence(args.seq_frames, dev, stream)
+            out["frame"]["measured_sequence"] = seq
+            out["frame"]["ms_per_frame_reference_sampling"] = seq["reference"]["ms_per_frame_mean"]
+            out["frame"]["ms_per_frame_device_sampling"] = seq["device"]["ms_per_frame_mean"]
+            out["frame"]["tracking_plus_mapping_ms_per_frame"] = seq["reference"]["ms_per_frame_mean"]
+            log("measured sequences done")
         out["inference"] = inference_rates(cfg, model, dev)
         log("inference consumers done")
     if multi is not None:

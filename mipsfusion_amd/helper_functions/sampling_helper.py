@@ -25,16 +25,25 @@ def select_samples(H, W, samples):
     return torch.tensor(random.sample(range(H * W), int(samples)))
 
 
-def _valid_scores(depth_image, blocked=None):
+def draw_pixel_scores(depth_image):
+    """The RNG half of the valid-pixel samplers: one N(0,1) draw per pixel from torch's default CPU generator, exactly
+    the ``torch.randn_like(mask)`` of sampling_helper.py:30 / :62.  Split out so that a producer thread can run the
+    generator stream ahead of the (independent) scoring + top-k half."""
+    return torch.randn_like(depth_image.flatten(), dtype=depth_image.dtype)
+
+
+def _valid_scores(depth_image, blocked=None, draw=None):
     valid = (depth_image > 0.).to(depth_image.dtype)
     if blocked is not None:
         valid[blocked[0], blocked[1]] = 0
     valid = valid.flatten()
-    return valid * torch.abs(torch.randn_like(valid))      # invalid pixels score 0, valid ones |N(0,1)|
+    if draw is None:
+        draw = torch.randn_like(valid)
+    return valid * torch.abs(draw)                          # invalid pixels score 0, valid ones |N(0,1)|
 
 
-def sample_valid_pixels_random(depth_image, num):
-    return torch.topk(_valid_scores(depth_image), num)[1]
+def sample_valid_pixels_random(depth_image, num, draw=None):
+    return torch.topk(_valid_scores(depth_image, draw=draw), num)[1]
 
 
 def _lattice_axis(size, count):
@@ -47,8 +56,9 @@ def sample_pixels_uniformly(img_h, img_w, num_h, num_w):
     return r[:, None].repeat(1, num_w).reshape(-1), c[None, :].repeat(num_h, 1).reshape(-1)
 
 
-def sample_pixels_mix(img_h, img_w, num_h, num_w, depth_image, num):
+def sample_pixels_mix(img_h, img_w, num_h, num_w, depth_image, num, draw=None):
+    """``draw`` (extension): the per-pixel N(0,1) draw made earlier by ``draw_pixel_scores`` for this call."""
     rows, cols = sample_pixels_uniformly(img_h, img_w, num_h, num_w)
-    extra = torch.topk(_valid_scores(depth_image, (rows, cols)), num - num_h * num_w)[1]
+    extra = torch.topk(_valid_scores(depth_image, (rows, cols), draw), num - num_h * num_w)[1]
     r2, c2 = pixel_indices_to_rc(extra, img_h, img_w)
     return torch.cat([rows, r2], 0), torch.cat([cols, c2], 0)

@@ -67,6 +67,13 @@ class DeviceRayDB:
 
     # ------------------------------------------------------------------ keyframeSet.py:386-436
     def sample_rays_in_submap(self, first_kf_Id, related_kf_ids, pix_num: int):
+        flat, kf_ids, kf_indices = self.indices_in_submap(first_kf_Id, related_kf_ids, pix_num)
+        return self._gather(flat), kf_ids, kf_indices
+
+    def indices_in_submap(self, first_kf_Id, related_kf_ids, pix_num: int):
+        """The host half of ``sample_rays_in_submap``: the python-``random`` draws and the index arithmetic, without
+        the gather -> (flat row indices into the database, kf_ids, kf_indices), all CPU int64.  A producer thread
+        calls this ahead of time; the rows are gathered later, inside the captured iteration."""
         R = self.num_rays_to_save
         n_rel = related_kf_ids.shape[0]
         n_first = max(pix_num // n_rel, pix_num // 10)
@@ -92,4 +99,4 @@ class DeviceRayDB:
             flat += [o_ids.to(torch.int64) * R + (idx_other - o_indices * R)] + tail_flat
             kf_indices += [o_indices + 1] + tail_indices
             kf_ids += [o_ids] + tail_ids
-        return self._gather(torch.cat(flat)), torch.cat(kf_ids), torch.cat(kf_indices)
+        return torch.cat(flat), torch.cat(kf_ids), torch.cat(kf_indices)

@@ -1,0 +1,557 @@
+"""The online loop around the hot path, with the host-side sampling OFF the critical path.
+
+``MIPSFusion.run`` (mipsfusion.py:661-735) calls, per frame, ``tracking_render`` (:470-577) and every ``map_every``-th
+frame ``local_BA`` (:259-371).  Both draw their pixel / keyframe-ray indices and the sample jitter on the HOST
+(python ``random``, torch's default CPU generator: sampling_helper.py:20-68, keyframeSet.py:386-436, scene_rep.py:176),
+once per optimisation iteration, between two GPU launches.  With the ~1 ms iterations of this package that host work
+(4.7 ms per mapping iteration on 8 cores: ``randn_like`` over the 285 200 pixels, ``topk``, ``torch.rand(N, S)``,
+``random.sample``) is 4x the GPU time.
+
+Nothing in those draws depends on a GPU result: the call sequence and every argument (image size, ray counts, the
+keyframes of the sub-map, the depth image of the frame) are known when the frame arrives.  So
+
+* ``ReferenceSampleProducer`` runs the three generator streams in their own threads, one frame AHEAD of the GPU, in the
+  reference's exact call order (the torch stream: per tracking frame ``randn_like`` + ``iter`` x ``rand(n, S)``, per
+  mapping iteration ``randn_like`` + ``rand(N, S)``; the python stream: per mapping iteration the ``random.sample`` calls
+  of ``sample_rays_in_submap``; scoring + ``topk`` is generator-free and runs on a third thread) and leaves index sets
+  and jitter in pinned buffers -- the index stream is bit-identical to calling the reference's functions in program
+  order (tests/test_host_cpu.py::test_sample_producer_reproduces_the_sequential_index_stream);
+* ``GraphedSequence`` replays one hipGraph per tracking frame and one per BA round whose static inputs (ray-table row
+  indices, owning pose, jitter) are refilled from those buffers with three async copies.
+
+``sampler="device"`` is the alternative without the reference's generators (indices and jitter drawn on the GPU: valid
+depth only, without replacement, same per-keyframe shares).
+"""
+import queue
+import random
+import threading
+import time
+import types
+from typing import Dict, List, NamedTuple, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .helper_functions import sampling_helper as sh
+from .helper_functions.geometry_helper import matrix_to_quaternion, qt_to_transform_matrix
+from .helper_functions.utils import get_loss_from_ret
+from .keyframe_rays import DeviceRayDB
+
+
+class FramePlan(NamedTuple):
+    """Everything the host samplers of one frame depend on (all known when the frame arrives)."""
+    frame_id: int
+    depth: torch.Tensor                 # [H,W] CPU
+    track: bool                         # tracking_render runs for this frame
+    ba_kf_ids: Optional[torch.Tensor]   # related keyframe ids of the active sub-map if local_BA runs, else None
+    kf_slot_base: int = 0               # row offset of the current frame's pixels in the device ray table
+
+
+class FrameSamples:
+    """One ring slot of pinned buffers.  track_idx [n_track] (pixel index row*W+col), track_noise [iters, n_track, S];
+    ba_rows / ba_owner [iters, N] (ray-table row, index of the owning pose), ba_noise [iters, N, S]; n_ba = N."""
+
+    def __init__(self, n_track, it_track, n_ba_max, it_ba, S, pinned):
+        def buf(*shape, dtype=torch.float32):
+            t = torch.empty(shape, dtype=dtype)
+            return t.pin_memory() if pinned else t
+        self.track_idx = buf(n_track, dtype=torch.int64)
+        self.track_noise = buf(it_track, n_track, S)
+        self.ba_rows = buf(it_ba, n_ba_max, dtype=torch.int64)
+        self.ba_owner = buf(it_ba, n_ba_max, dtype=torch.int64)
+        self.ba_noise = buf(it_ba, n_ba_max, S)
+        self.n_ba, self.frame_id = 0, -1
+        self.ready = threading.Event()
+        self.free = threading.Event()
+        self.free.set()
+        self._pending, self._lock = 0, threading.Lock()
+
+    def _arm(self, parts):
+        self._pending = parts
+        self.ready.clear()
+
+    def _part_done(self):
+        with self._lock:
+            self._pending -= 1
+            if self._pending == 0:
+                self.ready.set()
+
+
+def ba_ray_counts(cfg, n_related):
+    """(rays from stored keyframes, rays from the current frame) of one local-BA iteration (mipsfusion.py:295-309)."""
+    mp, tk = cfg["mapping"], cfg["tracking"]
+    if tk["iter_RO"] == 0:
+        return mp["sample"], max(mp["sample"] // n_related, 50)
+    return mp["sample"], max(mp["sample"] // n_related, mp["pixels_cur"])
+
+
+class ReferenceSampleProducer:
+    """See the module docstring.  ``submit(plan)`` enqueues a frame, ``get()`` returns the oldest submitted frame's
+    ``FrameSamples`` once complete, ``release(s)`` hands the slot back after its contents were copied to the device."""
+
+    def __init__(self, cfg, H, W, rays_per_kf, max_related, pinned=None, slots=3):
+        self.cfg, self.H, self.W, self.R = cfg, H, W, rays_per_kf
+        tr, tk, mp = cfg["training"], cfg["tracking"], cfg["mapping"]
+        self.S = tr["n_samples_d"] + tr["n_range_d"]
+        self.n_track, self.it_track, self.it_ba = tk["sample"], tk["iter"], mp["iters"]
+        n_ba_max = max(sum(ba_ray_counts(cfg, k)) for k in range(1, max_related + 1))
+        pinned = torch.cuda.is_available() if pinned is None else pinned
+        self.slots = [FrameSamples(self.n_track, self.it_track, n_ba_max, self.it_ba, self.S, pinned) for _ in range(slots)]
+        self._next = 0
+        self._order: "queue.Queue[FrameSamples]" = queue.Queue()
+        self._q_torch, self._q_topk, self._q_py = queue.Queue(), queue.Queue(), queue.Queue()
+        self._index_db = DeviceRayDB.__new__(DeviceRayDB)       # index arithmetic only (no storage, no gather)
+        self._index_db.num_rays_to_save = rays_per_kf
+        self._lattice_track = (cfg["sampling"]["n_rays_h"], cfg["sampling"]["n_rays_w"]) if "sampling" in cfg else \
+            (tk["RO"]["n_rows"], tk["RO"]["n_cols"])
+        self._threads = [threading.Thread(target=f, daemon=True, name=n) for f, n in
+                         ((self._torch_stream, "mipsf-torch-rng"), (self._topk_stage, "mipsf-topk"),
+                          (self._python_stream, "mipsf-python-rng"))]
+        for t in self._threads:
+            t.start()
+        self.host_ms = {"torch_rng": 0.0, "topk": 0.0, "python_rng": 0.0}
+
+    # ------------------------------------------------------------------------------------------- client side
+    def submit(self, plan: FramePlan):
+        s = self.slots[self._next % len(self.slots)]
+        self._next += 1
+        s.free.wait()
+        s.free.clear()
+        s.frame_id = plan.frame_id
+        iter_ro0 = self.cfg["tracking"]["iter_RO"] == 0
+        n_topk = (1 if plan.track and not iter_ro0 else 0) + (self.it_ba if plan.ba_kf_ids is not None else 0)
+        s._arm(1 + n_topk + 1)               # torch stream, every top-k item, python stream
+        if plan.ba_kf_ids is not None:
+            s.n_ba = sum(ba_ray_counts(self.cfg, plan.ba_kf_ids.shape[0]))
+        else:
+            s.n_ba = 0
+        self._order.put(s)
+        self._q_torch.put((plan, s))
+        self._q_py.put((plan, s))
+
+    def get(self, timeout=120.0) -> FrameSamples:
+        s = self._order.get()
+        if not s.ready.wait(timeout):
+            raise RuntimeError("sample producer stalled")
+        return s
+
+    def release(self, s: FrameSamples):
+        s.free.set()
+
+    def close(self):
+        for q in (self._q_torch, self._q_topk, self._q_py):
+            q.put(None)
+
+    # ------------------------------------------------------------------------------------------- the three stages
+    def _torch_stream(self):
+        """torch's default CPU generator, in the reference's call order."""
+        iter_ro0 = self.cfg["tracking"]["iter_RO"] == 0
+        while True:
+            item = self._q_torch.get()
+            if item is None:
+                self._q_topk.put(None)
+                return
+            plan, s = item
+            t0 = time.perf_counter()
+            if plan.track:
+                if not iter_ro0:                                    # sample_pixels_mix (mipsfusion.py:519-523)
+                    self._q_topk.put((plan, s, "track", 0, sh.draw_pixel_scores(plan.depth)))
+                for i in range(self.it_track):                      # scene_rep.py:176, one draw per forward
+                    torch.rand(self.n_track, self.S, out=s.track_noise[i])
+            if plan.ba_kf_ids is not None:
+                n = s.n_ba
+                for i in range(self.it_ba):
+                    self._q_topk.put((plan, s, "ba", i, sh.draw_pixel_scores(plan.depth)))   # :302 / :306-307
+                    torch.rand(n, self.S, out=s.ba_noise[i, :n])
+            self.host_ms["torch_rng"] += (time.perf_counter() - t0) * 1e3
+            s._part_done()
+
+    def _topk_stage(self):
+        """Generator-free half of the valid-pixel samplers: mask, lattice blocking, top-k."""
+        tk, H, W = self.cfg["tracking"], self.H, self.W
+        while True:
+            item = self._q_topk.get()
+            if item is None:
+                return
+            plan, s, kind, i, draw = item
+            t0 = time.perf_counter()
+            if kind == "track":
+                rows, cols = sh.sample_pixels_mix(H, W, self._lattice_track[0], self._lattice_track[1], plan.depth,
+                                                  self.n_track, draw=draw)
+                s.track_idx.copy_(sh.pixel_rc_to_indices(rows, cols, H, W))
+            else:
+                n_kf, n_cur = ba_ray_counts(self.cfg, plan.ba_kf_ids.shape[0])
+                if tk["iter_RO"] == 0:
+                    idx = sh.sample_valid_pixels_random(plan.depth, n_cur, draw=draw)
+                else:
+                    rows, cols = sh.sample_pixels_mix(H, W, tk["RO"]["n_rows"], tk["RO"]["n_cols"], plan.depth, n_cur,
+                                                      draw=draw)
+                    idx = sh.pixel_rc_to_indices(rows, cols, H, W)
+                s.ba_rows[i, n_kf:n_kf + n_cur].copy_(idx + plan.kf_slot_base)
+                s.ba_owner[i, n_kf:n_kf + n_cur].fill_(-1)
+            self.host_ms["topk"] += (time.perf_counter() - t0) * 1e3
+            s._part_done()
+
+    def _python_stream(self):
+        """python's ``random`` generator: the keyframe-ray draws of every mapping iteration (keyframeSet.py:386-436),
+        and the tracking pixels when iter_RO == 0 (select_samples, mipsfusion.py:510-515, its H-for-W quirk included)."""
+        tk = self.cfg["tracking"]
+        while True:
+            item = self._q_py.get()
+            if item is None:
+                return
+            plan, s = item
+            t0 = time.perf_counter()
+            if plan.track and tk["iter_RO"] == 0:
+                iH, iW = tk["ignore_edge_H"], tk["ignore_edge_W"]
+                hh = self.H - 2 * iH
+                indice = sh.select_samples(hh, self.W - 2 * iW, self.n_track)
+                ih, iw = torch.remainder(indice, hh), torch.div(indice, hh, rounding_mode="floor")
+                s.track_idx.copy_((ih + iH) * self.W + (iw + iW))
+            if plan.ba_kf_ids is not None:
+                n_kf, _ = ba_ray_counts(self.cfg, plan.ba_kf_ids.shape[0])
+                first = plan.ba_kf_ids[0]
+                for i in range(self.it_ba):
+                    flat, _, kf_indices = self._index_db.indices_in_submap(first, plan.ba_kf_ids, n_kf)
+                    s.ba_rows[i, :n_kf].copy_(flat)
+                    s.ba_owner[i, :n_kf].copy_(kf_indices)
+            self.host_ms["python_rng"] += (time.perf_counter() - t0) * 1e3
+            s._part_done()
+
+
+def sequential_reference_samples(cfg, H, W, rays_per_kf, plans: List[FramePlan]):
+    """The same index sets and jitter produced by calling the sampling functions one after the other in the
+    reference's program order on the calling thread (what the unchanged caller does): the producer's checker."""
+    tr, tk, mp = cfg["training"], cfg["tracking"], cfg["mapping"]
+    S = tr["n_samples_d"] + tr["n_range_d"]
+    db = DeviceRayDB.__new__(DeviceRayDB)
+    db.num_rays_to_save = rays_per_kf
+    lattice = (cfg["sampling"]["n_rays_h"], cfg["sampling"]["n_rays_w"]) if "sampling" in cfg else \
+        (tk["RO"]["n_rows"], tk["RO"]["n_cols"])
+    out = []
+    for plan in plans:
+        rec = {}
+        if plan.track:
+            if tk["iter_RO"] == 0:
+                iH, iW = tk["ignore_edge_H"], tk["ignore_edge_W"]
+                hh = H - 2 * iH
+                indice = sh.select_samples(hh, W - 2 * iW, tk["sample"])
+                ih, iw = torch.remainder(indice, hh), torch.div(indice, hh, rounding_mode="floor")
+                rec["track_idx"] = (ih + iH) * W + (iw + iW)
+            else:
+                rows, cols = sh.sample_pixels_mix(H, W, lattice[0], lattice[1], plan.depth, tk["sample"])
+                rec["track_idx"] = sh.pixel_rc_to_indices(rows, cols, H, W)
+            rec["track_noise"] = torch.stack([torch.rand(tk["sample"], S) for _ in range(tk["iter"])])
+        if plan.ba_kf_ids is not None:
+            n_kf, n_cur = ba_ray_counts(cfg, plan.ba_kf_ids.shape[0])
+            rows_l, own_l, noise_l = [], [], []
+            for _ in range(mp["iters"]):
+                flat, _, kf_indices = db.indices_in_submap(plan.ba_kf_ids[0], plan.ba_kf_ids, n_kf)
+                if tk["iter_RO"] == 0:
+                    idx = sh.sample_valid_pixels_random(plan.depth, n_cur)
+                else:
+                    r, c = sh.sample_pixels_mix(H, W, tk["RO"]["n_rows"], tk["RO"]["n_cols"], plan.depth, n_cur)
+                    idx = sh.pixel_rc_to_indices(r, c, H, W)
+                rows_l.append(torch.cat([flat, idx + plan.kf_slot_base]))
+                own_l.append(torch.cat([kf_indices, -torch.ones(n_cur, dtype=torch.int64)]))
+                noise_l.append(torch.rand(n_kf + n_cur, S))
+            rec["ba_rows"], rec["ba_owner"], rec["ba_noise"] = torch.stack(rows_l), torch.stack(own_l), torch.stack(noise_l)
+        out.append(rec)
+    return out
+
+
+# ======================================================================================================= the loop
+def frame_rays(frame):
+    """[H*W, 7] rows [direction | rgb | depth] of one frame (mipsfusion.py:296-297)."""
+    return torch.cat([frame["direction"], frame["rgb"], frame["depth"][..., None]], -1).reshape(-1, 7)
+
+
+class GraphedSequence:
+    """Tracking + mapping of a frame sequence on one sub-map with the iterations replayed as hipGraphs
+    (mipsfusion_amd.graph.GraphedSteps): RandomOptimizer rounds (eager, 5 launches each) -> one replay of the
+    ``tracking.iter`` pose-only iterations -> every ``map_every``-th frame one replay of the ``mapping.iters`` local-BA
+    iterations.  Rays are gathered inside the graphs from ONE device table [keyframe database | current frame]."""
+
+    def __init__(self, cfg, dev, frames, kf_every=15, sampler="reference", first_iters=200, stream=None):
+        from .RandomOptimizer import RandomOptimizer
+        from .graph import GraphedSteps, work_stream
+        from .model import JointEncoding
+        from .optim import FusedAdam
+        from . import synth
+        assert sampler in ("reference", "device")
+        self.cfg, self.dev, self.frames, self.sampler, self.kf_every = cfg, dev, frames, sampler, kf_every
+        self.stream = stream if stream is not None else work_stream(dev)
+        self._Graphed = GraphedSteps
+        tr, mp, tk = cfg["training"], cfg["mapping"], cfg["tracking"]
+        tk["RO"].setdefault("initial_scaling_factor", 0.02)
+        tk["RO"].setdefault("rescaling_factor", 0.5)
+        tk.setdefault("ignore_edge_H", 20), tk.setdefault("ignore_edge_W", 20)
+        self.S = tr["n_samples_d"] + tr["n_range_d"]
+        self.H, self.W, fx, fy, cx, cy = synth.intrinsics_after_crop(cfg)
+        H, W = self.H, self.W
+        bb = torch.from_numpy(np.array(mp["bound"]))
+        nf = torch.from_numpy(np.array(mp["localMLP_max_len"]))
+        self.model = JointEncoding(cfg, bb, nf).to(dev).train()
+        self.model.accumulate_param_grads_in_place = True
+        self.host_rays = [frame_rays(f).pin_memory() for f in frames]        # what a capture thread hands over
+        ds = types.SimpleNamespace(H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy, rays_d=frames[0]["direction"])
+        self.ro = RandomOptimizer(cfg, types.SimpleNamespace(dataset=ds, device=dev))
+        kr, kc = sh.sample_pixels_uniformly(H, W, 100, 300 if W >= 300 else W // 2)  # 30 000 rays per keyframe
+        self.kf_rows, self.kf_cols = kr.to(dev), kc.to(dev)
+        self.R = kr.shape[0]
+        self.Kmax = len(frames) // kf_every + 2
+        self.table = torch.zeros(self.Kmax * self.R + H * W, 7, device=dev)
+        self.db = DeviceRayDB(self.Kmax, self.R, dev, storage=self.table)
+        self.cur = self.table[self.Kmax * self.R:]
+        self.n_kf = 0
+        self.iters, self.first_iters = mp["iters"], first_iters
+        # ---- static state of the captured iterations
+        self.n_ba_max = max(sum(ba_ray_counts(cfg, k)) for k in range(1, self.Kmax + 1))
+        self.ba_rot = torch.nn.Parameter(torch.tensor([[1., 0., 0., 0.]], device=dev).repeat(self.Kmax, 1))
+        self.ba_trans = torch.nn.Parameter(torch.zeros(self.Kmax, 3, device=dev))       # slot j-1 = keyframe j, -1 = current
+        self.fixed = torch.eye(4, device=dev)[None].clone()
+        self.ba_rows = torch.zeros(self.iters, self.n_ba_max, dtype=torch.int64, device=dev)
+        self.ba_owner = torch.zeros(self.iters, self.n_ba_max, dtype=torch.int64, device=dev)
+        self.ba_noise = torch.zeros(self.iters, self.n_ba_max, self.S, device=dev)
+        self.map_opt = FusedAdam([{"params": self.model.decoder.parameters(), "weight_decay": 1e-6, "lr": mp["lr_decoder"]},
+                                  {"params": self.model.embed_fn.parameters(), "eps": 1e-15, "lr": mp["lr_embed"]}],
+                                 betas=(0.9, 0.99), capturable=True)
+        self.ba_popt = FusedAdam([{"params": self.ba_rot, "lr": mp["lr_rot"]}, {"params": self.ba_trans, "lr": mp["lr_trans"]}],
+                                 capturable=True)
+        self.n_track = tk["sample"]
+        self.go_rot = torch.nn.Parameter(torch.tensor([[1., 0., 0., 0.]], device=dev))
+        self.go_trans = torch.nn.Parameter(torch.zeros(1, 3, device=dev))
+        self.go_idx = torch.zeros(self.n_track, dtype=torch.int64, device=dev)
+        self.go_own = torch.zeros(self.n_track, dtype=torch.int64, device=dev)
+        self.go_noise = torch.zeros(tk["iter"], self.n_track, self.S, device=dev)
+        self.go_popt = FusedAdam([{"params": self.go_rot, "lr": tk["lr_rot"]}, {"params": self.go_trans, "lr": tk["lr_trans"]}],
+                                 capturable=True)
+        self.ba_graphs: Dict[int, object] = {}
+        self.go_graph = None
+        self.producer = None
+        if sampler == "reference":
+            self.producer = ReferenceSampleProducer(cfg, H, W, self.R, self.Kmax)
+        self.capture_ms = 0.0
+
+    # ------------------------------------------------------------------------------------- captured iterations
+    def _ba_step_fn(self, n):
+        tcfg, mp = self.cfg["training"], self.cfg["mapping"]
+
+        def step(k):
+            d_cam, rgb, depth = ops.gather_rays(self.table, self.ba_rows[k, :n].contiguous(), split=True)
+            rays_o, rays_d = ops.pose_rays(self.ba_rot, self.ba_trans, self.fixed, self.ba_owner[k, :n].contiguous(), d_cam)
+            ret = self.model.forward(rays_o, rays_d, rgb, depth, noise=self.ba_noise[k, :n].contiguous())
+            get_loss_from_ret(ret, tcfg).backward()
+            self.map_opt.step(zero_grad=True)
+            if (k + 1) % mp["pose_accum_step"] == 0:
+                self.ba_popt.step(zero_grad=True)
+        return step
+
+    def _go_step(self, k):
+        d_cam, rgb, depth = ops.gather_rays(self.cur, self.go_idx, split=True)
+        rays_o, rays_d = ops.pose_rays(self.go_rot, self.go_trans, None, self.go_own, d_cam)
+        ret = self.model.forward(rays_o, rays_d, rgb, depth, EMD_w=0., noise=self.go_noise[k])
+        get_loss_from_ret(ret, self.cfg["training"]).backward()
+        self.go_popt.step(zero_grad=True)
+
+    def _ba_graph(self, n):
+        g = self.ba_graphs.get(n)
+        if g is None:
+            t0 = time.perf_counter()
+            g = self.ba_graphs[n] = self._Graphed(self._ba_step_fn(n), self.iters, warmup=1, stream=self.stream)
+            torch.cuda.synchronize()
+            self.capture_ms += (time.perf_counter() - t0) * 1e3
+        return g
+
+    # --------------------------------------------------------------------------------------------- device sampler
+    def _device_draw(self, population, k, rows=1):
+        """k distinct integers of range(population) per row, uniformly: top-k of i.i.d. uniforms (no replacement)."""
+        return torch.rand(rows, population, device=self.dev).topk(k, dim=1).indices
+
+    def _device_valid_pixels(self, k, rows, lattice=None):
+        """sample_pixels_mix's distribution on the device: `rows` independent draws of k distinct VALID-depth pixels
+        (|N(0,1)| scores, invalid and lattice pixels score 0: sampling_helper.py:28-32, 53-68)."""
+        valid = (self.cur[:, 6] > 0).float()
+        if lattice is not None:
+            valid = valid.clone()
+            valid[lattice] = 0
+        return (valid[None] * torch.randn(rows, valid.shape[0], device=self.dev).abs()).topk(k, dim=1).indices
+
+    def _fill_ba_device(self, K, cur_is_first):
+        n_kf, n_cur = ba_ray_counts(self.cfg, K)
+        if K == 1 and cur_is_first:
+            n_kf, n_cur = 0, n_kf + n_cur
+        R, it = self.R, self.iters
+        idx, own = [], []
+        if n_kf:
+            n_first = max(n_kf // K, n_kf // 10)
+            idx.append(self._device_draw(R, n_first, it))
+            own.append(torch.zeros(it, n_first, dtype=torch.int64, device=self.dev))
+            n_last = max(n_kf // K, n_kf // 5) if K > 2 else 0
+            n_other = n_kf - n_first - n_last
+            if K > 1 and n_other:
+                span = (K - 2) if K > 2 else 1
+                o = self._device_draw(span * R, n_other, it)
+                idx.append(o + R), own.append(o // R + 1)
+            if n_last:
+                idx.append(self._device_draw(R, n_last, it) + (K - 1) * R)
+                own.append(torch.full((it, n_last), K - 1, dtype=torch.int64, device=self.dev))
+        tk = self.cfg["tracking"]
+        rows, cols = sh.sample_pixels_uniformly(self.H, self.W, tk["RO"]["n_rows"], tk["RO"]["n_cols"])
+        lat = (rows * self.W + cols).to(self.dev)
+        extra = self._device_valid_pixels(n_cur - lat.shape[0], it, lattice=lat)
+        idx.append(torch.cat([lat[None].expand(it, -1), extra], 1) + self.Kmax * R)
+        own.append(torch.full((it, n_cur), 0 if cur_is_first else -1, dtype=torch.int64, device=self.dev))
+        n = n_kf + n_cur
+        self.ba_rows[:, :n].copy_(torch.cat(idx, 1)), self.ba_owner[:, :n].copy_(torch.cat(own, 1))
+        self.ba_noise[:, :n].uniform_()
+        return n
+
+    def _fill_go_device(self):
+        s = self.cfg.get("sampling", {"n_rays_h": self.cfg["tracking"]["RO"]["n_rows"], "n_rays_w": self.cfg["tracking"]["RO"]["n_cols"]})
+        rows, cols = sh.sample_pixels_uniformly(self.H, self.W, s["n_rays_h"], s["n_rays_w"])
+        lat = (rows * self.W + cols).to(self.dev)
+        extra = self._device_valid_pixels(self.n_track - lat.shape[0], 1, lattice=lat)[0]
+        self.go_idx.copy_(torch.cat([lat, extra]))
+        self.go_noise.uniform_()
+
+    # ----------------------------------------------------------------------------------------------- bookkeeping
+    def _set_pose(self, rot, trans, slot, pose):
+        with torch.no_grad():
+            rot[slot].copy_(matrix_to_quaternion(pose[None, :3, :3])[0])
+            trans[slot].copy_(pose[:3, 3])
+
+    def _add_keyframe(self, pose):
+        self.db.store(self.n_kf, self.cur.view(self.H, self.W, 7)[self.kf_rows, self.kf_cols])
+        if self.n_kf == 0:
+            self.fixed[0].copy_(pose)
+        else:
+            self._set_pose(self.ba_rot, self.ba_trans, self.n_kf - 1, pose)
+        self.n_kf += 1
+
+    def _n_kf_at(self, k):
+        """keyframes stored when frame k's local BA runs (the frame itself is added AFTER its BA, mipsfusion.py:681-688)"""
+        return 1 + (k - 1) // self.kf_every
+
+    def _plan(self, k):
+        ba = torch.arange(self._n_kf_at(k)) if (k % self.cfg["mapping"]["map_every"] == 0) else None
+        return FramePlan(k, self.frames[k]["depth"], True, ba, self.Kmax * self.R)
+
+    def _load_ba(self, s: FrameSamples):
+        n = s.n_ba
+        self.ba_rows[:, :n].copy_(s.ba_rows[:, :n], non_blocking=True)
+        self.ba_owner[:, :n].copy_(s.ba_owner[:, :n], non_blocking=True)
+        self.ba_noise[:, :n].copy_(s.ba_noise[:, :n], non_blocking=True)
+        return n
+
+    # ------------------------------------------------------------------------------------------------------ run
+    def first_frame(self, gt_pose):
+        """mipsfusion.py:155-194: ground-truth pose, ``first_iters`` mapping iterations on frame 0's pixels."""
+        dev = self.dev
+        self.cur.copy_(self.host_rays[0], non_blocking=True)
+        pose0 = gt_pose.to(dev).float()
+        self._add_keyframe(pose0)
+        n = self._fill_ba_device(1, True)           # select_samples-style uniform pixels of frame 0 (device draws)
+        g = self._ba_graph(n)
+        for _ in range(max(0, self.first_iters // self.iters - 2)):
+            self._fill_ba_device(1, True)
+            g.replay()
+        for prm in self.model.parameters():         # the tracking graph is recorded with the map frozen
+            prm.requires_grad_(False)
+        self._set_pose(self.go_rot, self.go_trans, 0, pose0)
+        self._fill_go_device()
+        t0 = time.perf_counter()
+        self.go_graph = self._Graphed(self._go_step, self.cfg["tracking"]["iter"], warmup=1, stream=self.stream)
+        torch.cuda.synchronize()
+        self.capture_ms += (time.perf_counter() - t0) * 1e3
+        for prm in self.model.parameters():
+            prm.requires_grad_(True)
+        _ = pose0 @ torch.linalg.inv(pose0) @ pose0          # solver library start-up outside the loop
+        torch.cuda.synchronize()
+        return pose0
+
+    def run(self, gt_poses, precapture=True):
+        """-> dict of per-frame wall-clock lists (ms) and the estimated poses."""
+        cfg, dev = self.cfg, self.dev
+        tk, mp = cfg["tracking"], cfg["mapping"]
+        n_frames = len(self.frames)
+        est = [self.first_frame(gt_poses[0])]
+        if precapture:       # capture every BA graph shape of the sequence up front (one-off cost, reported separately)
+            for K in sorted({self._n_kf_at(k) for k in range(1, n_frames) if k % mp["map_every"] == 0}):
+                self._ba_graph(sum(ba_ray_counts(cfg, K)))
+        if self.producer is not None:
+            self.producer.submit(self._plan(1))
+        t_frame, t_ro, t_go, t_ba, t_wait = [], [], [], [], []
+        for k in range(1, n_frames):
+            t0 = time.perf_counter()
+            self.cur.copy_(self.host_rays[k], non_blocking=True)            # 8 MB frame hand-over (pinned)
+            samples, wait_ms = None, 0.0
+            if self.producer is not None:
+                if k + 1 < n_frames:
+                    self.producer.submit(self._plan(k + 1))                  # one frame ahead of the GPU
+            prev = est[-1]
+            init = prev if len(est) < 2 else prev @ torch.linalg.inv(est[-2]) @ prev   # constant velocity
+            self.model.eval()
+            pose = self.ro.optimize(self.model, self.cur.view(self.H, self.W, 7)[..., 6], init, None, n_iter=tk["iter_RO"])
+            self.model.train()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            self._set_pose(self.go_rot, self.go_trans, 0, pose)
+            self.go_popt.reset()
+            if self.producer is not None:
+                tw = time.perf_counter()
+                samples = self.producer.get()
+                wait_ms = (time.perf_counter() - tw) * 1e3
+                assert samples.frame_id == k
+                self.go_idx.copy_(samples.track_idx, non_blocking=True)
+                self.go_noise.copy_(samples.track_noise, non_blocking=True)
+            else:
+                self._fill_go_device()
+            self.go_graph.replay()
+            pose = qt_to_transform_matrix(self.go_rot.detach(), self.go_trans.detach())[0]
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            ba_ms = 0.0
+            if k % mp["map_every"] == 0:
+                assert self.n_kf == self._n_kf_at(k)
+                self._set_pose(self.ba_rot, self.ba_trans, -1, pose)
+                self.ba_popt.reset()
+                n = self._load_ba(samples) if samples is not None else self._fill_ba_device(self.n_kf, False)
+                self._ba_graph(n).replay()
+                pose = qt_to_transform_matrix(self.ba_rot[-1:].detach(), self.ba_trans[-1:].detach())[0]
+                torch.cuda.synchronize()
+                ba_ms = (time.perf_counter() - t2) * 1e3
+            if k % self.kf_every == 0:                                       # mipsfusion.py:686-688, after the BA
+                self._add_keyframe(pose)
+            est.append(pose)
+            torch.cuda.synchronize()
+            if samples is not None:
+                self.producer.release(samples)
+            t_frame.append((time.perf_counter() - t0) * 1e3), t_ro.append((t1 - t0) * 1e3)
+            t_go.append((t2 - t1) * 1e3), t_ba.append(ba_ms), t_wait.append(wait_ms)
+        if self.producer is not None:
+            self.producer.close()
+        return {"frame_ms": t_frame, "ro_ms": t_ro, "go_ms": t_go, "ba_ms": t_ba, "producer_wait_ms": t_wait,
+                "est": est, "capture_ms": self.capture_ms,
+                "producer_host_ms": dict(self.producer.host_ms) if self.producer is not None else None}
+
+
+def summarise(res, gt_poses, cfg, launch):
+    fm = np.array(res["frame_ms"])
+    err = [float((res["est"][k][:3, 3].cpu() - gt_poses[k][:3, 3].float()).norm()) for k in range(len(res["est"]))]
+    ba = [t for t in res["ba_ms"] if t > 0]
+    out = {"frames": len(res["est"]), "ms_per_frame_mean": round(float(fm.mean()), 3),
+           "ms_per_frame_median": round(float(np.median(fm)), 3), "ms_per_frame_p95": round(float(np.percentile(fm, 95)), 3),
+           "ro_ms_mean": round(float(np.mean(res["ro_ms"])), 3), "go_ms_mean": round(float(np.mean(res["go_ms"])), 3),
+           "ba_ms_per_round_median": round(float(np.median(ba)), 3) if ba else None,
+           "producer_wait_ms_mean": round(float(np.mean(res["producer_wait_ms"])), 3),
+           "graph_capture_ms_one_off": round(res["capture_ms"], 1),
+           "cadence": {"iter_RO": cfg["tracking"]["iter_RO"], "tracking_iter": cfg["tracking"]["iter"],
+                       "mapping_iters": cfg["mapping"]["iters"], "map_every": cfg["mapping"]["map_every"]},
+           "launch": launch, "ate_rmse_m": round(float(np.sqrt(np.mean(np.square(err)))), 4),
+           "ate_max_m": round(max(err), 4)}
+    if res.get("producer_host_ms"):
+        n = max(1, len(res["frame_ms"]))
+        out["producer_host_ms_per_frame"] = {k: round(v / n, 3) for k, v in res["producer_host_ms"].items()}
+    return out

@@ -88,7 +88,7 @@ def test_two_submap_sequence_matches_reference_run(fused_adam, in_place):
     print(f"sequence: worst relative loss deviation {worst:.2e} over {lo.size} iterations "
           f"(first 10: {np.max(np.abs(lo[:10] - lr[:10]) / np.abs(lr[:10])):.2e})")
     np.testing.assert_allclose(lo[:12], lr[:12], rtol=5e-4)       # before chaotic growth: tight
-    np.testing.assert_allclose(lo, lr, rtol=2e-2)                 # 51 Adam steps amplify fp32 summation-order noise
+    np.testing.assert_allclose(lo, lr, rtol=5e-3)                 # 51 Adam steps amplify fp32 summation-order noise (measured: <= 2e-3)
     # ---- poses: local pose of every frame (RandomOptimizer + pose Adam + BA + switch conversions)
     assert np.abs(out["est"][:, :3, 3] - g["est"][:, :3, 3]).max() < 2e-3, "translations (m)"
     assert np.abs(out["est"][:, :3, :3] - g["est"][:, :3, :3]).max() < 2e-3, "rotations"

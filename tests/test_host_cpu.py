@@ -181,3 +181,51 @@ def test_deepcopy_of_the_model_draws_no_random_numbers():
     assert torch.equal(torch.get_rng_state(), state)
     for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+@pytest.mark.parametrize("iter_ro", [5, 0])
+def test_sample_producer_reproduces_the_sequential_index_stream(iter_ro):
+    """mipsfusion_amd.sequence.ReferenceSampleProducer runs the torch-CPU and python generator streams in worker
+    threads, one frame ahead; its index sets and jitter must be bit-identical to calling the sampling functions one
+    after the other in the reference's program order (tracking_render mipsfusion.py:508-534, local_BA :293-317) from
+    the same seeds -- for both sampling branches (iter_RO > 0: sample_pixels_mix; iter_RO == 0: select_samples /
+    sample_valid_pixels_random).  The functions themselves are pinned by sampler.npz / keyframe_rays.npz."""
+    import random
+    import numpy as np
+    from mipsfusion_amd import sequence, synth
+    cfg = synth.config_headline()
+    cfg["tracking"].update(iter_RO=iter_ro, ignore_edge_H=20, ignore_edge_W=20, iter=3)
+    cfg["mapping"].update(iters=4)
+    H, W = 120, 160
+    R = 5000
+    plans = []
+    for k in range(1, 6):
+        g = torch.Generator().manual_seed(k)
+        depth = torch.rand(H, W, generator=g) * 3
+        depth[torch.rand(H, W, generator=g) < 0.05] = 0.0
+        related = torch.arange(1 + k // 2) if k % 2 == 0 else None          # BA on frames 2 and 4 with K = 2, 3
+        plans.append(sequence.FramePlan(k, depth, True, related, 7 * R))
+    random.seed(1), np.random.seed(1), torch.manual_seed(1)
+    want = sequence.sequential_reference_samples(cfg, H, W, R, plans)
+    state_after = (torch.get_rng_state(), random.getstate())
+    random.seed(1), np.random.seed(1), torch.manual_seed(1)
+    prod = sequence.ReferenceSampleProducer(cfg, H, W, R, max_related=4, pinned=False, slots=2)
+    prod.submit(plans[0])
+    for k, (plan, rec) in enumerate(zip(plans, want)):
+        if k + 1 < len(plans):
+            prod.submit(plans[k + 1])                                        # one frame ahead, as the loop does
+        s = prod.get()
+        assert s.frame_id == plan.frame_id
+        assert torch.equal(s.track_idx, rec["track_idx"])
+        assert torch.equal(s.track_noise, rec["track_noise"])
+        if plan.ba_kf_ids is not None:
+            n = rec["ba_rows"].shape[1]
+            assert s.n_ba == n
+            assert torch.equal(s.ba_rows[:, :n], rec["ba_rows"]) and torch.equal(s.ba_owner[:, :n], rec["ba_owner"])
+            assert torch.equal(s.ba_noise[:, :n], rec["ba_noise"])
+        prod.release(s)
+    prod.close()
+    for t in prod._threads:
+        t.join(10)
+    assert torch.equal(torch.get_rng_state(), state_after[0]) and random.getstate() == state_after[1], \
+        "both generators must end where the sequential program leaves them"

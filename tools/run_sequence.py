@@ -9,14 +9,13 @@ Only product modules are used (JointEncoding, RandomOptimizer, DeviceRayDB, Fuse
 JSON line: mean / median ms per frame (wall clock, eager launches, device synchronised per frame), the split into
 RO / GO / BA, and the trajectory error against the synthetic ground truth.
 
-``--graph`` runs the same cadence with the iterations replayed as hipGraphs (mipsfusion_amd.graph.GraphedSteps): all
-tracking iterations of a frame are one replay, all mapping iterations of a BA round another; rays are gathered inside
-the graph from one device table (keyframe database + current frame) through a static index buffer that is refilled
-per round with device-drawn indices (same per-keyframe shares as KeyframeSet.sample_rays_in_submap, drawn with
-replacement by torch.randint instead of python's random.sample), sample jitter is drawn inside the graph, the pose
-optimisers are reset in place (FusedAdam.reset) instead of rebuilt.
+``--graph`` runs the same cadence with the iterations replayed as hipGraphs (mipsfusion_amd/sequence.py): all tracking
+iterations of a frame are one replay, all mapping iterations of a BA round another; rays are gathered inside the graph
+from one device table (keyframe database + current frame) through static index / jitter buffers.  ``--sampler
+reference`` (default) fills them from the reference's own host generators, run one frame ahead by producer threads
+(bit-identical index stream); ``--sampler device`` draws indices and jitter on the GPU.
 
-usage: python tools/run_sequence.py [--frames 60] [--rays 4096] [--graph]
+usage: python tools/run_sequence.py [--frames 60] [--rays 4096] [--graph [--sampler reference|device]]
 """
 import argparse
 import json
@@ -62,6 +61,8 @@ def main():
     ap.add_argument("--first-iters", type=int, default=200, help="first-frame mapping iterations (reference: 500)")
     ap.add_argument("--profile", action="store_true", help="cProfile the per-frame loop (host side)")
     ap.add_argument("--graph", action="store_true", help="replay captured iterations instead of launching eagerly")
+    ap.add_argument("--sampler", choices=("reference", "device"), default="reference",
+                    help="--graph only: the reference's host generators run ahead in producer threads, or device draws")
     a = ap.parse_args()
     if a.graph:
         return main_graphed(a)
@@ -208,194 +209,28 @@ def main():
         "trajectory_length_m": round(float(sum((gt[k][:3, 3] - gt[k - 1][:3, 3]).norm() for k in range(1, a.frames))), 3)}))
 
 
-def report(a, cfg, gt, est, t_frame, t_ro, t_go, t_ba, launch, extra=None):
-    tr, mp = cfg["tracking"], cfg["mapping"]
-    err = [float((est[k][:3, 3].cpu() - gt[k][:3, 3].float()).norm()) for k in range(a.frames)]
-    hot = np.array(t_ro) + np.array(t_go) + np.array(t_ba)
-    out = {
-        "frames": a.frames, "rays_per_ba_iter": a.rays, "ms_per_frame_mean": round(float(np.mean(t_frame)), 3),
-        "ms_per_frame_median": round(float(np.median(t_frame)), 3),
-        "ro_ms_mean": round(float(np.mean(t_ro)), 3), "go_ms_mean": round(float(np.mean(t_go)), 3),
-        "ba_ms_mean_over_all_frames": round(float(np.mean(t_ba)), 3),
-        "ba_ms_per_round_median": round(float(np.median([t for t in t_ba if t > 0])), 3),
-        "hot_path_ms_per_frame_median": round(float(np.median(hot)), 3),
-        "hot_path_ms_per_frame_mean": round(float(np.mean(hot)), 3),
-        "cadence": {"iter_RO": tr["iter_RO"], "tracking_iter": tr["iter"], "mapping_iters": mp["iters"],
-                    "map_every": mp["map_every"], "keyframe_every": 15},
-        "launch": launch,
-        "ate_rmse_m": round(float(np.sqrt(np.mean(np.square(err)))), 4), "ate_max_m": round(max(err), 4),
-        "trajectory_length_m": round(float(sum((gt[k][:3, 3] - gt[k - 1][:3, 3]).norm() for k in range(1, a.frames))), 3)}
-    out.update(extra or {})
-    print("per-frame ms (RO, GO, BA):", " ".join(f"{r:.1f}/{g:.1f}/{b:.1f}" for r, g, b in zip(t_ro, t_go, t_ba)),
-          file=sys.stderr)
-    print(json.dumps(out))
-
-
 def main_graphed(a):
-    from mipsfusion_amd.graph import GraphedSteps, work_stream
+    """hipGraph replays + host sampling off the critical path: mipsfusion_amd/sequence.py."""
+    from mipsfusion_amd import sequence
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    stream = work_stream(dev)                 # everything that touches the optimised tensors runs on this stream
     random.seed(0), np.random.seed(0), torch.manual_seed(0)
     cfg = synth.config_headline()
-    tr, mp, tcfg = cfg["tracking"], cfg["mapping"], cfg["training"]
-    tr["RO"].setdefault("initial_scaling_factor", 0.02)
-    tr["RO"].setdefault("rescaling_factor", 0.5)
-    eh, ew = tr.setdefault("ignore_edge_H", 20), tr.setdefault("ignore_edge_W", 20)
-    kf_every, map_every, iters = 15, mp["map_every"], mp["iters"]
-    S = tcfg["n_samples_d"] + tcfg["n_range_d"]
-    H, W, fx, fy, cx, cy = synth.intrinsics_after_crop(cfg)
-    bb = torch.from_numpy(np.array(mp["bound"]))
-    nf = torch.from_numpy(np.array(mp["localMLP_max_len"]))
-    model = JointEncoding(cfg, bb, nf).to(dev).train()
-    model.accumulate_param_grads_in_place = True
+    if a.rays != 4096:
+        cfg["mapping"]["sample"] = a.rays - cfg["mapping"]["pixels_cur"]
     gt = trajectory(cfg, a.frames)
     frames = [synth.make_frame(cfg, gt[k], seed=k, frame_id=k) for k in range(a.frames)]
-    host_rays = [frame_rays(f).pin_memory() for f in frames]      # what a capture thread would hand over
-    ds = types.SimpleNamespace(H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy, rays_d=frames[0]["direction"])
-    ro = RandomOptimizer(cfg, types.SimpleNamespace(dataset=ds, device=dev))
-    kf_rows, kf_cols = sh.sample_pixels_uniformly(H, W, 100, 300 if W >= 300 else W // 2)
-    kf_rows, kf_cols = kf_rows.to(dev), kf_cols.to(dev)
-    R = kf_rows.shape[0]
-    Kmax = a.frames // kf_every + 2
-
-    # ---- one ray table: [Kmax keyframes x R rows | H*W rows of the current frame]
-    table = torch.zeros(Kmax * R + H * W, 7, device=dev)
-    db = DeviceRayDB(Kmax, R, dev, storage=table)
-    cur = table[Kmax * R:]                                        # [H*W, 7] view, refilled per frame
-    n_kf_stored = 0
-
-    # ---- static state of the captured mapping iteration
-    ba_rot = torch.nn.Parameter(torch.tensor([[1., 0., 0., 0.]], device=dev).repeat(Kmax, 1))    # slot j-1 = keyframe j,
-    ba_trans = torch.nn.Parameter(torch.zeros(Kmax, 3, device=dev))                               # slot -1 = current frame
-    fixed = torch.eye(4, device=dev)[None].clone()                # pose of keyframe 0 (never optimised)
-    ba_idx = torch.zeros(iters, a.rays, dtype=torch.int64, device=dev)
-    ba_owner = torch.zeros(iters, a.rays, dtype=torch.int64, device=dev)
-    map_opt = FusedAdam([{"params": model.decoder.parameters(), "weight_decay": 1e-6, "lr": mp["lr_decoder"]},
-                         {"params": model.embed_fn.parameters(), "eps": 1e-15, "lr": mp["lr_embed"]}],
-                        betas=(0.9, 0.99), capturable=True)
-    ba_popt = FusedAdam([{"params": ba_rot, "lr": mp["lr_rot"]}, {"params": ba_trans, "lr": mp["lr_trans"]}],
-                        capturable=True)
-
-    def ba_step(k):
-        d_cam, rgb, depth = ops.gather_rays(table, ba_idx[k], split=True)
-        rays_o, rays_d = ops.pose_rays(ba_rot, ba_trans, fixed, ba_owner[k], d_cam)
-        ret = model.forward(rays_o, rays_d, rgb, depth, noise=torch.rand(a.rays, S, device=dev))
-        get_loss_from_ret(ret, tcfg).backward()
-        map_opt.step(zero_grad=True)
-        if (k + 1) % mp["pose_accum_step"] == 0:
-            ba_popt.step(zero_grad=True)
-
-    def draw_ba_indices(K, cur_is_first):
-        """Per-keyframe shares of KeyframeSet.sample_rays_in_submap (keyframeSet.py:386-436) + current-frame pixels,
-        for all `iters` iterations of the round at once, on the device."""
-        n_cur = max(a.rays // max(K, 1), mp["pixels_cur"]) if K > 1 or not cur_is_first else a.rays
-        n_kf = a.rays - n_cur
-        idx, own = [], []
-        if n_kf:
-            n_first = max(n_kf // K, n_kf // 10)
-            idx.append(torch.randint(0, R, (iters, n_first), device=dev))
-            own.append(torch.zeros(iters, n_first, dtype=torch.int64, device=dev))
-            n_last = max(n_kf // K, n_kf // 5) if K > 2 else 0
-            n_other = n_kf - n_first - n_last
-            if K > 1 and n_other:
-                span = (K - 2) if K > 2 else 1
-                o = torch.randint(0, span * R, (iters, n_other), device=dev) + R
-                idx.append(o), own.append(o // R)
-            if n_last:
-                idx.append(torch.randint(0, R, (iters, n_last), device=dev) + (K - 1) * R)
-                own.append(torch.full((iters, n_last), K - 1, dtype=torch.int64, device=dev))
-        idx.append(torch.randint(0, H * W, (iters, n_cur), device=dev) + Kmax * R)
-        own.append(torch.full((iters, n_cur), 0 if cur_is_first else -1, dtype=torch.int64, device=dev))
-        ba_idx.copy_(torch.cat(idx, 1)), ba_owner.copy_(torch.cat(own, 1))
-
-    # ---- static state of the captured tracking iteration
-    n_track = tr["sample"]
-    go_rot = torch.nn.Parameter(torch.tensor([[1., 0., 0., 0.]], device=dev))
-    go_trans = torch.nn.Parameter(torch.zeros(1, 3, device=dev))
-    go_idx = torch.zeros(n_track, dtype=torch.int64, device=dev)
-    go_own = torch.zeros(n_track, dtype=torch.int64, device=dev)
-    go_popt = FusedAdam([{"params": go_rot, "lr": tr["lr_rot"]}, {"params": go_trans, "lr": tr["lr_trans"]}],
-                        capturable=True)
-
-    def go_step(k):
-        d_cam, rgb, depth = ops.gather_rays(cur, go_idx, split=True)
-        rays_o, rays_d = ops.pose_rays(go_rot, go_trans, None, go_own, d_cam)
-        ret = model.forward(rays_o, rays_d, rgb, depth, EMD_w=0., noise=torch.rand(n_track, S, device=dev))
-        get_loss_from_ret(ret, tcfg).backward()
-        go_popt.step(zero_grad=True)
-
-    def set_pose(rot, trans, slot, pose):
-        with torch.no_grad():
-            rot[slot].copy_(matrix_to_quaternion(pose[None, :3, :3])[0])
-            trans[slot].copy_(pose[:3, 3])
-
-    def add_keyframe(pose):
-        nonlocal n_kf_stored
-        db.store(n_kf_stored, cur.view(H, W, 7)[kf_rows, kf_cols])
-        if n_kf_stored == 0:
-            fixed[0].copy_(pose)
-        else:
-            set_pose(ba_rot, ba_trans, n_kf_stored - 1, pose)
-        n_kf_stored += 1
-
-    # ---- first frame: ground-truth pose, long mapping (mipsfusion.py:155-194); the capture warm-up iterations count
-    cur.copy_(host_rays[0], non_blocking=True)
-    est = [gt[0].to(dev).float()]
-    add_keyframe(est[0])
-    draw_ba_indices(1, True)
-    ba_graph = GraphedSteps(ba_step, iters, warmup=1, stream=stream)
-    for _ in range(max(0, a.first_iters // iters - 2)):
-        draw_ba_indices(1, True)
-        ba_graph.replay()
-    # tracking graph: the map is frozen while it is recorded (and therefore in every replay)
-    for prm in model.parameters():
-        prm.requires_grad_(False)
-    set_pose(go_rot, go_trans, 0, est[0])
-    go_idx.copy_(torch.randint(0, H * W, (n_track,), device=dev))
-    go_graph = GraphedSteps(go_step, tr["iter"], warmup=1, stream=stream)
-    for prm in model.parameters():
-        prm.requires_grad_(True)
-    _ = est[0] @ torch.linalg.inv(est[0]) @ est[0]               # solver / BLAS library start-up (~0.2 s) outside the loop
-    torch.cuda.synchronize()
-
-    t_frame, t_ro, t_go, t_ba = [], [], [], []
-    for k in range(1, a.frames):
-        t0 = time.perf_counter()
-        cur.copy_(host_rays[k], non_blocking=True)                # 8 MB frame hand-over (pinned)
-        prev = est[-1]
-        init = prev if len(est) < 2 else prev @ torch.linalg.inv(est[-2]) @ prev       # constant velocity
-        model.eval()
-        pose = ro.optimize(model, cur.view(H, W, 7)[..., 6], init, None, n_iter=tr["iter_RO"])
-        model.train()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        set_pose(go_rot, go_trans, 0, pose)
-        go_popt.reset()
-        rr = torch.randint(eh, H - eh, (n_track,), device=dev)
-        go_idx.copy_(rr * W + torch.randint(ew, W - ew, (n_track,), device=dev))
-        go_graph.replay()
-        pose = qt_to_transform_matrix(go_rot.detach(), go_trans.detach())[0]
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        ba_ms = 0.0
-        if k % kf_every == 0:
-            add_keyframe(pose)
-        if k % map_every == 0:
-            set_pose(ba_rot, ba_trans, -1, pose)
-            ba_popt.reset()
-            draw_ba_indices(n_kf_stored, False)
-            ba_graph.replay()
-            pose = qt_to_transform_matrix(ba_rot[-1:].detach(), ba_trans[-1:].detach())[0]
-            torch.cuda.synchronize()
-            ba_ms = (time.perf_counter() - t2) * 1e3
-        est.append(pose)
-        torch.cuda.synchronize()
-        t_frame.append((time.perf_counter() - t0) * 1e3), t_ro.append((t1 - t0) * 1e3)
-        t_go.append((t2 - t1) * 1e3), t_ba.append(ba_ms)
-    report(a, cfg, gt, est, t_frame, t_ro, t_go, t_ba,
-           "hipGraph replay per tracking frame / per BA round; index + jitter draws on the device; RO rounds eager; "
-           "includes the 8 MB pinned frame upload")
+    seq = sequence.GraphedSequence(cfg, dev, frames, kf_every=15, sampler=a.sampler, first_iters=a.first_iters)
+    res = seq.run(gt)
+    launch = ("hipGraph replay per tracking frame / per BA round; RO rounds eager; includes the 8 MB pinned frame upload; "
+              + ("pixel / keyframe-ray indices and jitter from the reference's host generators (python random, torch CPU), "
+                 "drawn one frame ahead by producer threads" if a.sampler == "reference" else
+                 "indices + jitter drawn on the device (valid depth only, without replacement)"))
+    out = sequence.summarise(res, gt, cfg, launch)
+    print("per-frame ms (RO, GO, BA, wait):", " ".join(f"{r:.1f}/{g:.1f}/{b:.1f}/{w:.1f}" for r, g, b, w in
+                                                        zip(res["ro_ms"], res["go_ms"], res["ba_ms"], res["producer_wait_ms"])),
+          file=sys.stderr)
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":
