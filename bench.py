@@ -30,8 +30,29 @@ import random
 import sys
 import time
 
-import numpy as np
-import torch
+
+
+def usable_cores():
+    """CPU threads this process may really use: min(affinity mask, cgroup CPU quota)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+# OpenMP sizes its pools by the machine's core count (256 on the GPU hosts) although the cgroup grants 16: every host
+# thread that touches a torch CPU op would oversubscribe the quota.  Must be set before torch is imported.
+os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -70,21 +91,6 @@ _T0 = time.time()
 
 def log(msg):
     print(f"[bench +{time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
-
-
-def usable_cores():
-    """CPU threads this process may really use: min(affinity mask, cgroup CPU quota)."""
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return max(1, n)
 
 
 def parse():
@@ -385,7 +391,7 @@ def measured_sequence(n_frames, dev, stream):
     """tracking + mapping ms/frame MEASURED over a synthetic sequence at the reference cadence (5 RO rounds, 10
     tracking iterations, 15 mapping iterations every 3rd frame, keyframe every 15th): mipsfusion_amd/sequence.py.
     `reference`: pixel / keyframe-ray indices and jitter from the reference's own host generators (bit-identical
-    index stream, drawn one frame ahead by producer threads); `device`: the same draws made on the GPU."""
+    index stream, drawn map_every frames ahead by producer threads); `device`: the same draws made on the GPU."""
     from mipsfusion_amd import sequence
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from run_sequence import trajectory

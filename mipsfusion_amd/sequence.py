@@ -10,7 +10,7 @@ once per optimisation iteration, between two GPU launches.  With the ~1 ms itera
 Nothing in those draws depends on a GPU result: the call sequence and every argument (image size, ray counts, the
 keyframes of the sub-map, the depth image of the frame) are known when the frame arrives.  So
 
-* ``ReferenceSampleProducer`` runs the three generator streams in their own threads, one frame AHEAD of the GPU, in the
+* ``ReferenceSampleProducer`` runs the three generator streams in their own threads, one mapping period (map_every frames) AHEAD of the GPU, in the
   reference's exact call order (the torch stream: per tracking frame ``randn_like`` + ``iter`` x ``rand(n, S)``, per
   mapping iteration ``randn_like`` + ``rand(N, S)``; the python stream: per mapping iteration the ``random.sample`` calls
   of ``sample_rays_in_submap``; scoring + ``topk`` is generator-free and runs on a third thread) and leaves index sets
@@ -146,6 +146,10 @@ class ReferenceSampleProducer:
     # ------------------------------------------------------------------------------------------- the three stages
     def _torch_stream(self):
         """torch's default CPU generator, in the reference's call order."""
+        # OpenMP's thread count is a per-thread setting whose default is the MACHINE's core count (256 on the GPU
+        # hosts, whose cgroup grants 16): an unset count oversubscribes the quota and these draws run 30x slower.
+        # The fills are serial under the generator lock anyway.
+        torch.set_num_threads(1)
         iter_ro0 = self.cfg["tracking"]["iter_RO"] == 0
         while True:
             item = self._q_torch.get()
@@ -169,6 +173,7 @@ class ReferenceSampleProducer:
 
     def _topk_stage(self):
         """Generator-free half of the valid-pixel samplers: mask, lattice blocking, top-k."""
+        torch.set_num_threads(2)
         tk, H, W = self.cfg["tracking"], self.H, self.W
         while True:
             item = self._q_topk.get()
@@ -196,6 +201,7 @@ class ReferenceSampleProducer:
     def _python_stream(self):
         """python's ``random`` generator: the keyframe-ray draws of every mapping iteration (keyframeSet.py:386-436),
         and the tracking pixels when iter_RO == 0 (select_samples, mipsfusion.py:510-515, its H-for-W quirk included)."""
+        torch.set_num_threads(1)
         tk = self.cfg["tracking"]
         while True:
             item = self._q_py.get()
@@ -273,7 +279,11 @@ class GraphedSequence:
     ``tracking.iter`` pose-only iterations -> every ``map_every``-th frame one replay of the ``mapping.iters`` local-BA
     iterations.  Rays are gathered inside the graphs from ONE device table [keyframe database | current frame]."""
 
-    def __init__(self, cfg, dev, frames, kf_every=15, sampler="reference", first_iters=200, stream=None):
+    def __init__(self, cfg, dev, frames, kf_every=15, sampler="reference", first_iters=200, stream=None,
+                 lookahead=None):
+        """lookahead: how many frames the sample producer runs ahead of the GPU (default: ``map_every``, one whole
+        mapping period -- a BA round needs ~40 ms of serial generator work, a frame without BA ~4 ms, so the work only
+        evens out over a period; the reference's own DataLoader prefetches 8 frames, mipsfusion.py:672)."""
         from .RandomOptimizer import RandomOptimizer
         from .graph import GraphedSteps, work_stream
         from .model import JointEncoding
@@ -330,8 +340,9 @@ class GraphedSequence:
         self.ba_graphs: Dict[int, object] = {}
         self.go_graph = None
         self.producer = None
+        self.lookahead = max(1, mp["map_every"] if lookahead is None else lookahead)
         if sampler == "reference":
-            self.producer = ReferenceSampleProducer(cfg, H, W, self.R, self.Kmax)
+            self.producer = ReferenceSampleProducer(cfg, H, W, self.R, self.Kmax, slots=self.lookahead + 2)
         self.capture_ms = 0.0
 
     # ------------------------------------------------------------------------------------- captured iterations
@@ -481,15 +492,16 @@ class GraphedSequence:
             for K in sorted({self._n_kf_at(k) for k in range(1, n_frames) if k % mp["map_every"] == 0}):
                 self._ba_graph(sum(ba_ray_counts(cfg, K)))
         if self.producer is not None:
-            self.producer.submit(self._plan(1))
+            for j in range(1, min(n_frames, 1 + self.lookahead)):
+                self.producer.submit(self._plan(j))
         t_frame, t_ro, t_go, t_ba, t_wait = [], [], [], [], []
         for k in range(1, n_frames):
             t0 = time.perf_counter()
             self.cur.copy_(self.host_rays[k], non_blocking=True)            # 8 MB frame hand-over (pinned)
             samples, wait_ms = None, 0.0
             if self.producer is not None:
-                if k + 1 < n_frames:
-                    self.producer.submit(self._plan(k + 1))                  # one frame ahead of the GPU
+                if k + self.lookahead < n_frames:
+                    self.producer.submit(self._plan(k + self.lookahead))     # `lookahead` frames ahead of the GPU
             prev = est[-1]
             init = prev if len(est) < 2 else prev @ torch.linalg.inv(est[-2]) @ prev   # constant velocity
             self.model.eval()

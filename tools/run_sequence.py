@@ -12,7 +12,7 @@ RO / GO / BA, and the trajectory error against the synthetic ground truth.
 ``--graph`` runs the same cadence with the iterations replayed as hipGraphs (mipsfusion_amd/sequence.py): all tracking
 iterations of a frame are one replay, all mapping iterations of a BA round another; rays are gathered inside the graph
 from one device table (keyframe database + current frame) through static index / jitter buffers.  ``--sampler
-reference`` (default) fills them from the reference's own host generators, run one frame ahead by producer threads
+reference`` (default) fills them from the reference's own host generators, run one mapping period ahead by producer threads
 (bit-identical index stream); ``--sampler device`` draws indices and jitter on the GPU.
 
 usage: python tools/run_sequence.py [--frames 60] [--rays 4096] [--graph [--sampler reference|device]]
@@ -27,6 +27,20 @@ import types
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
+
+
+def _usable_cores():
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+os.environ.setdefault("OMP_NUM_THREADS", str(_usable_cores()))      # see bench.py: the hosts report 256 cores, grant 16
 import torch  # noqa: E402
 
 from mipsfusion_amd import ops, synth  # noqa: E402
@@ -224,7 +238,7 @@ def main_graphed(a):
     res = seq.run(gt)
     launch = ("hipGraph replay per tracking frame / per BA round; RO rounds eager; includes the 8 MB pinned frame upload; "
               + ("pixel / keyframe-ray indices and jitter from the reference's host generators (python random, torch CPU), "
-                 "drawn one frame ahead by producer threads" if a.sampler == "reference" else
+                 "drawn map_every frames ahead by producer threads" if a.sampler == "reference" else
                  "indices + jitter drawn on the device (valid depth only, without replacement)"))
     out = sequence.summarise(res, gt, cfg, launch)
     print("per-frame ms (RO, GO, BA, wait):", " ".join(f"{r:.1f}/{g:.1f}/{b:.1f}/{w:.1f}" for r, g, b, w in
