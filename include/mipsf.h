@@ -128,6 +128,22 @@ int mipsf_decoder_fwd(const float* packed, const float* feat, int feat_layout, c
  * sdf: [M].  Bit-identical to column 3 of mipsf_decoder_fwd; layer 2 computes its sdf_emb half only, no rgb head. */
 int mipsf_decoder_fwd_sdf(const float* packed, const float* feat, int feat_layout, const float* x,
                           const float* embed_pos, int pe_mode, float* sdf, uint32_t M, void* stream);
+/* ---- the same forward on the f16 matrix cores (v_mfma_f32_32x32x16_f16, fp32 accumulate; csrc/decoder16.hip).
+ * precision MIPSF_PREC_F16X3: every fp32 operand is carried as hi + lo halves and a product is three MFMAs
+ *   (hi*hi + hi*lo + lo*hi): ~3e-7 relative, the training path -- `saved` has the layout mipsf_decoder_bwd_chain /
+ *   _wgrad read, results agree with mipsf_decoder_fwd to fp32 round-off class.
+ * precision MIPSF_PREC_F16: plain f16 operands (11 bits), fp32 accumulate: forward-only consumers with a stated
+ *   tolerance (RandomOptimizer fitness; BASELINE config 5 "fp16 decoder on CDNA4"), `saved` must be NULL.
+ * Positional encoding is always computed in-kernel (pe_mode 0).  sdf_only != 0: out is [M] (column 3 only).
+ * packed16: mipsf_decoder_packed16_floats() floats written by mipsf_decoder_pack16 (head tables + biases in fp32,
+ * hi and lo operand images of the three hidden layers). */
+#define MIPSF_PREC_F32 0
+#define MIPSF_PREC_F16X3 1
+#define MIPSF_PREC_F16 2
+uint32_t mipsf_decoder_packed16_floats(void);
+int mipsf_decoder_pack16(const mipsf_decoder_weights* w_host_struct, float* packed16, void* stream);
+int mipsf_decoder_fwd16(const float* packed16, const float* feat, int feat_layout, const float* x, float* out,
+                        float* saved, int sdf_only, int precision, uint32_t M, void* stream);
 /* Backward.  dout [M,10].  Outputs: dfeat (layout as feat), dx [M,3] (pe_mode 0: includes the PE chain),
  * dembed_pos [M,48] (pe_mode 1 only).  Weight gradients are ACCUMULATED into `grads`.
  * dact / partial: scratch of the sizes above. */

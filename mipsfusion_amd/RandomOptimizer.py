@@ -35,6 +35,10 @@ class RandomOptimizer:
         self.trunc_value = cfg["training"]["trunc"]
         # extension: split the swarm over the ranks of the default process group (each holds a replica of the sub-map)
         self.particle_split = False
+        # arithmetic of the decoder inside a round: plain f16 matrix-core operands by default (BASELINE config 5 "fp16
+        # decoder"; the swarm's weighted mean is insensitive to 1e-3 fitness noise: tracked pose within 1e-3 of the
+        # reference's, tests/test_gpu_parity.py); "f16x3" / "f32" reproduce the reference to 1e-4
+        self.decoder_precision = "f16"
 
         # particle swarm template, same draw as RandomOptimizer.py:26-33 (numpy global RNG)
         pst = np.random.multivariate_normal(np.zeros(6), np.eye(6), self.particle_size).astype(np.float32)
@@ -96,7 +100,9 @@ class RandomOptimizer:
         # point-major sample order: a hash-grid wavefront = 64 particles' copies of one lattice point (same cells)
         xn, pst7 = ops.ro_particles(pst, state, dirs, target_d, rc, point_major=_POINT_MAJOR)
         feat = ops.hashgrid_fwd(xn, model.embed_fn.params.detach(), model.embed_fn.meta, FEAT_LEVEL_MAJOR)
-        sdf = ops.decoder_fwd_sdf(packed, feat, FEAT_LEVEL_MAJOR, xn, None, P * n)      # SDF column only (scene_rep.py:106-107)
+        sdf = ops.decoder_fwd_sdf(packed if self.decoder_precision == "f32" else None, feat, FEAT_LEVEL_MAJOR, xn, None,
+                                  P * n, precision=self.decoder_precision,       # SDF column only (scene_rep.py:106-107)
+                                  packed16=None if self.decoder_precision == "f32" else packed)
         mean_masked = ops.ro_fitness(sdf.view(P, n, 1), target_d, self.trunc_value, point_major=_POINT_MAJOR)
         if world > 1:
             rows = mdist.gather_particle_results(torch.cat([mean_masked[:, None], pst7], 1), P_all, group)
@@ -118,7 +124,8 @@ class RandomOptimizer:
         state[9:12] = init[:3, 3]
         state[12:18] = float(self.scaling_coefficient1)
         rc = model._rc(1, 0)
-        packed = ops.decoder_pack(model.decoder.ordered_parameters())
+        ws = model.decoder.ordered_parameters()
+        packed = ops.decoder_pack(ws) if self.decoder_precision == "f32" else ops.decoder_pack16(ws)
         for i in range(n_iter):
             o = i % 5
             self._enqueue_round(model, state, td5[o], self._dirs[o], rc, packed)

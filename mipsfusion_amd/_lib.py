@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmipsf_hip.so")
 MAX_LEVELS = 32
 FEAT_AOS, FEAT_LEVEL_MAJOR = 0, 1
+PREC = {"f32": 0, "f16x3": 1, "f16": 2}      # MIPSF_PREC_* of include/mipsf.h
 
 
 class GridMeta(C.Structure):
@@ -89,6 +90,9 @@ SIGNATURES = {
     "mipsf_decoder_pack_host": (_I, [C.POINTER(DecoderWeights), _P]),
     "mipsf_decoder_fwd": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _U32, _P]),
     "mipsf_decoder_fwd_sdf": (_I, [_P, _P, _I, _P, _P, _I, _P, _U32, _P]),
+    "mipsf_decoder_packed16_floats": (_U32, []),
+    "mipsf_decoder_pack16": (_I, [C.POINTER(DecoderWeights), _P, _P]),
+    "mipsf_decoder_fwd16": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _U32, _P]),
     "mipsf_decoder_bwd": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.POINTER(DecoderGrads), _P, _P,
                                _U32, _P]),
     "mipsf_decoder_bwd_chain": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _U32, _P]),

@@ -1,0 +1,429 @@
+// SDF/colour decoder forward (model/decoder.py:53-75 of the reference) on the f16 matrix cores of gfx950
+// (v_mfma_f32_32x32x16_f16, fp32 accumulate): 16x the rate of the fp32-input MFMA the parity path of decoder.hip uses.
+//
+// Two arithmetic modes, one kernel template:
+//   SPLIT  ("f16x3")  every fp32 operand -- weights and activations -- is carried as hi + lo halves
+//                     (hi = rne(v), lo = rne(v - hi): 22 significant bits) and a product is three MFMAs,
+//                     hi*hi + hi*lo + lo*hi, accumulated in fp32.  Relative error of a dot product ~3e-7 (fp32's own
+//                     rounding is 6e-8): the training path, it passes the reference goldens at the fp32 kernel's
+//                     tolerances.  3/16 of the fp32-MFMA time in the matrix pipe.
+//   plain  ("f16")    one MFMA on the hi halves: 11-bit operands, fp32 accumulate.  Forward-only consumers whose
+//                     tolerance allows it (RandomOptimizer fitness, BASELINE config 5 "fp16 decoder").
+//
+// Same transposed, register-chained evaluation as decoder.hip (decoder_layout.h): the C/D register layout of the MFMA
+// does not depend on the operand type, so accumulator registers 8m..8m+7 of row tile q ARE the 8 B-operand elements
+// of k-step 2q+m of the next layer after a float -> half conversion; the saved-activation record (`saved`: H1, H2, H3
+// as accumulator images + ReLU masks) is bit-for-bit the layout the fp32 backward kernels read.
+//
+// Range: |activation| and |weight| must stay below 65504 (f16); the conversions saturate, they never produce inf.
+#include "decoder_dev.h"
+#include <stdlib.h>
+
+namespace mipsf {
+using namespace dl;
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// 8 fp32 values -> hi (and lo) halves: v_cvt_pk_f16_f32 (rne) per pair, two v_cvt_f32_f16, one v_pk_add_f32, one
+// more v_cvt_pk_f16_f32 for the residuals = 2.5 vector instructions per value
+template <bool SPLIT>
+__device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const h2 p = {(_Float16)v[i], (_Float16)v[i + 1]};
+        hi[i] = p.x, hi[i + 1] = p.y;
+        if (SPLIT) {
+            const h2 q = {(_Float16)(v[i] - (float)p.x), (_Float16)(v[i + 1] - (float)p.y)};
+            lo[i] = q.x, lo[i + 1] = q.y;
+        }
+    }
+}
+
+struct NoSide16 {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+
+__device__ __forceinline__ float relu1(float v) {          // one v_max_f32 (fmaxf costs a canonicalising second one)
+    float r;
+    asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+// acc[rt] (+)= A_image(rt, t) * B(t) over a layer's k-steps, software-pipelined and FENCED: the A operands of k-step
+// t+1 are requested and the B operand of k-step t+1 is converted while the MFMAs of k-step t run; the
+// sched_barrier(0) fences keep hipcc from sinking every operand read next to its consumer (measured with the naive
+// loop: ds_read + s_waitcnt lgkmcnt(0) in front of every MFMA pair, the matrix pipe 33 % busy).
+//   BIAS: the hi image has one extra k-step in front whose B operand is the constant (1, 1, 0, ...) of half 0 and whose
+//   A operand carries the bias as two halves; it also initialises the accumulators (C = 0).  Without BIAS the first
+//   data k-step starts from C = 0 (layer 1: the bias sits in that layer's padding elements).
+// img_hi: [rt][T + BIAS][lane], img_lo: [rt][T][lane] 16-byte operands (LDS in the persistent kernel, L2 otherwise).
+template <int RT, int T, bool SPLIT, bool BIAS, typename BFn, typename SideFn = NoSide16>
+__device__ __forceinline__ void mfma16_layer(const h8* img_hi, const h8* img_lo, int lane, int h, f32x16 (&acc)[RT],
+                                             BFn bfn, SideFn side = SideFn()) {
+    constexpr int TH = T + (BIAS ? 1 : 0);
+    // registers: the hi operands are double-buffered (requested one k-step ahead), the lo operands are requested at
+    // the top of their own k-step -- they are first needed two MFMA groups (8 MFMAs, 256 cycles) later
+    h8 ah[RT], al[RT], nh[RT], bh, bl, nbh, nbl;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) ah[rt] = img_hi[(rt * TH + (BIAS ? 1 : 0)) * 64 + lane];
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (BIAS) {
+        const _Float16 one = h == 0 ? (_Float16)1.0f : (_Float16)0.0f;
+        const h8 ones = {one, one, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(img_hi[(rt * TH) * 64 + lane], ones, zero);
+    }
+    bfn(0, bh, bl);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        if (SPLIT) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) al[rt] = img_lo[(rt * T + t) * 64 + lane];
+        }
+        if (t + 1 < T) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) nh[rt] = img_hi[(rt * TH + t + 1 + (BIAS ? 1 : 0)) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(ah[rt], bh, (!BIAS && t == 0) ? zero : acc[rt]);
+        if (SPLIT) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(ah[rt], bl, acc[rt]);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(al[rt], bh, acc[rt]);
+        }
+        if (t + 1 < T) bfn(t + 1, nbh, nbl);           // conversions of the next B operand ride under these MFMAs
+        side(t);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < T) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) ah[rt] = nh[rt];
+            bh = nbh, bl = nbl;
+        }
+    }
+}
+
+// one wave, one tile of 32 samples.  tail: fp32 head tables (LDS); img_hi / img_lo: the two operand image sets
+template <int LAYOUT, bool SAVE, bool SDF_ONLY, bool SPLIT>
+__device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const h8* img_hi, const h8* img_lo,
+                                                   const float* __restrict__ feat, const float* __restrict__ x,
+                                                   float* __restrict__ out, float* __restrict__ saved, uint32_t M,
+                                                   int pin, int64_t tile, int lane) {
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t s_raw = (uint32_t)(tile * 32 + j);
+    const bool live = s_raw < M;
+    const uint32_t s = live ? s_raw : M - 1;   // tail lanes recompute the last sample (finite values, no stores)
+    const uint32_t lane16 = 16u * (uint32_t)lane;
+    const srd_t sv = make_srd(SAVE ? saved + (size_t)tile * ACT_TILE_FLOATS : saved, SAVE ? ACT_TILE_FLOATS * 4 : 0);
+
+    float ev[E_SLOTS];
+    load_e<true>(x, nullptr, s, h, ev);
+
+    // ---- layer 1: pts_linear.0 + ReLU   (bias: elements BIAS16_U, +1 of k-step BIAS16_T meet the constant 1.0)
+    f32x16 H1[4];
+    mfma16_layer<RT_F1, T16_F1, SPLIT, false>(img_hi + OFF16H_F1 / 8, img_lo + OFF16L_F1 / 8, lane, h, H1,
+        [&](int t, h8& bh, h8& bl) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v[u] = 8 * t + u < E_SLOTS ? ev[8 * t + u] : 0.0f;
+                if (t == BIAS16_T && (u == BIAS16_U || u == BIAS16_U + 1)) v[u] = 1.0f;
+            }
+            split8<SPLIT>(v, bh, bl);
+        });
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H1[rt][r] = relu1(H1[rt][r]);
+    uint32_t m1[2] = {0u, 0u};
+    if (SAVE) relu_masks(H1, m1);
+
+    // ---- layer 2: pts_linear.2 -> [sdf_emb | rgb_emb]   (H1 leaves in two 16-byte pieces per k-step)
+    constexpr int RT2 = SDF_ONLY ? 2 : RT_F2;
+    f32x16 H2[RT2];
+    mfma16_layer<RT2, T16_F2, SPLIT, true>(img_hi + OFF16H_F2 / 8, img_lo + OFF16L_F2 / 8, lane, h, H2,
+        [&](int t, h8& bh, h8& bl) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = H1[t >> 1][8 * (t & 1) + u];
+            split8<SPLIT>(v, bh, bl);
+        },
+        [&](int t) {
+            if constexpr (SAVE) {
+                if (pin == 0) {
+                    buf_store_act_piece(sv, lane16, 0, H1, 2 * t);
+                    buf_store_act_piece(sv, lane16, 0, H1, 2 * t + 1);
+                }
+            }
+        });
+
+    // grid features of layer 3 (feature h of the 16 levels): requested before the rgb head, which covers the latency
+    float gf[16];
+    if (LAYOUT == MIPSF_FEAT_LEVEL_MAJOR && M < (1u << 24)) {
+        const srd_t fs = make_srd(feat, M * 128u);
+        const uint32_t voff = (2u * s + (uint32_t)h) * 4u;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            gf[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(fs, voff, (uint32_t)u * M * 8u, 0));
+    } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) gf[u] = load_feat<LAYOUT>(feat, s, u, h, M);
+    }
+
+    // ---- rgb_linear.0 on the vector ALU, fp32 (3 outputs): this lane's half of every dot product, then one swap
+    float rgb[3] = {0.f, 0.f, 0.f};
+    if constexpr (!SDF_ONLY) {
+        float pr[3];
+        const float4* trgb = reinterpret_cast<const float4*>(tail) + h * TRGB_SLOTS;
+        f32x2 p01 = {0.f, 0.f};
+        float p2 = 0.f;
+#pragma unroll
+        for (int slot = 0; slot < 32; ++slot) {
+            const float4 wv = trgb[slot];
+            const float v = H2[2 + (slot >> 4)][slot & 15];
+            p01 = __builtin_elementwise_fma(f32x2{wv.x, wv.y}, f32x2{v, v}, p01);
+            p2 = fmaf(wv.z, v, p2);
+        }
+#pragma unroll
+        for (int t = 0; t < E_SLOTS; ++t) {
+            const float4 wv = trgb[32 + t];
+            p01 = __builtin_elementwise_fma(f32x2{wv.x, wv.y}, f32x2{ev[t], ev[t]}, p01);
+            p2 = fmaf(wv.z, ev[t], p2);
+        }
+        pr[0] = p01.x, pr[1] = p01.y, pr[2] = p2;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb[c] = (pr[c] + __shfl_xor(pr[c], 32, 64)) + tail[OFF_BSMALL - OFF_TRGB + c];
+    }
+
+    // ---- layer 3: sdf_linear.0 + ReLU on [sdf_emb (H2 tiles 0,1) | grid features]
+    f32x16 H3[4];
+    mfma16_layer<RT_F3, T16_F3, SPLIT, true>(img_hi + OFF16H_F3 / 8, img_lo + OFF16L_F3 / 8, lane, h, H3,
+        [&](int t, h8& bh, h8& bl) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = t < 4 ? H2[(t >> 1) & 1][8 * (t & 1) + u] : gf[(8 * (t - 4) + u) & 15];
+            split8<SPLIT>(v, bh, bl);
+        },
+        [&](int t) {                                   // 16 pieces of H2 over 6 k-steps: 3, 3, 3, 3, 2, 2
+            if constexpr (SAVE && !SDF_ONLY) {
+                if (pin == 0) {
+                    buf_store_act_piece(sv, lane16, 1, H2, (t < 4 ? 3 * t : 12 + 2 * (t - 4)));
+                    buf_store_act_piece(sv, lane16, 1, H2, (t < 4 ? 3 * t : 12 + 2 * (t - 4)) + 1);
+                    if (t < 4) buf_store_act_piece(sv, lane16, 1, H2, 3 * t + 2);
+                }
+            }
+        });
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H3[rt][r] = relu1(H3[rt][r]);
+    if (SAVE) {
+        buf_store_act(sv, lane16, 2, H3);
+        uint32_t m3[2];
+        relu_masks(H3, m3);
+        uint2* mk = reinterpret_cast<uint2*>(saved + (((size_t)M + 127) / 128) * 4 * ACT_TILE_FLOATS) +
+                    (size_t)tile * (MASK_TILE_WORDS / 2) + lane;
+        mk[0] = make_uint2(m1[0], m1[1]);
+        mk[64] = make_uint2(m3[0], m3[1]);
+    }
+
+    // ---- sdf_linear.2 (5 logits) on the vector ALU in fp32, softmax, entropy, expected class -> SDF
+    float pl[N_CLASS];
+    {
+        const float4* ts2 = reinterpret_cast<const float4*>(tail) + (OFF_TS2 - OFF_TRGB) / 4 + h * 128;
+        f32x2 q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
+        float q4 = 0.f;
+#pragma unroll
+        for (int slot = 0; slot < 64; ++slot) {
+            const float4 w0 = ts2[2 * slot], w1 = ts2[2 * slot + 1];
+            const float v = H3[slot >> 4][slot & 15];
+            q01 = __builtin_elementwise_fma(f32x2{w0.x, w0.y}, f32x2{v, v}, q01);
+            q23 = __builtin_elementwise_fma(f32x2{w0.z, w0.w}, f32x2{v, v}, q23);
+            q4 = fmaf(w1.x, v, q4);
+        }
+        pl[0] = q01.x, pl[1] = q01.y, pl[2] = q23.x, pl[3] = q23.y, pl[4] = q4;
+    }
+    float lg[N_CLASS], mx = -3.0e38f;
+#pragma unroll
+    for (int c = 0; c < N_CLASS; ++c) {
+        lg[c] = (pl[c] + __shfl_xor(pl[c], 32, 64)) + tail[OFF_BSMALL - OFF_TRGB + 4 + c];
+        mx = fmaxf(mx, lg[c]);
+    }
+    float p[N_CLASS], den = 0.f;
+#pragma unroll
+    for (int c = 0; c < N_CLASS; ++c) {
+        p[c] = expf(lg[c] - mx);
+        den += p[c];
+    }
+    float ent = 0.f, cls = 0.f;
+#pragma unroll
+    for (int c = 0; c < N_CLASS; ++c) {
+        p[c] = p[c] / den;
+        ent += p[c] * log2f(p[c] + 1e-5f);
+        cls += p[c] * (float)c;
+    }
+    const float sdf = (cls / 4.0f - 0.5f) * 2.0f;
+    if (SDF_ONLY) {
+        if (live && h == 0) out[s] = sdf;
+        return;
+    }
+    if (live) {
+        float* o = out + (size_t)s * 10;
+        if (h == 0) {
+            o[0] = rgb[0], o[1] = rgb[1], o[2] = rgb[2], o[3] = sdf, o[4] = -1.0f * ent;
+        } else {
+            o[5] = p[0], o[6] = p[1], o[7] = p[2], o[8] = p[3], o[9] = p[4];
+        }
+    }
+}
+
+// Small batches: four independent waves per workgroup, operand images from L2, head tables + biases in LDS.
+template <int LAYOUT, bool SAVE, bool SDF_ONLY, bool SPLIT>
+__global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_fwd_kernel(const float* __restrict__ packed16,
+                                                                     const float* __restrict__ feat,
+                                                                     const float* __restrict__ x,
+                                                                     float* __restrict__ out,
+                                                                     float* __restrict__ saved, uint32_t M, int pin) {
+    __shared__ float4 tailbuf[TAIL_F4];
+    for (int q = threadIdx.x; q < TAIL_F4; q += DEC_BLOCK) tailbuf[q] = reinterpret_cast<const float4*>(packed16)[q];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (tile * 32 >= (int64_t)M) return;
+    const h8* img = reinterpret_cast<const h8*>(packed16 + TAIL_FLOATS);
+    decoder16_fwd_tile<LAYOUT, SAVE, SDF_ONLY, SPLIT>(reinterpret_cast<const float*>(tailbuf), img, img + IMG16H_HALVES / 8,
+                                                      feat, x, out, saved, M, pin, tile, lane);
+}
+
+// Large batches: persistent, one 8-wave workgroup per CU with the operand images (80 KB hi, + 72 KB lo when SPLIT) and
+// the head tables in LDS for its whole share of the batch (cf. decoder_fwd_lds_kernel).
+constexpr int F16_LDS_BLOCK = 512;
+template <bool SPLIT>
+constexpr int f16_lds_bytes() { return TAIL_FLOATS * 4 + IMG16H_HALVES * 2 + (SPLIT ? IMG16L_HALVES * 2 : 0); }
+template <int LAYOUT, bool SAVE, bool SDF_ONLY, bool SPLIT>
+__global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_fwd_lds_kernel(const float* __restrict__ packed16,
+                                                                             const float* __restrict__ feat,
+                                                                             const float* __restrict__ x,
+                                                                             float* __restrict__ out,
+                                                                             float* __restrict__ saved, uint32_t M,
+                                                                             int pin, uint32_t n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float4 wbuf[];
+    {
+        constexpr int N4 = f16_lds_bytes<SPLIT>() / 16;
+        const float4* src = reinterpret_cast<const float4*>(packed16);
+        for (int q = threadIdx.x; q < N4; q += F16_LDS_BLOCK) wbuf[q] = src[q];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    // EXPERIMENT (pin >> 8 = number of s_sleep(127)): delay the second wave of every SIMD so that the two co-resident
+    // waves are not in the same phase (both converting, then both wanting the matrix pipe)
+    if ((threadIdx.x >> 6) >= 4)
+        for (int q = 0; q < (pin >> 8); ++q) __builtin_amdgcn_s_sleep(127);
+    pin &= 255;
+    for (uint32_t tile = blockIdx.x * (F16_LDS_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+         tile < n_tiles; tile += gridDim.x * (F16_LDS_BLOCK / 64)) {
+        uint32_t z = 0;                       // opaque zero: keeps the loop-invariant LDS operand reads inside the loop
+        asm volatile("" : "+v"(z));
+        const float4* w4 = wbuf + z;
+        const h8* img = reinterpret_cast<const h8*>(w4 + TAIL_FLOATS / 4);
+        decoder16_fwd_tile<LAYOUT, SAVE, SDF_ONLY, SPLIT>(reinterpret_cast<const float*>(w4), img, img + IMG16H_HALVES / 8,
+                                                          feat, x, out, saved, M, pin, (int64_t)tile, lane);
+    }
+}
+
+__global__ __launch_bounds__(256) void decoder_pack16_kernel(W w, float* __restrict__ packed16) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < TAIL_FLOATS) packed16[idx] = packed_value(w, OFF_TRGB + idx);
+    if (idx < IMG16H_HALVES) {
+        _Float16* img = reinterpret_cast<_Float16*>(packed16 + TAIL_FLOATS);
+        const float v = img16_weight(w, idx);
+        const _Float16 hi = (_Float16)v;
+        img[idx] = hi;
+        const int lo = img16_lo_index(idx);
+        if (lo >= 0) img[IMG16H_HALVES + lo] = (_Float16)(v - (float)hi);
+    }
+}
+
+static W to_w16(const mipsf_decoder_weights& s) {
+    W w;
+    w.w_pts0 = s.w_pts0, w.b_pts0 = s.b_pts0, w.w_pts2 = s.w_pts2, w.b_pts2 = s.b_pts2, w.w_rgb0 = s.w_rgb0;
+    w.b_rgb0 = s.b_rgb0, w.w_sdf0 = s.w_sdf0, w.b_sdf0 = s.b_sdf0, w.w_sdf2 = s.w_sdf2, w.b_sdf2 = s.b_sdf2;
+    return w;
+}
+
+}  // namespace mipsf
+
+using namespace mipsf;
+
+extern "C" {
+
+uint32_t mipsf_decoder_packed16_floats(void) { return (uint32_t)PACKED16_FLOATS; }
+
+int mipsf_decoder_pack16(const mipsf_decoder_weights* w, float* packed16, void* stream) {
+    MIPSF_REQUIRE(w && packed16, "null pointer");
+    static_assert(IMG16H_HALVES >= TAIL_FLOATS, "one thread per image element covers the tail too");
+    static_assert(f16_lds_bytes<true>() <= 160 * 1024, "tail + both image sets must fit the 160 KB of LDS of a CU");
+    hipLaunchKernelGGL(decoder_pack16_kernel, dim3((IMG16H_HALVES + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       to_w16(*w), packed16);
+    return check_launch("decoder_pack16");
+}
+
+int mipsf_decoder_fwd16(const float* packed16, const float* feat, int feat_layout, const float* x, float* out,
+                        float* saved, int sdf_only, int precision, uint32_t M, void* stream) {
+    if (M == 0) return 0;
+    MIPSF_REQUIRE(packed16 && feat && x && out, "null pointer");
+    MIPSF_REQUIRE(feat_layout == MIPSF_FEAT_AOS || feat_layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout");
+    MIPSF_REQUIRE(precision == MIPSF_PREC_F16X3 || precision == MIPSF_PREC_F16, "precision must be f16x3 or f16");
+    MIPSF_REQUIRE(!(sdf_only && saved), "the SDF-only forward keeps no activations");
+    const uint32_t n_tiles = (uint32_t)(((uint64_t)M + 31) / 32);
+    const uint32_t blocks = (n_tiles + 3) / 4;
+    hipStream_t s = (hipStream_t)stream;
+    const int cus = device_cus();
+    if (cus <= 0) return 3;
+    const bool persistent = n_tiles >= (uint32_t)cus * 8u * 2u;
+    const char* st_env = getenv("MIPSF_F16_STAGGER");
+    const int stagger = st_env ? atoi(st_env) : 0;
+#define F16(LAY, SV, SDF, SPL)                                                                                     \
+    do {                                                                                                           \
+        if (persistent) {                                                                                          \
+            static bool attr_set_dev[MAX_DEVICES] = {false};                                                       \
+            bool& attr_set = attr_set_dev[device_slot()];                                                          \
+            if (!attr_set) {                                                                                       \
+                if (hipFuncSetAttribute((const void*)decoder16_fwd_lds_kernel<LAY, SV, SDF, SPL>,                  \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, f16_lds_bytes<SPL>()) !=       \
+                    hipSuccess) {                                                                                  \
+                    set_error("cannot raise dynamic LDS to %d bytes", f16_lds_bytes<SPL>());                       \
+                    return 4;                                                                                      \
+                }                                                                                                  \
+                attr_set = true;                                                                                   \
+            }                                                                                                      \
+            hipLaunchKernelGGL((decoder16_fwd_lds_kernel<LAY, SV, SDF, SPL>), dim3(cus), dim3(F16_LDS_BLOCK),      \
+                               f16_lds_bytes<SPL>(), s, packed16, feat, x, out, saved, M, stagger << 8, n_tiles);  \
+        } else {                                                                                                   \
+            hipLaunchKernelGGL((decoder16_fwd_kernel<LAY, SV, SDF, SPL>), dim3(blocks), dim3(DEC_BLOCK), 0, s,     \
+                               packed16, feat, x, out, saved, M, 0);                                               \
+        }                                                                                                          \
+    } while (0)
+#define F16_MODE(LAY, SPL)                                  \
+    do {                                                    \
+        if (sdf_only) F16(LAY, false, true, SPL);           \
+        else if (saved != nullptr) F16(LAY, true, false, SPL); \
+        else F16(LAY, false, false, SPL);                   \
+    } while (0)
+    if (feat_layout == MIPSF_FEAT_AOS) {
+        if (precision == MIPSF_PREC_F16X3) F16_MODE(MIPSF_FEAT_AOS, true); else F16_MODE(MIPSF_FEAT_AOS, false);
+    } else {
+        if (precision == MIPSF_PREC_F16X3) F16_MODE(MIPSF_FEAT_LEVEL_MAJOR, true); else F16_MODE(MIPSF_FEAT_LEVEL_MAJOR, false);
+    }
+#undef F16_MODE
+#undef F16
+    return check_launch("decoder_fwd16");
+}
+
+}  // extern "C"

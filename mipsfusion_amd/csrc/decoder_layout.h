@@ -144,6 +144,84 @@ MIPSF_HD float packed_value(const W& w, int idx) {
     return 0.f;
 }
 
+// ------------------------------------------------------------------ f16 operand images (decoder16.hip)
+// The same transposed, register-chained evaluation on v_mfma_f32_32x32x16_f16: one k-step carries 16 reduction
+// indices, the A/B operands are 8 halves per lane.  Lane (j, h) of the B operand supplies elements u = 0..7 = the
+// 8 input features of sample j that k-step t assigns to half h; with the C/D layout above (it does not depend on the
+// data type) accumulator registers 8m .. 8m+7 of row tile q of the previous layer are exactly the B operand of
+// k-step t = 2q + m of the next one, so the chaining needs no data movement, only a float -> half conversion.
+// fp32 values are carried as hi + lo halves (hi = rne(v), lo = rne(v - hi): 22 significant bits); a product is
+// hi*hi + hi*lo + lo*hi accumulated in fp32 (the dropped lo*lo term is 2^-22 relative).
+//
+// Biases ride on the matrix pipe: B-operand elements that are the constant 1.0 meet the bias in the A operand, so the
+// accumulators start from the inline constant 0 (no per-register initialisation, no bias loads).  A bias b occupies
+// TWO elements, b_hi = rne16(b) and b - b_hi, both against 1.0: exact to 22 bits with ONE MFMA (no lo products).
+// Layer 1 has padding to spare (elements u = 2, 3 of half 0 at k-step 3); layers 2 and 3 get a bias k-step of their
+// own in FRONT (t = 0: half 0, u = 0, 1) that exists in the hi image set only.
+constexpr int T16_F1 = 4, T16_F2 = 8, T16_F3 = 6;          // data k-steps (x16 inputs): e (52 -> 64), H1 (128), [sdf_emb | grid] (96)
+constexpr int T16H_F1 = 4, T16H_F2 = 9, T16H_F3 = 7;       // k-steps of the hi images (bias k-step first for layers 2, 3)
+constexpr int BIAS16_T = 3, BIAS16_U = 2;                  // layer 1: where the two bias elements sit (half 0)
+// e index carried by element (t, h, u) of layer 1's B operand (-1 = padding): the 26 e-slots of the fp32 kernel, 8 per k-step
+MIPSF_HD int e16(int t, int h, int u) { const int s = 8 * t + u; return s < E_SLOTS ? eidx(s, h) : -1; }
+// feature carried by element (t, h, u) when the B operand is accumulator registers 8*(t&1)+u of row tile t>>1
+MIPSF_HD int kfeat16(int t, int h, int u) { return 32 * (t >> 1) + rowmap(8 * (t & 1) + u, h); }
+// input index of sdf_linear.0 ([sdf_emb(64) | grid(32)]) carried by element (t, h, u): grid level 8*(t-4)+u, feature h
+MIPSF_HD int src16_f3(int t, int h, int u) { return t < 4 ? kfeat16(t, h, u) : N_EMB + 2 * (8 * (t - 4) + u) + h; }
+// images [layer][rt][t][lane][u]: halves; all hi images first, then all lo images (data k-steps only)
+constexpr int img16_halves(int rt, int T) { return rt * T * 64 * 8; }
+constexpr int OFF16H_F1 = 0;
+constexpr int OFF16H_F2 = OFF16H_F1 + img16_halves(RT_F1, T16H_F1);
+constexpr int OFF16H_F3 = OFF16H_F2 + img16_halves(RT_F2, T16H_F2);
+constexpr int IMG16H_HALVES = OFF16H_F3 + img16_halves(RT_F3, T16H_F3);   // 40 960 halves = 80 KB
+constexpr int OFF16L_F1 = 0;
+constexpr int OFF16L_F2 = OFF16L_F1 + img16_halves(RT_F1, T16_F1);
+constexpr int OFF16L_F3 = OFF16L_F2 + img16_halves(RT_F2, T16_F2);
+constexpr int IMG16L_HALVES = OFF16L_F3 + img16_halves(RT_F3, T16_F3);    // 36 864 halves = 72 KB
+constexpr int TAIL_FLOATS = PACKED_FLOATS - OFF_TRGB;                      // head tables (+ fp32 biases), as in `packed`
+constexpr int PACKED16_FLOATS = TAIL_FLOATS + (IMG16H_HALVES + IMG16L_HALVES) / 2;   // [tail fp32 | hi images | lo images]
+// the two halves a bias contributes: which = 0 -> rne16(b) as a float, 1 -> b - rne16(b)
+MIPSF_HD float bias16_part(float b, int which) {
+    const float hi = (float)(_Float16)b;
+    return which == 0 ? hi : b - hi;
+}
+// fp32 value behind element idx of the HI image set (the packer stores rne16 of it there and, for data k-steps, the
+// residual in the lo set at img16_lo_index)
+MIPSF_HD float img16_weight(const W& w, int idx) {
+    int base, T, kind;
+    if (idx < OFF16H_F2) { base = OFF16H_F1; T = T16H_F1; kind = 0; }
+    else if (idx < OFF16H_F3) { base = OFF16H_F2; T = T16H_F2; kind = 1; }
+    else { base = OFF16H_F3; T = T16H_F3; kind = 2; }
+    const int rel = idx - base;
+    const int u = rel & 7, lane = (rel >> 3) & 63, g = rel >> 9;       // g = rt * T + t
+    const int rt = g / T, t = g - rt * T;
+    const int i = lane & 31, h = lane >> 5;
+    const int row = 32 * rt + i;
+    if (kind == 0) {
+        if (t == BIAS16_T && h == 0 && (u == BIAS16_U || u == BIAS16_U + 1)) return bias16_part(w.b_pts0[row], u - BIAS16_U);
+        const int e = e16(t, h, u);
+        return e < 0 ? 0.f : w.w_pts0[row * N_E + e];
+    }
+    if (t == 0) {                                                       // bias k-step
+        const float* b = kind == 1 ? w.b_pts2 : w.b_sdf0;
+        return (h == 0 && u < 2) ? bias16_part(b[row], u) : 0.f;
+    }
+    if (kind == 1) return w.w_pts2[row * HID + kfeat16(t - 1, h, u)];
+    return w.w_sdf0[row * N_SDF_IN + src16_f3(t - 1, h, u)];
+}
+// index in the LO image set of hi-image element idx, or -1 (bias k-steps have no lo part)
+MIPSF_HD int img16_lo_index(int idx) {
+    int base, T, Tl, lbase;
+    if (idx < OFF16H_F2) { base = OFF16H_F1; T = T16H_F1; Tl = T16_F1; lbase = OFF16L_F1; }
+    else if (idx < OFF16H_F3) { base = OFF16H_F2; T = T16H_F2; Tl = T16_F2; lbase = OFF16L_F2; }
+    else { base = OFF16H_F3; T = T16H_F3; Tl = T16_F3; lbase = OFF16L_F3; }
+    const int rel = idx - base;
+    const int within = rel & 511, g = rel >> 9;
+    const int rt = g / T, t = g - rt * T;
+    const int tl = t - (T - Tl);                                         // data k-step number
+    if (tl < 0) return -1;
+    return lbase + ((rt * Tl + tl) << 9) + within;
+}
+
 // --------------------------------------------------------- activations kept between kernels
 // one 32-sample wave tile = 192 accumulator registers x 64 lanes, stored [tile][g = slot/4][lane][4]
 constexpr int ACT_SLOTS = 192;                 // 3 matrices x 4 row tiles x 16 regs

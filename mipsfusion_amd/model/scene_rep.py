@@ -79,9 +79,17 @@ class _QueryFn(torch.autograd.Function):
             feat, jac = ops.hashgrid_fwd(xn, grid_params.detach(), meta, FEAT_LEVEL_MAJOR, with_jac=True)
         else:
             feat = ops.hashgrid_fwd(xn, grid_params.detach(), meta, FEAT_LEVEL_MAJOR)
-        packed = ops.decoder_pack(weights)
         need = any(ctx.needs_input_grad)
-        out, saved = ops.decoder_fwd(packed, feat, FEAT_LEVEL_MAJOR, xn, None, M, save=need)
+        prec = owner.decoder_precision
+        if prec == "f16" and need:
+            raise RuntimeError('decoder_precision "f16" is forward-only (use "f16x3" or "f32" when gradients are needed)')
+        # the backward chain reads the fp32 operand images of `packed`; a forward-only f16 pass needs packed16 alone
+        packed = ops.decoder_pack(weights) if (need or prec == "f32") else None
+        packed16 = ops.decoder_pack16(weights) if prec != "f32" else None
+        out, saved = ops.decoder_fwd(packed, feat, FEAT_LEVEL_MAJOR, xn, None, M, save=need, precision=prec,
+                                     packed16=packed16)
+        if packed is None:
+            packed = packed16
         ctx.owner, ctx.M, ctx.meta, ctx.has_jac = owner, M, meta, jac is not None
         ctx.save_for_backward(xn, feat, out, saved, packed, grid_params, *weights, *([jac] if jac is not None else []))
         return out
@@ -164,6 +172,12 @@ class JointEncoding(nn.Module):
         self._half64 = torch.as_tensor(coords_norm_factor).detach().to("cpu", torch.float64).reshape(-1).tolist()
         # extension, off by default: see _QueryFn (plain `loss.backward()` loops may opt in)
         self.accumulate_param_grads_in_place = False
+        # arithmetic of the decoder's three hidden layers (csrc/decoder16.hip):
+        #   "f16x3" f16 matrix cores on hi/lo split operands, fp32 accumulate: ~3e-7 relative, passes the reference
+        #           goldens at the fp32 kernel's tolerances at 2.4x its speed (default)
+        #   "f32"   fp32-input matrix cores: exact fp32 products (the round-1 path)
+        #   "f16"   plain f16 operands, forward-only (2e-3 of the output range): set by consumers that state a tolerance
+        self.decoder_precision = "f16x3"
         self._tables = {}
         self.get_resolution()
         self.get_encoding(config)
@@ -229,6 +243,7 @@ class JointEncoding(nn.Module):
         new.load_state_dict(self.state_dict())
         new.initial_dict = copy.deepcopy(self.initial_dict)
         new.accumulate_param_grads_in_place = self.accumulate_param_grads_in_place
+        new.decoder_precision = self.decoder_precision
         new.train(self.training)
         return new
 
@@ -245,8 +260,12 @@ class JointEncoding(nn.Module):
             raise RuntimeError("JointEncoding runs on the GPU only (no CPU fallback)")
         xn = ops._f32c(flat)
         feat = ops.hashgrid_fwd(xn, self.embed_fn.params.detach(), self.embed_fn.meta, FEAT_LEVEL_MAJOR)
-        packed = ops.decoder_pack(self.decoder.ordered_parameters())
-        return ops.decoder_fwd_sdf(packed, feat, FEAT_LEVEL_MAJOR, xn, None, xn.shape[0])[:, None]
+        prec = self.decoder_precision
+        ws = self.decoder.ordered_parameters()
+        packed = ops.decoder_pack(ws) if prec == "f32" else None
+        packed16 = ops.decoder_pack16(ws) if prec != "f32" else None
+        return ops.decoder_fwd_sdf(packed, feat, FEAT_LEVEL_MAJOR, xn, None, xn.shape[0], precision=prec,
+                                   packed16=packed16)[:, None]
 
     def query_color(self, query_points):
         return torch.sigmoid(self.query_color_sdf(query_points)[..., :3])

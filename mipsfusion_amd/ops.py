@@ -172,11 +172,35 @@ def decoder_pack(weights, packed: Optional[torch.Tensor] = None) -> torch.Tensor
     return packed
 
 
-def decoder_fwd(packed, feat, layout, x, embed_pos, M, save: bool):
+def decoder_pack16(weights, packed16: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """weights: the 10 nn.Linear tensors in DECODER_PARAM_ORDER -> f16 operand images (hi + lo halves of every weight
+    of the three hidden layers) + the fp32 head tables and biases, for decoder_fwd(..., precision="f16x3" | "f16")."""
+    dev = weights[0].device
+    if packed16 is None:
+        packed16 = torch.empty(lib().mipsf_decoder_packed16_floats(), dtype=torch.float32, device=dev)
+    st = _decoder_struct([w.detach() for w in weights], _lib.DecoderWeights)
+    with _timed("decoder_pack"):
+        check(lib().mipsf_decoder_pack16(C.byref(st), dptr(packed16), stream_ptr()), "decoder_pack16")
+    return packed16
+
+
+def decoder_fwd(packed, feat, layout, x, embed_pos, M, save: bool, precision: str = "f32", packed16=None):
+    """precision "f32": fp32-input MFMA (exact fp32 products).  "f16x3": f16 MFMA on hi/lo split operands (~3e-7
+    relative; same `saved` layout, so the backward kernels are unchanged).  "f16": plain f16 operands, forward only.
+    The f16 modes need `packed16` (decoder_pack16) and the in-kernel positional encoding (embed_pos None)."""
     out = torch.empty((M, 10), dtype=torch.float32, device=x.device)
     saved = None
     if save:
         saved = torch.empty(lib().mipsf_decoder_saved_floats(M), dtype=torch.float32, device=x.device)
+    if precision != "f32":
+        if embed_pos is not None or packed16 is None:
+            raise RuntimeError("the f16 decoder modes take packed16 and compute the positional encoding in-kernel")
+        if save and precision != "f16x3":
+            raise RuntimeError('only precision "f32" / "f16x3" keep activations for the backward pass')
+        with _timed("decoder_fwd"):
+            check(lib().mipsf_decoder_fwd16(dptr(packed16), dptr(feat), layout, dptr(x), dptr(out), dptr(saved), 0,
+                                            _lib.PREC[precision], M, stream_ptr()), "decoder_fwd16")
+        return out, saved
     pe_mode = 0 if embed_pos is None else 1
     with _timed("decoder_fwd"):
         check(lib().mipsf_decoder_fwd(dptr(packed), dptr(feat), layout, dptr(x), dptr(embed_pos), pe_mode, dptr(out),
@@ -206,10 +230,17 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M):
     return dfeat, dx, dpe
 
 
-def decoder_fwd_sdf(packed, feat, layout, x, embed_pos, M) -> torch.Tensor:
+def decoder_fwd_sdf(packed, feat, layout, x, embed_pos, M, precision: str = "f32", packed16=None) -> torch.Tensor:
     """SDF column only (JointEncoding.query_sdf, model/scene_rep.py:106-107): [M] floats, bit-identical to column 3 of
     decoder_fwd, without the rgb half of layer 2, the rgb head and nine tenths of the output."""
     sdf = torch.empty((M,), dtype=torch.float32, device=x.device)
+    if precision != "f32":
+        if embed_pos is not None or packed16 is None:
+            raise RuntimeError("the f16 decoder modes take packed16 and compute the positional encoding in-kernel")
+        with _timed("decoder_fwd"):
+            check(lib().mipsf_decoder_fwd16(dptr(packed16), dptr(feat), layout, dptr(x), dptr(sdf), None, 1,
+                                            _lib.PREC[precision], M, stream_ptr()), "decoder_fwd16")
+        return sdf
     pe_mode = 0 if embed_pos is None else 1
     with _timed("decoder_fwd"):
         check(lib().mipsf_decoder_fwd_sdf(dptr(packed), dptr(feat), layout, dptr(x), dptr(embed_pos), pe_mode, dptr(sdf),

@@ -247,6 +247,7 @@ def test_config5_scannet_random_optimizer_slice_vs_oracle(dev):
     m.eval()
     f = synth.make_frame(cfg, seed=6)
     ro = _scannet_ro(cfg, dev, f)
+    ro.decoder_precision = "f16x3"                 # parity arithmetic against the oracle; plain f16 is checked at the end
     init = f["c2w"].clone()
     init[:3, 3] += torch.tensor([0.02, -0.015, 0.01])
     P, n = ro.particle_size, ro.row_indices.shape[0]
@@ -257,7 +258,7 @@ def test_config5_scannet_random_optimizer_slice_vs_oracle(dev):
     td = f["depth"][ro.row_indices, ro.col_indices].to(dev).contiguous()
     with torch.no_grad():
         mm = ro._enqueue_round(m, state.clone(), td, ro._dirs[0], m._rc(1, 0),
-                               ops.decoder_pack(m.decoder.ordered_parameters()))
+                               ops.decoder_pack16(m.decoder.ordered_parameters()))
         pst7 = ro_cpu.pose_6d_to_7d(ro.pre_sampled_particle.cpu() * 0.02)
         cam = f["direction"][ro.row_indices, ro.col_indices, :] * td.cpu()[:, None]
         world, _, _ = ro_cpu.particle_points(init[:3, :3], init[:3, 3:], pst7, cam)
@@ -273,6 +274,16 @@ def test_config5_scannet_random_optimizer_slice_vs_oracle(dev):
     check(pose[:3, 3], ref_pose[:3, 3], "tracked translation after 3 rounds", 1e-4, 1e-4)
     check(pose[:3, :3], ref_pose[:3, :3], "tracked rotation after 3 rounds", 1e-4, 1e-3, floor=1e-2)
     check(st[12:18], trace[-1]["search"].reshape(6), "search size", 1e-3, 1e-3, floor=1e-6)
+    # ---- BASELINE config 5's "fp16 decoder on CDNA4": plain f16 matrix-core operands (the RandomOptimizer's default)
+    ro.decoder_precision = "f16"
+    with torch.no_grad():
+        mm16 = ro._enqueue_round(m, state.clone(), td, ro._dirs[0], m._rc(1, 0),
+                                 ops.decoder_pack16(m.decoder.ordered_parameters()))
+    pose16 = ro.optimize(m, f["depth"], init, None, n_iter=3)
+    e_fit = float((mm16.cpu() - mm_ref).abs().max() / mm_ref.abs().max())
+    e_pose = float((pose16.cpu() - ref_pose).abs().max())
+    print(f"  plain f16 decoder: fitness error {e_fit:.2e} of max, tracked pose error {e_pose:.2e} (tolerances 5e-3, 1e-3)")
+    assert e_fit < 5e-3 and e_pose < 1e-3
 
 
 # ------------------------------------------------------------------------------------------------ config 4

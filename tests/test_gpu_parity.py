@@ -782,6 +782,7 @@ def test_random_optimizer_matches_reference_golden(dev):
     reference's own RandomOptimizer.optimize produced (tests/golden/ro.npz), round by round."""
     g = load_golden("ro.npz")
     cfg, ro = _ro_setup(g, dev)
+    ro.decoder_precision = "f16x3"          # parity arithmetic; the default plain-f16 rounds have their own test below
     assert np.array_equal(ro.row_indices.numpy(), g["rows"]) and np.array_equal(ro.col_indices.numpy(), g["cols"])
     ro.pre_sampled_particle = T(g["pst"]).to(dev).contiguous()
     m = make_scene(g, cfg, dev)
@@ -807,6 +808,27 @@ def test_random_optimizer_matches_reference_golden(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f16", "f32"])
+def test_random_optimizer_default_f16_rounds_track_the_reference_pose(dev, precision):
+    """The RandomOptimizer's default arithmetic is the plain-f16 matrix-core decoder (BASELINE config 5 "fp16 decoder
+    on CDNA4"): the pose tracked over 5 rounds (and every other round count of ro.npz) must stay within 1e-3 of the
+    pose the reference's own class produced; "f32" (fp32-input MFMA) is held to 1e-4 like "f16x3" above."""
+    g = load_golden("ro.npz")
+    cfg, ro = _ro_setup(g, dev)
+    assert ro.decoder_precision == "f16"
+    ro.decoder_precision = precision
+    ro.pre_sampled_particle = T(g["pst"]).to(dev).contiguous()
+    m = make_scene(g, cfg, dev).eval()
+    depth, init = T(g["depth"]), T(g["init_pose"])
+    worst = 0.0
+    for n_iter in range(0, 7):
+        pose = ro.optimize(m, depth, init.clone(), None, n_iter=n_iter)
+        worst = max(worst, float((pose.cpu() - T(g[f"pose_after_{n_iter}"])).abs().max()))
+    print(f"RandomOptimizer precision {precision}: max |pose - reference pose| over 0..6 rounds = {worst:.2e}")
+    assert worst < (1e-3 if precision == "f16" else 1e-4)
+
+
+@pytest.mark.gpu
 def test_random_optimizer_full_size_vs_oracle(dev):
     """2000 particles x (16 x 24) lattice points at the headline grid: three fused rounds vs oracle/ro_cpu.py fed
     with the same network (the oracle queries the GPU model so that only the particle logic is compared)."""
@@ -821,6 +843,7 @@ def test_random_optimizer_full_size_vs_oracle(dev):
     ds = types.SimpleNamespace(H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy, rays_d=frame["direction"])
     np.random.seed(5)
     ro = RandomOptimizer(cfg, types.SimpleNamespace(dataset=ds, device=dev))
+    ro.decoder_precision = m.decoder_precision      # the oracle below queries the GPU model: same arithmetic on both sides
     m.eval()
     init = frame["c2w"].clone()
     init[:3, 3] += torch.tensor([0.02, -0.015, 0.01])
@@ -1072,3 +1095,43 @@ def test_fused_adam_capturable_state_dict_roundtrip(dev):
             opt.step()
         return p.detach().clone()
     assert torch.equal(run(3, False), run(3, True))
+
+
+# ------------------------------------------------------------------ f16-MFMA decoder forward (csrc/decoder16.hip)
+@pytest.mark.parametrize("M", [1, 33, 1000, 70000])
+@pytest.mark.parametrize("layout", ["aos", "level_major"])
+def test_decoder_f16x3_forward_matches_fp32_kernel_and_oracle(dev, M, layout):
+    """precision "f16x3" (hi/lo split operands on v_mfma_f32_32x32x16_f16) vs the fp32-MFMA kernel and the oracle:
+    outputs to fp32 round-off class, the saved-activation record element for element (same layout: the fp32 backward
+    kernels consume it unchanged).  Small-batch and persistent (M = 70000) variants, both feature layouts."""
+    torch.manual_seed(M)
+    dec = MLP_reg({}, input_ch=32, input_ch_pos=48).to(dev)
+    with torch.no_grad():
+        dec.sdf_linear[2].weight.mul_(4.0)
+    ws = dec.ordered_parameters()
+    packed, packed16 = ops.decoder_pack(ws), ops.decoder_pack16(ws)
+    x = torch.rand(M, 3, device=dev)
+    feat_aos = (torch.randn(M, 32, device=dev) * 0.3).contiguous()
+    lay = _lib.FEAT_AOS if layout == "aos" else _lib.FEAT_LEVEL_MAJOR
+    feat = feat_aos if layout == "aos" else feat_aos.view(M, 16, 2).permute(1, 0, 2).contiguous()
+    o32, s32 = ops.decoder_fwd(packed, feat, lay, x, None, M, save=True)
+    o16, s16 = ops.decoder_fwd(packed, feat, lay, x, None, M, save=True, precision="f16x3", packed16=packed16)
+    assert_close(o16, o32, 2e-6, "f16x3 vs fp32 kernel, [M,10] output")
+    n_act = ((M + 127) // 128) * 4 * 192 * 64
+    n_tiles = (M + 31) // 32
+    a32 = s32[:n_act].view(-1, 192 * 64)[:n_tiles]
+    a16 = s16[:n_act].view(-1, 192 * 64)[:n_tiles]
+    assert_close(a16, a32, 2e-6, "saved activations (H1, H2, H3 accumulator images)")
+    w = {k: v.detach().cpu() for k, v in dec.state_dict().items()}
+    pe = tcnn_cpu.frequency_forward(x.cpu(), 8)
+    ref = path_cpu.decoder_forward(w, feat_aos.cpu(), pe, x.cpu())
+    assert_close(o16, ref, 3e-6, "f16x3 vs oracle")
+    sdf16 = ops.decoder_fwd_sdf(packed, feat, lay, x, None, M, precision="f16x3", packed16=packed16)
+    assert torch.equal(sdf16, o16[:, 3]), "f16x3 SDF-only branch = column 3 of the full f16x3 forward, bit for bit"
+    # plain f16 operands: forward-only, stated tolerance 2e-3 of the output range
+    p16, none = ops.decoder_fwd(packed, feat, lay, x, None, M, save=False, precision="f16", packed16=packed16)
+    assert none is None
+    assert_close(p16, ref, 2e-3, "plain f16 vs oracle")
+    sdfp = ops.decoder_fwd_sdf(packed, feat, lay, x, None, M, precision="f16", packed16=packed16)
+    assert_close(sdfp, ref[:, 3], 2e-3, "plain f16 SDF-only vs oracle")
+    assert float((sdfp - p16[:, 3]).abs().max()) <= 1e-6, "SDF-only branch = column 3 of the full plain-f16 forward"

@@ -45,6 +45,10 @@ class _KfSet:
 def product_backend(dev, fused_adam=True, in_place=False):
     from mipsfusion_amd.RandomOptimizer import RandomOptimizer
 
+    def _ro(ro):
+        ro.decoder_precision = "f16x3"      # parity arithmetic for the 51-iteration trace (plain f16 is the RO default)
+        return ro
+
     def make_model(cfg, bb, nf):
         m = JointEncoding(cfg, bb, nf).to(dev)
         m.accumulate_param_grads_in_place = in_place
@@ -55,7 +59,7 @@ def product_backend(dev, fused_adam=True, in_place=False):
         Adam=FusedAdam if fused_adam else torch.optim.Adam, sh=sh,
         qt_to_transform_matrix=gh.qt_to_transform_matrix, matrix_to_quaternion=gh.matrix_to_quaternion,
         make_kfset=lambda cfg, H, W, n: _KfSet(cfg, H, W, n, dev),
-        make_ro=lambda cfg, slam: RandomOptimizer(cfg, slam),
+        make_ro=lambda cfg, slam: _ro(RandomOptimizer(cfg, slam)),
         ro_optimize=lambda ro, model, depth, init, last, n: ro.optimize(model, depth, init, last, n_iter=n))
 
 
