@@ -48,11 +48,10 @@ struct NoSide16 {
     __device__ __forceinline__ void operator()(int) const {}
 };
 
-__device__ __forceinline__ float relu1(float v) {          // one v_max_f32 (fmaxf costs a canonicalising second one)
-    float r;
-    asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(v));
-    return r;
-}
+// ReLU as ONE compiler-visible instruction: v_med3_f32(v, 0, +inf).  (fmaxf costs a canonicalising v_max in front of
+// the real one; an inline-asm v_max reading an accumulator is invisible to hipcc's hazard padding: MFMA results must not
+// be read by asm without the 12 wait states of the 8-pass XDL, and the first version of this file read stale values.)
+__device__ __forceinline__ float relu1(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff()); }
 
 // acc[rt] (+)= A_image(rt, t) * B(t) over a layer's k-steps, software-pipelined and FENCED: the A operands of k-step
 // t+1 are requested and the B operand of k-step t+1 is converted while the MFMAs of k-step t run; the
@@ -156,10 +155,8 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const h8* 
         },
         [&](int t) {
             if constexpr (SAVE) {
-                if (pin == 0) {
-                    buf_store_act_piece(sv, lane16, 0, H1, 2 * t);
-                    buf_store_act_piece(sv, lane16, 0, H1, 2 * t + 1);
-                }
+                buf_store_act_piece(sv, lane16, 0, H1, 2 * t);
+                buf_store_act_piece(sv, lane16, 0, H1, 2 * t + 1);
             }
         });
 
@@ -212,11 +209,9 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const h8* 
         },
         [&](int t) {                                   // 16 pieces of H2 over 6 k-steps: 3, 3, 3, 3, 2, 2
             if constexpr (SAVE && !SDF_ONLY) {
-                if (pin == 0) {
-                    buf_store_act_piece(sv, lane16, 1, H2, (t < 4 ? 3 * t : 12 + 2 * (t - 4)));
-                    buf_store_act_piece(sv, lane16, 1, H2, (t < 4 ? 3 * t : 12 + 2 * (t - 4)) + 1);
-                    if (t < 4) buf_store_act_piece(sv, lane16, 1, H2, 3 * t + 2);
-                }
+                buf_store_act_piece(sv, lane16, 1, H2, (t < 4 ? 3 * t : 12 + 2 * (t - 4)));
+                buf_store_act_piece(sv, lane16, 1, H2, (t < 4 ? 3 * t : 12 + 2 * (t - 4)) + 1);
+                if (t < 4) buf_store_act_piece(sv, lane16, 1, H2, 3 * t + 2);
             }
         });
 #pragma unroll

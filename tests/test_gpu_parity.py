@@ -255,12 +255,30 @@ def test_scene_eval_golden(dev, name):
     assert_close(nd["depth"], g["nodepth.depth"], 1e-4, "no-depth depth")
 
 
+def assert_rays_close(a, b, tol, what, max_flipped_rays):
+    """Per-ray gradients: a ray's gradient changes by O(1) when ONE of its ~5000 discrete decisions (a ReLU, the first
+    sign change of the SDF along the ray) sits within rounding noise of its threshold and falls the other way.  The
+    fp32-MFMA path reproduces the reference's decisions on these fixtures (max_flipped_rays = 0); the f16x3 path carries
+    operands with 23 instead of 24 significant bits and is allowed that many rays with a flipped decision -- every other
+    ray must agree to `tol` of the maximum."""
+    a = a.detach().cpu().numpy()
+    b = np.asarray(b)
+    per_ray = np.abs(a - b).max(1) / (np.abs(b).max() + 1e-30)
+    off = np.nonzero(per_ray > tol)[0]
+    print(f"  {what}: {len(off)} of {len(per_ray)} rays off by > {tol:g} of max (allowed {max_flipped_rays}); "
+          f"median ray error {np.median(per_ray):.2e}")
+    assert len(off) <= max_flipped_rays, f"{what}: rays {off.tolist()} differ, worst {per_ray.max():.3e}"
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
 @pytest.mark.parametrize("name", ["scene_cfg1.npz", "scene_s75.npz"])
 @pytest.mark.parametrize("tag,emd", [("emd", 0.01), ("noemd", 0.0)])
-def test_scene_train_golden(dev, name, tag, emd):
+def test_scene_train_golden(dev, name, tag, emd, precision):
     g = load_golden(name)
     cfg = cfg_for(name)
     m = make_scene(g, cfg, dev).train()
+    assert m.decoder_precision == "f16x3", "the split-precision f16 matrix-core decoder is the default training path"
+    m.decoder_precision = precision
     ro = T(g["rays_o"]).to(dev).requires_grad_(True)
     rd = T(g["rays_d"]).to(dev).requires_grad_(True)
     ret = m.forward(ro, rd, T(g["target_rgb"]).to(dev), T(g["target_d"]).to(dev), EMD_w=emd,
@@ -272,11 +290,15 @@ def test_scene_train_golden(dev, name, tag, emd):
             + tr["sdf_weight"] * ret["sdf_loss"] + tr["fs_weight"] * ret["fs_loss"])
     assert_close(loss, g[f"{tag}.loss"], 1e-4, "total loss")
     loss.backward()
-    assert_close(ro.grad, g[f"{tag}.d_rays_o"], 5e-4, "d rays_o")
-    assert_close(rd.grad, g[f"{tag}.d_rays_d"], 5e-4, "d rays_d")
+    flips = 0 if precision == "f32" else 1
+    assert_rays_close(ro.grad, g[f"{tag}.d_rays_o"], 5e-4, "d rays_o", flips)
+    assert_rays_close(rd.grad, g[f"{tag}.d_rays_d"], 5e-4, "d rays_d", flips)
     for k, v in m.named_parameters():
         if v.numel():
-            assert_close(v.grad, g[f"{tag}.g.{k}"], 5e-4, "grad " + k)
+            if precision == "f32":
+                assert_close(v.grad, g[f"{tag}.g.{k}"], 5e-4, "grad " + k)
+            else:       # a flipped decision moves a handful of the entries that ray touches
+                assert_grad_close(v.grad, g[f"{tag}.g.{k}"], 5e-4, "grad " + k, outlier_frac=2e-3)
 
 
 def test_scene_module_api_and_queries(dev):
