@@ -144,6 +144,11 @@ uint32_t mipsf_decoder_packed16_floats(void);
 int mipsf_decoder_pack16(const mipsf_decoder_weights* w_host_struct, float* packed16, void* stream);
 int mipsf_decoder_fwd16(const float* packed16, const float* feat, int feat_layout, const float* x, float* out,
                         float* saved, int sdf_only, int precision, uint32_t M, void* stream);
+/* mipsf_decoder_bwd_chain on the f16 matrix cores (hi/lo split operands, fp32 accumulate; pe_mode 0 only): the same
+ * outputs and the same `dact` record, so mipsf_decoder_wgrad follows it unchanged.  saved: as written by
+ * mipsf_decoder_fwd / _fwd16 (only the ReLU masks are read). */
+int mipsf_decoder_bwd_chain16(const float* packed16, int feat_layout, const float* x, const float* out, const float* dout,
+                              const float* saved, float* dfeat, float* dx, float* dact, uint32_t M, void* stream);
 /* Backward.  dout [M,10].  Outputs: dfeat (layout as feat), dx [M,3] (pe_mode 0: includes the PE chain),
  * dembed_pos [M,48] (pe_mode 1 only).  Weight gradients are ACCUMULATED into `grads`.
  * dact / partial: scratch of the sizes above. */

@@ -93,6 +93,7 @@ SIGNATURES = {
     "mipsf_decoder_packed16_floats": (_U32, []),
     "mipsf_decoder_pack16": (_I, [C.POINTER(DecoderWeights), _P, _P]),
     "mipsf_decoder_fwd16": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _U32, _P]),
+    "mipsf_decoder_bwd_chain16": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _U32, _P]),
     "mipsf_decoder_bwd": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.POINTER(DecoderGrads), _P, _P,
                                _U32, _P]),
     "mipsf_decoder_bwd_chain": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _U32, _P]),

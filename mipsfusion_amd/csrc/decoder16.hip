@@ -61,9 +61,11 @@ __device__ __forceinline__ float relu1(float v) { return __builtin_amdgcn_fmed3f
 //   A operand carries the bias as two halves; it also initialises the accumulators (C = 0).  Without BIAS the first
 //   data k-step starts from C = 0 (layer 1: the bias sits in that layer's padding elements).
 // img_hi: [rt][T + BIAS][lane], img_lo: [rt][T][lane] 16-byte operands (LDS in the persistent kernel, L2 otherwise).
-template <int RT, int T, bool SPLIT, bool BIAS, typename BFn, typename SideFn = NoSide16>
+constexpr int INIT_ACC = 0, INIT_ZERO = 1, INIT_BIAS = 2;
+template <int RT, int T, bool SPLIT, int INIT, typename BFn, typename SideFn = NoSide16>
 __device__ __forceinline__ void mfma16_layer(const h8* img_hi, const h8* img_lo, int lane, int h, f32x16 (&acc)[RT],
                                              BFn bfn, SideFn side = SideFn()) {
+    constexpr bool BIAS = INIT == INIT_BIAS;
     constexpr int TH = T + (BIAS ? 1 : 0);
     // registers: the hi operands are double-buffered (requested one k-step ahead), the lo operands are requested at
     // the top of their own k-step -- they are first needed two MFMA groups (8 MFMAs, 256 cycles) later
@@ -90,7 +92,7 @@ __device__ __forceinline__ void mfma16_layer(const h8* img_hi, const h8* img_lo,
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(ah[rt], bh, (!BIAS && t == 0) ? zero : acc[rt]);
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(ah[rt], bh, (INIT == INIT_ZERO && t == 0) ? zero : acc[rt]);
         if (SPLIT) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(ah[rt], bl, acc[rt]);
@@ -126,7 +128,7 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const h8* 
 
     // ---- layer 1: pts_linear.0 + ReLU   (bias: elements BIAS16_U, +1 of k-step BIAS16_T meet the constant 1.0)
     f32x16 H1[4];
-    mfma16_layer<RT_F1, T16_F1, SPLIT, false>(img_hi + OFF16H_F1 / 8, img_lo + OFF16L_F1 / 8, lane, h, H1,
+    mfma16_layer<RT_F1, T16_F1, SPLIT, INIT_ZERO>(img_hi + OFF16H_F1 / 8, img_lo + OFF16L_F1 / 8, lane, h, H1,
         [&](int t, h8& bh, h8& bl) {
             float v[8];
 #pragma unroll
@@ -146,7 +148,7 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const h8* 
     // ---- layer 2: pts_linear.2 -> [sdf_emb | rgb_emb]   (H1 leaves in two 16-byte pieces per k-step)
     constexpr int RT2 = SDF_ONLY ? 2 : RT_F2;
     f32x16 H2[RT2];
-    mfma16_layer<RT2, T16_F2, SPLIT, true>(img_hi + OFF16H_F2 / 8, img_lo + OFF16L_F2 / 8, lane, h, H2,
+    mfma16_layer<RT2, T16_F2, SPLIT, INIT_BIAS>(img_hi + OFF16H_F2 / 8, img_lo + OFF16L_F2 / 8, lane, h, H2,
         [&](int t, h8& bh, h8& bl) {
             float v[8];
 #pragma unroll
@@ -200,7 +202,7 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const h8* 
 
     // ---- layer 3: sdf_linear.0 + ReLU on [sdf_emb (H2 tiles 0,1) | grid features]
     f32x16 H3[4];
-    mfma16_layer<RT_F3, T16_F3, SPLIT, true>(img_hi + OFF16H_F3 / 8, img_lo + OFF16L_F3 / 8, lane, h, H3,
+    mfma16_layer<RT_F3, T16_F3, SPLIT, INIT_BIAS>(img_hi + OFF16H_F3 / 8, img_lo + OFF16L_F3 / 8, lane, h, H3,
         [&](int t, h8& bh, h8& bl) {
             float v[8];
 #pragma unroll
@@ -332,6 +334,190 @@ __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_fwd_lds_kernel(con
     }
 }
 
+// ============================================================================ backward chain on the f16 matrix cores
+// d(out) -> d(grid features), d(x) and the pre-activation gradients dG3, dH2, dG1 + (d logits, d rgb) the
+// weight-gradient kernel consumes (`dact`, the fp32 record of decoder_bwd_lds_kernel, same layout).  Register-chained
+// like the forward: every gradient tile is an accumulator image whose registers are the next product's B operand after
+// a float -> (hi, lo) conversion; the two narrow products (Ws2^T dlogits, Wrgb^T drgb: K = 5 and 3) ride on the matrix
+// pipe as one k-step each instead of ~420 fmas and 160 table reads per tile.  Operand images come from L2.
+template <int LAYOUT>
+__global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_bwd_kernel(const float* __restrict__ packed16,
+                                                                     const float* __restrict__ x,
+                                                                     const float* __restrict__ out,
+                                                                     const float* __restrict__ dout,
+                                                                     const float* __restrict__ saved,
+                                                                     float* __restrict__ dfeat, float* __restrict__ dx,
+                                                                     float* __restrict__ dact, float* __restrict__ dsmall,
+                                                                     uint32_t M) {
+    constexpr bool SPLIT = true;
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (tile * 32 >= (int64_t)M) return;
+    const uint32_t s_raw = (uint32_t)(tile * 32 + j);
+    const bool live = s_raw < M;
+    const uint32_t s = live ? s_raw : M - 1;
+    const uint32_t lane16 = 16u * (uint32_t)lane;
+    const srd_t da = make_srd(dact + (size_t)tile * ACT_TILE_FLOATS, ACT_TILE_FLOATS * 4);
+    const h8* bhi = reinterpret_cast<const h8*>(packed16 + TAIL_FLOATS) + OFF16_BWD_HALVES / 8;
+    const h8* blo = bhi + IMG16B_HALVES / 8;
+
+    float2 o2[5], g2[5];
+    {
+        const float2* o = reinterpret_cast<const float2*>(out + (size_t)s * 10);
+        const float2* g = reinterpret_cast<const float2*>(dout + (size_t)s * 10);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) o2[c] = o[c], g2[c] = g[c];
+    }
+    const uint2* mk = reinterpret_cast<const uint2*>(saved + (((size_t)M + 127) / 128) * 4 * ACT_TILE_FLOATS) +
+                      (size_t)tile * (MASK_TILE_WORDS / 2) + lane;
+    const uint2 mk1 = mk[0], mk3 = mk[64];
+    const uint32_t m1[2] = {mk1.x, mk1.y}, m3[2] = {mk3.x, mk3.y};
+
+    // ---- softmax / entropy / expected-class backward -> d logits; d rgb is the incoming gradient itself
+    float dlg[N_CLASS], drgb[3];
+    {
+        const float gv[10] = {g2[0].x, g2[0].y, g2[1].x, g2[1].y, g2[2].x, g2[2].y, g2[3].x, g2[3].y, g2[4].x, g2[4].y};
+        const float ov[10] = {o2[0].x, o2[0].y, o2[1].x, o2[1].y, o2[2].x, o2[2].y, o2[3].x, o2[3].y, o2[4].x, o2[4].y};
+        const float g_sdf = live ? gv[3] : 0.f, g_ent = live ? gv[4] : 0.f;
+        float p[N_CLASS], dp[N_CLASS], dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < N_CLASS; ++c) {
+            p[c] = ov[5 + c];
+            const float q = p[c] + 1e-5f;
+            const float dent = -1.0f * (log2f(q) + p[c] / (q * 0.69314718055994530942f));
+            dp[c] = (live ? gv[5 + c] : 0.f) + g_sdf * (0.5f * (float)c) + g_ent * dent;
+            dot += p[c] * dp[c];
+        }
+#pragma unroll
+        for (int c = 0; c < N_CLASS; ++c) dlg[c] = p[c] * (dp[c] - dot);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) drgb[c] = live ? gv[c] : 0.f;
+        if (h == 0) {
+            float4* d4 = reinterpret_cast<float4*>(dsmall + (size_t)(tile * 32 + j) * 8);
+            d4[0] = make_float4(dlg[0], dlg[1], dlg[2], dlg[3]);
+            d4[1] = make_float4(dlg[4], drgb[0], drgb[1], drgb[2]);
+        }
+    }
+    // B operands of the two narrow products: half 0 carries the 5 (3) values in elements 0..4 (0..2), half 1 zeros
+    h8 lgh, lgl, rgh, rgl;
+    {
+        float v[8], r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            v[u] = (h == 0 && u < N_CLASS) ? dlg[u < N_CLASS ? u : 0] : 0.0f;
+            r[u] = (h == 0 && u < 3) ? drgb[u < 3 ? u : 0] : 0.0f;
+        }
+        split8<SPLIT>(v, lgh, lgl);
+        split8<SPLIT>(r, rgh, rgl);
+    }
+
+    // ---- dG3 = relu'(H3) * (Ws2^T dlogits)
+    f32x16 dG3[4];
+    mfma16_layer<RT16_S2T, T16_S2T, SPLIT, INIT_ZERO>(bhi + OFF16B_S2T / 8, blo + OFF16B_S2T / 8, lane, h, dG3,
+        [&](int, h8& b0, h8& b1) { b0 = lgh, b1 = lgl; });
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dG3[rt][r] = mask_apply(m3, rt, r, dG3[rt][r]);
+
+    // ---- d[sdf_emb | grid] = Ws1^T dG3   (row tiles 0,1 -> d sdf_emb, 2 -> d grid features); dG3 leaves for `dact`
+    f32x16 dIn3[3];
+    mfma16_layer<RT16_B3, T16_B3, SPLIT, INIT_ZERO>(bhi + OFF16B_B3 / 8, blo + OFF16B_B3 / 8, lane, h, dIn3,
+        [&](int t, h8& b0, h8& b1) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = dG3[t >> 1][8 * (t & 1) + u];
+            split8<SPLIT>(v, b0, b1);
+        },
+        [&](int t) {
+            buf_store_act_piece(da, lane16, 2, dG3, 2 * t);
+            buf_store_act_piece(da, lane16, 2, dG3, 2 * t + 1);
+        });
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const int row = rowmap(r, h);
+            const float2 v = make_float2(dIn3[2][r], dIn3[2][r + 1]);
+            if (LAYOUT == MIPSF_FEAT_AOS)
+                *reinterpret_cast<float2*>(dfeat + (size_t)s * N_GRID + row) = v;
+            else
+                *reinterpret_cast<float2*>(dfeat + ((size_t)(row >> 1) * M + s) * 2) = v;
+        }
+    }
+
+    // ---- dH2 = [d sdf_emb | d rgb_emb = Wrgb[:, :64]^T drgb]
+    f32x16 dH2[4];
+    dH2[0] = dIn3[0], dH2[1] = dIn3[1];
+    {
+        f32x16 dRgb[2];
+        mfma16_layer<RT16_RGBT, T16_RGBT, SPLIT, INIT_ZERO>(bhi + OFF16B_RGBT / 8, blo + OFF16B_RGBT / 8, lane, h, dRgb,
+            [&](int, h8& b0, h8& b1) { b0 = rgh, b1 = rgl; });
+        dH2[2] = dRgb[0], dH2[3] = dRgb[1];
+    }
+
+    // ---- dG1 = relu'(H1) * (W2^T dH2)
+    f32x16 dG1[4];
+    mfma16_layer<RT16_B2, T16_B2, SPLIT, INIT_ZERO>(bhi + OFF16B_B2 / 8, blo + OFF16B_B2 / 8, lane, h, dG1,
+        [&](int t, h8& b0, h8& b1) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = dH2[t >> 1][8 * (t & 1) + u];
+            split8<SPLIT>(v, b0, b1);
+        },
+        [&](int t) {
+            buf_store_act_piece(da, lane16, 1, dH2, 2 * t);
+            buf_store_act_piece(da, lane16, 1, dH2, 2 * t + 1);
+        });
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dG1[rt][r] = mask_apply(m1, rt, r, dG1[rt][r]);
+
+    // ---- d e = W1^T dG1 + Wrgb[:, 64:]^T drgb; rows are arranged so that e-slot (t, h) lands in THIS lane
+    f32x16 dE[2];
+    mfma16_layer<RT16_B1, T16_B1, SPLIT, INIT_ZERO>(bhi + OFF16B_B1 / 8, blo + OFF16B_B1 / 8, lane, h, dE,
+        [&](int t, h8& b0, h8& b1) {
+            if (t == 8) {
+                b0 = rgh, b1 = rgl;
+            } else {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = dG1[(t >> 1) & 3][8 * (t & 1) + u];
+                split8<SPLIT>(v, b0, b1);
+            }
+        },
+        [&](int t) {
+            if (t < 8) {
+                buf_store_act_piece(da, lane16, 0, dG1, 2 * t);
+                buf_store_act_piece(da, lane16, 0, dG1, 2 * t + 1);
+            }
+        });
+
+    const float x0 = x[3 * (size_t)s], x1 = x[3 * (size_t)s + 1], x2 = x[3 * (size_t)s + 2];
+    float de[E_SLOTS];
+#pragma unroll
+    for (int t = 0; t < E_SLOTS; ++t) de[t] = dE[t >> 4][t & 15];
+    float g3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float xd = d == 0 ? x0 : (d == 1 ? x1 : x2);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            // derivative at the argument the forward used (cos_reduced: 6 instructions)
+            const float arg = fmaf(ldexpf(xd, k), PI_F, h ? HALF_PI_F : 0.0f);
+            g3[d] = g3[d] + de[d * 8 + k] * ((ldexpf(1.0f, k) * PI_F) * cos_reduced(arg));
+        }
+    }
+    g3[0] += h == 0 ? de[24] : 0.0f;   // slot 24 carries x0 (lower half) / x1 (upper half)
+    g3[1] += h == 1 ? de[24] : 0.0f;
+    g3[2] += h == 0 ? de[25] : 0.0f;   // slot 25 carries x2 (lower half only)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) g3[d] = g3[d] + __shfl_xor(g3[d], 32, 64);
+    if (live && h == 0) {
+        dx[3 * (size_t)s] = g3[0], dx[3 * (size_t)s + 1] = g3[1], dx[3 * (size_t)s + 2] = g3[2];
+    }
+}
+
 __global__ __launch_bounds__(256) void decoder_pack16_kernel(W w, float* __restrict__ packed16) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < TAIL_FLOATS) packed16[idx] = packed_value(w, OFF_TRGB + idx);
@@ -342,6 +528,13 @@ __global__ __launch_bounds__(256) void decoder_pack16_kernel(W w, float* __restr
         img[idx] = hi;
         const int lo = img16_lo_index(idx);
         if (lo >= 0) img[IMG16H_HALVES + lo] = (_Float16)(v - (float)hi);
+    }
+    if (idx < IMG16B_HALVES) {
+        _Float16* img = reinterpret_cast<_Float16*>(packed16 + TAIL_FLOATS) + OFF16_BWD_HALVES;
+        const float v = img16b_weight(w, idx);
+        const _Float16 hi = (_Float16)v;
+        img[idx] = hi;
+        img[IMG16B_HALVES + idx] = (_Float16)(v - (float)hi);
     }
 }
 
@@ -362,7 +555,7 @@ uint32_t mipsf_decoder_packed16_floats(void) { return (uint32_t)PACKED16_FLOATS;
 
 int mipsf_decoder_pack16(const mipsf_decoder_weights* w, float* packed16, void* stream) {
     MIPSF_REQUIRE(w && packed16, "null pointer");
-    static_assert(IMG16H_HALVES >= TAIL_FLOATS, "one thread per image element covers the tail too");
+    static_assert(IMG16H_HALVES >= TAIL_FLOATS && IMG16H_HALVES >= IMG16B_HALVES, "one thread per hi-image element covers all");
     static_assert(f16_lds_bytes<true>() <= 160 * 1024, "tail + both image sets must fit the 160 KB of LDS of a CU");
     hipLaunchKernelGGL(decoder_pack16_kernel, dim3((IMG16H_HALVES + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        to_w16(*w), packed16);
@@ -419,6 +612,25 @@ int mipsf_decoder_fwd16(const float* packed16, const float* feat, int feat_layou
 #undef F16_MODE
 #undef F16
     return check_launch("decoder_fwd16");
+}
+
+
+int mipsf_decoder_bwd_chain16(const float* packed16, int feat_layout, const float* x, const float* out, const float* dout,
+                              const float* saved, float* dfeat, float* dx, float* dact, uint32_t M, void* stream) {
+    if (M == 0) return 0;
+    MIPSF_REQUIRE(packed16 && x && out && dout && saved && dfeat && dx && dact, "null pointer");
+    MIPSF_REQUIRE(feat_layout == MIPSF_FEAT_AOS || feat_layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout");
+    const uint64_t n_bt = ((uint64_t)M + 127) / 128;
+    const uint32_t blocks = (uint32_t)((((uint64_t)M + 31) / 32 + 3) / 4);
+    float* dsmall = dact + n_bt * 4 * ACT_TILE_FLOATS;
+    hipStream_t s = (hipStream_t)stream;
+    if (feat_layout == MIPSF_FEAT_AOS)
+        hipLaunchKernelGGL((decoder16_bwd_kernel<MIPSF_FEAT_AOS>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed16, x, out,
+                           dout, saved, dfeat, dx, dact, dsmall, M);
+    else
+        hipLaunchKernelGGL((decoder16_bwd_kernel<MIPSF_FEAT_LEVEL_MAJOR>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed16, x,
+                           out, dout, saved, dfeat, dx, dact, dsmall, M);
+    return check_launch("decoder_bwd_chain16");
 }
 
 }  // extern "C"

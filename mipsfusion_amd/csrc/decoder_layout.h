@@ -178,7 +178,51 @@ constexpr int OFF16L_F2 = OFF16L_F1 + img16_halves(RT_F1, T16_F1);
 constexpr int OFF16L_F3 = OFF16L_F2 + img16_halves(RT_F2, T16_F2);
 constexpr int IMG16L_HALVES = OFF16L_F3 + img16_halves(RT_F3, T16_F3);    // 36 864 halves = 72 KB
 constexpr int TAIL_FLOATS = PACKED_FLOATS - OFF_TRGB;                      // head tables (+ fp32 biases), as in `packed`
-constexpr int PACKED16_FLOATS = TAIL_FLOATS + (IMG16H_HALVES + IMG16L_HALVES) / 2;   // [tail fp32 | hi images | lo images]
+// ---- backward-chain images (decoder16.hip: decoder16_bwd_kernel), same element order [rt][t][lane][u]; hi set, then lo set
+//   S2T  dH3^T  = Ws2^T  dlogits^T      4 row tiles x 1 k-step  (k = class c: half 0, u = c < 5)
+//   B3   d[sdf_emb|grid]^T = Ws1^T dG3^T 3 x 8                  (k = hidden feature kfeat16)
+//   RGBT d rgb_emb^T = Wrgb[:, :64]^T drgb^T  2 x 1             (k = colour c: half 0, u = c < 3; rows = rgb_emb 32q + i)
+//   B2   dH1^T  = W2^T   dH2^T          4 x 8
+//   B1   d e^T  = W1^T   dG1^T          2 x 9   (k-steps 0..7: hidden features; k-step 8: the rgb head's share, k = c;
+//                                                output row i of tile rt lands in e-slot (16 rt + r', h') = row_owner(i))
+constexpr int T16_S2T = 1, T16_B3 = 8, T16_RGBT = 1, T16_B2 = 8, T16_B1 = 9;
+constexpr int RT16_S2T = 4, RT16_B3 = 3, RT16_RGBT = 2, RT16_B2 = 4, RT16_B1 = 2;
+constexpr int OFF16B_S2T = 0;
+constexpr int OFF16B_B3 = OFF16B_S2T + img16_halves(RT16_S2T, T16_S2T);
+constexpr int OFF16B_RGBT = OFF16B_B3 + img16_halves(RT16_B3, T16_B3);
+constexpr int OFF16B_B2 = OFF16B_RGBT + img16_halves(RT16_RGBT, T16_RGBT);
+constexpr int OFF16B_B1 = OFF16B_B2 + img16_halves(RT16_B2, T16_B2);
+constexpr int IMG16B_HALVES = OFF16B_B1 + img16_halves(RT16_B1, T16_B1);   // 40 960 halves = 80 KB per set
+MIPSF_HD float img16b_weight(const W& w, int idx) {
+    int base, T, kind;
+    if (idx < OFF16B_B3) { base = OFF16B_S2T; T = T16_S2T; kind = 0; }
+    else if (idx < OFF16B_RGBT) { base = OFF16B_B3; T = T16_B3; kind = 1; }
+    else if (idx < OFF16B_B2) { base = OFF16B_RGBT; T = T16_RGBT; kind = 2; }
+    else if (idx < OFF16B_B1) { base = OFF16B_B2; T = T16_B2; kind = 3; }
+    else { base = OFF16B_B1; T = T16_B1; kind = 4; }
+    const int rel = idx - base;
+    const int u = rel & 7, lane = (rel >> 3) & 63, g = rel >> 9;
+    const int rt = g / T, t = g - rt * T;
+    const int i = lane & 31, h = lane >> 5;
+    const int row = 32 * rt + i;
+    switch (kind) {
+        case 0: return (h == 0 && u < N_CLASS) ? w.w_sdf2[u * HID + row] : 0.f;
+        case 1: return w.w_sdf0[kfeat16(t, h, u) * N_SDF_IN + row];
+        case 2: return (h == 0 && u < 3) ? w.w_rgb0[u * N_RGB_IN + row] : 0.f;
+        case 3: return w.w_pts2[kfeat16(t, h, u) * HID + row];
+        default: {
+            int r2, h2;
+            row_owner(i, r2, h2);
+            const int e = eidx(16 * rt + r2, h2);
+            if (e < 0) return 0.f;
+            if (t == 8) return (h == 0 && u < 3) ? w.w_rgb0[u * N_RGB_IN + N_EMB + e] : 0.f;
+            return w.w_pts0[kfeat16(t, h, u) * N_E + e];
+        }
+    }
+}
+constexpr int OFF16_BWD_HALVES = IMG16H_HALVES + IMG16L_HALVES;            // where the backward sets start (in halves)
+// [tail fp32 | fwd hi | fwd lo | bwd hi | bwd lo]
+constexpr int PACKED16_FLOATS = TAIL_FLOATS + (IMG16H_HALVES + IMG16L_HALVES + 2 * IMG16B_HALVES) / 2;
 // the two halves a bias contributes: which = 0 -> rne16(b) as a float, 1 -> b - rne16(b)
 MIPSF_HD float bias16_part(float b, int which) {
     const float hi = (float)(_Float16)b;

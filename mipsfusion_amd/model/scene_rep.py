@@ -83,13 +83,17 @@ class _QueryFn(torch.autograd.Function):
         prec = owner.decoder_precision
         if prec == "f16" and need:
             raise RuntimeError('decoder_precision "f16" is forward-only (use "f16x3" or "f32" when gradients are needed)')
-        # the backward chain reads the fp32 operand images of `packed`; a forward-only f16 pass needs packed16 alone
-        packed = ops.decoder_pack(weights) if (need or prec == "f32") else None
-        packed16 = ops.decoder_pack16(weights) if prec != "f32" else None
+        # one operand-image buffer per arithmetic: `packed` (fp32 images) or `packed16` (f16 hi/lo images, forward and
+        # backward chain); it is saved for the backward under the same name
+        if prec == "f32":
+            packed, packed16 = ops.decoder_pack(weights), None
+        else:
+            packed, packed16 = None, ops.decoder_pack16(weights)
         out, saved = ops.decoder_fwd(packed, feat, FEAT_LEVEL_MAJOR, xn, None, M, save=need, precision=prec,
                                      packed16=packed16)
         if packed is None:
             packed = packed16
+        ctx.prec = prec
         ctx.owner, ctx.M, ctx.meta, ctx.has_jac = owner, M, meta, jac is not None
         ctx.save_for_backward(xn, feat, out, saved, packed, grid_params, *weights, *([jac] if jac is not None else []))
         return out
@@ -115,7 +119,7 @@ class _QueryFn(torch.autograd.Function):
                 else:
                     grads.append(torch.zeros_like(w))
         dfeat, dx, _ = ops.decoder_bwd(packed, feat, FEAT_LEVEL_MAJOR, xn, None, out, ops._f32c(dout), saved, grads,
-                                       ctx.M)
+                                       ctx.M, precision=ctx.prec, packed16=packed if ctx.prec != "f32" else None)
         dparams = None
         if need_g:
             if direct:

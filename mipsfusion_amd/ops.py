@@ -208,19 +208,29 @@ def decoder_fwd(packed, feat, layout, x, embed_pos, M, save: bool, precision: st
     return out, saved
 
 
-def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M):
+def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, precision: str = "f32", packed16=None):
     """grads: 10 tensors in DECODER_PARAM_ORDER, accumulated into, or None (frozen decoder: the weight-gradient
-    GEMMs are skipped).  -> (dfeat, dx, dembed_pos|None)"""
+    GEMMs are skipped).  -> (dfeat, dx, dembed_pos|None).  precision "f16x3": the activation-gradient chain runs on
+    the f16 matrix cores with hi/lo split operands (packed16, in-kernel positional encoding); it leaves the same `dact`
+    record, so the weight-gradient kernel is the same in both modes."""
     dev = x.device
     dfeat = torch.empty_like(feat)
     dx = torch.empty((M, 3), dtype=torch.float32, device=dev)
     dpe = torch.empty((M, 48), dtype=torch.float32, device=dev) if embed_pos is not None else None
     dact = torch.empty(lib().mipsf_decoder_dact_floats(M), dtype=torch.float32, device=dev)
     pe_mode = 0 if embed_pos is None else 1
-    with _timed("decoder_bwd_chain"):
-        check(lib().mipsf_decoder_bwd_chain(dptr(packed), layout, dptr(x), pe_mode, dptr(out), dptr(dout), dptr(saved),
-                                            dptr(dfeat), dptr(dx), dptr(dpe), dptr(dact), M, stream_ptr()),
-              "decoder_bwd_chain")
+    if precision == "f16x3":
+        if embed_pos is not None or packed16 is None:
+            raise RuntimeError("the f16x3 backward chain takes packed16 and computes the positional encoding in-kernel")
+        with _timed("decoder_bwd_chain"):
+            check(lib().mipsf_decoder_bwd_chain16(dptr(packed16), layout, dptr(x), dptr(out), dptr(dout), dptr(saved),
+                                                  dptr(dfeat), dptr(dx), dptr(dact), M, stream_ptr()),
+                  "decoder_bwd_chain16")
+    else:
+        with _timed("decoder_bwd_chain"):
+            check(lib().mipsf_decoder_bwd_chain(dptr(packed), layout, dptr(x), pe_mode, dptr(out), dptr(dout),
+                                                dptr(saved), dptr(dfeat), dptr(dx), dptr(dpe), dptr(dact), M,
+                                                stream_ptr()), "decoder_bwd_chain")
     if grads is not None:
         partial = torch.empty(lib().mipsf_decoder_wgrad_partial_floats(), dtype=torch.float32, device=dev)
         st = _decoder_struct(grads, _lib.DecoderGrads)

@@ -297,8 +297,9 @@ def test_scene_train_golden(dev, name, tag, emd, precision):
         if v.numel():
             if precision == "f32":
                 assert_close(v.grad, g[f"{tag}.g.{k}"], 5e-4, "grad " + k)
-            else:       # a flipped decision moves a handful of the entries that ray touches
-                assert_grad_close(v.grad, g[f"{tag}.g.{k}"], 5e-4, "grad " + k, outlier_frac=2e-3)
+            else:       # a flipped decision moves a handful of the entries that ray touches (one ReLU unit = one bias entry)
+                assert_grad_close(v.grad, g[f"{tag}.g.{k}"], 5e-4, "grad " + k,
+                                  outlier_frac=max(2e-3, 1.0 / v.numel()))
 
 
 def test_scene_module_api_and_queries(dev):
@@ -1157,3 +1158,32 @@ def test_decoder_f16x3_forward_matches_fp32_kernel_and_oracle(dev, M, layout):
     sdfp = ops.decoder_fwd_sdf(packed, feat, lay, x, None, M, precision="f16", packed16=packed16)
     assert_close(sdfp, ref[:, 3], 2e-3, "plain f16 SDF-only vs oracle")
     assert float((sdfp - p16[:, 3]).abs().max()) <= 1e-6, "SDF-only branch = column 3 of the full plain-f16 forward"
+
+
+@pytest.mark.parametrize("M", [1, 33, 1000, 70000])
+@pytest.mark.parametrize("layout", ["aos", "level_major"])
+def test_decoder_f16x3_backward_chain_matches_fp32_kernel(dev, M, layout):
+    """mipsf_decoder_bwd_chain16 (f16 matrix cores, hi/lo split) vs the fp32-MFMA chain on the same saved record:
+    d(features), d(x), the `dact` record (dG3, dH2, dG1 accumulator images + d logits / d rgb) and -- through the
+    unchanged weight-gradient kernel -- all ten parameter gradients."""
+    torch.manual_seed(100 + M)
+    dec = MLP_reg({}, input_ch=32, input_ch_pos=48).to(dev)
+    with torch.no_grad():
+        dec.sdf_linear[2].weight.mul_(4.0)
+    ws = dec.ordered_parameters()
+    packed, packed16 = ops.decoder_pack(ws), ops.decoder_pack16(ws)
+    x = torch.rand(M, 3, device=dev)
+    feat_aos = (torch.randn(M, 32, device=dev) * 0.3).contiguous()
+    lay = _lib.FEAT_AOS if layout == "aos" else _lib.FEAT_LEVEL_MAJOR
+    feat = feat_aos if layout == "aos" else feat_aos.view(M, 16, 2).permute(1, 0, 2).contiguous()
+    out, saved = ops.decoder_fwd(packed, feat, lay, x, None, M, save=True)
+    dout = torch.randn(M, 10, device=dev)
+    g32 = [torch.zeros_like(w) for w in ws]
+    g16 = [torch.zeros_like(w) for w in ws]
+    df32, dx32, _ = ops.decoder_bwd(packed, feat, lay, x, None, out, dout, saved, g32, M)
+    df16, dx16, _ = ops.decoder_bwd(None, feat, lay, x, None, out, dout, saved, g16, M, precision="f16x3",
+                                    packed16=packed16)
+    assert_close(df16, df32, 3e-6, "d grid features")
+    assert_close(dx16, dx32, 3e-6, "d x")
+    for k, a, b in zip(ops.DECODER_PARAM_ORDER, g16, g32):
+        assert_close(a, b, 3e-6, "grad " + k)
