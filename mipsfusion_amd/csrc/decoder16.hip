@@ -69,6 +69,9 @@ struct NoSide16 {
 // the real one; an inline-asm v_max reading an accumulator is invisible to hipcc's hazard padding: MFMA results must not
 // be read by asm without the 12 wait states of the 8-pass XDL, and the first version of this file read stale values.)
 __device__ __forceinline__ float relu1(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff()); }
+// 2^-W16_SHIFT: takes a completed accumulator back to its true magnitude (decoder_layout.h, RANGE)
+constexpr float ACC_UNSCALE = 1.0f / (float)(1 << W16_SHIFT);
+constexpr float GRID_UPSCALE = (float)(1 << G16_SHIFT);
 
 // acc[rt] (+)= A_image(rt, t) * B(t) over a layer's k-steps, software-pipelined and FENCED: the A operands of k-step
 // t+1 are requested and the B operand of k-step t+1 is converted while the MFMAs of k-step t run; the
@@ -181,7 +184,7 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) H1[rt][r] = relu1(H1[rt][r]);
+        for (int r = 0; r < 16; ++r) H1[rt][r] = relu1(H1[rt][r] * ACC_UNSCALE);
     uint32_t m1[2] = {0u, 0u};
     if (SAVE) relu_masks(H1, m1);
 
@@ -201,6 +204,11 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
                 store_act_piece(sv, lane16, 0, H1, 2 * t + 1);
             }
         });
+
+#pragma unroll
+    for (int rt = 0; rt < RT2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H2[rt][r] = H2[rt][r] * ACC_UNSCALE;
 
     // grid features of layer 3 (feature h of the 16 levels): requested before the rgb head, which covers the latency
     float gf[16];
@@ -253,7 +261,8 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
         [&](int t, h8& bh, h8& bl) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = t < 4 ? H2[(t >> 1) & 1][8 * (t & 1) + u] : gf[(8 * (t - 4) + u) & 15];
+            for (int u = 0; u < 8; ++u)
+                v[u] = t < 4 ? H2[(t >> 1) & 1][8 * (t & 1) + u] : gf[(8 * (t - 4) + u) & 15] * GRID_UPSCALE;
             split8<SPLIT>(v, bh, bl);
         },
         [&](int t) {                                   // the sdf_emb half of H2 (8 pieces) over the first 4 k-steps
@@ -267,7 +276,7 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) H3[rt][r] = relu1(H3[rt][r]);
+        for (int r = 0; r < 16; ++r) H3[rt][r] = relu1(H3[rt][r] * ACC_UNSCALE);
     if (SAVE) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) store_act_piece(sv, lane16, 2, H3, q);
@@ -492,7 +501,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_bwd_kernel(const float
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dG3[rt][r] = mask_apply(m3, rt, r, dG3[rt][r]);
+        for (int r = 0; r < 16; ++r) dG3[rt][r] = mask_apply(m3, rt, r, dG3[rt][r] * ACC_UNSCALE);
 
     // ---- d[sdf_emb | grid] = Ws1^T dG3   (row tiles 0,1 -> d sdf_emb, 2 -> d grid features); dG3 leaves for `dact`
     f32x16 dIn3[3];
@@ -507,6 +516,10 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_bwd_kernel(const float
             store_piece(2, dG3, 2 * t);
             store_piece(2, dG3, 2 * t + 1);
         });
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dIn3[rt][r] = dIn3[rt][r] * ACC_UNSCALE;
     if (live) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
@@ -526,7 +539,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_bwd_kernel(const float
         f32x16 dRgb[2];
         mfma16_layer<RT16_RGBT, T16_RGBT, SPLIT, INIT_ZERO>(bimg.at(OFF16B_RGBT, OFF16B_RGBT), lane, h, dRgb,
             [&](int, h8& b0, h8& b1) { b0 = rgh, b1 = rgl; });
-        dH2[2] = dRgb[0], dH2[3] = dRgb[1];
+        dH2[2] = dRgb[0] * ACC_UNSCALE, dH2[3] = dRgb[1] * ACC_UNSCALE;
     }
 
     // ---- dG1 = relu'(H1) * (W2^T dH2)
@@ -545,7 +558,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_bwd_kernel(const float
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dG1[rt][r] = mask_apply(m1, rt, r, dG1[rt][r]);
+        for (int r = 0; r < 16; ++r) dG1[rt][r] = mask_apply(m1, rt, r, dG1[rt][r] * ACC_UNSCALE);
 
     // ---- d e = W1^T dG1 + Wrgb[:, 64:]^T drgb; rows are arranged so that e-slot (t, h) lands in THIS lane
     f32x16 dE[2];
@@ -570,7 +583,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_bwd_kernel(const float
     const float x0 = x[3 * (size_t)s], x1 = x[3 * (size_t)s + 1], x2 = x[3 * (size_t)s + 2];
     float de[E_SLOTS];
 #pragma unroll
-    for (int t = 0; t < E_SLOTS; ++t) de[t] = dE[t >> 4][t & 15] * down;
+    for (int t = 0; t < E_SLOTS; ++t) de[t] = dE[t >> 4][t & 15] * (down * ACC_UNSCALE);
     float g3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int d = 0; d < 3; ++d) {

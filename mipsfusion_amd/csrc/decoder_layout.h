@@ -158,6 +158,14 @@ MIPSF_HD float packed_value(const W& w, int idx) {
 // TWO elements, b_hi = rne16(b) and b - b_hi, both against 1.0: exact to 22 bits with ONE MFMA (no lo products).
 // Layer 1 has padding to spare (elements u = 2, 3 of half 0 at k-step 3); layers 2 and 3 get a bias k-step of their
 // own in FRONT (t = 0: half 0, u = 0, 1) that exists in the hi image set only.
+// RANGE of the f16 halves.  A weight of 0.1 has lo = 0.1 * 2^-12 = 2e-5, below f16's smallest normal (6.1e-5): its lo
+// half would keep a handful of bits; a freshly initialised hash grid has FEATURES of 1e-4 (tcnn's U(-1e-4, 1e-4)) whose
+// lo half would vanish altogether (measured: the 51-iteration sequence drifted 100x further than with fp32 MFMA).  So
+// every operand image stores weight * 2^W16_SHIFT (exact; |w| < 2^(15 - W16_SHIFT) = 32 stays finite), every completed
+// accumulator is multiplied by 2^-W16_SHIFT (exact), and the grid features enter layer 3 as feature * 2^G16_SHIFT against
+// weight columns stored as weight * 2^(W16_SHIFT - G16_SHIFT).
+constexpr int W16_SHIFT = 10, G16_SHIFT = 12;
+MIPSF_HD float pow2f(int e) { float r = 1.0f; for (int i = 0; i < (e < 0 ? -e : e); ++i) r *= (e < 0 ? 0.5f : 2.0f); return r; }
 constexpr int T16_F1 = 4, T16_F2 = 8, T16_F3 = 6;          // data k-steps (x16 inputs): e (52 -> 64), H1 (128), [sdf_emb | grid] (96)
 constexpr int T16H_F1 = 4, T16H_F2 = 9, T16H_F3 = 7;       // k-steps of the hi images (bias k-step first for layers 2, 3)
 constexpr int BIAS16_T = 3, BIAS16_U = 2;                  // layer 1: where the two bias elements sit (half 0)
@@ -205,18 +213,19 @@ MIPSF_HD float img16b_weight(const W& w, int idx) {
     const int rt = g / T, t = g - rt * T;
     const int i = lane & 31, h = lane >> 5;
     const int row = 32 * rt + i;
+    const float sc = pow2f(W16_SHIFT);                 // every backward image is scaled alike (see RANGE above)
     switch (kind) {
-        case 0: return (h == 0 && u < N_CLASS) ? w.w_sdf2[u * HID + row] : 0.f;
-        case 1: return w.w_sdf0[kfeat16(t, h, u) * N_SDF_IN + row];
-        case 2: return (h == 0 && u < 3) ? w.w_rgb0[u * N_RGB_IN + row] : 0.f;
-        case 3: return w.w_pts2[kfeat16(t, h, u) * HID + row];
+        case 0: return (h == 0 && u < N_CLASS) ? w.w_sdf2[u * HID + row] * sc : 0.f;
+        case 1: return w.w_sdf0[kfeat16(t, h, u) * N_SDF_IN + row] * sc;
+        case 2: return (h == 0 && u < 3) ? w.w_rgb0[u * N_RGB_IN + row] * sc : 0.f;
+        case 3: return w.w_pts2[kfeat16(t, h, u) * HID + row] * sc;
         default: {
             int r2, h2;
             row_owner(i, r2, h2);
             const int e = eidx(16 * rt + r2, h2);
             if (e < 0) return 0.f;
-            if (t == 8) return (h == 0 && u < 3) ? w.w_rgb0[u * N_RGB_IN + N_EMB + e] : 0.f;
-            return w.w_pts0[kfeat16(t, h, u) * N_E + e];
+            if (t == 8) return (h == 0 && u < 3) ? w.w_rgb0[u * N_RGB_IN + N_EMB + e] * sc : 0.f;
+            return w.w_pts0[kfeat16(t, h, u) * N_E + e] * sc;
         }
     }
 }
@@ -240,17 +249,19 @@ MIPSF_HD float img16_weight(const W& w, int idx) {
     const int rt = g / T, t = g - rt * T;
     const int i = lane & 31, h = lane >> 5;
     const int row = 32 * rt + i;
+    const float sc = pow2f(W16_SHIFT);
     if (kind == 0) {
-        if (t == BIAS16_T && h == 0 && (u == BIAS16_U || u == BIAS16_U + 1)) return bias16_part(w.b_pts0[row], u - BIAS16_U);
+        if (t == BIAS16_T && h == 0 && (u == BIAS16_U || u == BIAS16_U + 1)) return bias16_part(w.b_pts0[row] * sc, u - BIAS16_U);
         const int e = e16(t, h, u);
-        return e < 0 ? 0.f : w.w_pts0[row * N_E + e];
+        return e < 0 ? 0.f : w.w_pts0[row * N_E + e] * sc;
     }
     if (t == 0) {                                                       // bias k-step
         const float* b = kind == 1 ? w.b_pts2 : w.b_sdf0;
-        return (h == 0 && u < 2) ? bias16_part(b[row], u) : 0.f;
+        return (h == 0 && u < 2) ? bias16_part(b[row] * sc, u) : 0.f;
     }
-    if (kind == 1) return w.w_pts2[row * HID + kfeat16(t - 1, h, u)];
-    return w.w_sdf0[row * N_SDF_IN + src16_f3(t - 1, h, u)];
+    if (kind == 1) return w.w_pts2[row * HID + kfeat16(t - 1, h, u)] * sc;
+    const int src = src16_f3(t - 1, h, u);
+    return w.w_sdf0[row * N_SDF_IN + src] * (src < N_EMB ? sc : pow2f(W16_SHIFT - G16_SHIFT));
 }
 // index in the LO image set of hi-image element idx, or -1 (bias k-steps have no lo part)
 MIPSF_HD int img16_lo_index(int idx) {

@@ -140,10 +140,13 @@ def test_config2_full_iteration_vs_oracle(dev):
     # ---- one dense Adam step on both sides (mipsfusion.py:580-584)
     FusedAdam(map_groups(m, cfg), betas=(0.9, 0.99)).step()
     torch.optim.Adam(map_groups(cpu, cfg), betas=(0.9, 0.99)).step()
-    # first Adam step = -lr * sign(g) wherever |g| >> eps: entries whose gradient is round-off around zero may flip
+    # first Adam step = -lr * sign(g) wherever |g| >> eps: entries whose gradient is round-off around zero may flip.
+    # "Solid" = above the rounding noise of BOTH sides: the oracle is fp32 itself and sits ~1e-5 of the maximum away from
+    # the fp64 truth (tools/dbg_bwd_accuracy.py; the f16x3 kernels are closer to the truth than the fp32-MFMA ones, but
+    # their error is independent of the oracle's instead of correlated with it)
     a, b = _np(m.embed_fn.params), _np(cpu.embed_fn.params)
     g = np.abs(_np(cpu.embed_fn.params.grad))
-    solid = g > 1e-6 * g.max()
+    solid = g > 1e-3 * g.max()
     print(f"  grid after Adam: {int(solid.sum())} entries with a solid gradient, max |diff| there "
           f"{np.abs(a - b)[solid].max():.2e}; untouched entries equal: {np.array_equal(a[g == 0], b[g == 0])}")
     assert np.abs(a - b)[solid].max() < 1e-4 * 0.01 + 1e-7, "grid entries after one Adam step"

@@ -1190,3 +1190,42 @@ def test_decoder_f16x3_backward_chain_matches_fp32_kernel(dev, M, layout):
     assert_close(dx16, dx32, 3e-6, "d x")
     for k, a, b in zip(ops.DECODER_PARAM_ORDER, g16, g32):
         assert_close(a, b, 3e-6, "grad " + k)
+
+
+def test_decoder_true_error_of_every_arithmetic_against_fp64(dev):
+    """What each decoder arithmetic is worth against the TRUTH (fp64 torch on the host, autograd for the backward) on
+    realistic magnitudes: weights as initialised / trained, hash-grid features from tcnn's initial 1e-4 up to 0.2,
+    loss gradients of 1e-7 .. 1e-3.  The split-precision f16 path ("f16x3", the default) must be fp32-class -- within
+    2x of the fp32-MFMA kernel's own error -- forward and backward; plain "f16" is held to its stated 2e-4."""
+    M = 20000
+    for feat_scale in (1e-4, 0.2):
+        torch.manual_seed(0)
+        dec = MLP_reg({}, input_ch=32, input_ch_pos=48).to(dev)
+        with torch.no_grad():
+            dec.sdf_linear[2].weight.mul_(3.0)
+        ws = dec.ordered_parameters()
+        packed, packed16 = ops.decoder_pack(ws), ops.decoder_pack16(ws)
+        x = torch.rand(M, 3, device=dev)
+        feat = ((torch.rand(M, 32, device=dev) * 2 - 1) * feat_scale).contiguous()
+        dout = torch.randn(M, 10, device=dev) * torch.exp(torch.empty(M, 1, device=dev).uniform_(-16.0, -6.0))
+        w64 = {k: v.detach().cpu().double().requires_grad_(True) for k, v in dec.state_dict().items()}
+        x64, f64 = x.cpu().double().requires_grad_(True), feat.cpu().double().requires_grad_(True)
+        ref = path_cpu.decoder_forward(w64, f64, tcnn_cpu.frequency_forward(x64, 8), x64)
+        ref.backward(dout.cpu().double())
+        err = {}
+        for prec in ("f32", "f16x3", "f16"):
+            kw = {} if prec == "f32" else dict(precision=prec, packed16=packed16)
+            out, saved = ops.decoder_fwd(packed, feat, _lib.FEAT_AOS, x, None, M, save=prec != "f16", **kw)
+            e = {"fwd": float((out.cpu().double() - ref.detach()).abs().max())}
+            if prec != "f16":
+                g = [torch.zeros_like(w) for w in ws]
+                dfeat, dx, _ = ops.decoder_bwd(packed, feat, _lib.FEAT_AOS, x, None, out, dout, saved, g, M, **kw)
+                rl2 = lambda a, b: float((a.cpu().double() - b).norm() / b.norm())   # noqa: E731
+                e.update(dfeat=rl2(dfeat, f64.grad), dx=rl2(dx, x64.grad), w_pts0=rl2(g[0], w64["pts_linear.0.weight"].grad),
+                         w_sdf0=rl2(g[6], w64["sdf_linear.0.weight"].grad))
+            err[prec] = e
+        print(f"features ~{feat_scale:g}: " + "; ".join(f"{p}: " + " ".join(f"{k} {v:.1e}" for k, v in e.items())
+                                                      for p, e in err.items()))
+        for k in err["f32"]:
+            assert err["f16x3"][k] <= 2.0 * err["f32"][k] + 1e-9, f"f16x3 {k}: {err['f16x3'][k]:.2e} vs fp32 {err['f32'][k]:.2e}"
+        assert err["f16"]["fwd"] < 2e-4
