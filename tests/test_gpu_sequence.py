@@ -94,9 +94,10 @@ def test_two_submap_sequence_matches_reference_run(fused_adam, in_place, precisi
     print(f"sequence: worst relative loss deviation {worst:.2e} over {lo.size} iterations "
           f"(first 10: {np.max(np.abs(lo[:10] - lr[:10]) / np.abs(lr[:10])):.2e})")
     # the loop is chaotic (51 Adam steps, best-of-iterations pose selection, a particle swarm's weighted mean): round-off
-    # differences grow.  fp32-MFMA arithmetic stays within 2e-3 of the reference's run; the f16x3 default (operands with
-    # 23 instead of 24 significant bits) drifts about twice as far and is held to 1e-2 on losses, 5 mm on poses.
-    tol_l, tol_p = (5e-3, 2e-3) if precision == "f32" else (1e-2, 5e-3)
+    # differences grow.  Measured: fp32-MFMA arithmetic ends <= 5e-5 m / 8e-4 in loss from the reference's run (its
+    # rounding errors are correlated with torch's fp32), the f16x3 default 3e-4 m / 3e-3 (equally accurate against fp64
+    # truth, tests/test_gpu_parity.py, but uncorrelated).  Both are held to 2 mm and 5e-3.
+    tol_l, tol_p = 5e-3, 2e-3
     np.testing.assert_allclose(lo[:12], lr[:12], rtol=5e-4)       # before chaotic growth: tight in both modes
     np.testing.assert_allclose(lo, lr, rtol=tol_l)
     # ---- poses: local pose of every frame (RandomOptimizer + pose Adam + BA + switch conversions)
