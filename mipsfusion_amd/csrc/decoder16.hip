@@ -399,26 +399,19 @@ __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_fwd_lds_kernel(con
 // like the forward: every gradient tile is an accumulator image whose registers are the next product's B operand after
 // a float -> (hi, lo) conversion; the two narrow products (Ws2^T dlogits, Wrgb^T drgb: K = 5 and 3) ride on the matrix
 // pipe as one k-step each instead of ~420 fmas and 160 table reads per tile.  Operand images come from L2.
-template <int LAYOUT>
-__global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_bwd_kernel(const float* __restrict__ packed16,
-                                                                     const float* __restrict__ x,
-                                                                     const float* __restrict__ out,
-                                                                     const float* __restrict__ dout,
-                                                                     const float* __restrict__ saved,
-                                                                     float* __restrict__ dfeat, float* __restrict__ dx,
-                                                                     float* __restrict__ dact, float* __restrict__ dsmall,
-                                                                     uint32_t M) {
+template <int LAYOUT, typename Img>
+__device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* __restrict__ x,
+                                                   const float* __restrict__ out, const float* __restrict__ dout,
+                                                   const float* __restrict__ saved, float* __restrict__ dfeat,
+                                                   float* __restrict__ dx, float* __restrict__ dact,
+                                                   float* __restrict__ dsmall, uint32_t M, int64_t tile, int lane) {
     constexpr bool SPLIT = true;
-    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (tile * 32 >= (int64_t)M) return;
+    const int j = lane & 31, h = lane >> 5;
     const uint32_t s_raw = (uint32_t)(tile * 32 + j);
     const bool live = s_raw < M;
     const uint32_t s = live ? s_raw : M - 1;
     const uint32_t lane16 = 16u * (uint32_t)lane;
     const srd_t da = make_srd(dact + (size_t)tile * ACT_TILE_FLOATS, ACT_TILE_FLOATS * 4);
-    const ImgBuf bimg{make_srd(reinterpret_cast<const _Float16*>(packed16 + TAIL_FLOATS) + OFF16_BWD_HALVES,
-                               IMG16B_HALVES * 4), 0u, (uint32_t)IMG16B_HALVES * 2u};
 
     float2 o2[5], g2[5];
     {
@@ -605,6 +598,57 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_bwd_kernel(const float
     }
 }
 
+// Small batches: four independent waves per workgroup, operand images from L2.
+template <int LAYOUT>
+__global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_bwd_kernel(const float* __restrict__ packed16,
+                                                                     const float* __restrict__ x,
+                                                                     const float* __restrict__ out,
+                                                                     const float* __restrict__ dout,
+                                                                     const float* __restrict__ saved,
+                                                                     float* __restrict__ dfeat, float* __restrict__ dx,
+                                                                     float* __restrict__ dact, float* __restrict__ dsmall,
+                                                                     uint32_t M) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (tile * 32 >= (int64_t)M) return;
+    const ImgBuf bimg{make_srd(reinterpret_cast<const _Float16*>(packed16 + TAIL_FLOATS) + OFF16_BWD_HALVES,
+                               IMG16B_HALVES * 4), 0u, (uint32_t)IMG16B_HALVES * 2u};
+    decoder16_bwd_tile<LAYOUT>(bimg, x, out, dout, saved, dfeat, dx, dact, dsmall, M, tile, lane);
+}
+
+// Large batches: persistent, one 8-wave workgroup per CU holding BOTH backward image sets in LDS: 2 x 80 KB = all 160 KB
+// of the CU (the backward needs no tables besides them).
+constexpr int B16_LDS_BYTES = IMG16B_HALVES * 4;
+static_assert(B16_LDS_BYTES <= 160 * 1024, "the backward image sets must fit the LDS of a CU");
+template <int LAYOUT>
+__global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_bwd_lds_kernel(const float* __restrict__ packed16,
+                                                                             const float* __restrict__ x,
+                                                                             const float* __restrict__ out,
+                                                                             const float* __restrict__ dout,
+                                                                             const float* __restrict__ saved,
+                                                                             float* __restrict__ dfeat,
+                                                                             float* __restrict__ dx,
+                                                                             float* __restrict__ dact,
+                                                                             float* __restrict__ dsmall, uint32_t M,
+                                                                             uint32_t n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float4 wbuf[];
+    {
+        const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const _Float16*>(packed16 + TAIL_FLOATS) +
+                                                            OFF16_BWD_HALVES);
+        for (int q = threadIdx.x; q < B16_LDS_BYTES / 16; q += F16_LDS_BLOCK) wbuf[q] = src[q];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (uint32_t tile = blockIdx.x * (F16_LDS_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+         tile < n_tiles; tile += gridDim.x * (F16_LDS_BLOCK / 64)) {
+        uint32_t z = 0;
+        asm volatile("" : "+v"(z));
+        const h8* imgp = reinterpret_cast<const h8*>(wbuf + z);
+        decoder16_bwd_tile<LAYOUT>(ImgLds{imgp, imgp + IMG16B_HALVES / 8}, x, out, dout, saved, dfeat, dx, dact, dsmall, M,
+                                   (int64_t)tile, lane);
+    }
+}
+
 __global__ __launch_bounds__(256) void decoder_pack16_kernel(W w, float* __restrict__ packed16) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < TAIL_FLOATS) packed16[idx] = packed_value(w, OFF_TRGB + idx);
@@ -711,12 +755,32 @@ int mipsf_decoder_bwd_chain16(const float* packed16, int feat_layout, const floa
     const uint32_t blocks = (uint32_t)((((uint64_t)M + 31) / 32 + 3) / 4);
     float* dsmall = dact + n_bt * 4 * ACT_TILE_FLOATS;
     hipStream_t s = (hipStream_t)stream;
-    if (feat_layout == MIPSF_FEAT_AOS)
-        hipLaunchKernelGGL((decoder16_bwd_kernel<MIPSF_FEAT_AOS>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed16, x, out,
-                           dout, saved, dfeat, dx, dact, dsmall, M);
-    else
-        hipLaunchKernelGGL((decoder16_bwd_kernel<MIPSF_FEAT_LEVEL_MAJOR>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed16, x,
-                           out, dout, saved, dfeat, dx, dact, dsmall, M);
+    const uint32_t n_tiles = (uint32_t)(((uint64_t)M + 31) / 32);
+    const int cus = device_cus();
+    if (cus <= 0) return 3;
+    const bool persistent = n_tiles >= (uint32_t)cus * 8u * 2u && !getenv("MIPSF_B16_NO_LDS");
+#define B16(LAY)                                                                                                   \
+    do {                                                                                                           \
+        if (persistent) {                                                                                          \
+            static bool attr_set_dev[MAX_DEVICES] = {false};                                                       \
+            bool& attr_set = attr_set_dev[device_slot()];                                                          \
+            if (!attr_set) {                                                                                       \
+                if (hipFuncSetAttribute((const void*)decoder16_bwd_lds_kernel<LAY>,                                \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, B16_LDS_BYTES) != hipSuccess) { \
+                    set_error("cannot raise dynamic LDS to %d bytes", B16_LDS_BYTES);                              \
+                    return 4;                                                                                      \
+                }                                                                                                  \
+                attr_set = true;                                                                                   \
+            }                                                                                                      \
+            hipLaunchKernelGGL((decoder16_bwd_lds_kernel<LAY>), dim3(cus), dim3(F16_LDS_BLOCK), B16_LDS_BYTES, s,   \
+                               packed16, x, out, dout, saved, dfeat, dx, dact, dsmall, M, n_tiles);                \
+        } else {                                                                                                   \
+            hipLaunchKernelGGL((decoder16_bwd_kernel<LAY>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed16, x, out,  \
+                               dout, saved, dfeat, dx, dact, dsmall, M);                                           \
+        }                                                                                                          \
+    } while (0)
+    if (feat_layout == MIPSF_FEAT_AOS) B16(MIPSF_FEAT_AOS); else B16(MIPSF_FEAT_LEVEL_MAJOR);
+#undef B16
     return check_launch("decoder_bwd_chain16");
 }
 
