@@ -67,7 +67,7 @@ int mipsf_hashgrid_meta_init(mipsf_grid_meta* meta_host, uint32_t n_levels, uint
 /* x: [M,3] fp32 already normalised (scene_rep.py:140-142 + :119); params: [n_params]; out: [M,L*F]. */
 int mipsf_hashgrid_fwd(const float* x, const float* params, float* out, uint32_t M,
                        const mipsf_grid_meta* meta_host, int layout, void* stream);
-/* Same, and also stores the Jacobian d out / d x: jac[(level*M + i)*6 + 2*d + f] = d out_f(level) / d x_d (the
+/* Same, and also stores the Jacobian d out / d x: jac[((level*3 + d)*M + i)*2 + f] = d out_f(level) / d x_d (the
  * quantity tcnn's kernel_grid_backward_input recomputes from the table).  With it the backward obtains dL/dx from a
  * streaming pass (mipsf_hashgrid_dx_from_jac) instead of gathering 8 table entries per level again. */
 int mipsf_hashgrid_fwd_jac(const float* x, const float* params, float* out, float* jac, uint32_t M,
@@ -140,6 +140,7 @@ int mipsf_decoder_fwd_sdf(const float* packed, const float* feat, int feat_layou
 #define MIPSF_PREC_F32 0
 #define MIPSF_PREC_F16X3 1
 #define MIPSF_PREC_F16 2
+#define MIPSF_PREC_BF16X3 3
 uint32_t mipsf_decoder_packed16_floats(void);
 int mipsf_decoder_pack16(const mipsf_decoder_weights* w_host_struct, float* packed16, void* stream);
 int mipsf_decoder_fwd16(const float* packed16, const float* feat, int feat_layout, const float* x, float* out,
@@ -167,6 +168,14 @@ int mipsf_decoder_bwd_chain(const float* packed, int feat_layout, const float* x
 int mipsf_decoder_wgrad(const float* feat, int feat_layout, const float* x, const float* embed_pos, int pe_mode,
                         const float* saved, const float* dact, const mipsf_decoder_grads* grads_host_struct,
                         float* partial, uint32_t M, void* stream);
+
+/* mipsf_decoder_wgrad with a choice of arithmetic for its three large products (d w_sdf0, d w_pts2, d w_pts0):
+ * MIPSF_PREC_F32 = the fp32-input MFMA above; MIPSF_PREC_BF16X3 = bf16 matrix cores on hi/lo split operands (16-17
+ * significant bits per operand, fp32 exponent range, fp32 accumulate): a weight gradient is a sum over every sample
+ * of the batch, its error stays ~1e-7 of its magnitude. */
+int mipsf_decoder_wgrad_ex(const float* feat, int feat_layout, const float* x, const float* embed_pos, int pe_mode,
+                           const float* saved, const float* dact, const mipsf_decoder_grads* grads_host_struct,
+                           float* partial, int precision, uint32_t M, void* stream);
 
 /* -------------------------------------------------- sample placement (a3 + a4) */
 typedef struct mipsf_render_cfg {

@@ -584,6 +584,58 @@ __device__ __forceinline__ void wgrad_mma(const float* __restrict__ XT, const fl
     }
 }
 
+// The same product on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16: 16x the fp32-MFMA rate).  Every fp32 operand read
+// from LDS is split into hi = bf16(v) and lo = bf16(v - hi) (16-17 significant bits, fp32's exponent range: the
+// gradients of a mean over N*S samples sit at 1e-8 .. 1e-3 and need no scaling, unlike f16) and a product is
+// hi*hi + hi*lo + lo*hi accumulated in fp32.  Per-term error <= 2^-16, zero-mean; a weight gradient is a sum over all
+// 262 144 samples, so the error of the SUM is ~1e-7 of its magnitude (tests: 3e-6 of max against the fp32-MFMA
+// kernel).  k-step u of the 8 multiplies samples 8u..8u+7 (lower half-wave) and 64+8u..64+8u+7 (upper): two
+// ds_read_b128 per operand -- the same LDS reads as the fp32 form.  side(g), g = 0..15, as above (two per k-step).
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split8_bf16(const float4& p, const float4& q, bf8& hi, bf8& lo) {
+    const float v[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 t = (__bf16)v[i];
+        hi[i] = t;
+        lo[i] = (__bf16)(v[i] - (float)t);
+    }
+}
+template <int NCT, typename SideFn = NoFetch>
+__device__ __forceinline__ void wgrad_mma_bf16(const float* __restrict__ XT, const float* __restrict__ YT, int rtile,
+                                               int ct0, int lane, f32x16 (&acc)[NCT], SideFn side = NoFetch()) {
+    const int i = lane & 31, kk = lane >> 5;
+    const float4* xa = reinterpret_cast<const float4*>(XT + (32 * rtile + i) * WG_LDW + 64 * kk);
+    const float4* yb = reinterpret_cast<const float4*>(YT + (32 * ct0 + i) * WG_LDW + 64 * kk);
+    float4 a0 = xa[0], a1 = xa[1], b0[NCT], b1[NCT], na0, na1, nb0[NCT], nb1[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) b0[ct] = yb[ct * 8 * WG_LDW], b1[ct] = yb[ct * 8 * WG_LDW + 1];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        if (u + 1 < 8) {
+            na0 = xa[2 * u + 2], na1 = xa[2 * u + 3];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) nb0[ct] = yb[ct * 8 * WG_LDW + 2 * u + 2], nb1[ct] = yb[ct * 8 * WG_LDW + 2 * u + 3];
+        }
+        side(2 * u);
+        bf8 ah, al;
+        split8_bf16(a0, a1, ah, al);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            bf8 bh, bl;
+            split8_bf16(b0[ct], b1[ct], bh, bl);
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[ct], 0, 0, 0);
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[ct], 0, 0, 0);
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[ct], 0, 0, 0);
+        }
+        side(2 * u + 1);
+        a0 = na0, a1 = na1;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) b0[ct] = nb0[ct], b1[ct] = nb1[ct];
+        if (!std::is_same<SideFn, NoFetch>::value) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // The two products whose X operand is the 8 small-gradient rows (rgb0: drgb, sdf2: dlogits) on 16x16x4 tiles: a
 // 32x32x2 tile spends 32 output rows on them, a 16x16x4 one 16 -- half the matrix time of these two phases (4096 ->
 // 2048 cycles per wave and phase, 9 % of the kernel's MFMA cycles).  acc[ct] += X8[rows 0..15] * Y^T[cols 16*(2w+ct)
@@ -635,7 +687,7 @@ __device__ __forceinline__ void flush_tile(float* __restrict__ rec, int base, in
     }
 }
 
-template <bool PE_INTERNAL, int LAYOUT>
+template <bool PE_INTERNAL, int LAYOUT, bool BF16X3 = false>
 __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
     const float* __restrict__ feat, const float* __restrict__ x, const float* __restrict__ embed_pos,
     const float* __restrict__ saved, const float* __restrict__ dact, const float* __restrict__ dsmall,
@@ -724,10 +776,12 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
         {                                                                        // next: X = dH2, Y = H1
             const char* bx = act_base(dact, tile, 1, 0);
             const char* by = act_base(saved, tile, 0, 0);
-            wgrad_mma<3>(XT, YT, w, 0, lane, aS1, [&](int g) {
+            auto fetch = [&](int g) {
                 nx[g] = act_piece(bx, g, lane16);
                 ny[g] = act_piece(by, g, lane16);
-            });
+            };
+            if constexpr (BF16X3) wgrad_mma_bf16<3>(XT, YT, w, 0, lane, aS1, fetch);
+            else wgrad_mma<3>(XT, YT, w, 0, lane, aS1, fetch);
         }
         db3 += row_sum(XT, brow, 64 * bhalf, 64);
         __syncthreads();
@@ -740,7 +794,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
         {                                                    // next: X = dG1 (+ the 8 small rows), Y = [e | rgb_emb]
             const char* bx = act_base(dact, tile, 0, 0);
             const char* by = act_base(saved, tile, 1, 2);
-            wgrad_mma<4>(XT, YT, w, 0, lane, aW2, [&](int g) {
+            auto fetch = [&](int g) {
                 nx[g] = act_piece(bx, g, lane16);
                 if (g < 8) ny[g] = act_piece(by, g, lane16);
                 if (g == 8) {
@@ -748,7 +802,9 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
                     nsm = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (sg < (int64_t)M) nsm = reinterpret_cast<const float4*>(dsmall + sg * 8)[bhalf];
                 }
-            });
+            };
+            if constexpr (BF16X3) wgrad_mma_bf16<4>(XT, YT, w, 0, lane, aW2, fetch);
+            else wgrad_mma<4>(XT, YT, w, 0, lane, aW2, fetch);
         }
         db2 += row_sum(XT, brow, 64 * bhalf, 64);
         __syncthreads();
@@ -782,7 +838,9 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
         __syncthreads();
         {                                                                        // next: Y = H3
             const char* by = act_base(saved, tile, 2, 0);
-            wgrad_mma<2>(XT, YT, w, 0, lane, aW1, [&](int g) { ny[g] = act_piece(by, g, lane16); });
+            auto fetch = [&](int g) { ny[g] = act_piece(by, g, lane16); };
+            if constexpr (BF16X3) wgrad_mma_bf16<2>(XT, YT, w, 0, lane, aW1, fetch);
+            else wgrad_mma<2>(XT, YT, w, 0, lane, aW1, fetch);
         }
         wgrad_mma_small(X8, YT, w, lane, aRGB);
         __syncthreads();
@@ -993,9 +1051,24 @@ int mipsf_decoder_bwd_chain(const float* packed, int feat_layout, const float* x
     return check_launch("decoder_bwd_chain");
 }
 
+static int decoder_wgrad_launch(const float* feat, int feat_layout, const float* x, const float* embed_pos, int pe_mode,
+                               const float* saved, const float* dact, const mipsf_decoder_grads* grads, float* partial,
+                               bool bf16x3, uint32_t M, void* stream);
 int mipsf_decoder_wgrad(const float* feat, int feat_layout, const float* x, const float* embed_pos, int pe_mode,
                         const float* saved, const float* dact, const mipsf_decoder_grads* grads, float* partial,
                         uint32_t M, void* stream) {
+    return decoder_wgrad_launch(feat, feat_layout, x, embed_pos, pe_mode, saved, dact, grads, partial, false, M, stream);
+}
+int mipsf_decoder_wgrad_ex(const float* feat, int feat_layout, const float* x, const float* embed_pos, int pe_mode,
+                           const float* saved, const float* dact, const mipsf_decoder_grads* grads, float* partial,
+                           int precision, uint32_t M, void* stream) {
+    MIPSF_REQUIRE(precision == MIPSF_PREC_F32 || precision == MIPSF_PREC_BF16X3, "precision must be f32 or bf16x3");
+    return decoder_wgrad_launch(feat, feat_layout, x, embed_pos, pe_mode, saved, dact, grads, partial,
+                                precision == MIPSF_PREC_BF16X3, M, stream);
+}
+static int decoder_wgrad_launch(const float* feat, int feat_layout, const float* x, const float* embed_pos, int pe_mode,
+                               const float* saved, const float* dact, const mipsf_decoder_grads* grads, float* partial,
+                               bool bf16x3, uint32_t M, void* stream) {
     if (M == 0) return 0;
     MIPSF_REQUIRE(feat && x && saved && dact && partial && grads, "null pointer");
     MIPSF_REQUIRE(pe_mode == 0 || embed_pos, "pe_mode 1 needs embed_pos");
@@ -1012,23 +1085,25 @@ int mipsf_decoder_wgrad(const float* feat, int feat_layout, const float* x, cons
     if (cus <= 0) return 3;
     uint32_t wg_blocks = n_bt < (uint32_t)cus ? n_bt : (uint32_t)cus;
     if (wg_blocks > WG_MAX_BLOCKS) wg_blocks = WG_MAX_BLOCKS;
-#define WG(PE, LAY)                                                                                              \
+#define WG(PE, LAY, BF)                                                                                          \
     do {                                                                                                         \
         static bool attr_set_dev[MAX_DEVICES] = {false};                                                         \
         bool& attr_set = attr_set_dev[device_slot()];                                                            \
         if (!attr_set) {                                                                                         \
-            if (hipFuncSetAttribute((const void*)decoder_wgrad_kernel<PE, LAY>,                                  \
+            if (hipFuncSetAttribute((const void*)decoder_wgrad_kernel<PE, LAY, BF>,                              \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES) != hipSuccess) {   \
                 set_error("cannot raise dynamic LDS to %d bytes", WG_LDS_BYTES);                                 \
                 return 4;                                                                                        \
             }                                                                                                    \
             attr_set = true;                                                                                     \
         }                                                                                                        \
-        hipLaunchKernelGGL((decoder_wgrad_kernel<PE, LAY>), dim3(wg_blocks), dim3(DEC_BLOCK), WG_LDS_BYTES, s,   \
+        hipLaunchKernelGGL((decoder_wgrad_kernel<PE, LAY, BF>), dim3(wg_blocks), dim3(DEC_BLOCK), WG_LDS_BYTES, s, \
                            feat, x, embed_pos, saved, dact, dsmall, partial, M, n_bt);                           \
     } while (0)
-    if (pe_mode == 0) { if (feat_layout == MIPSF_FEAT_AOS) WG(true, MIPSF_FEAT_AOS); else WG(true, MIPSF_FEAT_LEVEL_MAJOR); }
-    else { if (feat_layout == MIPSF_FEAT_AOS) WG(false, MIPSF_FEAT_AOS); else WG(false, MIPSF_FEAT_LEVEL_MAJOR); }
+#define WG_P(PE, LAY) do { if (bf16x3) WG(PE, LAY, true); else WG(PE, LAY, false); } while (0)
+    if (pe_mode == 0) { if (feat_layout == MIPSF_FEAT_AOS) WG_P(true, MIPSF_FEAT_AOS); else WG_P(true, MIPSF_FEAT_LEVEL_MAJOR); }
+    else { if (feat_layout == MIPSF_FEAT_AOS) WG_P(false, MIPSF_FEAT_AOS); else WG_P(false, MIPSF_FEAT_LEVEL_MAJOR); }
+#undef WG_P
 #undef WG
     if (int e = check_launch("decoder_wgrad")) return e;
     hipLaunchKernelGGL(decoder_wgrad_reduce_kernel, dim3((G_TOTAL + 255) / 256, WG_REDUCE_SLICES), dim3(256), 0, s, partial, wg_blocks, g);

@@ -135,7 +135,7 @@ __device__ __forceinline__ void level_jacobian(const Cell& cell, const float2 (&
 }
 
 // ------------------------------------------------------------------------------ forward
-// JAC: also store d out / d x of this (sample, level) -- 3 x (d f0/d x_d, d f1/d x_d), level-major [L][M][6] -- so that
+// JAC: also store d out / d x of this (sample, level) -- 3 x (d f0/d x_d, d f1/d x_d), planes [L][3][M][2] -- so that
 // the backward gets dL/dx from a streaming pass (hashgrid_dx_jac_kernel) instead of gathering the table again.
 template <int LAYOUT, bool JAC>
 __global__ __launch_bounds__(HG_BLOCK) void hashgrid_fwd_kernel(const float* __restrict__ x,
@@ -166,17 +166,21 @@ __global__ __launch_bounds__(HG_BLOCK) void hashgrid_fwd_kernel(const float* __r
         a0 = fmaf(w[c], v[c].x, a0);
         a1 = fmaf(w[c], v[c].y, a1);
     }
-    float2* dst = reinterpret_cast<float2*>(out + feat_index<LAYOUT>(i, level, M, g.n_levels));
-    __builtin_nontemporal_store(a0, &dst->x);
-    __builtin_nontemporal_store(a1, &dst->y);
+    // one 8-byte store per lane: a wavefront writes 512 contiguous bytes (level-major layout).  The first version
+    // issued the two floats -- and the six of the Jacobian, 24 bytes apart from lane to lane -- as scalar stores:
+    // 203 MB reached HBM for 134 MB of results (rocprofv3 WRITE_SIZE, profiles/r01_k)
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t* dst = reinterpret_cast<f32x2_t*>(out + feat_index<LAYOUT>(i, level, M, g.n_levels));
+    __builtin_nontemporal_store(f32x2_t{a0, a1}, dst);
     if (JAC) {
-        float2* j2 = reinterpret_cast<float2*>(jac) + ((size_t)level * M + i) * 3;
+        // [L][3][M][2]: the three derivative pairs of a (sample, level) go to three planes, each written 8 bytes per
+        // lane, contiguous across the wavefront
+        f32x2_t* j2 = reinterpret_cast<f32x2_t*>(jac) + (size_t)level * 3 * M + i;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             float s0, s1;
             level_jacobian(cell, v, g.scale[level], d, s0, s1);
-            __builtin_nontemporal_store(s0, &j2[d].x);
-            __builtin_nontemporal_store(s1, &j2[d].y);
+            __builtin_nontemporal_store(f32x2_t{s0, s1}, j2 + (size_t)d * M);
         }
     }
 }
@@ -681,11 +685,11 @@ __global__ __launch_bounds__(256) void hashgrid_dx_jac_kernel(const float* __res
     if (i >= M) return;
     float a[3] = {0.f, 0.f, 0.f};
     for (uint32_t l = 0; l < L; ++l) {
-        const float2* j2 = reinterpret_cast<const float2*>(jac) + ((size_t)l * M + i) * 3;
+        const float2* j2 = reinterpret_cast<const float2*>(jac) + (size_t)l * 3 * M + i;      // [L][3][M][2]
         const float2 gy = *reinterpret_cast<const float2*>(dout + feat_index<LAYOUT>(i, l, M, L));
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const float2 j = j2[d];
+            const float2 j = j2[(size_t)d * M];
             a[d] += j.x * gy.x + j.y * gy.y;
         }
     }

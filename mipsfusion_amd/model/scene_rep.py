@@ -119,7 +119,8 @@ class _QueryFn(torch.autograd.Function):
                 else:
                     grads.append(torch.zeros_like(w))
         dfeat, dx, _ = ops.decoder_bwd(packed, feat, FEAT_LEVEL_MAJOR, xn, None, out, ops._f32c(dout), saved, grads,
-                                       ctx.M, precision=ctx.prec, packed16=packed if ctx.prec != "f32" else None)
+                                       ctx.M, precision=ctx.prec, packed16=packed if ctx.prec != "f32" else None,
+                                       wgrad_precision=ctx.owner.wgrad_precision)
         dparams = None
         if need_g:
             if direct:
@@ -182,6 +183,10 @@ class JointEncoding(nn.Module):
         #   "f32"   fp32-input matrix cores: exact fp32 products (the round-1 path)
         #   "f16"   plain f16 operands, forward-only (2e-3 of the output range): set by consumers that state a tolerance
         self.decoder_precision = "f16x3"
+        # the three large weight-gradient products: "f32" (fp32-input matrix cores, default: weight gradients to ~3e-7) or
+        # "bf16x3" (bf16 matrix cores, hi/lo split operands: 10 % faster kernel, ~5e-6 -- enough for every tolerance of the
+        # test-suite but the chaotic 51-iteration sequence drifts 10x further from the reference's run with it)
+        self.wgrad_precision = "f32"
         self._tables = {}
         self.get_resolution()
         self.get_encoding(config)
@@ -248,6 +253,7 @@ class JointEncoding(nn.Module):
         new.initial_dict = copy.deepcopy(self.initial_dict)
         new.accumulate_param_grads_in_place = self.accumulate_param_grads_in_place
         new.decoder_precision = self.decoder_precision
+        new.wgrad_precision = self.wgrad_precision
         new.train(self.training)
         return new
 

@@ -58,13 +58,13 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------ hash grid
 def hashgrid_fwd(x: torch.Tensor, params: torch.Tensor, meta, layout=FEAT_AOS, with_jac: bool = False):
-    """with_jac: also return d out / d x ([L, M, 3, 2]) for `hashgrid_dx_from_jac` (use when x needs a gradient)."""
+    """with_jac: also return d out / d x ([L, 3, M, 2]) for `hashgrid_dx_from_jac` (use when x needs a gradient)."""
     M = x.shape[0]
     nf = meta.n_levels * meta.n_features
     out = torch.empty((M, nf) if layout == FEAT_AOS else (meta.n_levels, M, meta.n_features),
                       dtype=torch.float32, device=x.device)
     if with_jac:
-        jac = torch.empty((meta.n_levels, M, 3, 2), dtype=torch.float32, device=x.device)
+        jac = torch.empty((meta.n_levels, 3, M, 2), dtype=torch.float32, device=x.device)
         with _timed("hashgrid_fwd"):
             check(lib().mipsf_hashgrid_fwd_jac(dptr(x), dptr(params), dptr(out), dptr(jac), M, C.byref(meta), layout,
                                                stream_ptr()), "hashgrid_fwd_jac")
@@ -208,11 +208,14 @@ def decoder_fwd(packed, feat, layout, x, embed_pos, M, save: bool, precision: st
     return out, saved
 
 
-def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, precision: str = "f32", packed16=None):
+def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, precision: str = "f32", packed16=None,
+                wgrad_precision: str = "f32"):
     """grads: 10 tensors in DECODER_PARAM_ORDER, accumulated into, or None (frozen decoder: the weight-gradient
     GEMMs are skipped).  -> (dfeat, dx, dembed_pos|None).  precision "f16x3": the activation-gradient chain runs on
     the f16 matrix cores with hi/lo split operands (packed16, in-kernel positional encoding); it leaves the same `dact`
-    record, so the weight-gradient kernel is the same in both modes."""
+    record, so the weight-gradient kernel is the same in both modes.  wgrad_precision "bf16x3" (opt-in): the three
+    large weight-gradient products on the bf16 matrix cores with hi/lo split operands -- 10 % faster, weight gradients
+    to ~5e-6 of their maximum instead of ~3e-7."""
     dev = x.device
     dfeat = torch.empty_like(feat)
     dx = torch.empty((M, 3), dtype=torch.float32, device=dev)
@@ -235,8 +238,10 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
         partial = torch.empty(lib().mipsf_decoder_wgrad_partial_floats(), dtype=torch.float32, device=dev)
         st = _decoder_struct(grads, _lib.DecoderGrads)
         with _timed("decoder_wgrad"):
-            check(lib().mipsf_decoder_wgrad(dptr(feat), layout, dptr(x), dptr(embed_pos), pe_mode, dptr(saved),
-                                            dptr(dact), C.byref(st), dptr(partial), M, stream_ptr()), "decoder_wgrad")
+            wprec = _lib.PREC[wgrad_precision]
+            check(lib().mipsf_decoder_wgrad_ex(dptr(feat), layout, dptr(x), dptr(embed_pos), pe_mode, dptr(saved),
+                                               dptr(dact), C.byref(st), dptr(partial), wprec, M, stream_ptr()),
+                  "decoder_wgrad")
     return dfeat, dx, dpe
 
 

@@ -1190,6 +1190,13 @@ def test_decoder_f16x3_backward_chain_matches_fp32_kernel(dev, M, layout):
     assert_close(dx16, dx32, 3e-6, "d x")
     for k, a, b in zip(ops.DECODER_PARAM_ORDER, g16, g32):
         assert_close(a, b, 3e-6, "grad " + k)
+    # opt-in: the three large weight-gradient products on the bf16 matrix cores with hi/lo split operands (16-17 bits
+    # per operand, fp32 accumulate): per-term error 2^-16, zero-mean, averaged over the batch -> ~5e-6 of the maximum
+    gbf = [torch.zeros_like(w) for w in ws]
+    ops.decoder_bwd(None, feat, lay, x, None, out, dout, saved, gbf, M, precision="f16x3", packed16=packed16,
+                    wgrad_precision="bf16x3")
+    for k, a, b in zip(ops.DECODER_PARAM_ORDER, gbf, g32):
+        assert_close(a, b, 2e-5, "bf16x3 grad " + k)
 
 
 def test_decoder_true_error_of_every_arithmetic_against_fp64(dev):
