@@ -69,21 +69,28 @@ from mipsfusion_amd.optim import FusedAdam  # noqa: E402
 N_RAYS, N_SAMPLES = 4096, 64
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+MFMA_F16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: f16 / bf16 MFMA dense peak
 N_GRID_PARAMS, N_DEC_PARAMS = 9014144, 36577
 
-# algorithmic cost per unit (SURVEY.md 8d / BASELINE.md 3); unit = 1 ray*sample unless noted
+# algorithmic cost per unit (SURVEY.md 8d / BASELINE.md 3); unit = 1 ray*sample.
+# (bound, cost per unit, arithmetic type of the kernel, matrix-core products issued per algorithmic product or None)
+# The two f16x3 decoder kernels keep or leave the activation record of the backward pass: 1.7-1.8 KB of HBM traffic per
+# sample against 0.22 MFLOP at 2.5 PFLOP/s -- they are priced against the HBM roofline, their matrix-pipe utilisation is
+# reported next to it.
 KERNEL_COST = {
-    "hashgrid_fwd": ("hbm", 1164.0),
-    "hashgrid_bwd": ("hbm", 2188.0),          # scatter: x + dL/dy + read-modify-write of the touched entries
-    "hashgrid_dx": ("hbm", 536.0),            # saved Jacobian (384) + dL/dy (128) + dx read-modify-write (24)
-    "decoder_fwd": ("mfma", 72370.0),
-    "decoder_bwd_chain": ("mfma", 72370.0),
-    "decoder_wgrad": ("mfma", 72370.0),
-    "sample_rays": ("hbm", 20.0),
-    "render_fwd": ("hbm", 44.0),
-    "render_bwd": ("hbm", 84.0),
-    "rays_bwd": ("hbm", 16.0),
+    "hashgrid_fwd": ("hbm", 1164.0 + 384.0, "f32", None),   # 8 corners x 16 levels gathered + features out + Jacobian out
+    "hashgrid_bwd": ("hbm", 2188.0, "f32+f64 LDS", None),   # scatter: x + dL/dy + read-modify-write of the touched entries
+    "hashgrid_dx": ("hbm", 536.0, "f32", None),             # saved Jacobian (384) + dL/dy (128) + dx read-modify-write (24)
+    "decoder_fwd": ("hbm", 12.0 + 128.0 + 40.0 + 1536.0 + 32.0, "f16x3 (f16 MFMA on hi/lo split operands, fp32 accumulate)", 3),
+    "decoder_bwd_chain": ("hbm", 40.0 + 40.0 + 32.0 + 12.0 + 1536.0 + 32.0 + 128.0 + 12.0,
+                          "f16x3 (f16 MFMA on hi/lo split operands, fp32 accumulate)", 3),
+    "decoder_wgrad": ("mfma", 72370.0, "f32 (fp32-input MFMA)", 1),
+    "sample_rays": ("hbm", 20.0, "f32+f64", None),
+    "render_fwd": ("hbm", 44.0, "f32", None),
+    "render_bwd": ("hbm", 84.0, "f32", None),
+    "rays_bwd": ("hbm", 16.0, "f32+f64", None),
 }
+DECODER_FLOP_PER_SAMPLE = 72370.0
 
 
 _T0 = time.time()
@@ -551,15 +558,17 @@ def cpu_baseline(cfg, loop, n_rays, iters):
                       f"{n_rays} of the 4096 rays x 64 samples of the same batch, torch CPU threads = cores"}
 
 
-def pmc_traffic():
+def pmc_traffic(key="traffic_bytes_per_launch"):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_latest.json, written by
-    tools/pmc_to_json.py from `tools/pmc.sh`): FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE is NOT doubled here
-    because these kernels read 4-12 B per lane, not the 16 B/lane streams the x2 gfx950 correction was calibrated on."""
+    tools/pmc_to_json.py from `tools/pmc.sh`; FETCH_SIZE/WRITE_SIZE are in KiB).  `traffic` applies the guide's gfx950
+    correction -- FETCH_SIZE reports half the bytes of a 16-byte-per-lane streaming read -- to the kernels that read
+    that way (decoder kernels, Adam, hashgrid_dx; calibrated on adam_kernel: 72 MB reported for 144 MB read);
+    `traffic_uncorrected` is the plain FETCH_SIZE + WRITE_SIZE sum."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if not os.path.exists(path):
         return {}
     with open(path) as f:
-        return json.load(f).get("traffic_bytes_per_launch", {})
+        return json.load(f).get(key, {})
 
 
 def main():
@@ -681,12 +690,14 @@ def main():
 
     kernels = {}
     traffic = pmc_traffic()
+    traffic_raw = pmc_traffic("traffic_bytes_per_launch_uncorrected")
     for name, (n_launch, ms) in prof.items():
+        mult = None
         if name in KERNEL_COST:
-            bound, per_unit = KERNEL_COST[name]
+            bound, per_unit, dtype, mult = KERNEL_COST[name]
             work = per_unit * M
         elif name == "adam_step":
-            bound, work = "hbm", 28.0 * N_GRID_PARAMS
+            bound, work, dtype = "hbm", 28.0 * N_GRID_PARAMS, "f32"
         else:
             continue
         if bound == "hbm":
@@ -694,8 +705,16 @@ def main():
         else:
             achieved, peak, unit = work / (ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
         kernels[name] = {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
-                         "frac": round(achieved / peak, 4), "avg_ms": round(ms, 4),
-                         "launches": n_launch, "traffic": traffic.get(name)}
+                         "frac": round(achieved / peak, 4), "avg_ms": round(ms, 4), "dtype": dtype,
+                         "launches": n_launch, "traffic": traffic.get(name), "traffic_uncorrected": traffic_raw.get(name)}
+        if mult is not None:        # matrix-pipe view of the decoder kernels
+            issued = DECODER_FLOP_PER_SAMPLE * M * mult / (ms * 1e-3) / 1e12
+            mpeak = MFMA_F32_PEAK_TFLOPS if mult == 1 else MFMA_F16_PEAK_TFLOPS
+            kernels[name]["matrix_pipe"] = {"algorithmic_tflops": round(issued / mult, 2), "issued_tflops": round(issued, 2),
+                                            "peak_tflops": mpeak, "utilisation": round(issued / mpeak, 4)}
+        if name == "decoder_wgrad":  # co-limited: its HBM side
+            rd = (1536.0 + 1536.0 + 32.0 + 128.0 + 12.0) * M
+            kernels[name]["hbm_side"] = {"algorithmic_GBs": round(rd / (ms * 1e-3) / 1e9, 1), "frac_of_8TBs": round(rd / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"]) if kernels else None
     roofline = dict(kernels[dominant], kernel=dominant) if dominant else None
 
@@ -711,7 +730,10 @@ def main():
         "batches": "a fresh ray batch every step: rows gathered in-step from the HBM ray table (4 keyframes x 30 000 rays "
                    "+ current frame) by host-drawn index sets (reference samplers), indices and jitter resident in HBM",
         "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None,
+        "dtype": "f32 (parameters, activations, gradients, accumulators); the decoder's matrix products: f16 MFMA on "
+                 "hi/lo split operands = 22-bit operands (forward, activation-gradient chain), fp32-input MFMA (weight gradients)",
+        "data": "synthetic",
         "config": {"workload": "BASELINE config 2: FastCaMo-synth apartment_2 bound, 1 active submap per GPU, "
                                "4096 rays x 64 samples (43 uniform + 21 depth-guided), hash grid 2^19 x 16 levels x 2, "
                                "620x460 synthetic RGB-D (640x480 cropped by 10)",
