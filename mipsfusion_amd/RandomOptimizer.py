@@ -110,6 +110,58 @@ class RandomOptimizer:
         ops.ro_update(mean_masked, pst7, state, self.sdf_weight, self.scaling_coefficient2)
         return mean_masked
 
+    # ------------------------------------------------------------------------------ captured form of optimize()
+    @torch.no_grad()
+    def capture(self, model, n_iter, stream):
+        """Record the n_iter rounds of ``optimize`` once as a hipGraph (5 launches per round + the operand-image pack);
+        ``optimize_graphed`` then costs two small uploads, one replay and one 32-float read-back per frame instead of
+        ~30 eager launches with their Python between them.  The graph reads the model's parameter tensors in place, so
+        it stays valid while the map is optimised (not across ``load_state_dict`` into NEW tensors).  stream: the
+        non-default work stream (mipsfusion_amd.graph.work_stream)."""
+        dev = self.device
+        n = self.row_indices.shape[0]
+        self._g_state = torch.zeros(ops.RO_STATE_FLOATS, dtype=torch.float32, device=dev)
+        self._g_td5 = torch.zeros(5, n, dtype=torch.float32, device=dev)
+        self._g_state_host = torch.zeros(ops.RO_STATE_FLOATS, dtype=torch.float32).pin_memory()
+        self._g_td5_host = torch.zeros(5, n, dtype=torch.float32).pin_memory()
+        self._g_out_host = torch.zeros(ops.RO_STATE_FLOATS, dtype=torch.float32).pin_memory()
+        rc = model._rc(1, 0)
+
+        def rounds():
+            ws = model.decoder.ordered_parameters()
+            packed = ops.decoder_pack(ws) if self.decoder_precision == "f32" else ops.decoder_pack16(ws)
+            for i in range(n_iter):
+                o = i % 5
+                self._enqueue_round(model, self._g_state, self._g_td5[o], self._dirs[o], rc, packed)
+        with torch.cuda.stream(stream):
+            rounds()                                            # allocator warm-up on the capture stream
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph, stream=stream):
+                rounds()
+        self._g_n_iter, self._g_model = n_iter, model
+        self._lattice_flat = torch.stack([(self.row_indices + o) * self.dataset.W + (self.col_indices + o)
+                                          for o in range(5)]).to(dev)
+
+    @torch.no_grad()
+    def optimize_graphed(self, depth_flat_dev, initial_pose_cpu):
+        """depth_flat_dev: the frame's depth as a flat DEVICE tensor [H*W] (the lattice is gathered on the device);
+        initial_pose_cpu: [4,4] CPU tensor -> tracked pose [4,4] on the CPU.  Same arithmetic as ``optimize``."""
+        h = self._g_state_host
+        h.zero_()
+        h[0:9] = initial_pose_cpu[:3, :3].reshape(9)
+        h[9:12] = initial_pose_cpu[:3, 3]
+        h[12:18] = float(self.scaling_coefficient1)
+        self._g_state.copy_(h, non_blocking=True)
+        torch.index_select(depth_flat_dev, 0, self._lattice_flat.reshape(-1), out=self._g_td5.view(-1))
+        self._graph.replay()
+        self._g_out_host.copy_(self._g_state, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        pose = torch.eye(4, dtype=torch.float32)
+        pose[:3, :3] = self._g_out_host[0:9].view(3, 3)
+        pose[:3, 3] = self._g_out_host[9:12]
+        return pose
+
     @torch.no_grad()
     def optimize(self, model, depth_img, initial_pose, last_frame_pose, n_iter=10, return_state=False):
         if n_iter <= 0:

@@ -35,13 +35,17 @@ class FusedAdam(torch.optim.Optimizer):
         """Back to the state of a freshly constructed optimiser (moments and step counters zero), IN PLACE: the
         reference builds a new pose optimiser for every frame / BA round (mipsfusion.py:472-475, 300-303); a
         captured iteration keeps reading the same state tensors, so they are cleared instead of replaced."""
+        tensors = []
         for st in self.state.values():
             if st:
                 st["step"] = 0
-                st["exp_avg"].zero_()
-                st["exp_avg_sq"].zero_()
-        for step_dev, _ in self._dev.values():
-            step_dev.zero_()
+                tensors += [st["exp_avg"], st["exp_avg_sq"]]
+        tensors += [step_dev for step_dev, _ in self._dev.values()]
+        by_dtype = {}
+        for t in tensors:
+            by_dtype.setdefault((t.dtype, t.device), []).append(t)
+        for group in by_dtype.values():
+            torch._foreach_zero_(group)         # one launch per dtype instead of one per tensor
 
     # ---- checkpointing: with capturable=True the live step counters are the per-group device tensors (graph replays
     # advance them without the host seeing it), so they are read back / re-seeded around (load_)state_dict

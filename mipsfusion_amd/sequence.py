@@ -280,7 +280,7 @@ class GraphedSequence:
     iterations.  Rays are gathered inside the graphs from ONE device table [keyframe database | current frame]."""
 
     def __init__(self, cfg, dev, frames, kf_every=15, sampler="reference", first_iters=200, stream=None,
-                 lookahead=None):
+                 lookahead=None, graph_ro=True):
         """lookahead: how many frames the sample producer runs ahead of the GPU (default: ``map_every``, one whole
         mapping period -- a BA round needs ~40 ms of serial generator work, a frame without BA ~4 ms, so the work only
         evens out over a period; the reference's own DataLoader prefetches 8 frames, mipsfusion.py:672)."""
@@ -291,6 +291,7 @@ class GraphedSequence:
         from . import synth
         assert sampler in ("reference", "device")
         self.cfg, self.dev, self.frames, self.sampler, self.kf_every = cfg, dev, frames, sampler, kf_every
+        self.graph_ro = graph_ro and cfg["tracking"]["iter_RO"] > 0
         self.stream = stream if stream is not None else work_stream(dev)
         self._Graphed = GraphedSteps
         tr, mp, tk = cfg["training"], cfg["mapping"], cfg["tracking"]
@@ -429,14 +430,22 @@ class GraphedSequence:
 
     # ----------------------------------------------------------------------------------------------- bookkeeping
     def _set_pose(self, rot, trans, slot, pose):
+        """pose: CPU [4,4].  The 4x4 <-> (quaternion, translation) conversions of the loop run on the HOST (a dozen tiny
+        device launches each otherwise); two 16-byte uploads hand the result over."""
         with torch.no_grad():
-            rot[slot].copy_(matrix_to_quaternion(pose[None, :3, :3])[0])
-            trans[slot].copy_(pose[:3, 3])
+            pose = pose.detach().to("cpu", torch.float32)
+            rot[slot].copy_(matrix_to_quaternion(pose[None, :3, :3])[0], non_blocking=True)
+            trans[slot].copy_(pose[:3, 3], non_blocking=True)
+
+    def _get_pose(self, rot, trans, slot):
+        """-> CPU [4,4] of the optimised (quaternion, translation) in `slot` (one 28-byte read-back)."""
+        qt = torch.cat([rot.detach()[slot], trans.detach()[slot]]).cpu()
+        return qt_to_transform_matrix(qt[None, :4], qt[None, 4:])[0]
 
     def _add_keyframe(self, pose):
         self.db.store(self.n_kf, self.cur.view(self.H, self.W, 7)[self.kf_rows, self.kf_cols])
         if self.n_kf == 0:
-            self.fixed[0].copy_(pose)
+            self.fixed[0].copy_(pose.to(self.dev))
         else:
             self._set_pose(self.ba_rot, self.ba_trans, self.n_kf - 1, pose)
         self.n_kf += 1
@@ -461,7 +470,7 @@ class GraphedSequence:
         """mipsfusion.py:155-194: ground-truth pose, ``first_iters`` mapping iterations on frame 0's pixels."""
         dev = self.dev
         self.cur.copy_(self.host_rays[0], non_blocking=True)
-        pose0 = gt_pose.to(dev).float()
+        pose0 = gt_pose.float().cpu()
         self._add_keyframe(pose0)
         n = self._fill_ba_device(1, True)           # select_samples-style uniform pixels of frame 0 (device draws)
         g = self._ba_graph(n)
@@ -478,7 +487,11 @@ class GraphedSequence:
         self.capture_ms += (time.perf_counter() - t0) * 1e3
         for prm in self.model.parameters():
             prm.requires_grad_(True)
-        _ = pose0 @ torch.linalg.inv(pose0) @ pose0          # solver library start-up outside the loop
+        if self.graph_ro:
+            t0 = time.perf_counter()
+            self.ro.capture(self.model, self.cfg["tracking"]["iter_RO"], self.stream)
+            torch.cuda.synchronize()
+            self.capture_ms += (time.perf_counter() - t0) * 1e3
         torch.cuda.synchronize()
         return pose0
 
@@ -502,12 +515,16 @@ class GraphedSequence:
             if self.producer is not None:
                 if k + self.lookahead < n_frames:
                     self.producer.submit(self._plan(k + self.lookahead))     # `lookahead` frames ahead of the GPU
-            prev = est[-1]
+            prev = est[-1]                                                   # poses live on the host (4x4 algebra there)
             init = prev if len(est) < 2 else prev @ torch.linalg.inv(est[-2]) @ prev   # constant velocity
-            self.model.eval()
-            pose = self.ro.optimize(self.model, self.cur.view(self.H, self.W, 7)[..., 6], init, None, n_iter=tk["iter_RO"])
-            self.model.train()
-            torch.cuda.synchronize()
+            if self.graph_ro:
+                pose = self.ro.optimize_graphed(self.cur[:, 6], init)
+            else:
+                self.model.eval()
+                pose = self.ro.optimize(self.model, self.cur.view(self.H, self.W, 7)[..., 6], init.to(dev), None,
+                                        n_iter=tk["iter_RO"]).cpu()
+                self.model.train()
+                torch.cuda.synchronize()
             t1 = time.perf_counter()
             self._set_pose(self.go_rot, self.go_trans, 0, pose)
             self.go_popt.reset()
@@ -521,8 +538,7 @@ class GraphedSequence:
             else:
                 self._fill_go_device()
             self.go_graph.replay()
-            pose = qt_to_transform_matrix(self.go_rot.detach(), self.go_trans.detach())[0]
-            torch.cuda.synchronize()
+            pose = self._get_pose(self.go_rot, self.go_trans, 0)             # the read-back synchronises
             t2 = time.perf_counter()
             ba_ms = 0.0
             if k % mp["map_every"] == 0:
@@ -531,8 +547,7 @@ class GraphedSequence:
                 self.ba_popt.reset()
                 n = self._load_ba(samples) if samples is not None else self._fill_ba_device(self.n_kf, False)
                 self._ba_graph(n).replay()
-                pose = qt_to_transform_matrix(self.ba_rot[-1:].detach(), self.ba_trans[-1:].detach())[0]
-                torch.cuda.synchronize()
+                pose = self._get_pose(self.ba_rot, self.ba_trans, -1)
                 ba_ms = (time.perf_counter() - t2) * 1e3
             if k % self.kf_every == 0:                                       # mipsfusion.py:686-688, after the BA
                 self._add_keyframe(pose)
@@ -551,7 +566,7 @@ class GraphedSequence:
 
 def summarise(res, gt_poses, cfg, launch):
     fm = np.array(res["frame_ms"])
-    err = [float((res["est"][k][:3, 3].cpu() - gt_poses[k][:3, 3].float()).norm()) for k in range(len(res["est"]))]
+    err = [float((res["est"][k][:3, 3].cpu().float() - gt_poses[k][:3, 3].float()).norm()) for k in range(len(res["est"]))]
     ba = [t for t in res["ba_ms"] if t > 0]
     out = {"frames": len(res["est"]), "ms_per_frame_mean": round(float(fm.mean()), 3),
            "ms_per_frame_median": round(float(np.median(fm)), 3), "ms_per_frame_p95": round(float(np.percentile(fm, 95)), 3),

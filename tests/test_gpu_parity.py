@@ -1237,3 +1237,30 @@ def test_decoder_true_error_of_every_arithmetic_against_fp64(dev):
         for k in err["f32"]:
             assert err["f16x3"][k] <= 4.0 * err["f32"][k] + 1e-9, f"f16x3 {k}: {err['f16x3'][k]:.2e} vs fp32 {err['f32'][k]:.2e}"
         assert err["f16"]["fwd"] < 2e-4
+
+
+@pytest.mark.gpu
+def test_random_optimizer_graph_capture_equals_eager_rounds(dev):
+    """RandomOptimizer.capture / optimize_graphed (all rounds of a frame as ONE hipGraph replay, inputs through two
+    small uploads) must track exactly the pose the eager `optimize` tracks, frame after frame, while the map's
+    parameters change in place underneath the recorded graph."""
+    from mipsfusion_amd.graph import work_stream
+    g = load_golden("ro.npz")
+    cfg, ro = _ro_setup(g, dev)
+    ro.pre_sampled_particle = T(g["pst"]).to(dev).contiguous()
+    m = make_scene(g, cfg, dev).eval()
+    stream = torch.cuda.Stream()
+    depth, init = T(g["depth"]), T(g["init_pose"])
+    with torch.cuda.stream(stream):
+        ro.capture(m, 5, stream)
+        for trial in range(3):
+            if trial:       # the optimiser moves the map in place between frames
+                with torch.no_grad():
+                    m.embed_fn.params.mul_(1.01)
+                    m.decoder.sdf_linear[2].weight.mul_(0.99)
+            start = init.clone()
+            start[:3, 3] += 0.004 * trial
+            eager = ro.optimize(m, depth, start.clone(), None, n_iter=5).cpu()
+            graphed = ro.optimize_graphed(depth.to(dev).reshape(-1), start.clone())
+            assert torch.equal(eager, graphed), f"frame {trial}: captured rounds differ from eager rounds"
+    torch.cuda.synchronize()
