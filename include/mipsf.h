@@ -141,6 +141,7 @@ int mipsf_decoder_fwd_sdf(const float* packed, const float* feat, int feat_layou
 #define MIPSF_PREC_F16X3 1
 #define MIPSF_PREC_F16 2
 #define MIPSF_PREC_BF16X3 3
+#define MIPSF_PREC_BF16X6 4
 uint32_t mipsf_decoder_packed16_floats(void);
 int mipsf_decoder_pack16(const mipsf_decoder_weights* w_host_struct, float* packed16, void* stream);
 int mipsf_decoder_fwd16(const float* packed16, const float* feat, int feat_layout, const float* x, float* out,
@@ -176,6 +177,15 @@ int mipsf_decoder_wgrad(const float* feat, int feat_layout, const float* x, cons
 int mipsf_decoder_wgrad_ex(const float* feat, int feat_layout, const float* x, const float* embed_pos, int pe_mode,
                            const float* saved, const float* dact, const mipsf_decoder_grads* grads_host_struct,
                            float* partial, int precision, uint32_t M, void* stream);
+
+/* The same weight gradients from the same records by the STREAMING kernel of csrc/wgrad16.hip: no LDS, the 16-bit matrix
+ * cores transpose the records (an exact 0/1-matrix product per 16-bit plane) and multiply them.  arithmetic:
+ * MIPSF_PREC_F16X3 (hi + lo f16 planes, every 32 x 32 gradient block under its own power-of-two scale: fp32-class),
+ * MIPSF_PREC_BF16X6 (three bf16 planes, six products, no scale: fp32-class, slower), MIPSF_PREC_BF16X3 (two planes,
+ * 2^-16).  pe_mode 0 only (the positional encoding is recomputed in-kernel). */
+int mipsf_decoder_wgrad16(const float* feat, int feat_layout, const float* x, const float* saved, const float* dact,
+                          const mipsf_decoder_grads* grads_host_struct, float* partial, int arithmetic, uint32_t M,
+                          void* stream);
 
 /* -------------------------------------------------- sample placement (a3 + a4) */
 typedef struct mipsf_render_cfg {

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmipsf_hip.so")
 MAX_LEVELS = 32
 FEAT_AOS, FEAT_LEVEL_MAJOR = 0, 1
-PREC = {"f32": 0, "f16x3": 1, "f16": 2, "bf16x3": 3}      # MIPSF_PREC_* of include/mipsf.h
+PREC = {"f32": 0, "f16x3": 1, "f16": 2, "bf16x3": 3, "bf16x6": 4}      # MIPSF_PREC_* of include/mipsf.h
 
 
 class GridMeta(C.Structure):
@@ -99,6 +99,7 @@ SIGNATURES = {
     "mipsf_decoder_bwd_chain": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _U32, _P]),
     "mipsf_decoder_wgrad": (_I, [_P, _I, _P, _P, _I, _P, _P, C.POINTER(DecoderGrads), _P, _U32, _P]),
     "mipsf_decoder_wgrad_ex": (_I, [_P, _I, _P, _P, _I, _P, _P, C.POINTER(DecoderGrads), _P, _I, _U32, _P]),
+    "mipsf_decoder_wgrad16": (_I, [_P, _I, _P, _P, _P, C.POINTER(DecoderGrads), _P, _I, _U32, _P]),
     "mipsf_sample_rays": (_I, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _U32, _P]),
     "mipsf_normalise_points": (_I, [_P, C.POINTER(RenderCfg), _P, _U32, _P]),
     "mipsf_render_fwd": (_I, [_P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _U32, _U32,

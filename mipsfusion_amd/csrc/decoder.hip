@@ -944,6 +944,18 @@ static W to_w(const mipsf_decoder_weights& s) {
 
 constexpr uint32_t WG_MAX_BLOCKS = 256;
 
+// sum of `nrec` per-block partial records (G_* layout) into the ten gradient tensors; shared with wgrad16.hip
+int wgrad_reduce_launch(const float* partial, uint32_t nrec, const mipsf_decoder_grads* grads, hipStream_t s) {
+    GradPtrs g;
+    g.p[0] = grads->w_pts0, g.p[1] = grads->b_pts0, g.p[2] = grads->w_pts2, g.p[3] = grads->b_pts2;
+    g.p[4] = grads->w_rgb0, g.p[5] = grads->b_rgb0, g.p[6] = grads->w_sdf0, g.p[7] = grads->b_sdf0;
+    g.p[8] = grads->w_sdf2, g.p[9] = grads->b_sdf2;
+    for (int k = 0; k < 10; ++k) MIPSF_REQUIRE(g.p[k] != nullptr, "null gradient pointer %d", k);
+    hipLaunchKernelGGL(decoder_wgrad_reduce_kernel, dim3((G_TOTAL + 255) / 256, WG_REDUCE_SLICES), dim3(256), 0, s, partial,
+                       nrec, g);
+    return check_launch("decoder_wgrad_reduce");
+}
+
 static inline uint64_t n_wave_tiles(uint32_t M) { return ((uint64_t)M + 31) / 32; }
 static inline uint64_t n_block_tiles(uint32_t M) { return ((uint64_t)M + 127) / 128; }
 

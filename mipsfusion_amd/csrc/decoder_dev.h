@@ -181,4 +181,6 @@ __device__ __forceinline__ float load_feat(const float* __restrict__ feat, uint3
     return LAYOUT == MIPSF_FEAT_AOS ? feat[(size_t)s * N_GRID + 2 * level + f] : feat[((size_t)level * M + s) * 2 + f];
 }
 
+int wgrad_reduce_launch(const float* partial, uint32_t nrec, const mipsf_decoder_grads* grads, hipStream_t s);
+
 }  // namespace mipsf

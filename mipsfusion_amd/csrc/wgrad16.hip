@@ -1,0 +1,583 @@
+// Decoder weight gradients as a STREAMING kernel: no LDS, no barriers, the matrix cores do the transposes.
+//
+//   dW[out][in] = sum over samples s of dOut[s][out] * In[s][in]
+// has the SAMPLE as reduction index, while every activation / gradient record of the decoder (`saved`, `dact`:
+// accumulator images of the transposed evaluation, decoder_layout.h) has the sample in the LANE and the feature in the
+// register -- the wrong way round for an MFMA operand, whose reduction index must sit inside a lane.  decoder.hip
+// transposes through LDS (4 phases x 2 barriers per 128 samples, one wave per SIMD, 0.46 of its fp32-MFMA peak and
+// 3.4 TB/s).  Here the matrix core transposes:
+//
+//     T[sample][c] = sum_k X[sample][feature k] * I[k][c]          (I = 0/1 selection matrix)
+//
+// is an ordinary 16-bit v_mfma_f32_32x32x16 whose A operand is the record AS LOADED (lane = sample, 8 features per
+// k-step) and whose result -- lane = feature c, registers = 16 samples -- is exactly the operand layout the
+// weight-gradient product wants.  It is EXACT: every product is a 16-bit value times 1.0, every sum adds zeros.  An
+// fp32 record is cut into P planes first, each plane is transposed on its own (2 MFMAs per 32 x 32 block and plane), and
+// the weight-gradient product keeps the plane pairs with pa + pb <= P - 1.  Three arithmetics:
+//   f16, P = 2   v = hi + lo, 22 bits: 3 products per k-step, dropped remainder 2^-22 (fp32 class) -- the default.  f16
+//                has no exponent range to spare (loss gradients are 1e-3 .. 1e-9), and a per-sample scale does not
+//                factor out of a sum over samples.  So every GRADIENT block (32 samples x 32 features) is multiplied by
+//                a power of two 2^k that brings its largest entry below 2^15, and the accumulators fed by that block
+//                are kept in the same scaled domain: when a tile needs another k they are multiplied by 2^(k' - k)
+//                first -- exact -- which, with a hysteresis of 2^7, happens rarely; the flush multiplies by 2^-k.  A
+//                block's entries 2^10 below its maximum still carry all 22 bits (f16's subnormal floor, 2^-25 absolute,
+//                sits 2^40 below the maximum).  A single launch-wide scale is not enough: free-space samples with
+//                gradients 2^-17 below the batch maximum are the bulk of a sum and lose the lo plane (measured: 3e-5
+//                in the sequence test).  Grid features ride at 2^12 like in the forward.
+//   bf16, P = 3  v = hi + mid + lo, 24 bits with fp32's exponent range, no scale: 6 products per k-step, 2^-24.
+//   bf16, P = 2  3 products, 2^-16 (for comparison).
+//
+// A workgroup of 8 waves walks the 32-sample tiles of its share of the batch; every wave owns a few 32 x 32 output
+// tiles for the whole launch (<= 6 accumulator tiles = 96 registers -> two waves per SIMD) and loads, cuts and
+// transposes only the feature rows and columns those tiles need:
+//     waves 0..3 (rt = w):      d w_pts2[rt][0..3] = dH2[rt]^T H1            + (small rows)^T H3[col tile w]
+//     waves 4..7 (rt = w - 4):  d w_sdf0[rt][0..2] = dG3[rt]^T [sdf_emb | grid],  d w_pts0[rt][0..1] = dG1[rt]^T e,
+//                               (small rows)^T {rgb_emb col tile 0 | 1 | e col tile 0 | 1}[w - 4]
+// (small rows = d logits (5) and d rgb (3) of `dsmall`: d w_sdf2, d w_rgb0).  Bias gradients are register sums of the
+// transposed tiles.  Per-block partial records + the reduce kernel of decoder.hip (no atomics on weights).
+#include "decoder_dev.h"
+
+namespace mipsf {
+using namespace dl;
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+struct ArF16 { typedef h8 v8; typedef _Float16 elt; static constexpr int P = 2; static constexpr bool SCALED = true; };
+struct ArBF3 { typedef bf8 v8; typedef __bf16 elt; static constexpr int P = 3; static constexpr bool SCALED = false; };
+struct ArBF2 { typedef bf8 v8; typedef __bf16 elt; static constexpr int P = 2; static constexpr bool SCALED = false; };
+constexpr float W16_GRID_SHIFT = 4096.0f;      // 2^G16_SHIFT
+
+__device__ __forceinline__ f32x16 mfma16(bf8 a, bf8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+// next 16-bit plane of 8 fp32 residuals: pl = narrow(r), r -= pl (exact) unless it is the last plane
+template <typename A, bool LAST>
+__device__ __forceinline__ typename A::v8 next_plane(f32x8& r) {
+    typename A::v8 pl;
+    if constexpr (A::SCALED && !LAST) {
+        // f16: r - (float)half in ONE instruction per value -- v_fma_mix_f32 widens the selected half of the packed pair
+        // itself (hipcc emits cvt_f32_f16 + cvt_f32_f16_sdwa + pk_add: 4 instead of 3 instructions per pair)
+        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            h2_t t;
+            t[0] = (_Float16)r[i], t[1] = (_Float16)r[i + 1];
+            pl[i] = t[0], pl[i + 1] = t[1];
+            float lo, hi;
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(t), "v"(r[i]));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(hi) : "v"(t), "v"(r[i + 1]));
+            r[i] = lo, r[i + 1] = hi;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const typename A::elt t = (typename A::elt)r[i];
+            pl[i] = t;
+            if (!LAST) r[i] = r[i] - (float)t;
+        }
+    }
+    return pl;
+}
+
+// 16 fp32 accumulator registers holding 16-bit values -> the two k-step operands (samples 8m..8m+7 of this half); exact
+template <typename A>
+__device__ __forceinline__ void pack_T(const f32x16& T, typename A::v8 (&op)[2]) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) op[m][u] = (typename A::elt)T[8 * m + u];
+}
+
+// Ordering pins.  The matrix instructions and conversions are pure values to the compiler, which is free to compute all
+// planes' cuts first and to sink every transposing MFMA down to its use -- three planes of 16-register transposes alive
+// at once, and the kernel spills (a sched_barrier only binds the machine scheduler, not the IR passes before it).  An
+// empty asm that "rewrites" the residuals and the finished operands makes plane p + 1 depend on plane p being packed.
+#define W16_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#define W16_PIN5(a, b, c, d, e) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e))
+
+// One 32-feature block: A operands vals[q][0..7] (q = 0, 1: the 8 values this lane contributes to MFMA q) ->
+// transposed operands ops[p][m] (plane p, k-step m = samples 8m..8m+7 of this half) of lane = column c, where the value
+// of element u of MFMA q, contributed by half h, lands in column c = 16 q + 8 (u >> 2) + 4 h + (u & 3).
+// For the accumulator images (pieces g = 2q + (u >> 2), element u & 3) that is column = feature - 32 * row tile.
+// NQ = 1: only vals[0] is non-zero (the small rows), placed at columns 16 q0 + ...   SUM: rowsum += this lane's 16
+// samples of the block (bias gradients; plane by plane, each plane's sum is exact to fp32 rounding).  vals is consumed.
+template <typename A, bool SUM, int NQ = 2>
+__device__ __forceinline__ void transpose_block(f32x8 (&vals)[2], const typename A::v8 (&I)[2],
+                                                typename A::v8 (&ops)[A::P][2], float& rowsum, int q0 = 0) {
+    constexpr int P = A::P;
+#ifdef W16_DBG_NO_COMPUTE       // diagnosis builds (tools/micro): loads only
+    asm volatile("" ::"v"(vals[0]), "v"(vals[1]));
+    return;
+#endif
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float s = 0.f;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        f32x16 T = mfma16(p == P - 1 ? next_plane<A, true>(vals[0]) : next_plane<A, false>(vals[0]), I[q0], zero);
+        if (NQ == 2) T = mfma16(p == P - 1 ? next_plane<A, true>(vals[1]) : next_plane<A, false>(vals[1]), I[1], T);
+        pack_T<A>(T, ops[p]);
+        if (SUM) {
+            float sp = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sp = sp + T[r];
+            s = s + sp;
+        }
+        if (p + 1 < P) W16_PIN5(vals[0], vals[1], ops[p][0], ops[p][1], s);
+    }
+    if (SUM) rowsum = rowsum + s;
+}
+
+// The right-hand side of a product, plane by plane: plane pb of the block is transposed (2 MFMAs) and multiplied at
+// once with the planes pa <= P - 1 - pb of X (the dropped pairs are below 2^-(plane bits x P) of the product); only ONE
+// transposed plane is alive at a time.  vals is consumed.
+template <typename A>
+__device__ __forceinline__ void transpose_mac(f32x8 (&vals)[2], const typename A::v8 (&I)[2],
+                                              const typename A::v8 (&X)[A::P][2], f32x16& acc) {
+    constexpr int P = A::P;
+#ifdef W16_DBG_NO_COMPUTE
+    asm volatile("" ::"v"(vals[0]), "v"(vals[1]));
+    return;
+#endif
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pb = 0; pb < P; ++pb) {
+        f32x16 T = mfma16(pb == P - 1 ? next_plane<A, true>(vals[0]) : next_plane<A, false>(vals[0]), I[0], zero);
+        T = mfma16(pb == P - 1 ? next_plane<A, true>(vals[1]) : next_plane<A, false>(vals[1]), I[1], T);
+        typename A::v8 Y[2];
+        pack_T<A>(T, Y);
+        if (pb + 1 < P) W16_PIN4(vals[0], vals[1], Y[0], Y[1]);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int pa = 0; pa + pb < P; ++pa) acc = mfma16(X[pa][m], Y[m], acc);
+    }
+}
+
+// the four 16-byte pieces of row tile `rt` of matrix `mat` of a wave tile's accumulator-image record -> vals[q][u]
+__device__ __forceinline__ void load_tile_rows(srd_t rec, int mat, int rt, uint32_t lane16, f32x8 (&vals)[2]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#ifdef W16_DBG_NO_LOADS         // diagnosis builds: compute only
+        float4 v = make_float4((float)lane16, 1.0f, (float)mat, (float)rt);
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+#else
+        const float4 v = buf_load16(rec, lane16, (uint32_t)(mat * 16 + rt * 4 + g) * 1024u);
+#endif
+        vals[g >> 1][4 * (g & 1) + 0] = v.x, vals[g >> 1][4 * (g & 1) + 1] = v.y;
+        vals[g >> 1][4 * (g & 1) + 2] = v.z, vals[g >> 1][4 * (g & 1) + 3] = v.w;
+    }
+}
+
+__device__ __forceinline__ void zero_tile(f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+}
+
+// accumulator tile -> partial record; row_of(i) / col_of(j) map the tile's row (lane of X') and column (lane of Y')
+// to indices of the gradient matrix or -1
+template <typename RowFn, typename ColFn>
+__device__ __forceinline__ void flush_mapped(float* __restrict__ rec, int base, int in_dim, int lane, const f32x16& acc,
+                                             float mul, RowFn row_of, ColFn col_of) {
+    const int jj = lane & 31, hh = lane >> 5;
+    const int col = col_of(jj);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row_of(rowmap(r, hh));
+        if (row >= 0 && col >= 0) rec[base + row * in_dim + col] = acc[r] * mul;
+    }
+}
+
+constexpr int W16_BLOCK = 512;
+constexpr int W16_MAX_BLOCKS = 256;      // = WG_MAX_BLOCKS of decoder.hip: the partial buffer holds that many records
+
+struct W16Args {
+    const float* __restrict__ feat;
+    const float* __restrict__ x;
+    const float* __restrict__ saved;
+    const float* __restrict__ dact;
+    const float* __restrict__ dsmall;
+    float* __restrict__ rec;            // this block's partial record
+    uint32_t M, n_tiles;
+};
+
+// column of the e products: slot t = 16 ct + 8 (c >> 4) + 4 ((c >> 3) & 1) + (c & 3), half (c >> 2) & 1
+__device__ __forceinline__ int w16_e_col(int ct, int c) {
+    return eidx(16 * ct + 8 * (c >> 4) + 4 * ((c >> 3) & 1) + (c & 3), (c >> 2) & 1);
+}
+// small row (0..4 d logits, 5..7 d rgb) held by X' lane i: i in {0..3, 8..11} -> 0..7
+__device__ __forceinline__ int w16_small_row(int i) { return (i < 4) ? i : ((i >= 8 && i < 12) ? i - 4 : -1); }
+
+// The 16 e slots 16 ct .. 16 ct + 15 of this lane's half (load_e<true>'s values: slot 8 d + k = sin(2^k pi x_d [+ pi/2]),
+// slots 24, 25 the raw coordinates, the rest padding) as the two A operands of a transposing MFMA pair
+template <int CT>
+__device__ __forceinline__ void w16_e_tile(float x0, float x1, float x2, int h, f32x8 (&v)[2]) {
+    const float ph = h ? HALF_PI_F : 0.0f;
+    if (CT == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[0][k] = sin_reduced(fmaf(ldexpf(x0, k), PI_F, ph));
+            v[1][k] = sin_reduced(fmaf(ldexpf(x1, k), PI_F, ph));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[0][k] = sin_reduced(fmaf(ldexpf(x2, k), PI_F, ph)), v[1][k] = 0.0f;
+        v[1][0] = h ? x1 : x0;
+        v[1][1] = h ? 0.0f : x2;
+    }
+}
+
+#define W16_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// largest |value| of a wave's 16-register block, as the bit pattern of a non-negative float in a scalar register
+__device__ __forceinline__ uint32_t w16_block_max_bits(const f32x8 (&v)[2], int nq) {
+    float m = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (q < nq) {
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) m = fmaxf(fmaxf(m, fabsf(v[q][u])), fabsf(v[q][u + 1]));
+        }
+    int x = __float_as_int(m);          // non-negative floats order like their bit patterns
+    // DPP reduction: rows of 16 lanes (shift right by 1, 2, 4, 8), then lane 15 of a row into the next row, then lane 31
+    // into rows 2 and 3: lane 63 ends up with the maximum of all 64
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x111, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x112, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x114, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x118, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xa, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xc, 0xf, false));
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
+
+// The power-of-two exponent k a gradient block is multiplied by (f16 arithmetic): kept while the block's largest entry
+// x 2^k stays in [2^8, 2^15), else moved so that it lands in [2^14, 2^15); `rescale` = 2^(k_new - k_old) for the
+// accumulators that live in the block's scaled domain (1.0f: nothing to do).  All in scalar registers.
+__device__ __forceinline__ float w16_pick_scale(uint32_t max_bits, int& k, float& rescale) {
+    rescale = 1.0f;
+    const int eb = (int)(max_bits >> 23);                  // biased exponent: max in [2^(eb - 127), 2^(eb - 126))
+    if (eb != 0 && eb != 255) {
+        const int top = eb - 126 + k;                      // max x 2^k < 2^top
+        if (top > 15 || top < 9) {
+            int kn = 15 - (eb - 126);
+            kn = kn > 60 ? 60 : (kn < -60 ? -60 : kn);
+            rescale = __uint_as_float((uint32_t)(127 + kn - k) << 23);
+            k = kn;
+        }
+    }
+    return __uint_as_float((uint32_t)(127 + k) << 23);
+}
+__device__ __forceinline__ float w16_unscale(int k) { return __uint_as_float((uint32_t)(127 - k) << 23); }
+
+// Both roles are software pipelined by hand, TWO stages deep: the loads of stage k + 2 are issued before stage k
+// computes (three 16-register buffers in rotation; the stage counts, 9 and 6, are multiples of three so that a tile ends
+// with the first two stages of the wave's next tile in the buffers the loop expects them in), the fences keep the
+// compiler from sinking the loads back to their use.  One stage ahead leaves 32 KB per CU in flight -- 4 TB/s at the
+// loaded HBM latency, which is what the kernel then ran at; without any prefetch a wave waits out a full latency per stage.
+//
+// waves 0..3 (row tile w): d w_pts2[w][0..3] = dH2[w]^T H1, d b_pts2;  one more accumulator tile with
+//   rows 0..15 : (small rows)^T H3[col tile w]                                          -> d w_sdf2
+//   rows 16..31: (small rows)^T {rgb_emb col tile 0 | 1 | e col tile 0 | 1}[w]          -> d w_rgb0
+template <int LAYOUT, typename A>
+__device__ __forceinline__ void w16_role_a(const W16Args& a, const typename A::v8 (&I)[2], int w, int lane) {
+    constexpr int P = A::P;
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t lane16 = 16u * (uint32_t)lane;
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) zero_tile(acc[t]);
+    float bsum = 0.f, bsmall = 0.f, dummy = 0.f;
+    int k_main = 0, k_small = 0;         // f16: exponents of the scaled domains of acc[0..3] + bsum / acc[4] + bsmall
+    f32x8 buf[3][2];
+    auto act_srd = [&](const float* recs, uint32_t tile) {
+        return make_srd(recs + (size_t)tile * ACT_TILE_FLOATS, ACT_TILE_FLOATS * 4);
+    };
+    // small rows: lane (j, h = 0) contributes dsmall[s][0..7] to MFMA 0 -> columns {0..3, 8..11}; the other half and
+    // the samples past M read zeros through the buffer's bounds check (no branch)
+    const srd_t small_srd = make_srd(a.dsmall, a.M * 32u), x_srd = make_srd(a.x, a.M * 12u);
+    auto load_small = [&](uint32_t tile, f32x8 (&v)[2]) {
+        const uint32_t off = h == 0 ? (tile * 32u + (uint32_t)j) * 32u : 0xfffffff0u;
+        const float4 p = buf_load16(small_srd, off, 0), q = buf_load16(small_srd, off, 16);
+        v[0][0] = p.x, v[0][1] = p.y, v[0][2] = p.z, v[0][3] = p.w, v[0][4] = q.x, v[0][5] = q.y, v[0][6] = q.z, v[0][7] = q.w;
+    };
+    auto load_x = [&](uint32_t tile, f32x8 (&v)[2]) {
+        const uint32_t s_raw = tile * 32u + (uint32_t)j;
+        const uint32_t off = (s_raw < a.M ? s_raw : a.M - 1) * 12u;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) v[0][d] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_srd, off, 4 * d, 0));
+    };
+    // tiles in reverse: the records the chain kernel wrote last are still in the 256 MB Infinity Cache
+    uint32_t it = blockIdx.x;
+    if (it < a.n_tiles) {
+        load_tile_rows(act_srd(a.dact, a.n_tiles - 1 - it), 1, w, lane16, buf[0]);
+        load_tile_rows(act_srd(a.saved, a.n_tiles - 1 - it), 0, 0, lane16, buf[1]);
+    }
+#pragma clang loop unroll(disable)
+    for (; it < a.n_tiles; it += gridDim.x) {
+        const uint32_t tile = a.n_tiles - 1 - it;
+#ifndef W16_NO_TILE_BARRIER
+        // The 8 waves read each other's records (H1 by all of waves 0..3, H2 by waves 4..7 and 0, 1): kept within one tile
+        // of each other, the second to fourth reader hits in L2; free-running, they drift apart by whole tiles and the
+        // re-reads go back to memory.
+        __builtin_amdgcn_s_barrier();
+#endif
+        const srd_t sa = act_srd(a.saved, tile);
+        const uint32_t nt = it + gridDim.x < a.n_tiles ? tile - gridDim.x : tile;
+        typename A::v8 X[P][2];
+        load_tile_rows(sa, 0, 1, lane16, buf[2]);
+        W16_FENCE();
+        if (A::SCALED) {
+            float rs;
+            const float sx = w16_pick_scale(w16_block_max_bits(buf[0], 2), k_main, rs);
+            if (rs != 1.0f) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] *= rs;
+                bsum *= rs;
+            }
+            buf[0][0] *= sx, buf[0][1] *= sx;
+        }
+        transpose_block<A, true>(buf[0], I, X, bsum);                   // stage 0: X = dH2[w]
+        W16_FENCE();
+        load_tile_rows(sa, 0, 2, lane16, buf[0]);
+        W16_FENCE();
+        transpose_mac<A>(buf[1], I, X, acc[0]);                         // stages 1..4: H1 column tiles
+        W16_FENCE();
+        load_tile_rows(sa, 0, 3, lane16, buf[1]);
+        W16_FENCE();
+        transpose_mac<A>(buf[2], I, X, acc[1]);
+        W16_FENCE();
+        load_small(tile, buf[2]);
+        W16_FENCE();
+        transpose_mac<A>(buf[0], I, X, acc[2]);
+        W16_FENCE();
+        load_tile_rows(sa, 2, w, lane16, buf[0]);
+        W16_FENCE();
+        transpose_mac<A>(buf[1], I, X, acc[3]);
+        W16_FENCE();
+        load_tile_rows(sa, 1, 2 + (w & 1), lane16, buf[1]);             // rgb_emb = H2 row tiles 2, 3 (read by waves 0, 1)
+        W16_FENCE();
+        f32x8 sv1[2], sv2[2];                                           // stage 5: X = small rows (columns 0..11)
+        if (A::SCALED) {
+            float rs;
+            const float sx = w16_pick_scale(w16_block_max_bits(buf[2], 1), k_small, rs);
+            if (rs != 1.0f) acc[4] *= rs, bsmall *= rs;
+            buf[2][0] *= sx;
+        }
+        sv1[0] = buf[2][0], sv2[0] = buf[2][0], sv1[1] = buf[2][0], sv2[1] = buf[2][0];      // ([1] is not read: NQ = 1)
+        transpose_block<A, true, 1>(sv1, I, X, bsmall);                 // (its row sums are wave 0's to write)
+        W16_FENCE();
+        load_x(tile, buf[2]);                                           // coordinates (used by waves 2, 3)
+        W16_FENCE();
+        transpose_mac<A>(buf[0], I, X, acc[4]);                         // stage 6: H3[w]
+        transpose_block<A, false, 1>(sv2, I, X, dummy, 1);              // the same small rows at columns 16..27
+        W16_FENCE();
+        load_tile_rows(act_srd(a.dact, nt), 1, w, lane16, buf[0]);      // next tile's stage 0
+        W16_FENCE();
+        if (w < 2) transpose_mac<A>(buf[1], I, X, acc[4]);              // stage 7: rgb_emb (waves 0, 1)
+        W16_FENCE();
+        load_tile_rows(act_srd(a.saved, nt), 0, 0, lane16, buf[1]);     // next tile's stage 1
+        W16_FENCE();
+        if (w >= 2) {                                                   // stage 8: e (waves 2, 3)
+            const float x0 = buf[2][0][0], x1 = buf[2][0][1], x2 = buf[2][0][2];
+            if (w == 2) w16_e_tile<0>(x0, x1, x2, h, buf[2]);
+            else w16_e_tile<1>(x0, x1, x2, h, buf[2]);
+            transpose_mac<A>(buf[2], I, X, acc[4]);
+        }
+        W16_FENCE();
+    }
+    float* rec = a.rec;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+        flush_mapped(rec, G_W_PTS2, HID, lane, acc[ct], w16_unscale(k_main), [&](int i) { return 32 * w + i; }, [&](int c) { return 32 * ct + c; });
+    flush_mapped(rec, G_W_SDF2, HID, lane, acc[4], w16_unscale(k_small),
+                 [&](int i) { const int r = w16_small_row(i); return r < N_CLASS ? r : -1; }, [&](int c) { return 32 * w + c; });
+    auto rgb_row = [&](int i) { const int r = i >= 16 ? w16_small_row(i - 16) : -1; return r >= N_CLASS ? r - N_CLASS : -1; };
+    if (w < 2)
+        flush_mapped(rec, G_W_RGB0, N_RGB_IN, lane, acc[4], w16_unscale(k_small), rgb_row, [&](int c) { return 32 * w + c; });
+    else
+        flush_mapped(rec, G_W_RGB0, N_RGB_IN, lane, acc[4], w16_unscale(k_small), rgb_row,
+                     [&](int c) { const int e = w16_e_col(w - 2, c); return e >= 0 ? N_EMB + e : -1; });
+    // bias partials: this lane = feature (lane & 31) of the row tile; the two halves hold different samples
+    const float b2 = (bsum + __shfl_xor(bsum, 32, 64)) * w16_unscale(k_main);
+    if (h == 0) rec[G_B_PTS2 + 32 * w + j] = b2;
+    if (w == 0) {
+        const float bs = (bsmall + __shfl_xor(bsmall, 32, 64)) * w16_unscale(k_small);
+        const int r = w16_small_row(j);
+        if (h == 0 && r >= 0 && r < N_CLASS) rec[G_B_SDF2 + r] = bs;
+        if (h == 0 && r >= N_CLASS) rec[G_B_RGB0 + r - N_CLASS] = bs;
+    }
+}
+
+// waves 4..7 (row tile rt): d w_sdf0[rt][0..2] = dG3[rt]^T [sdf_emb | grid], d b_sdf0;  d w_pts0[rt][0..1] = dG1[rt]^T e,
+// d b_pts0 (e recomputed from x)
+template <int LAYOUT, typename A>
+__device__ __forceinline__ void w16_role_b(const W16Args& a, const typename A::v8 (&I)[2], int rt, int lane) {
+    constexpr int P = A::P;
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t lane16 = 16u * (uint32_t)lane;
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) zero_tile(acc[t]);
+    float bsum0 = 0.f, bsum1 = 0.f;
+    int k3 = 0, k1 = 0;                  // f16: exponents of the scaled domains of acc[0..2] + bsum0 / acc[3..4] + bsum1
+    f32x8 buf[3][2];
+    auto act_srd = [&](const float* recs, uint32_t tile) {
+        return make_srd(recs + (size_t)tile * ACT_TILE_FLOATS, ACT_TILE_FLOATS * 4);
+    };
+    // grid features and coordinates through buffer resources: one 32-bit lane offset instead of 16 address pairs
+    const uint64_t feat_bytes = (uint64_t)a.M * N_GRID * 4;
+    const srd_t feat_srd = make_srd(a.feat, feat_bytes > 0xffffffffull ? 0xffffffffu : (uint32_t)feat_bytes);
+    const srd_t x_srd = make_srd(a.x, a.M * 12u);
+    auto sample_of = [&](uint32_t tile) {
+        const uint32_t s_raw = tile * 32u + (uint32_t)j;
+        return s_raw < a.M ? s_raw : a.M - 1;
+    };
+    // grid features: this lane holds feature h of level 8 q + u  ->  column 16 q + 8 (u >> 2) + 4 h + (u & 3)
+    auto load_grid = [&](uint32_t tile, f32x8 (&v)[2]) {
+        const uint32_t s_c = sample_of(tile);
+        const uint32_t voff = LAYOUT == MIPSF_FEAT_AOS ? s_c * (uint32_t)(N_GRID * 4) + 4u * (uint32_t)h : (s_c * 2u + (uint32_t)h) * 4u;
+        const uint32_t lstride = LAYOUT == MIPSF_FEAT_AOS ? 8u : a.M * 8u;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[q][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(feat_srd, voff, (uint32_t)(8 * q + u) * lstride, 0));
+    };
+    auto load_x = [&](uint32_t tile, f32x8 (&v)[2]) {
+        const uint32_t off = sample_of(tile) * 12u;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) v[0][d] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_srd, off, 4 * d, 0));
+    };
+    uint32_t it = blockIdx.x;
+    if (it < a.n_tiles) {
+        load_tile_rows(act_srd(a.dact, a.n_tiles - 1 - it), 2, rt, lane16, buf[0]);
+        load_tile_rows(act_srd(a.saved, a.n_tiles - 1 - it), 1, 0, lane16, buf[1]);
+    }
+#pragma clang loop unroll(disable)
+    for (; it < a.n_tiles; it += gridDim.x) {
+        const uint32_t tile = a.n_tiles - 1 - it;
+#ifndef W16_NO_TILE_BARRIER
+        __builtin_amdgcn_s_barrier();
+#endif
+        const srd_t sa = act_srd(a.saved, tile), da = act_srd(a.dact, tile);
+        const uint32_t nt = it + gridDim.x < a.n_tiles ? tile - gridDim.x : tile;
+        typename A::v8 X[P][2];
+        load_tile_rows(sa, 1, 1, lane16, buf[2]);
+        W16_FENCE();
+        if (A::SCALED) {
+            float rs;
+            const float sx = w16_pick_scale(w16_block_max_bits(buf[0], 2), k3, rs);
+            if (rs != 1.0f) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[t] *= rs;
+                bsum0 *= rs;
+            }
+            buf[0][0] *= sx, buf[0][1] *= sx;
+        }
+        transpose_block<A, true>(buf[0], I, X, bsum0);                  // stage 0: X = dG3[rt]
+        W16_FENCE();
+        load_grid(tile, buf[0]);
+        W16_FENCE();
+        transpose_mac<A>(buf[1], I, X, acc[0]);                         // stages 1, 2: sdf_emb = H2 row tiles 0, 1
+        W16_FENCE();
+        load_tile_rows(da, 0, rt, lane16, buf[1]);
+        W16_FENCE();
+        transpose_mac<A>(buf[2], I, X, acc[1]);
+        W16_FENCE();
+        load_x(tile, buf[2]);
+        W16_FENCE();
+        if (A::SCALED) buf[0][0] *= W16_GRID_SHIFT, buf[0][1] *= W16_GRID_SHIFT;
+        transpose_mac<A>(buf[0], I, X, acc[2]);                         // stage 3: grid
+        W16_FENCE();
+        load_tile_rows(act_srd(a.dact, nt), 2, rt, lane16, buf[0]);     // next tile's stage 0
+        W16_FENCE();
+        if (A::SCALED) {
+            float rs;
+            const float sx = w16_pick_scale(w16_block_max_bits(buf[1], 2), k1, rs);
+            if (rs != 1.0f) acc[3] *= rs, acc[4] *= rs, bsum1 *= rs;
+            buf[1][0] *= sx, buf[1][1] *= sx;
+        }
+        transpose_block<A, true>(buf[1], I, X, bsum1);                  // stage 4: X = dG1[rt]
+        W16_FENCE();
+        load_tile_rows(act_srd(a.saved, nt), 1, 0, lane16, buf[1]);     // next tile's stage 1
+        W16_FENCE();
+        {                                                               // stage 5: e, both column tiles
+            const float x0 = buf[2][0][0], x1 = buf[2][0][1], x2 = buf[2][0][2];
+            w16_e_tile<0>(x0, x1, x2, h, buf[2]);
+            transpose_mac<A>(buf[2], I, X, acc[3]);
+            W16_FENCE();
+            w16_e_tile<1>(x0, x1, x2, h, buf[2]);
+            transpose_mac<A>(buf[2], I, X, acc[4]);
+        }
+        W16_FENCE();
+    }
+    float* rec = a.rec;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+        flush_mapped(rec, G_W_SDF0, N_SDF_IN, lane, acc[ct], w16_unscale(k3), [&](int i) { return 32 * rt + i; }, [&](int c) { return 32 * ct + c; });
+    // grid columns: level = 8 (c >> 4) + 4 ((c >> 3) & 1) + (c & 3), feature (c >> 2) & 1
+    flush_mapped(rec, G_W_SDF0, N_SDF_IN, lane, acc[2], A::SCALED ? w16_unscale(k3) / W16_GRID_SHIFT : 1.0f, [&](int i) { return 32 * rt + i; },
+                 [&](int c) { return N_EMB + 2 * (8 * (c >> 4) + 4 * ((c >> 3) & 1) + (c & 3)) + ((c >> 2) & 1); });
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+        flush_mapped(rec, G_W_PTS0, N_E, lane, acc[3 + ct], w16_unscale(k1), [&](int i) { return 32 * rt + i; },
+                     [&](int c) { return w16_e_col(ct, c); });
+    const float b3 = (bsum0 + __shfl_xor(bsum0, 32, 64)) * w16_unscale(k3), b1 = (bsum1 + __shfl_xor(bsum1, 32, 64)) * w16_unscale(k1);
+    if (h == 0) rec[G_B_SDF0 + 32 * rt + j] = b3, rec[G_B_PTS0 + 32 * rt + j] = b1;
+}
+
+template <int LAYOUT, typename A>
+__global__ __launch_bounds__(W16_BLOCK, 2) void decoder_wgrad16_kernel(const float* __restrict__ feat,
+                                                                       const float* __restrict__ x,
+                                                                       const float* __restrict__ saved,
+                                                                       const float* __restrict__ dact,
+                                                                       const float* __restrict__ dsmall,
+                                                                       float* __restrict__ partial, uint32_t M,
+                                                                       uint32_t n_tiles) {
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    // the two selection matrices (B operands of the transposing MFMAs): lane = column c, half hb supplies k = 8 hb + u;
+    // I[q][u] = 1 iff column c = 16 q + 8 (u >> 2) + 4 hb + (u & 3)
+    typename A::v8 I[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            I[q][u] = (j == 16 * q + 8 * (u >> 2) + 4 * h + (u & 3)) ? (typename A::elt)1.0f : (typename A::elt)0.0f;
+    const W16Args a = {feat, x, saved, dact, dsmall, partial + (size_t)blockIdx.x * G_STRIDE, M, n_tiles};
+    if (w < 4) w16_role_a<LAYOUT, A>(a, I, w, lane);
+    else w16_role_b<LAYOUT, A>(a, I, w - 4, lane);
+}
+
+}  // namespace mipsf
+
+using namespace mipsf;
+
+extern "C" int mipsf_decoder_wgrad16(const float* feat, int feat_layout, const float* x, const float* saved,
+                                     const float* dact, const mipsf_decoder_grads* grads, float* partial, int arithmetic,
+                                     uint32_t M, void* stream) {
+    if (M == 0) return 0;
+    MIPSF_REQUIRE(feat && x && saved && dact && partial && grads, "null pointer");
+    MIPSF_REQUIRE(feat_layout == MIPSF_FEAT_AOS || feat_layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout");
+    MIPSF_REQUIRE(arithmetic == MIPSF_PREC_F16X3 || arithmetic == MIPSF_PREC_BF16X6 || arithmetic == MIPSF_PREC_BF16X3,
+                  "arithmetic must be f16x3, bf16x6 or bf16x3");
+    MIPSF_REQUIRE(M < (1u << 25), "M = %u: the grid features are addressed through one 4 GB buffer resource", M);
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t n_tiles = (uint32_t)(((uint64_t)M + 31) / 32);
+    const uint64_t n_bt = ((uint64_t)M + 127) / 128;
+    const float* dsmall = dact + n_bt * 4 * ACT_TILE_FLOATS;
+    const int cus = device_cus();
+    if (cus <= 0) return 3;
+    uint32_t blocks = n_tiles < (uint32_t)cus ? n_tiles : (uint32_t)cus;
+    if (blocks > (uint32_t)W16_MAX_BLOCKS) blocks = (uint32_t)W16_MAX_BLOCKS;
+#define W16(LAY, AR) hipLaunchKernelGGL((decoder_wgrad16_kernel<LAY, AR>), dim3(blocks), dim3(W16_BLOCK), 0, s, feat, x, \
+                                        saved, dact, dsmall, partial, M, n_tiles)
+#define W16_L(LAY) do { if (arithmetic == MIPSF_PREC_F16X3) W16(LAY, ArF16); else if (arithmetic == MIPSF_PREC_BF16X6) W16(LAY, ArBF3); \
+                        else W16(LAY, ArBF2); } while (0)
+    if (feat_layout == MIPSF_FEAT_AOS) W16_L(MIPSF_FEAT_AOS); else W16_L(MIPSF_FEAT_LEVEL_MAJOR);
+#undef W16_L
+#undef W16
+    if (int e = check_launch("decoder_wgrad16")) return e;
+    return wgrad_reduce_launch(partial, blocks, grads, s);
+}

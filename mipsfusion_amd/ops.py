@@ -209,13 +209,19 @@ def decoder_fwd(packed, feat, layout, x, embed_pos, M, save: bool, precision: st
 
 
 def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, precision: str = "f32", packed16=None,
-                wgrad_precision: str = "f32"):
+                wgrad_precision: str = "auto"):
     """grads: 10 tensors in DECODER_PARAM_ORDER, accumulated into, or None (frozen decoder: the weight-gradient
     GEMMs are skipped).  -> (dfeat, dx, dembed_pos|None).  precision "f16x3": the activation-gradient chain runs on
     the f16 matrix cores with hi/lo split operands (packed16, in-kernel positional encoding); it leaves the same `dact`
-    record, so the weight-gradient kernel is the same in both modes.  wgrad_precision "bf16x3" (opt-in): the three
-    large weight-gradient products on the bf16 matrix cores with hi/lo split operands -- 10 % faster, weight gradients
-    to ~5e-6 of their maximum instead of ~3e-7."""
+    record as the fp32 chain, so every weight-gradient kernel works behind either.  wgrad_precision:
+      "stream_f16x3"  streaming kernel (csrc/wgrad16.hip), hi + lo f16 planes, a power-of-two scale per gradient block:
+                      fp32-class (~3e-7 of the maximum), runs at the device's read bandwidth; pe_mode 0
+      "stream_bf16x6" the same kernel on three bf16 planes (no scale; fp32-class, slower), "stream_bf16x3" two planes (~5e-6)
+      "f32"           LDS-transposing kernel on the fp32-input matrix cores (the round-1 path; any pe_mode)
+      "bf16x3"        that kernel with bf16 hi/lo operands for its three large products (~5e-6)
+      "auto"          "stream_f16x3" behind the f16x3 chain, "f32" otherwise."""
+    if wgrad_precision == "auto":
+        wgrad_precision = "stream_f16x3" if (precision == "f16x3" and embed_pos is None) else "f32"
     dev = x.device
     dfeat = torch.empty_like(feat)
     dx = torch.empty((M, 3), dtype=torch.float32, device=dev)
@@ -237,6 +243,15 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
     if grads is not None:
         partial = torch.empty(lib().mipsf_decoder_wgrad_partial_floats(), dtype=torch.float32, device=dev)
         st = _decoder_struct(grads, _lib.DecoderGrads)
+        if wgrad_precision.startswith("stream_"):
+            # streaming kernel (csrc/wgrad16.hip): "stream_f16x3" (default of the f16x3 decoder), "stream_bf16x6", "stream_bf16x3"
+            if embed_pos is not None:
+                raise RuntimeError("the streaming weight-gradient kernel computes the positional encoding in-kernel")
+            arith = _lib.PREC[wgrad_precision[len("stream_"):]]
+            with _timed("decoder_wgrad"):
+                check(lib().mipsf_decoder_wgrad16(dptr(feat), layout, dptr(x), dptr(saved), dptr(dact), C.byref(st),
+                                                  dptr(partial), arith, M, stream_ptr()), "decoder_wgrad16")
+            return dfeat, dx, dpe
         with _timed("decoder_wgrad"):
             wprec = _lib.PREC[wgrad_precision]
             check(lib().mipsf_decoder_wgrad_ex(dptr(feat), layout, dptr(x), dptr(embed_pos), pe_mode, dptr(saved),

@@ -1190,6 +1190,19 @@ def test_decoder_f16x3_backward_chain_matches_fp32_kernel(dev, M, layout):
     assert_close(dx16, dx32, 3e-6, "d x")
     for k, a, b in zip(ops.DECODER_PARAM_ORDER, g16, g32):
         assert_close(a, b, 3e-6, "grad " + k)
+    # every weight-gradient kernel reads the same records: the default above is the streaming f16 hi/lo kernel
+    # (wgrad16.hip); the fp32 LDS kernel and the streaming kernel on three bf16 planes must agree with it to fp32 class,
+    # and the streaming kernel must equally work behind the fp32 chain
+    for wp in ("f32", "stream_bf16x6"):
+        gw = [torch.zeros_like(w) for w in ws]
+        ops.decoder_bwd(None, feat, lay, x, None, out, dout, saved, gw, M, precision="f16x3", packed16=packed16,
+                        wgrad_precision=wp)
+        for k, a, b in zip(ops.DECODER_PARAM_ORDER, gw, g32):
+            assert_close(a, b, 3e-6, wp + " grad " + k)
+    gw = [torch.zeros_like(w) for w in ws]
+    ops.decoder_bwd(packed, feat, lay, x, None, out, dout, saved, gw, M, wgrad_precision="stream_f16x3")
+    for k, a, b in zip(ops.DECODER_PARAM_ORDER, gw, g32):
+        assert_close(a, b, 3e-6, "stream_f16x3 behind the fp32 chain, grad " + k)
     # opt-in: the three large weight-gradient products on the bf16 matrix cores with hi/lo split operands (16-17 bits
     # per operand, fp32 accumulate): per-term error 2^-16, zero-mean, averaged over the batch -> ~5e-6 of the maximum
     gbf = [torch.zeros_like(w) for w in ws]

@@ -93,11 +93,18 @@ def test_two_submap_sequence_matches_reference_run(fused_adam, in_place, precisi
     worst = float(np.max(np.abs(lo - lr) / np.abs(lr)))
     print(f"sequence: worst relative loss deviation {worst:.2e} over {lo.size} iterations "
           f"(first 10: {np.max(np.abs(lo[:10] - lr[:10]) / np.abs(lr[:10])):.2e})")
-    # the loop is chaotic (51 Adam steps, best-of-iterations pose selection, a particle swarm's weighted mean): round-off
-    # differences grow.  Measured: fp32-MFMA arithmetic ends <= 5e-5 m / 8e-4 in loss from the reference's run (its
-    # rounding errors are correlated with torch's fp32), the f16x3 default 3e-4 m / 3e-3 (equally accurate against fp64
-    # truth, tests/test_gpu_parity.py, but uncorrelated).  Both are held to 2 mm and 5e-3.
-    tol_l, tol_p = 5e-3, 2e-3
+    # The loop is chaotic (51 Adam steps, best-of-iterations pose selection, a particle swarm's weighted mean): round-off
+    # differences grow.  Measured with tools/dbg_seq_chaos.py (MI355X, distance of the final poses / worst loss
+    # deviation from the reference's run):
+    #   fp32 kernels                                            0.02 - 0.05 mm   6e-4 - 2e-3   (atomics: run to run)
+    #   fp32 kernels, initial decoder weights moved by one ulp  0.05, 0.05, 0.5 mm   1e-3 - 4e-3   (three seeds)
+    #   fp32 kernels, weights moved by 1e-6 relative            0.08, 0.18, 3.8 mm   9e-4 - 1.5e-2
+    #   f16x3 decoder, any fp32-class weight-gradient kernel    2.3 - 2.5 mm     3e-3 - 4e-3
+    # i.e. the f16x3 default -- as accurate against fp64 truth as the fp32 kernels (tests/test_gpu_parity.py), but with
+    # rounding errors UNCORRELATED with torch's fp32, ~1e-6 relative per step -- lands where a 1e-6 perturbation of the
+    # fp32 run itself lands.  fp32 arithmetic is held to 2 mm / 5e-3, f16x3 to 5 mm / 2e-2; before the chaotic growth
+    # (first 12 iterations) both to 5e-4.
+    tol_l, tol_p = (5e-3, 2e-3) if precision == "f32" else (2e-2, 5e-3)
     np.testing.assert_allclose(lo[:12], lr[:12], rtol=5e-4)       # before chaotic growth: tight in both modes
     np.testing.assert_allclose(lo, lr, rtol=tol_l)
     # ---- poses: local pose of every frame (RandomOptimizer + pose Adam + BA + switch conversions)
