@@ -81,6 +81,12 @@ int mipsf_hashgrid_dx_from_jac(const float* jac, const float* dout, float* dx, u
 uint64_t mipsf_hashgrid_bwd_scratch_floats(const mipsf_grid_meta* meta_host, uint32_t M, int need_dx);
 int mipsf_hashgrid_bwd(const float* x, const float* params, const float* dout, float* dparams, float* dx,
                        float* scratch, uint32_t M, const mipsf_grid_meta* meta_host, int layout, void* stream);
+/* The same in two halves.  The routing of the scatter (which table slices every sample touches: a third of the
+ * backward's time) depends on x only: mipsf_hashgrid_route may run as soon as x exists -- e.g. on a second stream next
+ * to the forward pass -- into the same scratch buffer, and mipsf_hashgrid_bwd_routed then does the rest. */
+int mipsf_hashgrid_route(const float* x, float* scratch, uint32_t M, const mipsf_grid_meta* meta_host, void* stream);
+int mipsf_hashgrid_bwd_routed(const float* x, const float* params, const float* dout, float* dparams, float* dx,
+                              float* scratch, uint32_t M, const mipsf_grid_meta* meta_host, int layout, void* stream);
 /* parity probe: idx[(i*L + level)*8 + corner] = entry index inside the level (uint32). */
 int mipsf_hashgrid_indices(const float* x, uint32_t* idx, uint32_t M, const mipsf_grid_meta* meta_host,
                            void* stream);

@@ -144,9 +144,11 @@ class RandomOptimizer:
                                           for o in range(5)]).to(dev)
 
     @torch.no_grad()
-    def optimize_graphed(self, depth_flat_dev, initial_pose_cpu):
+    def optimize_graphed(self, depth_flat_dev, initial_pose_cpu, waiting=None):
         """depth_flat_dev: the frame's depth as a flat DEVICE tensor [H*W] (the lattice is gathered on the device);
-        initial_pose_cpu: [4,4] CPU tensor -> tracked pose [4,4] on the CPU.  Same arithmetic as ``optimize``."""
+        initial_pose_cpu: [4,4] CPU tensor -> tracked pose [4,4] on the CPU.  Same arithmetic as ``optimize``.
+        waiting: optional ``f(fn)`` that runs the blocking read-back ``fn`` (mipsfusion_amd.sequence: lets the sample
+        producer threads use the host while this thread waits for the GPU)."""
         h = self._g_state_host
         h.zero_()
         h[0:9] = initial_pose_cpu[:3, :3].reshape(9)
@@ -156,7 +158,10 @@ class RandomOptimizer:
         torch.index_select(depth_flat_dev, 0, self._lattice_flat.reshape(-1), out=self._g_td5.view(-1))
         self._graph.replay()
         self._g_out_host.copy_(self._g_state, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        if waiting is None:
+            torch.cuda.current_stream().synchronize()
+        else:
+            waiting(torch.cuda.current_stream().synchronize)
         pose = torch.eye(4, dtype=torch.float32)
         pose[:3, :3] = self._g_out_host[0:9].view(3, 3)
         pose[:3, 3] = self._g_out_host[9:12]

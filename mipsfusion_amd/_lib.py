@@ -79,6 +79,8 @@ SIGNATURES = {
     "mipsf_hashgrid_dx_from_jac": (_I, [_P, _P, _P, _U32, C.POINTER(GridMeta), _I, _P]),
     "mipsf_hashgrid_bwd_scratch_floats": (_U64, [C.POINTER(GridMeta), _U32, _I]),
     "mipsf_hashgrid_bwd": (_I, [_P, _P, _P, _P, _P, _P, _U32, C.POINTER(GridMeta), _I, _P]),
+    "mipsf_hashgrid_route": (_I, [_P, _P, _U32, C.POINTER(GridMeta), _P]),
+    "mipsf_hashgrid_bwd_routed": (_I, [_P, _P, _P, _P, _P, _P, _U32, C.POINTER(GridMeta), _I, _P]),
     "mipsf_hashgrid_indices": (_I, [_P, _P, _U32, C.POINTER(GridMeta), _P]),
     "mipsf_freq_fwd": (_I, [_P, _P, _U32, _U32, _U32, _P]),
     "mipsf_freq_bwd": (_I, [_P, _P, _P, _U32, _U32, _U32, _P]),

@@ -203,7 +203,10 @@ __global__ __launch_bounds__(HG_BLOCK) void hashgrid_fwd_kernel(const float* __r
 //   * the slice is added to dparams with coalesced read-modify-writes; bins with several parts go through
 //     partial slices and a reduce kernel.  No global float atomics, no inter-workgroup communication.
 constexpr int SC_BLOCK = 1024;
-constexpr uint32_t SC_MAX_SLICE = 10240;            // entries: 10240 * 2 doubles = 163840 B = all of a CU's LDS
+#ifndef MIPSF_SC_MAX_SLICE
+#define MIPSF_SC_MAX_SLICE 10240
+#endif
+constexpr uint32_t SC_MAX_SLICE = MIPSF_SC_MAX_SLICE;   // entries: 10240 * 2 doubles = 163840 B = all of a CU's LDS
 #ifndef MIPSF_SC_SLICE_LOG2
 #define MIPSF_SC_SLICE_LOG2 13
 #endif
@@ -219,6 +222,7 @@ constexpr uint32_t SC_RUN = MIPSF_SC_RUN;                   // consecutive recor
 constexpr uint32_t SC_ROUTE_UNR = 4;                // samples per thread in the routing kernel
 constexpr uint32_t SC_MAX_NS = 512;                 // slices per level (2^22-entry levels)
 constexpr uint32_t SC_MAX_BINS = 8192;
+constexpr uint32_t SC_MASKED_MAX_M = 1u << 24;    // up to here a routing record has room for the 8-bit corner mask
 
 struct ScatterPlan {
     uint32_t n_levels;
@@ -350,13 +354,21 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __
     for (uint32_t q = threadIdx.x; q < ns; q += SC_BLOCK)
         base[q] = cnt[q] ? atomicAdd(&ws[plan.w_count + bin0 + q], cnt[q]) : 0u;
     __syncthreads();
+    // record = sample index | (the corners of the sample's cell that fall into this slice) << 24: the accumulate kernel
+    // then hashes those corners only (on a hashed level 2 of 8: the pair along x) instead of all 8 plus 8 membership tests
+    const bool masked = M <= SC_MASKED_MAX_M;
     uint32_t* rec = ws + plan.w_records;
 #pragma unroll
     for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u) {
         const uint32_t i = s0 + u * SC_BLOCK + threadIdx.x;
 #pragma unroll
         for (int c = 0; c < 8; ++c)
-            if (lead[u] >> c & 1u) rec[(size_t)(bin0 + sl[u][c]) * M + base[sl[u][c]] + rank[u][c]] = i;
+            if (lead[u] >> c & 1u) {
+                uint32_t m = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m |= (sl[u][k] == sl[u][c]) ? (1u << k) : 0u;
+                rec[(size_t)(bin0 + sl[u][c]) * M + base[sl[u][c]] + rank[u][c]] = masked ? (i | (m << 24)) : i;
+            }
     }
 }
 
@@ -424,6 +436,7 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
     __syncthreads();
 
     const int mode = level_mode(res, size);
+    const bool masked = M <= SC_MASKED_MAX_M;      // records carry the corner mask of scatter_route_kernel
     // Every thread takes SC_RUN consecutive records at a time (records are in sample order, so they are a
     // stretch of one ray) and merges the ones that sit in the same cell in registers; the atomics go out when the
     // cell changes.  On the coarse levels a ray spends ~10 samples per cell: up to SC_RUN x fewer atomics, and the
@@ -488,7 +501,7 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
             }
 #pragma unroll
             for (int u = 0; u < UD; ++u) {
-                const uint32_t ii = si[u];
+                const uint32_t ii = masked ? (si[u] & 0xffffffu) : si[u];
                 px[u][0] = x[3 * (size_t)ii], px[u][1] = x[3 * (size_t)ii + 1], px[u][2] = x[3 * (size_t)ii + 2];
                 pg[u] = *reinterpret_cast<const float2*>(dout + feat_index<LAYOUT>(ii, level, M, g.n_levels));
             }
@@ -503,21 +516,20 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
                     cell.c[d] = (uint32_t)(int)fl;
                     cell.f[d] = pos - fl;
                 }
-                uint32_t idx[8];
-                corner_indices(mode, cell, res, size, idx);
-                uint32_t hit = 0;
+                uint32_t hit = si[u] >> 24;           // the routing kernel's corner mask
+                if (!masked) {                        // (batches beyond 2^24 samples: membership of all 8 corners here)
+                    uint32_t idx[8];
+                    corner_indices(mode, cell, res, size, idx);
+                    hit = 0;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    idx[c] -= begin;
-                    hit |= (idx[c] < count) ? (1u << c) : 0u;
+                    for (int c = 0; c < 8; ++c) hit |= (idx[c] - begin < count) ? (1u << c) : 0u;
                 }
                 const float2 gy = pg[u];
                 while (hit) {
                     const int c = __ffs((int)hit) - 1;
                     hit &= hit - 1u;
-                    uint32_t e = idx[0];
-#pragma unroll
-                    for (int k = 1; k < 8; ++k) e = (c == k) ? idx[k] : e;
+                    const uint32_t cx = cell.c[0] + (c & 1), cy = cell.c[1] + ((c >> 1) & 1), cz = cell.c[2] + ((c >> 2) & 1);
+                    const uint32_t e = (mode == 1 ? corner_index<1>(cx, cy, cz, res, size) : corner_index<2>(cx, cy, cz, res, size)) - begin;
                     float wgt = (c & 1) ? cell.f[0] : 1.0f - cell.f[0];
                     wgt = wgt * ((c & 2) ? cell.f[1] : 1.0f - cell.f[1]);
                     wgt = wgt * ((c & 4) ? cell.f[2] : 1.0f - cell.f[2]);
@@ -537,7 +549,10 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
         float px[UNR][3];
         float2 pg[UNR];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) si[u] = rec[r + u < re ? r + u : re - 1];
+        for (int u = 0; u < UNR; ++u) {
+            si[u] = rec[r + u < re ? r + u : re - 1];
+            si[u] = masked ? (si[u] & 0xffffffu) : si[u];
+        }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const uint32_t ii = si[u];
@@ -788,8 +803,39 @@ uint64_t mipsf_hashgrid_bwd_scratch_floats(const mipsf_grid_meta* meta, uint32_t
     return p.w_end + (need_dx ? (uint64_t)g.n_levels * M * 3 : 0) + 64;
 }
 
-int mipsf_hashgrid_bwd(const float* x, const float* params, const float* dout, float* dparams, float* dx,
-                       float* scratch, uint32_t M, const mipsf_grid_meta* meta, int layout, void* stream) {
+static int check_plan(const ScatterPlan& plan, const GridLevels& g, uint32_t M) {
+    MIPSF_REQUIRE(plan.n_bins <= SC_MAX_BINS && plan.n_bins <= 0xffffu, "grid too large: %u table slices", plan.n_bins);
+    for (uint32_t l = 0; l < g.n_levels; ++l)
+        MIPSF_REQUIRE(plan.n_slices[l] <= SC_MAX_NS, "level %u too large: %u slices", l, plan.n_slices[l]);
+    MIPSF_REQUIRE(plan.w_end < (1ull << 32), "batch too large for 32-bit scratch offsets (M = %u)", M);
+    MIPSF_REQUIRE(((uint64_t)M + SC_PART - 1) / SC_PART < (1u << 16), "batch too large (M = %u)", M);
+    return 0;
+}
+
+static int launch_route(const float* x, uint32_t* ws, uint32_t M, const GridLevels& g, const ScatterPlan& plan, hipStream_t s) {
+    const uint32_t nz = plan.w_nitems + 4;   // bin counts, item count
+    hipLaunchKernelGGL(scatter_zero_kernel, dim3((nz + 255) / 256), dim3(256), 0, s, ws, nz);
+    const uint32_t rb = g.n_levels * ((M + SC_BLOCK * SC_ROUTE_UNR - 1) / (SC_BLOCK * SC_ROUTE_UNR));
+    hipLaunchKernelGGL(scatter_route_kernel, dim3(rb), dim3(SC_BLOCK), 0, s, x, M, g, plan, ws);
+    hipLaunchKernelGGL(scatter_scan_kernel, dim3(1), dim3(1024), 0, s, plan, ws);
+    return check_launch("hashgrid_route");
+}
+
+// The routing half of the parameter-gradient scatter depends on the sample positions only: a caller may run it as soon
+// as x exists (e.g. on a second stream next to the forward pass) and hand the scratch buffer to mipsf_hashgrid_bwd_routed.
+int mipsf_hashgrid_route(const float* x, float* scratch, uint32_t M, const mipsf_grid_meta* meta, void* stream) {
+    GridLevels g;
+    if (int rc = to_levels(meta, g)) return rc;
+    if (M == 0) return 0;
+    MIPSF_REQUIRE(x && scratch, "null pointer");
+    const ScatterPlan plan = make_plan(g, M);
+    if (int rc = check_plan(plan, g, M)) return rc;
+    return launch_route(x, reinterpret_cast<uint32_t*>(scratch), M, g, plan, (hipStream_t)stream);
+}
+
+static int hashgrid_bwd_impl(const float* x, const float* params, const float* dout, float* dparams, float* dx,
+                             float* scratch, uint32_t M, const mipsf_grid_meta* meta, int layout, bool routed,
+                             void* stream) {
     GridLevels g;
     if (int rc = to_levels(meta, g)) return rc;
     if (M == 0) return 0;
@@ -798,20 +844,12 @@ int mipsf_hashgrid_bwd(const float* x, const float* params, const float* dout, f
     MIPSF_REQUIRE(layout == MIPSF_FEAT_AOS || layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout %d", layout);
     hipStream_t s = (hipStream_t)stream;
     const ScatterPlan plan = make_plan(g, M);
-    MIPSF_REQUIRE(plan.n_bins <= SC_MAX_BINS && plan.n_bins <= 0xffffu, "grid too large: %u table slices", plan.n_bins);
-    for (uint32_t l = 0; l < g.n_levels; ++l)
-        MIPSF_REQUIRE(plan.n_slices[l] <= SC_MAX_NS, "level %u too large: %u slices", l, plan.n_slices[l]);
-    MIPSF_REQUIRE(plan.w_end < (1ull << 32), "batch too large for 32-bit scratch offsets (M = %u)", M);
-    MIPSF_REQUIRE(((uint64_t)M + SC_PART - 1) / SC_PART < (1u << 16), "batch too large (M = %u)", M);
+    if (int rc = check_plan(plan, g, M)) return rc;
     uint32_t* ws = reinterpret_cast<uint32_t*>(scratch);
     float* dxl = scratch + ((plan.w_end + 15) / 16) * 16;
     if (dparams) {   // a frozen grid (tracking) skips the scatter altogether
-        const uint32_t nz = plan.w_nitems + 4;   // bin counts, item count
-        hipLaunchKernelGGL(scatter_zero_kernel, dim3((nz + 255) / 256), dim3(256), 0, s, ws, nz);
-        const uint32_t rb = g.n_levels * ((M + SC_BLOCK * SC_ROUTE_UNR - 1) / (SC_BLOCK * SC_ROUTE_UNR));
-        hipLaunchKernelGGL(scatter_route_kernel, dim3(rb), dim3(SC_BLOCK), 0, s, x, M, g, plan, ws);
-        hipLaunchKernelGGL(scatter_scan_kernel, dim3(1), dim3(1024), 0, s, plan, ws);
-        if (int e = check_launch("hashgrid_route")) return e;
+        if (!routed)
+            if (int e = launch_route(x, ws, M, g, plan, s)) return e;
         uint32_t max_slice = 0;
         for (uint32_t l = 0; l < g.n_levels; ++l) max_slice = plan.slice_entries[l] > max_slice ? plan.slice_entries[l] : max_slice;
         const uint32_t lds_bytes = max_slice * 16;
@@ -851,6 +889,16 @@ int mipsf_hashgrid_bwd(const float* x, const float* params, const float* dout, f
         if (int e = check_launch("hashgrid_dx_reduce")) return e;
     }
     return 0;
+}
+
+int mipsf_hashgrid_bwd(const float* x, const float* params, const float* dout, float* dparams, float* dx,
+                       float* scratch, uint32_t M, const mipsf_grid_meta* meta, int layout, void* stream) {
+    return hashgrid_bwd_impl(x, params, dout, dparams, dx, scratch, M, meta, layout, false, stream);
+}
+
+int mipsf_hashgrid_bwd_routed(const float* x, const float* params, const float* dout, float* dparams, float* dx,
+                              float* scratch, uint32_t M, const mipsf_grid_meta* meta, int layout, void* stream) {
+    return hashgrid_bwd_impl(x, params, dout, dparams, dx, scratch, M, meta, layout, true, stream);
 }
 
 int mipsf_hashgrid_indices(const float* x, uint32_t* idx, uint32_t M, const mipsf_grid_meta* meta, void* stream) {

@@ -57,6 +57,10 @@ class _NormaliseFn(torch.autograd.Function):
         return ops.normalise_bwd(ops._f32c(dxn), ctx.rc), None
 
 
+# below this many samples the routing kernels take a few microseconds and a second stream only adds launch work
+_ROUTE_AHEAD_MIN_M = 65536
+
+
 class _QueryFn(torch.autograd.Function):
     """query_color_sdf (scene_rep.py:118-128) fused: hash grid (level-major features) -> decoder with the
     frequency encoding computed in its prologue.
@@ -75,6 +79,11 @@ class _QueryFn(torch.autograd.Function):
         # when the points need a gradient (pose optimisation) the forward also keeps d feat / d x, so the backward
         # never gathers the table a second time
         jac = None
+        # the routing half of the grid's parameter-gradient scatter only needs the points: it runs on a second stream
+        # next to this forward pass (joined before the forward returns, so nothing is left dangling if no backward follows)
+        routed = None
+        if ctx.needs_input_grad[2] and owner.route_ahead and M >= _ROUTE_AHEAD_MIN_M:
+            routed = ops.hashgrid_route_ahead(xn, meta)
         if ctx.needs_input_grad[0]:
             feat, jac = ops.hashgrid_fwd(xn, grid_params.detach(), meta, FEAT_LEVEL_MAJOR, with_jac=True)
         else:
@@ -94,6 +103,9 @@ class _QueryFn(torch.autograd.Function):
         if packed is None:
             packed = packed16
         ctx.prec = prec
+        if routed is not None:
+            torch.cuda.current_stream(xn.device).wait_event(routed[1])
+        ctx.routed = routed
         ctx.owner, ctx.M, ctx.meta, ctx.has_jac = owner, M, meta, jac is not None
         ctx.save_for_backward(xn, feat, out, saved, packed, grid_params, *weights, *([jac] if jac is not None else []))
         return out
@@ -130,7 +142,8 @@ class _QueryFn(torch.autograd.Function):
             else:
                 dparams = torch.zeros_like(grid_params)
         if need_g:
-            ops.hashgrid_bwd(xn, grid_params.detach(), dfeat, dparams, ctx.meta, FEAT_LEVEL_MAJOR, None)
+            ops.hashgrid_bwd(xn, grid_params.detach(), dfeat, dparams, ctx.meta, FEAT_LEVEL_MAJOR, None, routed=ctx.routed)
+            ctx.routed = None
         if need_x:
             ops.hashgrid_dx_from_jac(jac, dfeat, dx, ctx.meta, FEAT_LEVEL_MAJOR)
         w_out = [None] * len(weights)
@@ -188,6 +201,11 @@ class JointEncoding(nn.Module):
         # (The ~5e-6 arithmetics "bf16x3" / "stream_bf16x3" pass every per-step tolerance, but the chaotic 51-iteration
         # sequence drifts 10x further from the reference's run with them.)
         self.wgrad_precision = "auto"
+        # opt-in: run the routing half of the hash grid's backward on a second stream next to the forward pass
+        # (ops.hashgrid_route_ahead).  Off by default: measured on the headline workload the routing kernels, squeezed in
+        # beside the persistent decoder forward, take 211 us instead of 70 and slow that kernel from 99 to 137 us -- the
+        # step gets 40 us LONGER (0.88 -> 0.92 ms).  It pays only where the forward leaves CUs idle.
+        self.route_ahead = False
         self._tables = {}
         self.get_resolution()
         self.get_encoding(config)
@@ -255,6 +273,7 @@ class JointEncoding(nn.Module):
         new.accumulate_param_grads_in_place = self.accumulate_param_grads_in_place
         new.decoder_precision = self.decoder_precision
         new.wgrad_precision = self.wgrad_precision
+        new.route_ahead = self.route_ahead
         new.train(self.training)
         return new
 

@@ -26,18 +26,18 @@ PROFILE = None
 
 
 class _timed:
-    def __init__(self, name):
-        self.name = name
+    def __init__(self, name, stream=None):
+        self.name, self.stream = name, stream
 
     def __enter__(self):
         if PROFILE is not None:
             self.a = torch.cuda.Event(enable_timing=True)
             self.b = torch.cuda.Event(enable_timing=True)
-            self.a.record()
+            self.a.record(self.stream)
 
     def __exit__(self, *exc):
         if PROFILE is not None:
-            self.b.record()
+            self.b.record(self.stream)
             PROFILE.setdefault(self.name, []).append((self.a, self.b))
 
 
@@ -83,9 +83,45 @@ def hashgrid_dx_from_jac(jac, dout, dx, meta, layout=FEAT_AOS):
                                                stream_ptr()), "hashgrid_dx_from_jac")
 
 
-def hashgrid_bwd(x, params, dout, dparams, meta, layout=FEAT_AOS, dx: Optional[torch.Tensor] = None):
-    """dparams (and dx when given) are accumulated into."""
+_SIDE_STREAMS = {}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    """One helper stream per device for work that only depends on the inputs of a pass (hashgrid_route_ahead)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _SIDE_STREAMS[key]
+
+
+def hashgrid_route_ahead(x, meta):
+    """Routing half of hashgrid_bwd (a third of its time; depends on x only) enqueued on the device's side stream, i.e.
+    next to whatever the current stream does from here on.  -> (scratch, event): hand both to ``hashgrid_bwd(routed=...)``;
+    the CALLER must make the current stream wait for `event` (or the side stream) before the scratch buffer's memory can
+    be reused -- ``hashgrid_bwd`` does.  Works under hipGraph capture (a fork / join of the captured stream)."""
     M = x.shape[0]
+    n = lib().mipsf_hashgrid_bwd_scratch_floats(C.byref(meta), M, 0)
+    scratch = torch.empty(n, dtype=torch.float32, device=x.device)       # owned by the CURRENT stream's allocator pool
+    main, side = torch.cuda.current_stream(x.device), side_stream(x.device)
+    side.wait_stream(main)
+    with _timed("hashgrid_route", side):
+        check(lib().mipsf_hashgrid_route(dptr(x), dptr(scratch), M, C.byref(meta), C.c_void_p(side.cuda_stream)),
+              "hashgrid_route")
+    ev = torch.cuda.Event()
+    ev.record(side)
+    return scratch, ev
+
+
+def hashgrid_bwd(x, params, dout, dparams, meta, layout=FEAT_AOS, dx: Optional[torch.Tensor] = None, routed=None):
+    """dparams (and dx when given) are accumulated into.  routed: (scratch, event) of hashgrid_route_ahead for this x."""
+    M = x.shape[0]
+    if routed is not None and dx is None and dparams is not None:
+        scratch, ev = routed
+        torch.cuda.current_stream(x.device).wait_event(ev)
+        with _timed("hashgrid_bwd"):
+            check(lib().mipsf_hashgrid_bwd_routed(dptr(x), dptr(params), dptr(dout), dptr(dparams), None, dptr(scratch),
+                                                  M, C.byref(meta), layout, stream_ptr()), "hashgrid_bwd_routed")
+        return
     n = lib().mipsf_hashgrid_bwd_scratch_floats(C.byref(meta), M, 1 if dx is not None else 0)
     scratch = torch.empty(n, dtype=torch.float32, device=x.device)
     with _timed("hashgrid_bwd"):

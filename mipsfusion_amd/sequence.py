@@ -22,8 +22,10 @@ keyframes of the sub-map, the depth image of the frame) are known when the frame
 ``sampler="device"`` is the alternative without the reference's generators (indices and jitter drawn on the GPU: valid
 depth only, without replacement, same per-keyframe shares).
 """
+import os
 import queue
 import random
+import sys
 import threading
 import time
 import types
@@ -86,6 +88,9 @@ def ba_ray_counts(cfg, n_related):
     return mp["sample"], max(mp["sample"] // n_related, mp["pixels_cur"])
 
 
+_DIAG_OFF = os.environ.get("MIPSF_DIAG_STAGE_OFF", "")      # diagnosis: a stage that does no work (garbage samples)
+
+
 class ReferenceSampleProducer:
     """See the module docstring.  ``submit(plan)`` enqueues a frame, ``get()`` returns the oldest submitted frame's
     ``FrameSamples`` once complete, ``release(s)`` hands the slot back after its contents were copied to the device."""
@@ -108,6 +113,21 @@ class ReferenceSampleProducer:
         self._threads = [threading.Thread(target=f, daemon=True, name=n) for f, n in
                          ((self._torch_stream, "mipsf-torch-rng"), (self._topk_stage, "mipsf-topk"),
                           (self._python_stream, "mipsf-python-rng"))]
+        # The python-`random` stage is pure interpreter work: with CPython's default switch interval (5 ms) it keeps the GIL
+        # for 5 ms at a time while the thread that drives the GPU waits for it between two launches -- measured: 5 ms of
+        # `fill` per tracking frame and 15 ms per BA frame that are nothing but GIL waits.  0.1 ms hand-overs cost the
+        # producers a few per cent and take those stalls away (restored by close()).
+        self._switch_interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(self._switch_interval, float(os.environ.get("MIPSF_SWITCH_INTERVAL", "1e-4"))))
+        # ... which does not help against the python-`random` stage: it hands the GIL over every ~0.15 ms anyway (it calls
+        # into torch between its loops), and the consumer, whose 4x4 pose algebra is ~30 tiny torch calls each of which
+        # drops and re-takes the GIL, queues behind it 30 times: `_set_pose` 0.15 -> 5 ms, a tracking frame 3.3 -> 12 ms on
+        # the frames where the stage works (measured by switching the stages off one at a time, tools/micro/ab_stage.sh).
+        # So the consumer can close this gate while it is busy on the host; the PYTHON stage (4 ms of work per frame,
+        # the other two release the GIL inside their large torch ops) then pauses at its next chunk boundary and runs
+        # while the consumer waits for the GPU (GraphedSequence.run opens the gate around its blocking read-backs).
+        self.gate = threading.Event()
+        self.gate.set()
         for t in self._threads:
             t.start()
         self.host_ms = {"torch_rng": 0.0, "topk": 0.0, "python_rng": 0.0}
@@ -132,8 +152,14 @@ class ReferenceSampleProducer:
 
     def get(self, timeout=120.0) -> FrameSamples:
         s = self._order.get()
-        if not s.ready.wait(timeout):
-            raise RuntimeError("sample producer stalled")
+        if not s.ready.is_set():
+            was_open = self.gate.is_set()
+            self.gate.set()                  # the consumer has nothing better to do than wait: let the stages run
+            ok = s.ready.wait(timeout)
+            if not was_open:
+                self.gate.clear()
+            if not ok:
+                raise RuntimeError("sample producer stalled")
         return s
 
     def release(self, s: FrameSamples):
@@ -142,6 +168,7 @@ class ReferenceSampleProducer:
     def close(self):
         for q in (self._q_torch, self._q_topk, self._q_py):
             q.put(None)
+        sys.setswitchinterval(self._switch_interval)
 
     # ------------------------------------------------------------------------------------------- the three stages
     def _torch_stream(self):
@@ -158,6 +185,12 @@ class ReferenceSampleProducer:
                 return
             plan, s = item
             t0 = time.perf_counter()
+            if _DIAG_OFF == "torch":                                # diagnosis only (tools/micro): skip the draws
+                n_items = (1 if plan.track and not iter_ro0 else 0) + (self.it_ba if plan.ba_kf_ids is not None else 0)
+                for _ in range(n_items):
+                    s._part_done()
+                s._part_done()
+                continue
             if plan.track:
                 if not iter_ro0:                                    # sample_pixels_mix (mipsfusion.py:519-523)
                     self._q_topk.put((plan, s, "track", 0, sh.draw_pixel_scores(plan.depth)))
@@ -181,6 +214,9 @@ class ReferenceSampleProducer:
                 return
             plan, s, kind, i, draw = item
             t0 = time.perf_counter()
+            if _DIAG_OFF == "topk":
+                s._part_done()
+                continue
             if kind == "track":
                 rows, cols = sh.sample_pixels_mix(H, W, self._lattice_track[0], self._lattice_track[1], plan.depth,
                                                   self.n_track, draw=draw)
@@ -209,6 +245,9 @@ class ReferenceSampleProducer:
                 return
             plan, s = item
             t0 = time.perf_counter()
+            if _DIAG_OFF == "python":
+                s._part_done()
+                continue
             if plan.track and tk["iter_RO"] == 0:
                 iH, iW = tk["ignore_edge_H"], tk["ignore_edge_W"]
                 hh = self.H - 2 * iH
@@ -219,6 +258,7 @@ class ReferenceSampleProducer:
                 n_kf, _ = ba_ray_counts(self.cfg, plan.ba_kf_ids.shape[0])
                 first = plan.ba_kf_ids[0]
                 for i in range(self.it_ba):
+                    self.gate.wait()
                     flat, _, kf_indices = self._index_db.indices_in_submap(first, plan.ba_kf_ids, n_kf)
                     s.ba_rows[i, :n_kf].copy_(flat)
                     s.ba_owner[i, :n_kf].copy_(kf_indices)
@@ -280,7 +320,7 @@ class GraphedSequence:
     iterations.  Rays are gathered inside the graphs from ONE device table [keyframe database | current frame]."""
 
     def __init__(self, cfg, dev, frames, kf_every=15, sampler="reference", first_iters=200, stream=None,
-                 lookahead=None, graph_ro=True):
+                 lookahead=None, graph_ro=True, gate_producer=True):
         """lookahead: how many frames the sample producer runs ahead of the GPU (default: ``map_every``, one whole
         mapping period -- a BA round needs ~40 ms of serial generator work, a frame without BA ~4 ms, so the work only
         evens out over a period; the reference's own DataLoader prefetches 8 frames, mipsfusion.py:672)."""
@@ -292,6 +332,7 @@ class GraphedSequence:
         assert sampler in ("reference", "device")
         self.cfg, self.dev, self.frames, self.sampler, self.kf_every = cfg, dev, frames, sampler, kf_every
         self.graph_ro = graph_ro and cfg["tracking"]["iter_RO"] > 0
+        self.gate_producer = gate_producer
         self.stream = stream if stream is not None else work_stream(dev)
         self._Graphed = GraphedSteps
         tr, mp, tk = cfg["training"], cfg["mapping"], cfg["tracking"]
@@ -508,8 +549,23 @@ class GraphedSequence:
             for j in range(1, min(n_frames, 1 + self.lookahead)):
                 self.producer.submit(self._plan(j))
         t_frame, t_ro, t_go, t_ba, t_wait = [], [], [], [], []
+        detail = {"go_fill_ms": [], "go_replay_ms": [], "go_launch_ms": [], "go_gpu_ms": [], "ba_fill_ms": [], "ba_replay_ms": [], "tail_ms": []}
+        gate = self.producer.gate if (self.producer is not None and self.gate_producer) else None
+
+        def waiting(fn):
+            """fn blocks on the GPU: the producer stages may use the host meanwhile"""
+            if gate is None:
+                return fn()
+            gate.set()
+            try:
+                return fn()
+            finally:
+                gate.clear()
+
         for k in range(1, n_frames):
             t0 = time.perf_counter()
+            if gate is not None:
+                gate.clear()
             self.cur.copy_(self.host_rays[k], non_blocking=True)            # 8 MB frame hand-over (pinned)
             samples, wait_ms = None, 0.0
             if self.producer is not None:
@@ -518,7 +574,7 @@ class GraphedSequence:
             prev = est[-1]                                                   # poses live on the host (4x4 algebra there)
             init = prev if len(est) < 2 else prev @ torch.linalg.inv(est[-2]) @ prev   # constant velocity
             if self.graph_ro:
-                pose = self.ro.optimize_graphed(self.cur[:, 6], init)
+                pose = self.ro.optimize_graphed(self.cur[:, 6], init, waiting=waiting)
             else:
                 self.model.eval()
                 pose = self.ro.optimize(self.model, self.cur.view(self.H, self.W, 7)[..., 6], init.to(dev), None,
@@ -527,40 +583,57 @@ class GraphedSequence:
                 torch.cuda.synchronize()
             t1 = time.perf_counter()
             self._set_pose(self.go_rot, self.go_trans, 0, pose)
+            ta = time.perf_counter()
             self.go_popt.reset()
             if self.producer is not None:
                 tw = time.perf_counter()
                 samples = self.producer.get()
                 wait_ms = (time.perf_counter() - tw) * 1e3
                 assert samples.frame_id == k
+                tb = time.perf_counter()
                 self.go_idx.copy_(samples.track_idx, non_blocking=True)
                 self.go_noise.copy_(samples.track_noise, non_blocking=True)
+                detail.setdefault("go_fill_parts_ms", []).append([round((ta - t1) * 1e3, 2), round((tw - ta) * 1e3, 2),
+                                                                  round((tb - tw) * 1e3, 2), round((time.perf_counter() - tb) * 1e3, 2)])
             else:
                 self._fill_go_device()
+            t1b = time.perf_counter()
+            ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev_a.record()
             self.go_graph.replay()
-            pose = self._get_pose(self.go_rot, self.go_trans, 0)             # the read-back synchronises
+            ev_b.record()
+            t1c = time.perf_counter()
+            pose = waiting(lambda: self._get_pose(self.go_rot, self.go_trans, 0))     # the read-back synchronises
             t2 = time.perf_counter()
+            detail["go_fill_ms"].append((t1b - t1) * 1e3), detail["go_replay_ms"].append((t2 - t1b) * 1e3)
+            detail["go_launch_ms"].append((t1c - t1b) * 1e3)
+            detail["go_gpu_ms"].append(ev_a.elapsed_time(ev_b))
             ba_ms = 0.0
             if k % mp["map_every"] == 0:
                 assert self.n_kf == self._n_kf_at(k)
                 self._set_pose(self.ba_rot, self.ba_trans, -1, pose)
                 self.ba_popt.reset()
                 n = self._load_ba(samples) if samples is not None else self._fill_ba_device(self.n_kf, False)
+                t2b = time.perf_counter()
                 self._ba_graph(n).replay()
-                pose = self._get_pose(self.ba_rot, self.ba_trans, -1)
+                pose = waiting(lambda: self._get_pose(self.ba_rot, self.ba_trans, -1))
                 ba_ms = (time.perf_counter() - t2) * 1e3
+                detail["ba_fill_ms"].append((t2b - t2) * 1e3), detail["ba_replay_ms"].append(ba_ms - (t2b - t2) * 1e3)
+            t3 = time.perf_counter()
             if k % self.kf_every == 0:                                       # mipsfusion.py:686-688, after the BA
                 self._add_keyframe(pose)
             est.append(pose)
-            torch.cuda.synchronize()
+            waiting(torch.cuda.synchronize)
             if samples is not None:
                 self.producer.release(samples)
+            detail["tail_ms"].append((time.perf_counter() - t3) * 1e3)
             t_frame.append((time.perf_counter() - t0) * 1e3), t_ro.append((t1 - t0) * 1e3)
             t_go.append((t2 - t1) * 1e3), t_ba.append(ba_ms), t_wait.append(wait_ms)
         if self.producer is not None:
+            self.producer.gate.set()
             self.producer.close()
         return {"frame_ms": t_frame, "ro_ms": t_ro, "go_ms": t_go, "ba_ms": t_ba, "producer_wait_ms": t_wait,
-                "est": est, "capture_ms": self.capture_ms,
+                "est": est, "capture_ms": self.capture_ms, "detail_ms": detail,
                 "producer_host_ms": dict(self.producer.host_ms) if self.producer is not None else None}
 
 
@@ -578,6 +651,14 @@ def summarise(res, gt_poses, cfg, launch):
                        "mapping_iters": cfg["mapping"]["iters"], "map_every": cfg["mapping"]["map_every"]},
            "launch": launch, "ate_rmse_m": round(float(np.sqrt(np.mean(np.square(err)))), 4),
            "ate_max_m": round(max(err), 4)}
+    if res.get("detail_ms"):
+        out["detail_ms_mean"] = {k: round(float(np.mean(v)), 3) for k, v in res["detail_ms"].items() if len(v) and k != "go_fill_parts_ms"}
+        out["go_fill_parts_ms_all"] = res["detail_ms"].get("go_fill_parts_ms")
+        out["frame_ms_all"] = [round(float(t), 2) for t in fm]
+        out["ro_go_ms_all"] = [[round(float(a), 2), round(float(b), 2)] for a, b in zip(res["ro_ms"], res["go_ms"])]
+        out["go_fill_ms_all"] = [round(float(t), 2) for t in res["detail_ms"]["go_fill_ms"]]
+        out["go_launch_ms_all"] = [round(float(t), 2) for t in res["detail_ms"]["go_launch_ms"]]
+        out["go_gpu_ms_all"] = [round(float(t), 2) for t in res["detail_ms"]["go_gpu_ms"]]
     if res.get("producer_host_ms"):
         n = max(1, len(res["frame_ms"]))
         out["producer_host_ms_per_frame"] = {k: round(v / n, 3) for k, v in res["producer_host_ms"].items()}
