@@ -47,6 +47,16 @@ def usable_cores():
     return max(1, n)
 
 
+# one NUMA node per rank (mipsfusion_amd/hostcpu.py: the host sample producers run 9 or 14 ms per frame otherwise)
+# (loaded by path: importing the package would import torch before the OpenMP variables below are set)
+import importlib.util  # noqa: E402
+
+_spec = importlib.util.spec_from_file_location("mipsf_hostcpu", os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                                           "mipsfusion_amd", "hostcpu.py"))
+_hostcpu = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_hostcpu)
+HOST_CPUS = None if os.environ.get("MIPSF_NO_CONFINE") else _hostcpu.confine_to_numa_node(32, int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+
 # OpenMP sizes its pools by the machine's core count (256 on the GPU hosts) although the cgroup grants 16: every host
 # thread that touches a torch CPU op would oversubscribe the quota.  Must be set before torch is imported.
 os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))
@@ -753,7 +763,8 @@ def main():
                                "620x460 synthetic RGB-D (640x480 cropped by 10)",
                    "rays": N_RAYS, "samples_per_ray": N_SAMPLES, "hash_size": cfg["grid"]["hash_size"],
                    "parallelism": f"submap-per-gpu x{world}" if world > 1 else "single gpu",
-                   "ray_build": "torch eager ops" if args.torch_pose else "fused pose_rays kernel"},
+                   "ray_build": "torch eager ops" if args.torch_pose else "fused pose_rays kernel",
+                   "host_cpus": f"{len(HOST_CPUS)} CPUs of one NUMA node ({HOST_CPUS[0]}..{HOST_CPUS[-1]})" if HOST_CPUS else "unconfined"},
         "forward_only": {"value": round(fwd_rate, 1), "unit": "rays*samples/s", "ms": round(fwd_ms, 4)},
         "roofline": roofline, "kernels": kernels,
     }

@@ -308,6 +308,35 @@ def sequential_reference_samples(cfg, H, W, rays_per_kf, plans: List[FramePlan])
 
 
 # ======================================================================================================= the loop
+def _matrix_to_quaternion_np(R):
+    """geometry_helper.matrix_to_quaternion for ONE 3x3 in numpy fp32 scalars (same operations, same order)."""
+    f32 = np.float32
+    a, b, c, d, e, f, g, h, i = (f32(v) for v in R.reshape(9))
+    one = f32(1.0)
+    mag2 = [one + a + e + i, one + a - e - i, one - a + e - i, one - a - e + i]
+    mag = [np.sqrt(m) if m > 0 else f32(0.0) for m in mag2]
+    table = ((mag[0] * mag[0], h - f, c - g, d - b), (h - f, mag[1] * mag[1], d + b, c + g),
+             (c - g, d + b, mag[2] * mag[2], f + h), (d - b, g + c, h + f, mag[3] * mag[3]))
+    best = int(np.argmax(np.array(mag, dtype=np.float32)))
+    den = f32(2.0) * max(mag[best], f32(0.1))
+    q = np.array([t / den for t in table[best]], dtype=np.float32)
+    return -q if q[0] < 0 else q
+
+
+def _qt_to_matrix_np(qt):
+    """geometry_helper.qt_to_transform_matrix for ONE (w, x, y, z, tx, ty, tz) in numpy fp32 scalars -> [4,4] fp32."""
+    f32 = np.float32
+    w, x, y, z = (f32(v) for v in qt[:4])
+    k = f32(2.0) / (w * w + x * x + y * y + z * z)
+    one = f32(1.0)
+    T = np.eye(4, dtype=np.float32)
+    T[0, :3] = (one - k * (y * y + z * z), k * (x * y - z * w), k * (x * z + y * w))
+    T[1, :3] = (k * (x * y + z * w), one - k * (x * x + z * z), k * (y * z - x * w))
+    T[2, :3] = (k * (x * z - y * w), k * (y * z + x * w), one - k * (x * x + y * y))
+    T[:3, 3] = qt[4:7]
+    return T
+
+
 def frame_rays(frame):
     """[H*W, 7] rows [direction | rgb | depth] of one frame (mipsfusion.py:296-297)."""
     return torch.cat([frame["direction"], frame["rgb"], frame["depth"][..., None]], -1).reshape(-1, 7)
@@ -386,6 +415,10 @@ class GraphedSequence:
         if sampler == "reference":
             self.producer = ReferenceSampleProducer(cfg, H, W, self.R, self.Kmax, slots=self.lookahead + 2)
         self.capture_ms = 0.0
+        self._qt_host = torch.zeros(16, 7, dtype=torch.float32)
+        if torch.cuda.is_available():
+            self._qt_host = self._qt_host.pin_memory()
+        self._qt_next = 0
 
     # ------------------------------------------------------------------------------------- captured iterations
     def _ba_step_fn(self, n):
@@ -473,15 +506,23 @@ class GraphedSequence:
     def _set_pose(self, rot, trans, slot, pose):
         """pose: CPU [4,4].  The 4x4 <-> (quaternion, translation) conversions of the loop run on the HOST (a dozen tiny
         device launches each otherwise); two 16-byte uploads hand the result over."""
+        # ... in numpy fp32 scalars, not torch: every torch call drops and re-takes the GIL, and while the sample
+        # producer's python stage works each re-take queues behind it (30 tiny torch ops: 0.15 -> 5 ms, see
+        # ReferenceSampleProducer).  Same operations in the same order as geometry_helper.matrix_to_quaternion.
         with torch.no_grad():
-            pose = pose.detach().to("cpu", torch.float32)
-            rot[slot].copy_(matrix_to_quaternion(pose[None, :3, :3])[0], non_blocking=True)
-            trans[slot].copy_(pose[:3, 3], non_blocking=True)
+            R = pose.detach().to("cpu", torch.float32).numpy()
+            self._qt_next = (self._qt_next + 1) % self._qt_host.shape[0]      # ring of pinned staging rows: no wait
+            stage = self._qt_host[self._qt_next]
+            h = stage.numpy()
+            h[:4] = _matrix_to_quaternion_np(R[:3, :3])
+            h[4:] = R[:3, 3]
+            rot[slot].copy_(stage[:4], non_blocking=True)
+            trans[slot].copy_(stage[4:], non_blocking=True)
 
     def _get_pose(self, rot, trans, slot):
         """-> CPU [4,4] of the optimised (quaternion, translation) in `slot` (one 28-byte read-back)."""
-        qt = torch.cat([rot.detach()[slot], trans.detach()[slot]]).cpu()
-        return qt_to_transform_matrix(qt[None, :4], qt[None, 4:])[0]
+        qt = torch.cat([rot.detach()[slot], trans.detach()[slot]]).cpu().numpy()
+        return torch.from_numpy(_qt_to_matrix_np(qt))
 
     def _add_keyframe(self, pose):
         self.db.store(self.n_kf, self.cur.view(self.H, self.W, 7)[self.kf_rows, self.kf_cols])
@@ -533,6 +574,8 @@ class GraphedSequence:
             self.ro.capture(self.model, self.cfg["tracking"]["iter_RO"], self.stream)
             torch.cuda.synchronize()
             self.capture_ms += (time.perf_counter() - t0) * 1e3
+        # one-off lazy initialisations (the first torch._foreach_zero_ takes 65 ms) belong to the set-up, not to frame 1
+        self.go_popt.reset(), self.ba_popt.reset()
         torch.cuda.synchronize()
         return pose0
 
@@ -572,7 +615,10 @@ class GraphedSequence:
                 if k + self.lookahead < n_frames:
                     self.producer.submit(self._plan(k + self.lookahead))     # `lookahead` frames ahead of the GPU
             prev = est[-1]                                                   # poses live on the host (4x4 algebra there)
-            init = prev if len(est) < 2 else prev @ torch.linalg.inv(est[-2]) @ prev   # constant velocity
+            if len(est) < 2:
+                init = prev
+            else:                                                            # constant velocity, in numpy (see _set_pose)
+                init = torch.from_numpy(prev.numpy() @ np.linalg.inv(est[-2].numpy()) @ prev.numpy())
             if self.graph_ro:
                 pose = self.ro.optimize_graphed(self.cur[:, 6], init, waiting=waiting)
             else:
@@ -653,12 +699,10 @@ def summarise(res, gt_poses, cfg, launch):
            "ate_max_m": round(max(err), 4)}
     if res.get("detail_ms"):
         out["detail_ms_mean"] = {k: round(float(np.mean(v)), 3) for k, v in res["detail_ms"].items() if len(v) and k != "go_fill_parts_ms"}
-        out["go_fill_parts_ms_all"] = res["detail_ms"].get("go_fill_parts_ms")
         out["frame_ms_all"] = [round(float(t), 2) for t in fm]
-        out["ro_go_ms_all"] = [[round(float(a), 2), round(float(b), 2)] for a, b in zip(res["ro_ms"], res["go_ms"])]
-        out["go_fill_ms_all"] = [round(float(t), 2) for t in res["detail_ms"]["go_fill_ms"]]
-        out["go_launch_ms_all"] = [round(float(t), 2) for t in res["detail_ms"]["go_launch_ms"]]
-        out["go_gpu_ms_all"] = [round(float(t), 2) for t in res["detail_ms"]["go_gpu_ms"]]
+        if os.environ.get("MIPSF_SEQ_VERBOSE"):
+            out["ro_go_ms_all"] = [[round(float(a), 2), round(float(b), 2)] for a, b in zip(res["ro_ms"], res["go_ms"])]
+            out["go_fill_parts_ms_all"] = res["detail_ms"].get("go_fill_parts_ms")
     if res.get("producer_host_ms"):
         n = max(1, len(res["frame_ms"]))
         out["producer_host_ms_per_frame"] = {k: round(v / n, 3) for k, v in res["producer_host_ms"].items()}

@@ -40,6 +40,14 @@ def _usable_cores():
     return max(1, n)
 
 
+import importlib.util  # noqa: E402  (by path: importing the package would import torch before OMP_NUM_THREADS is set)
+
+_spec = importlib.util.spec_from_file_location("mipsf_hostcpu", os.path.join(os.path.dirname(os.path.dirname(
+    os.path.abspath(__file__))), "mipsfusion_amd", "hostcpu.py"))
+_hostcpu = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_hostcpu)
+if not os.environ.get("MIPSF_NO_CONFINE"):
+    _hostcpu.confine_to_numa_node(32)
 os.environ.setdefault("OMP_NUM_THREADS", str(_usable_cores()))      # see bench.py: the hosts report 256 cores, grant 16
 import torch  # noqa: E402
 
