@@ -1077,6 +1077,54 @@ def test_autograd_grad_and_partial_backward_with_trainable_params(dev):
         assert_grad_close(q.grad, p.grad, 1e-6, "in-place accumulation vs autograd path")
 
 
+def test_route_ahead_on_second_stream_gives_identical_gradients(dev, monkeypatch):
+    """JointEncoding.route_ahead (opt-in): the routing half of the hash grid's backward runs on a second stream next to
+    the forward (mipsf_hashgrid_route + mipsf_hashgrid_bwd_routed instead of mipsf_hashgrid_bwd).  Same kernels on the
+    same data: every gradient must equal the single-stream path's (to the run-to-run noise of the scatter's atomics),
+    eagerly and inside a captured graph."""
+    from mipsfusion_amd.model import scene_rep
+    monkeypatch.setattr(scene_rep, "_ROUTE_AHEAD_MIN_M", 0)
+    g = load_golden("scene_cfg1.npz")
+    cfg = cfg_for("scene_cfg1.npz")
+    inputs = [T(g[k]).to(dev) for k in ("rays_o", "rays_d", "target_rgb", "target_d", "noise")]
+
+    def grads(route_ahead):
+        m = make_scene(g, cfg, dev).train()
+        m.route_ahead = route_ahead
+        ret = m.forward(*inputs[:4], noise=inputs[4])
+        path_cpu.total_loss(ret, cfg["training"]).backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in m.parameters() if p.numel()]
+
+    ref, ahead = grads(False), grads(True)
+    assert float(ref[0].abs().max()) > 0
+    for a, b in zip(ahead, ref):       # (fp64 LDS atomics: the order of additions may differ in the last fp32 bit run to run)
+        assert_grad_close(a, b, 1e-6, "route-ahead vs single-stream")
+    # captured: the second stream forks from and re-joins the capturing stream inside the forward
+    m = make_scene(g, cfg, dev).train()
+    m.route_ahead = True
+    m.accumulate_param_grads_in_place = True
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        def step():
+            ret = m.forward(*inputs[:4], noise=inputs[4])
+            path_cpu.total_loss(ret, cfg["training"]).backward()
+        step()                                                     # allocator warm-up
+        for prm in m.parameters():
+            prm.grad = None
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            step()
+        for prm in m.parameters():
+            if prm.grad is not None:
+                prm.grad.zero_()
+        graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip([p.grad for p in m.parameters() if p.numel()], ref):
+        assert_grad_close(a, b, 1e-6, "captured route-ahead vs single-stream")
+
+
 def test_out_of_range_ray_index_is_loud(dev):
     """a bad keyframe id must not become a silent out-of-bounds read -- host index tensors raise
     IndexError like the reference's torch indexing, device-resident indices yield NaN rays."""

@@ -229,3 +229,49 @@ def test_sample_producer_reproduces_the_sequential_index_stream(iter_ro):
         t.join(10)
     assert torch.equal(torch.get_rng_state(), state_after[0]) and random.getstate() == state_after[1], \
         "both generators must end where the sequential program leaves them"
+
+
+def test_numa_confinement_picks_a_subset_of_the_allowed_cpus():
+    """mipsfusion_amd.hostcpu: the chosen CPUs are allowed ones, at most max_cpus, of one node; ranks get disjoint sets."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import os, json, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from mipsfusion_amd import hostcpu\n"
+        "allowed = sorted(os.sched_getaffinity(0))\n"
+        "nodes = hostcpu.numa_nodes()\n"
+        "r, w = int(sys.argv[1]), int(sys.argv[2])\n"
+        "chosen = hostcpu.confine_to_numa_node(2, r, w)\n"
+        "print(json.dumps({'allowed': allowed, 'chosen': chosen, 'now': sorted(os.sched_getaffinity(0)), 'nodes': [sorted(n) for n in nodes]}))\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import json
+    outs = []
+    for r in (0, 1):
+        o = json.loads(subprocess.run([sys.executable, "-c", code, str(r), "2"], capture_output=True, text=True, check=True).stdout)
+        outs.append(o)
+        if o["chosen"] is not None:
+            assert 1 <= len(o["chosen"]) <= 2 and set(o["chosen"]) <= set(o["allowed"]) and o["now"] == sorted(o["chosen"])
+            assert any(set(o["chosen"]) <= set(n) for n in o["nodes"]), "CPUs of more than one NUMA node"
+    if all(o["chosen"] is not None for o in outs) and len(outs[0]["allowed"]) >= 4:
+        assert not set(outs[0]["chosen"]) & set(outs[1]["chosen"]), "two ranks on the same CPUs"
+
+
+def test_host_pose_algebra_in_numpy_equals_the_torch_helpers():
+    """GraphedSequence converts poses on the host in numpy fp32 scalars (no GIL hand-overs per tiny torch op); same
+    operations in the same order as geometry_helper's torch functions -> equal to the last bit, up to the order of the
+    4-term quaternion norm (<= 1 ulp)."""
+    from mipsfusion_amd.sequence import _matrix_to_quaternion_np, _qt_to_matrix_np
+    gen = torch.Generator().manual_seed(0)
+    worst = 0.0
+    for _ in range(300):
+        q = torch.randn(4, generator=gen)
+        q = q / q.norm()
+        t = torch.randn(3, generator=gen)
+        T_ref = gh.qt_to_transform_matrix(q[None], t[None])[0]
+        T_np = torch.from_numpy(_qt_to_matrix_np(torch.cat([q, t]).numpy()))
+        q_ref = gh.matrix_to_quaternion(T_ref[None, :3, :3])[0]
+        q_np = torch.from_numpy(_matrix_to_quaternion_np(T_ref[:3, :3].numpy()))
+        worst = max(worst, float((T_np - T_ref).abs().max()), float((q_np - q_ref).abs().max()))
+    assert worst <= 2.4e-7, worst
