@@ -601,6 +601,20 @@ def test_pose_rays_matches_torch_composition(dev):
         ro4, rd4 = ops.pose_rays(rot_s, trans_s, fixed, owner[:70], d_cam[:70])
         (ro4 * go[:70]).sum().add((rd4 * gd[:70]).sum()).backward()
         assert torch.isfinite(rot_s.grad).all()
+    # above 16 384 rays the backward is the multi-workgroup kernel (per-workgroup partial rows + ticket)
+    Nb = 40000
+    owner_b = torch.randint(0, F + K, (Nb,), device=dev)
+    owner_b[:20000] = torch.arange(20000, device=dev) // 2000 % (F + K)         # long uniform stretches
+    d_b, go_b, gd_b = torch.randn(Nb, 3, device=dev), torch.randn(Nb, 3, device=dev), torch.randn(Nb, 3, device=dev)
+    for _ in range(2):
+        rot_m, trans_m = rot0.clone().requires_grad_(True), trans0.clone().requires_grad_(True)
+        ro5, rd5 = ops.pose_rays(rot_m, trans_m, fixed, owner_b, d_b)
+        (ro5 * go_b).sum().add((rd5 * gd_b).sum()).backward()
+        rot_n, trans_n = rot0.clone().requires_grad_(True), trans0.clone().requires_grad_(True)
+        poses_n = torch.cat([fixed, qt_to_transform_matrix(rot_n, trans_n)], 0)
+        ((poses_n[owner_b, :3, -1] * go_b).sum() + (torch.sum(d_b[..., None, :] * poses_n[owner_b, :3, :3], -1) * gd_b).sum()).backward()
+        assert_close(rot_m.grad, rot_n.grad, 5e-5, "d quaternion, 40 000 rays")
+        assert_close(trans_m.grad, trans_n.grad, 5e-5, "d translation, 40 000 rays")
     # and the chain alone against the reference's own autograd (golden)
     rot_c, trans_c = T(g["rot"]).to(dev).requires_grad_(True), T(g["trans"]).to(dev).requires_grad_(True)
     eye = torch.eye(3, device=dev)
