@@ -91,11 +91,12 @@ KERNEL_COST = {
     "hashgrid_fwd": ("hbm", 1164.0 + 384.0, "f32", None),   # 8 corners x 16 levels gathered + features out + Jacobian out
     "hashgrid_bwd": ("hbm", 2188.0, "f32+f64 LDS", None),   # scatter: x + dL/dy + read-modify-write of the touched entries
     "hashgrid_dx": ("hbm", 536.0, "f32", None),             # saved Jacobian (384) + dL/dy (128) + dx read-modify-write (24)
-    "decoder_fwd": ("hbm", 12.0 + 128.0 + 40.0 + 1536.0 + 32.0, "f16x3 (f16 MFMA on hi/lo split operands, fp32 accumulate)", 3),
+    # lean activation record: H2 + H3 (1024 B) + ReLU masks; H1 is recomputed by the weight-gradient kernel
+    "decoder_fwd": ("hbm", 12.0 + 128.0 + 40.0 + 1024.0 + 32.0, "f16x3 (f16 MFMA on hi/lo split operands, fp32 accumulate)", 3),
     "decoder_bwd_chain": ("hbm", 40.0 + 40.0 + 32.0 + 12.0 + 1536.0 + 32.0 + 128.0 + 12.0,
                           "f16x3 (f16 MFMA on hi/lo split operands, fp32 accumulate)", 3),
-    # streaming kernel (csrc/wgrad16.hip): reads both activation records once -- 3.2 KB per sample against 0.22 MFLOP
-    "decoder_wgrad": ("hbm", 1536.0 + 1536.0 + 32.0 + 128.0 + 12.0,
+    # streaming kernel (csrc/wgrad16.hip): reads H2, H3 and the gradient record once (H1 recomputed) -- 2.7 KB per sample
+    "decoder_wgrad": ("hbm", 1024.0 + 1536.0 + 32.0 + 128.0 + 12.0,
                       "f16x3 (f16 MFMA on hi/lo split operands under per-block power-of-two scales, fp32 accumulate)", 3),
     "sample_rays": ("hbm", 20.0, "f32+f64", None),
     "render_fwd": ("hbm", 44.0, "f32", None),

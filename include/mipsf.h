@@ -152,6 +152,11 @@ uint32_t mipsf_decoder_packed16_floats(void);
 int mipsf_decoder_pack16(const mipsf_decoder_weights* w_host_struct, float* packed16, void* stream);
 int mipsf_decoder_fwd16(const float* packed16, const float* feat, int feat_layout, const float* x, float* out,
                         float* saved, int sdf_only, int precision, uint32_t M, void* stream);
+/* lean_record != 0 (f16x3 with `saved` only): the record keeps H2, H3 and the ReLU masks but NOT H1 -- a third of the
+ * record's bytes; valid when the weight gradients come from mipsf_decoder_wgrad16 with `packed16` given (it recomputes H1
+ * from x); the backward chain never reads H1.  The buffer keeps its size and layout (the H1 pieces stay unwritten). */
+int mipsf_decoder_fwd16_ex(const float* packed16, const float* feat, int feat_layout, const float* x, float* out,
+                           float* saved, int sdf_only, int precision, int lean_record, uint32_t M, void* stream);
 /* mipsf_decoder_bwd_chain on the f16 matrix cores (hi/lo split operands, fp32 accumulate; pe_mode 0 only): the same
  * outputs and the same `dact` record, so mipsf_decoder_wgrad follows it unchanged.  saved: as written by
  * mipsf_decoder_fwd / _fwd16 (only the ReLU masks are read). */
@@ -192,6 +197,12 @@ int mipsf_decoder_wgrad_ex(const float* feat, int feat_layout, const float* x, c
 int mipsf_decoder_wgrad16(const float* feat, int feat_layout, const float* x, const float* saved, const float* dact,
                           const mipsf_decoder_grads* grads_host_struct, float* partial, int arithmetic, uint32_t M,
                           void* stream);
+/* packed16 != NULL (MIPSF_PREC_F16X3 only): H1 is not read from `saved` but RECOMPUTED from x with the forward's own
+ * layer-1 operand images (bit-identical to what the forward computed) -- the companion of the lean record of
+ * mipsf_decoder_fwd16_ex.  packed16 == NULL: mipsf_decoder_wgrad16. */
+int mipsf_decoder_wgrad16_ex(const float* packed16, const float* feat, int feat_layout, const float* x, const float* saved,
+                             const float* dact, const mipsf_decoder_grads* grads_host_struct, float* partial,
+                             int arithmetic, uint32_t M, void* stream);
 
 /* -------------------------------------------------- sample placement (a3 + a4) */
 typedef struct mipsf_render_cfg {

@@ -154,7 +154,9 @@ __device__ __forceinline__ void mfma16_layer(const Img img, int lane, int h, f32
 }
 
 // one wave, one tile of 32 samples.  tail: fp32 head tables (LDS); img_hi / img_lo: the two operand image sets
-template <int LAYOUT, bool SAVE, bool SDF_ONLY, bool SPLIT, typename Img>
+// SAVE: 0 no record, 1 the full activation record, 2 the LEAN record -- H2, H3 and the ReLU masks; H1 (a third of the
+// record) is left out: the streaming weight-gradient kernel recomputes it from x (wgrad16.hip) and nothing else reads it
+template <int LAYOUT, int SAVE, bool SDF_ONLY, bool SPLIT, typename Img>
 __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img img,
                                                    const float* __restrict__ feat, const float* __restrict__ x,
                                                    float* __restrict__ out, float* __restrict__ saved, uint32_t M,
@@ -199,7 +201,7 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
             split8<SPLIT>(v, bh, bl);
         },
         [&](int t) {
-            if constexpr (SAVE) {
+            if constexpr (SAVE == 1) {
                 store_act_piece(sv, lane16, 0, H1, 2 * t);
                 store_act_piece(sv, lane16, 0, H1, 2 * t + 1);
             }
@@ -339,7 +341,7 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
 }
 
 // Small batches: four independent waves per workgroup, operand images from L2, head tables + biases in LDS.
-template <int LAYOUT, bool SAVE, bool SDF_ONLY, bool SPLIT>
+template <int LAYOUT, int SAVE, bool SDF_ONLY, bool SPLIT>
 __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_fwd_kernel(const float* __restrict__ packed16,
                                                                      const float* __restrict__ feat,
                                                                      const float* __restrict__ x,
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_fwd_kernel(const float
 constexpr int F16_LDS_BLOCK = 512;
 template <bool SPLIT>
 constexpr int f16_lds_bytes() { return TAIL_FLOATS * 4 + IMG16H_HALVES * 2 + (SPLIT ? IMG16L_HALVES * 2 : 0); }
-template <int LAYOUT, bool SAVE, bool SDF_ONLY, bool SPLIT>
+template <int LAYOUT, int SAVE, bool SDF_ONLY, bool SPLIT>
 __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_fwd_lds_kernel(const float* __restrict__ packed16,
                                                                              const float* __restrict__ feat,
                                                                              const float* __restrict__ x,
@@ -695,8 +697,14 @@ int mipsf_decoder_pack16(const mipsf_decoder_weights* w, float* packed16, void* 
 
 int mipsf_decoder_fwd16(const float* packed16, const float* feat, int feat_layout, const float* x, float* out,
                         float* saved, int sdf_only, int precision, uint32_t M, void* stream) {
+    return mipsf_decoder_fwd16_ex(packed16, feat, feat_layout, x, out, saved, sdf_only, precision, 0, M, stream);
+}
+
+int mipsf_decoder_fwd16_ex(const float* packed16, const float* feat, int feat_layout, const float* x, float* out,
+                           float* saved, int sdf_only, int precision, int lean_record, uint32_t M, void* stream) {
     if (M == 0) return 0;
     MIPSF_REQUIRE(packed16 && feat && x && out, "null pointer");
+    MIPSF_REQUIRE(!lean_record || (saved && precision == MIPSF_PREC_F16X3), "the lean record belongs to the f16x3 training forward");
     MIPSF_REQUIRE(feat_layout == MIPSF_FEAT_AOS || feat_layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout");
     MIPSF_REQUIRE(precision == MIPSF_PREC_F16X3 || precision == MIPSF_PREC_F16, "precision must be f16x3 or f16");
     MIPSF_REQUIRE(!(sdf_only && saved), "the SDF-only forward keeps no activations");
@@ -731,9 +739,10 @@ int mipsf_decoder_fwd16(const float* packed16, const float* feat, int feat_layou
     } while (0)
 #define F16_MODE(LAY, SPL)                                  \
     do {                                                    \
-        if (sdf_only) F16(LAY, false, true, SPL);           \
-        else if (saved != nullptr) F16(LAY, true, false, SPL); \
-        else F16(LAY, false, false, SPL);                   \
+        if (sdf_only) F16(LAY, 0, true, SPL);               \
+        else if (saved != nullptr && lean_record) F16(LAY, 2, false, true); \
+        else if (saved != nullptr) F16(LAY, 1, false, SPL); \
+        else F16(LAY, 0, false, SPL);                       \
     } while (0)
     if (feat_layout == MIPSF_FEAT_AOS) {
         if (precision == MIPSF_PREC_F16X3) F16_MODE(MIPSF_FEAT_AOS, true); else F16_MODE(MIPSF_FEAT_AOS, false);

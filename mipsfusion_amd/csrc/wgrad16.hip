@@ -200,6 +200,8 @@ struct W16Args {
     const float* __restrict__ dsmall;
     float* __restrict__ rec;            // this block's partial record
     uint32_t M, n_tiles;
+    const h8* w1_hi;                    // LDS copies of the forward's layer-1 operand images (recompute variant), else null
+    const h8* w1_lo;
 };
 
 // column of the e products: slot t = 16 ct + 8 (c >> 4) + 4 ((c >> 3) & 1) + (c & 3), half (c >> 2) & 1
@@ -409,6 +411,171 @@ __device__ __forceinline__ void w16_role_a(const W16Args& a, const typename A::v
     }
 }
 
+// Role A of the LEAN record (mipsf_decoder_fwd16_ex: H1 is not stored).  H1 is RECOMPUTED, directly in the layout the product
+// wants: the forward evaluates H1^T = W1 e^T with the weight image as A operand; with the operands swapped the same
+// instruction yields H1 = e W1^T -- lane = feature, registers = 16 samples -- from the SAME image (an A-operand image of
+// W1's rows is a B-operand image of W1^T's columns) and the same e operands, products in the same order: the forward's H1,
+// bit for bit, 12 MFMAs per 32 features instead of a 4 KB load + 4 transposing MFMAs.  The images (hi + lo, 32 KB) sit in
+// LDS.  Every load of a tile has its own buffer and is issued a whole tile ahead.
+template <int LAYOUT, typename A>
+__device__ __forceinline__ void w16_role_a_recompute(const W16Args& a, const typename A::v8 (&I)[2], int w, int lane) {
+    static_assert(A::SCALED && A::P == 2, "f16 hi/lo arithmetic only");
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t lane16 = 16u * (uint32_t)lane;
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) zero_tile(acc[t]);
+    float bsum = 0.f, bsmall = 0.f, dummy = 0.f;
+    int k_main = 0, k_small = 0;
+    auto act_srd = [&](const float* recs, uint32_t tile) {
+        return make_srd(recs + (size_t)tile * ACT_TILE_FLOATS, ACT_TILE_FLOATS * 4);
+    };
+    const srd_t small_srd = make_srd(a.dsmall, a.M * 32u), x_srd = make_srd(a.x, a.M * 12u);
+    auto load_small = [&](uint32_t tile, f32x8 (&v)[2]) {
+        const uint32_t off = h == 0 ? (tile * 32u + (uint32_t)j) * 32u : 0xfffffff0u;
+        const float4 p = buf_load16(small_srd, off, 0), q = buf_load16(small_srd, off, 16);
+        v[0][0] = p.x, v[0][1] = p.y, v[0][2] = p.z, v[0][3] = p.w, v[0][4] = q.x, v[0][5] = q.y, v[0][6] = q.z, v[0][7] = q.w;
+    };
+    auto load_x = [&](uint32_t tile, float (&v)[3]) {
+        const uint32_t s_raw = tile * 32u + (uint32_t)j;
+        const uint32_t off = (s_raw < a.M ? s_raw : a.M - 1) * 12u;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) v[d] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_srd, off, 4 * d, 0));
+    };
+    f32x8 bX[2], bS[2], bH3[2], bE[2];
+    float xv[3];
+    uint32_t it = blockIdx.x;
+    if (it < a.n_tiles) {
+        const uint32_t t0 = a.n_tiles - 1 - it;
+        load_tile_rows(act_srd(a.dact, t0), 1, w, lane16, bX);
+        load_x(t0, xv);
+        load_small(t0, bS);
+        load_tile_rows(act_srd(a.saved, t0), 2, w, lane16, bH3);
+        load_tile_rows(act_srd(a.saved, t0), 1, 2 + (w & 1), lane16, bE);
+    }
+#pragma clang loop unroll(disable)
+    for (; it < a.n_tiles; it += gridDim.x) {
+        const uint32_t tile = a.n_tiles - 1 - it;
+#ifndef W16_NO_TILE_BARRIER
+        __builtin_amdgcn_s_barrier();
+#endif
+        const uint32_t nt = it + gridDim.x < a.n_tiles ? tile - gridDim.x : tile;
+        const srd_t nsa = act_srd(a.saved, nt);
+        const float x0 = xv[0], x1 = xv[1], x2 = xv[2];
+        typename A::v8 X[2][2];
+        // ---- the small-row products first: their three buffers are free again before the long H1 phase starts
+        f32x8 sv1[2], sv2[2];
+        {
+            float rs;
+            const float sx = w16_pick_scale(w16_block_max_bits(bS, 1), k_small, rs);
+            if (rs != 1.0f) acc[4] *= rs, bsmall *= rs;
+            bS[0] *= sx;
+        }
+        sv1[0] = bS[0], sv2[0] = bS[0], sv1[1] = bS[0], sv2[1] = bS[0];
+        transpose_block<A, true, 1>(sv1, I, X, bsmall);                             // X = small rows (columns 0..11)
+        W16_FENCE();
+        transpose_mac<A>(bH3, I, X, acc[4]);                                        // H3[w] -> rows 0..15
+        transpose_block<A, false, 1>(sv2, I, X, dummy, 1);                          // the small rows at columns 16..27
+        W16_FENCE();
+        if (w < 2) {
+            transpose_mac<A>(bE, I, X, acc[4]);                                     // rgb_emb (waves 0, 1)
+        } else {
+            f32x8 ev[2];
+            if (w == 2) w16_e_tile<0>(x0, x1, x2, h, ev);
+            else w16_e_tile<1>(x0, x1, x2, h, ev);
+            transpose_mac<A>(ev, I, X, acc[4]);                                     // e (waves 2, 3)
+        }
+        W16_FENCE();
+        // ---- X = dH2[w]
+        {
+            float rs;
+            const float sx = w16_pick_scale(w16_block_max_bits(bX, 2), k_main, rs);
+            if (rs != 1.0f) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] *= rs;
+                bsum *= rs;
+            }
+            bX[0] *= sx, bX[1] *= sx;
+        }
+        transpose_block<A, true>(bX, I, X, bsum);
+        W16_FENCE();
+        // ---- e as the forward's layer-1 operand: 4 k-steps of 8 slots per half, bias ones in slots 26, 27
+        typename A::v8 eh[4], el[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {            // one k-step at a time (pinned: 24 interleaved sines need 60 temporaries)
+            f32x8 ev;
+            if (t < 3) {
+                const float xd = t == 0 ? x0 : (t == 1 ? x1 : x2);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ev[k] = sin_reduced(fmaf(ldexpf(xd, k), PI_F, h ? HALF_PI_F : 0.0f));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ev[k] = 0.0f;
+                ev[0] = h ? x1 : x0, ev[1] = h ? 0.0f : x2;                  // slots 24, 25: the raw coordinates
+                ev[BIAS16_U] = 1.0f, ev[BIAS16_U + 1] = 1.0f;                // slots 26, 27 meet the bias halves of the image
+            }
+            eh[t] = next_plane<A, false>(ev), el[t] = next_plane<A, true>(ev);
+            asm volatile("" : "+v"(eh[t]), "+v"(el[t]));
+            W16_FENCE();
+        }
+        // the next tile's small-row operands have the whole H1 phase to arrive
+        load_small(nt, bS);
+        load_tile_rows(nsa, 2, w, lane16, bH3);
+        load_tile_rows(nsa, 1, 2 + (w & 1), lane16, bE);
+        W16_FENCE();
+        // ---- H1 column tiles, recomputed, multiplied at once
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            f32x16 hacc = zero;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const h8 wh = a.w1_hi[(ct * T16H_F1 + t) * 64 + lane], wl = a.w1_lo[(ct * T16_F1 + t) * 64 + lane];
+                hacc = mfma16(eh[t], wh, hacc);
+                hacc = mfma16(el[t], wh, hacc);
+                hacc = mfma16(eh[t], wl, hacc);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {                   // (k-step by k-step: one pair of operand planes alive)
+                f32x8 r;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    r[u] = __builtin_amdgcn_fmed3f(hacc[8 * m + u] * (1.0f / (float)(1 << W16_SHIFT)), 0.0f, __builtin_inff());
+                const typename A::v8 yh = next_plane<A, false>(r);
+                const typename A::v8 yl = next_plane<A, true>(r);
+                acc[ct] = mfma16(X[0][m], yh, acc[ct]);
+                acc[ct] = mfma16(X[1][m], yh, acc[ct]);
+                acc[ct] = mfma16(X[0][m], yl, acc[ct]);
+            }
+            W16_FENCE();
+        }
+        // the next tile's dH2 and coordinates: needed after its small-row stages
+        load_tile_rows(act_srd(a.dact, nt), 1, w, lane16, bX);
+        load_x(nt, xv);
+        W16_FENCE();
+    }
+    float* rec = a.rec;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+        flush_mapped(rec, G_W_PTS2, HID, lane, acc[ct], w16_unscale(k_main), [&](int i) { return 32 * w + i; }, [&](int c) { return 32 * ct + c; });
+    flush_mapped(rec, G_W_SDF2, HID, lane, acc[4], w16_unscale(k_small),
+                 [&](int i) { const int r = w16_small_row(i); return r < N_CLASS ? r : -1; }, [&](int c) { return 32 * w + c; });
+    auto rgb_row = [&](int i) { const int r = i >= 16 ? w16_small_row(i - 16) : -1; return r >= N_CLASS ? r - N_CLASS : -1; };
+    if (w < 2)
+        flush_mapped(rec, G_W_RGB0, N_RGB_IN, lane, acc[4], w16_unscale(k_small), rgb_row, [&](int c) { return 32 * w + c; });
+    else
+        flush_mapped(rec, G_W_RGB0, N_RGB_IN, lane, acc[4], w16_unscale(k_small), rgb_row,
+                     [&](int c) { const int e = w16_e_col(w - 2, c); return e >= 0 ? N_EMB + e : -1; });
+    const float b2 = (bsum + __shfl_xor(bsum, 32, 64)) * w16_unscale(k_main);
+    if (h == 0) rec[G_B_PTS2 + 32 * w + j] = b2;
+    if (w == 0) {
+        const float bs = (bsmall + __shfl_xor(bsmall, 32, 64)) * w16_unscale(k_small);
+        const int r = w16_small_row(j);
+        if (h == 0 && r >= 0 && r < N_CLASS) rec[G_B_SDF2 + r] = bs;
+        if (h == 0 && r >= N_CLASS) rec[G_B_RGB0 + r - N_CLASS] = bs;
+    }
+}
+
 // waves 4..7 (row tile rt): d w_sdf0[rt][0..2] = dG3[rt]^T [sdf_emb | grid], d b_sdf0;  d w_pts0[rt][0..1] = dG1[rt]^T e,
 // d b_pts0 (e recomputed from x)
 template <int LAYOUT, typename A>
@@ -527,8 +694,9 @@ __device__ __forceinline__ void w16_role_b(const W16Args& a, const typename A::v
     if (h == 0) rec[G_B_SDF0 + 32 * rt + j] = b3, rec[G_B_PTS0 + 32 * rt + j] = b1;
 }
 
-template <int LAYOUT, typename A>
-__global__ __launch_bounds__(W16_BLOCK, 2) void decoder_wgrad16_kernel(const float* __restrict__ feat,
+template <int LAYOUT, typename A, bool RECOMP>
+__global__ __launch_bounds__(W16_BLOCK, 2) void decoder_wgrad16_kernel(const float* __restrict__ packed16,
+                                                                       const float* __restrict__ feat,
                                                                        const float* __restrict__ x,
                                                                        const float* __restrict__ saved,
                                                                        const float* __restrict__ dact,
@@ -545,9 +713,25 @@ __global__ __launch_bounds__(W16_BLOCK, 2) void decoder_wgrad16_kernel(const flo
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             I[q][u] = (j == 16 * q + 8 * (u >> 2) + 4 * h + (u & 3)) ? (typename A::elt)1.0f : (typename A::elt)0.0f;
-    const W16Args a = {feat, x, saved, dact, dsmall, partial + (size_t)blockIdx.x * G_STRIDE, M, n_tiles};
-    if (w < 4) w16_role_a<LAYOUT, A>(a, I, w, lane);
-    else w16_role_b<LAYOUT, A>(a, I, w - 4, lane);
+    constexpr int W1_ENTRIES = RT_F1 * T16H_F1 * 64;          // 16-byte operands of one layer-1 image (hi; lo has as many)
+    static_assert(T16H_F1 == T16_F1, "layer 1 has no separate bias k-step");
+    __shared__ h8 w1img[RECOMP ? 2 * W1_ENTRIES : 1];
+    if constexpr (RECOMP) {
+        const h8* img = reinterpret_cast<const h8*>(packed16 + TAIL_FLOATS);
+        for (int q = tid; q < W1_ENTRIES; q += W16_BLOCK) {
+            w1img[q] = img[OFF16H_F1 / 8 + q];
+            w1img[W1_ENTRIES + q] = img[(IMG16H_HALVES + OFF16L_F1) / 8 + q];
+        }
+        __syncthreads();
+    }
+    const W16Args a = {feat, x, saved, dact, dsmall, partial + (size_t)blockIdx.x * G_STRIDE, M, n_tiles,
+                       RECOMP ? w1img : nullptr, RECOMP ? w1img + W1_ENTRIES : nullptr};
+    if (w < 4) {
+        if constexpr (RECOMP) w16_role_a_recompute<LAYOUT, A>(a, I, w, lane);
+        else w16_role_a<LAYOUT, A>(a, I, w, lane);
+    } else {
+        w16_role_b<LAYOUT, A>(a, I, w - 4, lane);
+    }
 }
 
 }  // namespace mipsf
@@ -557,7 +741,14 @@ using namespace mipsf;
 extern "C" int mipsf_decoder_wgrad16(const float* feat, int feat_layout, const float* x, const float* saved,
                                      const float* dact, const mipsf_decoder_grads* grads, float* partial, int arithmetic,
                                      uint32_t M, void* stream) {
+    return mipsf_decoder_wgrad16_ex(nullptr, feat, feat_layout, x, saved, dact, grads, partial, arithmetic, M, stream);
+}
+
+extern "C" int mipsf_decoder_wgrad16_ex(const float* packed16, const float* feat, int feat_layout, const float* x,
+                                        const float* saved, const float* dact, const mipsf_decoder_grads* grads,
+                                        float* partial, int arithmetic, uint32_t M, void* stream) {
     if (M == 0) return 0;
+    MIPSF_REQUIRE(packed16 == nullptr || arithmetic == MIPSF_PREC_F16X3, "H1 is recomputed by the f16x3 arithmetic only");
     MIPSF_REQUIRE(feat && x && saved && dact && partial && grads, "null pointer");
     MIPSF_REQUIRE(feat_layout == MIPSF_FEAT_AOS || feat_layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout");
     MIPSF_REQUIRE(arithmetic == MIPSF_PREC_F16X3 || arithmetic == MIPSF_PREC_BF16X6 || arithmetic == MIPSF_PREC_BF16X3,
@@ -571,10 +762,10 @@ extern "C" int mipsf_decoder_wgrad16(const float* feat, int feat_layout, const f
     if (cus <= 0) return 3;
     uint32_t blocks = n_tiles < (uint32_t)cus ? n_tiles : (uint32_t)cus;
     if (blocks > (uint32_t)W16_MAX_BLOCKS) blocks = (uint32_t)W16_MAX_BLOCKS;
-#define W16(LAY, AR) hipLaunchKernelGGL((decoder_wgrad16_kernel<LAY, AR>), dim3(blocks), dim3(W16_BLOCK), 0, s, feat, x, \
-                                        saved, dact, dsmall, partial, M, n_tiles)
-#define W16_L(LAY) do { if (arithmetic == MIPSF_PREC_F16X3) W16(LAY, ArF16); else if (arithmetic == MIPSF_PREC_BF16X6) W16(LAY, ArBF3); \
-                        else W16(LAY, ArBF2); } while (0)
+#define W16(LAY, AR, RC) hipLaunchKernelGGL((decoder_wgrad16_kernel<LAY, AR, RC>), dim3(blocks), dim3(W16_BLOCK), 0, s, packed16, \
+                                            feat, x, saved, dact, dsmall, partial, M, n_tiles)
+#define W16_L(LAY) do { if (arithmetic == MIPSF_PREC_F16X3) { if (packed16) W16(LAY, ArF16, true); else W16(LAY, ArF16, false); } \
+                        else if (arithmetic == MIPSF_PREC_BF16X6) W16(LAY, ArBF3, false); else W16(LAY, ArBF2, false); } while (0)
     if (feat_layout == MIPSF_FEAT_AOS) W16_L(MIPSF_FEAT_AOS); else W16_L(MIPSF_FEAT_LEVEL_MAJOR);
 #undef W16_L
 #undef W16

@@ -98,8 +98,12 @@ class _QueryFn(torch.autograd.Function):
             packed, packed16 = ops.decoder_pack(weights), None
         else:
             packed, packed16 = None, ops.decoder_pack16(weights)
-        out, saved = ops.decoder_fwd(packed, feat, FEAT_LEVEL_MAJOR, xn, None, M, save=need, precision=prec,
-                                     packed16=packed16)
+        # lean record: when the weight gradients will come from the streaming f16 kernel (the default behind the f16x3
+        # chain) H1 is recomputed there from x and the forward does not write it (a third of the record)
+        lean = bool(need and prec == "f16x3" and owner.wgrad_precision in ("auto", "stream_f16x3") and owner.lean_record)
+        out, saved = ops.decoder_fwd(packed, feat, FEAT_LEVEL_MAJOR, xn, None, M, save="lean" if lean else need,
+                                     precision=prec, packed16=packed16)
+        ctx.lean = lean
         if packed is None:
             packed = packed16
         ctx.prec = prec
@@ -132,7 +136,8 @@ class _QueryFn(torch.autograd.Function):
                     grads.append(torch.zeros_like(w))
         dfeat, dx, _ = ops.decoder_bwd(packed, feat, FEAT_LEVEL_MAJOR, xn, None, out, ops._f32c(dout), saved, grads,
                                        ctx.M, precision=ctx.prec, packed16=packed if ctx.prec != "f32" else None,
-                                       wgrad_precision=ctx.owner.wgrad_precision)
+                                       wgrad_precision="stream_f16x3" if ctx.lean else ctx.owner.wgrad_precision,
+                                       recompute_h1=ctx.lean)
         dparams = None
         if need_g:
             if direct:
@@ -201,6 +206,8 @@ class JointEncoding(nn.Module):
         # (The ~5e-6 arithmetics "bf16x3" / "stream_bf16x3" pass every per-step tolerance, but the chaotic 51-iteration
         # sequence drifts 10x further from the reference's run with them.)
         self.wgrad_precision = "auto"
+        # with the streaming f16 weight-gradient kernel: keep the lean activation record (no H1) and recompute H1 there
+        self.lean_record = True
         # opt-in: run the routing half of the hash grid's backward on a second stream next to the forward pass
         # (ops.hashgrid_route_ahead).  Off by default: measured on the headline workload the routing kernels, squeezed in
         # beside the persistent decoder forward, take 211 us instead of 70 and slow that kernel from 99 to 137 us -- the
@@ -273,6 +280,7 @@ class JointEncoding(nn.Module):
         new.accumulate_param_grads_in_place = self.accumulate_param_grads_in_place
         new.decoder_precision = self.decoder_precision
         new.wgrad_precision = self.wgrad_precision
+        new.lean_record = self.lean_record
         new.route_ahead = self.route_ahead
         new.train(self.training)
         return new

@@ -220,10 +220,15 @@ def decoder_pack16(weights, packed16: Optional[torch.Tensor] = None) -> torch.Te
     return packed16
 
 
-def decoder_fwd(packed, feat, layout, x, embed_pos, M, save: bool, precision: str = "f32", packed16=None):
+def decoder_fwd(packed, feat, layout, x, embed_pos, M, save, precision: str = "f32", packed16=None):
     """precision "f32": fp32-input MFMA (exact fp32 products).  "f16x3": f16 MFMA on hi/lo split operands (~3e-7
     relative; same `saved` layout, so the backward kernels are unchanged).  "f16": plain f16 operands, forward only.
-    The f16 modes need `packed16` (decoder_pack16) and the in-kernel positional encoding (embed_pos None)."""
+    The f16 modes need `packed16` (decoder_pack16) and the in-kernel positional encoding (embed_pos None).
+    save: False, True (the full activation record) or "lean" (f16x3: H1, a third of the record, is not written -- only
+    valid with ``decoder_bwd(..., wgrad_precision="stream_f16x3", recompute_h1=True)``, which recomputes it from x)."""
+    lean = save == "lean"
+    if lean and precision != "f16x3":
+        raise RuntimeError('save="lean" belongs to precision "f16x3"')
     out = torch.empty((M, 10), dtype=torch.float32, device=x.device)
     saved = None
     if save:
@@ -234,8 +239,8 @@ def decoder_fwd(packed, feat, layout, x, embed_pos, M, save: bool, precision: st
         if save and precision != "f16x3":
             raise RuntimeError('only precision "f32" / "f16x3" keep activations for the backward pass')
         with _timed("decoder_fwd"):
-            check(lib().mipsf_decoder_fwd16(dptr(packed16), dptr(feat), layout, dptr(x), dptr(out), dptr(saved), 0,
-                                            _lib.PREC[precision], M, stream_ptr()), "decoder_fwd16")
+            check(lib().mipsf_decoder_fwd16_ex(dptr(packed16), dptr(feat), layout, dptr(x), dptr(out), dptr(saved), 0,
+                                               _lib.PREC[precision], 1 if lean else 0, M, stream_ptr()), "decoder_fwd16")
         return out, saved
     pe_mode = 0 if embed_pos is None else 1
     with _timed("decoder_fwd"):
@@ -245,7 +250,7 @@ def decoder_fwd(packed, feat, layout, x, embed_pos, M, save: bool, precision: st
 
 
 def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, precision: str = "f32", packed16=None,
-                wgrad_precision: str = "auto"):
+                wgrad_precision: str = "auto", recompute_h1: bool = False):
     """grads: 10 tensors in DECODER_PARAM_ORDER, accumulated into, or None (frozen decoder: the weight-gradient
     GEMMs are skipped).  -> (dfeat, dx, dembed_pos|None).  precision "f16x3": the activation-gradient chain runs on
     the f16 matrix cores with hi/lo split operands (packed16, in-kernel positional encoding); it leaves the same `dact`
@@ -255,7 +260,9 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
       "stream_bf16x6" the same kernel on three bf16 planes (no scale; fp32-class, slower), "stream_bf16x3" two planes (~5e-6)
       "f32"           LDS-transposing kernel on the fp32-input matrix cores (the round-1 path; any pe_mode)
       "bf16x3"        that kernel with bf16 hi/lo operands for its three large products (~5e-6)
-      "auto"          "stream_f16x3" behind the f16x3 chain, "f32" otherwise."""
+      "auto"          "stream_f16x3" behind the f16x3 chain, "f32" otherwise.
+    recompute_h1 (stream_f16x3 + packed16): H1 is recomputed from x instead of read from `saved` -- required when the
+    forward kept the lean record (``decoder_fwd(save="lean")``), bit-identical otherwise."""
     if wgrad_precision == "auto":
         wgrad_precision = "stream_f16x3" if (precision == "f16x3" and embed_pos is None) else "f32"
     dev = x.device
@@ -284,10 +291,15 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
             if embed_pos is not None:
                 raise RuntimeError("the streaming weight-gradient kernel computes the positional encoding in-kernel")
             arith = _lib.PREC[wgrad_precision[len("stream_"):]]
+            if recompute_h1 and (arith != _lib.PREC["f16x3"] or packed16 is None):
+                raise RuntimeError("recompute_h1 needs wgrad_precision 'stream_f16x3' and packed16")
             with _timed("decoder_wgrad"):
-                check(lib().mipsf_decoder_wgrad16(dptr(feat), layout, dptr(x), dptr(saved), dptr(dact), C.byref(st),
-                                                  dptr(partial), arith, M, stream_ptr()), "decoder_wgrad16")
+                check(lib().mipsf_decoder_wgrad16_ex(dptr(packed16) if recompute_h1 else None, dptr(feat), layout, dptr(x),
+                                                     dptr(saved), dptr(dact), C.byref(st), dptr(partial), arith, M,
+                                                     stream_ptr()), "decoder_wgrad16")
             return dfeat, dx, dpe
+        if recompute_h1:
+            raise RuntimeError("recompute_h1 needs wgrad_precision 'stream_f16x3'")
         with _timed("decoder_wgrad"):
             wprec = _lib.PREC[wgrad_precision]
             check(lib().mipsf_decoder_wgrad_ex(dptr(feat), layout, dptr(x), dptr(embed_pos), pe_mode, dptr(saved),

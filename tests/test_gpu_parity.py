@@ -1261,6 +1261,23 @@ def test_decoder_f16x3_backward_chain_matches_fp32_kernel(dev, M, layout):
                         wgrad_precision=wp)
         for k, a, b in zip(ops.DECODER_PARAM_ORDER, gw, g32):
             assert_close(a, b, 3e-6, wp + " grad " + k)
+    # the lean record: the f16x3 forward leaves H1 out, the streaming kernel recomputes it from x with the forward's own
+    # layer-1 operand images (the final reduction adds its 8 slices atomically: equal up to the last bit only)
+    out16, saved16 = ops.decoder_fwd(None, feat, lay, x, None, M, save=True, precision="f16x3", packed16=packed16)
+    outl, savedl = ops.decoder_fwd(None, feat, lay, x, None, M, save="lean", precision="f16x3", packed16=packed16)
+    assert torch.equal(outl, out16)
+    g_full, g_rc, g_lean = ([torch.zeros_like(w) for w in ws] for _ in range(3))
+    ops.decoder_bwd(None, feat, lay, x, None, out16, dout, saved16, g_full, M, precision="f16x3", packed16=packed16,
+                    wgrad_precision="stream_f16x3")
+    ops.decoder_bwd(None, feat, lay, x, None, out16, dout, saved16, g_rc, M, precision="f16x3", packed16=packed16,
+                    wgrad_precision="stream_f16x3", recompute_h1=True)
+    ops.decoder_bwd(None, feat, lay, x, None, outl, dout, savedl, g_lean, M, precision="f16x3", packed16=packed16,
+                    wgrad_precision="stream_f16x3", recompute_h1=True)
+    for k, a, b, c in zip(ops.DECODER_PARAM_ORDER, g_full, g_rc, g_lean):
+        assert_close(b, a, 1e-6, "recomputed H1 vs stored H1, grad " + k)
+        assert_close(c, b, 1e-6, "lean record vs full record (H1 is not read either way), grad " + k)
+    # (g_full is not compared with g32 here: this block differentiates the f16x3 forward, whose ReLU masks differ from
+    # the fp32 forward's in a few of 9 M decisions)
     gw = [torch.zeros_like(w) for w in ws]
     ops.decoder_bwd(packed, feat, lay, x, None, out, dout, saved, gw, M, wgrad_precision="stream_f16x3")
     for k, a, b in zip(ops.DECODER_PARAM_ORDER, gw, g32):
