@@ -243,7 +243,8 @@ class MappingLoop:
             rays_d = torch.sum(rays_d_cam[..., None, :] * self.poses_all[owner, :3, :3], -1)
             rays_o = self.poses_all[owner, :3, -1]
         else:   # same arithmetic, one kernel each way (gradients reach cur_rot / cur_trans through autograd)
-            rays_o, rays_d = ops.pose_rays(self.cur_rot, self.cur_trans, self.pose_fixed, owner, rays_d_cam)
+            rays_o, rays_d = ops.pose_rays(self.cur_rot, self.cur_trans, self.pose_fixed, owner, rays_d_cam,
+                                           accumulate_in_place=True)
         ret = self.model.forward(rays_o, rays_d, target_s, target_d, noise=noise)
         loss = get_loss_from_ret(ret, cfg["training"])
         loss.backward(retain_graph=self.torch_pose)
@@ -364,7 +365,7 @@ def frame_estimate(cfg, model, loop, dev, ba_ms, stream=None):
             rays_o = c2w[..., :3, -1].repeat(ns, 1)
             rays_d = torch.sum(d_cam[..., None, :] * c2w[:, :3, :3], -1)
         else:
-            rays_o, rays_d = ops.pose_rays(rot, trans, None, own, d_cam)
+            rays_o, rays_d = ops.pose_rays(rot, trans, None, own, d_cam, accumulate_in_place=True)
         ret = model.forward(rays_o, rays_d, t_rgb, t_d, EMD_w=0., noise=noise)
         get_loss_from_ret(ret, cfg["training"]).backward()
         popt.step()

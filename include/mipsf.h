@@ -270,6 +270,10 @@ uint64_t mipsf_pose_rays_scratch_floats(uint32_t F, uint32_t K, uint32_t N);
 int mipsf_pose_rays_bwd(const float* g_rays_o, const float* g_rays_d, const float* rot, uint32_t F, uint32_t K,
                         const int64_t* owner, const float* d_cam, float* d_rot, float* d_trans, float* scratch,
                         uint32_t N, void* stream);
+/* accumulate != 0: d_rot / d_trans are ADDED to (the parameters' own .grad buffers: no separate accumulation pass) */
+int mipsf_pose_rays_bwd_ex(const float* g_rays_o, const float* g_rays_d, const float* rot, uint32_t F, uint32_t K,
+                           const int64_t* owner, const float* d_cam, float* d_rot, float* d_trans, float* scratch,
+                           uint32_t N, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------- Adam (a11) */
 /* One dense torch.optim.Adam step over n floats.  step = 1-based count after increment.

@@ -113,6 +113,7 @@ SIGNATURES = {
     "mipsf_normalise_bwd": (_I, [_P, C.POINTER(RenderCfg), _P, _U32, _P]),
     "mipsf_pose_rays_fwd": (_I, [_P, _P, _P, _U32, _U32, _P, _P, _P, _P, _U32, _P]),
     "mipsf_pose_rays_bwd": (_I, [_P, _P, _P, _U32, _U32, _P, _P, _P, _P, _P, _U32, _P]),
+    "mipsf_pose_rays_bwd_ex": (_I, [_P, _P, _P, _U32, _U32, _P, _P, _P, _P, _P, _U32, _I, _P]),
     "mipsf_pose_rays_scratch_floats": (_U64, [_U32, _U32, _U32]),
     "mipsf_adam_step": (_I, [_P, _P, _P, _P, _U64, _F, _F, _F, _F, _F, _U32, _I, _P]),
     "mipsf_adam_advance": (_I, [_P, _P, _F, _F, _F, _P]),

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(PR_BLOCK) void pose_rays_fwd_kernel(const float* __
 // chain through R(q) = I + s A(q), s = 2/|q|^2 (pytorch3d quaternion_to_matrix, not assuming unit norm);
 // G = {dR (9, row-major), dt (3)} of optimisable pose k
 __device__ __forceinline__ void pose_chain(const float* __restrict__ rot, const float* G, int k,
-                                           float* __restrict__ d_rot, float* __restrict__ d_trans) {
+                                           float* __restrict__ d_rot, float* __restrict__ d_trans, bool accumulate = false) {
     const float w = rot[4 * k], x = rot[4 * k + 1], y = rot[4 * k + 2], z = rot[4 * k + 3];
     const float n = w * w + x * x + y * y + z * z;
     const float s = 2.0f / n;
@@ -82,11 +82,14 @@ __device__ __forceinline__ void pose_chain(const float* __restrict__ rot, const 
     const float dAy = (-2 * y * G[0] + x * G[1] + w * G[2]) + (x * G[3] + z * G[5]) + (-w * G[6] + z * G[7] - 2 * y * G[8]);
     const float dAz = (-2 * z * G[0] - w * G[1] + x * G[2]) + (w * G[3] - 2 * z * G[4] + y * G[5]) + (x * G[6] + y * G[7]);
     const float c = s * GA * 2.0f / n;
-    d_rot[4 * k] = s * dAw - c * w;
-    d_rot[4 * k + 1] = s * dAx - c * x;
-    d_rot[4 * k + 2] = s * dAy - c * y;
-    d_rot[4 * k + 3] = s * dAz - c * z;
-    d_trans[3 * k] = G[9], d_trans[3 * k + 1] = G[10], d_trans[3 * k + 2] = G[11];
+    const float r0 = s * dAw - c * w, r1 = s * dAx - c * x, r2 = s * dAy - c * y, r3 = s * dAz - c * z;
+    if (accumulate) {       // `.grad +=` semantics: the caller passed the parameters' gradient buffers themselves
+        d_rot[4 * k] += r0, d_rot[4 * k + 1] += r1, d_rot[4 * k + 2] += r2, d_rot[4 * k + 3] += r3;
+        d_trans[3 * k] += G[9], d_trans[3 * k + 1] += G[10], d_trans[3 * k + 2] += G[11];
+    } else {
+        d_rot[4 * k] = r0, d_rot[4 * k + 1] = r1, d_rot[4 * k + 2] = r2, d_rot[4 * k + 3] = r3;
+        d_trans[3 * k] = G[9], d_trans[3 * k + 1] = G[10], d_trans[3 * k + 2] = G[11];
+    }
 }
 
 // ONE launch (it used to be zero-fill + accumulate-with-atomics + chain = three, ~5 us each in a captured iteration):
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(PR_BLOCK) void pose_rays_bwd_kernel(const float* __
                                                                  const float* __restrict__ rot, int F, int K,
                                                                  float* __restrict__ part, uint32_t* __restrict__ ticket,
                                                                  float* __restrict__ d_rot, float* __restrict__ d_trans,
-                                                                 uint32_t N) {
+                                                                 uint32_t N, int accumulate) {
     __shared__ float sacc[PR_MAX_POSES * 12];
     __shared__ bool is_last;
     const int P = F + K;
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(PR_BLOCK) void pose_rays_bwd_kernel(const float* __
         sacc[q] = s;
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < K; k += PR_BLOCK) pose_chain(rot, sacc + 12 * (F + k), k, d_rot, d_trans);
+    for (int k = threadIdx.x; k < K; k += PR_BLOCK) pose_chain(rot, sacc + 12 * (F + k), k, d_rot, d_trans, accumulate != 0);
     if (threadIdx.x == 0) *ticket = 0u;
 }
 
@@ -198,10 +201,17 @@ uint64_t mipsf_pose_rays_scratch_floats(uint32_t F, uint32_t K, uint32_t N) {
 int mipsf_pose_rays_bwd(const float* g_rays_o, const float* g_rays_d, const float* rot, uint32_t F, uint32_t K,
                         const int64_t* owner, const float* d_cam, float* d_rot, float* d_trans, float* scratch,
                         uint32_t N, void* stream) {
+    return mipsf_pose_rays_bwd_ex(g_rays_o, g_rays_d, rot, F, K, owner, d_cam, d_rot, d_trans, scratch, N, 0, stream);
+}
+
+int mipsf_pose_rays_bwd_ex(const float* g_rays_o, const float* g_rays_d, const float* rot, uint32_t F, uint32_t K,
+                           const int64_t* owner, const float* d_cam, float* d_rot, float* d_trans, float* scratch,
+                           uint32_t N, int accumulate, void* stream) {
     MIPSF_REQUIRE(K >= 1, "no optimisable pose");
     MIPSF_REQUIRE(rot && owner && d_cam && d_rot && d_trans && scratch, "null pointer");
     MIPSF_REQUIRE(F + K <= PR_MAX_POSES, "number of poses %u above %d", F + K, PR_MAX_POSES);
     hipStream_t s = (hipStream_t)stream;
+    if (N == 0 && accumulate) return 0;       // nothing to add
     if (N == 0) {       // no rays: zero gradients
         hipLaunchKernelGGL(pose_zero_kernel, dim3(1), dim3(256), 0, s, d_rot, (int)(4 * K));
         hipLaunchKernelGGL(pose_zero_kernel, dim3(1), dim3(256), 0, s, d_trans, (int)(3 * K));
@@ -210,7 +220,7 @@ int mipsf_pose_rays_bwd(const float* g_rays_o, const float* g_rays_d, const floa
     // scratch[0] = ticket (zero on entry, zero again on return), then one row of partials per workgroup
     hipLaunchKernelGGL(pose_rays_bwd_kernel, dim3((N + PR_BLOCK - 1) / PR_BLOCK), dim3(PR_BLOCK), 0, s, g_rays_o,
                        g_rays_d, d_cam, owner, rot, (int)F, (int)K, scratch + 1, reinterpret_cast<uint32_t*>(scratch),
-                       d_rot, d_trans, N);
+                       d_rot, d_trans, N, accumulate);
     return check_launch("pose_rays_bwd");
 }
 

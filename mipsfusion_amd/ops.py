@@ -451,7 +451,8 @@ class PoseRaysFn(torch.autograd.Function):
     ``qt_to_transform_matrix`` + ``poses_all[owner]`` gather + ``sum(d_cam * R, -1)`` (mipsfusion.py:320-322)."""
 
     @staticmethod
-    def forward(ctx, rot, trans, fixed, owner, d_cam):
+    def forward(ctx, rot, trans, fixed, owner, d_cam, in_place=False):
+        ctx.params = (rot, trans) if in_place else None
         rot, trans, d_cam = _f32c(rot), _f32c(trans), _f32c(d_cam)
         fixed = _f32c(fixed) if fixed is not None and fixed.numel() else None
         owner = owner.to(torch.int64).contiguous()
@@ -470,22 +471,37 @@ class PoseRaysFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_o, g_d):
         rot, owner, d_cam = ctx.saved_tensors
-        d_rot = torch.empty((ctx.K, 4), dtype=torch.float32, device=rot.device)
-        d_trans = torch.empty((ctx.K, 3), dtype=torch.float32, device=rot.device)
         scratch = _pose_scratch(rot.device, ctx.F, ctx.K, ctx.N)
         g_o = _f32c(g_o) if g_o is not None else None
         g_d = _f32c(g_d) if g_d is not None else None
+        # opt-in (`pose_rays(..., accumulate_in_place=True)`, plain loss.backward() loops): the kernel adds straight into
+        # the leaf parameters' .grad -- no two `grad += new` passes of autograd's AccumulateGrad per iteration
+        direct = ctx.params is not None and all(
+            p.is_leaf and p.requires_grad and not p._backward_hooks and p.dtype == torch.float32 and p.is_contiguous()
+            for p in ctx.params)
+        if direct:
+            for p in ctx.params:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            d_rot, d_trans = ctx.params[0].grad, ctx.params[1].grad
+        else:
+            d_rot = torch.empty((ctx.K, 4), dtype=torch.float32, device=rot.device)
+            d_trans = torch.empty((ctx.K, 3), dtype=torch.float32, device=rot.device)
         with _timed("pose_rays_bwd"):
-            check(lib().mipsf_pose_rays_bwd(dptr(g_o), dptr(g_d), dptr(rot), ctx.F, ctx.K, dptr(owner, torch.int64),
-                                            dptr(d_cam), dptr(d_rot), dptr(d_trans), dptr(scratch), ctx.N,
-                                            stream_ptr()), "pose_rays_bwd")
-        return d_rot, d_trans, None, None, None
+            check(lib().mipsf_pose_rays_bwd_ex(dptr(g_o), dptr(g_d), dptr(rot), ctx.F, ctx.K, dptr(owner, torch.int64),
+                                               dptr(d_cam), dptr(d_rot), dptr(d_trans), dptr(scratch), ctx.N,
+                                               1 if direct else 0, stream_ptr()), "pose_rays_bwd")
+        if direct:
+            return None, None, None, None, None, None
+        return d_rot, d_trans, None, None, None, None
 
 
-def pose_rays(rot, trans, fixed_poses, owner, d_cam):
+def pose_rays(rot, trans, fixed_poses, owner, d_cam, accumulate_in_place=False):
     """rays_o, rays_d for rays whose camera pose is poses_all[owner] with
-    poses_all = cat([fixed_poses, qt_to_transform_matrix(rot, trans)])."""
-    return PoseRaysFn.apply(rot, trans, fixed_poses, owner, d_cam)
+    poses_all = cat([fixed_poses, qt_to_transform_matrix(rot, trans)]).  accumulate_in_place (opt-in, only valid for plain
+    ``loss.backward()`` accumulation loops, ignored for non-leaf / hooked parameters): the backward adds the pose
+    gradients straight into ``rot.grad`` / ``trans.grad``."""
+    return PoseRaysFn.apply(rot, trans, fixed_poses, owner, d_cam, accumulate_in_place)
 
 
 # ----------------------------------------------------------------------------------- Adam

@@ -426,7 +426,8 @@ class GraphedSequence:
 
         def step(k):
             d_cam, rgb, depth = ops.gather_rays(self.table, self.ba_rows[k, :n].contiguous(), split=True)
-            rays_o, rays_d = ops.pose_rays(self.ba_rot, self.ba_trans, self.fixed, self.ba_owner[k, :n].contiguous(), d_cam)
+            rays_o, rays_d = ops.pose_rays(self.ba_rot, self.ba_trans, self.fixed, self.ba_owner[k, :n].contiguous(), d_cam,
+                                           accumulate_in_place=True)
             ret = self.model.forward(rays_o, rays_d, rgb, depth, noise=self.ba_noise[k, :n].contiguous())
             get_loss_from_ret(ret, tcfg).backward()
             self.map_opt.step(zero_grad=True)
@@ -436,7 +437,7 @@ class GraphedSequence:
 
     def _go_step(self, k):
         d_cam, rgb, depth = ops.gather_rays(self.cur, self.go_idx, split=True)
-        rays_o, rays_d = ops.pose_rays(self.go_rot, self.go_trans, None, self.go_own, d_cam)
+        rays_o, rays_d = ops.pose_rays(self.go_rot, self.go_trans, None, self.go_own, d_cam, accumulate_in_place=True)
         ret = self.model.forward(rays_o, rays_d, rgb, depth, EMD_w=0., noise=self.go_noise[k])
         get_loss_from_ret(ret, self.cfg["training"]).backward()
         self.go_popt.step(zero_grad=True)

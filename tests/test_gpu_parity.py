@@ -601,7 +601,14 @@ def test_pose_rays_matches_torch_composition(dev):
         ro4, rd4 = ops.pose_rays(rot_s, trans_s, fixed, owner[:70], d_cam[:70])
         (ro4 * go[:70]).sum().add((rd4 * gd[:70]).sum()).backward()
         assert torch.isfinite(rot_s.grad).all()
-    # above 16 384 rays the backward is the multi-workgroup kernel (per-workgroup partial rows + ticket)
+    # opt-in: the backward adds straight into rot.grad / trans.grad (twice -> twice the gradient)
+    rot_i, trans_i = rot0.clone().requires_grad_(True), trans0.clone().requires_grad_(True)
+    for _ in range(2):
+        ro6, rd6 = ops.pose_rays(rot_i, trans_i, fixed, owner, d_cam, accumulate_in_place=True)
+        (ro6 * go).sum().add((rd6 * gd).sum()).backward()
+    assert_close(rot_i.grad, 2 * rot_b.grad, 2e-5, "d quaternion, accumulated in place twice")
+    assert_close(trans_i.grad, 2 * trans_b.grad, 2e-5, "d translation, accumulated in place twice")
+    # a batch of 40 000 rays: many workgroups (per-workgroup partial rows + ticket)
     Nb = 40000
     owner_b = torch.randint(0, F + K, (Nb,), device=dev)
     owner_b[:20000] = torch.arange(20000, device=dev) // 2000 % (F + K)         # long uniform stretches
