@@ -243,12 +243,25 @@ int mipsf_render_fwd(const float* raw, const float* z_vals, const float* target_
                      const uint32_t* counts, const mipsf_render_cfg* cfg_host, float* rgb, float* depth,
                      float* depth_var, float* disp, float* acc, float* weights, float* losses,
                      float* partial, uint32_t N, uint32_t S, void* stream);
+/* The same with the training objective formed in the same launch: loss_total[0] = sum_k loss_weights[k] * losses[k], k < 4
+ * (both device pointers; MIPSFusion.get_loss_from_ret, mipsfusion.py:142-152). */
+int mipsf_render_fwd_ex(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
+                        const uint32_t* counts, const mipsf_render_cfg* cfg_host, float* rgb, float* depth,
+                        float* depth_var, float* disp, float* acc, float* weights, float* losses,
+                        float* partial, const float* loss_weights, float* loss_total, uint32_t N, uint32_t S,
+                        void* stream);
 /* Gradients wrt raw.  g_losses[4] (device): d total / d {rgb_loss, depth_loss, sdf_loss, fs_loss};
  * g_rgb [N,3], g_depth [N] nullable extra gradients on the rendered maps.  draw [N,S,10] is written. */
 int mipsf_render_bwd(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
                      const uint32_t* counts, const float* losses, const mipsf_render_cfg* cfg_host,
                      const float* g_losses, const float* g_rgb, const float* g_depth, float* draw,
                      uint32_t N, uint32_t S, void* stream);
+/* g_losses nullable; g_total[1] (device, nullable): gradient of mipsf_render_fwd_ex's loss_total -- the kernel uses
+ * g_losses[k] + g_total[0] * loss_weights[k]. */
+int mipsf_render_bwd_ex(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
+                        const uint32_t* counts, const float* losses, const mipsf_render_cfg* cfg_host,
+                        const float* g_losses, const float* g_total, const float* loss_weights, const float* g_rgb,
+                        const float* g_depth, float* draw, uint32_t N, uint32_t S, void* stream);
 /* dxn [N*S,3] -> d_rays_o [N,3], d_rays_d [N,3] (written) */
 int mipsf_rays_bwd(const float* dxn, const float* z_vals, const mipsf_render_cfg* cfg_host, float* d_rays_o,
                    float* d_rays_d, uint32_t N, uint32_t S, void* stream);

@@ -109,6 +109,9 @@ SIGNATURES = {
     "mipsf_render_fwd": (_I, [_P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _U32, _U32,
                               _P]),
     "mipsf_render_bwd": (_I, [_P, _P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _U32, _U32, _P]),
+    "mipsf_render_fwd_ex": (_I, [_P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U32,
+                                 _U32, _P]),
+    "mipsf_render_bwd_ex": (_I, [_P, _P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _P, _P, _U32, _U32, _P]),
     "mipsf_rays_bwd": (_I, [_P, _P, C.POINTER(RenderCfg), _P, _P, _U32, _U32, _P]),
     "mipsf_normalise_bwd": (_I, [_P, C.POINTER(RenderCfg), _P, _U32, _P]),
     "mipsf_pose_rays_fwd": (_I, [_P, _P, _P, _U32, _U32, _P, _P, _P, _P, _U32, _P]),

@@ -247,7 +247,9 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void render_fwd_kernel
 constexpr int LF_BLOCK = 1024;
 __global__ __launch_bounds__(LF_BLOCK) void loss_finalize_kernel(const float* __restrict__ partial,
                                                             const uint32_t* __restrict__ counts, float emd_w,
-                                                            float* __restrict__ losses, uint32_t N, uint32_t S) {
+                                                            float* __restrict__ losses, uint32_t N, uint32_t S,
+                                                            const float* __restrict__ loss_weights,
+                                                            float* __restrict__ loss_total) {
     __shared__ double red[LF_BLOCK / MIPSF_WAVE][9];
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     // four rays' loads in flight per thread (4096 rays = 4 per thread: one memory round trip instead of four); the
@@ -308,6 +310,16 @@ __global__ __launch_bounds__(LF_BLOCK) void loss_finalize_kernel(const float* __
         losses[5] = fs_w;
         losses[6] = sdf_w;
         losses[7] = (float)t[6];
+        // the training objective itself (MIPSFusion.get_loss_from_ret, mipsfusion.py:142-152): the same products added left
+        // to right in fp32 -- saves the caller a dot product forward and a scaling pass backward (5 us launches each)
+        if (loss_total) {
+            float tot = 0.0f;
+            tot = tot + loss_weights[0] * rgb_loss;
+            tot = tot + loss_weights[1] * depth_loss;
+            tot = tot + loss_weights[2] * sd;
+            tot = tot + loss_weights[3] * fs;
+            loss_total[0] = tot;
+        }
     }
 }
 
@@ -316,7 +328,8 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void render_bwd_kernel
     const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ target_rgb,
     const float* __restrict__ target_d, const float* __restrict__ losses, RenderCfg rc, int train,
     const float* __restrict__ g_losses, const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
-    float* __restrict__ draw, uint32_t N, uint32_t S) {
+    float* __restrict__ draw, uint32_t N, uint32_t S, const float* __restrict__ g_total,
+    const float* __restrict__ loss_weights) {
     __shared__ float ssdf[RAYS_PER_BLOCK][MAX_S];
     const uint32_t w = threadIdx.x / MIPSF_WAVE, lane = threadIdx.x & (MIPSF_WAVE - 1);
     const uint32_t n = blockIdx.x * RAYS_PER_BLOCK + w;
@@ -360,8 +373,12 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void render_bwd_kernel
         d = target_d[n];
         const bool valid = (d > 0.f) && (d < rc.depth_trunc);
         const float cw = (valid || rc.rgb_missing_nonzero) ? 1.f : 0.f;
-        const float gR = g_losses[0], gD = g_losses[1];
-        gS = g_losses[2], gF = g_losses[3];
+        // d objective / d {rgb, depth, sdf, fs}_loss: given directly and / or as (d objective / d total) x weights
+        float gl[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gl[k] = (g_losses ? g_losses[k] : 0.f) + (g_total ? g_total[0] * loss_weights[k] : 0.f);
+        const float gR = gl[0], gD = gl[1];
+        gS = gl[2], gF = gl[3];
         fs_w = losses[5], sdf_w = losses[6];
         const float k_rgb = gR * 2.f * cw * cw / (3.f * (float)N);
         G_r += k_rgb * (a_r - target_rgb[3 * n]);
@@ -495,6 +512,16 @@ int mipsf_render_fwd(const float* raw, const float* z_vals, const float* target_
                      const uint32_t* counts, const mipsf_render_cfg* cfg, float* rgb, float* depth,
                      float* depth_var, float* disp, float* acc, float* weights, float* losses, float* partial,
                      uint32_t N, uint32_t S, void* stream) {
+    return mipsf_render_fwd_ex(raw, z_vals, target_rgb, target_d, counts, cfg, rgb, depth, depth_var, disp, acc, weights,
+                               losses, partial, nullptr, nullptr, N, S, stream);
+}
+
+int mipsf_render_fwd_ex(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
+                        const uint32_t* counts, const mipsf_render_cfg* cfg, float* rgb, float* depth,
+                        float* depth_var, float* disp, float* acc, float* weights, float* losses, float* partial,
+                        const float* loss_weights, float* loss_total, uint32_t N, uint32_t S, void* stream) {
+    MIPSF_REQUIRE((loss_weights == nullptr) == (loss_total == nullptr), "loss_weights and loss_total come together");
+    MIPSF_REQUIRE(loss_total == nullptr || losses != nullptr, "loss_total needs the training mode (losses)");
     if (N == 0) return 0;
     MIPSF_REQUIRE(cfg && raw && z_vals && rgb && depth, "null pointer");
     MIPSF_REQUIRE(S >= 1 && S <= MAX_S, "samples per ray %u outside [1,%d]", S, MAX_S);
@@ -506,7 +533,8 @@ int mipsf_render_fwd(const float* raw, const float* z_vals, const float* target_
         hipLaunchKernelGGL(render_fwd_kernel<true>, grid, block, 0, s, raw, z_vals, target_rgb, target_d, rc, rgb,
                            depth, depth_var, disp, acc, weights, partial, N, S);
         if (int e = check_launch("render_fwd")) return e;
-        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(LF_BLOCK), 0, s, partial, counts, rc.emd_w, losses, N, S);
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(LF_BLOCK), 0, s, partial, counts, rc.emd_w, losses, N, S,
+                           loss_weights, loss_total);
         return check_launch("loss_finalize");
     }
     hipLaunchKernelGGL(render_fwd_kernel<false>, grid, block, 0, s, raw, z_vals, target_rgb, target_d, rc, rgb, depth,
@@ -518,15 +546,24 @@ int mipsf_render_bwd(const float* raw, const float* z_vals, const float* target_
                      const uint32_t* counts, const float* losses, const mipsf_render_cfg* cfg,
                      const float* g_losses, const float* g_rgb, const float* g_depth, float* draw, uint32_t N,
                      uint32_t S, void* stream) {
+    return mipsf_render_bwd_ex(raw, z_vals, target_rgb, target_d, counts, losses, cfg, g_losses, nullptr, nullptr, g_rgb,
+                               g_depth, draw, N, S, stream);
+}
+
+int mipsf_render_bwd_ex(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
+                        const uint32_t* counts, const float* losses, const mipsf_render_cfg* cfg,
+                        const float* g_losses, const float* g_total, const float* loss_weights, const float* g_rgb,
+                        const float* g_depth, float* draw, uint32_t N, uint32_t S, void* stream) {
     (void)counts;
     if (N == 0) return 0;
     MIPSF_REQUIRE(cfg && raw && z_vals && draw, "null pointer");
     MIPSF_REQUIRE(S >= 1 && S <= MAX_S, "samples per ray %u outside [1,%d]", S, MAX_S);
-    const int train = g_losses != nullptr;
+    MIPSF_REQUIRE(g_total == nullptr || loss_weights != nullptr, "g_total needs the loss weights");
+    const int train = g_losses != nullptr || g_total != nullptr;
     MIPSF_REQUIRE(!train || (target_rgb && target_d && losses), "training backward needs targets and losses");
     hipLaunchKernelGGL(render_bwd_kernel, dim3((N + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK),
                        dim3(RAYS_PER_BLOCK * MIPSF_WAVE), 0, (hipStream_t)stream, raw, z_vals, target_rgb, target_d,
-                       losses, to_render_cfg(*cfg), train, g_losses, g_rgb, g_depth, draw, N, S);
+                       losses, to_render_cfg(*cfg), train, g_losses, g_rgb, g_depth, draw, N, S, g_total, loss_weights);
     return check_launch("render_bwd");
 }
 

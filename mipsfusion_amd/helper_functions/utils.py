@@ -49,6 +49,10 @@ def get_loss_from_ret(ret, training_cfg, rgb=True, sdf=True, depth=True, fs=True
     """MIPSFusion.get_loss_from_ret (mipsfusion.py:142-152).  When ``ret`` comes from this package's
     JointEncoding.forward the weighted sum is one fused op over the kernel's loss vector (same value: the products
     and the left-to-right sum of the reference, to fp32 rounding of a 4-term dot product)."""
+    if isinstance(ret, dict) and "_loss_total" in ret and rgb and sdf and depth and fs and ret["_loss_total_weights"] == (
+            float(training_cfg["rgb_weight"]), float(training_cfg["depth_weight"]), float(training_cfg["sdf_weight"]),
+            float(training_cfg["fs_weight"])):
+        return ret["_loss_total"]           # formed inside the loss kernel with exactly these weights
     vec = ret.get("_loss_vec") if isinstance(ret, dict) else None
     if vec is not None and vec.is_cuda:
         w = _loss_weights(training_cfg, vec.device, vec.shape[0], (float(rgb), float(depth), float(sdf), float(fs)))

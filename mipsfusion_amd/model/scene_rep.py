@@ -161,28 +161,37 @@ class _RenderFn(torch.autograd.Function):
     """raw2outputs / sdf2weights (+ the four training losses): scene_rep.py:58-103, 211-236."""
 
     @staticmethod
-    def forward(ctx, raw, z_vals, target_rgb, target_d, counts, rc, N, S, train):
+    def forward(ctx, raw, z_vals, target_rgb, target_d, counts, rc, N, S, train, loss_w=None):
         raw = ops._f32c(raw)
-        rgb, depth, var, disp, acc, _, losses = ops.render_fwd(raw, z_vals, target_rgb, target_d, counts, rc, N, S,
-                                                               train)
+        total = None
+        if train and loss_w is not None:     # the weighted objective comes out of the loss kernel itself
+            rgb, depth, var, disp, acc, _, losses, total = ops.render_fwd(raw, z_vals, target_rgb, target_d, counts, rc, N,
+                                                                          S, train, loss_weights=loss_w)
+        else:
+            rgb, depth, var, disp, acc, _, losses = ops.render_fwd(raw, z_vals, target_rgb, target_d, counts, rc, N, S,
+                                                                   train)
         ctx.rc, ctx.N, ctx.S, ctx.train = rc, N, S, train
-        ctx.save_for_backward(raw, z_vals, target_rgb, target_d, counts, losses)
+        ctx.save_for_backward(raw, z_vals, target_rgb, target_d, counts, losses, loss_w if total is not None else None)
         ctx.mark_non_differentiable(var, disp, acc)
         ctx.set_materialize_grads(False)      # rgb / depth usually carry no gradient in training: skip their zero fills
+        if total is not None:
+            return rgb, depth, var, disp, acc, losses, total.reshape(())
         if train:
             return rgb, depth, var, disp, acc, losses
         return rgb, depth, var, disp, acc
 
     @staticmethod
-    def backward(ctx, g_rgb, g_depth, _gv, _gd, _ga, g_losses=None):
-        raw, z_vals, target_rgb, target_d, counts, losses = ctx.saved_tensors
+    def backward(ctx, g_rgb, g_depth, _gv, _gd, _ga, g_losses=None, g_total=None):
+        raw, z_vals, target_rgb, target_d, counts, losses, loss_w = ctx.saved_tensors
         g_rgb = ops._f32c(g_rgb) if g_rgb is not None else None
         g_depth = ops._f32c(g_depth) if g_depth is not None else None
-        if ctx.train and g_losses is None:
+        g_total = ops._f32c(g_total).reshape(1) if (g_total is not None and loss_w is not None) else None
+        if ctx.train and g_losses is None and g_total is None:
             g_losses = torch.zeros(8, dtype=torch.float32, device=raw.device)
         draw = ops.render_bwd(raw, z_vals, target_rgb, target_d, counts, losses, ctx.rc,
-                              ops._f32c(g_losses) if ctx.train else None, g_rgb, g_depth, ctx.N, ctx.S)
-        return draw, None, None, None, None, None, None, None, None
+                              ops._f32c(g_losses) if (ctx.train and g_losses is not None) else None, g_rgb, g_depth,
+                              ctx.N, ctx.S, g_total=g_total, loss_weights=loss_w)
+        return draw, None, None, None, None, None, None, None, None, None
 
 
 class JointEncoding(nn.Module):
@@ -355,8 +364,21 @@ class JointEncoding(nn.Module):
         z_vals, xn, counts = _PlaceFn.apply(rays_o, rays_d, td, noise, tables, rc, N, S)
         raw = self._query(xn)
         trgb = ops._f32c(target_rgb) if train else None
-        res = _RenderFn.apply(raw, z_vals, trgb, td if train else None, counts if train else None, rc, N, S, train)
+        res = _RenderFn.apply(raw, z_vals, trgb, td if train else None, counts if train else None, rc, N, S, train,
+                              self._objective_weights(raw.device) if train else None)
         return res, z_vals, raw.reshape(N, S, 10)
+
+    def _objective_weights(self, device):
+        """(rgb, depth, sdf, fs) weights of config["training"] as a device tensor, or None when the config has none: the
+        loss kernel then also forms the objective of MIPSFusion.get_loss_from_ret (helper_functions.utils)."""
+        tr = self.config.get("training", {})
+        if not all(k in tr for k in ("rgb_weight", "depth_weight", "sdf_weight", "fs_weight")):
+            return None
+        vals = (float(tr["rgb_weight"]), float(tr["depth_weight"]), float(tr["sdf_weight"]), float(tr["fs_weight"]))
+        key = (str(device), vals)
+        if getattr(self, "_obj_w_key", None) != key:
+            self._obj_w, self._obj_w_key = torch.tensor(vals, dtype=torch.float32, device=device), key
+        return self._obj_w
 
     def render_rays(self, rays_o, rays_d, target_d=None, noise=None):
         (rgb, depth, var, disp, acc), z_vals, raw = self._render(rays_o, rays_d, None, target_d, noise, False, 0.0)
@@ -368,9 +390,13 @@ class JointEncoding(nn.Module):
         drawing torch.rand on the CPU."""
         if not self.training:
             return self.render_rays(rays_o, rays_d, target_d=target_d, noise=noise)
-        (rgb, depth, _var, _disp, _acc, losses), _z, _raw = self._render(rays_o, rays_d, target_rgb, target_d, noise,
-                                                                         True, float(EMD_w))
+        res, _z, _raw = self._render(rays_o, rays_d, target_rgb, target_d, noise, True, float(EMD_w))
+        rgb, depth, losses = res[0], res[1], res[5]
+        total = res[6] if len(res) > 6 else None
         # "_loss_vec" (extension): the kernel's loss vector itself, so that get_loss_from_ret can form the weighted
         # sum with one dot product instead of 4 selects + 4 scalings + 3 adds and their ~25 backward launches
-        return {"rgb": rgb, "depth": depth, "rgb_loss": losses[0], "depth_loss": losses[1], "sdf_loss": losses[2],
-                "fs_loss": losses[3], "psnr": losses[4:5].detach(), "_loss_vec": losses}
+        ret = {"rgb": rgb, "depth": depth, "rgb_loss": losses[0], "depth_loss": losses[1], "sdf_loss": losses[2],
+               "fs_loss": losses[3], "psnr": losses[4:5].detach(), "_loss_vec": losses}
+        if total is not None:   # "_loss_total" (extension): the objective with this model's own config weights, from the kernel
+            ret["_loss_total"], ret["_loss_total_weights"] = total, self._obj_w_key[1]
+        return ret

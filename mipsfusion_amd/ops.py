@@ -396,28 +396,37 @@ def sample_rays(rays_o, rays_d, target_d, noise, tables, rc, N, S):
     return z_vals, xn, counts
 
 
-def render_fwd(raw, z_vals, target_rgb, target_d, counts, rc, N, S, train: bool, want_weights=False):
+def render_fwd(raw, z_vals, target_rgb, target_d, counts, rc, N, S, train: bool, want_weights=False, loss_weights=None):
+    """loss_weights (train only): device tensor of the 4 loss weights -> an 8th return value, the objective
+    sum_k w_k * losses[k] formed inside the loss kernel (one float)."""
     dev = raw.device
     f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)   # noqa: E731
     rgb, depth, var, disp, acc = f(N, 3), f(N), f(N), f(N), f(N)
     weights = f(N, S) if want_weights else None
     losses = f(8) if train else None
     partial = f(N * 8) if train else None
+    total = f(1) if (train and loss_weights is not None) else None
     with _timed("render_fwd"):
-        check(lib().mipsf_render_fwd(dptr(raw), dptr(z_vals), dptr(target_rgb), dptr(target_d),
-                                     dptr(counts, torch.int32) if counts is not None else None, C.byref(rc), dptr(rgb),
-                                     dptr(depth), dptr(var), dptr(disp), dptr(acc), dptr(weights), dptr(losses),
-                                     dptr(partial), N, S, stream_ptr()), "render_fwd")
+        check(lib().mipsf_render_fwd_ex(dptr(raw), dptr(z_vals), dptr(target_rgb), dptr(target_d),
+                                        dptr(counts, torch.int32) if counts is not None else None, C.byref(rc), dptr(rgb),
+                                        dptr(depth), dptr(var), dptr(disp), dptr(acc), dptr(weights), dptr(losses),
+                                        dptr(partial), dptr(loss_weights) if total is not None else None, dptr(total),
+                                        N, S, stream_ptr()), "render_fwd")
+    if loss_weights is not None and train:
+        return rgb, depth, var, disp, acc, weights, losses, total
     return rgb, depth, var, disp, acc, weights, losses
 
 
-def render_bwd(raw, z_vals, target_rgb, target_d, counts, losses, rc, g_losses, g_rgb, g_depth, N, S):
+def render_bwd(raw, z_vals, target_rgb, target_d, counts, losses, rc, g_losses, g_rgb, g_depth, N, S, g_total=None,
+               loss_weights=None):
+    """g_total / loss_weights: gradient of render_fwd's objective and its weights (the kernel forms g_total * w itself)."""
     draw = torch.empty_like(raw)
     with _timed("render_bwd"):
-        check(lib().mipsf_render_bwd(dptr(raw), dptr(z_vals), dptr(target_rgb), dptr(target_d),
-                                     dptr(counts, torch.int32) if counts is not None else None, dptr(losses),
-                                     C.byref(rc), dptr(g_losses), dptr(g_rgb), dptr(g_depth), dptr(draw), N, S,
-                                     stream_ptr()), "render_bwd")
+        check(lib().mipsf_render_bwd_ex(dptr(raw), dptr(z_vals), dptr(target_rgb), dptr(target_d),
+                                        dptr(counts, torch.int32) if counts is not None else None, dptr(losses),
+                                        C.byref(rc), dptr(g_losses), dptr(g_total),
+                                        dptr(loss_weights) if g_total is not None else None, dptr(g_rgb), dptr(g_depth),
+                                        dptr(draw), N, S, stream_ptr()), "render_bwd")
     return draw
 
 

@@ -1146,6 +1146,43 @@ def test_route_ahead_on_second_stream_gives_identical_gradients(dev, monkeypatch
         assert_grad_close(a, b, 1e-6, "captured route-ahead vs single-stream")
 
 
+def test_objective_formed_inside_the_loss_kernel_equals_get_loss_from_ret(dev):
+    """JointEncoding.forward also returns the weighted objective formed by the loss kernel ("_loss_total", the model's own
+    config weights); get_loss_from_ret hands it out when asked for exactly those weights with all four terms on.  Value
+    and gradients must equal the explicit weighted sum (other weights / a term switched off take the dot-product path)."""
+    from mipsfusion_amd.helper_functions.utils import get_loss_from_ret
+    g = load_golden("scene_cfg1.npz")
+    cfg = cfg_for("scene_cfg1.npz")
+    inputs = [T(g[k]).to(dev) for k in ("rays_o", "rays_d", "target_rgb", "target_d", "noise")]
+    tr = cfg["training"]
+
+    def run(how):
+        m = make_scene(g, cfg, dev).train()
+        ret = m.forward(*inputs[:4], noise=inputs[4])
+        assert "_loss_total" in ret
+        if how == "kernel":
+            loss = get_loss_from_ret(ret, tr)
+            assert loss is ret["_loss_total"]
+        elif how == "explicit":
+            loss = tr["rgb_weight"] * ret["rgb_loss"] + tr["depth_weight"] * ret["depth_loss"] + \
+                tr["sdf_weight"] * ret["sdf_loss"] + tr["fs_weight"] * ret["fs_loss"]
+        else:                                   # other weights: must NOT take the kernel's total
+            other = dict(tr, rgb_weight=tr["rgb_weight"] * 2.0)
+            loss = get_loss_from_ret(ret, other)
+            assert loss is not ret["_loss_total"]
+            return float(loss), None
+        loss.backward()
+        return float(loss), [p.grad.clone() for p in m.parameters() if p.numel()]
+
+    lk, gk = run("kernel")
+    le, ge = run("explicit")
+    lo, _ = run("other")
+    assert abs(lk - le) <= 2e-6 * abs(le), (lk, le)
+    assert abs(lo - le) > 1e-4 * abs(le)
+    for a, b in zip(gk, ge):
+        assert_grad_close(a, b, 1e-6, "objective from the kernel vs explicit weighted sum")
+
+
 def test_out_of_range_ray_index_is_loud(dev):
     """a bad keyframe id must not become a silent out-of-bounds read -- host index tensors raise
     IndexError like the reference's torch indexing, device-resident indices yield NaN rays."""
