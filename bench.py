@@ -238,13 +238,13 @@ class MappingLoop:
 
     def _iterate(self, rows, owner, noise, set_to_none):
         cfg = self.cfg
-        rays_d_cam, target_s, target_d = ops.gather_rays(self.table, rows, split=True)      # fresh rows of the ray table
         if self.torch_pose:
+            rays_d_cam, target_s, target_d = ops.gather_rays(self.table, rows, split=True)  # fresh rows of the ray table
             rays_d = torch.sum(rays_d_cam[..., None, :] * self.poses_all[owner, :3, :3], -1)
             rays_o = self.poses_all[owner, :3, -1]
-        else:   # same arithmetic, one kernel each way (gradients reach cur_rot / cur_trans through autograd)
-            rays_o, rays_d = ops.pose_rays(self.cur_rot, self.cur_trans, self.pose_fixed, owner, rays_d_cam,
-                                           accumulate_in_place=True)
+        else:   # fresh rows of the ray table + the same pose arithmetic in one kernel (the pose gradients go straight to .grad)
+            rays_o, rays_d, target_s, target_d = ops.gather_pose_rays(self.table, rows, self.cur_rot, self.cur_trans,
+                                                                      self.pose_fixed, owner, accumulate_in_place=True)
         ret = self.model.forward(rays_o, rays_d, target_s, target_d, noise=noise)
         loss = get_loss_from_ret(ret, cfg["training"])
         loss.backward(retain_graph=self.torch_pose)
@@ -766,7 +766,7 @@ def main():
                    "rays": N_RAYS, "samples_per_ray": N_SAMPLES, "hash_size": cfg["grid"]["hash_size"],
                    "parallelism": f"submap-per-gpu x{world}" if world > 1 else "single gpu",
                    "ray_build": "torch eager ops" if args.torch_pose else "fused pose_rays kernel",
-                   "host_cpus": f"{len(HOST_CPUS)} CPUs of one NUMA node ({HOST_CPUS[0]}..{HOST_CPUS[-1]})" if HOST_CPUS else "unconfined"},
+                   "host_cpus": f"{len(HOST_CPUS)} least-busy CPUs of one NUMA node ({HOST_CPUS[0]}..{HOST_CPUS[-1]})" if HOST_CPUS else "unconfined"},
         "forward_only": {"value": round(fwd_rate, 1), "unit": "rays*samples/s", "ms": round(fwd_ms, 4)},
         "roofline": roofline, "kernels": kernels,
     }

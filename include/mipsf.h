@@ -276,6 +276,13 @@ int mipsf_normalise_bwd(const float* dxn, const mipsf_render_cfg* cfg_host, floa
 int mipsf_pose_rays_fwd(const float* fixed_poses, const float* rot, const float* trans, uint32_t F, uint32_t K,
                         const int64_t* owner, const float* d_cam, float* rays_o, float* rays_d, uint32_t N,
                         void* stream);
+/* mipsf_gather_rays (split outputs) + mipsf_pose_rays_fwd in one launch: the rows idx[N] of the ray table db [n_rows,7]
+ * -> d_cam [N,3], rgb [N,3], depth [N] and the world rays of those directions under poses_all[owner]
+ * (keyframeSet.py:264-290 + mipsfusion.py:296-322). */
+int mipsf_gather_pose_rays_fwd(const float* db, uint64_t n_rows, const int64_t* idx, const float* fixed_poses,
+                               const float* rot, const float* trans, uint32_t F, uint32_t K, const int64_t* owner,
+                               float* d_cam, float* rgb, float* depth, float* rays_o, float* rays_d, uint32_t N,
+                               void* stream);
 /* d_rot [K,4], d_trans [K,3] are WRITTEN.  scratch: mipsf_pose_rays_scratch_floats(F, K, N) floats whose FIRST word
  * must be zero on entry (clear it once after allocating) and is zero again on return -- it is the ticket that lets
  * the last workgroup finish the reduction and the quaternion chain in the same launch; the rest needs no init. */

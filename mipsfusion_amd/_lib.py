@@ -116,6 +116,7 @@ SIGNATURES = {
     "mipsf_normalise_bwd": (_I, [_P, C.POINTER(RenderCfg), _P, _U32, _P]),
     "mipsf_pose_rays_fwd": (_I, [_P, _P, _P, _U32, _U32, _P, _P, _P, _P, _U32, _P]),
     "mipsf_pose_rays_bwd": (_I, [_P, _P, _P, _U32, _U32, _P, _P, _P, _P, _P, _U32, _P]),
+    "mipsf_gather_pose_rays_fwd": (_I, [_P, C.c_uint64, _P, _P, _P, _P, _U32, _U32, _P, _P, _P, _P, _P, _P, _U32, _P]),
     "mipsf_pose_rays_bwd_ex": (_I, [_P, _P, _P, _U32, _U32, _P, _P, _P, _P, _P, _U32, _I, _P]),
     "mipsf_pose_rays_scratch_floats": (_U64, [_U32, _U32, _U32]),
     "mipsf_adam_step": (_I, [_P, _P, _P, _P, _U64, _F, _F, _F, _F, _F, _U32, _I, _P]),

@@ -65,6 +65,38 @@ __global__ __launch_bounds__(PR_BLOCK) void pose_rays_fwd_kernel(const float* __
     }
 }
 
+// The row gather of the ray table (mipsf_gather_rays, ro.hip) and the ray construction in ONE launch: both are one
+// thread per ray and each was a 5 us launch of every iteration.  Writes d_cam / rgb / depth (the gather's outputs: d_cam
+// is what the backward needs) and rays_o / rays_d; same arithmetic and the same NaN conventions as the two kernels.
+__global__ __launch_bounds__(PR_BLOCK) void gather_pose_rays_fwd_kernel(
+    const float* __restrict__ db, uint64_t n_rows, const int64_t* __restrict__ idx, const float* __restrict__ fixed,
+    const float* __restrict__ rot, const float* __restrict__ trans, int F, int K, const int64_t* __restrict__ owner,
+    float* __restrict__ d_cam, float* __restrict__ rgb, float* __restrict__ depth, float* __restrict__ rays_o,
+    float* __restrict__ rays_d, uint32_t N) {
+    const uint32_t n = blockIdx.x * PR_BLOCK + threadIdx.x;
+    if (n >= N) return;
+    int64_t r = idx[n];
+    if (r < 0) r += (int64_t)n_rows;
+    const bool row_ok = r >= 0 && (uint64_t)r < n_rows;
+    const float* s = db + 7 * (size_t)(row_ok ? r : 0);
+    float v[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v[k] = row_ok ? s[k] : __builtin_nanf("");
+    d_cam[3 * (size_t)n] = v[0], d_cam[3 * (size_t)n + 1] = v[1], d_cam[3 * (size_t)n + 2] = v[2];
+    rgb[3 * (size_t)n] = v[3], rgb[3 * (size_t)n + 1] = v[4], rgb[3 * (size_t)n + 2] = v[5];
+    depth[n] = v[6];
+    int64_t p = owner[n];
+    if (p < 0) p += F + K;
+    const bool in_range = p >= 0 && p < F + K;
+    const Mat34 m = load_pose(fixed, rot, trans, F, in_range ? (int)p : 0);
+    const float dx = in_range ? v[0] : __builtin_nanf(""), dy = v[1], dz = v[2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        rays_d[3 * n + j] = (dx * m.r[3 * j] + dy * m.r[3 * j + 1]) + dz * m.r[3 * j + 2];
+        rays_o[3 * n + j] = m.t[j];
+    }
+}
+
 // chain through R(q) = I + s A(q), s = 2/|q|^2 (pytorch3d quaternion_to_matrix, not assuming unit norm);
 // G = {dR (9, row-major), dt (3)} of optimisable pose k
 __device__ __forceinline__ void pose_chain(const float* __restrict__ rot, const float* G, int k,
@@ -192,6 +224,20 @@ int mipsf_pose_rays_fwd(const float* fixed_poses, const float* rot, const float*
     hipLaunchKernelGGL(pose_rays_fwd_kernel, dim3((N + PR_BLOCK - 1) / PR_BLOCK), dim3(PR_BLOCK), 0,
                        (hipStream_t)stream, fixed_poses, rot, trans, (int)F, (int)K, owner, d_cam, rays_o, rays_d, N);
     return check_launch("pose_rays_fwd");
+}
+
+int mipsf_gather_pose_rays_fwd(const float* db, uint64_t n_rows, const int64_t* idx, const float* fixed_poses,
+                               const float* rot, const float* trans, uint32_t F, uint32_t K, const int64_t* owner,
+                               float* d_cam, float* rgb, float* depth, float* rays_o, float* rays_d, uint32_t N,
+                               void* stream) {
+    if (N == 0) return 0;
+    MIPSF_REQUIRE(db && idx && owner && d_cam && rgb && depth && rays_o && rays_d, "null pointer");
+    MIPSF_REQUIRE((F == 0 || fixed_poses) && (K == 0 || (rot && trans)), "null pose pointer");
+    MIPSF_REQUIRE(F + K >= 1 && F + K <= PR_MAX_POSES, "number of poses %u outside [1,%d]", F + K, PR_MAX_POSES);
+    hipLaunchKernelGGL(gather_pose_rays_fwd_kernel, dim3((N + PR_BLOCK - 1) / PR_BLOCK), dim3(PR_BLOCK), 0,
+                       (hipStream_t)stream, db, n_rows, idx, fixed_poses, rot, trans, (int)F, (int)K, owner, d_cam, rgb,
+                       depth, rays_o, rays_d, N);
+    return check_launch("gather_pose_rays_fwd");
 }
 
 uint64_t mipsf_pose_rays_scratch_floats(uint32_t F, uint32_t K, uint32_t N) {

@@ -460,25 +460,46 @@ class PoseRaysFn(torch.autograd.Function):
     ``qt_to_transform_matrix`` + ``poses_all[owner]`` gather + ``sum(d_cam * R, -1)`` (mipsfusion.py:320-322)."""
 
     @staticmethod
-    def forward(ctx, rot, trans, fixed, owner, d_cam, in_place=False):
+    def forward(ctx, rot, trans, fixed, owner, d_cam, in_place=False, table=None, rows=None):
+        """table / rows given: d_cam is None and the rows of the ray table are gathered in the same launch
+        (-> rays_o, rays_d, rgb, depth [N,1])."""
         ctx.params = (rot, trans) if in_place else None
-        rot, trans, d_cam = _f32c(rot), _f32c(trans), _f32c(d_cam)
+        rot, trans = _f32c(rot), _f32c(trans)
         fixed = _f32c(fixed) if fixed is not None and fixed.numel() else None
         owner = owner.to(torch.int64).contiguous()
         F = 0 if fixed is None else fixed.shape[0]
-        K, N = rot.shape[0], d_cam.shape[0]
-        rays_o = torch.empty((N, 3), dtype=torch.float32, device=d_cam.device)
-        rays_d = torch.empty((N, 3), dtype=torch.float32, device=d_cam.device)
+        K = rot.shape[0]
+        dev = rot.device
+        if table is not None:
+            flat = table.reshape(-1, 7)
+            N = rows.shape[0]
+            d_cam = torch.empty((N, 3), dtype=torch.float32, device=dev)
+            rgb = torch.empty((N, 3), dtype=torch.float32, device=dev)
+            depth = torch.empty((N, 1), dtype=torch.float32, device=dev)
+        else:
+            d_cam = _f32c(d_cam)
+            N = d_cam.shape[0]
+        rays_o = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        rays_d = torch.empty((N, 3), dtype=torch.float32, device=dev)
         with _timed("pose_rays_fwd"):
-            check(lib().mipsf_pose_rays_fwd(dptr(fixed), dptr(rot), dptr(trans), F, K, dptr(owner, torch.int64),
-                                            dptr(d_cam), dptr(rays_o), dptr(rays_d), N, stream_ptr()), "pose_rays_fwd")
+            if table is not None:
+                check(lib().mipsf_gather_pose_rays_fwd(dptr(flat), flat.shape[0], dptr(rows, torch.int64), dptr(fixed),
+                                                       dptr(rot), dptr(trans), F, K, dptr(owner, torch.int64), dptr(d_cam),
+                                                       dptr(rgb), dptr(depth), dptr(rays_o), dptr(rays_d), N, stream_ptr()),
+                      "gather_pose_rays_fwd")
+            else:
+                check(lib().mipsf_pose_rays_fwd(dptr(fixed), dptr(rot), dptr(trans), F, K, dptr(owner, torch.int64),
+                                                dptr(d_cam), dptr(rays_o), dptr(rays_d), N, stream_ptr()), "pose_rays_fwd")
         ctx.F, ctx.K, ctx.N = F, K, N
         ctx.save_for_backward(rot, owner, d_cam)
         ctx.set_materialize_grads(False)
+        if table is not None:
+            ctx.mark_non_differentiable(rgb, depth)
+            return rays_o, rays_d, rgb, depth
         return rays_o, rays_d
 
     @staticmethod
-    def backward(ctx, g_o, g_d):
+    def backward(ctx, g_o, g_d, _g_rgb=None, _g_depth=None):
         rot, owner, d_cam = ctx.saved_tensors
         scratch = _pose_scratch(rot.device, ctx.F, ctx.K, ctx.N)
         g_o = _f32c(g_o) if g_o is not None else None
@@ -501,8 +522,8 @@ class PoseRaysFn(torch.autograd.Function):
                                                dptr(d_cam), dptr(d_rot), dptr(d_trans), dptr(scratch), ctx.N,
                                                1 if direct else 0, stream_ptr()), "pose_rays_bwd")
         if direct:
-            return None, None, None, None, None, None
-        return d_rot, d_trans, None, None, None, None
+            return None, None, None, None, None, None, None, None
+        return d_rot, d_trans, None, None, None, None, None, None
 
 
 def pose_rays(rot, trans, fixed_poses, owner, d_cam, accumulate_in_place=False):
@@ -511,6 +532,12 @@ def pose_rays(rot, trans, fixed_poses, owner, d_cam, accumulate_in_place=False):
     ``loss.backward()`` accumulation loops, ignored for non-leaf / hooked parameters): the backward adds the pose
     gradients straight into ``rot.grad`` / ``trans.grad``."""
     return PoseRaysFn.apply(rot, trans, fixed_poses, owner, d_cam, accumulate_in_place)
+
+
+def gather_pose_rays(table, rows, rot, trans, fixed_poses, owner, accumulate_in_place=False):
+    """``gather_rays(table, rows, split=True)`` + ``pose_rays(...)`` in one launch (each is a 5 us launch of every
+    iteration): rows int64 [N] (device) of the ray table [..., 7] -> rays_o, rays_d, target rgb [N,3], target depth [N,1]."""
+    return PoseRaysFn.apply(rot, trans, fixed_poses, owner, None, accumulate_in_place, table, rows.to(torch.int64).contiguous())
 
 
 # ----------------------------------------------------------------------------------- Adam

@@ -105,7 +105,11 @@ class ReferenceSampleProducer:
         self.slots = [FrameSamples(self.n_track, self.it_track, n_ba_max, self.it_ba, self.S, pinned) for _ in range(slots)]
         self._next = 0
         self._order: "queue.Queue[FrameSamples]" = queue.Queue()
-        self._q_torch, self._q_topk, self._q_py = queue.Queue(), queue.Queue(), queue.Queue()
+        # per-pixel score draws go into a ring of preallocated buffers (see sampling_helper.draw_pixel_scores); the bounded
+        # queue keeps the generator stage from lapping the top-k stage
+        self._draw_bufs = [torch.empty(H * W, dtype=torch.float32) for _ in range(self.it_ba + 3)]
+        self._draw_next = 0
+        self._q_torch, self._q_topk, self._q_py = queue.Queue(), queue.Queue(maxsize=len(self._draw_bufs) - 2), queue.Queue()
         self._index_db = DeviceRayDB.__new__(DeviceRayDB)       # index arithmetic only (no storage, no gather)
         self._index_db.num_rays_to_save = rays_per_kf
         self._lattice_track = (cfg["sampling"]["n_rays_h"], cfg["sampling"]["n_rays_w"]) if "sampling" in cfg else \
@@ -170,6 +174,13 @@ class ReferenceSampleProducer:
             q.put(None)
         sys.setswitchinterval(self._switch_interval)
 
+    def _next_draw_buf(self, depth):
+        if depth.numel() != self._draw_bufs[0].numel() or depth.dtype != torch.float32:
+            return None                                       # unexpected image: a fresh tensor, as the reference does
+        b = self._draw_bufs[self._draw_next % len(self._draw_bufs)]
+        self._draw_next += 1
+        return b
+
     # ------------------------------------------------------------------------------------------- the three stages
     def _torch_stream(self):
         """torch's default CPU generator, in the reference's call order."""
@@ -193,13 +204,14 @@ class ReferenceSampleProducer:
                 continue
             if plan.track:
                 if not iter_ro0:                                    # sample_pixels_mix (mipsfusion.py:519-523)
-                    self._q_topk.put((plan, s, "track", 0, sh.draw_pixel_scores(plan.depth)))
+                    self._q_topk.put((plan, s, "track", 0, sh.draw_pixel_scores(plan.depth, out=self._next_draw_buf(plan.depth))))
                 for i in range(self.it_track):                      # scene_rep.py:176, one draw per forward
                     torch.rand(self.n_track, self.S, out=s.track_noise[i])
             if plan.ba_kf_ids is not None:
                 n = s.n_ba
                 for i in range(self.it_ba):
-                    self._q_topk.put((plan, s, "ba", i, sh.draw_pixel_scores(plan.depth)))   # :302 / :306-307
+                    draw = sh.draw_pixel_scores(plan.depth, out=self._next_draw_buf(plan.depth))   # :302 / :306-307
+                    self._q_topk.put((plan, s, "ba", i, draw))
                     torch.rand(n, self.S, out=s.ba_noise[i, :n])
             self.host_ms["torch_rng"] += (time.perf_counter() - t0) * 1e3
             s._part_done()
@@ -425,9 +437,9 @@ class GraphedSequence:
         tcfg, mp = self.cfg["training"], self.cfg["mapping"]
 
         def step(k):
-            d_cam, rgb, depth = ops.gather_rays(self.table, self.ba_rows[k, :n].contiguous(), split=True)
-            rays_o, rays_d = ops.pose_rays(self.ba_rot, self.ba_trans, self.fixed, self.ba_owner[k, :n].contiguous(), d_cam,
-                                           accumulate_in_place=True)
+            rays_o, rays_d, rgb, depth = ops.gather_pose_rays(self.table, self.ba_rows[k, :n].contiguous(), self.ba_rot,
+                                                              self.ba_trans, self.fixed, self.ba_owner[k, :n].contiguous(),
+                                                              accumulate_in_place=True)
             ret = self.model.forward(rays_o, rays_d, rgb, depth, noise=self.ba_noise[k, :n].contiguous())
             get_loss_from_ret(ret, tcfg).backward()
             self.map_opt.step(zero_grad=True)
@@ -436,8 +448,8 @@ class GraphedSequence:
         return step
 
     def _go_step(self, k):
-        d_cam, rgb, depth = ops.gather_rays(self.cur, self.go_idx, split=True)
-        rays_o, rays_d = ops.pose_rays(self.go_rot, self.go_trans, None, self.go_own, d_cam, accumulate_in_place=True)
+        rays_o, rays_d, rgb, depth = ops.gather_pose_rays(self.cur, self.go_idx, self.go_rot, self.go_trans, None,
+                                                          self.go_own, accumulate_in_place=True)
         ret = self.model.forward(rays_o, rays_d, rgb, depth, EMD_w=0., noise=self.go_noise[k])
         get_loss_from_ret(ret, self.cfg["training"]).backward()
         self.go_popt.step(zero_grad=True)

@@ -608,6 +608,20 @@ def test_pose_rays_matches_torch_composition(dev):
         (ro6 * go).sum().add((rd6 * gd).sum()).backward()
     assert_close(rot_i.grad, 2 * rot_b.grad, 2e-5, "d quaternion, accumulated in place twice")
     assert_close(trans_i.grad, 2 * trans_b.grad, 2e-5, "d translation, accumulated in place twice")
+    # gather of the ray table's rows + ray construction in one launch == the two separate ops, forward and backward
+    table = torch.randn(50, 60, 7, device=dev)
+    rows_t = torch.randint(-3000, 3000, (N,), device=dev)
+    rot_g, trans_g = rot0.clone().requires_grad_(True), trans0.clone().requires_grad_(True)
+    ro7, rd7, rgb7, dep7 = ops.gather_pose_rays(table, rows_t, rot_g, trans_g, fixed, owner)
+    dc, rgb_ref, dep_ref = ops.gather_rays(table, rows_t, split=True)
+    rot_h, trans_h = rot0.clone().requires_grad_(True), trans0.clone().requires_grad_(True)
+    ro8, rd8 = ops.pose_rays(rot_h, trans_h, fixed, owner, dc)
+    assert torch.equal(rgb7, rgb_ref) and torch.equal(dep7, dep_ref)
+    assert torch.equal(ro7, ro8) and torch.equal(rd7, rd8)
+    (ro7 * go).sum().add((rd7 * gd).sum()).backward()
+    (ro8 * go).sum().add((rd8 * gd).sum()).backward()
+    assert_close(rot_g.grad, rot_h.grad, 1e-6, "d quaternion, fused gather + pose rays")
+    assert_close(trans_g.grad, trans_h.grad, 1e-6, "d translation, fused gather + pose rays")
     # a batch of 40 000 rays: many workgroups (per-workgroup partial rows + ticket)
     Nb = 40000
     owner_b = torch.randint(0, F + K, (Nb,), device=dev)
