@@ -94,10 +94,16 @@ class _QueryFn(torch.autograd.Function):
             raise RuntimeError('decoder_precision "f16" is forward-only (use "f16x3" or "f32" when gradients are needed)')
         # one operand-image buffer per arithmetic: `packed` (fp32 images) or `packed16` (f16 hi/lo images, forward and
         # backward chain); it is saved for the backward under the same name
-        if prec == "f32":
-            packed, packed16 = ops.decoder_pack(weights), None
+        cache = owner._frozen_pack                  # see JointEncoding.frozen_weights(): the map does not change in here
+        if cache is not None and prec in cache:
+            packed, packed16 = cache[prec]
         else:
-            packed, packed16 = None, ops.decoder_pack16(weights)
+            if prec == "f32":
+                packed, packed16 = ops.decoder_pack(weights), None
+            else:
+                packed, packed16 = None, ops.decoder_pack16(weights)
+            if cache is not None:
+                cache[prec] = (packed, packed16)
         # lean record: when the weight gradients will come from the streaming f16 kernel (the default behind the f16x3
         # chain) H1 is recomputed there from x and the forward does not write it (a third of the record)
         lean = bool(need and prec == "f16x3" and owner.wgrad_precision in ("auto", "stream_f16x3") and owner.lean_record)
@@ -222,6 +228,7 @@ class JointEncoding(nn.Module):
         # beside the persistent decoder forward, take 211 us instead of 70 and slow that kernel from 99 to 137 us -- the
         # step gets 40 us LONGER (0.88 -> 0.92 ms).  It pays only where the forward leaves CUs idle.
         self.route_ahead = False
+        self._frozen_pack = None
         self._tables = {}
         self.get_resolution()
         self.get_encoding(config)
@@ -291,6 +298,7 @@ class JointEncoding(nn.Module):
         new.wgrad_precision = self.wgrad_precision
         new.lean_record = self.lean_record
         new.route_ahead = self.route_ahead
+        new._frozen_pack = None
         new.train(self.training)
         return new
 
@@ -367,6 +375,13 @@ class JointEncoding(nn.Module):
         res = _RenderFn.apply(raw, z_vals, trgb, td if train else None, counts if train else None, rc, N, S, train,
                               self._objective_weights(raw.device) if train else None)
         return res, z_vals, raw.reshape(N, S, 10)
+
+    def frozen_weights(self, begin: bool):
+        """``frozen_weights(True)`` ... ``frozen_weights(False)`` brackets a stretch in which the decoder's weights do not
+        change (the tracking iterations of a frame: pose-only optimisation, mipsfusion.py:456-575): the operand images
+        are packed by the first forward inside and reused by the others (a 5 us launch per iteration otherwise; inside a
+        captured tracking graph the pack is then recorded once per replay)."""
+        self._frozen_pack = {} if begin else None
 
     def _objective_weights(self, device):
         """(rgb, depth, sdf, fs) weights of config["training"] as a device tensor, or None when the config has none: the

@@ -431,6 +431,8 @@ class GraphedSequence:
         if torch.cuda.is_available():
             self._qt_host = self._qt_host.pin_memory()
         self._qt_next = 0
+        self._score_bufs = {}
+        self._lattice_dev = {}
 
     # ------------------------------------------------------------------------------------- captured iterations
     def _ba_step_fn(self, n):
@@ -448,11 +450,15 @@ class GraphedSequence:
         return step
 
     def _go_step(self, k):
+        if k == 0:
+            self.model.frozen_weights(True)          # the map is frozen for the frame's tracking iterations: one pack
         rays_o, rays_d, rgb, depth = ops.gather_pose_rays(self.cur, self.go_idx, self.go_rot, self.go_trans, None,
                                                           self.go_own, accumulate_in_place=True)
         ret = self.model.forward(rays_o, rays_d, rgb, depth, EMD_w=0., noise=self.go_noise[k])
         get_loss_from_ret(ret, self.cfg["training"]).backward()
         self.go_popt.step(zero_grad=True)
+        if k == self.cfg["tracking"]["iter"] - 1:
+            self.model.frozen_weights(False)
 
     def _ba_graph(self, n):
         g = self.ba_graphs.get(n)
@@ -464,18 +470,34 @@ class GraphedSequence:
         return g
 
     # --------------------------------------------------------------------------------------------- device sampler
+    def _scratch(self, rows, n):
+        """persistent score buffer [rows, n]: a fresh 17 MB temporary (three of them) per BA round made the caching
+        allocator release and re-request device memory -- milliseconds of host stall per round"""
+        buf = self._score_bufs.get((rows, n))
+        if buf is None:
+            buf = self._score_bufs[(rows, n)] = torch.empty(rows, n, dtype=torch.float32, device=self.dev)
+        return buf
+
     def _device_draw(self, population, k, rows=1):
         """k distinct integers of range(population) per row, uniformly: top-k of i.i.d. uniforms (no replacement)."""
-        return torch.rand(rows, population, device=self.dev).topk(k, dim=1).indices
+        return self._scratch(rows, population).uniform_().topk(k, dim=1).indices
 
     def _device_valid_pixels(self, k, rows, lattice=None):
         """sample_pixels_mix's distribution on the device: `rows` independent draws of k distinct VALID-depth pixels
         (|N(0,1)| scores, invalid and lattice pixels score 0: sampling_helper.py:28-32, 53-68)."""
         valid = (self.cur[:, 6] > 0).float()
         if lattice is not None:
-            valid = valid.clone()
             valid[lattice] = 0
-        return (valid[None] * torch.randn(rows, valid.shape[0], device=self.dev).abs()).topk(k, dim=1).indices
+        scores = self._scratch(rows, valid.shape[0]).normal_().abs_().mul_(valid[None])
+        return scores.topk(k, dim=1).indices
+
+    def _lattice(self, n_rows, n_cols):
+        """flat pixel indices of the uniform lattice (sample_pixels_uniformly), on the device, built once"""
+        lat = self._lattice_dev.get((n_rows, n_cols))
+        if lat is None:
+            rows, cols = sh.sample_pixels_uniformly(self.H, self.W, n_rows, n_cols)
+            lat = self._lattice_dev[(n_rows, n_cols)] = (rows * self.W + cols).to(self.dev)
+        return lat
 
     def _fill_ba_device(self, K, cur_is_first):
         n_kf, n_cur = ba_ray_counts(self.cfg, K)
@@ -497,8 +519,7 @@ class GraphedSequence:
                 idx.append(self._device_draw(R, n_last, it) + (K - 1) * R)
                 own.append(torch.full((it, n_last), K - 1, dtype=torch.int64, device=self.dev))
         tk = self.cfg["tracking"]
-        rows, cols = sh.sample_pixels_uniformly(self.H, self.W, tk["RO"]["n_rows"], tk["RO"]["n_cols"])
-        lat = (rows * self.W + cols).to(self.dev)
+        lat = self._lattice(tk["RO"]["n_rows"], tk["RO"]["n_cols"])
         extra = self._device_valid_pixels(n_cur - lat.shape[0], it, lattice=lat)
         idx.append(torch.cat([lat[None].expand(it, -1), extra], 1) + self.Kmax * R)
         own.append(torch.full((it, n_cur), 0 if cur_is_first else -1, dtype=torch.int64, device=self.dev))
@@ -509,8 +530,7 @@ class GraphedSequence:
 
     def _fill_go_device(self):
         s = self.cfg.get("sampling", {"n_rays_h": self.cfg["tracking"]["RO"]["n_rows"], "n_rays_w": self.cfg["tracking"]["RO"]["n_cols"]})
-        rows, cols = sh.sample_pixels_uniformly(self.H, self.W, s["n_rays_h"], s["n_rays_w"])
-        lat = (rows * self.W + cols).to(self.dev)
+        lat = self._lattice(s["n_rays_h"], s["n_rays_w"])
         extra = self._device_valid_pixels(self.n_track - lat.shape[0], 1, lattice=lat)[0]
         self.go_idx.copy_(torch.cat([lat, extra]))
         self.go_noise.uniform_()
@@ -599,8 +619,16 @@ class GraphedSequence:
         n_frames = len(self.frames)
         est = [self.first_frame(gt_poses[0])]
         if precapture:       # capture every BA graph shape of the sequence up front (one-off cost, reported separately)
-            for K in sorted({self._n_kf_at(k) for k in range(1, n_frames) if k % mp["map_every"] == 0}):
+            Ks = sorted({self._n_kf_at(k) for k in range(1, n_frames) if k % mp["map_every"] == 0})
+            for K in Ks:
                 self._ba_graph(sum(ba_ray_counts(cfg, K)))
+            if self.producer is None:
+                # the device sampler's draws have shapes that depend on K: torch's first top-k / index op of a new shape
+                # costs 10-70 ms (measured: 72 ms in the first BA round after a keyframe was added).  AFTER the captures:
+                # their warm-up iterations train on whatever the index buffers hold, which must stay frame 0's rows.
+                for K in Ks:
+                    self._fill_ba_device(K, False)
+            torch.cuda.synchronize()
         if self.producer is not None:
             for j in range(1, min(n_frames, 1 + self.lookahead)):
                 self.producer.submit(self._plan(j))
