@@ -241,6 +241,8 @@ def decoder_fwd(packed, feat, layout, x, embed_pos, M, save, precision: str = "f
         with _timed("decoder_fwd"):
             check(lib().mipsf_decoder_fwd16_ex(dptr(packed16), dptr(feat), layout, dptr(x), dptr(out), dptr(saved), 0,
                                                _lib.PREC[precision], 1 if lean else 0, M, stream_ptr()), "decoder_fwd16")
+        if lean:
+            saved.mipsf_lean_record = True          # decoder_bwd refuses to read H1 from such a record
         return out, saved
     pe_mode = 0 if embed_pos is None else 1
     with _timed("decoder_fwd"):
@@ -265,6 +267,11 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
     forward kept the lean record (``decoder_fwd(save="lean")``), bit-identical otherwise."""
     if wgrad_precision == "auto":
         wgrad_precision = "stream_f16x3" if (precision == "f16x3" and embed_pos is None) else "f32"
+    if getattr(saved, "mipsf_lean_record", False) and grads is not None:
+        if wgrad_precision != "stream_f16x3" or packed16 is None:
+            raise RuntimeError("this activation record was saved lean (no H1): the weight gradients need "
+                               "wgrad_precision='stream_f16x3' with packed16 (H1 is recomputed from x)")
+        recompute_h1 = True
     dev = x.device
     dfeat = torch.empty_like(feat)
     dx = torch.empty((M, 3), dtype=torch.float32, device=dev)

@@ -1331,6 +1331,9 @@ def test_decoder_f16x3_backward_chain_matches_fp32_kernel(dev, M, layout):
                     wgrad_precision="stream_f16x3", recompute_h1=True)
     ops.decoder_bwd(None, feat, lay, x, None, outl, dout, savedl, g_lean, M, precision="f16x3", packed16=packed16,
                     wgrad_precision="stream_f16x3", recompute_h1=True)
+    with pytest.raises(RuntimeError, match="lean"):            # a kernel that reads H1 must refuse the lean record
+        ops.decoder_bwd(None, feat, lay, x, None, outl, dout, savedl, [torch.zeros_like(w) for w in ws], M,
+                        precision="f16x3", packed16=packed16, wgrad_precision="f32")
     for k, a, b, c in zip(ops.DECODER_PARAM_ORDER, g_full, g_rc, g_lean):
         assert_close(b, a, 1e-6, "recomputed H1 vs stored H1, grad " + k)
         assert_close(c, b, 1e-6, "lean record vs full record (H1 is not read either way), grad " + k)
