@@ -81,10 +81,16 @@ def confine_to_numa_node(max_cpus=32, local_rank=0, local_world=1, avoid_busy=Tr
         return None
     per_node = max(1, -(-local_world // len(nodes)))              # ranks that share a node
     if local_world > 1:
+        # ranks sharing a node split its PHYSICAL cores (both hardware threads of a core go to the same rank)
         node = nodes[(local_rank // per_node) % len(nodes)]
-        width = min(max_cpus, max(1, len(node) // per_node))
-        first = (local_rank % per_node) * width
-        cpus = node[first:first + width] or node[:width]
+        cores = {}
+        for c in node:
+            cores.setdefault(min(_siblings(c)), []).append(c)
+        keys = sorted(cores)
+        n_cores = max(1, len(keys) // per_node)
+        first = (local_rank % per_node) * n_cores
+        mine = keys[first:first + n_cores] or keys[:n_cores]
+        cpus = sorted(c for k in mine for c in cores[k])[:max(max_cpus, 1)]
     else:
         # one logical CPU per PHYSICAL core (two busy threads on SMT siblings run ~35 % slower each), the cores whose
         # both hardware threads were least busy
