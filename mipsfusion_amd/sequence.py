@@ -34,7 +34,7 @@ from typing import Dict, List, NamedTuple, Optional
 import numpy as np
 import torch
 
-from . import ops
+from . import hostrng, ops
 from .helper_functions import sampling_helper as sh
 from .helper_functions.geometry_helper import matrix_to_quaternion, qt_to_transform_matrix
 from .helper_functions.utils import get_loss_from_ret
@@ -132,6 +132,7 @@ class ReferenceSampleProducer:
         # while the consumer waits for the GPU (GraphedSequence.run opens the gate around its blocking read-backs).
         self.gate = threading.Event()
         self.gate.set()
+        hostrng.available()                  # (its one-off self-check borrows the default generator: before the stages run)
         for t in self._threads:
             t.start()
         self.host_ms = {"torch_rng": 0.0, "topk": 0.0, "python_rng": 0.0}
@@ -196,25 +197,38 @@ class ReferenceSampleProducer:
                 return
             plan, s = item
             t0 = time.perf_counter()
+            # the draws below go through the C replica of torch's CPU generator (mipsfusion_amd/hostrng.py: same stream,
+            # same bits, checked against torch at start-up, torch's own functions otherwise): 0.55 instead of 1.5-2.3 ms
+            # per mapping iteration of this serial stage
+            rng = hostrng.session()
+            g = rng.__enter__()
             if _DIAG_OFF == "torch":                                # diagnosis only (tools/micro): skip the draws
                 n_items = (1 if plan.track and not iter_ro0 else 0) + (self.it_ba if plan.ba_kf_ids is not None else 0)
                 for _ in range(n_items):
                     s._part_done()
                 s._part_done()
+                rng.__exit__(None, None, None)
                 continue
             if plan.track:
                 if not iter_ro0:                                    # sample_pixels_mix (mipsfusion.py:519-523)
-                    self._q_topk.put((plan, s, "track", 0, sh.draw_pixel_scores(plan.depth, out=self._next_draw_buf(plan.depth))))
+                    self._q_topk.put((plan, s, "track", 0, self._draw_scores(g, plan.depth)))
                 for i in range(self.it_track):                      # scene_rep.py:176, one draw per forward
-                    torch.rand(self.n_track, self.S, out=s.track_noise[i])
+                    g.rand_(s.track_noise[i])
             if plan.ba_kf_ids is not None:
                 n = s.n_ba
                 for i in range(self.it_ba):
-                    draw = sh.draw_pixel_scores(plan.depth, out=self._next_draw_buf(plan.depth))   # :302 / :306-307
-                    self._q_topk.put((plan, s, "ba", i, draw))
-                    torch.rand(n, self.S, out=s.ba_noise[i, :n])
+                    self._q_topk.put((plan, s, "ba", i, self._draw_scores(g, plan.depth)))   # :302 / :306-307
+                    g.rand_(s.ba_noise[i, :n])
+            rng.__exit__(None, None, None)
             self.host_ms["torch_rng"] += (time.perf_counter() - t0) * 1e3
             s._part_done()
+
+    def _draw_scores(self, g, depth):
+        """sampling_helper.draw_pixel_scores (torch.randn_like of the depth image) into the next ring buffer"""
+        buf = self._next_draw_buf(depth)
+        if buf is None:                                       # unexpected image size / dtype: torch's own draw
+            return g.through_torch(lambda: sh.draw_pixel_scores(depth))
+        return g.randn_(buf)
 
     def _topk_stage(self):
         """Generator-free half of the valid-pixel samplers: mask, lattice blocking, top-k."""

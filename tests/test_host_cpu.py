@@ -275,3 +275,53 @@ def test_host_pose_algebra_in_numpy_equals_the_torch_helpers():
         q_np = torch.from_numpy(_matrix_to_quaternion_np(T_ref[:3, :3].numpy()))
         worst = max(worst, float((T_np - T_ref).abs().max()), float((q_np - q_ref).abs().max()))
     assert worst <= 2.4e-7, worst
+
+
+def _hostrng_or_skip():
+    from mipsfusion_amd import hostrng
+    if not os.path.exists(hostrng._LIB_PATH):
+        pytest.skip("libmipsf_hostrng.so not built (make -C mipsfusion_amd/csrc)")
+    return hostrng
+
+
+@pytest.mark.parametrize("n", [16, 17, 31, 32, 100, 4099, 65539, 285200])
+def test_host_rng_replica_draws_what_torch_draws(n):
+    """mipsfusion_amd.hostrng: `randn_` / `rand_` fill the values torch's default CPU generator would (torch.randn_like of
+    sampling_helper.py:30/:62, torch.rand of scene_rep.py:176), bit for bit, for sizes with and without the ragged tail
+    of torch's 16-wide normal fill, over interleaved calls; and hand torch back the state it would be in."""
+    hostrng = _hostrng_or_skip()
+    assert hostrng.available(), "the replica no longer matches this torch build (tools/micro/randn_match.py)"
+    for seed in (0, 1, 20240917):
+        torch.manual_seed(seed)
+        want = [torch.empty(n).normal_(), torch.empty(3, 77).uniform_(), torch.empty(n).normal_(),
+                torch.empty(5).normal_(), torch.empty(1000).uniform_()]
+        want_state = torch.get_rng_state()
+        after = torch.rand(4)
+        torch.manual_seed(seed)
+        with hostrng.session() as g:
+            assert g.native
+            got = [g.randn_(torch.empty(n)), g.rand_(torch.empty(3, 77)), g.randn_(torch.empty(n)),
+                   g.randn_(torch.empty(5)), g.rand_(torch.empty(1000))]
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+        assert torch.equal(torch.get_rng_state(), want_state)
+        assert torch.equal(torch.rand(4), after)
+
+
+def test_host_rng_refuses_what_it_cannot_fill_and_falls_back_without_the_library(monkeypatch):
+    hostrng = _hostrng_or_skip()
+    with hostrng.session() as g:
+        with pytest.raises(ValueError):
+            g.rand_(torch.empty(8, 8)[:, ::2])                  # not contiguous
+        with pytest.raises(ValueError):
+            g.randn_(torch.empty(64, dtype=torch.float64))
+        torch.manual_seed(3)
+    # the same calls without the replica are torch's own functions (a torch build the self-check rejects, no library)
+    monkeypatch.setattr(hostrng, "_ok", False)
+    torch.manual_seed(5)
+    want = (torch.empty(100).normal_(), torch.empty(10).uniform_())
+    torch.manual_seed(5)
+    with hostrng.session() as g:
+        assert not g.native
+        got = (g.randn_(torch.empty(100)), g.rand_(torch.empty(10)))
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
