@@ -175,4 +175,52 @@ int mipsf_mt_normal_f32(mipsf_mt* g, float* out, int64_t n, int threads) {
     return 0;
 }
 
-int mipsf_hostrng_abi(void) { return 1; }
+/* ------------------------------------------------------------------------------------------------------------------
+ * python's `random.sample(range(n), k)` (CPython 3.10 Lib/random.py: Random.sample, _randbelow_with_getrandbits;
+ * Modules/_randommodule.c: getrandbits(b <= 32) = genrand_uint32() >> (32 - b)) -- the keyframe-ray draws of every
+ * mapping iteration (keyframeSet.py:386-436).  Here g->next is python's `index` into the state (state[624] of
+ * random.getstate()); `left` is unused.  scratch: n int64 (pool branch) or n bytes (set branch) -- n * 8 bytes cover both.
+ * Returns 0, -1 for arguments python would refuse or that exceed this replica (n >= 2^32).                           */
+static inline uint32_t py_genrand(mipsf_mt* g) {
+    if (g->next >= MT_N) mt_next_state(g);
+    uint32_t y = g->state[g->next++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+static inline int64_t py_randbelow(mipsf_mt* g, int64_t n) {       /* n >= 1 */
+    int bits = 64 - __builtin_clzll((unsigned long long)n);          /* n.bit_length() */
+    uint32_t r = py_genrand(g) >> (32 - bits);
+    while ((int64_t)r >= n) r = py_genrand(g) >> (32 - bits);
+    return (int64_t)r;
+}
+
+int mipsf_py_sample_range(mipsf_mt* g, int64_t n, int64_t k, int64_t* out, void* scratch) {
+    if (k < 0 || k > n || n >= ((int64_t)1 << 32)) return -1;
+    double setsize = 21.0;
+    if (k > 5) setsize += pow(4.0, ceil(log((double)(k * 3)) / log(4.0)));      /* 4 ** _ceil(_log(k * 3, 4)) */
+    if ((double)n <= setsize) {
+        int64_t* pool = (int64_t*)scratch;
+        for (int64_t i = 0; i < n; ++i) pool[i] = i;
+        for (int64_t i = 0; i < k; ++i) {
+            const int64_t j = py_randbelow(g, n - i);
+            out[i] = pool[j];
+            pool[j] = pool[n - i - 1];
+        }
+    } else {
+        uint8_t* selected = (uint8_t*)scratch;
+        memset(selected, 0, (size_t)n);
+        for (int64_t i = 0; i < k; ++i) {
+            int64_t j = py_randbelow(g, n);
+            while (selected[j]) j = py_randbelow(g, n);
+            selected[j] = 1;
+            out[i] = j;
+        }
+    }
+    return 0;
+}
+
+int mipsf_hostrng_abi(void) { return 2; }

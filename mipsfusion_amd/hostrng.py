@@ -15,6 +15,7 @@ order, which is the point of running it on one thread)."""
 import contextlib
 import ctypes as C
 import os
+import random
 
 import numpy as np
 import torch
@@ -33,6 +34,8 @@ class _MT(C.Structure):
 
 _lib = None
 _ok = None
+_topk_ok = None
+_py_ok = None
 
 
 def _load():
@@ -43,6 +46,11 @@ def _load():
         lib.mipsf_mt_uniform_f32.restype = None
         lib.mipsf_mt_normal_f32.argtypes = [C.POINTER(_MT), C.c_void_p, C.c_int64, C.c_int]
         lib.mipsf_mt_normal_f32.restype = C.c_int
+        lib.mipsf_topk_valid_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                                C.c_void_p]
+        lib.mipsf_topk_valid_scores.restype = C.c_int
+        lib.mipsf_py_sample_range.argtypes = [C.POINTER(_MT), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+        lib.mipsf_py_sample_range.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -136,6 +144,147 @@ def available(threads: int = 4) -> bool:
 @contextlib.contextmanager
 def session(threads: int = 4):
     s = _Session(available(threads), threads)
+    s.take()
+    try:
+        yield s
+    finally:
+        s.give()
+
+
+# ---------------------------------------------------------------------------------------------- scores + top-k
+def _topk_torch(depth, draw, k, blocked):
+    """sampling_helper._valid_scores + torch.topk, as the reference computes them (sampling_helper.py:24-33, :62-66)"""
+    valid = (depth.flatten() > 0.).to(depth.dtype)
+    if blocked is not None:
+        valid = valid * (1 - blocked.to(depth.dtype))
+    return torch.topk(valid * torch.abs(draw), k)[1]
+
+
+def _topk_native(depth, draw, k, blocked, out=None):
+    n = depth.numel()
+    for t in (depth, draw):
+        if t.device.type != "cpu" or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+            return None
+    if blocked is not None and (blocked.dtype != torch.uint8 or not blocked.is_contiguous() or blocked.numel() != n):
+        return None
+    if out is None:
+        out = torch.empty(k, dtype=torch.int64)
+    scratch = np.empty(k, dtype=np.int64)
+    rc = _lib.mipsf_topk_valid_scores(depth.data_ptr(), draw.data_ptr(), blocked.data_ptr() if blocked is not None else None,
+                                      n, k, out.data_ptr(), scratch.ctypes.data)
+    return out if rc == 0 else None
+
+
+def _topk_self_check() -> bool:
+    g = torch.Generator().manual_seed(5)
+    for n, k, p_valid, with_block in ((70000, 1000, 0.95, True), (70000, 1000, 0.01, True), (8192, 128, 0.5, False),
+                                      (8192, 128, 0.0, False), (285200, 2048, 0.9, True)):
+        depth = torch.rand(n, generator=g) * (torch.rand(n, generator=g) < p_valid)
+        draw = torch.randn(n, generator=g)
+        m = draw[3::7].numel()
+        draw[0::7][:m] = -draw[3::7]                                        # exact ties among the valid scores, too
+        blocked = (torch.rand(n, generator=g) < 0.01).to(torch.uint8) if with_block else None
+        want = _topk_torch(depth, draw, k, blocked)
+        for d in (draw, torch.randn(n, generator=g)):                       # with ties / (almost surely) without
+            if d is not draw:
+                want = _topk_torch(depth, d, k, blocked)
+            got = _topk_native(depth, d, k, blocked)
+            if got is None or not torch.equal(got, want):
+                return False
+    return True
+
+
+def topk_available() -> bool:
+    """True when the one-pass score + top-k of the library returns torch.topk's indices in torch.topk's order here."""
+    global _topk_ok
+    if _topk_ok is None:
+        _topk_ok = bool(_load()) and not os.environ.get("MIPSF_NO_HOSTRNG") and _topk_self_check()
+    return _topk_ok
+
+
+def topk_valid_pixels(depth: torch.Tensor, draw: torch.Tensor, k: int, blocked: torch.Tensor = None) -> torch.Tensor:
+    """``torch.topk((depth > 0) * |draw|, k)[1]`` with the pixels of the uint8 mask `blocked` scored 0 -- the second half
+    of sample_valid_pixels_random / sample_pixels_mix (sampling_helper.py:24-33, :55-68) -- in one pass, same indices in
+    the same order (ties included); torch's own ops when the library is missing, disagrees, or k * 64 > n."""
+    if topk_available():
+        got = _topk_native(depth, draw, k, blocked)
+        if got is not None:
+            return got
+    return _topk_torch(depth, draw, k, blocked)
+
+
+# ---------------------------------------------------------------------------------------------- python's `random`
+class _PySession:
+    """python's global `random` generator between `take` and `give`: ``sample_range(n, k)`` == ``torch.tensor(
+    random.sample(range(n), k))`` (keyframeSet.py:386-436 draws the rays of a mapping iteration this way, ~1 us per
+    index in the interpreter)."""
+
+    def __init__(self, native: bool):
+        self.native = native
+        self.mt = _MT()
+        self._version, self._gauss = 3, None
+        self._scratch = np.empty(0, dtype=np.int64)
+
+    def take(self):
+        if not self.native:
+            return
+        self._version, internal, self._gauss = random.getstate()
+        np.ctypeslib.as_array(self.mt.state)[:] = np.array(internal[:_N], dtype=np.uint32)
+        self.mt.next = internal[_N]
+
+    def give(self):
+        if not self.native:
+            return
+        random.setstate((self._version, tuple(np.ctypeslib.as_array(self.mt.state).tolist()) + (int(self.mt.next),),
+                         self._gauss))
+
+    def sample_range(self, n: int, k: int) -> torch.Tensor:
+        if self.native:
+            out = torch.empty(k, dtype=torch.int64)
+            if self._scratch.shape[0] < n:
+                self._scratch = np.empty(n, dtype=np.int64)
+            if _lib.mipsf_py_sample_range(C.byref(self.mt), n, k, out.data_ptr(), self._scratch.ctypes.data) == 0:
+                return out
+            self.give()                         # arguments the replica refuses: python's own function (and its errors)
+            try:
+                return torch.tensor(random.sample(range(n), k))
+            finally:
+                self.take()
+        return torch.tensor(random.sample(range(n), k))
+
+
+def _py_self_check() -> bool:
+    keep = random.getstate()
+    try:
+        for seed, n, k in ((1, 5000, 409), (2, 35000, 2048), (3, 600, 500), (4, 20, 5), (5, 1, 1), (6, 5000, 0),
+                           (7, 4096, 1365), (8, 87, 22)):
+            random.seed(seed)
+            random.random()                                 # (an odd position inside the state block)
+            want = [random.sample(range(n), k) for _ in range(3)]
+            end = random.getstate()
+            random.seed(seed)
+            random.random()
+            s = _PySession(True)
+            s.take()
+            got = [s.sample_range(n, k).tolist() for _ in range(3)]
+            s.give()
+            if got != want or random.getstate() != end:
+                return False
+        return True
+    finally:
+        random.setstate(keep)
+
+
+def py_available() -> bool:
+    global _py_ok
+    if _py_ok is None:
+        _py_ok = bool(_load()) and not os.environ.get("MIPSF_NO_HOSTRNG") and _py_self_check()
+    return _py_ok
+
+
+@contextlib.contextmanager
+def py_session():
+    s = _PySession(py_available())
     s.take()
     try:
         yield s

@@ -70,14 +70,19 @@ class DeviceRayDB:
         flat, kf_ids, kf_indices = self.indices_in_submap(first_kf_Id, related_kf_ids, pix_num)
         return self._gather(flat), kf_ids, kf_indices
 
-    def indices_in_submap(self, first_kf_Id, related_kf_ids, pix_num: int):
+    def indices_in_submap(self, first_kf_Id, related_kf_ids, pix_num: int, sample_range=None):
         """The host half of ``sample_rays_in_submap``: the python-``random`` draws and the index arithmetic, without
         the gather -> (flat row indices into the database, kf_ids, kf_indices), all CPU int64.  A producer thread
-        calls this ahead of time; the rows are gathered later, inside the captured iteration."""
+        calls this ahead of time; the rows are gathered later, inside the captured iteration.
+        sample_range(n, k): a stand-in for ``torch.tensor(random.sample(range(n), k))`` that draws the same indices
+        from the same generator (mipsfusion_amd.hostrng's session over python's global generator)."""
+        if sample_range is None:
+            def sample_range(n, k):
+                return torch.tensor(random.sample(range(n), k))
         R = self.num_rays_to_save
         n_rel = related_kf_ids.shape[0]
         n_first = max(pix_num // n_rel, pix_num // 10)
-        idx_first = torch.tensor(random.sample(range(R), n_first))
+        idx_first = sample_range(R, n_first)
         first = int(first_kf_Id)
         flat = [first * R + idx_first]
         kf_indices = [torch.zeros_like(idx_first)]
@@ -87,13 +92,13 @@ class DeviceRayDB:
             if n_rel > 2:
                 last = related_kf_ids[-1]
                 n_last = max(pix_num // n_rel, pix_num // 5)
-                idx_last = torch.tensor(random.sample(range(R), n_last))
+                idx_last = sample_range(R, n_last)
                 tail_flat, tail_indices = [int(last) * R + idx_last], [torch.ones_like(idx_last) * (n_rel - 1)]
                 tail_ids = [torch.ones_like(idx_last) * last]
                 other_ids, n_other, n_other_kf = related_kf_ids[1:-1], pix_num - n_first - n_last, n_rel - 2
             else:
                 other_ids, n_other, n_other_kf = related_kf_ids[1:], pix_num - n_first, n_rel - 1
-            idx_other = torch.tensor(random.sample(range(n_other_kf * R), n_other))
+            idx_other = sample_range(n_other_kf * R, n_other)
             o_indices = torch.div(idx_other, R, rounding_mode="floor")
             o_ids = other_ids[o_indices]
             flat += [o_ids.to(torch.int64) * R + (idx_other - o_indices * R)] + tail_flat

@@ -325,3 +325,64 @@ def test_host_rng_refuses_what_it_cannot_fill_and_falls_back_without_the_library
         assert not g.native
         got = (g.randn_(torch.empty(100)), g.rand_(torch.empty(10)))
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
+@pytest.mark.parametrize("n,k,p_valid,with_lattice", [(285200, 1024, 0.95, True), (285200, 4096, 0.9, True),
+                                                       (70000, 1000, 0.01, True), (8192, 128, 0.5, False),
+                                                       (8192, 128, 0.0, False), (8192, 129, 0.5, False)])
+def test_host_topk_pass_returns_torch_topk_indices_in_torch_topk_order(n, k, p_valid, with_lattice):
+    """mipsfusion_amd.hostrng.topk_valid_pixels == the second half of sample_valid_pixels_random / sample_pixels_mix
+    (sampling_helper.py:24-33, :55-68): torch.topk((depth > 0, lattice zeroed) * |draw|, k)[1], index for index --
+    also where scores tie (duplicated draws; fewer valid pixels than k, so that zeros fill the tail in the order
+    torch's heap leaves them), and where torch leaves its partial_sort path (k * 64 > n: torch's own ops run)."""
+    hostrng = _hostrng_or_skip()
+    assert hostrng.topk_available()
+    g = torch.Generator().manual_seed(n + k)
+    for rep in range(3):
+        depth = torch.rand(n, generator=g) * (torch.rand(n, generator=g) < p_valid)
+        draw = torch.randn(n, generator=g)
+        if rep == 1:
+            m = draw[3::7].numel()
+            draw[0::7][:m] = -draw[3::7]
+        blocked = None
+        if with_lattice:
+            blocked = torch.zeros(n, dtype=torch.uint8)
+            blocked[torch.arange(0, n, 293)] = 1
+        valid = (depth > 0).to(torch.float32)
+        if blocked is not None:
+            valid[blocked.bool()] = 0
+        want = torch.topk(valid * torch.abs(draw), k)[1]
+        got = hostrng.topk_valid_pixels(depth, draw, k, blocked)
+        assert got.dtype == torch.int64 and torch.equal(got, want)
+    nan_draw = draw.clone()
+    nan_draw[11] = float("nan")                                   # torch sorts NaN first: the pass hands such inputs over
+    assert torch.equal(hostrng.topk_valid_pixels(depth, nan_draw, k, blocked),
+                       torch.topk(valid * torch.abs(nan_draw), k)[1])
+
+
+def test_host_replica_of_python_random_sample_draws_the_same_indices():
+    """mipsfusion_amd.hostrng.py_session().sample_range(n, k) == torch.tensor(random.sample(range(n), k)) -- the draws of
+    keyframeSet.py:386-436 / mipsfusion.py:135-138 -- for both of CPython's branches (pool for small n, rejection set
+    otherwise), interleaved with python's own calls, leaving the global generator where python would."""
+    hostrng = _hostrng_or_skip()
+    assert hostrng.py_available()
+    for seed in range(4):
+        calls = [(5000, 409), (35000, 2048), (600, 500), (20, 5), (1, 1), (5000, 0), (4096, 1365), (87, 22), (285200, 1000)]
+        random.seed(seed)
+        want = [random.sample(range(n), k) for n, k in calls]
+        mid = random.random()
+        want2 = [random.sample(range(n), k) for n, k in calls[:3]]
+        end = random.getstate()
+        random.seed(seed)
+        with hostrng.py_session() as r:
+            assert r.native
+            got = [r.sample_range(n, k) for n, k in calls]
+        assert random.random() == mid
+        with hostrng.py_session() as r:
+            got2 = [r.sample_range(n, k) for n, k in calls[:3]]
+        assert [g.tolist() for g in got] == want and [g.tolist() for g in got2] == want2
+        assert all(g.dtype == torch.int64 for g in got)
+        assert random.getstate() == end
+    with hostrng.py_session() as r:
+        with pytest.raises(ValueError):
+            r.sample_range(10, 11)                                 # python's own error for python's own reasons
