@@ -50,9 +50,20 @@ class FramePlan(NamedTuple):
     kf_slot_base: int = 0               # row offset of the current frame's pixels in the device ray table
 
 
+def packed(t, n):
+    """[iters, n(, S)] view over the FRONT of the [iters, n_max(, S)] buffer `t`: the rays of a local-BA round vary with the
+    number of related keyframes (8192, 6144, 5461 ...), and a [:, :n] slice of the full buffer is strided -- torch copies
+    such a slice from pinned host memory through a pageable temporary (1.2-4 ms per round and a 10-20 ms first use,
+    instead of three asynchronous DMA transfers)."""
+    it = t.shape[0]
+    inner = t.shape[2:]
+    return t.view(-1)[:it * n * int(np.prod(inner, dtype=np.int64))].view(it, n, *inner)
+
+
 class FrameSamples:
     """One ring slot of pinned buffers.  track_idx [n_track] (pixel index row*W+col), track_noise [iters, n_track, S];
-    ba_rows / ba_owner [iters, N] (ray-table row, index of the owning pose), ba_noise [iters, N, S]; n_ba = N."""
+    ba_packed() = ba_rows / ba_owner [iters, N] (ray-table row, index of the owning pose), ba_noise [iters, N, S] with
+    N = n_ba, packed at the front of the slot's buffers."""
 
     def __init__(self, n_track, it_track, n_ba_max, it_ba, S, pinned):
         def buf(*shape, dtype=torch.float32):
@@ -68,6 +79,10 @@ class FrameSamples:
         self.free = threading.Event()
         self.free.set()
         self._pending, self._lock = 0, threading.Lock()
+
+    def ba_packed(self):
+        n = self.n_ba
+        return packed(self.ba_rows, n), packed(self.ba_owner, n), packed(self.ba_noise, n)
 
     def _arm(self, parts):
         self._pending = parts
@@ -217,10 +232,10 @@ class ReferenceSampleProducer:
                 for i in range(self.it_track):                      # scene_rep.py:176, one draw per forward
                     g.rand_(s.track_noise[i])
             if plan.ba_kf_ids is not None:
-                n = s.n_ba
+                noise = s.ba_packed()[2]
                 for i in range(self.it_ba):
                     self._q_topk.put((plan, s, "ba", i, self._draw_scores(g, plan.depth)))   # :302 / :306-307
-                    g.rand_(s.ba_noise[i, :n])
+                    g.rand_(noise[i])
             rng.__exit__(None, None, None)
             self.host_ms["torch_rng"] += (time.perf_counter() - t0) * 1e3
             s._part_done()
@@ -253,8 +268,9 @@ class ReferenceSampleProducer:
                     idx = hostrng.topk_valid_pixels(plan.depth, draw, n_cur)
                 else:
                     idx = self._pixels_mix((tk["RO"]["n_rows"], tk["RO"]["n_cols"]), plan.depth, n_cur, draw)
-                s.ba_rows[i, n_kf:n_kf + n_cur].copy_(idx + plan.kf_slot_base)
-                s.ba_owner[i, n_kf:n_kf + n_cur].fill_(-1)
+                rows, owner, _ = s.ba_packed()
+                rows[i, n_kf:n_kf + n_cur].copy_(idx + plan.kf_slot_base)
+                owner[i, n_kf:n_kf + n_cur].fill_(-1)
             self.host_ms["topk"] += (time.perf_counter() - t0) * 1e3
             s._part_done()
 
@@ -298,11 +314,12 @@ class ReferenceSampleProducer:
             if plan.ba_kf_ids is not None:
                 n_kf, _ = ba_ray_counts(self.cfg, plan.ba_kf_ids.shape[0])
                 first = plan.ba_kf_ids[0]
+                rows, owner, _ = s.ba_packed()
                 for i in range(self.it_ba):
                     self.gate.wait()
                     flat, _, kf_indices = self._index_db.indices_in_submap(first, plan.ba_kf_ids, n_kf, r.sample_range)
-                    s.ba_rows[i, :n_kf].copy_(flat)
-                    s.ba_owner[i, :n_kf].copy_(kf_indices)
+                    rows[i, :n_kf].copy_(flat)
+                    owner[i, :n_kf].copy_(kf_indices)
             rng.__exit__(None, None, None)
             self.host_ms["python_rng"] += (time.perf_counter() - t0) * 1e3
             s._part_done()
@@ -468,11 +485,12 @@ class GraphedSequence:
     def _ba_step_fn(self, n):
         tcfg, mp = self.cfg["training"], self.cfg["mapping"]
 
+        rows, owner, noise = packed(self.ba_rows, n), packed(self.ba_owner, n), packed(self.ba_noise, n)
+
         def step(k):
-            rays_o, rays_d, rgb, depth = ops.gather_pose_rays(self.table, self.ba_rows[k, :n].contiguous(), self.ba_rot,
-                                                              self.ba_trans, self.fixed, self.ba_owner[k, :n].contiguous(),
-                                                              accumulate_in_place=True)
-            ret = self.model.forward(rays_o, rays_d, rgb, depth, noise=self.ba_noise[k, :n].contiguous())
+            rays_o, rays_d, rgb, depth = ops.gather_pose_rays(self.table, rows[k], self.ba_rot, self.ba_trans, self.fixed,
+                                                              owner[k], accumulate_in_place=True)
+            ret = self.model.forward(rays_o, rays_d, rgb, depth, noise=noise[k])
             get_loss_from_ret(ret, tcfg).backward()
             self.map_opt.step(zero_grad=True)
             if (k + 1) % mp["pose_accum_step"] == 0:
@@ -554,8 +572,8 @@ class GraphedSequence:
         idx.append(torch.cat([lat[None].expand(it, -1), extra], 1) + self.Kmax * R)
         own.append(torch.full((it, n_cur), 0 if cur_is_first else -1, dtype=torch.int64, device=self.dev))
         n = n_kf + n_cur
-        self.ba_rows[:, :n].copy_(torch.cat(idx, 1)), self.ba_owner[:, :n].copy_(torch.cat(own, 1))
-        self.ba_noise[:, :n].uniform_()
+        packed(self.ba_rows, n).copy_(torch.cat(idx, 1)), packed(self.ba_owner, n).copy_(torch.cat(own, 1))
+        packed(self.ba_noise, n).uniform_()
         return n
 
     def _fill_go_device(self):
@@ -605,9 +623,8 @@ class GraphedSequence:
 
     def _load_ba(self, s: FrameSamples):
         n = s.n_ba
-        self.ba_rows[:, :n].copy_(s.ba_rows[:, :n], non_blocking=True)
-        self.ba_owner[:, :n].copy_(s.ba_owner[:, :n], non_blocking=True)
-        self.ba_noise[:, :n].copy_(s.ba_noise[:, :n], non_blocking=True)
+        for dst, src in zip((self.ba_rows, self.ba_owner, self.ba_noise), s.ba_packed()):
+            packed(dst, n).copy_(src, non_blocking=True)                     # contiguous on both sides: plain DMA
         return n
 
     # ------------------------------------------------------------------------------------------------------ run

@@ -221,8 +221,9 @@ def test_sample_producer_reproduces_the_sequential_index_stream(iter_ro):
         if plan.ba_kf_ids is not None:
             n = rec["ba_rows"].shape[1]
             assert s.n_ba == n
-            assert torch.equal(s.ba_rows[:, :n], rec["ba_rows"]) and torch.equal(s.ba_owner[:, :n], rec["ba_owner"])
-            assert torch.equal(s.ba_noise[:, :n], rec["ba_noise"])
+            rows, owner, noise = s.ba_packed()
+            assert torch.equal(rows, rec["ba_rows"]) and torch.equal(owner, rec["ba_owner"])
+            assert torch.equal(noise, rec["ba_noise"])
         prod.release(s)
     prod.close()
     for t in prod._threads:
