@@ -235,6 +235,7 @@ struct ScatterPlan {
     uint32_t bin0[MIPSF_MAX_LEVELS + 1];          // first bin of each level
     uint32_t n_bins;
     uint32_t max_items;                           // upper bound on accumulate work items for this M
+    uint32_t max_slice;                           // entries of the largest slice (= the accumulate kernel's LDS / 16)
     // scratch layout, in 4-byte words from the start of the scratch buffer
     uint32_t w_count, w_first, w_parts, w_nitems, w_items;
     uint64_t w_records, w_partial, w_end;         // records: n_bins regions of bin_cap words
@@ -258,6 +259,7 @@ static ScatterPlan make_plan(const GridLevels& g, uint32_t M) {
     }
     p.bin0[g.n_levels] = bins;
     p.n_bins = bins;
+    for (uint32_t l = 0; l < g.n_levels; ++l) p.max_slice = p.slice_entries[l] > p.max_slice ? p.slice_entries[l] : p.max_slice;
     const uint64_t max_records = 8ull * g.n_levels * M;
     p.max_items = (uint32_t)((max_records + SC_PART - 1) / SC_PART) + bins;
     uint64_t w = 0;
@@ -265,7 +267,8 @@ static ScatterPlan make_plan(const GridLevels& g, uint32_t M) {
     p.w_nitems = (uint32_t)w, w += 4;
     p.w_first = (uint32_t)w, w += bins;
     p.w_parts = (uint32_t)w, w += bins;
-    p.w_items = (uint32_t)w, w += p.max_items;
+    w = (w + 3) / 4 * 4;
+    p.w_items = (uint32_t)w, w += 4ull * p.max_items;       // {bin | part << 16, records of the bin, parts of the bin, -}
     w = (w + 15) / 16 * 16;
     p.w_records = w, w += (uint64_t)bins * M;
     w = (w + 15) / 16 * 16;
@@ -277,25 +280,6 @@ static ScatterPlan make_plan(const GridLevels& g, uint32_t M) {
 __global__ void scatter_zero_kernel(uint32_t* __restrict__ ws, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) ws[i] = 0u;
-}
-
-// slice of every corner of one (sample, level); lead = bit c set when corner c is the first one in its slice
-__device__ __forceinline__ uint32_t corner_slices(int mode, const float* __restrict__ x, uint32_t i, float scale,
-                                                  uint32_t res, uint32_t size, uint32_t shift, uint32_t sl[8]) {
-    const Cell cell = locate(x, i, scale);
-    uint32_t idx[8];
-    corner_indices(mode, cell, res, size, idx);
-    uint32_t lead = 0;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const uint32_t q = idx[c] >> shift;          // power-of-two slices (shift 31 = the level is one slice)
-        sl[c] = q;
-        bool first = true;
-#pragma unroll
-        for (int k = 0; k < c; ++k) first = first && (sl[k] != q);
-        lead |= first ? (1u << c) : 0u;
-    }
-    return lead;
 }
 
 // rank of this lane's record inside its bin, LDS counter `cnt[s]`.  Levels with few bins (coarse dense levels:
@@ -319,6 +303,70 @@ __device__ __forceinline__ uint32_t ranked_add(uint32_t* cnt, uint32_t s, bool a
     return rank;
 }
 
+// The slices the 8 corners of one (sample, level) fall into, each with the mask of its corners: slot k is in use when
+// m[k] != 0.  GENERAL form: slot c = corner c when it is the first corner of its slice (28 + 64 comparisons).  The two
+// FAST forms build at most four slots from what the addressing guarantees and say whether the guarantee held:
+//   dense level   the index grows with the corner number, so all corners lie between corner 0's slice and corner 7's;
+//                 two slots, valid when every corner is in one of the two (always, while a slice is thicker than the
+//                 cell's index span res^2 + res + 1 and the point is inside the box);
+//   hashed level, power-of-two size: x enters the hash as `cx ^ ...`, and cx, cx + 1 < 2^shift leave the bits >= shift
+//                 -- the slice -- alone: the corners come in four x-pairs that share a slice; four hashes instead of 8.
+// The routing kernel was VALU-bound (70 % of its wave cycles, ~320 vector instructions per (sample, level)).
+__device__ __forceinline__ void route_groups_general(int mode, const Cell& cell, uint32_t res, uint32_t size,
+                                                     uint32_t shift, uint32_t (&s)[8], uint32_t (&m)[8]) {
+    uint32_t idx[8];
+    corner_indices(mode, cell, res, size, idx);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s[c] = idx[c] >> shift;            // (shift 31 = the level is one slice)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        bool first = true;
+        uint32_t mm = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k < c) first = first && (s[k] != s[c]);
+            mm |= (s[k] == s[c]) ? (1u << k) : 0u;
+        }
+        m[c] = first ? mm : 0u;
+    }
+}
+
+__device__ __forceinline__ bool route_groups_dense(const Cell& cell, uint32_t res, uint32_t size, uint32_t shift,
+                                                   uint32_t (&s)[8], uint32_t (&m)[8]) {
+    uint32_t idx[8];
+    corner_indices_m<0>(cell, res, size, idx);
+    const uint32_t lo = idx[0] >> shift, hi = idx[7] >> shift;
+    uint32_t m_lo = 0, m_hi = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint32_t q = idx[c] >> shift;
+        m_lo |= (q == lo) ? (1u << c) : 0u;
+        m_hi |= (q == hi) ? (1u << c) : 0u;
+    }
+    s[0] = lo, m[0] = m_lo;
+    s[1] = hi, m[1] = hi != lo ? m_hi : 0u;
+    return (m_lo | m_hi) == 0xffu;
+}
+
+__device__ __forceinline__ bool route_groups_hashed_pow2(const Cell& cell, uint32_t size, uint32_t shift,
+                                                         uint32_t (&s)[8], uint32_t (&m)[8]) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const uint32_t cy = cell.c[1] + (p & 1), cz = cell.c[2] + (p >> 1);
+        s[p] = ((cell.c[0] ^ (cy * P1) ^ (cz * P2)) & (size - 1u)) >> shift;
+        m[p] = 3u << (2 * p);                                      // corners 2p (x) and 2p + 1 (x + 1)
+    }
+#pragma unroll
+    for (int p = 1; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < p; ++q) {
+            const bool same = m[p] != 0u && m[q] != 0u && s[q] == s[p];
+            m[q] |= same ? m[p] : 0u;
+            m[p] = same ? 0u : m[p];
+        }
+    return cell.c[0] + 1u < (1u << shift);
+}
+
 // One workgroup = one level x 4096 consecutive samples: rank the records inside the workgroup with LDS counters,
 // reserve room in every bin with ONE global atomic per bin, write the sample indices.  (Staging the records bin by
 // bin in LDS to make the stores coalesced was measured slower: 67 vs 61 us.)
@@ -326,6 +374,15 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __
                                                                 ScatterPlan plan, uint32_t* __restrict__ ws) {
     __shared__ uint32_t cnt[SC_MAX_NS];
     __shared__ uint32_t base[SC_MAX_NS];
+#ifndef MIPSF_SC_STAGE
+#define MIPSF_SC_STAGE 1        // experiments: 0 = every lane stores its records straight to the bins
+#endif
+    // Records are collected bin by bin in LDS and leave as runs of consecutive words: a lane-per-record store sends 64
+    // four-byte writes to 64 different lines (the bins of the 64 lanes), 10 M of them per launch -- half of this kernel's
+    // time (ablation, tools/micro/route_probe.py: 52 us, 28 without the stores, 21 with a coalesced stand-in).
+    constexpr uint32_t STAGE_CAP = 4 * SC_BLOCK * SC_ROUTE_UNR;     // typical: <= 4 records per sample; more go direct
+    __shared__ uint32_t lstart[SC_MAX_NS];
+    __shared__ uint32_t stage[MIPSF_SC_STAGE ? STAGE_CAP : 1];
     const uint32_t level = blockIdx.x % plan.n_levels;
     const uint32_t chunk = blockIdx.x / plan.n_levels;
     const uint32_t size = g.offsets[level + 1] - g.offsets[level];
@@ -337,22 +394,71 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __
 #ifndef MIPSF_SC_AGG_MAX
 #define MIPSF_SC_AGG_MAX 1   // measured on the mapping workload: 65 us (<= 1 bin), 67 (<= 2), 88 (<= 8)
 #endif
+#ifndef MIPSF_SC_ROUTE_FAST
+#define MIPSF_SC_ROUTE_FAST 1   // experiments: 0 = the general grouping for every sample
+#endif
     const bool aggregate = ns <= MIPSF_SC_AGG_MAX;
     for (uint32_t q = threadIdx.x; q < ns; q += SC_BLOCK) cnt[q] = 0u;
     __syncthreads();
     const uint32_t s0 = chunk * (SC_BLOCK * SC_ROUTE_UNR);
-    uint32_t sl[SC_ROUTE_UNR][8], lead[SC_ROUTE_UNR], rank[SC_ROUTE_UNR][8];
+    // across the barrier, per sample: 8 slots of (slice < 512, rank < 4096) as 16-bit halves, masks as bytes
+    uint32_t sp[SC_ROUTE_UNR][4], rp[SC_ROUTE_UNR][4], mp[SC_ROUTE_UNR][2];
 #pragma unroll
     for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u) {
         const uint32_t i = s0 + u * SC_BLOCK + threadIdx.x;
-        lead[u] = 0;
-        if (i < M) lead[u] = corner_slices(mode, x, i, scale, res, size, shift, sl[u]);
+        uint32_t s[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, m[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        bool general = false;
+        if (i < M) {
+            const Cell cell = locate(x, i, scale);
+            if (MIPSF_SC_ROUTE_FAST && mode == 0) general = !route_groups_dense(cell, res, size, shift, s, m);
+            else if (MIPSF_SC_ROUTE_FAST && mode == 1) general = !route_groups_hashed_pow2(cell, size, shift, s, m);
+            else general = true;
+        }
+        if (__any(general)) {                       // (wave-uniform: the ranking below needs whole waves)
+            if (general) route_groups_general(mode, locate(x, i, scale), res, size, shift, s, m);
+        }
+        const bool wide = __any((m[4] | m[5] | m[6] | m[7]) != 0u) != 0;
+        uint32_t r[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int c = 0; c < 8; ++c) rank[u][c] = ranked_add(cnt, sl[u][c], (lead[u] >> c & 1u) != 0u, aggregate);
+        for (int k = 0; k < 4; ++k) r[k] = ranked_add(cnt, s[k], m[k] != 0u, aggregate);
+        if (wide) {
+#pragma unroll
+            for (int k = 4; k < 8; ++k) r[k] = ranked_add(cnt, s[k], m[k] != 0u, aggregate);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sp[u][k] = s[2 * k] | (s[2 * k + 1] << 16);
+            rp[u][k] = r[2 * k] | (r[2 * k + 1] << 16);
+        }
+        mp[u][0] = m[0] | (m[1] << 8) | (m[2] << 16) | (m[3] << 24);
+        mp[u][1] = m[4] | (m[5] << 8) | (m[6] << 16) | (m[7] << 24);
     }
     __syncthreads();
     for (uint32_t q = threadIdx.x; q < ns; q += SC_BLOCK)
         base[q] = cnt[q] ? atomicAdd(&ws[plan.w_count + bin0 + q], cnt[q]) : 0u;
+    if (MIPSF_SC_STAGE && threadIdx.x < 64) {       // exclusive prefix of the bin counts: where a bin starts in `stage`
+        constexpr uint32_t PER = SC_MAX_NS / 64;
+        uint32_t c[PER], sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t q = threadIdx.x * PER + k;
+            c[k] = q < ns ? cnt[q] : 0u;
+            sum += c[k];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, d, 64);
+            incl += (int)threadIdx.x >= d ? v : 0u;
+        }
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t q = threadIdx.x * PER + k;
+            if (q < ns) lstart[q] = run;
+            run += c[k];
+        }
+    }
     __syncthreads();
     // record = sample index | (the corners of the sample's cell that fall into this slice) << 24: the accumulate kernel
     // then hashes those corners only (on a hashed level 2 of 8: the pair along x) instead of all 8 plus 8 membership tests
@@ -362,13 +468,31 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __
     for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u) {
         const uint32_t i = s0 + u * SC_BLOCK + threadIdx.x;
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-            if (lead[u] >> c & 1u) {
-                uint32_t m = 0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) m |= (sl[u][k] == sl[u][c]) ? (1u << k) : 0u;
-                rec[(size_t)(bin0 + sl[u][c]) * M + base[sl[u][c]] + rank[u][c]] = masked ? (i | (m << 24)) : i;
+        for (int k = 0; k < 8; ++k) {
+            if (k == 4 && !__any(mp[u][1] != 0u)) break;
+            const uint32_t m = (mp[u][k >> 2] >> (8 * (k & 3))) & 0xffu;
+            if (m) {
+                const uint32_t sl = (sp[u][k >> 1] >> (16 * (k & 1))) & 0xffffu;
+                const uint32_t rk = (rp[u][k >> 1] >> (16 * (k & 1))) & 0xffffu;
+                if (MIPSF_SC_STAGE) {
+                    const uint32_t p = lstart[sl] + rk;
+                    if (p < STAGE_CAP) {
+                        stage[p] = masked ? (i | (m << 24)) : i;
+                        continue;
+                    }
+                }
+                rec[(size_t)(bin0 + sl) * M + base[sl] + rk] = masked ? (i | (m << 24)) : i;
             }
+        }
+    }
+    if (MIPSF_SC_STAGE) {
+        __syncthreads();
+        const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+        for (uint32_t q = wave; q < ns; q += SC_BLOCK / 64) {
+            const uint32_t n = cnt[q], src = lstart[q];
+            uint32_t* dstp = rec + (size_t)(bin0 + q) * M + base[q];
+            for (uint32_t p = lane; p < n && src + p < STAGE_CAP; p += 64) dstp[p] = stage[src + p];
+        }
     }
 }
 
@@ -394,6 +518,10 @@ __global__ __launch_bounds__(1024) void scatter_scan_kernel(ScatterPlan plan, ui
     }
     uint32_t oitm = sitm[t] - litm;
     if (t == 1023) ws[plan.w_nitems] = sitm[t];
+    // One 16-byte descriptor per work item, and an "unused" mark on the rest of the table: an accumulate workgroup
+    // starts with ONE load instead of four dependent ones (item count, item, records of the bin, parts of the bin:
+    // ~2 us of a 30 us item).
+    uint4* items = reinterpret_cast<uint4*>(ws + plan.w_items);
 #pragma unroll
     for (uint32_t k = 0; k < PER; ++k) {
         const uint32_t b = t * PER + k;
@@ -401,10 +529,11 @@ __global__ __launch_bounds__(1024) void scatter_scan_kernel(ScatterPlan plan, ui
             const uint32_t parts = (cnt[k] + SC_PART - 1) / SC_PART;
             ws[plan.w_first + b] = oitm;
             ws[plan.w_parts + b] = parts;
-            for (uint32_t q = 0; q < parts; ++q) ws[plan.w_items + oitm + q] = b | (q << 16);
+            for (uint32_t q = 0; q < parts; ++q) items[oitm + q] = make_uint4(b | (q << 16), cnt[k], parts, 0u);
             oitm += parts;
         }
     }
+    for (uint32_t i = sitm[1023] + t; i < plan.max_items; i += 1024) items[i] = make_uint4(0xffffffffu, 0u, 0u, 0u);
 }
 
 template <int LAYOUT>
@@ -414,9 +543,19 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
                                                                    GridLevels g, ScatterPlan plan,
                                                                    uint32_t* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) double acc[];   // [slice entries][2]
-    if (blockIdx.x >= ws[plan.w_nitems]) return;
-    const uint32_t item = ws[plan.w_items + blockIdx.x];
+#ifdef MIPSF_SC_TRACE    // tools/probe_scatter_trace.py: (item, records, begin, end in 10 ns ticks, XCC, HW_ID) per workgroup
+    const uint64_t trace_t0 = wall_clock64();
+#endif
+    const uint4 desc = reinterpret_cast<const uint4*>(ws + plan.w_items)[blockIdx.x];
+    // the slice is cleared while the descriptor is on its way (all of the LDS: the level is not known yet)
+    {
+        double2* z = reinterpret_cast<double2*>(acc);
+        for (uint32_t e = threadIdx.x; e < plan.max_slice; e += SC_BLOCK) z[e] = make_double2(0.0, 0.0);
+    }
+    const uint32_t item = desc.x;
+    if (item == 0xffffffffu) return;
     const uint32_t bin = item & 0xffffu, part = item >> 16;
+    const bool single = desc.z == 1u;             // the bin's only work item: its slice goes straight into dparams
     uint32_t level = 0;
     while (level + 1 < plan.n_levels && bin >= plan.bin0[level + 1]) ++level;
     const uint32_t slice = bin - plan.bin0[level];
@@ -427,13 +566,29 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
     const uint32_t count = begin + se <= size ? se : size - begin;
     const uint32_t res = g.res[level];
     const float scale = g.scale[level];
-    const uint32_t n_rec_bin = ws[plan.w_count + bin];
+    const uint32_t n_rec_bin = desc.y;
     const uint32_t r0 = part * SC_PART;
     const uint32_t n_rec = n_rec_bin - r0 < SC_PART ? n_rec_bin - r0 : SC_PART;
     const uint32_t* __restrict__ rec = ws + plan.w_records + (size_t)bin * M + r0;
 
-    for (uint32_t e = threadIdx.x; e < 2 * count; e += SC_BLOCK) acc[e] = 0.0;
+    // ... and the current gradient values of the slice are requested now: by the time the records are through they have
+    // arrived (they used to cost a memory round trip behind the last barrier, 3 us per item)
+    float2* dst = reinterpret_cast<float2*>(dparams) + off + begin;
+    constexpr uint32_t FL = SC_MAX_SLICE / SC_BLOCK;
+    float2 cur[FL];
+    if (single) {
+#pragma unroll
+        for (uint32_t k = 0; k < FL; ++k) {
+            const uint32_t e = threadIdx.x + k * SC_BLOCK;
+            cur[k] = e < count ? dst[e] : make_float2(0.f, 0.f);
+        }
+    }
     __syncthreads();
+#ifdef MIPSF_SC_TRACE
+    const uint64_t trace_t_zero = wall_clock64();
+    uint32_t trace_iter[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t trace_k = 0;
+#endif
 
     const int mode = level_mode(res, size);
     const bool masked = M <= SC_MASKED_MAX_M;      // records carry the corner mask of scatter_route_kernel
@@ -537,6 +692,9 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
                     atomicAdd(&acc[2 * e + 1], (double)(wgt * gy.y));
                 }
             }
+#ifdef MIPSF_SC_TRACE
+            if (trace_k < 6) trace_iter[trace_k++] = (uint32_t)(wall_clock64() - trace_t0);
+#endif
         }
     } else {
     constexpr int UNR = (int)SC_RUN;   // independent record -> x chains in flight per thread
@@ -590,32 +748,44 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
         }
         if (open) flush();
         open = false;
+#ifdef MIPSF_SC_TRACE
+        if (trace_k < 6) trace_iter[trace_k++] = (uint32_t)(wall_clock64() - trace_t0);
+#endif
     }
     }
+#ifdef MIPSF_SC_TRACE
+    const uint64_t trace_t_loop = wall_clock64();
+#endif
     __syncthreads();
+#ifdef MIPSF_SC_TRACE
+    const uint64_t trace_t_sync = wall_clock64();
+#endif
 
     const double2* a2 = reinterpret_cast<const double2*>(acc);
-    if (ws[plan.w_parts + bin] == 1) {
-        // read-modify-write of the whole slice; all loads are issued before the first add (a load -> add -> store
-        // chain per iteration costs one HBM round trip each, ~10 us per workgroup)
-        float2* dst = reinterpret_cast<float2*>(dparams) + off + begin;
-        constexpr uint32_t FL = SC_MAX_SLICE / SC_BLOCK;
-        float2 cur[FL];
-#pragma unroll
-        for (uint32_t k = 0; k < FL; ++k) {
-            const uint32_t e = threadIdx.x + k * SC_BLOCK;
-            cur[k] = e < count ? dst[e] : make_float2(0.f, 0.f);
-        }
+    if (single) {
 #pragma unroll
         for (uint32_t k = 0; k < FL; ++k) {
             const uint32_t e = threadIdx.x + k * SC_BLOCK;
             if (e < count) dst[e] = make_float2(cur[k].x + (float)a2[e].x, cur[k].y + (float)a2[e].y);
         }
     } else {
-        float2* dst = reinterpret_cast<float2*>(reinterpret_cast<float*>(ws) + plan.w_partial) +
-                      (size_t)blockIdx.x * SC_MAX_SLICE;
-        for (uint32_t e = threadIdx.x; e < count; e += SC_BLOCK) dst[e] = make_float2((float)a2[e].x, (float)a2[e].y);
+        float2* pdst = reinterpret_cast<float2*>(reinterpret_cast<float*>(ws) + plan.w_partial) +
+                       (size_t)blockIdx.x * SC_MAX_SLICE;
+        for (uint32_t e = threadIdx.x; e < count; e += SC_BLOCK) pdst[e] = make_float2((float)a2[e].x, (float)a2[e].y);
     }
+#ifdef MIPSF_SC_TRACE
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint64_t t1 = wall_clock64();
+        uint32_t* tr = ws + plan.w_end + 64 + 16 * (size_t)blockIdx.x;
+        tr[0] = item, tr[1] = n_rec, tr[2] = (uint32_t)trace_t0, tr[3] = (uint32_t)(trace_t0 >> 32);
+        tr[4] = (uint32_t)t1, tr[5] = (uint32_t)(t1 >> 32);
+        tr[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20), tr[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        tr[8] = (uint32_t)(trace_t_zero - trace_t0), tr[9] = (uint32_t)(trace_t_loop - trace_t0);
+        tr[10] = (uint32_t)(trace_t_sync - trace_t0);
+        for (int k = 0; k < 5; ++k) tr[11 + k] = trace_iter[k];
+    }
+#endif
 }
 
 // folds the partial slices of bins that were split over several workgroups into dparams
@@ -635,13 +805,18 @@ __global__ __launch_bounds__(256) void hashgrid_scatter_reduce_kernel(float* __r
     if (e >= count) return;
     const float2* p2 = reinterpret_cast<const float2*>(reinterpret_cast<const float*>(ws) + plan.w_partial) +
                        (size_t)ws[plan.w_first + bin] * SC_MAX_SLICE + e;
-    float2 a = make_float2(0.f, 0.f);
-    for (uint32_t q = 0; q < parts; ++q) {
-        const float2 v = p2[(size_t)q * SC_MAX_SLICE];
-        a.x += v.x, a.y += v.y;
-    }
     float2* d = reinterpret_cast<float2*>(dparams) + g.offsets[level] + begin + e;
     float2 cur = *d;
+    // eight partial slices in flight (a load per iteration was one memory round trip per part: 11 parts on the coarsest
+    // levels, 10 us for 10 MB); the sum keeps the order part 0, 1, 2, ...
+    float2 a = make_float2(0.f, 0.f);
+    for (uint32_t q = 0; q < parts; q += 8) {
+        float2 v[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) v[k] = q + k < parts ? p2[(size_t)(q + k) * SC_MAX_SLICE] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) a.x += v[k].x, a.y += v[k].y;
+    }
     cur.x += a.x, cur.y += a.y;
     *d = cur;
 }
@@ -800,8 +975,23 @@ uint64_t mipsf_hashgrid_bwd_scratch_floats(const mipsf_grid_meta* meta, uint32_t
     GridLevels g;
     if (to_levels(meta, g)) return 0;
     const ScatterPlan p = make_plan(g, M);
+#ifdef MIPSF_SC_TRACE
+    return p.w_end + 64 + 16ull * p.max_items + 64;
+#endif
     return p.w_end + (need_dx ? (uint64_t)g.n_levels * M * 3 : 0) + 64;
 }
+
+#ifdef MIPSF_SC_TRACE
+// word offset of the trace rows and their number (diagnosis builds only)
+uint64_t mipsf_hashgrid_trace_words(const mipsf_grid_meta* meta, uint32_t M, uint32_t* n_rows, uint32_t* bin0) {
+    GridLevels g;
+    if (to_levels(meta, g)) return 0;
+    const ScatterPlan p = make_plan(g, M);
+    *n_rows = p.max_items;
+    for (uint32_t l = 0; l <= g.n_levels; ++l) bin0[l] = p.bin0[l];
+    return p.w_end + 64;
+}
+#endif
 
 static int check_plan(const ScatterPlan& plan, const GridLevels& g, uint32_t M) {
     MIPSF_REQUIRE(plan.n_bins <= SC_MAX_BINS && plan.n_bins <= 0xffffu, "grid too large: %u table slices", plan.n_bins);
