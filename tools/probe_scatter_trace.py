@@ -91,6 +91,15 @@ for c, s, t in zip(cu, b, e):
     per_cu_busy[c] = per_cu_busy.get(c, 0.0) + (t - s)
 v = np.array(list(per_cu_busy.values()))
 print("per-CU busy us: mean %.1f min %.1f max %.1f" % (v.mean(), v.min(), v.max()))
+print("per XCD: items, busy CU-us, first idle CU at, last end")
+for k in sorted(np.unique(xcc)):
+    mk = xcc == k
+    ends = {}
+    for c, t_ in zip(cu[mk], e[mk]):
+        ends[c] = max(ends.get(c, 0.0), t_)
+    print("  xcd %d: %3d items (blockIdx %% 8: %s)  busy %7.0f  CUs %d  earliest-idle %.0f  last %.0f" % (
+        k, mk.sum(), ",".join(str(v) for v in sorted(set((np.nonzero(mk)[0] % 8).tolist()))), (e[mk] - b[mk]).sum(), len(ends),
+        min(ends.values()), max(ends.values())))
 order = np.argsort(e)[-12:]
 print("last finishers: " + " ".join("L%d/%dr/%.0f-%.0f" % (level[i], nrec[i], b[i], e[i]) for i in order))
 # corners per routing record on the multi-slice levels (how many of a sample's 8 corners share a slice)
