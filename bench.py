@@ -71,7 +71,7 @@ from mipsfusion_amd import dist as mdist  # noqa: E402
 from mipsfusion_amd import ops, synth  # noqa: E402
 from mipsfusion_amd.helper_functions import sampling_helper as sh  # noqa: E402
 from mipsfusion_amd.helper_functions.geometry_helper import matrix_to_quaternion, qt_to_transform_matrix  # noqa: E402
-from mipsfusion_amd.helper_functions.utils import get_loss_from_ret  # noqa: E402
+from mipsfusion_amd.helper_functions.utils import backward_from_one, get_loss_from_ret  # noqa: E402
 from mipsfusion_amd.graph import GraphedSteps, work_stream  # noqa: E402
 from mipsfusion_amd.model import JointEncoding  # noqa: E402
 from mipsfusion_amd.optim import FusedAdam  # noqa: E402
@@ -247,7 +247,7 @@ class MappingLoop:
                                                                       self.pose_fixed, owner, accumulate_in_place=True)
         ret = self.model.forward(rays_o, rays_d, target_s, target_d, noise=noise)
         loss = get_loss_from_ret(ret, cfg["training"])
-        loss.backward(retain_graph=self.torch_pose)
+        backward_from_one(loss, retain_graph=self.torch_pose)     # = loss.backward(), minus autograd's ones_like fill
         self.i += 1
         if self.i % cfg["mapping"]["map_accum_step"] == 0:
             self.map_opt.step(zero_grad=True)           # step + zero_grad (mipsfusion.py:330-335) in one pass

@@ -37,7 +37,7 @@ import torch
 from . import hostrng, ops
 from .helper_functions import sampling_helper as sh
 from .helper_functions.geometry_helper import matrix_to_quaternion, qt_to_transform_matrix
-from .helper_functions.utils import get_loss_from_ret
+from .helper_functions.utils import backward_from_one, get_loss_from_ret
 from .keyframe_rays import DeviceRayDB
 
 
@@ -491,7 +491,7 @@ class GraphedSequence:
             rays_o, rays_d, rgb, depth = ops.gather_pose_rays(self.table, rows[k], self.ba_rot, self.ba_trans, self.fixed,
                                                               owner[k], accumulate_in_place=True)
             ret = self.model.forward(rays_o, rays_d, rgb, depth, noise=noise[k])
-            get_loss_from_ret(ret, tcfg).backward()
+            backward_from_one(get_loss_from_ret(ret, tcfg))
             self.map_opt.step(zero_grad=True)
             if (k + 1) % mp["pose_accum_step"] == 0:
                 self.ba_popt.step(zero_grad=True)
@@ -503,7 +503,7 @@ class GraphedSequence:
         rays_o, rays_d, rgb, depth = ops.gather_pose_rays(self.cur, self.go_idx, self.go_rot, self.go_trans, None,
                                                           self.go_own, accumulate_in_place=True)
         ret = self.model.forward(rays_o, rays_d, rgb, depth, EMD_w=0., noise=self.go_noise[k])
-        get_loss_from_ret(ret, self.cfg["training"]).backward()
+        backward_from_one(get_loss_from_ret(ret, self.cfg["training"]))
         self.go_popt.step(zero_grad=True)
         if k == self.cfg["tracking"]["iter"] - 1:
             self.model.frozen_weights(False)
