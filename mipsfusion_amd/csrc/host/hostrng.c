@@ -18,11 +18,7 @@
 #define MT_N 624
 #define MT_M 397
 
-typedef struct {
-    uint32_t state[MT_N];
-    int32_t left;
-    uint32_t next;
-} mipsf_mt;
+#include "mipsf_host.h"          /* mipsf_mt and the entry points (include/mipsf_host.h) */
 
 static inline uint32_t mt_twist(uint32_t u, uint32_t v) {
     return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u);

@@ -15,6 +15,8 @@
 #include <immintrin.h>
 #include <stdint.h>
 
+#include "mipsf_host.h"
+
 #include <algorithm>
 #include <cmath>
 #include <utility>

@@ -387,3 +387,15 @@ def test_host_replica_of_python_random_sample_draws_the_same_indices():
     with hostrng.py_session() as r:
         with pytest.raises(ValueError):
             r.sample_range(10, 11)                                 # python's own error for python's own reasons
+
+
+def test_host_library_exports_every_symbol_of_its_header():
+    """include/mipsf_host.h (libmipsf_hostrng.so, the host generator replicas) against the built library."""
+    hostrng = _hostrng_or_skip()
+    header = open(os.path.join(ROOT, "include", "mipsf_host.h")).read()
+    names = sorted(set(re.findall(r"\b(mipsf_[a-z0-9_]+)\s*\(", header)))
+    assert len(names) >= 5, names
+    handle = C.CDLL(hostrng._LIB_PATH)
+    for name in names:
+        assert hasattr(handle, name), f"{name} declared in mipsf_host.h but not exported"
+    assert handle.mipsf_hostrng_abi() == 2
