@@ -55,6 +55,17 @@ def _load():
     return _lib
 
 
+def _guarded(check) -> bool:
+    """a replica is used only if the library loads, is not switched off, and its check against the library routine passes
+    -- a check that cannot even run (another generator state layout, a missing symbol) counts as failed"""
+    if os.environ.get("MIPSF_NO_HOSTRNG"):
+        return False
+    try:
+        return bool(_load()) and bool(check())
+    except Exception:                                            # noqa: BLE001 -- any failure selects the library routine
+        return False
+
+
 class _Session:
     """the generator state lives here between `take` and `give`"""
 
@@ -137,7 +148,7 @@ def available(threads: int = 4) -> bool:
     """True when the C replica is present AND reproduces this torch build's draws bit for bit (checked once)."""
     global _ok
     if _ok is None:
-        _ok = bool(_load()) and not os.environ.get("MIPSF_NO_HOSTRNG") and _self_check(threads)
+        _ok = _guarded(lambda: _self_check(threads))
     return _ok
 
 
@@ -198,7 +209,7 @@ def topk_available() -> bool:
     """True when the one-pass score + top-k of the library returns torch.topk's indices in torch.topk's order here."""
     global _topk_ok
     if _topk_ok is None:
-        _topk_ok = bool(_load()) and not os.environ.get("MIPSF_NO_HOSTRNG") and _topk_self_check()
+        _topk_ok = _guarded(_topk_self_check)
     return _topk_ok
 
 
@@ -278,7 +289,7 @@ def _py_self_check() -> bool:
 def py_available() -> bool:
     global _py_ok
     if _py_ok is None:
-        _py_ok = bool(_load()) and not os.environ.get("MIPSF_NO_HOSTRNG") and _py_self_check()
+        _py_ok = _guarded(_py_self_check)
     return _py_ok
 
 
