@@ -424,7 +424,7 @@ def measured_sequence(n_frames, dev, stream):
         frames = [synth.make_frame(cfg, gt[k], seed=k, frame_id=k) for k in range(n_frames)]
         seq = sequence.GraphedSequence(cfg, dev, frames, kf_every=15, sampler=sampler, first_iters=200, stream=stream)
         res = seq.run(gt)
-        out[sampler] = sequence.summarise(res, gt, cfg, "hipGraph replay per tracking frame / per BA round; RO eager")
+        out[sampler] = sequence.summarise(res, gt, cfg, "hipGraph replay per tracking frame / per BA round; RandomOptimizer rounds of a frame in one replay")
         del seq
         torch.cuda.empty_cache()
     return out

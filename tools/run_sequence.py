@@ -244,7 +244,7 @@ def main_graphed(a):
     frames = [synth.make_frame(cfg, gt[k], seed=k, frame_id=k) for k in range(a.frames)]
     seq = sequence.GraphedSequence(cfg, dev, frames, kf_every=15, sampler=a.sampler, first_iters=a.first_iters)
     res = seq.run(gt)
-    launch = ("hipGraph replay per tracking frame / per BA round; RO rounds eager; includes the 8 MB pinned frame upload; "
+    launch = ("hipGraph replay per tracking frame / per BA round; RandomOptimizer rounds of a frame in one replay; includes the 8 MB pinned frame upload; "
               + ("pixel / keyframe-ray indices and jitter from the reference's host generators (python random, torch CPU), "
                  "drawn map_every frames ahead by producer threads" if a.sampler == "reference" else
                  "indices + jitter drawn on the device (valid depth only, without replacement)"))
