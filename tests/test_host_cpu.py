@@ -399,3 +399,35 @@ def test_host_library_exports_every_symbol_of_its_header():
     for name in names:
         assert hasattr(handle, name), f"{name} declared in mipsf_host.h but not exported"
     assert handle.mipsf_hostrng_abi() == 2
+
+
+def test_packed_ba_views_share_the_front_of_the_slot_buffers():
+    """mipsfusion_amd.sequence.packed: the [iters, n(, S)] view of a local-BA round is the contiguous FRONT of the
+    [iters, n_max(, S)] buffer (host and device sides copy it with one DMA transfer each), for every ray count."""
+    from mipsfusion_amd import sequence
+    rows = torch.arange(5 * 12, dtype=torch.int64).view(5, 12).clone()
+    noise = torch.arange(5 * 12 * 3, dtype=torch.float32).view(5, 12, 3).clone()
+    for n in (12, 8, 1):
+        v, w = sequence.packed(rows, n), sequence.packed(noise, n)
+        assert v.shape == (5, n) and w.shape == (5, n, 3) and v.is_contiguous() and w.is_contiguous()
+        assert v.data_ptr() == rows.data_ptr() and w.data_ptr() == noise.data_ptr()
+        assert torch.equal(v.reshape(-1), rows.reshape(-1)[:5 * n])
+    s = sequence.FrameSamples(n_track=4, it_track=2, n_ba_max=12, it_ba=5, S=3, pinned=False)
+    s.n_ba = 7
+    r, o, z = s.ba_packed()
+    assert r.shape == (5, 7) and o.shape == (5, 7) and z.shape == (5, 7, 3)
+    r.fill_(3)
+    assert int(s.ba_rows.reshape(-1)[:35].sum()) == 105
+
+
+def test_backward_from_one_is_loss_backward():
+    """helper_functions.utils.backward_from_one: the same gradients as loss.backward() (the root gradient comes from a
+    cached tensor of ones instead of a fill per call)."""
+    from mipsfusion_amd.helper_functions.utils import backward_from_one
+    w1 = torch.randn(7, requires_grad=True)
+    w2 = w1.detach().clone().requires_grad_(True)
+    x = torch.randn(7)
+    ((w1 * x).sin().sum() * 3).backward()
+    for _ in range(2):                                   # second call: the cached root gradient, accumulated grads
+        backward_from_one((w2 * x).sin().sum() * 3)
+    assert torch.equal(w2.grad, 2 * w1.grad)
