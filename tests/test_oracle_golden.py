@@ -277,7 +277,9 @@ def test_random_optimizer_restatement_matches_reference():
     c1, c2, trunc = float(g["c1"]), float(g["c2"]), float(g["trunc"])
     # one fitness evaluation
     pst7 = ro_cpu.pose_6d_to_7d(pst * c1)
-    close(pst7, g["pst7_0"], rtol=0, atol=0)
+    # one ulp of fp32 at |v| <= 1: torch's CPU sin / cos / sqrt kernels differ by that much between the SIMD paths of
+    # different hosts (bit-equal on the machine that wrote the fixture, 26 of 672 values 6e-8 off on the GPU hosts' CPUs)
+    close(pst7, g["pst7_0"], rtol=0, atol=1.2e-7)
     td = depth[rows, cols][:, None]
     world, a_rot, a_trans = ro_cpu.particle_points(init[:3, :3], init[:3, 3:], pst7, rays_dir[rows, cols, :] * td)
     close(a_rot, g["abs_rot0"], rtol=1e-6, atol=1e-7)
