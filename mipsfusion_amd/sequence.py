@@ -217,26 +217,23 @@ class ReferenceSampleProducer:
             # the draws below go through the C replica of torch's CPU generator (mipsfusion_amd/hostrng.py: same stream,
             # same bits, checked against torch at start-up, torch's own functions otherwise): 0.55 instead of 1.5-2.3 ms
             # per mapping iteration of this serial stage
-            rng = hostrng.session()
-            g = rng.__enter__()
             if _DIAG_OFF == "torch":                                # diagnosis only (tools/micro): skip the draws
                 n_items = (1 if plan.track and not iter_ro0 else 0) + (self.it_ba if plan.ba_kf_ids is not None else 0)
                 for _ in range(n_items):
                     s._part_done()
                 s._part_done()
-                rng.__exit__(None, None, None)
                 continue
-            if plan.track:
-                if not iter_ro0:                                    # sample_pixels_mix (mipsfusion.py:519-523)
-                    self._q_topk.put((plan, s, "track", 0, self._draw_scores(g, plan.depth)))
-                for i in range(self.it_track):                      # scene_rep.py:176, one draw per forward
-                    g.rand_(s.track_noise[i])
-            if plan.ba_kf_ids is not None:
-                noise = s.ba_packed()[2]
-                for i in range(self.it_ba):
-                    self._q_topk.put((plan, s, "ba", i, self._draw_scores(g, plan.depth)))   # :302 / :306-307
-                    g.rand_(noise[i])
-            rng.__exit__(None, None, None)
+            with hostrng.session() as g:
+                if plan.track:
+                    if not iter_ro0:                                # sample_pixels_mix (mipsfusion.py:519-523)
+                        self._q_topk.put((plan, s, "track", 0, self._draw_scores(g, plan.depth)))
+                    for i in range(self.it_track):                  # scene_rep.py:176, one draw per forward
+                        g.rand_(s.track_noise[i])
+                if plan.ba_kf_ids is not None:
+                    noise = s.ba_packed()[2]
+                    for i in range(self.it_ba):
+                        self._q_topk.put((plan, s, "ba", i, self._draw_scores(g, plan.depth)))   # :302 / :306-307
+                        g.rand_(noise[i])
             self.host_ms["torch_rng"] += (time.perf_counter() - t0) * 1e3
             s._part_done()
 
@@ -303,24 +300,22 @@ class ReferenceSampleProducer:
                 continue
             # the draws go through hostrng's replica of random.sample(range(n), k) (same generator, same indices, checked
             # against python's at start-up, python's own otherwise): 25 -> 1 ms per mapping round of 15 iterations here
-            rng = hostrng.py_session()
-            r = rng.__enter__()
-            if plan.track and tk["iter_RO"] == 0:
-                iH, iW = tk["ignore_edge_H"], tk["ignore_edge_W"]
-                hh = self.H - 2 * iH
-                indice = r.sample_range(hh * (self.W - 2 * iW), int(self.n_track))      # sh.select_samples
-                ih, iw = torch.remainder(indice, hh), torch.div(indice, hh, rounding_mode="floor")
-                s.track_idx.copy_((ih + iH) * self.W + (iw + iW))
-            if plan.ba_kf_ids is not None:
-                n_kf, _ = ba_ray_counts(self.cfg, plan.ba_kf_ids.shape[0])
-                first = plan.ba_kf_ids[0]
-                rows, owner, _ = s.ba_packed()
-                for i in range(self.it_ba):
-                    self.gate.wait()
-                    flat, _, kf_indices = self._index_db.indices_in_submap(first, plan.ba_kf_ids, n_kf, r.sample_range)
-                    rows[i, :n_kf].copy_(flat)
-                    owner[i, :n_kf].copy_(kf_indices)
-            rng.__exit__(None, None, None)
+            with hostrng.py_session() as r:
+                if plan.track and tk["iter_RO"] == 0:
+                    iH, iW = tk["ignore_edge_H"], tk["ignore_edge_W"]
+                    hh = self.H - 2 * iH
+                    indice = r.sample_range(hh * (self.W - 2 * iW), int(self.n_track))      # sh.select_samples
+                    ih, iw = torch.remainder(indice, hh), torch.div(indice, hh, rounding_mode="floor")
+                    s.track_idx.copy_((ih + iH) * self.W + (iw + iW))
+                if plan.ba_kf_ids is not None:
+                    n_kf, _ = ba_ray_counts(self.cfg, plan.ba_kf_ids.shape[0])
+                    first = plan.ba_kf_ids[0]
+                    rows, owner, _ = s.ba_packed()
+                    for i in range(self.it_ba):
+                        self.gate.wait()
+                        flat, _, kf_indices = self._index_db.indices_in_submap(first, plan.ba_kf_ids, n_kf, r.sample_range)
+                        rows[i, :n_kf].copy_(flat)
+                        owner[i, :n_kf].copy_(kf_indices)
             self.host_ms["python_rng"] += (time.perf_counter() - t0) * 1e3
             s._part_done()
 
