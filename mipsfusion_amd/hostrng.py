@@ -228,7 +228,8 @@ def topk_valid_pixels(depth: torch.Tensor, draw: torch.Tensor, k: int, blocked: 
 class _PySession:
     """python's global `random` generator between `take` and `give`: ``sample_range(n, k)`` == ``torch.tensor(
     random.sample(range(n), k))`` (keyframeSet.py:386-436 draws the rays of a mapping iteration this way, ~1 us per
-    index in the interpreter)."""
+    index in the interpreter).  As with the torch session: whoever else draws from the global generator while a session
+    is open sees the state of `take` time and is overwritten by `give` -- one thread owns a generator's stream."""
 
     def __init__(self, native: bool):
         self.native = native
