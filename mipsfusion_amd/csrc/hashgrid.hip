@@ -214,10 +214,22 @@ constexpr uint32_t SC_SLICE_LOG2 = MIPSF_SC_SLICE_LOG2;   // slices of multi-sli
 #ifndef MIPSF_SC_PART
 #define MIPSF_SC_PART 24576
 #endif
+#ifndef MIPSF_SC_PART_DENSE
+#define MIPSF_SC_PART_DENSE 12288
+#endif
 #ifndef MIPSF_SC_RUN
 #define MIPSF_SC_RUN 4
 #endif
-constexpr uint32_t SC_PART = MIPSF_SC_PART;           // records per accumulate workgroup
+#ifndef MIPSF_SC_SKIP_ZERO
+#define MIPSF_SC_SKIP_ZERO 1    // experiments: 0 = records for samples with a zero feature gradient, too
+#endif
+// Records per accumulate workgroup.  A hashed level's bins are split only when they must be (a part that is not the bin's
+// only one goes through a 64 KB partial slice and the reduce kernel); the dense levels' slices are small and their bins
+// hold every live sample of the batch: they are cut finer, because the longest work item bounds the kernel's span once
+// half of the samples are skipped (zero feature gradient) -- 24576-record parts: 111 us, 12288: 73 us.
+constexpr uint32_t SC_PART = MIPSF_SC_PART;
+constexpr uint32_t SC_PART_DENSE = MIPSF_SC_PART_DENSE;
+constexpr uint32_t SC_PART_MIN = SC_PART < SC_PART_DENSE ? SC_PART : SC_PART_DENSE;
 constexpr uint32_t SC_RUN = MIPSF_SC_RUN;                   // consecutive records merged per thread in the accumulate kernel
 constexpr uint32_t SC_ROUTE_UNR = 4;                // samples per thread in the routing kernel
 constexpr uint32_t SC_MAX_NS = 512;                 // slices per level (2^22-entry levels)
@@ -236,6 +248,7 @@ struct ScatterPlan {
     uint32_t n_bins;
     uint32_t max_items;                           // upper bound on accumulate work items for this M
     uint32_t max_slice;                           // entries of the largest slice (= the accumulate kernel's LDS / 16)
+    uint32_t dense_bins;                          // bins [0, dense_bins) belong to the dense levels (they come first)
     // scratch layout, in 4-byte words from the start of the scratch buffer
     uint32_t w_count, w_first, w_parts, w_nitems, w_items;
     uint64_t w_records, w_partial, w_end;         // records: n_bins regions of bin_cap words
@@ -259,9 +272,13 @@ static ScatterPlan make_plan(const GridLevels& g, uint32_t M) {
     }
     p.bin0[g.n_levels] = bins;
     p.n_bins = bins;
+    for (uint32_t l = 0; l < g.n_levels; ++l) {          // (hashed levels follow the dense ones: resolutions only grow)
+        if (level_is_hashed(g.res[l], g.offsets[l + 1] - g.offsets[l])) break;
+        p.dense_bins = p.bin0[l + 1];
+    }
     for (uint32_t l = 0; l < g.n_levels; ++l) p.max_slice = p.slice_entries[l] > p.max_slice ? p.slice_entries[l] : p.max_slice;
     const uint64_t max_records = 8ull * g.n_levels * M;
-    p.max_items = (uint32_t)((max_records + SC_PART - 1) / SC_PART) + bins;
+    p.max_items = (uint32_t)((max_records + SC_PART_MIN - 1) / SC_PART_MIN) + bins;
     uint64_t w = 0;
     p.w_count = (uint32_t)w, w += bins;
     p.w_nitems = (uint32_t)w, w += 4;
@@ -370,7 +387,15 @@ __device__ __forceinline__ bool route_groups_hashed_pow2(const Cell& cell, uint3
 // One workgroup = one level x 4096 consecutive samples: rank the records inside the workgroup with LDS counters,
 // reserve room in every bin with ONE global atomic per bin, write the sample indices.  (Staging the records bin by
 // bin in LDS to make the stores coalesced was measured slower: 67 vs 61 us.)
-__global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __restrict__ x, uint32_t M, GridLevels g,
+//
+// dout (optional: the feature gradient the records will be used with, in `layout`): a (sample, level) whose two feature
+// gradients are exactly zero adds nothing to the table gradient and gets no record.  Half of a mapping batch is like that
+// -- samples behind the truncation band carry no loss term and no rendering weight (45-56 % of the samples, on every
+// level, tools/micro/dout_zero_probe.py) -- so routing and accumulation handle half the records.  Exact: the skipped
+// contributions are +-0.
+template <int LAYOUT>
+__global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ dout, uint32_t M, GridLevels g,
                                                                 ScatterPlan plan, uint32_t* __restrict__ ws) {
     __shared__ uint32_t cnt[SC_MAX_NS];
     __shared__ uint32_t base[SC_MAX_NS];
@@ -408,7 +433,12 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __
         const uint32_t i = s0 + u * SC_BLOCK + threadIdx.x;
         uint32_t s[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, m[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
         bool general = false;
-        if (i < M) {
+        bool live = i < M;
+        if (live && dout != nullptr) {
+            const float2 gy = *reinterpret_cast<const float2*>(dout + feat_index<LAYOUT>(i, level, M, plan.n_levels));
+            live = !(gy.x == 0.0f && gy.y == 0.0f);           // (NaN gradients stay live)
+        }
+        if (live) {
             const Cell cell = locate(x, i, scale);
             if (MIPSF_SC_ROUTE_FAST && mode == 0) general = !route_groups_dense(cell, res, size, shift, s, m);
             else if (MIPSF_SC_ROUTE_FAST && mode == 1) general = !route_groups_hashed_pow2(cell, size, shift, s, m);
@@ -496,6 +526,10 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __
     }
 }
 
+__device__ __forceinline__ uint32_t part_of(const ScatterPlan& plan, uint32_t bin) {
+    return bin < plan.dense_bins ? SC_PART_DENSE : SC_PART;
+}
+
 // one workgroup: the (bin, part) work-item table from the bin counts
 __global__ __launch_bounds__(1024) void scatter_scan_kernel(ScatterPlan plan, uint32_t* __restrict__ ws) {
     __shared__ uint32_t sitm[1024];
@@ -506,7 +540,7 @@ __global__ __launch_bounds__(1024) void scatter_scan_kernel(ScatterPlan plan, ui
     for (uint32_t k = 0; k < PER; ++k) {
         const uint32_t b = t * PER + k;
         cnt[k] = b < plan.n_bins ? ws[plan.w_count + b] : 0u;
-        litm += (cnt[k] + SC_PART - 1) / SC_PART;
+        litm += (cnt[k] + part_of(plan, b) - 1) / part_of(plan, b);
     }
     sitm[t] = litm;
     __syncthreads();
@@ -526,7 +560,7 @@ __global__ __launch_bounds__(1024) void scatter_scan_kernel(ScatterPlan plan, ui
     for (uint32_t k = 0; k < PER; ++k) {
         const uint32_t b = t * PER + k;
         if (b < plan.n_bins) {
-            const uint32_t parts = (cnt[k] + SC_PART - 1) / SC_PART;
+            const uint32_t parts = (cnt[k] + part_of(plan, b) - 1) / part_of(plan, b);
             ws[plan.w_first + b] = oitm;
             ws[plan.w_parts + b] = parts;
             for (uint32_t q = 0; q < parts; ++q) items[oitm + q] = make_uint4(b | (q << 16), cnt[k], parts, 0u);
@@ -567,8 +601,8 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
     const uint32_t res = g.res[level];
     const float scale = g.scale[level];
     const uint32_t n_rec_bin = desc.y;
-    const uint32_t r0 = part * SC_PART;
-    const uint32_t n_rec = n_rec_bin - r0 < SC_PART ? n_rec_bin - r0 : SC_PART;
+    const uint32_t r0 = part * part_of(plan, bin);
+    const uint32_t n_rec = n_rec_bin - r0 < part_of(plan, bin) ? n_rec_bin - r0 : part_of(plan, bin);
     const uint32_t* __restrict__ rec = ws + plan.w_records + (size_t)bin * M + r0;
 
     // ... and the current gradient values of the slice are requested now: by the time the records are through they have
@@ -998,15 +1032,19 @@ static int check_plan(const ScatterPlan& plan, const GridLevels& g, uint32_t M) 
     for (uint32_t l = 0; l < g.n_levels; ++l)
         MIPSF_REQUIRE(plan.n_slices[l] <= SC_MAX_NS, "level %u too large: %u slices", l, plan.n_slices[l]);
     MIPSF_REQUIRE(plan.w_end < (1ull << 32), "batch too large for 32-bit scratch offsets (M = %u)", M);
-    MIPSF_REQUIRE(((uint64_t)M + SC_PART - 1) / SC_PART < (1u << 16), "batch too large (M = %u)", M);
+    MIPSF_REQUIRE(((uint64_t)M + SC_PART_MIN - 1) / SC_PART_MIN < (1u << 16), "batch too large (M = %u)", M);
     return 0;
 }
 
-static int launch_route(const float* x, uint32_t* ws, uint32_t M, const GridLevels& g, const ScatterPlan& plan, hipStream_t s) {
+static int launch_route(const float* x, const float* dout, int layout, uint32_t* ws, uint32_t M, const GridLevels& g,
+                        const ScatterPlan& plan, hipStream_t s) {
     const uint32_t nz = plan.w_nitems + 4;   // bin counts, item count
     hipLaunchKernelGGL(scatter_zero_kernel, dim3((nz + 255) / 256), dim3(256), 0, s, ws, nz);
     const uint32_t rb = g.n_levels * ((M + SC_BLOCK * SC_ROUTE_UNR - 1) / (SC_BLOCK * SC_ROUTE_UNR));
-    hipLaunchKernelGGL(scatter_route_kernel, dim3(rb), dim3(SC_BLOCK), 0, s, x, M, g, plan, ws);
+    if (layout == MIPSF_FEAT_AOS)
+        hipLaunchKernelGGL(scatter_route_kernel<MIPSF_FEAT_AOS>, dim3(rb), dim3(SC_BLOCK), 0, s, x, dout, M, g, plan, ws);
+    else
+        hipLaunchKernelGGL(scatter_route_kernel<MIPSF_FEAT_LEVEL_MAJOR>, dim3(rb), dim3(SC_BLOCK), 0, s, x, dout, M, g, plan, ws);
     hipLaunchKernelGGL(scatter_scan_kernel, dim3(1), dim3(1024), 0, s, plan, ws);
     return check_launch("hashgrid_route");
 }
@@ -1020,7 +1058,7 @@ int mipsf_hashgrid_route(const float* x, float* scratch, uint32_t M, const mipsf
     MIPSF_REQUIRE(x && scratch, "null pointer");
     const ScatterPlan plan = make_plan(g, M);
     if (int rc = check_plan(plan, g, M)) return rc;
-    return launch_route(x, reinterpret_cast<uint32_t*>(scratch), M, g, plan, (hipStream_t)stream);
+    return launch_route(x, nullptr, MIPSF_FEAT_AOS, reinterpret_cast<uint32_t*>(scratch), M, g, plan, (hipStream_t)stream);
 }
 
 static int hashgrid_bwd_impl(const float* x, const float* params, const float* dout, float* dparams, float* dx,
@@ -1039,7 +1077,7 @@ static int hashgrid_bwd_impl(const float* x, const float* params, const float* d
     float* dxl = scratch + ((plan.w_end + 15) / 16) * 16;
     if (dparams) {   // a frozen grid (tracking) skips the scatter altogether
         if (!routed)
-            if (int e = launch_route(x, ws, M, g, plan, s)) return e;
+            if (int e = launch_route(x, MIPSF_SC_SKIP_ZERO ? dout : nullptr, layout, ws, M, g, plan, s)) return e;
         uint32_t max_slice = 0;
         for (uint32_t l = 0; l < g.n_levels; ++l) max_slice = plan.slice_entries[l] > max_slice ? plan.slice_entries[l] : max_slice;
         const uint32_t lds_bytes = max_slice * 16;
