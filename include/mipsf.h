@@ -162,6 +162,16 @@ int mipsf_decoder_fwd16_ex(const float* packed16, const float* feat, int feat_la
  * mipsf_decoder_fwd / _fwd16 (only the ReLU masks are read). */
 int mipsf_decoder_bwd_chain16(const float* packed16, int feat_layout, const float* x, const float* out, const float* dout,
                               const float* saved, float* dfeat, float* dx, float* dact, uint32_t M, void* stream);
+/* The same with ZERO-TILE flags.  Samples behind the truncation band receive an exactly zero gradient from the losses
+ * (scene_rep.py:58-78, helper_functions/utils.py:21-49: no mask covers them); along a ray they are the tail, so whole
+ * 32-sample tiles are zero.  tile_live (mipsf_decoder_tile_words(M) words, NULL = the call above) receives lists of
+ * the tiles with a non-zero incoming gradient (opaque: work counters + eight lists, csrc/decoder16.hip); a tile that is
+ * not listed gets dfeat = dx = 0 and NO entry in `dact` (nothing else is read or written for it).  The buffer then
+ * goes to mipsf_decoder_wgrad16_tiles, which visits the listed tiles only. */
+uint64_t mipsf_decoder_tile_words(uint32_t M);
+int mipsf_decoder_bwd_chain16_ex(const float* packed16, int feat_layout, const float* x, const float* out,
+                                 const float* dout, const float* saved, float* dfeat, float* dx, float* dact,
+                                 uint32_t* tile_live, uint32_t M, void* stream);
 /* Backward.  dout [M,10].  Outputs: dfeat (layout as feat), dx [M,3] (pe_mode 0: includes the PE chain),
  * dembed_pos [M,48] (pe_mode 1 only).  Weight gradients are ACCUMULATED into `grads`.
  * dact / partial: scratch of the sizes above. */
@@ -203,6 +213,11 @@ int mipsf_decoder_wgrad16(const float* feat, int feat_layout, const float* x, co
 int mipsf_decoder_wgrad16_ex(const float* packed16, const float* feat, int feat_layout, const float* x, const float* saved,
                              const float* dact, const mipsf_decoder_grads* grads_host_struct, float* partial,
                              int arithmetic, uint32_t M, void* stream);
+/* ... over the tiles listed by mipsf_decoder_bwd_chain16_ex only (tile_live as written there; NULL = every tile). */
+int mipsf_decoder_wgrad16_tiles(const float* packed16, const float* feat, int feat_layout, const float* x,
+                                const float* saved, const float* dact, const uint32_t* tile_live,
+                                const mipsf_decoder_grads* grads_host_struct, float* partial, int arithmetic, uint32_t M,
+                                void* stream);
 
 /* -------------------------------------------------- sample placement (a3 + a4) */
 typedef struct mipsf_render_cfg {

@@ -401,12 +401,26 @@ __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_fwd_lds_kernel(con
 // like the forward: every gradient tile is an accumulator image whose registers are the next product's B operand after
 // a float -> (hi, lo) conversion; the two narrow products (Ws2^T dlogits, Wrgb^T drgb: K = 5 and 3) ride on the matrix
 // pipe as one k-step each instead of ~420 fmas and 160 table reads per tile.  Operand images come from L2.
+// LIVE-TILE BUFFER (mipsf_decoder_bwd_chain16_ex -> mipsf_decoder_wgrad16_tiles), in words:
+//     [64 q]        hand-out counter of queue q = blockIdx.x & 7 (persistent kernel: tiles are dealt dynamically)
+//     [64 q + 32]   number of live tiles in list q
+//     [512 + q cap] list q: the tiles with a non-zero gradient, cap = tl_cap(n_tiles)
+// Eight queues / lists because ONE counter is one L2 atomic unit: ~12 ns per operation, 8192 tile grabs = 100 us (measured:
+// the kernel took 194 us instead of 97).  Workgroup b runs on XCD b % 8, so a queue stays within one XCD's L2; the
+// counters sit 128 bytes apart.  Queue q owns the groups of 8 consecutive tiles g with g % 8 == q.
+// (TL_HEADER, tl_cap: decoder_layout.h)
+__device__ __forceinline__ void tl_append(uint32_t* tl, uint32_t n_tiles, uint32_t tile) {
+    const uint32_t q = (tile >> 3) & 7u;
+    tl[TL_HEADER + q * tl_cap(n_tiles) + atomicAdd(tl + 64 * q + 32, 1u)] = tile;
+}
+
 template <int LAYOUT, typename Img>
 __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* __restrict__ x,
                                                    const float* __restrict__ out, const float* __restrict__ dout,
                                                    const float* __restrict__ saved, float* __restrict__ dfeat,
                                                    float* __restrict__ dx, float* __restrict__ dact,
-                                                   float* __restrict__ dsmall, uint32_t M, int64_t tile, int lane) {
+                                                   float* __restrict__ dsmall, uint32_t M, int64_t tile, int lane,
+                                                   uint32_t* __restrict__ tile_live = nullptr) {
     constexpr bool SPLIT = true;
     const int j = lane & 31, h = lane >> 5;
     const uint32_t s_raw = (uint32_t)(tile * 32 + j);
@@ -417,10 +431,40 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
 
     float2 o2[5], g2[5];
     {
-        const float2* o = reinterpret_cast<const float2*>(out + (size_t)s * 10);
         const float2* g = reinterpret_cast<const float2*>(dout + (size_t)s * 10);
 #pragma unroll
-        for (int c = 0; c < 5; ++c) o2[c] = o[c], g2[c] = g[c];
+        for (int c = 0; c < 5; ++c) g2[c] = g[c];
+    }
+    // ZERO TILES.  A sample behind the truncation band has no loss term and no rendering weight: its incoming gradient
+    // is exactly zero, and so is everything this function derives from it.  Along a ray those samples are the tail (33 of
+    // 64 on the mapping workload), so a third of the 32-sample tiles are zero throughout (tools/micro/dout_zero_probe.py).
+    // With `tile_live` the caller asks for them to be short-cut: d(features) and d(x) are written as zeros, nothing else is
+    // read or written, and the tile is left out of the list of live tiles the weight-gradient kernel works from.
+    if (tile_live != nullptr) {
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) any = any || (live && !(g2[c].x == 0.0f && g2[c].y == 0.0f));
+        const bool tile_any = __any(any) != 0;
+        if (tile_any && lane == 0) tl_append(tile_live, (uint32_t)(((uint64_t)M + 31) / 32), (uint32_t)tile);
+        if (!tile_any) {
+            if (live) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int row = rowmap(r, h);
+                    if (LAYOUT == MIPSF_FEAT_AOS)
+                        *reinterpret_cast<float2*>(dfeat + (size_t)s * N_GRID + row) = make_float2(0.f, 0.f);
+                    else
+                        *reinterpret_cast<float2*>(dfeat + ((size_t)(row >> 1) * M + s) * 2) = make_float2(0.f, 0.f);
+                }
+                if (h == 0) dx[3 * (size_t)s] = 0.f, dx[3 * (size_t)s + 1] = 0.f, dx[3 * (size_t)s + 2] = 0.f;
+            }
+            return;
+        }
+    }
+    {
+        const float2* o = reinterpret_cast<const float2*>(out + (size_t)s * 10);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) o2[c] = o[c];
     }
     const uint2* mk = reinterpret_cast<const uint2*>(saved + (((size_t)M + 127) / 128) * 4 * ACT_TILE_FLOATS) +
                       (size_t)tile * (MASK_TILE_WORDS / 2) + lane;
@@ -609,13 +653,13 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_bwd_kernel(const float
                                                                      const float* __restrict__ saved,
                                                                      float* __restrict__ dfeat, float* __restrict__ dx,
                                                                      float* __restrict__ dact, float* __restrict__ dsmall,
-                                                                     uint32_t M) {
+                                                                     uint32_t M, uint32_t* __restrict__ tile_live) {
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (tile * 32 >= (int64_t)M) return;
     const ImgBuf bimg{make_srd(reinterpret_cast<const _Float16*>(packed16 + TAIL_FLOATS) + OFF16_BWD_HALVES,
                                IMG16B_HALVES * 4), 0u, (uint32_t)IMG16B_HALVES * 2u};
-    decoder16_bwd_tile<LAYOUT>(bimg, x, out, dout, saved, dfeat, dx, dact, dsmall, M, tile, lane);
+    decoder16_bwd_tile<LAYOUT>(bimg, x, out, dout, saved, dfeat, dx, dact, dsmall, M, tile, lane, tile_live);
 }
 
 // Large batches: persistent, one 8-wave workgroup per CU holding BOTH backward image sets in LDS: 2 x 80 KB = all 160 KB
@@ -632,7 +676,8 @@ __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_bwd_lds_kernel(con
                                                                              float* __restrict__ dx,
                                                                              float* __restrict__ dact,
                                                                              float* __restrict__ dsmall, uint32_t M,
-                                                                             uint32_t n_tiles) {
+                                                                             uint32_t n_tiles,
+                                                                             uint32_t* __restrict__ tile_live) {
     extern __shared__ __attribute__((aligned(16))) float4 wbuf[];
     {
         const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const _Float16*>(packed16 + TAIL_FLOATS) +
@@ -641,13 +686,42 @@ __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_bwd_lds_kernel(con
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    for (uint32_t tile = blockIdx.x * (F16_LDS_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-         tile < n_tiles; tile += gridDim.x * (F16_LDS_BLOCK / 64)) {
+    // Round k: the workgroup's 8 waves take 8 consecutive tiles, wave w the ((w + k) & 7)-th of them (every wave
+    // alternates between first and second halves of rays, whose gradients differ in sparsity).
+    constexpr uint32_t WPB = F16_LDS_BLOCK / 64;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (tile_live != nullptr) {
+        // With the short cut a wave's four tiles cost anything between 0 and 4 live ones, and the kernel would last as
+        // long as its unluckiest wave (measured: -12 % instead of the -35 % of the tiles skipped): tiles are handed out
+        // through counters instead (one per queue, see the buffer layout above; cleared by the launcher).
+        const uint32_t q = blockIdx.x & 7u;
+        uint32_t* counter = tile_live + 64 * q;
+        // (grabbing the next tile before working on this one was measured slower, 95 vs 86 us: the atomic's round trip is
+        // longer than a load's and the tile's first loads queue behind it)
+        for (;;) {
+            uint32_t i = 0;
+            if (lane == 0) i = atomicAdd(counter, 1u);
+            i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+            const uint32_t tile = (((i >> 3) * 8u + q) << 3) + (i & 7u);          // group (i / 8) * 8 + q, member i % 8
+            if ((tile & ~7u) >= n_tiles) break;
+            if (tile >= n_tiles) continue;
+            uint32_t z = 0;
+            asm volatile("" : "+v"(z));
+            const h8* imgp = reinterpret_cast<const h8*>(wbuf + z);
+            decoder16_bwd_tile<LAYOUT>(ImgLds{imgp, imgp + IMG16B_HALVES / 8}, x, out, dout, saved, dfeat, dx, dact, dsmall,
+                                       M, (int64_t)tile, lane, tile_live);
+        }
+        return;
+    }
+    uint32_t k = 0;
+    for (uint32_t first = blockIdx.x * WPB; first < n_tiles; first += gridDim.x * WPB, ++k) {
+        const uint32_t tile = first + ((w + k) & (WPB - 1));
+        if (tile >= n_tiles) continue;
         uint32_t z = 0;
         asm volatile("" : "+v"(z));
         const h8* imgp = reinterpret_cast<const h8*>(wbuf + z);
         decoder16_bwd_tile<LAYOUT>(ImgLds{imgp, imgp + IMG16B_HALVES / 8}, x, out, dout, saved, dfeat, dx, dact, dsmall, M,
-                                   (int64_t)tile, lane);
+                                   (int64_t)tile, lane, tile_live);
     }
 }
 
@@ -757,6 +831,15 @@ int mipsf_decoder_fwd16_ex(const float* packed16, const float* feat, int feat_la
 
 int mipsf_decoder_bwd_chain16(const float* packed16, int feat_layout, const float* x, const float* out, const float* dout,
                               const float* saved, float* dfeat, float* dx, float* dact, uint32_t M, void* stream) {
+    return mipsf_decoder_bwd_chain16_ex(packed16, feat_layout, x, out, dout, saved, dfeat, dx, dact, nullptr, M, stream);
+}
+
+// tile_live (optional, mipsf_decoder_tile_words(M) words): receives the lists of the 32-sample tiles whose incoming
+// gradient is not zero throughout (layout above); the other tiles get d(features) = d(x) = 0 and NO entry in `dact` --
+// hand the same buffer to mipsf_decoder_wgrad16_tiles.
+int mipsf_decoder_bwd_chain16_ex(const float* packed16, int feat_layout, const float* x, const float* out,
+                                 const float* dout, const float* saved, float* dfeat, float* dx, float* dact,
+                                 uint32_t* tile_live, uint32_t M, void* stream) {
     if (M == 0) return 0;
     MIPSF_REQUIRE(packed16 && x && out && dout && saved && dfeat && dx && dact, "null pointer");
     MIPSF_REQUIRE(feat_layout == MIPSF_FEAT_AOS || feat_layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout");
@@ -768,6 +851,10 @@ int mipsf_decoder_bwd_chain16(const float* packed16, int feat_layout, const floa
     const int cus = device_cus();
     if (cus <= 0) return 3;
     const bool persistent = n_tiles >= (uint32_t)cus * 8u * 2u && !getenv("MIPSF_B16_NO_LDS");
+    if (tile_live != nullptr && hipMemsetAsync(tile_live, 0, TL_HEADER * sizeof(uint32_t), s) != hipSuccess) {
+        set_error("cannot clear the tile counters");
+        return 4;
+    }
 #define B16(LAY)                                                                                                   \
     do {                                                                                                           \
         if (persistent) {                                                                                          \
@@ -782,10 +869,10 @@ int mipsf_decoder_bwd_chain16(const float* packed16, int feat_layout, const floa
                 attr_set = true;                                                                                   \
             }                                                                                                      \
             hipLaunchKernelGGL((decoder16_bwd_lds_kernel<LAY>), dim3(cus), dim3(F16_LDS_BLOCK), B16_LDS_BYTES, s,   \
-                               packed16, x, out, dout, saved, dfeat, dx, dact, dsmall, M, n_tiles);                \
+                               packed16, x, out, dout, saved, dfeat, dx, dact, dsmall, M, n_tiles, tile_live);     \
         } else {                                                                                                   \
             hipLaunchKernelGGL((decoder16_bwd_kernel<LAY>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed16, x, out,  \
-                               dout, saved, dfeat, dx, dact, dsmall, M);                                           \
+                               dout, saved, dfeat, dx, dact, dsmall, M, tile_live);                                \
         }                                                                                                          \
     } while (0)
     if (feat_layout == MIPSF_FEAT_AOS) B16(MIPSF_FEAT_AOS); else B16(MIPSF_FEAT_LEVEL_MAJOR);

@@ -39,6 +39,10 @@ constexpr int T_F1 = 28, T_F2 = 64, T_F3 = 48;      // forward: pts0, pts2, sdf0
 constexpr int T_B3 = 64, T_B2 = 64, T_B1 = 64;      // backward chain: sdf0^T, pts2^T, pts0^T
 constexpr int RT_F1 = 4, RT_F2 = 4, RT_F3 = 4, RT_B3 = 3, RT_B2 = 4, RT_B1 = 2;
 
+// live-tile buffer of the backward pass (decoder16.hip: layout; wgrad16.hip: reader): header words, list capacity
+constexpr unsigned TL_HEADER = 512;
+MIPSF_HD unsigned tl_cap(unsigned n_tiles) { return ((n_tiles + 63u) / 64u) * 8u + 8u; }
+
 MIPSF_HD int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 MIPSF_HD int feat_of(int q, int r, int h) { return 32 * q + rowmap(r, h); }
 // feature carried by half h at k-step t when the B operand is accumulator reg (t/16, t%16)

@@ -199,10 +199,24 @@ struct W16Args {
     const float* __restrict__ dact;
     const float* __restrict__ dsmall;
     float* __restrict__ rec;            // this block's partial record
-    uint32_t M, n_tiles;
+    uint32_t M, n_tiles;                // n_tiles: tiles to visit (= all list entries when there are lists)
+    const uint32_t* live;               // the live-tile buffer of the chain kernel (decoder16.hip), or null = every tile
+    uint32_t live_cap;                  // capacity of one of its eight lists
+    uint32_t live_start[8];             // first visit index of each list
     const h8* w1_hi;                    // LDS copies of the forward's layer-1 operand images (recompute variant), else null
     const h8* w1_lo;
 };
+
+// the it-th tile of a pass, last first: the records the chain kernel wrote last are still in the 256 MB Infinity Cache
+__device__ __forceinline__ uint32_t w16_tile(const W16Args& a, uint32_t it) {
+    const uint32_t k = a.n_tiles - 1 - it;
+    if (!a.live) return k;
+    uint32_t q = 0, first = 0;
+#pragma unroll
+    for (uint32_t j = 1; j < 8; ++j)
+        if (k >= a.live_start[j]) q = j, first = a.live_start[j];
+    return a.live[TL_HEADER + q * a.live_cap + (k - first)];
+}
 
 // column of the e products: slot t = 16 ct + 8 (c >> 4) + 4 ((c >> 3) & 1) + (c & 3), half (c >> 2) & 1
 __device__ __forceinline__ int w16_e_col(int ct, int c) {
@@ -312,12 +326,12 @@ __device__ __forceinline__ void w16_role_a(const W16Args& a, const typename A::v
     // tiles in reverse: the records the chain kernel wrote last are still in the 256 MB Infinity Cache
     uint32_t it = blockIdx.x;
     if (it < a.n_tiles) {
-        load_tile_rows(act_srd(a.dact, a.n_tiles - 1 - it), 1, w, lane16, buf[0]);
-        load_tile_rows(act_srd(a.saved, a.n_tiles - 1 - it), 0, 0, lane16, buf[1]);
+        load_tile_rows(act_srd(a.dact, w16_tile(a, it)), 1, w, lane16, buf[0]);
+        load_tile_rows(act_srd(a.saved, w16_tile(a, it)), 0, 0, lane16, buf[1]);
     }
 #pragma clang loop unroll(disable)
     for (; it < a.n_tiles; it += gridDim.x) {
-        const uint32_t tile = a.n_tiles - 1 - it;
+        const uint32_t tile = w16_tile(a, it);
 #ifndef W16_NO_TILE_BARRIER
         // The 8 waves read each other's records (H1 by all of waves 0..3, H2 by waves 4..7 and 0, 1): kept within one tile
         // of each other, the second to fourth reader hits in L2; free-running, they drift apart by whole tiles and the
@@ -325,7 +339,7 @@ __device__ __forceinline__ void w16_role_a(const W16Args& a, const typename A::v
         __builtin_amdgcn_s_barrier();
 #endif
         const srd_t sa = act_srd(a.saved, tile);
-        const uint32_t nt = it + gridDim.x < a.n_tiles ? tile - gridDim.x : tile;
+        const uint32_t nt = it + gridDim.x < a.n_tiles ? w16_tile(a, it + gridDim.x) : tile;
         typename A::v8 X[P][2];
         load_tile_rows(sa, 0, 1, lane16, buf[2]);
         W16_FENCE();
@@ -446,7 +460,7 @@ __device__ __forceinline__ void w16_role_a_recompute(const W16Args& a, const typ
     float xv[3];
     uint32_t it = blockIdx.x;
     if (it < a.n_tiles) {
-        const uint32_t t0 = a.n_tiles - 1 - it;
+        const uint32_t t0 = w16_tile(a, it);
         load_tile_rows(act_srd(a.dact, t0), 1, w, lane16, bX);
         load_x(t0, xv);
         load_small(t0, bS);
@@ -455,11 +469,11 @@ __device__ __forceinline__ void w16_role_a_recompute(const W16Args& a, const typ
     }
 #pragma clang loop unroll(disable)
     for (; it < a.n_tiles; it += gridDim.x) {
-        const uint32_t tile = a.n_tiles - 1 - it;
+        const uint32_t tile = w16_tile(a, it);
 #ifndef W16_NO_TILE_BARRIER
         __builtin_amdgcn_s_barrier();
 #endif
-        const uint32_t nt = it + gridDim.x < a.n_tiles ? tile - gridDim.x : tile;
+        const uint32_t nt = it + gridDim.x < a.n_tiles ? w16_tile(a, it + gridDim.x) : tile;
         const srd_t nsa = act_srd(a.saved, nt);
         const float x0 = xv[0], x1 = xv[1], x2 = xv[2];
         typename A::v8 X[2][2];
@@ -618,17 +632,17 @@ __device__ __forceinline__ void w16_role_b(const W16Args& a, const typename A::v
     };
     uint32_t it = blockIdx.x;
     if (it < a.n_tiles) {
-        load_tile_rows(act_srd(a.dact, a.n_tiles - 1 - it), 2, rt, lane16, buf[0]);
-        load_tile_rows(act_srd(a.saved, a.n_tiles - 1 - it), 1, 0, lane16, buf[1]);
+        load_tile_rows(act_srd(a.dact, w16_tile(a, it)), 2, rt, lane16, buf[0]);
+        load_tile_rows(act_srd(a.saved, w16_tile(a, it)), 1, 0, lane16, buf[1]);
     }
 #pragma clang loop unroll(disable)
     for (; it < a.n_tiles; it += gridDim.x) {
-        const uint32_t tile = a.n_tiles - 1 - it;
+        const uint32_t tile = w16_tile(a, it);
 #ifndef W16_NO_TILE_BARRIER
         __builtin_amdgcn_s_barrier();
 #endif
         const srd_t sa = act_srd(a.saved, tile), da = act_srd(a.dact, tile);
-        const uint32_t nt = it + gridDim.x < a.n_tiles ? tile - gridDim.x : tile;
+        const uint32_t nt = it + gridDim.x < a.n_tiles ? w16_tile(a, it + gridDim.x) : tile;
         typename A::v8 X[P][2];
         load_tile_rows(sa, 1, 1, lane16, buf[2]);
         W16_FENCE();
@@ -702,8 +716,19 @@ __global__ __launch_bounds__(W16_BLOCK, 2) void decoder_wgrad16_kernel(const flo
                                                                        const float* __restrict__ dact,
                                                                        const float* __restrict__ dsmall,
                                                                        float* __restrict__ partial, uint32_t M,
-                                                                       uint32_t n_tiles) {
+                                                                       uint32_t n_tiles_all,
+                                                                       const uint32_t* __restrict__ live) {
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // live: the chain kernel's live-tile buffer (mipsf_decoder_bwd_chain16_ex): eight lists, visited one after the other
+    uint32_t n_tiles = n_tiles_all, live_start[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (live) {
+        n_tiles = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            live_start[q] = n_tiles;
+            n_tiles += (uint32_t)__builtin_amdgcn_readfirstlane((int)live[64 * q + 32]);
+        }
+    }
     const int j = lane & 31, h = lane >> 5;
     // the two selection matrices (B operands of the transposing MFMAs): lane = column c, half hb supplies k = 8 hb + u;
     // I[q][u] = 1 iff column c = 16 q + 8 (u >> 2) + 4 hb + (u & 3)
@@ -725,6 +750,9 @@ __global__ __launch_bounds__(W16_BLOCK, 2) void decoder_wgrad16_kernel(const flo
         __syncthreads();
     }
     const W16Args a = {feat, x, saved, dact, dsmall, partial + (size_t)blockIdx.x * G_STRIDE, M, n_tiles,
+                       live, tl_cap(n_tiles_all),
+                       {live_start[0], live_start[1], live_start[2], live_start[3], live_start[4], live_start[5],
+                        live_start[6], live_start[7]},
                        RECOMP ? w1img : nullptr, RECOMP ? w1img + W1_ENTRIES : nullptr};
     if (w < 4) {
         if constexpr (RECOMP) w16_role_a_recompute<LAYOUT, A>(a, I, w, lane);
@@ -738,6 +766,10 @@ __global__ __launch_bounds__(W16_BLOCK, 2) void decoder_wgrad16_kernel(const flo
 
 using namespace mipsf;
 
+extern "C" uint64_t mipsf_decoder_tile_words(uint32_t M) {
+    return TL_HEADER + 8ull * tl_cap((uint32_t)(((uint64_t)M + 31) / 32));
+}
+
 extern "C" int mipsf_decoder_wgrad16(const float* feat, int feat_layout, const float* x, const float* saved,
                                      const float* dact, const mipsf_decoder_grads* grads, float* partial, int arithmetic,
                                      uint32_t M, void* stream) {
@@ -747,6 +779,14 @@ extern "C" int mipsf_decoder_wgrad16(const float* feat, int feat_layout, const f
 extern "C" int mipsf_decoder_wgrad16_ex(const float* packed16, const float* feat, int feat_layout, const float* x,
                                         const float* saved, const float* dact, const mipsf_decoder_grads* grads,
                                         float* partial, int arithmetic, uint32_t M, void* stream) {
+    return mipsf_decoder_wgrad16_tiles(packed16, feat, feat_layout, x, saved, dact, nullptr, grads, partial, arithmetic, M,
+                                       stream);
+}
+
+extern "C" int mipsf_decoder_wgrad16_tiles(const float* packed16, const float* feat, int feat_layout, const float* x,
+                                           const float* saved, const float* dact, const uint32_t* tile_live,
+                                           const mipsf_decoder_grads* grads, float* partial, int arithmetic, uint32_t M,
+                                           void* stream) {
     if (M == 0) return 0;
     MIPSF_REQUIRE(packed16 == nullptr || arithmetic == MIPSF_PREC_F16X3, "H1 is recomputed by the f16x3 arithmetic only");
     MIPSF_REQUIRE(feat && x && saved && dact && partial && grads, "null pointer");
@@ -762,8 +802,9 @@ extern "C" int mipsf_decoder_wgrad16_ex(const float* packed16, const float* feat
     if (cus <= 0) return 3;
     uint32_t blocks = n_tiles < (uint32_t)cus ? n_tiles : (uint32_t)cus;
     if (blocks > (uint32_t)W16_MAX_BLOCKS) blocks = (uint32_t)W16_MAX_BLOCKS;
+    const uint32_t* live = tile_live;
 #define W16(LAY, AR, RC) hipLaunchKernelGGL((decoder_wgrad16_kernel<LAY, AR, RC>), dim3(blocks), dim3(W16_BLOCK), 0, s, packed16, \
-                                            feat, x, saved, dact, dsmall, partial, M, n_tiles)
+                                            feat, x, saved, dact, dsmall, partial, M, n_tiles, live)
 #define W16_L(LAY) do { if (arithmetic == MIPSF_PREC_F16X3) { if (packed16) W16(LAY, ArF16, true); else W16(LAY, ArF16, false); } \
                         else if (arithmetic == MIPSF_PREC_BF16X6) W16(LAY, ArBF3, false); else W16(LAY, ArBF2, false); } while (0)
     if (feat_layout == MIPSF_FEAT_AOS) W16_L(MIPSF_FEAT_AOS); else W16_L(MIPSF_FEAT_LEVEL_MAJOR);

@@ -6,6 +6,7 @@ torch-allocated and handed over by pointer (the kernels never allocate).  No CPU
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -84,6 +85,9 @@ def hashgrid_dx_from_jac(jac, dout, dx, meta, layout=FEAT_AOS):
 
 
 _SIDE_STREAMS = {}
+# decoder_bwd: short-cut the 32-sample tiles whose incoming gradient is zero throughout (exact; MIPSF_NO_TILE_SKIP=1 keeps
+# every tile, for A/B measurements)
+SKIP_ZERO_TILES = os.environ.get("MIPSF_NO_TILE_SKIP", "0") != "1"
 
 
 def side_stream(device) -> "torch.cuda.Stream":
@@ -264,7 +268,10 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
       "bf16x3"        that kernel with bf16 hi/lo operands for its three large products (~5e-6)
       "auto"          "stream_f16x3" behind the f16x3 chain, "f32" otherwise.
     recompute_h1 (stream_f16x3 + packed16): H1 is recomputed from x instead of read from `saved` -- required when the
-    forward kept the lean record (``decoder_fwd(save="lean")``), bit-identical otherwise."""
+    forward kept the lean record (``decoder_fwd(save="lean")``), bit-identical otherwise.
+    Zero tiles (SKIP_ZERO_TILES, f16x3 chain with the streaming weight-gradient kernel or a frozen decoder): 32-sample
+    tiles whose incoming gradient is zero throughout -- the ray tails behind the truncation band, a third of a mapping
+    batch -- are flagged by the chain, get zero dfeat / dx, and are never touched by the weight-gradient kernel."""
     if wgrad_precision == "auto":
         wgrad_precision = "stream_f16x3" if (precision == "f16x3" and embed_pos is None) else "f32"
     if getattr(saved, "mipsf_lean_record", False) and grads is not None:
@@ -278,13 +285,16 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
     dpe = torch.empty((M, 48), dtype=torch.float32, device=dev) if embed_pos is not None else None
     dact = torch.empty(lib().mipsf_decoder_dact_floats(M), dtype=torch.float32, device=dev)
     pe_mode = 0 if embed_pos is None else 1
+    tile_live = None
     if precision == "f16x3":
         if embed_pos is not None or packed16 is None:
             raise RuntimeError("the f16x3 backward chain takes packed16 and computes the positional encoding in-kernel")
+        if SKIP_ZERO_TILES and (grads is None or wgrad_precision.startswith("stream_")):
+            tile_live = torch.empty(lib().mipsf_decoder_tile_words(M), dtype=torch.int32, device=dev)
         with _timed("decoder_bwd_chain"):
-            check(lib().mipsf_decoder_bwd_chain16(dptr(packed16), layout, dptr(x), dptr(out), dptr(dout), dptr(saved),
-                                                  dptr(dfeat), dptr(dx), dptr(dact), M, stream_ptr()),
-                  "decoder_bwd_chain16")
+            check(lib().mipsf_decoder_bwd_chain16_ex(dptr(packed16), layout, dptr(x), dptr(out), dptr(dout), dptr(saved),
+                                                     dptr(dfeat), dptr(dx), dptr(dact),
+                                                     dptr(tile_live, torch.int32), M, stream_ptr()), "decoder_bwd_chain16")
     else:
         with _timed("decoder_bwd_chain"):
             check(lib().mipsf_decoder_bwd_chain(dptr(packed), layout, dptr(x), pe_mode, dptr(out), dptr(dout),
@@ -301,9 +311,10 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
             if recompute_h1 and (arith != _lib.PREC["f16x3"] or packed16 is None):
                 raise RuntimeError("recompute_h1 needs wgrad_precision 'stream_f16x3' and packed16")
             with _timed("decoder_wgrad"):
-                check(lib().mipsf_decoder_wgrad16_ex(dptr(packed16) if recompute_h1 else None, dptr(feat), layout, dptr(x),
-                                                     dptr(saved), dptr(dact), C.byref(st), dptr(partial), arith, M,
-                                                     stream_ptr()), "decoder_wgrad16")
+                check(lib().mipsf_decoder_wgrad16_tiles(dptr(packed16) if recompute_h1 else None, dptr(feat), layout,
+                                                        dptr(x), dptr(saved), dptr(dact),
+                                                        dptr(tile_live, torch.int32), C.byref(st), dptr(partial), arith, M, stream_ptr()),
+                      "decoder_wgrad16")
             return dfeat, dx, dpe
         if recompute_h1:
             raise RuntimeError("recompute_h1 needs wgrad_precision 'stream_f16x3'")

@@ -1280,6 +1280,56 @@ def test_decoder_f16x3_forward_matches_fp32_kernel_and_oracle(dev, M, layout):
     assert float((sdfp - p16[:, 3]).abs().max()) <= 1e-6, "SDF-only branch = column 3 of the full plain-f16 forward"
 
 
+@pytest.mark.parametrize("M", [64, 4096 + 17, 70000])
+@pytest.mark.parametrize("layout", ["aos", "level_major"])
+def test_decoder_backward_short_cuts_zero_gradient_tiles_exactly(dev, M, layout):
+    """ops.decoder_bwd with the zero-tile flags (mipsf_decoder_bwd_chain16_ex + mipsf_decoder_wgrad16_tiles) against the
+    same call with every tile processed: the incoming gradient is zero on the tail of every 64-sample ray (as behind the
+    truncation band, scene_rep.py:58-78), on some whole rays and on scattered single samples.  d(features) and d(x) must
+    be EQUAL (the skipped tiles are zeros either way, the others go through the same arithmetic); the parameter gradients
+    agree to fp32 class (the tiles are dealt to the weight-gradient workgroups in a different order); a frozen decoder
+    (no weight gradients) takes the short cut too; a batch without any gradient gives zeros."""
+    torch.manual_seed(7 + M)
+    dec = MLP_reg({}, input_ch=32, input_ch_pos=48).to(dev)
+    ws = dec.ordered_parameters()
+    packed16 = ops.decoder_pack16(ws)
+    x = torch.rand(M, 3, device=dev)
+    feat_aos = (torch.randn(M, 32, device=dev) * 0.3).contiguous()
+    lay = _lib.FEAT_AOS if layout == "aos" else _lib.FEAT_LEVEL_MAJOR
+    feat = feat_aos if layout == "aos" else feat_aos.view(M, 16, 2).permute(1, 0, 2).contiguous()
+    out, saved = ops.decoder_fwd(None, feat, lay, x, None, M, save="lean", precision="f16x3", packed16=packed16)
+    dout = torch.randn(M, 10, device=dev) * torch.exp(torch.empty(M, 1, device=dev).uniform_(-16.0, -6.0))
+    pos = torch.arange(M, device=dev) % 64
+    tail = torch.randint(10, 60, ((M + 63) // 64,), device=dev).repeat_interleave(64)[:M]
+    dout[pos >= tail] = 0.0                                      # ray tails
+    dout[(torch.arange(M, device=dev) // 64) % 5 == 3] = 0.0     # whole rays
+    dout[::11] = 0.0                                             # single samples inside live tiles
+
+    def run(skip, grads):
+        keep = ops.SKIP_ZERO_TILES
+        ops.SKIP_ZERO_TILES = skip
+        try:
+            return ops.decoder_bwd(None, feat, lay, x, None, out, dout, saved, grads, M, precision="f16x3",
+                                   packed16=packed16)
+        finally:
+            ops.SKIP_ZERO_TILES = keep
+
+    g_all, g_skip = [torch.zeros_like(w) for w in ws], [torch.zeros_like(w) for w in ws]
+    df_all, dx_all, _ = run(False, g_all)
+    df_skip, dx_skip, _ = run(True, g_skip)
+    assert torch.equal(df_skip, df_all) and torch.equal(dx_skip, dx_all)
+    n_zero_tiles = int((dout.view(-1, 10)[:(M // 32) * 32].view(-1, 32 * 10) == 0).all(1).sum())
+    assert M < 100 or n_zero_tiles > M // 32 // 5, "the test is meant to exercise the short cut"
+    for k, a, b in zip(ops.DECODER_PARAM_ORDER, g_skip, g_all):
+        assert_close(a, b, 1e-6, "zero-tile short cut, grad " + k)
+    df_frozen, dx_frozen, _ = run(True, None)
+    assert torch.equal(df_frozen, df_all) and torch.equal(dx_frozen, dx_all)
+    dout.zero_()
+    g0 = [torch.zeros_like(w) for w in ws]
+    df0, dx0, _ = run(True, g0)
+    assert not df0.any() and not dx0.any() and all(not g.any() for g in g0)
+
+
 @pytest.mark.parametrize("M", [1, 33, 1000, 70000])
 @pytest.mark.parametrize("layout", ["aos", "level_major"])
 def test_decoder_f16x3_backward_chain_matches_fp32_kernel(dev, M, layout):
