@@ -744,6 +744,9 @@ def main():
     dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"]) if kernels else None
     roofline = dict(kernels[dominant], kernel=dominant) if dominant else None
 
+    # what the backward pass found sparse in the last timed step (no term of the objective reaches a sample behind the
+    # truncation band: its gradient is exactly zero and the kernels skip it; the roofline figures above count every sample)
+    live_share = ops.last_live_tile_share()
     fwd_rate, fwd_ms = forward_only_rate(model, loop, dev)
     log(f"forward-only {fwd_ms:.3f} ms")
     out = {
@@ -769,6 +772,11 @@ def main():
                    "host_cpus": f"{len(HOST_CPUS)} least-busy CPUs of one NUMA node ({HOST_CPUS[0]}..{HOST_CPUS[-1]})" if HOST_CPUS else "unconfined"},
         "forward_only": {"value": round(fwd_rate, 1), "unit": "rays*samples/s", "ms": round(fwd_ms, 4)},
         "roofline": roofline, "kernels": kernels,
+        "gradient_sparsity": {"live_32_sample_tiles": None if live_share is None else round(live_share, 4),
+                              "note": "samples behind the truncation band carry no loss term and no rendering weight: "
+                                      "exactly zero gradient; the backward chain, the weight-gradient kernel and the grid "
+                                      "scatter skip them (tiles / records); algorithmic bytes in `kernels` are per sample "
+                                      "of the full batch"},
     }
     if not args.no_frame_estimate:
         out["frame"] = frame_estimate(cfg, model, loop, dev, ms_step, stream if use_graph else None)

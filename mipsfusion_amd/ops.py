@@ -88,6 +88,17 @@ _SIDE_STREAMS = {}
 # decoder_bwd: short-cut the 32-sample tiles whose incoming gradient is zero throughout (exact; MIPSF_NO_TILE_SKIP=1 keeps
 # every tile, for A/B measurements)
 SKIP_ZERO_TILES = os.environ.get("MIPSF_NO_TILE_SKIP", "0") != "1"
+_LAST_TILE_LIVE = None          # (buffer, M) of the most recent decoder_bwd that used the short cut (reporting only)
+
+
+def last_live_tile_share() -> Optional[float]:
+    """Share of the 32-sample tiles the most recent ``decoder_bwd`` found to carry a gradient (None: no such call yet).
+    Reads the counts of the chain kernel's live-tile lists (words 64 q + 32, csrc/decoder16.hip); synchronises."""
+    if _LAST_TILE_LIVE is None:
+        return None
+    buf, M = _LAST_TILE_LIVE
+    counts = buf[32:512:64].cpu()
+    return float(counts.sum().item()) / max(1, (M + 31) // 32)
 
 
 def side_stream(device) -> "torch.cuda.Stream":
@@ -290,7 +301,9 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
         if embed_pos is not None or packed16 is None:
             raise RuntimeError("the f16x3 backward chain takes packed16 and computes the positional encoding in-kernel")
         if SKIP_ZERO_TILES and (grads is None or wgrad_precision.startswith("stream_")):
+            global _LAST_TILE_LIVE
             tile_live = torch.empty(lib().mipsf_decoder_tile_words(M), dtype=torch.int32, device=dev)
+            _LAST_TILE_LIVE = (tile_live, M)
         with _timed("decoder_bwd_chain"):
             check(lib().mipsf_decoder_bwd_chain16_ex(dptr(packed16), layout, dptr(x), dptr(out), dptr(dout), dptr(saved),
                                                      dptr(dfeat), dptr(dx), dptr(dact),
