@@ -690,7 +690,7 @@ __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_bwd_lds_kernel(con
     // alternates between first and second halves of rays, whose gradients differ in sparsity).
     constexpr uint32_t WPB = F16_LDS_BLOCK / 64;
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (tile_live != nullptr) {
+    if (tile_live != nullptr && gridDim.x >= 8u) {           // (all eight queues need a workgroup: always, on 256 CUs)
         // With the short cut a wave's four tiles cost anything between 0 and 4 live ones, and the kernel would last as
         // long as its unluckiest wave (measured: -12 % instead of the -35 % of the tiles skipped): tiles are handed out
         // through counters instead (one per queue, see the buffer layout above; cleared by the launcher).
