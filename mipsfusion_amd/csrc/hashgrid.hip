@@ -426,17 +426,62 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __
     for (uint32_t q = threadIdx.x; q < ns; q += SC_BLOCK) cnt[q] = 0u;
     __syncthreads();
     const uint32_t s0 = chunk * (SC_BLOCK * SC_ROUTE_UNR);
+    // COMPACTION.  The dead samples (zero gradient) are the tails of the rays, i.e. every wave of 64 consecutive samples
+    // has some: skipping them lane by lane leaves the grouping and ranking below as expensive as before.  The workgroup's
+    // live samples are first packed (order kept) into `live_list`; round u then works on entries u * 1024 + thread, and
+    // a batch that is half dead takes two rounds of full waves instead of four of half-empty ones.
+    __shared__ uint32_t live_list[SC_BLOCK * SC_ROUTE_UNR];
+    __shared__ uint32_t wave_base[(SC_BLOCK / 64) * SC_ROUTE_UNR + 1];
+    {
+        const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+        unsigned long long alive[SC_ROUTE_UNR];
+#pragma unroll
+        for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u) {
+            const uint32_t i = s0 + u * SC_BLOCK + threadIdx.x;
+            bool live = i < M;
+            if (live && dout != nullptr) {
+                const float2 gy = *reinterpret_cast<const float2*>(dout + feat_index<LAYOUT>(i, level, M, plan.n_levels));
+                live = !(gy.x == 0.0f && gy.y == 0.0f);           // (NaN gradients stay live)
+            }
+            alive[u] = __ballot(live);
+            if (lane == 0) wave_base[1 + u * (SC_BLOCK / 64) + wave] = (uint32_t)__popcll(alive[u]);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {                      // inclusive prefix of the 64 (round, wave) counts
+            uint32_t v = wave_base[1 + threadIdx.x];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
+                v += (int)threadIdx.x >= d ? o : 0u;
+            }
+            wave_base[1 + threadIdx.x] = v;
+            if (threadIdx.x == 0) wave_base[0] = 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u)
+            if (alive[u] >> lane & 1ull)
+                live_list[wave_base[u * (SC_BLOCK / 64) + wave] + (uint32_t)__popcll(alive[u] & ((1ull << lane) - 1ull))] =
+                    s0 + u * SC_BLOCK + threadIdx.x;
+        __syncthreads();
+    }
+    const uint32_t n_live = wave_base[(SC_BLOCK / 64) * SC_ROUTE_UNR];
     // across the barrier, per sample: 8 slots of (slice < 512, rank < 4096) as 16-bit halves, masks as bytes
     uint32_t sp[SC_ROUTE_UNR][4], rp[SC_ROUTE_UNR][4], mp[SC_ROUTE_UNR][2];
+    uint32_t mine[SC_ROUTE_UNR];                     // the sample this thread handles in round u
 #pragma unroll
     for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u) {
-        const uint32_t i = s0 + u * SC_BLOCK + threadIdx.x;
+        const uint32_t c = u * SC_BLOCK + threadIdx.x;
+        const bool live = c < n_live;
+        const uint32_t i = live ? live_list[c] : 0u;
+        mine[u] = i;
         uint32_t s[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, m[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
         bool general = false;
-        bool live = i < M;
-        if (live && dout != nullptr) {
-            const float2 gy = *reinterpret_cast<const float2*>(dout + feat_index<LAYOUT>(i, level, M, plan.n_levels));
-            live = !(gy.x == 0.0f && gy.y == 0.0f);           // (NaN gradients stay live)
+        if (!__any(live)) {                          // (whole wave past the end of the list)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sp[u][k] = 0u, rp[u][k] = 0u;
+            mp[u][0] = 0u, mp[u][1] = 0u;
+            continue;
         }
         if (live) {
             const Cell cell = locate(x, i, scale);
@@ -496,7 +541,7 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __
     uint32_t* rec = ws + plan.w_records;
 #pragma unroll
     for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u) {
-        const uint32_t i = s0 + u * SC_BLOCK + threadIdx.x;
+        const uint32_t i = mine[u];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if (k == 4 && !__any(mp[u][1] != 0u)) break;
