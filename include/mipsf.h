@@ -73,6 +73,10 @@ int mipsf_hashgrid_fwd(const float* x, const float* params, float* out, uint32_t
 int mipsf_hashgrid_fwd_jac(const float* x, const float* params, float* out, float* jac, uint32_t M,
                            const mipsf_grid_meta* meta_host, int layout, void* stream);
 /* dx [M,3] += sum over levels of jac . dL/dout   (bit-identical to the dx part of mipsf_hashgrid_bwd) */
+/* ... over the 32-sample tiles listed in tile_live only (the buffer mipsf_decoder_bwd_chain16_ex filled for the same
+ * batch; NULL = every sample): the other samples have a zero feature gradient and add nothing. */
+int mipsf_hashgrid_dx_from_jac_tiles(const float* jac, const float* dout, float* dx, const uint32_t* tile_live, uint32_t M,
+                                     const mipsf_grid_meta* meta, int layout, void* stream);
 int mipsf_hashgrid_dx_from_jac(const float* jac, const float* dout, float* dx, uint32_t M,
                                const mipsf_grid_meta* meta_host, int layout, void* stream);
 /* dparams (nullable: frozen grid) += scatter of dL/dout (accumulated on chip in LDS slices, see hashgrid.hip);

@@ -11,6 +11,7 @@
 // XCD k serves levels {k+8, k} one after the other (fine level first), which keeps each L2 filled with
 // one level's table instead of thrashing all 34 MiB through every L2.  The mapping only affects speed.
 #include "common.h"
+#include "decoder_layout.h"      // layout of the backward chain's live-tile lists (mipsf_hashgrid_dx_from_jac_tiles)
 
 namespace mipsf {
 
@@ -946,11 +947,27 @@ __global__ __launch_bounds__(256) void hashgrid_dx_reduce_kernel(const float* __
 
 // dx += sum over levels of J_l . dL/dy_l with the Jacobian saved by the forward (same arithmetic and the same
 // level order as hashgrid_dx_kernel + hashgrid_dx_reduce_kernel: bit-identical results)
+// tiles (optional): the live-tile lists of the decoder's backward chain (decoder16.hip / decoder_layout.h).  Thread t then
+// works on sample 32 * tile(t / 32) + t % 32 of the listed tiles only: the others have a zero feature gradient, add
+// nothing, and their 384 bytes of Jacobian per sample stay unread.
 template <int LAYOUT>
 __global__ __launch_bounds__(256) void hashgrid_dx_jac_kernel(const float* __restrict__ jac,
                                                               const float* __restrict__ dout, float* __restrict__ dx,
-                                                              uint32_t M, uint32_t L) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+                                                              uint32_t M, uint32_t L,
+                                                              const uint32_t* __restrict__ tiles) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tiles != nullptr) {
+        const uint32_t k = i >> 5, cap = mipsf::dl::tl_cap((M + 31u) / 32u);
+        uint32_t q = 0, first = 0, total = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+            const uint32_t n = tiles[64 * j + 32];
+            if (k >= total && n != 0u) q = j, first = total;
+            total += n;
+        }
+        if (k >= total) return;
+        i = tiles[mipsf::dl::TL_HEADER + q * cap + (k - first)] * 32u + (i & 31u);
+    }
     if (i >= M) return;
     float a[3] = {0.f, 0.f, 0.f};
     for (uint32_t l = 0; l < L; ++l) {
@@ -1037,6 +1054,11 @@ int mipsf_hashgrid_fwd_jac(const float* x, const float* params, float* out, floa
 
 int mipsf_hashgrid_dx_from_jac(const float* jac, const float* dout, float* dx, uint32_t M,
                                const mipsf_grid_meta* meta, int layout, void* stream) {
+    return mipsf_hashgrid_dx_from_jac_tiles(jac, dout, dx, nullptr, M, meta, layout, stream);
+}
+
+int mipsf_hashgrid_dx_from_jac_tiles(const float* jac, const float* dout, float* dx, const uint32_t* tile_live, uint32_t M,
+                                     const mipsf_grid_meta* meta, int layout, void* stream) {
     GridLevels g;
     if (int rc = to_levels(meta, g)) return rc;
     if (M == 0) return 0;
@@ -1044,9 +1066,9 @@ int mipsf_hashgrid_dx_from_jac(const float* jac, const float* dout, float* dx, u
     MIPSF_REQUIRE(layout == MIPSF_FEAT_AOS || layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout %d", layout);
     hipStream_t s = (hipStream_t)stream;
     if (layout == MIPSF_FEAT_AOS)
-        hipLaunchKernelGGL(hashgrid_dx_jac_kernel<MIPSF_FEAT_AOS>, dim3((M + 255) / 256), dim3(256), 0, s, jac, dout, dx, M, g.n_levels);
+        hipLaunchKernelGGL(hashgrid_dx_jac_kernel<MIPSF_FEAT_AOS>, dim3((M + 255) / 256), dim3(256), 0, s, jac, dout, dx, M, g.n_levels, tile_live);
     else
-        hipLaunchKernelGGL(hashgrid_dx_jac_kernel<MIPSF_FEAT_LEVEL_MAJOR>, dim3((M + 255) / 256), dim3(256), 0, s, jac, dout, dx, M, g.n_levels);
+        hipLaunchKernelGGL(hashgrid_dx_jac_kernel<MIPSF_FEAT_LEVEL_MAJOR>, dim3((M + 255) / 256), dim3(256), 0, s, jac, dout, dx, M, g.n_levels, tile_live);
     return check_launch("hashgrid_dx_from_jac");
 }
 

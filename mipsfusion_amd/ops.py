@@ -77,11 +77,14 @@ def hashgrid_fwd(x: torch.Tensor, params: torch.Tensor, meta, layout=FEAT_AOS, w
 
 
 def hashgrid_dx_from_jac(jac, dout, dx, meta, layout=FEAT_AOS):
-    """dx += J . dout with the Jacobian saved by hashgrid_fwd(with_jac=True)."""
+    """dx += J . dout with the Jacobian saved by hashgrid_fwd(with_jac=True).  A `dout` that comes from ``decoder_bwd``
+    with the zero-tile short cut carries the chain's live-tile lists (``dout.mipsf_tile_live``): the samples of the other
+    tiles have a zero gradient and are left out (their Jacobian is not read)."""
     M = dx.shape[0]
+    tiles = getattr(dout, "mipsf_tile_live", None)
     with _timed("hashgrid_dx"):
-        check(lib().mipsf_hashgrid_dx_from_jac(dptr(jac), dptr(dout), dptr(dx), M, C.byref(meta), layout,
-                                               stream_ptr()), "hashgrid_dx_from_jac")
+        check(lib().mipsf_hashgrid_dx_from_jac_tiles(dptr(jac), dptr(dout), dptr(dx), dptr(tiles, torch.int32), M,
+                                                     C.byref(meta), layout, stream_ptr()), "hashgrid_dx_from_jac")
 
 
 _SIDE_STREAMS = {}
@@ -304,6 +307,7 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
             global _LAST_TILE_LIVE
             tile_live = torch.empty(lib().mipsf_decoder_tile_words(M), dtype=torch.int32, device=dev)
             _LAST_TILE_LIVE = (tile_live, M)
+            dfeat.mipsf_tile_live = tile_live       # (hashgrid_dx_from_jac skips the dead tiles with it)
         with _timed("decoder_bwd_chain"):
             check(lib().mipsf_decoder_bwd_chain16_ex(dptr(packed16), layout, dptr(x), dptr(out), dptr(dout), dptr(saved),
                                                      dptr(dfeat), dptr(dx), dptr(dact),
