@@ -588,12 +588,21 @@ __global__ __launch_bounds__(1024) void scatter_scan_kernel(ScatterPlan plan, ui
         cnt[k] = b < plan.n_bins ? ws[plan.w_count + b] : 0u;
         litm += (cnt[k] + part_of(plan, b) - 1) / part_of(plan, b);
     }
-    sitm[t] = litm;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        const uint32_t c = t >= d ? sitm[t - d] : 0u;
+    // inclusive prefix over the 1024 threads: within the wave by shuffles, across the 16 waves through 16 words of LDS
+    // (the 10-step scan through LDS it replaces spent 20 barriers on it: a third of this one-workgroup kernel)
+    {
+        __shared__ uint32_t wtot[16];
+        uint32_t incl = litm;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, d, 64);
+            incl += (int)(t & 63u) >= d ? v : 0u;
+        }
+        if ((t & 63u) == 63u) wtot[t >> 6] = incl;
         __syncthreads();
-        sitm[t] += c;
+        uint32_t before = 0;
+        for (uint32_t q = 0; q < (t >> 6); ++q) before += wtot[q];
+        sitm[t] = before + incl;
         __syncthreads();
     }
     uint32_t oitm = sitm[t] - litm;
