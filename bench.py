@@ -83,26 +83,36 @@ MFMA_F16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: f16 / bf16 MFMA dense pe
 N_GRID_PARAMS, N_DEC_PARAMS = 9014144, 36577
 
 # algorithmic cost per unit (SURVEY.md 8d / BASELINE.md 3); unit = 1 ray*sample.
-# (bound, cost per unit, arithmetic type of the kernel, matrix-core products issued per algorithmic product or None)
+# (bound, bytes per LIVE unit, bytes per DEAD unit, liveness that applies, arithmetic type, matrix products issued per
+#  algorithmic product or None).  A sample behind the truncation band has an exactly zero gradient: the
+# backward chain short-cuts its 32-sample tile, the weight-gradient and dx kernels never visit it, the scatter makes no
+# record for a (sample, level) pair with a zero feature gradient.  `work` of a launch = the units it PROCESSED:
+#   liveness "tile": share of live 32-sample tiles of the step (the chain kernel's own lists), "pair": share of live
+#   (sample, level) pairs, None: every unit.  The full-batch figure (every unit priced as live) is kept as `frac_full_batch`.
 # The two f16x3 decoder kernels keep or leave the activation record of the backward pass: 1.7-1.8 KB of HBM traffic per
 # sample against 0.22 MFLOP at 2.5 PFLOP/s -- they are priced against the HBM roofline, their matrix-pipe utilisation is
 # reported next to it.
 KERNEL_COST = {
-    "hashgrid_fwd": ("hbm", 1164.0 + 384.0, "f32", None),   # 8 corners x 16 levels gathered + features out + Jacobian out
-    "hashgrid_bwd": ("hbm", 2188.0, "f32+f64 LDS", None),   # scatter: x + dL/dy + read-modify-write of the touched entries
-    "hashgrid_dx": ("hbm", 536.0, "f32", None),             # saved Jacobian (384) + dL/dy (128) + dx read-modify-write (24)
+    "hashgrid_fwd": ("hbm", 1164.0 + 384.0, 0.0, None, "f32", None),   # 8 corners x 16 levels gathered + features out + Jacobian out
+    # scatter: x + dL/dy + read-modify-write of the touched entries; a dead pair costs the 8-byte read that finds it dead
+    "hashgrid_bwd": ("hbm", 2188.0, 128.0, "pair", "f32+f64 LDS", None),
+    "hashgrid_dx": ("hbm", 536.0, 0.0, "tile", "f32", None),            # saved Jacobian (384) + dL/dy (128) + dx read-modify-write (24)
     # lean activation record: H2 + H3 (1024 B) + ReLU masks; H1 is recomputed by the weight-gradient kernel
-    "decoder_fwd": ("hbm", 12.0 + 128.0 + 40.0 + 1024.0 + 32.0, "f16x3 (f16 MFMA on hi/lo split operands, fp32 accumulate)", 3),
-    "decoder_bwd_chain": ("hbm", 40.0 + 40.0 + 32.0 + 12.0 + 1536.0 + 32.0 + 128.0 + 12.0,
+    "decoder_fwd": ("hbm", 12.0 + 128.0 + 40.0 + 1024.0 + 32.0, 0.0, None, "f16x3 (f16 MFMA on hi/lo split operands, fp32 accumulate)", 3),
+    # chain: a dead tile costs the read of its incoming gradient (40) and the zero d feat / d x it leaves (128 + 12)
+    "decoder_bwd_chain": ("hbm", 40.0 + 40.0 + 32.0 + 12.0 + 1536.0 + 32.0 + 128.0 + 12.0, 40.0 + 128.0 + 12.0, "tile",
                           "f16x3 (f16 MFMA on hi/lo split operands, fp32 accumulate)", 3),
     # streaming kernel (csrc/wgrad16.hip): reads H2, H3 and the gradient record once (H1 recomputed) -- 2.7 KB per sample
-    "decoder_wgrad": ("hbm", 1024.0 + 1536.0 + 32.0 + 128.0 + 12.0,
+    "decoder_wgrad": ("hbm", 1024.0 + 1536.0 + 32.0 + 128.0 + 12.0, 0.0, "tile",
                       "f16x3 (f16 MFMA on hi/lo split operands under per-block power-of-two scales, fp32 accumulate)", 3),
-    "sample_rays": ("hbm", 20.0, "f32+f64", None),
-    "render_fwd": ("hbm", 44.0, "f32", None),
-    "render_bwd": ("hbm", 84.0, "f32", None),
-    "rays_bwd": ("hbm", 16.0, "f32+f64", None),
+    "sample_rays": ("hbm", 20.0, 0.0, None, "f32+f64", None),
+    "render_fwd": ("hbm", 44.0, 0.0, None, "f32", None),
+    "render_bwd": ("hbm", 84.0, 0.0, None, "f32", None),
+    "rays_bwd": ("hbm", 16.0, 0.0, None, "f32+f64", None),
 }
+# device streaming rates measured with hand-written kernels (tools/micro/stream.hip, 1 GiB, 16 B per lane, >= 32 KB in
+# flight per CU; profiles/r03_stream.txt): what "the HBM roofline" is worth on this part for each access mix
+STREAM_CEILINGS_TBS = {"read": 6.3, "read_nt": 7.0, "write": 6.0, "copy": 5.6, "spec": 8.0}
 DECODER_FLOP_PER_SAMPLE = 72370.0
 
 
@@ -120,12 +130,14 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--setup-iters", type=int, default=50, help="untimed mapping iterations so the SDF has sign changes")
     p.add_argument("--cpu-rays", type=int, default=4096, help="rays of the bounded CPU-baseline sample (0 = skip)")
-    p.add_argument("--cpu-iters", type=int, default=4)
+    p.add_argument("--cpu-iters", type=int, default=10)
+    p.add_argument("--cpu-warmup", type=int, default=3)
     p.add_argument("--no-frame-estimate", action="store_true")
     p.add_argument("--stats-steps", type=int, default=200, help="further steps timed one replay at a time (min/median/p95)")
     p.add_argument("--seq-frames", type=int, default=31, help="frames of the measured tracking+mapping sequence (0 = skip)")
     p.add_argument("--no-graph", action="store_true",
                    help="time eager launches instead of hipGraph replays of pose_accum_step iterations")
+    p.add_argument("--no-variants", action="store_true", help="skip the f32 / dense / unchanged-caller steps")
     p.add_argument("--torch-pose", action="store_true",
                    help="build rays with the reference's eager torch ops (mipsfusion.py:320-322) instead of the fused op")
     return p.parse_args()
@@ -259,6 +271,101 @@ class MappingLoop:
         return loss
 
 
+class UnchangedCallerLoop:
+    """What the three import lines of INTEGRATION.md section 1 alone deliver: the reference's own local-BA iteration
+    (mipsfusion.py:293-342) as the unchanged caller runs it -- host pixel sampling per iteration (keyframe rays by python
+    random.sample, current frame by sample_pixels_mix), CPU gather of the ray rows + three .to(device) copies, eager torch
+    ray ops (:320-322), JointEncoding.forward drawing its jitter with torch.rand on the CPU + upload (scene_rep.py:176),
+    get_loss_from_ret's selects, loss.backward(retain_graph=True) with autograd-path parameter gradients, torch.optim.Adam
+    for map and poses (:580-584, :300-303), zero_grad() calls -- no fused ray op, no FusedAdam, no in-place gradient
+    accumulation, no pre-drawn indices, no hipGraph.  Runs on a deep copy of the submap."""
+
+    def __init__(self, cfg, model, frames, poses, table, db, R, dev):
+        import copy
+        self.cfg, self.dev, self.frames, self.db, self.R = cfg, dev, frames, db, R
+        self.model = copy.deepcopy(model)
+        self.model.accumulate_param_grads_in_place = False
+        self.table_cpu = table.cpu()
+        self.map_opt = torch.optim.Adam([{"params": self.model.decoder.parameters(), "weight_decay": 1e-6, "lr": cfg["mapping"]["lr_decoder"]},
+                                         {"params": self.model.embed_fn.parameters(), "eps": 1e-15, "lr": cfg["mapping"]["lr_embed"]}],
+                                        betas=(0.9, 0.99))
+        poses = poses.to(dev)
+        self.pose_fixed = poses[:1]
+        self.cur_trans = torch.nn.Parameter(poses[1:, :3, 3].clone())
+        self.cur_rot = torch.nn.Parameter(matrix_to_quaternion(poses[1:, :3, :3]))
+        self.pose_opt = torch.optim.Adam([{"params": self.cur_rot, "lr": cfg["mapping"]["lr_rot"]},
+                                          {"params": self.cur_trans, "lr": cfg["mapping"]["lr_trans"]}])
+        self.poses_all = torch.cat([self.pose_fixed, qt_to_transform_matrix(self.cur_rot, self.cur_trans)], 0)
+        self.i = 0
+
+    def iterate(self, predrawn=None):
+        cfg, dev = self.cfg, self.dev
+        if predrawn is None:
+            rows, owner = draw_index_sets(cfg, self.frames, self.db, self.R, 1)
+            rows, owner = rows[0], owner[0]
+        else:
+            rows, owner = predrawn
+        rays = self.table_cpu[rows]                                         # CPU gather (keyframeSet.py:386-436)
+        rays_d_cam, target_s, target_d = rays[..., :3].to(dev), rays[..., 3:6].to(dev), rays[..., 6:7].to(dev)
+        owner = owner.to(dev)
+        rays_d = torch.sum(rays_d_cam[..., None, :] * self.poses_all[owner, :3, :3], -1)
+        rays_o = self.poses_all[owner, :3, -1]
+        ret = self.model.forward(rays_o, rays_d, target_s, target_d)        # jitter: torch.rand on the CPU + upload
+        ret = {k: v for k, v in ret.items() if not k.startswith("_")}       # the reference's dictionary keys only
+        loss = get_loss_from_ret(ret, cfg["training"])
+        loss.backward(retain_graph=True)
+        self.i += 1
+        if self.i % cfg["mapping"]["map_accum_step"] == 0:
+            self.map_opt.step()
+            self.map_opt.zero_grad()
+        if self.i % cfg["mapping"]["pose_accum_step"] == 0:
+            self.pose_opt.step()
+            self.poses_all = torch.cat([self.pose_fixed, qt_to_transform_matrix(self.cur_rot, self.cur_trans)], 0)
+            self.pose_opt.zero_grad()
+        return loss
+
+
+def unchanged_caller_rate(cfg, model, frames, poses, table, db, R, dev, steps):
+    loop = UnchangedCallerLoop(cfg, model, frames, poses, table, db, R, dev)
+    pre_rows, pre_owner = draw_index_sets(cfg, frames, db, R, 8)
+    out = {}
+    for key, pre in (("ms_per_step", False), ("ms_per_step_indices_predrawn", True)):
+        for k in range(3):
+            loop.iterate((pre_rows[k % 8], pre_owner[k % 8]) if pre else None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            loop.iterate((pre_rows[k % 8], pre_owner[k % 8]) if pre else None)
+        torch.cuda.synchronize()
+        out[key] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+    out["value"] = round(N_RAYS * N_SAMPLES / (out["ms_per_step"] * 1e-3), 1)
+    out["unit"] = "rays*samples/s"
+    out["what"] = ("the reference's own local_BA iteration (mipsfusion.py:293-342) over the drop-in modules and nothing "
+                   "else: host pixel sampling per iteration, CPU ray gather + uploads, eager torch ray ops, CPU torch.rand "
+                   "jitter + upload, autograd-path gradients, torch.optim.Adam, eager launches")
+    del loop
+    torch.cuda.empty_cache()
+    return out
+
+
+def graphed_ms_per_step(loop, stream, n_inner, steps, warmup):
+    """ms per step of `steps` graph-replayed mapping steps with the model / ops switches as they are now."""
+    loop.refill_static()
+    g = GraphedSteps(loop.step_static, n_inner, stream=stream)
+    for _ in range(max(1, warmup // n_inner)):
+        loop.refill_static()
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps // n_inner):
+        loop.refill_static()
+        g.replay()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    del g
+    return ms
+
+
 def forward_only_rate(model, loop, dev, iters=10):
     rays, owner = loop.batch(0)
     poses_now = torch.cat([loop.pose_fixed, qt_to_transform_matrix(loop.cur_rot, loop.cur_trans)], 0).detach()
@@ -334,6 +441,7 @@ def frame_estimate(cfg, model, loop, dev, ba_ms, stream=None):
     frame = synth.make_frame(cfg, seed=1)
     ds = types.SimpleNamespace(H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy, rays_d=frame["direction"])
     ro = RandomOptimizer(cfg, types.SimpleNamespace(dataset=ds, device=dev))
+    ro.decoder_precision = "f16"        # opt-in: BASELINE config 5 "fp16 decoder on CDNA4" (pose within 1e-3 of the reference's)
     n_ro = max(1, cfg["tracking"]["iter_RO"])
     init = frame["c2w"].clone()
     was_training = model.training
@@ -401,7 +509,8 @@ def frame_estimate(cfg, model, loop, dev, ba_ms, stream=None):
         go_ms = go_graph_ms
     tr, mp = cfg["tracking"], cfg["mapping"]
     total = tr["iter_RO"] * ro_ms + tr["iter"] * go_ms + mp["iters"] * ba_ms / mp["map_every"]
-    return {"ro_iter_ms": round(ro_ms, 4), "go_iter_ms": round(go_ms, 4),
+    return {"ro_iter_ms": round(ro_ms, 4), "ro_decoder_arithmetic": "plain f16 (opt-in; the RandomOptimizer's default is f16x3)",
+            "go_iter_ms": round(go_ms, 4),
             "go_iter_ms_eager": round(go_eager_ms, 4),
             "go_iter_ms_map_grads_computed_and_discarded": round(go_ms_unfrozen, 4), "ba_iter_ms": round(ba_ms, 4),
             "ms_per_frame_from_iteration_times": round(total, 3),
@@ -505,6 +614,24 @@ def multi_gpu_checks(cfg, model, dev, rank, world):
     model.train()
     res = ba.result()
     spread = mdist.exchange_poses(res[:, :3, :3].reshape(world, 9)[:, :4], res[:, :3, 3])   # any 7 numbers per anchor
+    # the two collectives of the sharded paths on their own (latency-bound: K x 7 and (n - 1) x 7 floats), 50 calls each
+    def timed_collective(fn, n=50):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return mdist.max_over_ranks((time.perf_counter() - t0) / n * 1e3, dev)
+    k_rot, k_trans = torch.randn(4, 4, device=dev), torch.randn(4, 3, device=dev)
+    out["pose_all_gather_ms"] = round(timed_collective(lambda: mdist.exchange_poses(k_rot, k_trans)), 4)
+    g7 = torch.zeros(max(1, world - 1), 7, device=dev)
+    out["pose_grad_all_reduce_ms"] = round(timed_collective(lambda: mdist.all_reduce_sum_(g7)), 4)
+    tbl = torch.zeros(max(1, world - 1), 2, bs, device=dev)
+    out["prediction_table_all_reduce_ms"] = round(timed_collective(lambda: mdist.all_reduce_sum_(tbl)), 4)
+    out["backend"] = dist.get_backend()
     out["global_ba_iter_ms"] = round(mdist.max_over_ranks(ms, dev), 4)
     out["global_ba_final_loss"] = float(loss)
     out["global_ba_anchor_spread_over_ranks"] = float((spread - spread[0:1]).abs().max())
@@ -514,7 +641,7 @@ def multi_gpu_checks(cfg, model, dev, rank, world):
     return out
 
 
-def cpu_baseline(cfg, loop, n_rays, iters):
+def cpu_baseline(cfg, loop, n_rays, iters, warmup=3):
     """The oracle (torch-CPU restatement of the reference path, oracle/path_cpu.py) on a bounded sample."""
     from oracle import path_cpu
     torch.set_num_threads(usable_cores())
@@ -546,7 +673,7 @@ def cpu_baseline(cfg, loop, n_rays, iters):
     g_loss = path_cpu.total_loss(g_ret, cfg["training"])
     g_loss.backward()
     t_w = time.perf_counter()
-    c_ret, c_loss, c_grad = it()
+    c_ret, c_loss, c_grad = it()            # (the first warm-up iteration is the one compared with the GPU below)
     log(f"cpu_baseline warm-up iteration {time.perf_counter() - t_w:.1f}s on {torch.get_num_threads()} threads")
 
     def rel(a, b):
@@ -556,6 +683,8 @@ def cpu_baseline(cfg, loop, n_rays, iters):
               "grid_grad_rel_err": rel(m.embed_fn.params.grad, c_grad)}
     log("cpu_baseline: GPU vs oracle on this batch " + ", ".join(f"{k} {v:.2e}" for k, v in parity.items()))
     m.zero_grad(set_to_none=False)
+    for _ in range(max(0, warmup - 1)):         # 3 warm-up + 10 timed iterations
+        it()
     t0 = time.perf_counter()
     done = 0
     for _ in range(iters):
@@ -568,7 +697,7 @@ def cpu_baseline(cfg, loop, n_rays, iters):
     return {"value": n_rays * N_SAMPLES / dt, "unit": "rays*samples/s", "cores": torch.get_num_threads(),
             "kind": "port", "s_per_iter": round(dt, 3),
             "gpu_vs_oracle_same_batch": {k: float(f"{v:.3e}") for k, v in parity.items()},
-            "sample": f"{iters} full iterations (fwd+bwd+dense Adam over the 2^19 grid) of oracle/path_cpu.py on "
+            "sample": f"{warmup} warm-up + {iters} timed full iterations (fwd+bwd+dense Adam over the 2^19 grid) of oracle/path_cpu.py on "
                       f"{n_rays} of the 4096 rays x 64 samples of the same batch, torch CPU threads = cores"}
 
 
@@ -690,8 +819,34 @@ def main():
         step_stats = {"steps": n_rep * n_inner, "granularity": f"one replay of {n_inner} steps incl. its input refill",
                       "min": round(float(per_step.min()), 4), "median": round(float(np.median(per_step)), 4),
                       "p95": round(float(np.percentile(per_step, 95)), 4), "max": round(float(per_step.max()), 4)}
+    # ---- the same step under the two switches the headline depends on, and the unchanged caller (N = 1 only)
+    variants = None
+    if use_graph and world == 1 and not args.no_variants:
+        variants = {}
+        M_ = N_RAYS * N_SAMPLES
+        model.decoder_precision = "f32"              # the reference's arithmetic: fp32 products (fp32-input MFMA), fp32 LDS weight-gradient kernel
+        ms = graphed_ms_per_step(loop, stream, n_inner, args.steps, args.warmup)
+        variants["decoder_precision_f32"] = {"ms_per_step": round(ms, 4), "value": round(M_ / (ms * 1e-3), 1),
+                                             "dtype": "f32 everywhere (fp32-input MFMA = exact fp32 products)"}
+        model.decoder_precision = "f16x3"
+        ops.SKIP_ZERO_TILES = False                  # = MIPSF_NO_TILE_SKIP=1: chain, weight gradients and dx visit every tile
+        ms = graphed_ms_per_step(loop, stream, n_inner, args.steps, args.warmup)
+        variants["dense_no_tile_skip"] = {"ms_per_step": round(ms, 4), "value": round(M_ / (ms * 1e-3), 1),
+                                          "note": "MIPSF_NO_TILE_SKIP=1: zero-gradient tiles are processed like live ones"}
+        ops.SKIP_ZERO_TILES = True
+        log(f"variants: {variants}")
+        variants["unchanged_caller"] = unchanged_caller_rate(cfg, model, frames, poses, table, db, R, dev, min(args.steps, 20))
+        log(f"unchanged caller: {variants['unchanged_caller']}")
+    per_rank_ms = None
+    if dist is not None:        # every rank's own step time (diagnosis of the first multi-GPU runs: which rank is slow)
+        mine = torch.tensor([elapsed / args.steps * 1e3], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [round(float(t), 4) for t in allr]
     elapsed = mdist.max_over_ranks(elapsed, dev)
     multi = multi_gpu_checks(cfg, model, dev, rank, world) if world > 1 else None
+    if multi is not None:
+        multi["ms_per_step_of_each_rank"] = per_rank_ms
 
     if rank != 0:
         dist.barrier()              # rank 0 finishes its untimed extras, then everybody leaves together
@@ -716,37 +871,49 @@ def main():
         hashgrid_route_ms = route_ms
     else:
         hashgrid_route_ms = None
+    # what the backward pass found sparse in the last timed (eager) step: the units each skipping kernel processed
+    live_share = ops.last_live_tile_share()
+    pair_share = ops.last_live_record_share()
+    shares = {"tile": live_share, "pair": pair_share, None: 1.0}
     for name, (n_launch, ms) in prof.items():
-        mult = None
+        mult, share = None, 1.0
         if name in KERNEL_COST:
-            bound, per_unit, dtype, mult = KERNEL_COST[name]
-            work = per_unit * M
+            bound, per_live, per_dead, liveness, dtype, mult = KERNEL_COST[name]
+            share = shares[liveness] if shares[liveness] is not None else 1.0
+            work = M * (share * per_live + (1.0 - share) * per_dead)
+            work_full = M * per_live
         elif name == "adam_step":
-            bound, work, dtype = "hbm", 28.0 * N_GRID_PARAMS, "f32"
+            bound, dtype, liveness = "hbm", "f32", None
+            work = work_full = 28.0 * N_GRID_PARAMS
         else:
             continue
         if bound == "hbm":
-            achieved, peak, unit = work / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+            scale, peak, unit = 1e9, HBM_PEAK_GBS, "GB/s"
         else:
-            achieved, peak, unit = work / (ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+            scale, peak, unit = 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+        achieved = work / (ms * 1e-3) / scale
         kernels[name] = {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
                          "frac": round(achieved / peak, 4), "avg_ms": round(ms, 4), "dtype": dtype,
-                         "launches": n_launch, "traffic": traffic.get(name), "traffic_uncorrected": traffic_raw.get(name)}
-        if mult is not None:        # matrix-pipe view of the decoder kernels
-            issued = DECODER_FLOP_PER_SAMPLE * M * mult / (ms * 1e-3) / 1e12
+                         "launches": n_launch, "work_per_launch": round(work, 1),
+                         "traffic": traffic.get(name), "traffic_uncorrected": traffic_raw.get(name)}
+        if liveness is not None:
+            kernels[name]["units"] = f"live {liveness}s: share {share:.4f} of the batch"
+            kernels[name]["frac_full_batch"] = round(work_full / (ms * 1e-3) / scale / peak, 4)
+        if mult is not None:        # matrix-pipe view of the decoder kernels (products of the units processed)
+            issued = DECODER_FLOP_PER_SAMPLE * M * share * mult / (ms * 1e-3) / 1e12
             mpeak = MFMA_F32_PEAK_TFLOPS if mult == 1 else MFMA_F16_PEAK_TFLOPS
             kernels[name]["matrix_pipe"] = {"algorithmic_tflops": round(issued / mult, 2), "issued_tflops": round(issued, 2),
                                             "peak_tflops": mpeak, "utilisation": round(issued / mpeak, 4)}
         if name == "hashgrid_bwd" and hashgrid_route_ms is not None:
             kernels[name]["routing_on_second_stream_ms"] = round(hashgrid_route_ms, 4)
-        if name == "decoder_wgrad":  # pure READ stream: torch's own x.sum() over 850 MB reads 3.8 TB/s on this device (tools/micro/bw.py)
-            kernels[name]["note"] = "read-only stream; measured device read ceiling 3.8-4.0 TB/s (tools/micro/bw.py), 8 TB/s is the spec peak"
     dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"]) if kernels else None
     roofline = dict(kernels[dominant], kernel=dominant) if dominant else None
+    if roofline is not None:
+        roofline["traffic_source"] = ("profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                      "command on an earlier box (per launch, gfx950 x2 FETCH correction where the kernel "
+                                      "reads 16 B per lane); not collected in this run")
+        roofline["device_stream_ceilings_TBps"] = STREAM_CEILINGS_TBS
 
-    # what the backward pass found sparse in the last timed step (no term of the objective reaches a sample behind the
-    # truncation band: its gradient is exactly zero and the kernels skip it; the roofline figures above count every sample)
-    live_share = ops.last_live_tile_share()
     fwd_rate, fwd_ms = forward_only_rate(model, loop, dev)
     log(f"forward-only {fwd_ms:.3f} ms")
     out = {
@@ -771,12 +938,15 @@ def main():
                    "ray_build": "torch eager ops" if args.torch_pose else "fused pose_rays kernel",
                    "host_cpus": f"{len(HOST_CPUS)} least-busy CPUs of one NUMA node ({HOST_CPUS[0]}..{HOST_CPUS[-1]})" if HOST_CPUS else "unconfined"},
         "forward_only": {"value": round(fwd_rate, 1), "unit": "rays*samples/s", "ms": round(fwd_ms, 4)},
+        "variants": variants,
         "roofline": roofline, "kernels": kernels,
         "gradient_sparsity": {"live_32_sample_tiles": None if live_share is None else round(live_share, 4),
+                              "live_sample_level_pairs": None if pair_share is None else round(pair_share, 4),
                               "note": "samples behind the truncation band carry no loss term and no rendering weight: "
-                                      "exactly zero gradient; the backward chain, the weight-gradient kernel and the grid "
-                                      "scatter skip them (tiles / records); algorithmic bytes in `kernels` are per sample "
-                                      "of the full batch"},
+                                      "exactly zero gradient; the backward chain, the weight-gradient kernel, dx and the grid "
+                                      "scatter skip them (tiles / records); `kernels[*].achieved` counts the units a launch "
+                                      "processed (live units at the full cost, dead units at the cost of finding them dead), "
+                                      "`frac_full_batch` prices every unit as live"},
     }
     if not args.no_frame_estimate:
         out["frame"] = frame_estimate(cfg, model, loop, dev, ms_step, stream if use_graph else None)
@@ -793,7 +963,7 @@ def main():
     if multi is not None:
         out["multi_gpu"] = multi
     if world == 1 and args.cpu_rays > 0:
-        out["cpu_baseline"] = cpu_baseline(cfg, loop, args.cpu_rays, args.cpu_iters)
+        out["cpu_baseline"] = cpu_baseline(cfg, loop, args.cpu_rays, args.cpu_iters, args.cpu_warmup)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -12,7 +12,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmipsf_hip.so")
+# MIPSF_LIB (developer switch): an experiment build of the same C ABI (tools/micro/variant.sh) instead of the in-tree library
+LIB_PATH = os.environ.get("MIPSF_LIB") or os.path.join(_HERE, "libmipsf_hip.so")
 MAX_LEVELS = 32
 FEAT_AOS, FEAT_LEVEL_MAJOR = 0, 1
 PREC = {"f32": 0, "f16x3": 1, "f16": 2, "bf16x3": 3, "bf16x6": 4}      # MIPSF_PREC_* of include/mipsf.h

@@ -116,6 +116,12 @@ __device__ __forceinline__ float4 buf_load16(srd_t r, uint32_t lane16, uint32_t 
     const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, lane16, off_u, 0);
     return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
 }
+// the same load with a cache policy (aux bit 1 = nt: a stream that is read once and should not displace L2 / MALL lines)
+template <int AUX>
+__device__ __forceinline__ float4 buf_load16_aux(srd_t r, uint32_t lane16, uint32_t off_u) {
+    const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, lane16, off_u, AUX);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+}
 __device__ __forceinline__ void buf_store16(srd_t r, uint32_t lane16, uint32_t off_u, const float4& v) {
     u32x4 u;
     u.x = __float_as_uint(v.x), u.y = __float_as_uint(v.y), u.z = __float_as_uint(v.z), u.w = __float_as_uint(v.w);

@@ -172,13 +172,23 @@ __global__ __launch_bounds__(PR_BLOCK) void pose_rays_bwd_kernel(const float* __
     __syncthreads();
     for (int q = threadIdx.x; q < P * 12; q += PR_BLOCK)
         __hip_atomic_store(&part[(size_t)blockIdx.x * (P * 12) + q], sacc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // The rows are device-scope atomic stores (written through) and are read back with device-scope atomic loads, so all
-    // the ticket needs is that this workgroup's stores have COMPLETED: a workgroup-scope release = s_waitcnt vmcnt(0).
-    // An agent-scope __threadfence() here writes back and invalidates the XCD's whole L2 on this multi-XCD part (the
+    // Hand-off form: "sc1 write-through stores + s_waitcnt vmcnt(0) + flag" on the producer side, sc1 loads on the
+    // consumer side (MI355X_MICROARCH.md, inter-workgroup visibility: `__hip_atomic_store/load(relaxed, agent)` lower to
+    // `global_store / global_load ... sc1`, which bypass the CU's L1 and leave no dirty line in the XCD's L2, so there
+    // is nothing for an agent-scope release to write back and nothing stale for an acquire to invalidate; "sc1 loads may
+    // replace the acquire only when the producer stored sc1" -- both sides do).  What the ticket needs is that this
+    // workgroup's row stores have been ACKNOWLEDGED before its increment is issued: every wave waits for its own stores
+    // (the explicit asm: the compiler may drop a fence's wait when it believes the counter is empty, and inline asm is
+    // invisible to that pass), the barrier collects the waves, one lane takes the ticket with a device-scope atomic.
+    // An agent-scope __threadfence() instead writes back and invalidates the XCD's whole L2 on this multi-XCD part (the
     // same pattern took a scatter kernel from 61 to 690 us; this kernel: 15 -> ~8 us for 16 workgroups).
+    // Stress-tested under uneven load with 400 workgroups x 2000 alternating calls, every word checked
+    // (tests/test_gpu_parity.py::test_pose_rays_bwd_ticket_reduction_under_load).
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    if (threadIdx.x == 0)
+        is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
     if (!is_last) return;
     // (a plain loop over the rows is one dependent ~1 us load after the other: 16 rows were 10 of this kernel's 15 us;

@@ -155,6 +155,13 @@ __device__ __forceinline__ void transpose_mac(f32x8 (&vals)[2], const typename A
     }
 }
 
+// Cache policy of the record loads: nt (aux bit 1).  The records are a read-once stream of 0.5 GB; with the default
+// policy they displace each other and the hash table in L2 / MALL.  Measured on the headline step (tools/replay.py, live
+// tile share 0.65, 514 MB): loads only 142 -> 115 us, the kernel 152 -> 135 us; a hand-written read stream does 6.3 TB/s
+// with the default policy and 7.0 with nt (tools/micro/stream.hip).
+#ifndef W16_LOAD_AUX
+#define W16_LOAD_AUX 2
+#endif
 // the four 16-byte pieces of row tile `rt` of matrix `mat` of a wave tile's accumulator-image record -> vals[q][u]
 __device__ __forceinline__ void load_tile_rows(srd_t rec, int mat, int rt, uint32_t lane16, f32x8 (&vals)[2]) {
 #pragma unroll
@@ -163,7 +170,7 @@ __device__ __forceinline__ void load_tile_rows(srd_t rec, int mat, int rt, uint3
         float4 v = make_float4((float)lane16, 1.0f, (float)mat, (float)rt);
         asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
 #else
-        const float4 v = buf_load16(rec, lane16, (uint32_t)(mat * 16 + rt * 4 + g) * 1024u);
+        const float4 v = buf_load16_aux<W16_LOAD_AUX>(rec, lane16, (uint32_t)(mat * 16 + rt * 4 + g) * 1024u);
 #endif
         vals[g >> 1][4 * (g & 1) + 0] = v.x, vals[g >> 1][4 * (g & 1) + 1] = v.y;
         vals[g >> 1][4 * (g & 1) + 2] = v.z, vals[g >> 1][4 * (g & 1) + 3] = v.w;

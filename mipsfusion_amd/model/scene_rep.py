@@ -140,10 +140,10 @@ class _QueryFn(torch.autograd.Function):
                     grads.append(w.grad)
                 else:
                     grads.append(torch.zeros_like(w))
-        dfeat, dx, _ = ops.decoder_bwd(packed, feat, FEAT_LEVEL_MAJOR, xn, None, out, ops._f32c(dout), saved, grads,
-                                       ctx.M, precision=ctx.prec, packed16=packed if ctx.prec != "f32" else None,
-                                       wgrad_precision="stream_f16x3" if ctx.lean else ctx.owner.wgrad_precision,
-                                       recompute_h1=ctx.lean)
+        dfeat, dx, _, tiles = ops.decoder_bwd(packed, feat, FEAT_LEVEL_MAJOR, xn, None, out, ops._f32c(dout), saved, grads,
+                                              ctx.M, precision=ctx.prec, packed16=packed if ctx.prec != "f32" else None,
+                                              wgrad_precision="stream_f16x3" if ctx.lean else ctx.owner.wgrad_precision,
+                                              recompute_h1=ctx.lean, return_tiles=True)
         dparams = None
         if need_g:
             if direct:
@@ -156,7 +156,7 @@ class _QueryFn(torch.autograd.Function):
             ops.hashgrid_bwd(xn, grid_params.detach(), dfeat, dparams, ctx.meta, FEAT_LEVEL_MAJOR, None, routed=ctx.routed)
             ctx.routed = None
         if need_x:
-            ops.hashgrid_dx_from_jac(jac, dfeat, dx, ctx.meta, FEAT_LEVEL_MAJOR)
+            ops.hashgrid_dx_from_jac(jac, dfeat, dx, ctx.meta, FEAT_LEVEL_MAJOR, tiles=tiles)   # (dfeat is untouched since the chain wrote it)
         w_out = [None] * len(weights)
         if need_w and not direct:
             w_out = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[3:])]

@@ -76,12 +76,12 @@ def hashgrid_fwd(x: torch.Tensor, params: torch.Tensor, meta, layout=FEAT_AOS, w
     return out
 
 
-def hashgrid_dx_from_jac(jac, dout, dx, meta, layout=FEAT_AOS):
-    """dx += J . dout with the Jacobian saved by hashgrid_fwd(with_jac=True).  A `dout` that comes from ``decoder_bwd``
-    with the zero-tile short cut carries the chain's live-tile lists (``dout.mipsf_tile_live``): the samples of the other
-    tiles have a zero gradient and are left out (their Jacobian is not read)."""
+def hashgrid_dx_from_jac(jac, dout, dx, meta, layout=FEAT_AOS, tiles=None):
+    """dx += J . dout with the Jacobian saved by hashgrid_fwd(with_jac=True).  tiles: the live-tile lists that
+    ``decoder_bwd(..., return_tiles=True)`` hands back together with THIS `dout` -- the samples of the other tiles have a
+    zero gradient and are left out (their Jacobian is not read).  Only pass lists that describe `dout` as it is now: a
+    gradient added into `dout` afterwards (a feature regulariser, say) makes them stale -- leave `tiles` out then."""
     M = dx.shape[0]
-    tiles = getattr(dout, "mipsf_tile_live", None)
     with _timed("hashgrid_dx"):
         check(lib().mipsf_hashgrid_dx_from_jac_tiles(dptr(jac), dptr(dout), dptr(dx), dptr(tiles, torch.int32), M,
                                                      C.byref(meta), layout, stream_ptr()), "hashgrid_dx_from_jac")
@@ -102,6 +102,18 @@ def last_live_tile_share() -> Optional[float]:
     buf, M = _LAST_TILE_LIVE
     counts = buf[32:512:64].cpu()
     return float(counts.sum().item()) / max(1, (M + 31) // 32)
+
+
+_LAST_SCATTER_DOUT = None       # the feature gradient of the most recent profiled hashgrid_bwd (reporting only)
+
+
+def last_live_record_share() -> Optional[float]:
+    """Share of the (sample, level) pairs of the most recent PROFILED ``hashgrid_bwd`` whose two feature gradients are
+    not both zero -- the pairs the routed scatter makes records for (None: no such call).  Synchronises."""
+    if _LAST_SCATTER_DOUT is None:
+        return None
+    d = _LAST_SCATTER_DOUT.reshape(-1, 2)
+    return float(((d[:, 0] != 0) | (d[:, 1] != 0)).float().mean().item())
 
 
 def side_stream(device) -> "torch.cuda.Stream":
@@ -133,6 +145,9 @@ def hashgrid_route_ahead(x, meta):
 def hashgrid_bwd(x, params, dout, dparams, meta, layout=FEAT_AOS, dx: Optional[torch.Tensor] = None, routed=None):
     """dparams (and dx when given) are accumulated into.  routed: (scratch, event) of hashgrid_route_ahead for this x."""
     M = x.shape[0]
+    if PROFILE is not None:
+        global _LAST_SCATTER_DOUT
+        _LAST_SCATTER_DOUT = dout
     if routed is not None and dx is None and dparams is not None:
         scratch, ev = routed
         torch.cuda.current_stream(x.device).wait_event(ev)
@@ -270,7 +285,7 @@ def decoder_fwd(packed, feat, layout, x, embed_pos, M, save, precision: str = "f
 
 
 def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, precision: str = "f32", packed16=None,
-                wgrad_precision: str = "auto", recompute_h1: bool = False):
+                wgrad_precision: str = "auto", recompute_h1: bool = False, return_tiles: bool = False):
     """grads: 10 tensors in DECODER_PARAM_ORDER, accumulated into, or None (frozen decoder: the weight-gradient
     GEMMs are skipped).  -> (dfeat, dx, dembed_pos|None).  precision "f16x3": the activation-gradient chain runs on
     the f16 matrix cores with hi/lo split operands (packed16, in-kernel positional encoding); it leaves the same `dact`
@@ -285,7 +300,9 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
     forward kept the lean record (``decoder_fwd(save="lean")``), bit-identical otherwise.
     Zero tiles (SKIP_ZERO_TILES, f16x3 chain with the streaming weight-gradient kernel or a frozen decoder): 32-sample
     tiles whose incoming gradient is zero throughout -- the ray tails behind the truncation band, a third of a mapping
-    batch -- are flagged by the chain, get zero dfeat / dx, and are never touched by the weight-gradient kernel."""
+    batch -- are flagged by the chain, get zero dfeat / dx, and are never touched by the weight-gradient kernel.
+    return_tiles: a 4th return value, the chain's live-tile lists (or None when no short cut was taken), for
+    ``hashgrid_dx_from_jac(..., tiles=)``."""
     if wgrad_precision == "auto":
         wgrad_precision = "stream_f16x3" if (precision == "f16x3" and embed_pos is None) else "f32"
     if getattr(saved, "mipsf_lean_record", False) and grads is not None:
@@ -307,7 +324,6 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
             global _LAST_TILE_LIVE
             tile_live = torch.empty(lib().mipsf_decoder_tile_words(M), dtype=torch.int32, device=dev)
             _LAST_TILE_LIVE = (tile_live, M)
-            dfeat.mipsf_tile_live = tile_live       # (hashgrid_dx_from_jac skips the dead tiles with it)
         with _timed("decoder_bwd_chain"):
             check(lib().mipsf_decoder_bwd_chain16_ex(dptr(packed16), layout, dptr(x), dptr(out), dptr(dout), dptr(saved),
                                                      dptr(dfeat), dptr(dx), dptr(dact),
@@ -332,7 +348,7 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
                                                         dptr(x), dptr(saved), dptr(dact),
                                                         dptr(tile_live, torch.int32), C.byref(st), dptr(partial), arith, M, stream_ptr()),
                       "decoder_wgrad16")
-            return dfeat, dx, dpe
+            return (dfeat, dx, dpe, tile_live) if return_tiles else (dfeat, dx, dpe)
         if recompute_h1:
             raise RuntimeError("recompute_h1 needs wgrad_precision 'stream_f16x3'")
         with _timed("decoder_wgrad"):
@@ -340,7 +356,7 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
             check(lib().mipsf_decoder_wgrad_ex(dptr(feat), layout, dptr(x), dptr(embed_pos), pe_mode, dptr(saved),
                                                dptr(dact), C.byref(st), dptr(partial), wprec, M, stream_ptr()),
                   "decoder_wgrad")
-    return dfeat, dx, dpe
+    return (dfeat, dx, dpe, tile_live) if return_tiles else (dfeat, dx, dpe)
 
 
 def decoder_fwd_sdf(packed, feat, layout, x, embed_pos, M, precision: str = "f32", packed16=None) -> torch.Tensor:

@@ -403,7 +403,7 @@ class GraphedSequence:
     iterations.  Rays are gathered inside the graphs from ONE device table [keyframe database | current frame]."""
 
     def __init__(self, cfg, dev, frames, kf_every=15, sampler="reference", first_iters=200, stream=None,
-                 lookahead=None, graph_ro=True, gate_producer=True):
+                 lookahead=None, graph_ro=True, gate_producer=True, ro_precision="f16"):
         """lookahead: how many frames the sample producer runs ahead of the GPU (default: ``map_every``, one whole
         mapping period -- a BA round needs ~40 ms of serial generator work, a frame without BA ~4 ms, so the work only
         evens out over a period; the reference's own DataLoader prefetches 8 frames, mipsfusion.py:672)."""
@@ -432,6 +432,9 @@ class GraphedSequence:
         self.host_rays = [frame_rays(f).pin_memory() for f in frames]        # what a capture thread hands over
         ds = types.SimpleNamespace(H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy, rays_d=frames[0]["direction"])
         self.ro = RandomOptimizer(cfg, types.SimpleNamespace(dataset=ds, device=dev))
+        # explicit opt-in to the plain-f16 decoder for the particle rounds (BASELINE config 5 "fp16 decoder"; tolerance: the
+        # tracked pose stays within 1e-3 of the reference's, test_random_optimizer_f16_rounds_track_the_reference_pose)
+        self.ro.decoder_precision = ro_precision
         kr, kc = sh.sample_pixels_uniformly(H, W, 100, 300 if W >= 300 else W // 2)  # 30 000 rays per keyframe
         self.kf_rows, self.kf_cols = kr.to(dev), kc.to(dev)
         self.R = kr.shape[0]

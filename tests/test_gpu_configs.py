@@ -250,7 +250,7 @@ def test_config5_scannet_random_optimizer_slice_vs_oracle(dev):
     m.eval()
     f = synth.make_frame(cfg, seed=6)
     ro = _scannet_ro(cfg, dev, f)
-    ro.decoder_precision = "f16x3"                 # parity arithmetic against the oracle; plain f16 is checked at the end
+    assert ro.decoder_precision == "f16x3"         # the default: parity arithmetic; the opt-in plain f16 is checked at the end
     init = f["c2w"].clone()
     init[:3, 3] += torch.tensor([0.02, -0.015, 0.01])
     P, n = ro.particle_size, ro.row_indices.shape[0]
@@ -277,7 +277,7 @@ def test_config5_scannet_random_optimizer_slice_vs_oracle(dev):
     check(pose[:3, 3], ref_pose[:3, 3], "tracked translation after 3 rounds", 1e-4, 1e-4)
     check(pose[:3, :3], ref_pose[:3, :3], "tracked rotation after 3 rounds", 1e-4, 1e-3, floor=1e-2)
     check(st[12:18], trace[-1]["search"].reshape(6), "search size", 1e-3, 1e-3, floor=1e-6)
-    # ---- BASELINE config 5's "fp16 decoder on CDNA4": plain f16 matrix-core operands (the RandomOptimizer's default)
+    # ---- BASELINE config 5's "fp16 decoder on CDNA4": plain f16 matrix-core operands (opt-in)
     ro.decoder_precision = "f16"
     with torch.no_grad():
         mm16 = ro._enqueue_round(m, state.clone(), td, ro._dirs[0], m._rc(1, 0),

@@ -46,7 +46,7 @@ def product_backend(dev, fused_adam=True, in_place=False, precision="f16x3"):
     from mipsfusion_amd.RandomOptimizer import RandomOptimizer
 
     def _ro(ro):
-        ro.decoder_precision = precision    # parity arithmetic for the 51-iteration trace (plain f16 is the RO default)
+        ro.decoder_precision = precision    # the 51-iteration trace runs the RandomOptimizer in the model's arithmetic
         return ro
 
     def make_model(cfg, bb, nf):

@@ -1,0 +1,110 @@
+"""Kernel A/B on a FIXED workload: records every C-ABI call of one headline mapping step (BASELINE config 2, after the
+usual set-up iterations) and replays the recorded sequence -- same pointers, same contents -- against the in-tree library
+and any number of experiment builds (tools/micro/variant.sh), timing each call with an event pair on the launch stream.
+
+    python tools/replay.py [name ...]         names of tools/micro/libv_<name>.so; "base" is always measured first
+    REPLAY_ONLY=regex                         replay (and time) only the calls whose entry point matches
+    REPLAY_REPS=20
+
+The optimiser calls are left out of the replay, so the parameters -- and with them every tensor a kernel reads -- stay what
+they were when the step was recorded: a diagnosis build that produces garbage (loads only, compute only) cannot change the
+work of the kernels that run after it.  (bench.py's own per-kernel table feeds back: with a loads-only weight-gradient
+kernel the model diverges and the live-tile share of the next steps changes.)
+"""
+import ctypes as C
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from mipsfusion_amd import _lib, ops, synth  # noqa: E402
+from mipsfusion_amd.graph import work_stream  # noqa: E402
+
+
+class Recorder:
+    def __init__(self, handle):
+        self.handle, self.calls = handle, []
+
+    def __getattr__(self, name):
+        fn = getattr(self.handle, name)
+        if not name.startswith("mipsf_") or fn.restype is not C.c_int:
+            return fn
+
+        def wrapped(*args):
+            self.calls.append((name, args))
+            return fn(*args)
+        return wrapped
+
+
+def open_lib(path):
+    h = C.CDLL(path)
+    for name, (res, args) in _lib.SIGNATURES.items():
+        fn = getattr(h, name)
+        fn.restype, fn.argtypes = res, args
+    return h
+
+
+def main():
+    names = [a for a in sys.argv[1:]]
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    stream = work_stream(dev)
+    cfg = synth.config_headline()
+    model, frames, poses = bench.build_submap(cfg, dev, seed=0)
+    table, db, R = bench.build_ray_table(cfg, frames, dev)
+    idx_rows, idx_owner = bench.draw_index_sets(cfg, frames, db, R, 64)
+    loop = bench.MappingLoop(cfg, model, poses, table, idx_rows, idx_owner, dev)
+    for _ in range(int(os.environ.get("REPLAY_SETUP", "55"))):
+        loop.step()
+    torch.cuda.synchronize()
+    base = _lib.lib()
+    rec = Recorder(base)
+    _lib._lib = rec
+    loop.i = 4                      # a step that also runs the pose optimiser (pose_accum_step = 5)
+    loss = loop.step()
+    torch.cuda.synchronize()
+    _lib._lib = base
+    live = ops.last_live_tile_share()
+    calls = [(n, a) for n, a in rec.calls if "adam" not in n]
+    only = os.environ.get("REPLAY_ONLY")
+    if only:
+        calls = [(n, a) for n, a in calls if re.search(only, n)]
+    print(f"recorded {len(rec.calls)} calls, replaying {len(calls)}; loss {float(loss):.5f}; live tile share {live}")
+    reps = int(os.environ.get("REPLAY_REPS", "20"))
+    libs = [("base", base)] + [(n, open_lib(os.path.join(ROOT, "tools", "micro", f"libv_{n}.so"))) for n in names if n != "base"]
+    table_out = {}
+    for lname, h in libs:
+        evs = [[] for _ in calls]
+        for r in range(reps + 3):
+            for k, (n, a) in enumerate(calls):
+                fn = getattr(h, n)
+                if r >= 3:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                rc = fn(*a)
+                if r >= 3:
+                    e1.record()
+                    evs[k].append((e0, e1))
+                if rc != 0:
+                    raise RuntimeError(f"{n}: rc {rc}: {h.mipsf_last_error().decode()}")
+        torch.cuda.synchronize()
+        for k, (n, _a) in enumerate(calls):
+            us = sum(a.elapsed_time(b) for a, b in evs[k]) / len(evs[k]) * 1e3
+            table_out.setdefault((k, n), {})[lname] = us
+    w = max(len(n) for _, n in table_out) + 4
+    print(" " * w + "".join(f"{l:>12s}" for l, _ in libs))
+    tot = {l: 0.0 for l, _ in libs}
+    for (k, n), row in sorted(table_out.items()):
+        print(f"{k:2d} {n[6:]:{w - 3}s}" + "".join(f"{row[l]:12.1f}" for l, _ in libs))
+        for l, _ in libs:
+            tot[l] += row[l]
+    print(f"{'sum':{w}s}" + "".join(f"{tot[l]:12.1f}" for l, _ in libs))
+
+
+if __name__ == "__main__":
+    main()
