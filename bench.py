@@ -135,6 +135,7 @@ def parse():
     p.add_argument("--no-frame-estimate", action="store_true")
     p.add_argument("--stats-steps", type=int, default=200, help="further steps timed one replay at a time (min/median/p95)")
     p.add_argument("--seq-frames", type=int, default=31, help="frames of the measured tracking+mapping sequence (0 = skip)")
+    p.add_argument("--config3-frames", type=int, default=300, help="frames of the multi-sub-map sequence (0 = skip)")
     p.add_argument("--no-graph", action="store_true",
                    help="time eager launches instead of hipGraph replays of pose_accum_step iterations")
     p.add_argument("--no-variants", action="store_true", help="skip the f32 / dense / unchanged-caller steps")
@@ -519,9 +520,10 @@ def frame_estimate(cfg, model, loop, dev, ba_ms, stream=None):
 
 def measured_sequence(n_frames, dev, stream):
     """tracking + mapping ms/frame MEASURED over a synthetic sequence at the reference cadence (5 RO rounds, 10
-    tracking iterations, 15 mapping iterations every 3rd frame, keyframe every 15th): mipsfusion_amd/sequence.py.
-    `reference`: pixel / keyframe-ray indices and jitter from the reference's own host generators (bit-identical
-    index stream, drawn map_every frames ahead by producer threads); `device`: the same draws made on the GPU."""
+    tracking iterations, 15 mapping iterations every 3rd frame, keyframe every 15th, 500 initialisation iterations):
+    mipsfusion_amd/sequence.py.  `reference`: pixel / keyframe-ray indices and jitter from the reference's own host
+    generators (bit-identical index stream, drawn map_every frames ahead by producer threads); `device`: the same draws made
+    on the GPU."""
     from mipsfusion_amd import sequence
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from run_sequence import trajectory
@@ -531,11 +533,34 @@ def measured_sequence(n_frames, dev, stream):
         cfg = synth.config_reference_defaults()                   # S = 50 + 25, sample 1800 + pixels_cur 800: as shipped
         gt = trajectory(cfg, n_frames)
         frames = [synth.make_frame(cfg, gt[k], seed=k, frame_id=k) for k in range(n_frames)]
-        seq = sequence.GraphedSequence(cfg, dev, frames, kf_every=15, sampler=sampler, first_iters=200, stream=stream)
+        seq = sequence.GraphedSequence(cfg, dev, frames, kf_every=15, sampler=sampler, stream=stream)
         res = seq.run(gt)
         out[sampler] = sequence.summarise(res, gt, cfg, "hipGraph replay per tracking frame / per BA round; RandomOptimizer rounds of a frame in one replay")
         del seq
         torch.cuda.empty_cache()
+    return out
+
+
+def measured_config3(n_frames, dev, stream):
+    """BASELINE config 3: the full-size online loop over SEVERAL sub-maps -- a 300-frame walk through two rooms
+    (synth.two_room_sequence), a new sub-map at the first keyframe behind the door (parameter store, recover_initial_param,
+    fresh map optimiser, 500 initialisation iterations), a switch back to sub-map 0 on the return (store, load, 15 pose-only
+    iterations of local_BA_switch).  Every frame counts, switch frames included."""
+    from mipsfusion_amd import sequence
+    random.seed(0), np.random.seed(0), torch.manual_seed(0)
+    cfg = synth.config_two_rooms()
+    t0 = time.perf_counter()
+    gt, frames, schedule = synth.two_room_sequence(cfg, n_frames, kf_every=cfg["mapping"]["keyframe_every"])
+    log(f"config 3: {n_frames} two-room frames rendered on the host in {time.perf_counter() - t0:.1f}s, schedule {schedule}")
+    seq = sequence.GraphedSequence(cfg, dev, frames, kf_every=cfg["mapping"]["keyframe_every"], sampler="reference", stream=stream,
+                                   schedule=schedule)
+    res = seq.run(gt)
+    out = sequence.summarise(res, gt, cfg, "hipGraph replay per tracking frame / BA round / 25 initialisation iterations / switch refinement")
+    out["sampler"] = ("reference host generators (run ahead by producer threads) for tracking and local BA; the sub-map "
+                      "initialisation and switch-refinement iterations draw pixels and jitter on the device")
+    out.pop("frame_ms_all", None)
+    del seq
+    torch.cuda.empty_cache()
     return out
 
 
@@ -958,6 +983,9 @@ def main():
             out["frame"]["ms_per_frame_device_sampling"] = seq["device"]["ms_per_frame_mean"]
             out["frame"]["tracking_plus_mapping_ms_per_frame"] = seq["reference"]["ms_per_frame_mean"]
             log("measured sequences done")
+            if args.config3_frames > 1:
+                out["frame"]["config3_multi_submap"] = measured_config3(args.config3_frames, dev, stream)
+                log(f"config 3 done: {out['frame']['config3_multi_submap']['ms_per_frame_mean']} ms/frame")
         out["inference"] = inference_rates(cfg, model, dev)
         log("inference consumers done")
     if multi is not None:

@@ -396,17 +396,58 @@ def frame_rays(frame):
     return torch.cat([frame["direction"], frame["rgb"], frame["depth"][..., None]], -1).reshape(-1, 7)
 
 
-class GraphedSequence:
-    """Tracking + mapping of a frame sequence on one sub-map with the iterations replayed as hipGraphs
-    (mipsfusion_amd.graph.GraphedSteps): RandomOptimizer rounds (eager, 5 launches each) -> one replay of the
-    ``tracking.iter`` pose-only iterations -> every ``map_every``-th frame one replay of the ``mapping.iters`` local-BA
-    iterations.  Rays are gathered inside the graphs from ONE device table [keyframe database | current frame]."""
+def submap_timeline(n_frames, kf_every, schedule):
+    """frame -> (active sub-map, its keyframe slots) as they are when that frame is tracked and bundle-adjusted (the frame's
+    own keyframe / switch is processed AFTER its BA, mipsfusion.py:681-712).  Keyframe slot = frame // kf_every; a frame
+    with a ("new",) event is the first keyframe of the new sub-map, one with ("back", s) joins sub-map s after the
+    refinement of local_BA_switch (mipsfusion.py:379-444)."""
+    subs, active, tl = {0: [0]}, 0, {}
+    for k in range(1, n_frames):
+        tl[k] = (active, list(subs[active]))
+        if k % kf_every == 0:
+            ev, slot = schedule.get(k), k // kf_every
+            if ev is None:
+                subs[active].append(slot)
+            elif ev[0] == "new":
+                active = len(subs)
+                subs[active] = [slot]
+            else:
+                active = ev[1]
+                if active not in subs:
+                    raise ValueError(f"schedule: sub-map {active} does not exist at frame {k}")
+                subs[active].append(slot)
+    return tl
 
-    def __init__(self, cfg, dev, frames, kf_every=15, sampler="reference", first_iters=200, stream=None,
-                 lookahead=None, graph_ro=True, gate_producer=True, ro_precision="f16"):
+
+class GraphedSequence:
+    """Tracking + mapping of a frame sequence with the iterations replayed as hipGraphs
+    (mipsfusion_amd.graph.GraphedSteps): RandomOptimizer rounds (one replay) -> one replay of the ``tracking.iter``
+    pose-only iterations -> every ``map_every``-th frame one replay of the ``mapping.iters`` local-BA iterations.  Rays are
+    gathered inside the graphs from ONE device table [keyframe database | current frame].
+
+    Several sub-maps (BASELINE config 3; ``schedule``): the active process of the reference owns ONE model whose
+    parameters are swapped at a switch (mipsfusion.py:607-658), and so does this class -- the captured graphs keep reading
+    the same parameter tensors, a switch is a handful of device-to-device copies:
+      ("new",)      active_submap_switch_new + initialize_new_localMLP (mipsfusion.py:637-652, 198-222): the active
+                    sub-map's parameters are stored, ``recover_initial_param()``, a fresh map optimiser (cleared in place),
+                    ``first_iters`` initialisation iterations on the keyframe's pixels as replays of one 25-iteration graph;
+      ("back", s)   active_submap_switch + local_BA_switch (mipsfusion.py:608-634, 379-444): store, load sub-map s (the map
+                    optimiser is NOT rebuilt -- the reference keeps its object), ``tracking.switch.map_num`` pose-only
+                    iterations on rays of s's keyframes + the frame's pixels with the switch learning rates (one replay).
+    What replaces host control plane here (out of scope): the switch decisions of Manager.py are the fixed
+    ``schedule``; the sub-maps share one estimated world frame (the reference re-bases the pose to the new sub-map's first
+    keyframe, mipsfusion.py:652 -- a rigid change of coordinates that moves no work; the miniature parity run of
+    tests/seq_harness.py keeps the reference's local frames), PoseCorrector's ICP rectification is dropped."""
+
+    INIT_INNER = 25          # iterations per replay of the sub-map initialisation graph (500 = 20 replays)
+
+    def __init__(self, cfg, dev, frames, kf_every=15, sampler="reference", first_iters=None, stream=None,
+                 lookahead=None, graph_ro=True, gate_producer=True, ro_precision="f16", schedule=None):
         """lookahead: how many frames the sample producer runs ahead of the GPU (default: ``map_every``, one whole
         mapping period -- a BA round needs ~40 ms of serial generator work, a frame without BA ~4 ms, so the work only
-        evens out over a period; the reference's own DataLoader prefetches 8 frames, mipsfusion.py:672)."""
+        evens out over a period; the reference's own DataLoader prefetches 8 frames, mipsfusion.py:672).
+        first_iters: initialisation iterations of a sub-map (default: mapping.first_iters, 500 in the reference's configs).
+        schedule: {frame: ("new",) | ("back", submap)} at keyframe frames (see the class docstring)."""
         from .RandomOptimizer import RandomOptimizer
         from .graph import GraphedSteps, work_stream
         from .model import JointEncoding
@@ -429,6 +470,8 @@ class GraphedSequence:
         nf = torch.from_numpy(np.array(mp["localMLP_max_len"]))
         self.model = JointEncoding(cfg, bb, nf).to(dev).train()
         self.model.accumulate_param_grads_in_place = True
+        # recover_initial_param() at a switch is a device-to-device copy (the reference's initial_dict sits where the model was built)
+        self.model.initial_dict = {k: v.to(dev) for k, v in self.model.initial_dict.items()}
         self.host_rays = [frame_rays(f).pin_memory() for f in frames]        # what a capture thread hands over
         ds = types.SimpleNamespace(H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy, rays_d=frames[0]["direction"])
         self.ro = RandomOptimizer(cfg, types.SimpleNamespace(dataset=ds, device=dev))
@@ -443,12 +486,23 @@ class GraphedSequence:
         self.db = DeviceRayDB(self.Kmax, self.R, dev, storage=self.table)
         self.cur = self.table[self.Kmax * self.R:]
         self.n_kf = 0
-        self.iters, self.first_iters = mp["iters"], first_iters
+        self.iters = mp["iters"]
+        self.first_iters = mp.get("first_iters", 500) if first_iters is None else first_iters
+        # ---- sub-maps: key-frame slots (rows of the ray database) of each, the stored parameters of the inactive ones
+        self.schedule = dict(schedule or {})
+        for k, ev in self.schedule.items():
+            assert k % kf_every == 0 and 0 < k < len(frames) and ev[0] in ("new", "back"), "switches happen at keyframe frames"
+        self.submaps = {0: {"kfs": [], "state": None}}
+        self.active = 0
+        self._timeline = self._make_timeline(len(frames))
+        self.kf_qt = torch.zeros(self.Kmax, 7, device=dev)                   # (quaternion | translation) of every keyframe slot
+        self.kf_qt[:, 0] = 1.0
         # ---- static state of the captured iterations
-        self.n_ba_max = max(sum(ba_ray_counts(cfg, k)) for k in range(1, self.Kmax + 1))
+        k_related = [len(kfs) for _, kfs in self._timeline.values()] or [1]
+        self.n_ba_max = max(sum(ba_ray_counts(cfg, k)) for k in range(1, max(k_related) + 1))
         self.ba_rot = torch.nn.Parameter(torch.tensor([[1., 0., 0., 0.]], device=dev).repeat(self.Kmax, 1))
-        self.ba_trans = torch.nn.Parameter(torch.zeros(self.Kmax, 3, device=dev))       # slot j-1 = keyframe j, -1 = current
-        self.fixed = torch.eye(4, device=dev)[None].clone()
+        self.ba_trans = torch.nn.Parameter(torch.zeros(self.Kmax, 3, device=dev))       # slot j-1 = j-th keyframe of the ACTIVE sub-map, -1 = current
+        self.fixed = torch.eye(4, device=dev)[None].clone()                  # its first keyframe (never optimised)
         self.ba_rows = torch.zeros(self.iters, self.n_ba_max, dtype=torch.int64, device=dev)
         self.ba_owner = torch.zeros(self.iters, self.n_ba_max, dtype=torch.int64, device=dev)
         self.ba_noise = torch.zeros(self.iters, self.n_ba_max, self.S, device=dev)
@@ -465,12 +519,31 @@ class GraphedSequence:
         self.go_noise = torch.zeros(tk["iter"], self.n_track, self.S, device=dev)
         self.go_popt = FusedAdam([{"params": self.go_rot, "lr": tk["lr_rot"]}, {"params": self.go_trans, "lr": tk["lr_trans"]}],
                                  capturable=True)
+        # sub-map initialisation (first frame / ("new",)): mapping.sample pixels of the keyframe, its pose fixed
+        self.n_init = mp["sample"]
+        self.init_rows = torch.zeros(self.INIT_INNER, self.n_init, dtype=torch.int64, device=dev)
+        self.init_owner = torch.zeros(self.n_init, dtype=torch.int64, device=dev)
+        self.init_noise = torch.zeros(self.INIT_INNER, self.n_init, self.S, device=dev)
+        self.init_graph = None
+        # pose-only refinement after a switch back (local_BA_switch): every keyframe pose of the sub-map fixed, one optimisable pose
+        sw = tk.get("switch", {"lr_rot": tk["lr_rot"], "lr_trans": tk["lr_trans"], "map_num": self.iters})
+        self.sw_iters = sw["map_num"]
+        self.sw_rot = torch.nn.Parameter(torch.tensor([[1., 0., 0., 0.]], device=dev))
+        self.sw_trans = torch.nn.Parameter(torch.zeros(1, 3, device=dev))
+        self.sw_popt = FusedAdam([{"params": self.sw_rot, "lr": sw["lr_rot"]}, {"params": self.sw_trans, "lr": sw["lr_trans"]}],
+                                 capturable=True)
+        self.sw_fixed = torch.eye(4, device=dev)[None].repeat(self.Kmax, 1, 1).contiguous()
+        self.n_sw_max = mp["sample"] + max(mp["sample"] // 1, mp["sample"] // 5) if self.schedule else 1
+        self.sw_rows = torch.zeros(self.sw_iters, self.n_sw_max, dtype=torch.int64, device=dev)
+        self.sw_owner = torch.zeros(self.sw_iters, self.n_sw_max, dtype=torch.int64, device=dev)
+        self.sw_noise = torch.zeros(self.sw_iters, self.n_sw_max, self.S if self.schedule else 1, device=dev)
+        self.sw_graphs: Dict[int, object] = {}
         self.ba_graphs: Dict[int, object] = {}
         self.go_graph = None
         self.producer = None
         self.lookahead = max(1, mp["map_every"] if lookahead is None else lookahead)
         if sampler == "reference":
-            self.producer = ReferenceSampleProducer(cfg, H, W, self.R, self.Kmax, slots=self.lookahead + 2)
+            self.producer = ReferenceSampleProducer(cfg, H, W, self.R, max(k_related), slots=self.lookahead + 2)
         self.capture_ms = 0.0
         self._qt_host = torch.zeros(16, 7, dtype=torch.float32)
         if torch.cuda.is_available():
@@ -478,6 +551,55 @@ class GraphedSequence:
         self._qt_next = 0
         self._score_bufs = {}
         self._lattice_dev = {}
+
+    def _make_timeline(self, n_frames):
+        return submap_timeline(n_frames, self.kf_every, self.schedule)
+
+    # --------------------------------------------------------------------------- state kept out of warm-ups / switches
+    def _optimizers(self):
+        return (self.map_opt, self.ba_popt, self.go_popt, self.sw_popt)
+
+    def _guarded(self, make_graph):
+        """Capture a graph WITHOUT training on its warm-up: ``GraphedSteps`` runs the step function eagerly before it
+        records (allocator and lazy-initialisation warm-up), i.e. real optimisation steps on whatever the static buffers
+        hold.  Parameters, poses and every optimiser's state (moments, device step counters, host step counts) are
+        snapshotted before and put back after, so the model that enters the next frame does not depend on how many graph
+        shapes a sequence needs (a long sequence used to receive tens of extra mapping rounds before frame 1)."""
+        with torch.no_grad():
+            params = list(self.model.parameters()) + [self.ba_rot, self.ba_trans, self.go_rot, self.go_trans, self.sw_rot,
+                                                      self.sw_trans]
+            saved = [(p, p.detach().clone()) for p in params]
+            opt_saved = []
+            for opt in self._optimizers():
+                st = {p: (s["step"], s["exp_avg"].clone(), s["exp_avg_sq"].clone()) for p, s in opt.state.items() if s}
+                dev_saved = {gi: (a.clone(), b.clone()) for gi, (a, b) in opt._dev.items()}
+                opt_saved.append((opt, st, dev_saved))
+        t0 = time.perf_counter()
+        g = make_graph()
+        torch.cuda.synchronize()
+        self.capture_ms += (time.perf_counter() - t0) * 1e3
+        with torch.no_grad():
+            for p, v in saved:
+                p.copy_(v)
+                if p.grad is not None:
+                    p.grad.zero_()
+            for opt, st, dev_saved in opt_saved:
+                for p, s in opt.state.items():
+                    if not s:
+                        continue
+                    if p in st:
+                        s["step"] = st[p][0]
+                        s["exp_avg"].copy_(st[p][1]), s["exp_avg_sq"].copy_(st[p][2])
+                    else:                               # state created by the warm-up: a fresh optimiser has zeros
+                        s["step"] = 0
+                        s["exp_avg"].zero_(), s["exp_avg_sq"].zero_()
+                for gi, (a, b) in opt._dev.items():
+                    if gi in dev_saved:
+                        a.copy_(dev_saved[gi][0]), b.copy_(dev_saved[gi][1])
+                    else:
+                        a.zero_(), b.zero_()
+        torch.cuda.synchronize()
+        return g
 
     # ------------------------------------------------------------------------------------- captured iterations
     def _ba_step_fn(self, n):
@@ -509,10 +631,52 @@ class GraphedSequence:
     def _ba_graph(self, n):
         g = self.ba_graphs.get(n)
         if g is None:
-            t0 = time.perf_counter()
-            g = self.ba_graphs[n] = self._Graphed(self._ba_step_fn(n), self.iters, warmup=1, stream=self.stream)
-            torch.cuda.synchronize()
-            self.capture_ms += (time.perf_counter() - t0) * 1e3
+            g = self.ba_graphs[n] = self._guarded(lambda: self._Graphed(self._ba_step_fn(n), self.iters, warmup=1, stream=self.stream))
+        return g
+
+    def _init_step(self, k):
+        """One initialisation iteration of a sub-map (first_frame_mapping / initialize_new_localMLP, mipsfusion.py:172-190,
+        206-221): mapping.sample pixels of the keyframe, its pose fixed (owner 0), map Adam step."""
+        rays_o, rays_d, rgb, depth = ops.gather_pose_rays(self.table, self.init_rows[k], self.ba_rot.detach(), self.ba_trans.detach(),
+                                                          self.fixed, self.init_owner)
+        ret = self.model.forward(rays_o, rays_d, rgb, depth, noise=self.init_noise[k])
+        backward_from_one(get_loss_from_ret(ret, self.cfg["training"]))
+        self.map_opt.step(zero_grad=True)
+
+    def _sw_step_fn(self, n):
+        """local_BA_switch (mipsfusion.py:379-444) for n rays: the keyframe poses of the sub-map are all fixed, the overlapping
+        frame's pose is the one optimisable pose (switch learning rates), stepped every pose_accum_step iterations; the map
+        is not stepped (the reference lets its gradients pile up unused until the next local BA clears them: the graph is
+        recorded with the map frozen, which gives the same poses without computing them)."""
+        rows, owner, noise = packed(self.sw_rows, n), packed(self.sw_owner, n), packed(self.sw_noise, n)
+        accum = self.cfg["mapping"]["pose_accum_step"]
+
+        def step(k):
+            if k == 0:
+                self.model.frozen_weights(True)
+            rays_o, rays_d, rgb, depth = ops.gather_pose_rays(self.table, rows[k], self.sw_rot, self.sw_trans, self.sw_fixed,
+                                                              owner[k], accumulate_in_place=True)
+            ret = self.model.forward(rays_o, rays_d, rgb, depth, noise=noise[k])
+            backward_from_one(get_loss_from_ret(ret, self.cfg["training"]))
+            if (k + 1) % accum == 0:
+                self.sw_popt.step(zero_grad=True)
+            if k == self.sw_iters - 1:
+                self.model.frozen_weights(False)
+        return step
+
+    def _frozen_map(self, make_graph):
+        for prm in self.model.parameters():
+            prm.requires_grad_(False)
+        try:
+            return self._guarded(make_graph)
+        finally:
+            for prm in self.model.parameters():
+                prm.requires_grad_(True)
+
+    def _sw_graph(self, n):
+        g = self.sw_graphs.get(n)
+        if g is None:
+            g = self.sw_graphs[n] = self._frozen_map(lambda: self._Graphed(self._sw_step_fn(n), self.sw_iters, warmup=1, stream=self.stream))
         return g
 
     # --------------------------------------------------------------------------------------------- device sampler
@@ -545,33 +709,70 @@ class GraphedSequence:
             lat = self._lattice_dev[(n_rows, n_cols)] = (rows * self.W + cols).to(self.dev)
         return lat
 
-    def _fill_ba_device(self, K, cur_is_first):
+    def _slots_dev(self, slots):
+        key = tuple(slots)
+        if getattr(self, "_slots_key", None) != key:
+            self._slots_key, self._slots_t = key, torch.tensor(list(slots), dtype=torch.int64, device=self.dev)
+        return self._slots_t
+
+    def _fill_ba_device(self, slots):
+        """Device draws with the per-keyframe shares of sample_rays_in_submap (keyframeSet.py:386-436) over the keyframe
+        slots `slots` of the active sub-map + sample_pixels_mix's distribution for the current frame."""
+        K = len(slots)
         n_kf, n_cur = ba_ray_counts(self.cfg, K)
-        if K == 1 and cur_is_first:
-            n_kf, n_cur = 0, n_kf + n_cur
         R, it = self.R, self.iters
         idx, own = [], []
-        if n_kf:
-            n_first = max(n_kf // K, n_kf // 10)
-            idx.append(self._device_draw(R, n_first, it))
-            own.append(torch.zeros(it, n_first, dtype=torch.int64, device=self.dev))
-            n_last = max(n_kf // K, n_kf // 5) if K > 2 else 0
-            n_other = n_kf - n_first - n_last
-            if K > 1 and n_other:
-                span = (K - 2) if K > 2 else 1
-                o = self._device_draw(span * R, n_other, it)
-                idx.append(o + R), own.append(o // R + 1)
-            if n_last:
-                idx.append(self._device_draw(R, n_last, it) + (K - 1) * R)
-                own.append(torch.full((it, n_last), K - 1, dtype=torch.int64, device=self.dev))
+        n_first = max(n_kf // K, n_kf // 10)
+        idx.append(self._device_draw(R, n_first, it) + slots[0] * R)
+        own.append(torch.zeros(it, n_first, dtype=torch.int64, device=self.dev))
+        n_last = max(n_kf // K, n_kf // 5) if K > 2 else 0
+        n_other = n_kf - n_first - n_last
+        if K > 1 and n_other:
+            span = (K - 2) if K > 2 else 1
+            o = self._device_draw(span * R, n_other, it)
+            pos = o // R + 1
+            idx.append(self._slots_dev(slots)[pos] * R + (o - (pos - 1) * R)), own.append(pos)
+        elif n_other:                       # one keyframe: every keyframe ray comes from it
+            idx.append(self._device_draw(R, n_other, it) + slots[0] * R)
+            own.append(torch.zeros(it, n_other, dtype=torch.int64, device=self.dev))
+        if n_last:
+            idx.append(self._device_draw(R, n_last, it) + slots[K - 1] * R)
+            own.append(torch.full((it, n_last), K - 1, dtype=torch.int64, device=self.dev))
         tk = self.cfg["tracking"]
         lat = self._lattice(tk["RO"]["n_rows"], tk["RO"]["n_cols"])
         extra = self._device_valid_pixels(n_cur - lat.shape[0], it, lattice=lat)
         idx.append(torch.cat([lat[None].expand(it, -1), extra], 1) + self.Kmax * R)
-        own.append(torch.full((it, n_cur), 0 if cur_is_first else -1, dtype=torch.int64, device=self.dev))
+        own.append(torch.full((it, n_cur), -1, dtype=torch.int64, device=self.dev))
         n = n_kf + n_cur
         packed(self.ba_rows, n).copy_(torch.cat(idx, 1)), packed(self.ba_owner, n).copy_(torch.cat(own, 1))
         packed(self.ba_noise, n).uniform_()
+        return n
+
+    def _fill_init_device(self):
+        """select_samples (mipsfusion.py:135-138, 175-177): mapping.sample pixels of the keyframe, uniform over ALL pixels
+        (drawn with replacement here: ~6 repeats among 1800 of 285 200), and the jitter, for INIT_INNER iterations."""
+        torch.randint(0, self.H * self.W, tuple(self.init_rows.shape), out=self.init_rows)
+        self.init_rows.add_(self.Kmax * self.R)
+        self.init_noise.uniform_()
+
+    def _sw_counts(self, K):
+        mp = self.cfg["mapping"]
+        return mp["sample"], max(mp["sample"] // K, mp["sample"] // 5)
+
+    def _fill_sw_device(self, slots):
+        """sample_rays_in_given_kf (keyframeSet.py:444-455) over the sub-map's keyframes + random pixels of the frame
+        (mipsfusion.py:410-416), drawn on the device for the map_num iterations of one local_BA_switch."""
+        K = len(slots)
+        n_kf, n_ov = self._sw_counts(K)
+        it, R = self.sw_iters, self.R
+        o = torch.randint(0, K * R, (it, n_kf), device=self.dev)
+        pos = o // R
+        rows_kf = self._slots_dev(slots)[pos] * R + (o - pos * R)
+        rows_ov = torch.randint(0, self.H * self.W, (it, n_ov), device=self.dev) + self.Kmax * R
+        n = n_kf + n_ov
+        packed(self.sw_rows, n).copy_(torch.cat([rows_kf, rows_ov], 1))
+        packed(self.sw_owner, n).copy_(torch.cat([pos, torch.full((it, n_ov), -1, dtype=torch.int64, device=self.dev)], 1))
+        packed(self.sw_noise, n).uniform_()
         return n
 
     def _fill_go_device(self):
@@ -603,20 +804,87 @@ class GraphedSequence:
         qt = torch.cat([rot.detach()[slot], trans.detach()[slot]]).cpu().numpy()
         return torch.from_numpy(_qt_to_matrix_np(qt))
 
+    def _store_keyframe_rays(self, slot):
+        self.db.store(slot, self.cur.view(self.H, self.W, 7)[self.kf_rows, self.kf_cols])
+
     def _add_keyframe(self, pose):
-        self.db.store(self.n_kf, self.cur.view(self.H, self.W, 7)[self.kf_rows, self.kf_cols])
-        if self.n_kf == 0:
+        """the current frame becomes the next keyframe of the ACTIVE sub-map (its pose: position j of the pose slots)"""
+        slot, kfs = self.n_kf, self.submaps[self.active]["kfs"]
+        self._store_keyframe_rays(slot)
+        self._set_pose(self.kf_qt[:, :4], self.kf_qt[:, 4:], slot, pose)
+        if not kfs:
             self.fixed[0].copy_(pose.to(self.dev))
         else:
-            self._set_pose(self.ba_rot, self.ba_trans, self.n_kf - 1, pose)
+            self._set_pose(self.ba_rot, self.ba_trans, len(kfs) - 1, pose)
+        kfs.append(slot)
         self.n_kf += 1
 
+    def _state_tensors(self):
+        return [p.data for p in self.model.parameters()]
+
+    def _store_active(self):
+        """the active sub-map leaves the model: parameters -> its store (device-to-device; the reference copies them to the
+        other process through shared memory, mipsfusion.py:616, 642, InactiveMap.py:66-70), optimised keyframe poses ->
+        the keyframe table"""
+        sm = self.submaps[self.active]
+        with torch.no_grad():
+            if sm["state"] is None:
+                sm["state"] = [t.clone() for t in self._state_tensors()]
+            else:
+                for dst, src in zip(sm["state"], self._state_tensors()):
+                    dst.copy_(src)
+            k = len(sm["kfs"])
+            if k > 1:
+                self.kf_qt[self._slots_dev(sm["kfs"])[1:]] = torch.cat([self.ba_rot.detach()[:k - 1], self.ba_trans.detach()[:k - 1]], 1)
+
+    def _switch_new(self, pose):
+        """active_submap_switch_new + initialize_new_localMLP (mipsfusion.py:637-652, 198-222)"""
+        self._store_active()
+        self.model.recover_initial_param()
+        self.map_opt.reset()                                # create_optimizer(): a fresh Adam
+        self.active = len(self.submaps)
+        self.submaps[self.active] = {"kfs": [], "state": None}
+        self._add_keyframe(pose)                            # first keyframe of the new sub-map: fixed[0]
+        self._initialise()
+
+    def _initialise(self):
+        if self.init_graph is None:
+            self._fill_init_device()
+            self.init_graph = self._guarded(lambda: self._Graphed(self._init_step, self.INIT_INNER, warmup=1, stream=self.stream))
+        for _ in range(max(1, self.first_iters // self.INIT_INNER)):
+            self._fill_init_device()
+            self.init_graph.replay()
+
+    def _switch_back(self, target, pose, waiting):
+        """active_submap_switch + local_BA_switch (mipsfusion.py:608-634, 379-444) -> the refined pose of the frame (CPU)"""
+        self._store_active()
+        sm = self.submaps[target]
+        with torch.no_grad():
+            for dst, src in zip(self._state_tensors(), sm["state"]):
+                dst.copy_(src)                              # load_state_dict of the asked sub-map, device to device
+            self.active = target
+            slots = sm["kfs"]
+            k = len(slots)
+            qt = self.kf_qt[self._slots_dev(slots)]
+            poses = qt_to_transform_matrix(qt[:, :4], qt[:, 4:])
+            self.sw_fixed[:k].copy_(poses)
+            self.fixed[0].copy_(poses[0])
+            if k > 1:
+                self.ba_rot.data[:k - 1].copy_(qt[1:, :4]), self.ba_trans.data[:k - 1].copy_(qt[1:, 4:])
+        self._set_pose(self.sw_rot, self.sw_trans, 0, pose)
+        self.sw_popt.reset()
+        n = self._fill_sw_device(slots)
+        self._sw_graph(n).replay()
+        pose = waiting(lambda: self._get_pose(self.sw_rot, self.sw_trans, 0))
+        self._add_keyframe(pose)                            # the overlapping keyframe joins the sub-map switched to
+        return pose
+
     def _n_kf_at(self, k):
-        """keyframes stored when frame k's local BA runs (the frame itself is added AFTER its BA, mipsfusion.py:681-688)"""
-        return 1 + (k - 1) // self.kf_every
+        """related keyframes when frame k's local BA runs (the frame itself is added AFTER its BA, mipsfusion.py:681-688)"""
+        return len(self._timeline[k][1])
 
     def _plan(self, k):
-        ba = torch.arange(self._n_kf_at(k)) if (k % self.cfg["mapping"]["map_every"] == 0) else None
+        ba = torch.tensor(self._timeline[k][1]) if (k % self.cfg["mapping"]["map_every"] == 0) else None
         return FramePlan(k, self.frames[k]["depth"], True, ba, self.Kmax * self.R)
 
     def _load_ba(self, s: FrameSamples):
@@ -628,34 +896,54 @@ class GraphedSequence:
     # ------------------------------------------------------------------------------------------------------ run
     def first_frame(self, gt_pose):
         """mipsfusion.py:155-194: ground-truth pose, ``first_iters`` mapping iterations on frame 0's pixels."""
-        dev = self.dev
         self.cur.copy_(self.host_rays[0], non_blocking=True)
         pose0 = gt_pose.float().cpu()
         self._add_keyframe(pose0)
-        n = self._fill_ba_device(1, True)           # select_samples-style uniform pixels of frame 0 (device draws)
-        g = self._ba_graph(n)
-        for _ in range(max(0, self.first_iters // self.iters - 2)):
-            self._fill_ba_device(1, True)
-            g.replay()
-        for prm in self.model.parameters():         # the tracking graph is recorded with the map frozen
-            prm.requires_grad_(False)
+        self._initialise()
         self._set_pose(self.go_rot, self.go_trans, 0, pose0)
         self._fill_go_device()
-        t0 = time.perf_counter()
-        self.go_graph = self._Graphed(self._go_step, self.cfg["tracking"]["iter"], warmup=1, stream=self.stream)
-        torch.cuda.synchronize()
-        self.capture_ms += (time.perf_counter() - t0) * 1e3
-        for prm in self.model.parameters():
-            prm.requires_grad_(True)
+        # the tracking graph is recorded with the map frozen
+        self.go_graph = self._frozen_map(lambda: self._Graphed(self._go_step, self.cfg["tracking"]["iter"], warmup=1, stream=self.stream))
         if self.graph_ro:
             t0 = time.perf_counter()
             self.ro.capture(self.model, self.cfg["tracking"]["iter_RO"], self.stream)
             torch.cuda.synchronize()
             self.capture_ms += (time.perf_counter() - t0) * 1e3
         # one-off lazy initialisations (the first torch._foreach_zero_ takes 65 ms) belong to the set-up, not to frame 1
-        self.go_popt.reset(), self.ba_popt.reset()
+        self.go_popt.reset(), self.ba_popt.reset(), self.sw_popt.reset()
         torch.cuda.synchronize()
         return pose0
+
+    def precapture(self):
+        """Capture every graph shape the sequence will need up front (one-off cost, reported as `capture_ms`); every
+        capture leaves parameters and optimiser state as it found them (`_guarded`)."""
+        mp = self.cfg["mapping"]
+        n_frames = len(self.frames)
+        slot_sets = {}
+        for k in range(1, n_frames):
+            if k % mp["map_every"] == 0:
+                slot_sets.setdefault(len(self._timeline[k][1]), self._timeline[k][1])
+        for K, slots in sorted(slot_sets.items()):
+            self._ba_graph(sum(ba_ray_counts(self.cfg, K)))
+        if self.producer is None:
+            # the device sampler's draws have shapes that depend on K: torch's first top-k / index op of a new shape
+            # costs 10-70 ms (measured: 72 ms in the first BA round after a keyframe was added)
+            for K, slots in sorted(slot_sets.items()):
+                self._fill_ba_device(slots)
+        for k, ev in sorted(self.schedule.items()):
+            if ev[0] == "back":                         # the sub-map switched to has these keyframes at that moment
+                subs = {}
+                for kk in range(1, k + 1):
+                    subs[self._timeline[kk][0]] = self._timeline[kk][1]
+                slots = subs[ev[1]]
+                self._sw_graph(sum(self._sw_counts(len(slots))))
+                self._fill_sw_device(slots)
+                with torch.no_grad():                   # the pose-table operations of a switch, once per shape (torch loads a
+                    qt = self.kf_qt[self._slots_dev(slots)]      # kernel of a new shape lazily: 10-70 ms inside the switch frame)
+                    qt_to_transform_matrix(qt[:, :4], qt[:, 4:])
+                    self.kf_qt[self._slots_dev(slots)[1:]] = qt[1:].clone()
+                    torch.cat([self.ba_rot.detach()[:len(slots) - 1], self.ba_trans.detach()[:len(slots) - 1]], 1)
+        torch.cuda.synchronize()
 
     def run(self, gt_poses, precapture=True):
         """-> dict of per-frame wall-clock lists (ms) and the estimated poses."""
@@ -663,23 +951,15 @@ class GraphedSequence:
         tk, mp = cfg["tracking"], cfg["mapping"]
         n_frames = len(self.frames)
         est = [self.first_frame(gt_poses[0])]
-        if precapture:       # capture every BA graph shape of the sequence up front (one-off cost, reported separately)
-            Ks = sorted({self._n_kf_at(k) for k in range(1, n_frames) if k % mp["map_every"] == 0})
-            for K in Ks:
-                self._ba_graph(sum(ba_ray_counts(cfg, K)))
-            if self.producer is None:
-                # the device sampler's draws have shapes that depend on K: torch's first top-k / index op of a new shape
-                # costs 10-70 ms (measured: 72 ms in the first BA round after a keyframe was added).  AFTER the captures:
-                # their warm-up iterations train on whatever the index buffers hold, which must stay frame 0's rows.
-                for K in Ks:
-                    self._fill_ba_device(K, False)
-            torch.cuda.synchronize()
+        if precapture:
+            self.precapture()
         if self.producer is not None:
             for j in range(1, min(n_frames, 1 + self.lookahead)):
                 self.producer.submit(self._plan(j))
-        t_frame, t_ro, t_go, t_ba, t_wait = [], [], [], [], []
+        t_frame, t_ro, t_go, t_ba, t_wait, t_switch = [], [], [], [], [], {}
         detail = {"go_fill_ms": [], "go_replay_ms": [], "go_launch_ms": [], "go_gpu_ms": [], "ba_fill_ms": [], "ba_replay_ms": [], "tail_ms": []}
         gate = self.producer.gate if (self.producer is not None and self.gate_producer) else None
+        last_switch = 0
 
         def waiting(fn):
             """fn blocks on the GPU: the producer stages may use the host meanwhile"""
@@ -701,7 +981,7 @@ class GraphedSequence:
                 if k + self.lookahead < n_frames:
                     self.producer.submit(self._plan(k + self.lookahead))     # `lookahead` frames ahead of the GPU
             prev = est[-1]                                                   # poses live on the host (4x4 algebra there)
-            if len(est) < 2:
+            if len(est) < 2 or (k - last_switch) < 2:                        # predict_current_pose (mipsfusion.py:448-457)
                 init = prev
             else:                                                            # constant velocity, in numpy (see _set_pose)
                 init = torch.from_numpy(prev.numpy() @ np.linalg.inv(est[-2].numpy()) @ prev.numpy())
@@ -742,18 +1022,30 @@ class GraphedSequence:
             detail["go_gpu_ms"].append(ev_a.elapsed_time(ev_b))
             ba_ms = 0.0
             if k % mp["map_every"] == 0:
-                assert self.n_kf == self._n_kf_at(k)
+                slots = self.submaps[self.active]["kfs"]
+                assert slots == self._timeline[k][1], "the sub-map bookkeeping left the planned timeline"
                 self._set_pose(self.ba_rot, self.ba_trans, -1, pose)
                 self.ba_popt.reset()
-                n = self._load_ba(samples) if samples is not None else self._fill_ba_device(self.n_kf, False)
+                n = self._load_ba(samples) if samples is not None else self._fill_ba_device(slots)
                 t2b = time.perf_counter()
                 self._ba_graph(n).replay()
                 pose = waiting(lambda: self._get_pose(self.ba_rot, self.ba_trans, -1))
                 ba_ms = (time.perf_counter() - t2) * 1e3
                 detail["ba_fill_ms"].append((t2b - t2) * 1e3), detail["ba_replay_ms"].append(ba_ms - (t2b - t2) * 1e3)
             t3 = time.perf_counter()
-            if k % self.kf_every == 0:                                       # mipsfusion.py:686-688, after the BA
-                self._add_keyframe(pose)
+            if k % self.kf_every == 0:                                       # mipsfusion.py:686-712, after the BA
+                ev = self.schedule.get(k)
+                if ev is None:
+                    self._add_keyframe(pose)
+                elif ev[0] == "new":
+                    self._switch_new(pose)
+                    last_switch = k
+                else:
+                    pose = self._switch_back(ev[1], pose, waiting)
+                    last_switch = k
+                if ev is not None:
+                    waiting(torch.cuda.synchronize)
+                    t_switch[k] = {"kind": ev[0], "ms": round((time.perf_counter() - t3) * 1e3, 3)}
             est.append(pose)
             waiting(torch.cuda.synchronize)
             if samples is not None:
@@ -765,7 +1057,8 @@ class GraphedSequence:
             self.producer.gate.set()
             self.producer.close()
         return {"frame_ms": t_frame, "ro_ms": t_ro, "go_ms": t_go, "ba_ms": t_ba, "producer_wait_ms": t_wait,
-                "est": est, "capture_ms": self.capture_ms, "detail_ms": detail,
+                "est": est, "capture_ms": self.capture_ms, "detail_ms": detail, "switch": t_switch,
+                "submaps": {s: list(v["kfs"]) for s, v in self.submaps.items()},
                 "producer_host_ms": dict(self.producer.host_ms) if self.producer is not None else None}
 
 
@@ -783,6 +1076,15 @@ def summarise(res, gt_poses, cfg, launch):
                        "mapping_iters": cfg["mapping"]["iters"], "map_every": cfg["mapping"]["map_every"]},
            "launch": launch, "ate_rmse_m": round(float(np.sqrt(np.mean(np.square(err)))), 4),
            "ate_max_m": round(max(err), 4)}
+    if res.get("switch"):
+        sw = {int(k): v for k, v in res["switch"].items()}
+        plain = np.array([t for i, t in enumerate(fm) if (i + 1) not in sw])
+        out["switch_frames"] = sw
+        out["submap_keyframe_slots"] = res.get("submaps")
+        out["ms_per_frame_mean_without_switch_frames"] = round(float(plain.mean()), 3)
+        out["switch_frames_note"] = ("ms_per_frame_mean / median / p95 include the switch frames: 'new' = parameter store + "
+                                     "recover_initial_param + fresh map optimiser + mapping.first_iters initialisation iterations, "
+                                     "'back' = store + load + tracking.switch.map_num pose-only iterations")
     if res.get("detail_ms"):
         out["detail_ms_mean"] = {k: round(float(np.mean(v)), 3) for k, v in res["detail_ms"].items() if len(v) and k != "go_fill_parts_ms"}
         out["frame_ms_all"] = [round(float(t), 2) for t in fm]

@@ -53,6 +53,106 @@ def render_box_frame(bound, c2w: torch.Tensor, H, W, fx, fy, cx, cy, shrink=0.3,
             "direction": dirs}
 
 
+def render_rooms_frame(room_a, room_b, door, c2w: torch.Tensor, H, W, fx, fy, cx, cy, drop=0.02, seed=0,
+                       frame_id=0) -> Dict[str, torch.Tensor]:
+    """One frame of TWO box rooms that share the wall z = room_a[2][1] = room_b[2][0], with a door opening
+    ``door`` = [[x0, x1], [y0, y1]] in that wall (BASELINE config 3: a trajectory through several rooms).  A ray that
+    leaves the camera's room through the door ends on the other room's walls."""
+    A, B = torch.as_tensor(room_a, dtype=torch.float32), torch.as_tensor(room_b, dtype=torch.float32)
+    dirs = camera_rays(H, W, fx, fy, cx, cy)
+    R, t = c2w[:3, :3].float(), c2w[:3, 3].float()
+    d_world = torch.sum(dirs[..., None, :] * R, -1)
+    safe = torch.where(d_world.abs() < 1e-9, torch.full_like(d_world, 1e-9), d_world)
+
+    def exit_depth(box):
+        wall = torch.where(d_world > 0, box[:, 1], box[:, 0])
+        tt = (wall - t) / safe
+        tt = torch.where(d_world.abs() < 1e-9, torch.full_like(tt, float("inf")), tt)
+        return tt.min(-1)
+    z_wall = float(A[2, 1])
+    in_a = float(t[2]) < z_wall
+    own, other = (A, B) if in_a else (B, A)
+    dep, face = exit_depth(own)
+    hit = t + d_world * dep[..., None]
+    through = (face == 2) & ((d_world[..., 2] > 0) == in_a) & ((hit[..., 2] - z_wall).abs() < 1e-3) & \
+        (hit[..., 0] > door[0][0]) & (hit[..., 0] < door[0][1]) & (hit[..., 1] > door[1][0]) & (hit[..., 1] < door[1][1])
+    dep2, _ = exit_depth(other)
+    depth = torch.where(through, dep2, dep)
+    hit = t + d_world * depth[..., None]
+    rgb = 0.5 + 0.5 * torch.sin(4.0 * hit)
+    g = torch.Generator().manual_seed(seed)
+    dead = torch.rand(H, W, generator=g) < drop
+    depth = torch.where(dead, torch.zeros_like(depth), depth)
+    return {"frame_id": frame_id, "c2w": c2w.clone(), "rgb": rgb.contiguous(), "depth": depth.contiguous(),
+            "direction": dirs}
+
+
+def config_two_rooms() -> dict:
+    """BASELINE config 3 workload: the reference's FastCaMo-synth settings as shipped (S = 50 + 25, 1800 + 800 rays, 5 RO
+    rounds, 10 tracking / 15 mapping iterations, 500 initialisation iterations per sub-map, 15 pose-only iterations after a
+    switch back: FastCaMo-synth.yaml:16-33, 53-55, 73-80) over a bound that covers two rooms joined by a door."""
+    c = copy.deepcopy(_BASE)
+    c["mapping"]["bound"] = [[-0.6, 2.95], [0.5, 7.05], [-1.15, 7.05]]
+    c["mapping"]["keyframe_every"] = 15
+    c["tracking"]["switch"] = {"lr_rot": 0.001, "lr_trans": 0.001, "map_num": 15}
+    c["cam"]["far"] = 6
+    return c
+
+
+TWO_ROOMS = {"room_a": [[-0.3, 2.65], [0.8, 6.75], [-0.85, 2.75]], "room_b": [[-0.3, 2.65], [0.8, 6.75], [2.75, 6.75]],
+             "door": [[0.55, 1.85], [0.8, 5.2]]}
+
+
+def two_room_sequence(cfg: dict, n_frames: int = 300, kf_every: int = 15):
+    """-> (ground-truth poses, frames, schedule): a camera walks a loop in room A, through the door into room B, a loop
+    there, and backwards through the door into room A again (4 cm and 0.5 degrees per frame on average, peaks 7.5 cm / 2
+    degrees; the camera keeps a corner in view: facing a single textureless-geometry wall of a box room leaves a translation
+    along the wall to the weak colour term -- measured: a 20 cm slide in the middle of a half turn, kept by the map from then on).  schedule {frame: ("new",) | ("back", submap)}: a NEW
+    sub-map at the first keyframe after the door, back to sub-map 0 at the first keyframe after the return -- the decisions
+    Manager.process_keyframe (Manager.py, host control plane, out of scope) would take, fixed in advance."""
+    H, W, fx, fy, cx, cy = intrinsics_after_crop(cfg)
+
+    def smooth(a):
+        a = min(1.0, max(0.0, a))
+        return a * a * (3 - 2 * a)
+    # way points in the horizontal (x, z) plane, height y = 3.8; yaw pi looks along +z
+    seg = [0.27, 0.20, 0.20, 0.20, 0.13]                    # shares of the sequence: loop A, to B, loop B, back, loop A
+    edges = np.cumsum([0.0] + seg)
+    poses, room_of = [], []
+    for k in range(n_frames):
+        u = k / max(1, n_frames - 1)
+        s = int(np.searchsorted(edges, u, side="right") - 1)
+        s = min(s, len(seg) - 1)
+        a = (u - edges[s]) / seg[s]
+        if s == 0:                                          # loop in A around (1.2, 0.9), looking outwards then towards the door
+            ang = 2 * math.pi * smooth(a)
+            x, z, yaw = 1.2 + 0.45 * math.sin(ang), 0.9 - 0.45 * math.cos(ang) + 0.45, math.pi + 0.35 * math.sin(ang)
+        elif s == 1:                                        # through the door
+            x, z, yaw = 1.2, 0.9 + (3.9 - 0.9) * smooth(a), math.pi
+        elif s == 2:                                        # loop in B around (1.2, 4.4)
+            ang = 2 * math.pi * smooth(a)
+            x, z, yaw = 1.2 + 0.45 * math.sin(ang), 4.35 - 0.45 * math.cos(ang), math.pi - 0.35 * math.sin(ang)
+        elif s == 3:                                        # back through the door, walking backwards (still looking along +z)
+            x, z, yaw = 1.2, 3.9 + (1.1 - 3.9) * smooth(a), math.pi
+        else:
+            ang = 2 * math.pi * smooth(a)
+            x, z, yaw = 1.2 - 0.2 * math.sin(ang), 1.1 + 0.2 * math.cos(ang) - 0.2, math.pi + 0.25 * math.sin(ang)
+        c2w = torch.eye(4)
+        c2w[:3, :3] = look_rotation(yaw, -0.08 + 0.04 * math.sin(9.0 * u))
+        c2w[:3, 3] = torch.tensor([x, 3.8 + 0.08 * math.sin(5.0 * u), z])
+        poses.append(c2w)
+        room_of.append(0 if z < TWO_ROOMS["room_a"][2][1] else 1)
+    frames = [render_rooms_frame(TWO_ROOMS["room_a"], TWO_ROOMS["room_b"], TWO_ROOMS["door"], poses[k], H, W, fx, fy, cx, cy,
+                                 seed=k, frame_id=k) for k in range(n_frames)]
+    schedule, active = {}, 0
+    for k in range(kf_every, n_frames, kf_every):
+        if room_of[k] == 1 and active == 0:
+            schedule[k], active = ("new",), 1
+        elif room_of[k] == 0 and active == 1:
+            schedule[k], active = ("back", 0), 0
+    return poses, frames, schedule
+
+
 _BASE = {
     "grid": {"enc": "HashGrid", "tcnn_encoding": True, "hash_size": 19, "voxel_sdf": 0.04,
              "use_bound_normalize": True},

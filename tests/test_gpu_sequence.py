@@ -7,12 +7,14 @@ product consumes the python-`random`, torch-CPU and numpy generators exactly as 
 jitter draw inside ``forward`` --, the 51-entry loss trace, every frame's local pose, both sub-maps' weights after the
 hand-offs (deepcopy / load_state_dict / recover_initial_param)."""
 import copy
+import random
 import types
 
 import numpy as np
 import pytest
 import torch
 
+from mipsfusion_amd import synth
 from mipsfusion_amd.helper_functions import geometry_helper as gh
 from mipsfusion_amd.helper_functions import sampling_helper as sh
 from mipsfusion_amd.keyframe_rays import DeviceRayDB
@@ -70,7 +72,7 @@ def rel_max(a, b):
 
 
 @pytest.mark.parametrize("fused_adam,in_place,precision", [(True, False, "f32"), (True, True, "f32"), (False, False, "f32"),
-                                                          (True, True, "f16x3")])
+                                                          (True, True, "f16x3"), (False, False, "f16x3")])
 def test_two_submap_sequence_matches_reference_run(fused_adam, in_place, precision):
     if not torch.cuda.is_available():
         pytest.fail("no GPU visible: the gpu-marked tests must run on the MI355X box")
@@ -125,3 +127,109 @@ def test_two_submap_sequence_matches_reference_run(fused_adam, in_place, precisi
     # the InactiveMap-side copy is the active model as of the last BA round (mipsfusion.py:683)
     for k in ("decoder.pts_linear.0.weight", "decoder.sdf_linear.2.weight"):
         assert rel_max(out["active_copy"][k].numpy(), g[f"copy.{k}"]) < 5e-2
+
+
+# ------------------------------------------------------------------------------- graphed multi-sub-map loop (config 3)
+def _small_two_room_cfg(quick=True):
+    """config_two_rooms on 160 x 120 images; quick: fewer rays / iterations (the switch mechanics), else the reference's
+    cadence (5 RO rounds, 10 tracking / 15 mapping iterations) on a 2^16 table (the trajectory test)."""
+    cfg = synth.config_two_rooms()
+    cfg["cam"].update(H=140, W=180, fx=80.0, fy=80.0, cx=89.5, cy=69.5, crop_edge=10)
+    if quick:
+        cfg["grid"]["hash_size"] = 14
+        cfg["mapping"].update(sample=600, pixels_cur=240, iters=6, first_iters=100)
+        cfg["tracking"].update(sample=300, iter=6, iter_RO=3)
+        cfg["tracking"]["RO"].update(particle_size=512, n_rows=8, n_cols=12)
+        cfg["tracking"]["switch"]["map_num"] = 6
+    else:
+        cfg["grid"]["hash_size"] = 16
+        cfg["mapping"].update(sample=1200, pixels_cur=500, first_iters=300)
+        cfg["tracking"].update(sample=600)
+        cfg["tracking"]["RO"].update(particle_size=1024, n_rows=12, n_cols=16)
+    cfg["tracking"]["RO"].update(initial_scaling_factor=0.02, rescaling_factor=0.5)
+    return cfg
+
+
+def test_graphed_sequence_switches_submaps_and_captures_without_training():
+    """mipsfusion_amd.sequence.GraphedSequence with a switch schedule (BASELINE config 3): (1) capturing graphs leaves
+    parameters, poses and optimiser state exactly as they were (the warm-up iterations of a capture used to train the map);
+    (2) ("new",) stores the active sub-map's parameters bit for bit, resets the model to its initial parameters and trains
+    it; (3) ("back", 0) stores sub-map 1, restores sub-map 0 bit for bit -- the pose-only refinement of local_BA_switch
+    does not touch the map -- and returns a finite refined pose; the bookkeeping follows the planned timeline."""
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the gpu-marked tests must run on the MI355X box")
+    from mipsfusion_amd import sequence
+    from mipsfusion_amd.graph import work_stream
+    dev = torch.device("cuda:0")
+    cfg = _small_two_room_cfg()
+    random.seed(0), np.random.seed(0), torch.manual_seed(0)
+    gt, frames, schedule = synth.two_room_sequence(cfg, 40, kf_every=5)
+    schedule = {10: ("new",), 25: ("back", 0)}
+    prev = torch.cuda.current_stream(dev)
+    seq = sequence.GraphedSequence(cfg, dev, frames, kf_every=5, sampler="device", stream=work_stream(dev), schedule=schedule)
+    try:
+        pose0 = seq.first_frame(gt[0])
+        snap = lambda: [p.detach().clone() for p in seq.model.parameters()]       # noqa: E731
+        opt_snap = lambda: [s["exp_avg"].clone() for s in seq.map_opt.state.values() if s]     # noqa: E731
+        a, oa = snap(), opt_snap()
+        init = [v.clone() for v in seq.model.initial_dict.values()]
+        seq.precapture()
+        for x, y in zip(a, snap()):
+            assert torch.equal(x, y), "capturing the graphs of the sequence changed the map"
+        for x, y in zip(oa, opt_snap()):
+            assert torch.equal(x, y), "capturing the graphs of the sequence changed the map optimiser's moments"
+        assert float(seq.ba_rot.detach()[:, 0].min()) == 1.0 and float(seq.ba_trans.detach().abs().max()) == 0.0
+        # ---- ("new",)
+        seq.cur.copy_(seq.host_rays[10])
+        seq.n_kf = 2                                    # slots 0, 1 are taken when frame 10 arrives (kf_every 5)
+        seq.submaps[0]["kfs"] = [0, 1]
+        seq._switch_new(gt[10].float())
+        torch.cuda.synchronize()
+        for x, y in zip(a, seq.submaps[0]["state"]):
+            assert torch.equal(x, y), "the stored sub-map is not the model that was active"
+        assert seq.active == 1 and seq.submaps[1]["kfs"] == [2]
+        b = snap()
+        grid_now, grid_init = seq.model.embed_fn.params.detach(), seq.model.initial_dict["embed_fn.params"]
+        assert not torch.equal(grid_now, grid_init), "the new sub-map was not trained"
+        moved = (grid_now - grid_init).abs().max()
+        assert float(moved) < 1.0 and torch.isfinite(grid_now).all()
+        big = max(range(len(a)), key=lambda i: a[i].numel())                 # the hash grid
+        assert not torch.equal(a[big], b[big]), "the new sub-map still holds the old parameters"
+        # ---- ("back", 0)
+        seq.cur.copy_(seq.host_rays[25])
+        pose = seq._switch_back(0, gt[25].float(), lambda f: f())
+        torch.cuda.synchronize()
+        for x, y in zip(b, seq.submaps[1]["state"]):
+            assert torch.equal(x, y), "sub-map 1 was not stored as it was"
+        for x, y in zip(a, snap()):
+            assert torch.equal(x, y), "sub-map 0 did not come back bit for bit (the switch refinement must not touch the map)"
+        assert seq.active == 0 and seq.submaps[0]["kfs"] == [0, 1, 3]
+        assert torch.isfinite(pose).all() and float((pose[:3, 3] - gt[25][:3, 3]).norm()) < 0.5
+    finally:
+        torch.cuda.set_stream(prev)
+
+
+def test_graphed_two_room_sequence_tracks_through_both_switches():
+    """The whole loop at a reduced size: 300 two-room frames, new sub-map behind the door, switch back on the return; the
+    trajectory error stays at the centimetre level and every switch frame is accounted for."""
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the gpu-marked tests must run on the MI355X box")
+    from mipsfusion_amd import sequence
+    from mipsfusion_amd.graph import work_stream
+    dev = torch.device("cuda:0")
+    cfg = _small_two_room_cfg(quick=False)
+    random.seed(0), np.random.seed(0), torch.manual_seed(0)
+    gt, frames, schedule = synth.two_room_sequence(cfg, 300, kf_every=15)
+    assert [ev[0] for _, ev in sorted(schedule.items())] == ["new", "back"]
+    prev = torch.cuda.current_stream(dev)
+    try:
+        seq = sequence.GraphedSequence(cfg, dev, frames, kf_every=15, sampler="device", stream=work_stream(dev), schedule=schedule)
+        res = seq.run(gt)
+    finally:
+        torch.cuda.set_stream(prev)
+    out = sequence.summarise(res, gt, cfg, "graphs")
+    print({k: out[k] for k in ("ms_per_frame_mean", "ms_per_frame_median", "ate_rmse_m", "ate_max_m", "switch_frames")})
+    assert sorted(out["switch_frames"]) == sorted(schedule)
+    new_k, back_k = sorted(schedule)
+    assert out["submap_keyframe_slots"][1] == list(range(new_k // 15, back_k // 15))
+    assert out["ate_rmse_m"] < 0.05 and out["ate_max_m"] < 0.15

@@ -431,3 +431,18 @@ def test_backward_from_one_is_loss_backward():
     for _ in range(2):                                   # second call: the cached root gradient, accumulated grads
         backward_from_one((w2 * x).sin().sum() * 3)
     assert torch.equal(w2.grad, 2 * w1.grad)
+
+
+def test_submap_timeline_follows_the_switch_schedule():
+    """mipsfusion_amd.sequence.submap_timeline: which sub-map is active, and with which keyframe slots, when a frame's local
+    BA runs (the frame's own keyframe / switch comes after its BA, mipsfusion.py:681-712)."""
+    from mipsfusion_amd.sequence import submap_timeline
+    tl = submap_timeline(50, 5, {20: ("new",), 35: ("back", 0)})
+    assert tl[1] == (0, [0]) and tl[5] == (0, [0]) and tl[6] == (0, [0, 1])
+    assert tl[20] == (0, [0, 1, 2, 3])                 # frame 20 is still bundle-adjusted in sub-map 0 ...
+    assert tl[21] == (1, [4]) and tl[26] == (1, [4, 5])    # ... then opens sub-map 1 as its first keyframe
+    assert tl[35] == (1, [4, 5, 6])
+    assert tl[36] == (0, [0, 1, 2, 3, 7])              # back in sub-map 0, the overlapping keyframe joined it
+    assert tl[49] == (0, [0, 1, 2, 3, 7, 8, 9])
+    with pytest.raises(ValueError):
+        submap_timeline(30, 5, {10: ("back", 3)})
