@@ -639,6 +639,55 @@ def multi_gpu_checks(cfg, model, dev, rank, world):
     model.train()
     res = ba.result()
     spread = mdist.exchange_poses(res[:, :3, :3].reshape(world, 9)[:, :4], res[:, :3, 3])   # any 7 numbers per anchor
+    # ---- row 2: ray-data-parallel TRAINING of one replicated sub-map (mipsfusion_amd/ray_dp.py): every rank renders its
+    #      share of the SAME 4096-ray batch; grid gradient reduce-scatter -> Adam on this rank's 1/world slice -> all-gather
+    from mipsfusion_amd.ray_dp import RayDataParallelStep
+    rep, rframes, rposes = build_submap(cfg, dev, seed=0)
+    rep.train()
+    mpc = cfg["mapping"]
+    rdp = RayDataParallelStep(
+        rep, lambda shard: FusedAdam([{"params": [shard], "eps": 1e-15, "lr": mpc["lr_embed"]}], betas=(0.9, 0.99)),
+        lambda ps: FusedAdam([{"params": ps, "weight_decay": 1e-6, "lr": mpc["lr_decoder"]}], betas=(0.9, 0.99)))
+    gq = torch.Generator().manual_seed(77)                      # the same batches on every rank
+    fr = rframes[-1]
+    f7r = torch.cat([fr["direction"], fr["rgb"], fr["depth"][..., None]], -1).reshape(-1, 7)
+    c2w = rposes[-1].to(dev)
+    n_rdp, losses_rdp = 12, []
+    b_, e_ = rdp.my_share(N_RAYS)
+    t_rdp = None
+    for it in range(n_rdp):
+        idx = torch.randint(0, f7r.shape[0], (N_RAYS,), generator=gq)
+        rays = f7r[idx][b_:e_].to(dev)
+        noise = torch.rand(N_RAYS, N_SAMPLES, generator=gq)[b_:e_].to(dev)
+        rays_d = torch.sum(rays[:, None, :3] * c2w[:3, :3], -1)
+        rays_o = c2w[None, :3, 3].repeat(e_ - b_, 1)
+        if it == 2:
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_rdp = time.perf_counter()
+        ret = rep.forward(rays_o, rays_d, rays[:, 3:6].contiguous(), rays[:, 6:7].contiguous(), noise=noise)
+        loss_rdp = get_loss_from_ret(ret, cfg["training"])
+        loss_rdp.backward()
+        rdp.step()
+        losses_rdp.append(float(loss_rdp))
+    torch.cuda.synchronize()
+    ms_rdp = (time.perf_counter() - t_rdp) / (n_rdp - 2) * 1e3
+    chk = torch.stack([rep.embed_fn.params.detach().double().sum(), rep.embed_fn.params.detach().double().abs().sum(),
+                       torch.cat([p.detach().reshape(-1) for p in rep.decoder.parameters()]).double().sum()])
+    sums = [torch.empty_like(chk) for _ in range(world)] if dist.get_backend() != "gloo" else None
+    if sums is None:
+        h = chk.cpu()
+        sums = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(sums, h)
+    else:
+        dist.all_gather(sums, chk)
+    out["ray_dp_training"] = {"ms_per_step": round(mdist.max_over_ranks(ms_rdp, dev), 4), "rays_per_rank": e_ - b_,
+                              "params_equal_over_ranks": bool(all(torch.equal(s.cpu(), sums[0].cpu()) for s in sums)),
+                              "loss_first_last": [round(losses_rdp[0], 5), round(losses_rdp[-1], 5)],
+                              "collectives_per_step": f"reduce_scatter[{rep.embed_fn.params.numel()} floats] + all_gather[same] "
+                                                      f"+ all_reduce[{sum(p.numel() for p in rep.decoder.parameters())} floats]"}
+    del rep, rdp
+    torch.cuda.empty_cache()
     # the two collectives of the sharded paths on their own (latency-bound: K x 7 and (n - 1) x 7 floats), 50 calls each
     def timed_collective(fn, n=50):
         for _ in range(5):

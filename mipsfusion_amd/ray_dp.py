@@ -1,0 +1,156 @@
+"""Ray-batch data parallelism for ONE sub-map: the step mipsfusion.py:320-335 shards.
+
+Every rank holds a replica of the sub-map (grid + decoder) and renders its contiguous share of the iteration's rays; the
+gradients are dense (the hash table's 36 MB, the decoder's 146 KB, the pose parameters' K x 7 floats), so
+
+    grid      reduce-scatter of the flat gradient  ->  every rank runs Adam on ITS 1/world slice of the table
+              (parameters, moments and the 28 B/parameter of Adam traffic divided by world)  ->  all-gather of the updated slices
+    decoder   all-reduce of its ten small gradients, the identical (replicated) Adam step on every rank
+    poses     all-reduce of the pose gradients, identical step on every rank
+
+-- the bytes of one all-reduce, with the optimiser's work and state divided by the world size.  The objective is the MEAN
+of the ranks' objectives (each rank normalises its losses by its own N/world rays and its own front / band counts, as
+``pose_accum_step``-style gradient accumulation over sub-batches does in the reference, mipsfusion.py:327-342).
+
+xGMI is point-to-point: with 8 GPUs a direct schedule moves 7 x 4.5 MB per phase per GPU (~30 us per phase at 153 GB/s per
+link), a ring would be per-link bound at ~0.4 ms -- against ~0.1 ms of per-rank compute for 512 rays x 64 samples.  At the
+headline batch this sharding is communication-bound (SURVEY 8e says so); it pays for large batches (full-image supervision,
+several backward passes accumulated per ``step()``).  UNMEASURED on more than one GPU (no multi-GPU node was
+available to this build); covered by a two-rank gloo test on CPU tensors and a two-process run on one GPU.
+"""
+from typing import Callable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from .dist import all_reduce_sum_, rank_world, share_of
+
+
+def _padded(n: int, world: int) -> int:
+    return (n + world - 1) // world * world
+
+
+class ShardedFlatAdam:
+    """reduce-scatter -> Adam on this rank's slice -> all-gather, for ONE flat fp32 parameter (the hash table).
+
+    param: the replicated flat parameter (a leaf with ``.grad`` accumulated by the caller's backward passes).
+    make_optimizer(shard_param) -> an optimiser with ``step()`` over the 1-D slice parameter it is given (FusedAdam on the
+    GPU: the slice is a VIEW of ``param``'s storage, so the kernel updates the replica in place; torch.optim.Adam in the CPU
+    test).  Gradients arrive as the SUM over ranks divided by world (mean objective)."""
+
+    def __init__(self, param: torch.Tensor, make_optimizer: Callable[[torch.nn.Parameter], torch.optim.Optimizer], group=None):
+        self.group = group
+        self.rank, self.world = rank_world(group)
+        self.param = param
+        n = param.numel()
+        self.n, self.n_pad = n, _padded(n, self.world)
+        self.per = self.n_pad // self.world
+        self.begin = self.rank * self.per
+        self.end = min(n, self.begin + self.per)
+        # the slice this rank owns, as a Parameter sharing the replica's storage (padding lives in a private tail)
+        flat = param.data.view(-1)
+        if self.n_pad == n:
+            self._buf = flat
+        else:       # padded copy: parameters are exchanged through it (one extra copy per step; the table sizes of the
+            self._buf = torch.zeros(self.n_pad, dtype=flat.dtype, device=flat.device)      # reference's configs divide by 8)
+            self._buf[:n].copy_(flat)
+        self.shard = torch.nn.Parameter(self._buf[self.begin:self.begin + self.per])
+        self.shard.grad = torch.zeros_like(self.shard)
+        self._grad_pad = None if self.n_pad == n else torch.zeros(self.n_pad, dtype=flat.dtype, device=flat.device)
+        self.opt = make_optimizer(self.shard)
+
+    def _backend_is_gloo(self):
+        return self.world > 1 and dist.get_backend(self.group) == "gloo"
+
+    @torch.no_grad()
+    def step(self):
+        """Consumes ``param.grad`` (sum of this rank's backward passes since the last step), leaves it zero."""
+        g = self.param.grad.view(-1)
+        if self._grad_pad is not None:
+            self._grad_pad[:self.n].copy_(g)
+            g_full = self._grad_pad
+        else:
+            g_full = g
+        out = self.shard.grad
+        if self.world == 1:
+            out.copy_(g_full[self.begin:self.begin + self.per])
+        elif self._backend_is_gloo():
+            # gloo has no reduce-scatter: all-reduce and keep the slice (CPU tests; a GPU tensor takes a host round trip)
+            h = g_full.detach().cpu() if g_full.is_cuda else g_full.clone()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            out.copy_(h[self.begin:self.begin + self.per])
+        else:
+            dist.reduce_scatter_tensor(out, g_full, op=dist.ReduceOp.SUM, group=self.group)
+        if self.world > 1:
+            out.mul_(1.0 / self.world)
+        self.opt.step()
+        g.zero_()
+        if self.world > 1:
+            if self._backend_is_gloo():
+                mine = self.shard.data.detach().cpu() if self.shard.is_cuda else self.shard.data.clone()
+                parts = [torch.empty_like(mine) for _ in range(self.world)]
+                dist.all_gather(parts, mine, group=self.group)
+                self._buf.copy_(torch.cat(parts).to(self._buf.device))
+            else:
+                dist.all_gather_into_tensor(self._buf, self.shard.data, group=self.group)
+        if self._grad_pad is not None:
+            self.param.data.view(-1).copy_(self._buf[:self.n])
+
+
+class RayDataParallelStep:
+    """The optimiser side of a ray-data-parallel mapping iteration over one replicated ``JointEncoding``:
+
+        rdp = RayDataParallelStep(model, make_grid_opt, make_decoder_opt, pose_params, make_pose_opt)
+        for it in range(iters):
+            rays = my_share(all_rays)                       # ``share_of(N, rank, world)``
+            loss = objective(model.forward(*rays)); loss.backward()
+            rdp.step(pose=(it + 1) % pose_accum_step == 0)
+
+    ``step`` averages the gradients over the ranks (grid: reduce-scatter into this rank's slice; decoder and poses:
+    all-reduce), runs the optimisers, and hands every rank the updated table (all-gather).  All ranks end every step with
+    bit-identical parameters (asserted in the tests)."""
+
+    def __init__(self, model, make_grid_opt, make_decoder_opt, pose_params: Sequence[torch.nn.Parameter] = (),
+                 make_pose_opt: Optional[Callable[[List[torch.nn.Parameter]], torch.optim.Optimizer]] = None, group=None):
+        self.group = group
+        self.rank, self.world = rank_world(group)
+        self.model = model
+        self.grid = ShardedFlatAdam(model.embed_fn.params, make_grid_opt, group)
+        self.dec_params = [p for p in model.decoder.parameters()]
+        self.dec_opt = make_decoder_opt(self.dec_params)
+        self.pose_params = list(pose_params)
+        self.pose_opt = make_pose_opt(self.pose_params) if (self.pose_params and make_pose_opt) else None
+        self._dec_flat = None
+
+    def my_share(self, n: int):
+        return share_of(n, self.rank, self.world)
+
+    @torch.no_grad()
+    def _mean_grads(self, params):
+        """one all-reduce for a list of small gradients (flattened into one buffer: a collective per tensor would be ten
+        latency-bound calls)"""
+        if self.world == 1:
+            return
+        grads = [p.grad for p in params if p.grad is not None]
+        if not grads:
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        all_reduce_sum_(flat, self.group)
+        flat.mul_(1.0 / self.world)
+        off = 0
+        for g in grads:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
+    @torch.no_grad()
+    def step(self, pose: bool = False):
+        if self.model.embed_fn.params.grad is None:
+            raise RuntimeError("RayDataParallelStep.step() needs a backward pass first (the table has no gradient)")
+        self.grid.step()
+        self._mean_grads(self.dec_params)
+        self.dec_opt.step()
+        torch._foreach_zero_([p.grad for p in self.dec_params if p.grad is not None])
+        if pose and self.pose_opt is not None:
+            self._mean_grads(self.pose_params)
+            self.pose_opt.step()
+            torch._foreach_zero_([p.grad for p in self.pose_params if p.grad is not None])

@@ -2,6 +2,7 @@
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -169,3 +170,96 @@ def test_sharded_global_ba_world2_equals_single_process_and_oracle():
         assert torch.allclose(torch.tensor(trace), torch.tensor(ref_trace), rtol=1e-5), f"rank {rank} loss trace"
         assert torch.equal(torch.from_numpy(full), torch.arange(88, dtype=torch.float32).reshape(11, 8))
     assert (res[0][1] == res[1][1]).all(), "every rank must hold bit-identical anchors (same all-reduced gradient)"
+
+
+# ------------------------------------------------------------------------ ray-data-parallel training
+class _ToyScene(torch.nn.Module):
+    """the two parameter families of a sub-map: one flat table (embed_fn.params) and a few small decoder tensors"""
+
+    def __init__(self, n_table):
+        super().__init__()
+        g = torch.Generator().manual_seed(5)
+        self.embed_fn = torch.nn.Module()
+        self.embed_fn.params = torch.nn.Parameter(torch.randn(n_table, generator=g) * 0.1)
+        self.decoder = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.Linear(4, 2))
+        with torch.no_grad():
+            for p in self.decoder.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+
+    def objective(self, x):          # x [n, 3]: a per-ray loss, MEAN over the rays given
+        feat = self.embed_fn.params[(x[:, 0].abs() * 1000).long() % self.embed_fn.params.numel()]
+        return ((self.decoder(x) * feat[:, None]).pow(2).sum(-1) + feat.pow(2)).mean()
+
+
+def _toy_optimisers():
+    return (lambda shard: torch.optim.Adam([shard], lr=0.01, betas=(0.9, 0.99), eps=1e-15),
+            lambda ps: torch.optim.Adam(ps, lr=0.01, betas=(0.9, 0.99), weight_decay=1e-6),
+            lambda ps: torch.optim.Adam(ps, lr=1e-3))
+
+
+def _ray_dp_worker(rank, world, port, q, n_table):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mipsfusion_amd.ray_dp import RayDataParallelStep
+        torch.manual_seed(0)
+        m = _ToyScene(n_table)
+        pose = torch.nn.Parameter(torch.tensor([0.1, -0.2, 0.3]))
+        g_opt, d_opt, p_opt = _toy_optimisers()
+        rdp = RayDataParallelStep(m, g_opt, d_opt, [pose], p_opt)
+        gen = torch.Generator().manual_seed(9)
+        for it in range(4):
+            x = torch.randn(10, 3, generator=gen)                 # the SAME batch on every rank ...
+            b, e = rdp.my_share(10)                               # ... of which each renders its share
+            (m.objective(x[b:e] + pose)).backward()
+            rdp.step(pose=(it + 1) % 2 == 0)
+        q.put((rank, m.embed_fn.params.detach().numpy().copy(), [p.detach().numpy().copy() for p in m.decoder.parameters()],
+               pose.detach().numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_table", [12, 11])
+def test_ray_data_parallel_step_world2_equals_mean_gradient_adam(n_table):
+    """reduce-scatter -> sharded Adam -> all-gather over two gloo ranks: both ranks end with bit-identical parameters, equal
+    to ONE process that averages the two shares' gradients and runs the plain optimisers (n_table 11: the padded path)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ray_dp_worker, args=(r, world, port, q, n_table)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, t0, d0, p0), (_, t1, d1, p1) = res
+    assert (t0 == t1).all() and all((a == b).all() for a, b in zip(d0, d1)) and (p0 == p1).all(), "ranks diverged"
+    # one process, table and decoder only (the pose of the single-process run accumulates differently by construction)
+    torch.manual_seed(0)
+    m = _ToyScene(n_table)
+    pose = torch.nn.Parameter(torch.tensor([0.1, -0.2, 0.3]))
+    g_opt, d_opt, p_opt = _toy_optimisers()
+    og, od, op_ = g_opt(m.embed_fn.params), d_opt(list(m.decoder.parameters())), p_opt([pose])
+    gen = torch.Generator().manual_seed(9)
+    for it in range(4):
+        x = torch.randn(10, 3, generator=gen)
+        params = [m.embed_fn.params] + list(m.decoder.parameters()) + [pose]
+        total = None
+        for r in range(world):
+            b, e = mdist.share_of(10, r, world)
+            gs = torch.autograd.grad(m.objective(x[b:e] + pose), params)
+            total = list(gs) if total is None else [a + g for a, g in zip(total, gs)]
+        for p, g in zip(params[:-1], total[:-1]):
+            p.grad = g * (1.0 / world)
+        pose.grad = total[-1] * (1.0 / world) if pose.grad is None else pose.grad + total[-1] * (1.0 / world)
+        og.step(), od.step()
+        if (it + 1) % 2 == 0:
+            op_.step()
+            pose.grad = None
+    import numpy as np
+    np.testing.assert_allclose(t0, m.embed_fn.params.detach().numpy(), rtol=0, atol=1e-7)
+    for a, b in zip(d0, m.decoder.parameters()):
+        np.testing.assert_allclose(a, b.detach().numpy(), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(p0, pose.detach().numpy(), rtol=0, atol=1e-7)

@@ -365,3 +365,8 @@ def test_two_process_run_exercises_every_sharding(dev):
     assert mg["ro_split_pose_equals_unsplit"] is True
     assert mg["ro_particles_per_rank"] == 1000
     assert mg["global_ba_anchor_spread_over_ranks"] == 0.0 and mg["global_ba_anchors_moved"] is True
+    # ray-data-parallel training: both ranks render half the batch, reduce-scatter / sharded Adam / all-gather
+    rdp = mg["ray_dp_training"]
+    assert rdp["params_equal_over_ranks"] is True and rdp["rays_per_rank"] == 2048
+    assert rdp["loss_first_last"][1] < rdp["loss_first_last"][0]
+    assert mg["pose_all_gather_ms"] > 0 and mg["pose_grad_all_reduce_ms"] > 0 and len(mg["ms_per_step_of_each_rank"]) == 2
