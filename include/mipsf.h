@@ -85,6 +85,14 @@ int mipsf_hashgrid_dx_from_jac(const float* jac, const float* dout, float* dx, u
 uint64_t mipsf_hashgrid_bwd_scratch_floats(const mipsf_grid_meta* meta_host, uint32_t M, int need_dx);
 int mipsf_hashgrid_bwd(const float* x, const float* params, const float* dout, float* dparams, float* dx,
                        float* scratch, uint32_t M, const mipsf_grid_meta* meta_host, int layout, void* stream);
+/* The same with a small counter block the CALLER keeps between calls (mipsf_hashgrid_counter_words(meta) uint32 words,
+ * all zero before the first call; every call leaves it ready for the next one): one launch fewer -- the routed scatter is
+ * then three launches (route, accumulate, fold of split bins).  One block per stream: calls that share a block must be
+ * ordered. */
+uint64_t mipsf_hashgrid_counter_words(const mipsf_grid_meta* meta_host);
+int mipsf_hashgrid_bwd_keep(const float* x, const float* params, const float* dout, float* dparams, float* dx,
+                            float* scratch, uint32_t* counters, uint32_t M, const mipsf_grid_meta* meta_host, int feat_layout,
+                            void* stream);
 /* The same in two halves.  The routing of the scatter (which table slices every sample touches: a third of the
  * backward's time) depends on x only: mipsf_hashgrid_route may run as soon as x exists -- e.g. on a second stream next
  * to the forward pass -- into the same scratch buffer, and mipsf_hashgrid_bwd_routed then does the rest. */

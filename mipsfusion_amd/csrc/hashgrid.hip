@@ -190,7 +190,7 @@ __global__ __launch_bounds__(HG_BLOCK) void hashgrid_fwd_kernel(const float* __r
 // dL/dparams is a scatter of 16 floats per (sample, level).  Global fp32 atomics top out at ~18 G atomics/s on
 // MI355X whatever the access pattern (measured: 4.0 ms for the 67 M atomics of a 4096x64 batch), so the scatter
 // target is moved ON CHIP: the 256 CUs own 40 MiB of LDS.
-//   * a level that fits 10240 entries (160 KiB of fp64 pairs) is one slice, a larger one is cut into 8192-entry
+//   * a level that fits 8192 entries (128 KiB of fp64 pairs) is one slice, a larger one is cut into 8192-entry
 //     slices (power of two: slice = index >> 13) -- one "bin" per slice;
 //   * ROUTE: every (sample, level) is sent to the bins its 8 corners fall into (a record is the sample index,
 //     duplicates inside a bin are merged, so a bin holds at most M records and gets a fixed M-record region of
@@ -205,9 +205,11 @@ __global__ __launch_bounds__(HG_BLOCK) void hashgrid_fwd_kernel(const float* __r
 //     partial slices and a reduce kernel.  No global float atomics, no inter-workgroup communication.
 constexpr int SC_BLOCK = 1024;
 #ifndef MIPSF_SC_MAX_SLICE
-#define MIPSF_SC_MAX_SLICE 10240
+#define MIPSF_SC_MAX_SLICE 8192
 #endif
-constexpr uint32_t SC_MAX_SLICE = MIPSF_SC_MAX_SLICE;   // entries: 10240 * 2 doubles = 163840 B = all of a CU's LDS
+// entries of the largest one-slice level: 8192 * 2 doubles = 128 KB of the CU's 160 KB of LDS (the persistent accumulate
+// kernel keeps the bin counts, 32 KB for the 8192 bins of a 2^22 table, next to the slice)
+constexpr uint32_t SC_MAX_SLICE = MIPSF_SC_MAX_SLICE;
 #ifndef MIPSF_SC_SLICE_LOG2
 #define MIPSF_SC_SLICE_LOG2 13
 #endif
@@ -216,7 +218,7 @@ constexpr uint32_t SC_SLICE_LOG2 = MIPSF_SC_SLICE_LOG2;   // slices of multi-sli
 #define MIPSF_SC_PART 24576
 #endif
 #ifndef MIPSF_SC_PART_DENSE
-#define MIPSF_SC_PART_DENSE 12288
+#define MIPSF_SC_PART_DENSE 8192
 #endif
 #ifndef MIPSF_SC_RUN
 #define MIPSF_SC_RUN 4
@@ -286,7 +288,7 @@ static ScatterPlan make_plan(const GridLevels& g, uint32_t M) {
     p.w_first = (uint32_t)w, w += bins;
     p.w_parts = (uint32_t)w, w += bins;
     w = (w + 3) / 4 * 4;
-    p.w_items = (uint32_t)w, w += 4ull * p.max_items;       // {bin | part << 16, records of the bin, parts of the bin, -}
+    p.w_items = (uint32_t)w;                                // end of the counter block {counts | head, tickets | first | parts}
     w = (w + 15) / 16 * 16;
     p.w_records = w, w += (uint64_t)bins * M;
     w = (w + 15) / 16 * 16;
@@ -397,7 +399,8 @@ __device__ __forceinline__ bool route_groups_hashed_pow2(const Cell& cell, uint3
 template <int LAYOUT>
 __global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __restrict__ x,
                                                                 const float* __restrict__ dout, uint32_t M, GridLevels g,
-                                                                ScatterPlan plan, uint32_t* __restrict__ ws) {
+                                                                ScatterPlan plan, uint32_t* __restrict__ ws,
+                                                                uint32_t* __restrict__ cw) {
     __shared__ uint32_t cnt[SC_MAX_NS];
     __shared__ uint32_t base[SC_MAX_NS];
 #ifndef MIPSF_SC_STAGE
@@ -406,7 +409,14 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __
     // Records are collected bin by bin in LDS and leave as runs of consecutive words: a lane-per-record store sends 64
     // four-byte writes to 64 different lines (the bins of the 64 lanes), 10 M of them per launch -- half of this kernel's
     // time (ablation, tools/micro/route_probe.py: 52 us, 28 without the stores, 21 with a coalesced stand-in).
-    constexpr uint32_t STAGE_CAP = 4 * SC_BLOCK * SC_ROUTE_UNR;     // typical: <= 4 records per sample; more go direct
+#ifndef MIPSF_SC_STAGE_CAP
+#define MIPSF_SC_STAGE_CAP 10240
+#endif
+    // Records beyond the staging capacity go straight to their bins (lane-per-record stores).  A workgroup's 4096 samples
+    // make <= 4 records each on most levels; with the dead half of a mapping batch skipped that is ~8000 records, and
+    // 10240 words keep the kernel's LDS at 62 KB = two workgroups per CU, whose barrier- and round-trip-separated phases
+    // then overlap (16384 words, one workgroup per CU: +4 us on the headline step; 8192: -1 us but overflows there)
+    constexpr uint32_t STAGE_CAP = MIPSF_SC_STAGE_CAP;
     __shared__ uint32_t lstart[SC_MAX_NS];
     __shared__ uint32_t stage[MIPSF_SC_STAGE ? STAGE_CAP : 1];
     const uint32_t level = blockIdx.x % plan.n_levels;
@@ -511,7 +521,7 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __
     }
     __syncthreads();
     for (uint32_t q = threadIdx.x; q < ns; q += SC_BLOCK)
-        base[q] = cnt[q] ? atomicAdd(&ws[plan.w_count + bin0 + q], cnt[q]) : 0u;
+        base[q] = cnt[q] ? atomicAdd(&cw[plan.w_count + bin0 + q], cnt[q]) : 0u;
     if (MIPSF_SC_STAGE && threadIdx.x < 64) {       // exclusive prefix of the bin counts: where a bin starts in `stage`
         constexpr uint32_t PER = SC_MAX_NS / 64;
         uint32_t c[PER], sum = 0;
@@ -576,73 +586,15 @@ __device__ __forceinline__ uint32_t part_of(const ScatterPlan& plan, uint32_t bi
     return bin < plan.dense_bins ? SC_PART_DENSE : SC_PART;
 }
 
-// one workgroup: the (bin, part) work-item table from the bin counts
-__global__ __launch_bounds__(1024) void scatter_scan_kernel(ScatterPlan plan, uint32_t* __restrict__ ws) {
-    __shared__ uint32_t sitm[1024];
-    constexpr uint32_t PER = SC_MAX_BINS / 1024;
-    const uint32_t t = threadIdx.x;
-    uint32_t cnt[PER], litm = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < PER; ++k) {
-        const uint32_t b = t * PER + k;
-        cnt[k] = b < plan.n_bins ? ws[plan.w_count + b] : 0u;
-        litm += (cnt[k] + part_of(plan, b) - 1) / part_of(plan, b);
-    }
-    // inclusive prefix over the 1024 threads: within the wave by shuffles, across the 16 waves through 16 words of LDS
-    // (the 10-step scan through LDS it replaces spent 20 barriers on it: a third of this one-workgroup kernel)
-    {
-        __shared__ uint32_t wtot[16];
-        uint32_t incl = litm;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t v = (uint32_t)__shfl_up((int)incl, d, 64);
-            incl += (int)(t & 63u) >= d ? v : 0u;
-        }
-        if ((t & 63u) == 63u) wtot[t >> 6] = incl;
-        __syncthreads();
-        uint32_t before = 0;
-        for (uint32_t q = 0; q < (t >> 6); ++q) before += wtot[q];
-        sitm[t] = before + incl;
-        __syncthreads();
-    }
-    uint32_t oitm = sitm[t] - litm;
-    if (t == 1023) ws[plan.w_nitems] = sitm[t];
-    // One 16-byte descriptor per work item, and an "unused" mark on the rest of the table: an accumulate workgroup
-    // starts with ONE load instead of four dependent ones (item count, item, records of the bin, parts of the bin:
-    // ~2 us of a 30 us item).
-    uint4* items = reinterpret_cast<uint4*>(ws + plan.w_items);
-#pragma unroll
-    for (uint32_t k = 0; k < PER; ++k) {
-        const uint32_t b = t * PER + k;
-        if (b < plan.n_bins) {
-            const uint32_t parts = (cnt[k] + part_of(plan, b) - 1) / part_of(plan, b);
-            ws[plan.w_first + b] = oitm;
-            ws[plan.w_parts + b] = parts;
-            for (uint32_t q = 0; q < parts; ++q) items[oitm + q] = make_uint4(b | (q << 16), cnt[k], parts, 0u);
-            oitm += parts;
-        }
-    }
-    for (uint32_t i = sitm[1023] + t; i < plan.max_items; i += 1024) items[i] = make_uint4(0xffffffffu, 0u, 0u, 0u);
-}
-
+// One work item = (bin, part of its records): the slice's gradient is accumulated in LDS (fp64) and added to dparams (the
+// bin's only part) or left as a partial slice for the reduce kernel.  desc = {bin | part << 16, records of the bin, parts of
+// the bin}, item_index = position in the item order (names the partial slice).
 template <int LAYOUT>
-__global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float* __restrict__ x,
-                                                                   const float* __restrict__ dout,
-                                                                   float* __restrict__ dparams, uint32_t M,
-                                                                   GridLevels g, ScatterPlan plan,
-                                                                   uint32_t* __restrict__ ws) {
-    extern __shared__ __attribute__((aligned(16))) double acc[];   // [slice entries][2]
-#ifdef MIPSF_SC_TRACE    // tools/probe_scatter_trace.py: (item, records, begin, end in 10 ns ticks, XCC, HW_ID) per workgroup
-    const uint64_t trace_t0 = wall_clock64();
-#endif
-    const uint4 desc = reinterpret_cast<const uint4*>(ws + plan.w_items)[blockIdx.x];
-    // the slice is cleared while the descriptor is on its way (all of the LDS: the level is not known yet)
-    {
-        double2* z = reinterpret_cast<double2*>(acc);
-        for (uint32_t e = threadIdx.x; e < plan.max_slice; e += SC_BLOCK) z[e] = make_double2(0.0, 0.0);
-    }
+__device__ __forceinline__ void scatter_item(const float* __restrict__ x, const float* __restrict__ dout,
+                                             float* __restrict__ dparams, uint32_t M, const GridLevels& g,
+                                             const ScatterPlan& plan, uint32_t* __restrict__ ws, double* __restrict__ acc,
+                                             const uint4 desc, const uint32_t item_index) {
     const uint32_t item = desc.x;
-    if (item == 0xffffffffu) return;
     const uint32_t bin = item & 0xffffu, part = item >> 16;
     const bool single = desc.z == 1u;             // the bin's only work item: its slice goes straight into dparams
     uint32_t level = 0;
@@ -662,6 +614,10 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
 
     // ... and the current gradient values of the slice are requested now: by the time the records are through they have
     // arrived (they used to cost a memory round trip behind the last barrier, 3 us per item)
+    {   // the slice is cleared (only the entries of this level's slice: the fixed cost of an item used to include all 160 KB)
+        double2* z = reinterpret_cast<double2*>(acc);
+        for (uint32_t e = threadIdx.x; e < count; e += SC_BLOCK) z[e] = make_double2(0.0, 0.0);
+    }
     float2* dst = reinterpret_cast<float2*>(dparams) + off + begin;
     constexpr uint32_t FL = SC_MAX_SLICE / SC_BLOCK;
     float2 cur[FL];
@@ -673,11 +629,6 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
         }
     }
     __syncthreads();
-#ifdef MIPSF_SC_TRACE
-    const uint64_t trace_t_zero = wall_clock64();
-    uint32_t trace_iter[6] = {0, 0, 0, 0, 0, 0};
-    uint32_t trace_k = 0;
-#endif
 
     const int mode = level_mode(res, size);
     const bool masked = M <= SC_MASKED_MAX_M;      // records carry the corner mask of scatter_route_kernel
@@ -781,9 +732,6 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
                     atomicAdd(&acc[2 * e + 1], (double)(wgt * gy.y));
                 }
             }
-#ifdef MIPSF_SC_TRACE
-            if (trace_k < 6) trace_iter[trace_k++] = (uint32_t)(wall_clock64() - trace_t0);
-#endif
         }
     } else {
     constexpr int UNR = (int)SC_RUN;   // independent record -> x chains in flight per thread
@@ -837,18 +785,9 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
         }
         if (open) flush();
         open = false;
-#ifdef MIPSF_SC_TRACE
-        if (trace_k < 6) trace_iter[trace_k++] = (uint32_t)(wall_clock64() - trace_t0);
-#endif
     }
     }
-#ifdef MIPSF_SC_TRACE
-    const uint64_t trace_t_loop = wall_clock64();
-#endif
     __syncthreads();
-#ifdef MIPSF_SC_TRACE
-    const uint64_t trace_t_sync = wall_clock64();
-#endif
 
     const double2* a2 = reinterpret_cast<const double2*>(acc);
     if (single) {
@@ -859,30 +798,131 @@ __global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_kernel(const float*
         }
     } else {
         float2* pdst = reinterpret_cast<float2*>(reinterpret_cast<float*>(ws) + plan.w_partial) +
-                       (size_t)blockIdx.x * SC_MAX_SLICE;
+                       (size_t)item_index * SC_MAX_SLICE;
         for (uint32_t e = threadIdx.x; e < count; e += SC_BLOCK) pdst[e] = make_float2((float)a2[e].x, (float)a2[e].y);
     }
-#ifdef MIPSF_SC_TRACE
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint64_t t1 = wall_clock64();
-        uint32_t* tr = ws + plan.w_end + 64 + 16 * (size_t)blockIdx.x;
-        tr[0] = item, tr[1] = n_rec, tr[2] = (uint32_t)trace_t0, tr[3] = (uint32_t)(trace_t0 >> 32);
-        tr[4] = (uint32_t)t1, tr[5] = (uint32_t)(t1 >> 32);
-        tr[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20), tr[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-        tr[8] = (uint32_t)(trace_t_zero - trace_t0), tr[9] = (uint32_t)(trace_t_loop - trace_t0);
-        tr[10] = (uint32_t)(trace_t_sync - trace_t0);
-        for (int k = 0; k < 5; ++k) tr[11 + k] = trace_iter[k];
+}
+
+
+// PERSISTENT accumulate kernel: one workgroup per CU (the fp64 slice fills most of a CU's LDS) that
+//   (1) builds the work-item order from the bin counts itself -- every workgroup runs the same 1024-thread prefix scan and
+//       keeps its share of it in registers (thread t: the counts of bins 8 t .. 8 t + 7 and the index of their first item);
+//       this used to be a one-workgroup kernel of its own (7 us + a launch gap) in front of a grid of max_items workgroups,
+//       most of which found an "unused" mark, cleared 160 KB of LDS for nothing and left;
+//   (2) pulls items from ONE device-scope counter (dense levels first: the long items lead, as in LPT scheduling) until the
+//       order is exhausted -- no static assignment of items to workgroups, the tail is as short as the last item.
+// cw = the small counter block: {bin counts | head, ticket A, ticket B, - | first item of every bin | parts of every bin}.
+// On entry the counts are the routing kernel's and head / tickets are zero; on exit everything but first / parts is zero
+// again (those two are rewritten for EVERY bin by every call), so a caller that keeps the block between calls never
+// launches a clearing kernel.  Nobody waits for a ticket: the LAST workgroup through a point does the clearing --
+//   ticket A (after the prologue: every workgroup has read the counts)   -> the counts are cleared,
+//   ticket B (after the loop: every workgroup has made its last pull)    -> head and both tickets are cleared.
+template <int LAYOUT>
+__global__ __launch_bounds__(SC_BLOCK) void hashgrid_scatter_persist_kernel(const float* __restrict__ x,
+                                                                           const float* __restrict__ dout,
+                                                                           float* __restrict__ dparams, uint32_t M,
+                                                                           GridLevels g, ScatterPlan plan,
+                                                                           uint32_t* __restrict__ ws,
+                                                                           uint32_t* __restrict__ cw) {
+    extern __shared__ __attribute__((aligned(16))) double acc[];   // [slice entries][2], then the bin counts
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t sh_total, sh_next;
+    __shared__ uint4 sh_desc;
+    constexpr uint32_t PER = SC_MAX_BINS / SC_BLOCK;
+    const uint32_t t = threadIdx.x;
+    // the counts of this thread's bins stay in LDS behind the slice (in registers they cost 8 VGPRs of the 128 a
+    // 1024-thread workgroup has: the item loop spilled)
+    uint32_t* scnt = reinterpret_cast<uint32_t*>(acc + 2 * (size_t)plan.max_slice);
+    uint32_t litm = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+        const uint32_t b = t * PER + k;
+        const uint32_t c = b < plan.n_bins ? cw[plan.w_count + b] : 0u;
+        if (b < plan.n_bins) scnt[b] = c;
+        litm += (c + part_of(plan, b) - 1) / part_of(plan, b);
     }
+    uint32_t oitm;                               // index of the first item of this thread's bins
+    {
+        uint32_t incl = litm;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, d, 64);
+            incl += (int)(t & 63u) >= d ? v : 0u;
+        }
+        if ((t & 63u) == 63u) wtot[t >> 6] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t q = 0; q < (t >> 6); ++q) before += wtot[q];
+        oitm = before + incl - litm;
+        if (t == SC_BLOCK - 1) sh_total = before + incl;
+    }
+    {   // where every bin's partial slices start, for the reduce kernel (all workgroups write the same values)
+        uint32_t first = oitm;
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t b = t * PER + k;
+            if (b >= plan.n_bins) break;
+            const uint32_t parts = (scnt[b] + part_of(plan, b) - 1) / part_of(plan, b);
+            cw[plan.w_first + b] = first, cw[plan.w_parts + b] = parts;
+            first += parts;
+        }
+    }
+    __syncthreads();                             // (sh_total; and every count of this workgroup has been read and used)
+    const uint32_t total = sh_total;
+    if (t == 0) sh_next = __hip_atomic_fetch_add(&cw[plan.w_nitems + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (sh_next == gridDim.x - 1) {              // ticket A: the last workgroup past the prologue clears the counts
+        for (uint32_t b = t; b < plan.n_bins; b += SC_BLOCK) cw[plan.w_count + b] = 0u;
+    }
+    for (;;) {
+        __syncthreads();                         // (sh_next / sh_desc / the slice are free again)
+        if (t == 0) sh_next = __hip_atomic_fetch_add(&cw[plan.w_nitems], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const uint32_t i = sh_next;
+        if (i >= total) break;
+        if (i >= oitm && i < oitm + litm) {      // exactly one thread owns item i: it names the bin and the part
+            uint32_t first = oitm;
+            for (uint32_t k = 0; k < PER; ++k) {
+                const uint32_t b = t * PER + k;
+                if (b >= plan.n_bins) break;
+                const uint32_t c = scnt[b];
+                const uint32_t parts = (c + part_of(plan, b) - 1) / part_of(plan, b);
+                if (i >= first && i < first + parts) sh_desc = make_uint4(b | ((i - first) << 16), c, parts, 0u);
+                first += parts;
+            }
+        }
+        __syncthreads();
+        const uint4 desc = sh_desc;
+#ifdef MIPSF_SC_TRACE    // tools/probe_scatter_trace.py: one row per item {item, bin | part << 16, records, begin, end (10 ns ticks), XCC, workgroup}
+        const uint64_t tr_t0 = wall_clock64();
 #endif
+        scatter_item<LAYOUT>(x, dout, dparams, M, g, plan, ws, acc, desc, i);
+#ifdef MIPSF_SC_TRACE
+        __syncthreads();
+        if (t == 0) {
+            const uint64_t tr_t1 = wall_clock64();
+            uint32_t* tr = ws + plan.w_end + 64 + 8 * (size_t)i;
+            tr[0] = i, tr[1] = desc.x, tr[2] = desc.y, tr[3] = (uint32_t)tr_t0, tr[4] = (uint32_t)tr_t1;
+            tr[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20), tr[6] = blockIdx.x, tr[7] = desc.z;
+            if (i == 0) ws[plan.w_end + 63] = total;
+        }
+#endif
+    }
+    __syncthreads();
+    if (t == 0) {                                // ticket B: the last workgroup out resets the queue for the next call
+        if (__hip_atomic_fetch_add(&cw[plan.w_nitems + 2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+            __hip_atomic_store(&cw[plan.w_nitems], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&cw[plan.w_nitems + 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&cw[plan.w_nitems + 2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // folds the partial slices of bins that were split over several workgroups into dparams
 __global__ __launch_bounds__(256) void hashgrid_scatter_reduce_kernel(float* __restrict__ dparams, GridLevels g,
-                                                                      ScatterPlan plan,
-                                                                      const uint32_t* __restrict__ ws) {
+                                                                      ScatterPlan plan, const uint32_t* __restrict__ ws,
+                                                                      const uint32_t* __restrict__ cw) {
     const uint32_t bin = blockIdx.x;
-    const uint32_t parts = ws[plan.w_parts + bin];
+    const uint32_t parts = cw[plan.w_parts + bin];
     if (parts <= 1) return;
     uint32_t level = 0;
     while (level + 1 < plan.n_levels && bin >= plan.bin0[level + 1]) ++level;
@@ -893,7 +933,7 @@ __global__ __launch_bounds__(256) void hashgrid_scatter_reduce_kernel(float* __r
     const uint32_t e = blockIdx.y * 256 + threadIdx.x;
     if (e >= count) return;
     const float2* p2 = reinterpret_cast<const float2*>(reinterpret_cast<const float*>(ws) + plan.w_partial) +
-                       (size_t)ws[plan.w_first + bin] * SC_MAX_SLICE + e;
+                       (size_t)cw[plan.w_first + bin] * SC_MAX_SLICE + e;
     float2* d = reinterpret_cast<float2*>(dparams) + g.offsets[level] + begin + e;
     float2 cur = *d;
     // eight partial slices in flight (a load per iteration was one memory round trip per part: 11 parts on the coarsest
@@ -1086,13 +1126,13 @@ uint64_t mipsf_hashgrid_bwd_scratch_floats(const mipsf_grid_meta* meta, uint32_t
     if (to_levels(meta, g)) return 0;
     const ScatterPlan p = make_plan(g, M);
 #ifdef MIPSF_SC_TRACE
-    return p.w_end + 64 + 16ull * p.max_items + 64;
+    return p.w_end + 64 + 8ull * p.max_items + 64;
 #endif
     return p.w_end + (need_dx ? (uint64_t)g.n_levels * M * 3 : 0) + 64;
 }
 
 #ifdef MIPSF_SC_TRACE
-// word offset of the trace rows and their number (diagnosis builds only)
+// word offset of the trace rows, their capacity and the first bin of every level (diagnosis builds only)
 uint64_t mipsf_hashgrid_trace_words(const mipsf_grid_meta* meta, uint32_t M, uint32_t* n_rows, uint32_t* bin0) {
     GridLevels g;
     if (to_levels(meta, g)) return 0;
@@ -1103,6 +1143,7 @@ uint64_t mipsf_hashgrid_trace_words(const mipsf_grid_meta* meta, uint32_t M, uin
 }
 #endif
 
+
 static int check_plan(const ScatterPlan& plan, const GridLevels& g, uint32_t M) {
     MIPSF_REQUIRE(plan.n_bins <= SC_MAX_BINS && plan.n_bins <= 0xffffu, "grid too large: %u table slices", plan.n_bins);
     for (uint32_t l = 0; l < g.n_levels; ++l)
@@ -1112,16 +1153,19 @@ static int check_plan(const ScatterPlan& plan, const GridLevels& g, uint32_t M) 
     return 0;
 }
 
-static int launch_route(const float* x, const float* dout, int layout, uint32_t* ws, uint32_t M, const GridLevels& g,
-                        const ScatterPlan& plan, hipStream_t s) {
-    const uint32_t nz = plan.w_nitems + 4;   // bin counts, item count
-    hipLaunchKernelGGL(scatter_zero_kernel, dim3((nz + 255) / 256), dim3(256), 0, s, ws, nz);
+// cw: the counter block; `clear`: it lives in caller scratch of unknown content (one more launch), else the caller keeps
+// it between calls and every call leaves it ready (hashgrid_scatter_persist_kernel)
+static int launch_route(const float* x, const float* dout, int layout, uint32_t* ws, uint32_t* cw, bool clear, uint32_t M,
+                        const GridLevels& g, const ScatterPlan& plan, hipStream_t s) {
+    if (clear) {
+        const uint32_t nz = plan.w_nitems + 4;   // bin counts, queue head, tickets
+        hipLaunchKernelGGL(scatter_zero_kernel, dim3((nz + 255) / 256), dim3(256), 0, s, cw, nz);
+    }
     const uint32_t rb = g.n_levels * ((M + SC_BLOCK * SC_ROUTE_UNR - 1) / (SC_BLOCK * SC_ROUTE_UNR));
     if (layout == MIPSF_FEAT_AOS)
-        hipLaunchKernelGGL(scatter_route_kernel<MIPSF_FEAT_AOS>, dim3(rb), dim3(SC_BLOCK), 0, s, x, dout, M, g, plan, ws);
+        hipLaunchKernelGGL(scatter_route_kernel<MIPSF_FEAT_AOS>, dim3(rb), dim3(SC_BLOCK), 0, s, x, dout, M, g, plan, ws, cw);
     else
-        hipLaunchKernelGGL(scatter_route_kernel<MIPSF_FEAT_LEVEL_MAJOR>, dim3(rb), dim3(SC_BLOCK), 0, s, x, dout, M, g, plan, ws);
-    hipLaunchKernelGGL(scatter_scan_kernel, dim3(1), dim3(1024), 0, s, plan, ws);
+        hipLaunchKernelGGL(scatter_route_kernel<MIPSF_FEAT_LEVEL_MAJOR>, dim3(rb), dim3(SC_BLOCK), 0, s, x, dout, M, g, plan, ws, cw);
     return check_launch("hashgrid_route");
 }
 
@@ -1134,12 +1178,19 @@ int mipsf_hashgrid_route(const float* x, float* scratch, uint32_t M, const mipsf
     MIPSF_REQUIRE(x && scratch, "null pointer");
     const ScatterPlan plan = make_plan(g, M);
     if (int rc = check_plan(plan, g, M)) return rc;
-    return launch_route(x, nullptr, MIPSF_FEAT_AOS, reinterpret_cast<uint32_t*>(scratch), M, g, plan, (hipStream_t)stream);
+    uint32_t* ws = reinterpret_cast<uint32_t*>(scratch);
+    return launch_route(x, nullptr, MIPSF_FEAT_AOS, ws, ws, true, M, g, plan, (hipStream_t)stream);
+}
+
+uint64_t mipsf_hashgrid_counter_words(const mipsf_grid_meta* meta) {
+    GridLevels g;
+    if (to_levels(meta, g)) return 0;
+    return make_plan(g, 1).w_items;              // {counts | head, tickets | first | parts}: independent of the batch size
 }
 
 static int hashgrid_bwd_impl(const float* x, const float* params, const float* dout, float* dparams, float* dx,
-                             float* scratch, uint32_t M, const mipsf_grid_meta* meta, int layout, bool routed,
-                             void* stream) {
+                             float* scratch, uint32_t* counters, uint32_t M, const mipsf_grid_meta* meta, int layout,
+                             bool routed, void* stream) {
     GridLevels g;
     if (int rc = to_levels(meta, g)) return rc;
     if (M == 0) return 0;
@@ -1150,33 +1201,36 @@ static int hashgrid_bwd_impl(const float* x, const float* params, const float* d
     const ScatterPlan plan = make_plan(g, M);
     if (int rc = check_plan(plan, g, M)) return rc;
     uint32_t* ws = reinterpret_cast<uint32_t*>(scratch);
+    uint32_t* cw = counters ? counters : ws;     // (without a kept block the counters sit at the front of the scratch)
     float* dxl = scratch + ((plan.w_end + 15) / 16) * 16;
     if (dparams) {   // a frozen grid (tracking) skips the scatter altogether
         if (!routed)
-            if (int e = launch_route(x, MIPSF_SC_SKIP_ZERO ? dout : nullptr, layout, ws, M, g, plan, s)) return e;
-        uint32_t max_slice = 0;
-        for (uint32_t l = 0; l < g.n_levels; ++l) max_slice = plan.slice_entries[l] > max_slice ? plan.slice_entries[l] : max_slice;
-        const uint32_t lds_bytes = max_slice * 16;
+            if (int e = launch_route(x, MIPSF_SC_SKIP_ZERO ? dout : nullptr, layout, ws, cw, counters == nullptr, M, g, plan, s)) return e;
+        const uint32_t lds_bytes = plan.max_slice * 16 + plan.n_bins * 4;      // the slice + the bin counts
+        const int cus = device_cus();
+        if (cus <= 0) return 3;
+        // one workgroup per CU (its slice fills most of the CU's LDS), never more than there can be items
+        const uint32_t blocks = plan.max_items < (uint32_t)cus ? plan.max_items : (uint32_t)cus;
 #define SCATTER(LAY)                                                                                             \
     do {                                                                                                         \
         static uint32_t attr_bytes_dev[MAX_DEVICES] = {0};                                                       \
         uint32_t& attr_bytes = attr_bytes_dev[device_slot()];                                                    \
         if (lds_bytes > attr_bytes) {                                                                            \
-            if (hipFuncSetAttribute((const void*)hashgrid_scatter_kernel<LAY>,                                   \
+            if (hipFuncSetAttribute((const void*)hashgrid_scatter_persist_kernel<LAY>,                           \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {      \
                 set_error("cannot raise dynamic LDS to %u bytes", lds_bytes);                                    \
                 return 4;                                                                                        \
             }                                                                                                    \
             attr_bytes = lds_bytes;                                                                              \
         }                                                                                                        \
-        hipLaunchKernelGGL((hashgrid_scatter_kernel<LAY>), dim3(plan.max_items), dim3(SC_BLOCK), lds_bytes, s,   \
-                           x, dout, dparams, M, g, plan, ws);                                                    \
+        hipLaunchKernelGGL((hashgrid_scatter_persist_kernel<LAY>), dim3(blocks), dim3(SC_BLOCK), lds_bytes, s,   \
+                           x, dout, dparams, M, g, plan, ws, cw);                                                \
     } while (0)
         if (layout == MIPSF_FEAT_AOS) SCATTER(MIPSF_FEAT_AOS); else SCATTER(MIPSF_FEAT_LEVEL_MAJOR);
 #undef SCATTER
         if (int e = check_launch("hashgrid_scatter")) return e;
-        hipLaunchKernelGGL(hashgrid_scatter_reduce_kernel, dim3(plan.n_bins, (SC_MAX_SLICE + 255) / 256), dim3(256), 0, s,
-                           dparams, g, plan, ws);
+        hipLaunchKernelGGL(hashgrid_scatter_reduce_kernel, dim3(plan.n_bins, (plan.max_slice + 255) / 256), dim3(256), 0, s,
+                           dparams, g, plan, ws, cw);
         if (int e = check_launch("hashgrid_scatter_reduce")) return e;
     }
     if (dx) {
@@ -1197,12 +1251,19 @@ static int hashgrid_bwd_impl(const float* x, const float* params, const float* d
 
 int mipsf_hashgrid_bwd(const float* x, const float* params, const float* dout, float* dparams, float* dx,
                        float* scratch, uint32_t M, const mipsf_grid_meta* meta, int layout, void* stream) {
-    return hashgrid_bwd_impl(x, params, dout, dparams, dx, scratch, M, meta, layout, false, stream);
+    return hashgrid_bwd_impl(x, params, dout, dparams, dx, scratch, nullptr, M, meta, layout, false, stream);
+}
+
+int mipsf_hashgrid_bwd_keep(const float* x, const float* params, const float* dout, float* dparams, float* dx,
+                            float* scratch, uint32_t* counters, uint32_t M, const mipsf_grid_meta* meta, int layout,
+                            void* stream) {
+    MIPSF_REQUIRE(counters, "null counter block");
+    return hashgrid_bwd_impl(x, params, dout, dparams, dx, scratch, counters, M, meta, layout, false, stream);
 }
 
 int mipsf_hashgrid_bwd_routed(const float* x, const float* params, const float* dout, float* dparams, float* dx,
                               float* scratch, uint32_t M, const mipsf_grid_meta* meta, int layout, void* stream) {
-    return hashgrid_bwd_impl(x, params, dout, dparams, dx, scratch, M, meta, layout, true, stream);
+    return hashgrid_bwd_impl(x, params, dout, dparams, dx, scratch, nullptr, M, meta, layout, true, stream);
 }
 
 int mipsf_hashgrid_indices(const float* x, uint32_t* idx, uint32_t M, const mipsf_grid_meta* meta, void* stream) {

@@ -142,6 +142,21 @@ def hashgrid_route_ahead(x, meta):
     return scratch, ev
 
 
+_SCATTER_COUNTERS = {}
+
+
+def _scatter_counters(device, meta):
+    """The routed scatter's counter block (bin counts, queue head, tickets): zero once, left ready by every call
+    (mipsf_hashgrid_bwd_keep), so one zero-initialised block per (device, stream, size) is kept -- calls on one stream are
+    ordered -- and no call launches a clearing kernel."""
+    n = int(lib().mipsf_hashgrid_counter_words(C.byref(meta)))
+    key = (device.index, stream_ptr(), n)
+    buf = _SCATTER_COUNTERS.get(key)
+    if buf is None:
+        buf = _SCATTER_COUNTERS[key] = torch.zeros(n, dtype=torch.int32, device=device)
+    return buf
+
+
 def hashgrid_bwd(x, params, dout, dparams, meta, layout=FEAT_AOS, dx: Optional[torch.Tensor] = None, routed=None):
     """dparams (and dx when given) are accumulated into.  routed: (scratch, event) of hashgrid_route_ahead for this x."""
     M = x.shape[0]
@@ -157,9 +172,10 @@ def hashgrid_bwd(x, params, dout, dparams, meta, layout=FEAT_AOS, dx: Optional[t
         return
     n = lib().mipsf_hashgrid_bwd_scratch_floats(C.byref(meta), M, 1 if dx is not None else 0)
     scratch = torch.empty(n, dtype=torch.float32, device=x.device)
+    counters = _scatter_counters(x.device, meta)
     with _timed("hashgrid_bwd"):
-        check(lib().mipsf_hashgrid_bwd(dptr(x), dptr(params), dptr(dout), dptr(dparams), dptr(dx), dptr(scratch), M,
-                                       C.byref(meta), layout, stream_ptr()), "hashgrid_bwd")
+        check(lib().mipsf_hashgrid_bwd_keep(dptr(x), dptr(params), dptr(dout), dptr(dparams), dptr(dx), dptr(scratch),
+                                            dptr(counters, torch.int32), M, C.byref(meta), layout, stream_ptr()), "hashgrid_bwd")
 
 
 def hashgrid_indices(x, meta) -> torch.Tensor:
