@@ -184,6 +184,15 @@ uint64_t mipsf_decoder_tile_words(uint32_t M);
 int mipsf_decoder_bwd_chain16_ex(const float* packed16, int feat_layout, const float* x, const float* out,
                                  const float* dout, const float* saved, float* dfeat, float* dx, float* dact,
                                  uint32_t* tile_live, uint32_t M, void* stream);
+/* One launch fewer per training step: the forward clears the counters of the live-tile buffer its backward chain will fill
+ * (tile_live_clear, mipsf_decoder_tile_words(M) words), the chain is told so (header_is_clear = 1; the buffer must not have
+ * been used in between -- a second backward through the same record passes 0 and pays the memset). */
+int mipsf_decoder_fwd16_ex2(const float* packed16, const float* feat, int feat_layout, const float* x, float* out,
+                            float* saved, int sdf_only, int precision, int lean_record, uint32_t* tile_live_clear,
+                            uint32_t M, void* stream);
+int mipsf_decoder_bwd_chain16_ex2(const float* packed16, int feat_layout, const float* x, const float* out,
+                                  const float* dout, const float* saved, float* dfeat, float* dx, float* dact,
+                                  uint32_t* tile_live, int header_is_clear, uint32_t M, void* stream);
 /* Backward.  dout [M,10].  Outputs: dfeat (layout as feat), dx [M,3] (pe_mode 0: includes the PE chain),
  * dembed_pos [M,48] (pe_mode 1 only).  Weight gradients are ACCUMULATED into `grads`.
  * dact / partial: scratch of the sizes above. */
@@ -277,6 +286,14 @@ int mipsf_render_fwd_ex(const float* raw, const float* z_vals, const float* targ
                         float* depth_var, float* disp, float* acc, float* weights, float* losses,
                         float* partial, const float* loss_weights, float* loss_total, uint32_t N, uint32_t S,
                         void* stream);
+/* The same in ONE launch: ticket = one uint32 the CALLER keeps (zero before the first call, left at zero by every call; one
+ * per stream): the last workgroup of the render kernel finishes the losses (fp64 sums of the fp32 per-ray rows in a fixed
+ * order: the result does not depend on which workgroup is last).  ticket NULL = mipsf_render_fwd_ex. */
+int mipsf_render_fwd_ex2(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
+                         const uint32_t* counts, const mipsf_render_cfg* cfg_host, float* rgb, float* depth,
+                         float* depth_var, float* disp, float* acc, float* weights, float* losses,
+                         float* partial, const float* loss_weights, float* loss_total, uint32_t* ticket, uint32_t N,
+                         uint32_t S, void* stream);
 /* Gradients wrt raw.  g_losses[4] (device): d total / d {rgb_loss, depth_loss, sdf_loss, fs_loss};
  * g_rgb [N,3], g_depth [N] nullable extra gradients on the rendered maps.  draw [N,S,10] is written. */
 int mipsf_render_bwd(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
@@ -376,6 +393,12 @@ typedef struct mipsf_adam_small {
     uint32_t group_of[MIPSF_ADAM_MAX_TENSORS];
 } mipsf_adam_small;
 int mipsf_adam_step_small(const mipsf_adam_small* desc_host_struct, int zero_grad, void* stream);
+/* The same descriptor without the size limit: the whole step of an optimiser with tensors of ANY size in one launch (the map
+ * optimiser: hash table + decoder).  ticket: MIPSF_ADAM_TICKET_WORDS uint32 the caller keeps (zero before the first call,
+ * left ready by every call; the block belongs to ONE optimiser: it also carries the scalars the last workgroup leaves for
+ * that optimiser's next step). */
+#define MIPSF_ADAM_TICKET_WORDS 576
+int mipsf_adam_step_all(const mipsf_adam_small* desc_host_struct, int zero_grad, uint32_t* ticket, void* stream);
 
 /* -------------------------------------------------- RandomOptimizer fitness (a12) */
 /* sdf [P,n] (column 3 of run_network output, stride `sdf_stride` floats) , valid [n] ->

@@ -102,6 +102,8 @@ SIGNATURES = {
     "mipsf_decoder_fwd16_ex": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _U32, _P]),
     "mipsf_decoder_bwd_chain16": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _U32, _P]),
     "mipsf_decoder_bwd_chain16_ex": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _U32, _P]),
+    "mipsf_decoder_fwd16_ex2": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _U32, _P]),
+    "mipsf_decoder_bwd_chain16_ex2": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _U32, _P]),
     "mipsf_decoder_tile_words": (C.c_uint64, [_U32]),
     "mipsf_decoder_bwd": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.POINTER(DecoderGrads), _P, _P,
                                _U32, _P]),
@@ -118,6 +120,8 @@ SIGNATURES = {
     "mipsf_render_bwd": (_I, [_P, _P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _U32, _U32, _P]),
     "mipsf_render_fwd_ex": (_I, [_P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U32,
                                  _U32, _P]),
+    "mipsf_render_fwd_ex2": (_I, [_P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                  _U32, _U32, _P]),
     "mipsf_render_bwd_ex": (_I, [_P, _P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _P, _P, _U32, _U32, _P]),
     "mipsf_rays_bwd": (_I, [_P, _P, C.POINTER(RenderCfg), _P, _P, _U32, _U32, _P]),
     "mipsf_normalise_bwd": (_I, [_P, C.POINTER(RenderCfg), _P, _U32, _P]),
@@ -133,6 +137,7 @@ SIGNATURES = {
     "mipsf_adam_step_multi_ex": (_I, [C.POINTER(AdamTensors), _F, _F, _F, _F, _F, _U32, _P, _I, _P]),
     "mipsf_adam_step_multi": (_I, [C.POINTER(AdamTensors), _F, _F, _F, _F, _F, _U32, _I, _P]),
     "mipsf_adam_step_small": (_I, [C.POINTER(AdamSmall), _I, _P]),
+    "mipsf_adam_step_all": (_I, [C.POINTER(AdamSmall), _I, _P, _P]),
     "mipsf_ro_fitness": (_I, [_P, _U32, _P, _F, _P, _U32, _U32, _P]),
     "mipsf_ro_fitness_sdf": (_I, [_P, _P, _F, _P, _U32, _U32, _I, _P]),
     "mipsf_ro_particles": (_I, [_P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _U32, _U32, _P]),

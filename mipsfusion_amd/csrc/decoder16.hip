@@ -346,7 +346,12 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_fwd_kernel(const float
                                                                      const float* __restrict__ feat,
                                                                      const float* __restrict__ x,
                                                                      float* __restrict__ out,
-                                                                     float* __restrict__ saved, uint32_t M, int pin) {
+                                                                     float* __restrict__ saved, uint32_t M, int pin,
+                                                                     uint32_t* __restrict__ clear_hdr) {
+    // the header (counters) of the backward chain's live-tile lists, cleared here for the chain kernel that follows this
+    // forward: a memset in front of that kernel was a launch of its own (4.4 us of a step)
+    if (clear_hdr != nullptr && blockIdx.x == 0)
+        for (int q = threadIdx.x; q < (int)TL_HEADER; q += DEC_BLOCK) clear_hdr[q] = 0u;
     __shared__ float4 tailbuf[TAIL_F4];
     for (int q = threadIdx.x; q < TAIL_F4; q += DEC_BLOCK) tailbuf[q] = reinterpret_cast<const float4*>(packed16)[q];
     __syncthreads();
@@ -369,7 +374,10 @@ __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_fwd_lds_kernel(con
                                                                              const float* __restrict__ x,
                                                                              float* __restrict__ out,
                                                                              float* __restrict__ saved, uint32_t M,
-                                                                             int pin, uint32_t n_tiles) {
+                                                                             int pin, uint32_t n_tiles,
+                                                                             uint32_t* __restrict__ clear_hdr) {
+    if (clear_hdr != nullptr && blockIdx.x == 0)      // (see decoder16_fwd_kernel)
+        for (int q = threadIdx.x; q < (int)TL_HEADER; q += F16_LDS_BLOCK) clear_hdr[q] = 0u;
     extern __shared__ __attribute__((aligned(16))) float4 wbuf[];
     {
         constexpr int N4 = f16_lds_bytes<SPLIT>() / 16;
@@ -776,6 +784,15 @@ int mipsf_decoder_fwd16(const float* packed16, const float* feat, int feat_layou
 
 int mipsf_decoder_fwd16_ex(const float* packed16, const float* feat, int feat_layout, const float* x, float* out,
                            float* saved, int sdf_only, int precision, int lean_record, uint32_t M, void* stream) {
+    return mipsf_decoder_fwd16_ex2(packed16, feat, feat_layout, x, out, saved, sdf_only, precision, lean_record, nullptr, M, stream);
+}
+
+// tile_live_clear (optional): the live-tile buffer the backward chain of THIS forward will fill
+// (mipsf_decoder_bwd_chain16_ex2 with header_is_clear = 1): its counters are cleared by this launch.
+int mipsf_decoder_fwd16_ex2(const float* packed16, const float* feat, int feat_layout, const float* x, float* out,
+                            float* saved, int sdf_only, int precision, int lean_record, uint32_t* tile_live_clear,
+                            uint32_t M, void* stream) {
+    uint32_t* clear_hdr = tile_live_clear;
     if (M == 0) return 0;
     MIPSF_REQUIRE(packed16 && feat && x && out, "null pointer");
     MIPSF_REQUIRE(!lean_record || (saved && precision == MIPSF_PREC_F16X3), "the lean record belongs to the f16x3 training forward");
@@ -805,10 +822,11 @@ int mipsf_decoder_fwd16_ex(const float* packed16, const float* feat, int feat_la
                 attr_set = true;                                                                                   \
             }                                                                                                      \
             hipLaunchKernelGGL((decoder16_fwd_lds_kernel<LAY, SV, SDF, SPL>), dim3(cus), dim3(F16_LDS_BLOCK),      \
-                               f16_lds_bytes<SPL>(), s, packed16, feat, x, out, saved, M, stagger << 8, n_tiles);  \
+                               f16_lds_bytes<SPL>(), s, packed16, feat, x, out, saved, M, stagger << 8, n_tiles,   \
+                               clear_hdr);                                                                         \
         } else {                                                                                                   \
             hipLaunchKernelGGL((decoder16_fwd_kernel<LAY, SV, SDF, SPL>), dim3(blocks), dim3(DEC_BLOCK), 0, s,     \
-                               packed16, feat, x, out, saved, M, 0);                                               \
+                               packed16, feat, x, out, saved, M, 0, clear_hdr);                                    \
         }                                                                                                          \
     } while (0)
 #define F16_MODE(LAY, SPL)                                  \
@@ -840,6 +858,13 @@ int mipsf_decoder_bwd_chain16(const float* packed16, int feat_layout, const floa
 int mipsf_decoder_bwd_chain16_ex(const float* packed16, int feat_layout, const float* x, const float* out,
                                  const float* dout, const float* saved, float* dfeat, float* dx, float* dact,
                                  uint32_t* tile_live, uint32_t M, void* stream) {
+    return mipsf_decoder_bwd_chain16_ex2(packed16, feat_layout, x, out, dout, saved, dfeat, dx, dact, tile_live, 0, M, stream);
+}
+
+// header_is_clear: the counters of tile_live were cleared by the forward (mipsf_decoder_fwd16_ex2) and not used since
+int mipsf_decoder_bwd_chain16_ex2(const float* packed16, int feat_layout, const float* x, const float* out,
+                                  const float* dout, const float* saved, float* dfeat, float* dx, float* dact,
+                                  uint32_t* tile_live, int header_is_clear, uint32_t M, void* stream) {
     if (M == 0) return 0;
     MIPSF_REQUIRE(packed16 && x && out && dout && saved && dfeat && dx && dact, "null pointer");
     MIPSF_REQUIRE(feat_layout == MIPSF_FEAT_AOS || feat_layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout");
@@ -851,7 +876,7 @@ int mipsf_decoder_bwd_chain16_ex(const float* packed16, int feat_layout, const f
     const int cus = device_cus();
     if (cus <= 0) return 3;
     const bool persistent = n_tiles >= (uint32_t)cus * 8u * 2u && !getenv("MIPSF_B16_NO_LDS");
-    if (tile_live != nullptr && hipMemsetAsync(tile_live, 0, TL_HEADER * sizeof(uint32_t), s) != hipSuccess) {
+    if (tile_live != nullptr && !header_is_clear && hipMemsetAsync(tile_live, 0, TL_HEADER * sizeof(uint32_t), s) != hipSuccess) {
         set_error("cannot clear the tile counters");
         return 4;
     }

@@ -200,6 +200,138 @@ __global__ __launch_bounds__(256) void adam_small_kernel(mipsf_adam_small d) {
     }
 }
 
+// The whole step of ANY capturable optimiser in one launch (map optimiser: the 36 MB table + the decoder's ten tensors; it
+// used to be adam_advance_n + adam_kernel + adam_multi_kernel = three launches, two of them 5 us of latency each).
+// Workgroup b serves tensor `tensor_of(b)`; every workgroup derives its group's step-dependent scalars from the device step
+// counter itself (old value + 1, the arithmetic of adam_advance_n_kernel), nobody writes the counter while others may still
+// read it: the LAST workgroup to take a ticket (each takes one after its read) advances the counters, refreshes hyper_dev
+// and puts the ticket back to zero.  ticket: MIPSF_ADAM_TICKET_WORDS words that belong to ONE optimiser (they also carry
+// the next step's scalars of its groups).
+// beta^t for an integer step count by repeated squaring in double precision (within a few double-precision ulps of libm's
+// pow -- 1e-16 relative, far below the fp32 rounding of the scalars derived from it -- at a tenth of its registers: with
+// pow in the kernel its 105 SGPRs admit 6 workgroups per CU instead of 8, and the bandwidth-bound update ran 48 us
+// instead of 42)
+__device__ __forceinline__ double powi(double b, int t) {
+    double r = 1.0;
+    while (t > 0) {
+        if (t & 1) r *= b;
+        b *= b;
+        t >>= 1;
+    }
+    return r;
+}
+
+// what the scalars left for the next step were computed from (a learning-rate schedule changes lr between two steps)
+__device__ __forceinline__ uint32_t adam_key(float lr, float b1, float b2) {
+    return __float_as_uint(lr) ^ (__float_as_uint(b1) * 3u) ^ (__float_as_uint(b2) * 7u);
+}
+
+struct AdamAllMap {
+    uint32_t blk0[MIPSF_ADAM_MAX_TENSORS + 1];      // first workgroup of every tensor
+};
+
+template <bool ZERO>
+__global__ __launch_bounds__(256) void adam_all_kernel(mipsf_adam_small d, AdamAllMap map, uint32_t* __restrict__ ticket) {
+    __shared__ float hyp[2];
+    uint32_t ti = 0;
+    while (ti + 1 < d.n_tensors && blockIdx.x >= map.blk0[ti + 1]) ++ti;
+    const uint32_t gi = d.group_of[ti];
+    float *p = d.param[ti], *g = d.grad[ti], *m = d.exp_avg[ti], *v = d.exp_avg_sq[ti];
+    const uint64_t n = d.numel[ti];
+    const uint32_t nb = map.blk0[ti + 1] - map.blk0[ti], b = blockIdx.x - map.blk0[ti];
+    const uint64_t stride = (uint64_t)nb * 256;
+    const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+    const uint64_t n4 = vec ? n / 4 : 0;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    float4* g4 = reinterpret_cast<float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    // the first elements are requested BEFORE the step-dependent scalars are worked out (two double-precision pow by one
+    // thread and a barrier: ~3 us in front of every workgroup's first load otherwise)
+    uint64_t i = (uint64_t)b * 256 + threadIdx.x;
+    float4 pp, gg, mm, vv;
+    if (i < n4) pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+    // The step-dependent scalars of THIS step were left by the last workgroup of the previous step (tagged with the step
+    // they belong to, behind the tickets); only a first call -- or one after a reset / a loaded state -- works them out here
+    // (two double-precision pow by one thread: ~1 us in front of the workgroup's first store).
+    uint32_t* nexth = ticket + 16u * 33u + 4u * gi;            // {step tag, lr / bc1, 1 / sqrt(bc2), -}
+    if (threadIdx.x == 0) {
+        const int t = d.step_dev[gi][0] + 1;
+        const uint32_t tag = nexth[0];
+        const float h0 = __uint_as_float(nexth[1]), h1 = __uint_as_float(nexth[2]);
+        if (tag == (uint32_t)t && nexth[3] == adam_key(d.lr[gi], d.beta1[gi], d.beta2[gi])) {
+            hyp[0] = h0, hyp[1] = h1;
+        } else {
+            const double bc1 = 1.0 - powi((double)d.beta1[gi], t);
+            const double bc2 = 1.0 - powi((double)d.beta2[gi], t);
+            hyp[0] = (float)((double)d.lr[gi] / bc1), hyp[1] = (float)(1.0 / sqrt(bc2));
+        }
+    }
+    __syncthreads();
+    AdamK k;
+    k.lr_over_bc1 = hyp[0], k.inv_sqrt_bc2 = hyp[1];
+    k.beta1 = d.beta1[gi], k.beta2 = d.beta2[gi];
+    k.one_minus_b1 = (float)(1.0 - (double)d.beta1[gi]), k.one_minus_b2 = (float)(1.0 - (double)d.beta2[gi]);
+    k.eps = d.eps[gi], k.wd = d.weight_decay[gi], k.dev_hyper = nullptr;
+    // Two-level ticket, taken by ONE thread right after this workgroup has read the counter and the scalars (the other
+    // three waves go on; nobody waits at a barrier for the atomic's round trip, and nothing is left to do when the
+    // kernel ends): same-address device atomics retire at ~90 per microsecond and the grid has ~2000 workgroups (one
+    // ticket word: 23 us of a 42 us kernel).  32 sub-tickets on their own cache lines take ~64 increments each; the last
+    // workgroup of a sub-ticket takes the master ticket, the last of those knows that EVERY workgroup has read: it
+    // advances the counters and leaves the next step's scalars while the others are still streaming.
+    if (threadIdx.x == 0) {
+        const uint32_t sub = blockIdx.x & 31u;
+        const uint32_t n_sub = (gridDim.x - sub + 31u) / 32u;                 // workgroups with this sub-ticket
+        bool last = false;
+        if (__hip_atomic_fetch_add(ticket + 16u * (1u + sub), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_sub - 1) {
+            __hip_atomic_store(ticket + 16u * (1u + sub), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t n_master = gridDim.x < 32u ? gridDim.x : 32u;
+            last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_master - 1;
+        }
+        if (last) {
+            for (uint32_t q = 0; q < d.n_groups; ++q) {
+                const int t = d.step_dev[q][0] + 1;
+                d.step_dev[q][0] = t;
+                const double b1 = (double)d.beta1[q], b2 = (double)d.beta2[q];
+                d.hyper_dev[q][0] = (float)((double)d.lr[q] / (1.0 - powi(b1, t)));
+                d.hyper_dev[q][1] = (float)(1.0 / sqrt(1.0 - powi(b2, t)));
+                uint32_t* nx = ticket + 16u * 33u + 4u * q;          // the scalars of step t + 1
+                nx[1] = __float_as_uint((float)((double)d.lr[q] / (1.0 - powi(b1, t + 1))));
+                nx[2] = __float_as_uint((float)(1.0 / sqrt(1.0 - powi(b2, t + 1))));
+                nx[3] = adam_key(d.lr[q], d.beta1[q], d.beta2[q]);
+                nx[0] = (uint32_t)(t + 1);
+            }
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (i < n4) {           // the element requested before the barrier
+        adam1(pp.x, gg.x, mm.x, vv.x, k);
+        adam1(pp.y, gg.y, mm.y, vv.y, k);
+        adam1(pp.z, gg.z, mm.z, vv.z, k);
+        adam1(pp.w, gg.w, mm.w, vv.w, k);
+        p4[i] = pp, m4[i] = mm, v4[i] = vv;
+        if (ZERO) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // (fresh registers per round: a loop that carries the loaded values from one round into the next makes the compiler
+    // drain every store before the next load may land in the registers the store reads -- s_waitcnt vmcnt(0) per round,
+    // one load in flight at a time: 48 instead of 42 us)
+    for (uint64_t r = i + stride; r < n4; r += stride) {
+        float4 p1 = p4[r], g1 = g4[r], m1 = m4[r], v1 = v4[r];
+        adam1(p1.x, g1.x, m1.x, v1.x, k);
+        adam1(p1.y, g1.y, m1.y, v1.y, k);
+        adam1(p1.z, g1.z, m1.z, v1.z, k);
+        adam1(p1.w, g1.w, m1.w, v1.w, k);
+        p4[r] = p1, m4[r] = m1, v4[r] = v1;
+        if (ZERO) g4[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (uint64_t q = n4 * 4 + (uint64_t)b * 256 + threadIdx.x; q < n; q += stride) {
+        float p1 = p[q], g1 = g[q], m1 = m[q], v1 = v[q];
+        adam1(p1, g1, m1, v1, k);
+        p[q] = p1, m[q] = m1, v[q] = v1;
+        if (ZERO) g[q] = 0.f;
+    }
+}
+
 // ------------------------------------------------------ RandomOptimizer.get_fitness (RandomOptimizer.py:125-129)
 // one wave per particle: mean_j( (d_j > 0) * |sdf_pj * trunc| )
 // row of (particle, point) = particle * row_p + point * row_j, `stride` floats per row, SDF in column 3
@@ -372,6 +504,35 @@ int mipsf_adam_step_small(const mipsf_adam_small* d, int zero_grad, void* stream
     if (zero_grad) hipLaunchKernelGGL(adam_small_kernel<true>, dim3(1), dim3(256), 0, (hipStream_t)stream, *d);
     else hipLaunchKernelGGL(adam_small_kernel<false>, dim3(1), dim3(256), 0, (hipStream_t)stream, *d);
     return check_launch("adam_step_small");
+}
+
+int mipsf_adam_step_all(const mipsf_adam_small* d, int zero_grad, uint32_t* ticket, void* stream) {
+    MIPSF_REQUIRE(d && ticket, "null pointer");
+    MIPSF_REQUIRE(d->n_groups >= 1 && d->n_groups <= MIPSF_ADAM_MAX_GROUPS, "bad group count %u", d->n_groups);
+    MIPSF_REQUIRE(d->n_tensors >= 1 && d->n_tensors <= MIPSF_ADAM_MAX_TENSORS, "bad tensor count %u", d->n_tensors);
+    for (uint32_t i = 0; i < d->n_groups; ++i) MIPSF_REQUIRE(d->step_dev[i] && d->hyper_dev[i], "null pointer in group %u", i);
+    AdamAllMap map;
+    // All workgroups must be resident at once (8 of 256 threads per CU): a workgroup that has to wait for a slot starts
+    // when the first grid-stride loop ends, i.e. a whole kernel duration late (measured: the decoder's 40 small workgroups
+    // behind 2048 table workgroups made the launch 48 us instead of 42).  The budget is shared in proportion to the sizes.
+    const int cus = device_cus();
+    if (cus <= 0) return 3;
+    const uint64_t budget = (uint64_t)cus * 8;
+    uint64_t want_all = 0;
+    for (uint32_t i = 0; i < d->n_tensors; ++i) want_all += ((uint64_t)d->numel[i] / 4 + 255) / 256 + 1;
+    uint32_t blocks = 0;
+    for (uint32_t i = 0; i < d->n_tensors; ++i) {
+        MIPSF_REQUIRE(d->param[i] && d->grad[i] && d->exp_avg[i] && d->exp_avg_sq[i], "null pointer in tensor %u", i);
+        MIPSF_REQUIRE(d->group_of[i] < d->n_groups, "tensor %u: group out of range", i);
+        map.blk0[i] = blocks;
+        uint64_t want = ((uint64_t)d->numel[i] / 4 + 255) / 256 + 1;
+        if (want_all > budget) want = want * budget / want_all;        // (rounded down: the sum stays within the budget)
+        blocks += (uint32_t)(want < 1 ? 1 : want);
+    }
+    for (uint32_t i = d->n_tensors; i <= MIPSF_ADAM_MAX_TENSORS; ++i) map.blk0[i] = blocks;
+    if (zero_grad) hipLaunchKernelGGL(adam_all_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d, map, ticket);
+    else hipLaunchKernelGGL(adam_all_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d, map, ticket);
+    return check_launch("adam_step_all");
 }
 
 int mipsf_ro_fitness(const float* raw, uint32_t raw_stride, const float* target_d, float trunc, float* mean_masked,

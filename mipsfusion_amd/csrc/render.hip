@@ -139,19 +139,26 @@ __device__ __forceinline__ uint32_t first_crossing(const float* __restrict__ sro
 
 // ------------------------------------------------------------------------ forward
 // partial[n*8 + {0..5}] = {rgb_sq, depth_sq(valid), fs_sq, sdf_sq, fs_emd, sdf_emd}; [6] = valid flag
-template <bool TRAIN>
-__global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void render_fwd_kernel(
+struct LossFinalize {           // FUSED: the last workgroup of render_fwd_kernel finishes the losses (ticket != null)
+    const uint32_t* counts;
+    uint32_t* ticket;
+    float* losses;
+    const float* loss_weights;
+    float* loss_total;
+};
+
+__device__ void finalize_losses(const double (&t)[9], float emd_w, uint32_t N, uint32_t S, float* __restrict__ losses,
+                                const float* __restrict__ loss_weights, float* __restrict__ loss_total);
+
+template <bool TRAIN, bool FUSED>
+__device__ __forceinline__ void render_fwd_ray(
     const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ target_rgb,
-    const float* __restrict__ target_d, RenderCfg rc, float* __restrict__ rgb_out, float* __restrict__ depth_out,
+    const float* __restrict__ target_d, const RenderCfg& rc, float* __restrict__ rgb_out, float* __restrict__ depth_out,
     float* __restrict__ var_out, float* __restrict__ disp_out, float* __restrict__ acc_out,
-    float* __restrict__ weights_out, float* __restrict__ partial, uint32_t N, uint32_t S) {
-    __shared__ float ssdf[RAYS_PER_BLOCK][MAX_S];
-    const uint32_t w = threadIdx.x / MIPSF_WAVE, lane = threadIdx.x & (MIPSF_WAVE - 1);
-    const uint32_t n = blockIdx.x * RAYS_PER_BLOCK + w;
-    if (n >= N) return;
+    float* __restrict__ weights_out, float* __restrict__ partial, uint32_t N, uint32_t S, float* srow, uint32_t n,
+    uint32_t lane, float (&row)[7]) {
     const float* rraw = raw + (size_t)n * S * 10;
     const float* rz = z_vals + (size_t)n * S;
-    float* srow = ssdf[w];
     for (uint32_t k = lane; k < S; k += MIPSF_WAVE) srow[k] = rraw[k * 10 + 3];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -229,17 +236,102 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void render_fwd_kernel
         }
     }
     p_fs = wave_sum(p_fs), p_sd = wave_sum(p_sd), p_fe = wave_sum(p_fe), p_se = wave_sum(p_se);
+    float* p = partial + (size_t)n * 8;
+    const float e0 = a_r * cw - target_rgb[3 * n] * cw;
+    const float e1 = a_g * cw - target_rgb[3 * n + 1] * cw;
+    const float e2 = a_b * cw - target_rgb[3 * n + 2] * cw;
+    const float ed = a_d - d;
+    const float v0 = e0 * e0 + e1 * e1 + e2 * e2, v1 = valid ? ed * ed : 0.f, v6 = valid ? 1.f : 0.f;
+    if (!FUSED) {
+        if (lane == 0) {
+            p[0] = v0, p[1] = v1;
+            p[2] = p_fs, p[3] = p_sd, p[4] = p_fe, p[5] = p_se;
+            p[6] = v6, p[7] = 0.f;
+        }
+    } else {        // (every value is wave-uniform after the reductions above)
+        row[0] = v0, row[1] = v1, row[2] = p_fs, row[3] = p_sd, row[4] = p_fe, row[5] = p_se, row[6] = v6;
+    }
+}
+
+// partial[n*8 + {0..5}] = {rgb_sq, depth_sq(valid), fs_sq, sdf_sq, fs_emd, sdf_emd}; [6] = valid flag
+// FUSED (training, fin.ticket given): ONE launch.  Every workgroup adds its four rays' rows (and their front / band
+// counts) in fp64, writes the 9 sums through as ITS row of `partial` ([workgroups][9] doubles), waits for the stores'
+// acknowledgement (s_waitcnt vmcnt(0)) and takes a device-scope ticket; the LAST workgroup adds all rows in a fixed order
+// (so the result does not depend on which workgroup is last), finishes the losses and leaves the ticket at zero.  The same
+// hand-off as pose_rays_bwd_kernel (csrc/pose.hip: sc1 stores + vmcnt(0) + ticket, sc1 loads on the reading side).
+// 16 rays per workgroup in this form: the tickets are same-address device atomics (~90 per microsecond): the 1024 workgroups
+// of the 4-ray form spent 12 us on them (30 us instead of the 21 us of the two launches), 256 workgroups spend 3.
+template <bool TRAIN, bool FUSED, int RPB>
+__global__ __launch_bounds__(RPB * MIPSF_WAVE) void render_fwd_kernel(
+    const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ target_rgb,
+    const float* __restrict__ target_d, RenderCfg rc, float* __restrict__ rgb_out, float* __restrict__ depth_out,
+    float* __restrict__ var_out, float* __restrict__ disp_out, float* __restrict__ acc_out,
+    float* __restrict__ weights_out, float* __restrict__ partial, uint32_t N, uint32_t S, LossFinalize fin) {
+    __shared__ float ssdf[RPB][MAX_S];
+    const uint32_t w = threadIdx.x / MIPSF_WAVE, lane = threadIdx.x & (MIPSF_WAVE - 1);
+    const uint32_t n = blockIdx.x * RPB + w;
+    float row[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (n < N)
+        render_fwd_ray<TRAIN, FUSED>(raw, z_vals, target_rgb, target_d, rc, rgb_out, depth_out, var_out, disp_out, acc_out,
+                                     weights_out, partial, N, S, ssdf[w], n, lane, row);
+    if (!FUSED) return;
+    __shared__ bool is_last;
+    __shared__ double red[RPB][9];
     if (lane == 0) {
-        float* p = partial + (size_t)n * 8;
-        const float e0 = a_r * cw - target_rgb[3 * n] * cw;
-        const float e1 = a_g * cw - target_rgb[3 * n + 1] * cw;
-        const float e2 = a_b * cw - target_rgb[3 * n + 2] * cw;
-        p[0] = e0 * e0 + e1 * e1 + e2 * e2;
-        const float ed = a_d - d;
-        p[1] = valid ? ed * ed : 0.f;
-        p[2] = p_fs, p[3] = p_sd, p[4] = p_fe, p[5] = p_se;
-        p[6] = valid ? 1.f : 0.f;
-        p[7] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) red[w][j] = (double)row[j];
+        const uint2 c = n < N ? reinterpret_cast<const uint2*>(fin.counts)[n] : make_uint2(0u, 0u);
+        red[w][7] = (double)c.x, red[w][8] = (double)c.y;          // integers: exact
+    }
+    __syncthreads();
+    double* rows = reinterpret_cast<double*>(partial);             // [gridDim.x][9]
+    if (threadIdx.x < 9) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < RPB; ++q) t += red[q][threadIdx.x];
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(rows + 9 * (size_t)blockIdx.x + threadIdx.x),
+                           (unsigned long long)__double_as_longlong(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the row is acknowledged before the ticket is taken
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        is_last = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    // thread (g, j): column j of the rows g, g + G, g + 2G, ... -- every load of a thread in flight at once
+    constexpr uint32_t T = RPB * MIPSF_WAVE;
+    constexpr uint32_t G = T / 9;
+    const uint32_t j = threadIdx.x % 9, gidx = threadIdx.x / 9;
+    double acc = 0.0;
+    if (gidx < G) {
+        constexpr int U = 8;
+        for (uint32_t b0 = gidx; b0 < gridDim.x; b0 += U * G) {
+            unsigned long long q[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t b = b0 + u * G;
+                q[u] = b < gridDim.x ? __hip_atomic_load(reinterpret_cast<const unsigned long long*>(rows + 9 * (size_t)b + j),
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += __longlong_as_double((long long)q[u]);
+        }
+    }
+    __shared__ double red2[T];
+    red2[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        double t = 0.0;
+        for (uint32_t g2 = 0; g2 < G; ++g2) t += red2[g2 * 9 + threadIdx.x];
+        red[0][threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) t[c] = red[0][c];
+        finalize_losses(t, rc.emd_w, N, S, fin.losses, fin.loss_weights, fin.loss_total);
+        __hip_atomic_store(fin.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -288,38 +380,41 @@ __global__ __launch_bounds__(LF_BLOCK) void loss_finalize_kernel(const float* __
     double t[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) t[j] = wave_sum_d(lane < LF_BLOCK / MIPSF_WAVE ? red[lane][j] : 0.0);
-    if (lane == 0) {
-        const double NS = (double)N * (double)S;
-        const float n_front = (float)t[7], n_band = (float)t[8];
-        const float total = n_front + n_band;
-        const float fs_w = 1.0f - n_front / total;     // 0/0 -> NaN exactly like the reference
-        const float sdf_w = 1.0f - n_band / total;
-        const float rgb_loss = (float)(t[0] / (3.0 * (double)N));
-        const float depth_loss = (float)(t[1] / t[6]);   // no valid depth -> 0/0 = NaN (mse of an empty tensor)
-        float fs = (float)(t[2] / NS) * fs_w;
-        float sd = (float)(t[3] / NS) * sdf_w;
-        if (emd_w > 0.f) {
-            fs = fs + ((float)(t[4] / NS) / 250.f) * emd_w;
-            sd = sd + ((float)(t[5] / NS) / 5000.f) * emd_w;
-        }
-        losses[0] = rgb_loss;
-        losses[1] = depth_loss;
-        losses[2] = sd;
-        losses[3] = fs;
-        losses[4] = -10.f * logf(rgb_loss) / logf(10.f);
-        losses[5] = fs_w;
-        losses[6] = sdf_w;
-        losses[7] = (float)t[6];
-        // the training objective itself (MIPSFusion.get_loss_from_ret, mipsfusion.py:142-152): the same products added left
-        // to right in fp32 -- saves the caller a dot product forward and a scaling pass backward (5 us launches each)
-        if (loss_total) {
-            float tot = 0.0f;
-            tot = tot + loss_weights[0] * rgb_loss;
-            tot = tot + loss_weights[1] * depth_loss;
-            tot = tot + loss_weights[2] * sd;
-            tot = tot + loss_weights[3] * fs;
-            loss_total[0] = tot;
-        }
+    if (lane == 0) finalize_losses(t, emd_w, N, S, losses, loss_weights, loss_total);
+}
+
+__device__ void finalize_losses(const double (&t)[9], float emd_w, uint32_t N, uint32_t S, float* __restrict__ losses,
+                                const float* __restrict__ loss_weights, float* __restrict__ loss_total) {
+    const double NS = (double)N * (double)S;
+    const float n_front = (float)t[7], n_band = (float)t[8];
+    const float total = n_front + n_band;
+    const float fs_w = 1.0f - n_front / total;     // 0/0 -> NaN exactly like the reference
+    const float sdf_w = 1.0f - n_band / total;
+    const float rgb_loss = (float)(t[0] / (3.0 * (double)N));
+    const float depth_loss = (float)(t[1] / t[6]);   // no valid depth -> 0/0 = NaN (mse of an empty tensor)
+    float fs = (float)(t[2] / NS) * fs_w;
+    float sd = (float)(t[3] / NS) * sdf_w;
+    if (emd_w > 0.f) {
+        fs = fs + ((float)(t[4] / NS) / 250.f) * emd_w;
+        sd = sd + ((float)(t[5] / NS) / 5000.f) * emd_w;
+    }
+    losses[0] = rgb_loss;
+    losses[1] = depth_loss;
+    losses[2] = sd;
+    losses[3] = fs;
+    losses[4] = -10.f * logf(rgb_loss) / logf(10.f);
+    losses[5] = fs_w;
+    losses[6] = sdf_w;
+    losses[7] = (float)t[6];
+    // the training objective itself (MIPSFusion.get_loss_from_ret, mipsfusion.py:142-152): the same products added left
+    // to right in fp32 -- saves the caller a dot product forward and a scaling pass backward (5 us launches each)
+    if (loss_total) {
+        float tot = 0.0f;
+        tot = tot + loss_weights[0] * rgb_loss;
+        tot = tot + loss_weights[1] * depth_loss;
+        tot = tot + loss_weights[2] * sd;
+        tot = tot + loss_weights[3] * fs;
+        loss_total[0] = tot;
     }
 }
 
@@ -520,6 +615,15 @@ int mipsf_render_fwd_ex(const float* raw, const float* z_vals, const float* targ
                         const uint32_t* counts, const mipsf_render_cfg* cfg, float* rgb, float* depth,
                         float* depth_var, float* disp, float* acc, float* weights, float* losses, float* partial,
                         const float* loss_weights, float* loss_total, uint32_t N, uint32_t S, void* stream) {
+    return mipsf_render_fwd_ex2(raw, z_vals, target_rgb, target_d, counts, cfg, rgb, depth, depth_var, disp, acc, weights,
+                                losses, partial, loss_weights, loss_total, nullptr, N, S, stream);
+}
+
+int mipsf_render_fwd_ex2(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
+                         const uint32_t* counts, const mipsf_render_cfg* cfg, float* rgb, float* depth,
+                         float* depth_var, float* disp, float* acc, float* weights, float* losses, float* partial,
+                         const float* loss_weights, float* loss_total, uint32_t* ticket, uint32_t N, uint32_t S,
+                         void* stream) {
     MIPSF_REQUIRE((loss_weights == nullptr) == (loss_total == nullptr), "loss_weights and loss_total come together");
     MIPSF_REQUIRE(loss_total == nullptr || losses != nullptr, "loss_total needs the training mode (losses)");
     if (N == 0) return 0;
@@ -528,17 +632,24 @@ int mipsf_render_fwd_ex(const float* raw, const float* z_vals, const float* targ
     const RenderCfg rc = to_render_cfg(*cfg);
     const dim3 grid((N + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK), block(RAYS_PER_BLOCK * MIPSF_WAVE);
     hipStream_t s = (hipStream_t)stream;
+    const LossFinalize fin = {counts, ticket, losses, loss_weights, loss_total};
     if (losses) {
         MIPSF_REQUIRE(target_rgb && target_d && counts && partial, "training mode needs targets, counts, partial");
-        hipLaunchKernelGGL(render_fwd_kernel<true>, grid, block, 0, s, raw, z_vals, target_rgb, target_d, rc, rgb,
-                           depth, depth_var, disp, acc, weights, partial, N, S);
+        if (ticket) {       // one launch: the last workgroup finishes the losses
+            constexpr int RPB = 16;
+            hipLaunchKernelGGL((render_fwd_kernel<true, true, RPB>), dim3((N + RPB - 1) / RPB), dim3(RPB * MIPSF_WAVE), 0, s, raw,
+                               z_vals, target_rgb, target_d, rc, rgb, depth, depth_var, disp, acc, weights, partial, N, S, fin);
+            return check_launch("render_fwd");
+        }
+        hipLaunchKernelGGL((render_fwd_kernel<true, false, RAYS_PER_BLOCK>), grid, block, 0, s, raw, z_vals, target_rgb, target_d, rc, rgb,
+                           depth, depth_var, disp, acc, weights, partial, N, S, fin);
         if (int e = check_launch("render_fwd")) return e;
         hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(LF_BLOCK), 0, s, partial, counts, rc.emd_w, losses, N, S,
                            loss_weights, loss_total);
         return check_launch("loss_finalize");
     }
-    hipLaunchKernelGGL(render_fwd_kernel<false>, grid, block, 0, s, raw, z_vals, target_rgb, target_d, rc, rgb, depth,
-                       depth_var, disp, acc, weights, partial, N, S);
+    hipLaunchKernelGGL((render_fwd_kernel<false, false, RAYS_PER_BLOCK>), grid, block, 0, s, raw, z_vals, target_rgb, target_d, rc, rgb, depth,
+                       depth_var, disp, acc, weights, partial, N, S, fin);
     return check_launch("render_fwd");
 }
 

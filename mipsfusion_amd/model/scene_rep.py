@@ -110,6 +110,7 @@ class _QueryFn(torch.autograd.Function):
         out, saved = ops.decoder_fwd(packed, feat, FEAT_LEVEL_MAJOR, xn, None, M, save="lean" if lean else need,
                                      precision=prec, packed16=packed16)
         ctx.lean = lean
+        ctx.tile_live = getattr(saved, "mipsf_tile_live", None)    # (python attributes do not travel with saved tensors)
         if packed is None:
             packed = packed16
         ctx.prec = prec
@@ -127,6 +128,8 @@ class _QueryFn(torch.autograd.Function):
         need_w = any(ctx.needs_input_grad[3:])
         need_g = ctx.needs_input_grad[2]
         need_x = ctx.needs_input_grad[0]
+        if ctx.tile_live is not None:
+            saved.mipsf_tile_live = ctx.tile_live
         direct = ctx.owner.accumulate_param_grads_in_place and all(
             p.is_leaf and not p._backward_hooks for p in (grid_params, *weights))
         # frozen parameters (requires_grad False, e.g. the map during tracking) skip their kernels entirely

@@ -142,6 +142,19 @@ def hashgrid_route_ahead(x, meta):
     return scratch, ev
 
 
+_ZEROED = {}
+
+
+def _zeroed_words(device, n, tag):
+    """A small int32 buffer that is zero when a kernel starts and is left at zero by it (tickets, counter blocks): one per
+    (device, stream, use, size), created zero once -- calls on one stream are ordered."""
+    key = (device.index, stream_ptr(), tag, n)
+    buf = _ZEROED.get(key)
+    if buf is None:
+        buf = _ZEROED[key] = torch.zeros(n, dtype=torch.int32, device=device)
+    return buf
+
+
 _SCATTER_COUNTERS = {}
 
 
@@ -287,11 +300,19 @@ def decoder_fwd(packed, feat, layout, x, embed_pos, M, save, precision: str = "f
             raise RuntimeError("the f16 decoder modes take packed16 and compute the positional encoding in-kernel")
         if save and precision != "f16x3":
             raise RuntimeError('only precision "f32" / "f16x3" keep activations for the backward pass')
+        # the live-tile lists of the backward chain that will follow this record: allocated here so that THIS launch clears
+        # their counters (a memset in front of the chain kernel was a launch of its own)
+        tile_live = None
+        if save and SKIP_ZERO_TILES:
+            tile_live = torch.empty(lib().mipsf_decoder_tile_words(M), dtype=torch.int32, device=x.device)
         with _timed("decoder_fwd"):
-            check(lib().mipsf_decoder_fwd16_ex(dptr(packed16), dptr(feat), layout, dptr(x), dptr(out), dptr(saved), 0,
-                                               _lib.PREC[precision], 1 if lean else 0, M, stream_ptr()), "decoder_fwd16")
+            check(lib().mipsf_decoder_fwd16_ex2(dptr(packed16), dptr(feat), layout, dptr(x), dptr(out), dptr(saved), 0,
+                                                _lib.PREC[precision], 1 if lean else 0, dptr(tile_live, torch.int32), M,
+                                                stream_ptr()), "decoder_fwd16")
         if lean:
             saved.mipsf_lean_record = True          # decoder_bwd refuses to read H1 from such a record
+        if tile_live is not None:
+            saved.mipsf_tile_live = [tile_live, True]      # (buffer, its counters are still clear)
         return out, saved
     pe_mode = 0 if embed_pos is None else 1
     with _timed("decoder_fwd"):
@@ -336,14 +357,20 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
     if precision == "f16x3":
         if embed_pos is not None or packed16 is None:
             raise RuntimeError("the f16x3 backward chain takes packed16 and computes the positional encoding in-kernel")
+        hdr_clear = 0
         if SKIP_ZERO_TILES and (grads is None or wgrad_precision.startswith("stream_")):
             global _LAST_TILE_LIVE
-            tile_live = torch.empty(lib().mipsf_decoder_tile_words(M), dtype=torch.int32, device=dev)
+            pre = getattr(saved, "mipsf_tile_live", None)
+            if pre is not None and pre[1]:          # the forward of this record cleared the counters: use its buffer once
+                tile_live, hdr_clear = pre[0], 1
+                pre[1] = False                      # (a second backward through the same record clears them itself)
+            else:
+                tile_live = torch.empty(lib().mipsf_decoder_tile_words(M), dtype=torch.int32, device=dev)
             _LAST_TILE_LIVE = (tile_live, M)
         with _timed("decoder_bwd_chain"):
-            check(lib().mipsf_decoder_bwd_chain16_ex(dptr(packed16), layout, dptr(x), dptr(out), dptr(dout), dptr(saved),
-                                                     dptr(dfeat), dptr(dx), dptr(dact),
-                                                     dptr(tile_live, torch.int32), M, stream_ptr()), "decoder_bwd_chain16")
+            check(lib().mipsf_decoder_bwd_chain16_ex2(dptr(packed16), layout, dptr(x), dptr(out), dptr(dout), dptr(saved),
+                                                      dptr(dfeat), dptr(dx), dptr(dact), dptr(tile_live, torch.int32),
+                                                      hdr_clear, M, stream_ptr()), "decoder_bwd_chain16")
     else:
         with _timed("decoder_bwd_chain"):
             check(lib().mipsf_decoder_bwd_chain(dptr(packed), layout, dptr(x), pe_mode, dptr(out), dptr(dout),
@@ -473,12 +500,13 @@ def render_fwd(raw, z_vals, target_rgb, target_d, counts, rc, N, S, train: bool,
     losses = f(8) if train else None
     partial = f(N * 8) if train else None
     total = f(1) if (train and loss_weights is not None) else None
+    ticket = _zeroed_words(dev, 1, "render_fwd") if train else None    # the last workgroup finishes the losses: one launch
     with _timed("render_fwd"):
-        check(lib().mipsf_render_fwd_ex(dptr(raw), dptr(z_vals), dptr(target_rgb), dptr(target_d),
-                                        dptr(counts, torch.int32) if counts is not None else None, C.byref(rc), dptr(rgb),
-                                        dptr(depth), dptr(var), dptr(disp), dptr(acc), dptr(weights), dptr(losses),
-                                        dptr(partial), dptr(loss_weights) if total is not None else None, dptr(total),
-                                        N, S, stream_ptr()), "render_fwd")
+        check(lib().mipsf_render_fwd_ex2(dptr(raw), dptr(z_vals), dptr(target_rgb), dptr(target_d),
+                                         dptr(counts, torch.int32) if counts is not None else None, C.byref(rc), dptr(rgb),
+                                         dptr(depth), dptr(var), dptr(disp), dptr(acc), dptr(weights), dptr(losses),
+                                         dptr(partial), dptr(loss_weights) if total is not None else None, dptr(total),
+                                         dptr(ticket, torch.int32), N, S, stream_ptr()), "render_fwd")
     if loss_weights is not None and train:
         return rgb, depth, var, disp, acc, weights, losses, total
     return rgb, depth, var, disp, acc, weights, losses
@@ -664,6 +692,27 @@ def adam_step_small(groups, zero_grad=False):
     d.n_tensors = ti
     with _timed("adam_step_small"):
         check(lib().mipsf_adam_step_small(C.byref(d), 1 if zero_grad else 0, stream_ptr()), "adam_step_small")
+
+
+def adam_step_all(groups, ticket, zero_grad=False):
+    """groups as for ``adam_step_small`` but with tensors of any size: the whole optimiser step -- counters, bias corrections,
+    every update -- in ONE launch (the map optimiser: hash table + the decoder's ten tensors).  ticket: an int32 tensor of
+    MIPSF_ADAM_TICKET_WORDS (576) zeros owned by THIS optimiser (tickets + the scalars left for its next step)."""
+    d = _lib.AdamSmall()
+    d.n_groups = len(groups)
+    ti, dev, big = 0, None, False
+    for gi, (step_dev, hyper_dev, lr, b1, b2, eps, wd, tensors) in enumerate(groups):
+        d.step_dev[gi], d.hyper_dev[gi] = dptr(step_dev, torch.int32), dptr(hyper_dev)
+        d.lr[gi], d.beta1[gi], d.beta2[gi], d.eps[gi], d.weight_decay[gi] = lr, b1, b2, eps, wd
+        for p, g, m, v in tensors:
+            d.param[ti], d.grad[ti], d.exp_avg[ti], d.exp_avg_sq[ti] = dptr(p), dptr(g), dptr(m), dptr(v)
+            d.numel[ti], d.group_of[ti] = p.numel(), gi
+            dev, big = p.device, big or p.numel() > (1 << 20)
+            ti += 1
+    d.n_tensors = ti
+    with _timed("adam_step" if big else "adam_step_small"):
+        check(lib().mipsf_adam_step_all(C.byref(d), 1 if zero_grad else 0, dptr(ticket, torch.int32), stream_ptr()),
+              "adam_step_all")
 
 
 def ro_fitness(raw, target_d, trunc: float, point_major: bool = False) -> torch.Tensor:

@@ -112,6 +112,18 @@ class FusedAdam(torch.optim.Optimizer):
                                   [(p.data, p.grad, self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"]) for p in live])
                                  for gi, group, live, _ in work], zero_grad)
             return loss
+        n_t = sum(len(live) for _, _, live, _ in work)
+        if (self.capturable and work and len(work) <= _lib.ADAM_MAX_GROUPS and n_t <= _lib.ADAM_MAX_TENSORS and
+                all(p.numel() < (1 << 32) and p.is_contiguous() for _, _, live, _ in work for p in live)):
+            # any optimiser that fits one descriptor (the map optimiser: table + ten decoder tensors): ONE launch instead of
+            # advance + one launch per large tensor + one multi-tensor launch per group
+            if getattr(self, "_ticket", None) is None or self._ticket.device != work[0][2][0].device:
+                self._ticket = torch.zeros(576, dtype=torch.int32, device=work[0][2][0].device)    # MIPSF_ADAM_TICKET_WORDS
+            ops.adam_step_all([(self._dev[gi][0], self._dev[gi][1], group["lr"], group["betas"][0], group["betas"][1],
+                                group["eps"], group["weight_decay"],
+                                [(p.data, p.grad, self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"]) for p in live])
+                               for gi, group, live, _ in work], self._ticket, zero_grad)
+            return loss
         if self.capturable and work:       # all groups' step counters / bias corrections in ONE launch
             adv = [(self._dev[gi][0], self._dev[gi][1], group["lr"], group["betas"][0], group["betas"][1])
                    for gi, group, _, _ in work]
