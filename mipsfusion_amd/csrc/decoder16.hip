@@ -50,14 +50,21 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
 // well: `buffer_store_dwordx4 v[168:171], .., s44 offen` followed by `v_pk_mul_f32 v[170:171]` stored the NEW values
 // (every first of two back-to-back scaled stores of the backward chain was wrong).  So: constant part of the address in
 // the vector offset (folds into the 12-bit immediate below 4 KB, one v_add above), soffset = 0.
+#ifndef D16_FWD_STORE_AUX
+#define D16_FWD_STORE_AUX 0      // cache policy of the forward's activation record stores (2 = nt)
+#endif
+#ifndef D16_BWD_STORE_AUX
+#define D16_BWD_STORE_AUX 0      // cache policy of the chain's gradient record stores (2 = nt)
+#endif
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store16_nosoff(srd_t r, uint32_t lane16, uint32_t const_off, const float4& v) {
     u32x4 u;
     u.x = __float_as_uint(v.x), u.y = __float_as_uint(v.y), u.z = __float_as_uint(v.z), u.w = __float_as_uint(v.w);
-    __builtin_amdgcn_raw_buffer_store_b128(u, r, lane16 + const_off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, lane16 + const_off, 0, AUX);
 }
 __device__ __forceinline__ void store_act_piece(srd_t sv, uint32_t lane16, int mat, const f32x16 (&acc)[4], int q) {
     const int rt = q >> 2, g = q & 3;
-    buf_store16_nosoff(sv, lane16, (mat * 16 + q) * 1024,
+    buf_store16_nosoff<D16_FWD_STORE_AUX>(sv, lane16, (mat * 16 + q) * 1024,
                        make_float4(acc[rt][4 * g], acc[rt][4 * g + 1], acc[rt][4 * g + 2], acc[rt][4 * g + 3]));
 }
 
@@ -536,7 +543,7 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
     // a 16-byte piece of a (scaled) gradient tile, back at its true magnitude, into `dact`
     auto store_piece = [&](int mat, const f32x16 (&acc)[4], int q) {
         const int rt = q >> 2, g = q & 3;
-        buf_store16_nosoff(da, lane16, (mat * 16 + q) * 1024,
+        buf_store16_nosoff<D16_BWD_STORE_AUX>(da, lane16, (mat * 16 + q) * 1024,
                            make_float4(acc[rt][4 * g] * down, acc[rt][4 * g + 1] * down, acc[rt][4 * g + 2] * down,
                                        acc[rt][4 * g + 3] * down));
     };

@@ -203,7 +203,14 @@ __global__ __launch_bounds__(HG_BLOCK) void hashgrid_fwd_kernel(const float* __r
 //     fp64 sums make the result independent of the arrival order to fp32 precision;
 //   * the slice is added to dparams with coalesced read-modify-writes; bins with several parts go through
 //     partial slices and a reduce kernel.  No global float atomics, no inter-workgroup communication.
-constexpr int SC_BLOCK = 1024;
+constexpr int SC_BLOCK = 1024;                      // threads of an accumulate workgroup
+#ifndef MIPSF_RT_BLOCK
+#define MIPSF_RT_BLOCK 512
+#endif
+// threads of a routing workgroup (x SC_ROUTE_UNR samples of one level).  The kernel is a chain of short phases between
+// barriers (liveness loads, compaction, ranking with LDS atomics, one device atomic per bin, staging, write-out): with 512
+// threads four workgroups share a CU and their phases overlap (1024: 128.7 us for the whole scatter, 512: 122.3, 256: 128.0)
+constexpr int RT_BLOCK = MIPSF_RT_BLOCK;
 #ifndef MIPSF_SC_MAX_SLICE
 #define MIPSF_SC_MAX_SLICE 8192
 #endif
@@ -397,7 +404,7 @@ __device__ __forceinline__ bool route_groups_hashed_pow2(const Cell& cell, uint3
 // level, tools/micro/dout_zero_probe.py) -- so routing and accumulation handle half the records.  Exact: the skipped
 // contributions are +-0.
 template <int LAYOUT>
-__global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(RT_BLOCK) void scatter_route_kernel(const float* __restrict__ x,
                                                                 const float* __restrict__ dout, uint32_t M, GridLevels g,
                                                                 ScatterPlan plan, uint32_t* __restrict__ ws,
                                                                 uint32_t* __restrict__ cw) {
@@ -410,7 +417,7 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __
     // four-byte writes to 64 different lines (the bins of the 64 lanes), 10 M of them per launch -- half of this kernel's
     // time (ablation, tools/micro/route_probe.py: 52 us, 28 without the stores, 21 with a coalesced stand-in).
 #ifndef MIPSF_SC_STAGE_CAP
-#define MIPSF_SC_STAGE_CAP 10240
+#define MIPSF_SC_STAGE_CAP (10 * RT_BLOCK)
 #endif
     // Records beyond the staging capacity go straight to their bins (lane-per-record stores).  A workgroup's 4096 samples
     // make <= 4 records each on most levels; with the dead half of a mapping batch skipped that is ~8000 records, and
@@ -434,55 +441,56 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __
 #define MIPSF_SC_ROUTE_FAST 1   // experiments: 0 = the general grouping for every sample
 #endif
     const bool aggregate = ns <= MIPSF_SC_AGG_MAX;
-    for (uint32_t q = threadIdx.x; q < ns; q += SC_BLOCK) cnt[q] = 0u;
+    for (uint32_t q = threadIdx.x; q < ns; q += RT_BLOCK) cnt[q] = 0u;
     __syncthreads();
-    const uint32_t s0 = chunk * (SC_BLOCK * SC_ROUTE_UNR);
+    const uint32_t s0 = chunk * (RT_BLOCK * SC_ROUTE_UNR);
     // COMPACTION.  The dead samples (zero gradient) are the tails of the rays, i.e. every wave of 64 consecutive samples
     // has some: skipping them lane by lane leaves the grouping and ranking below as expensive as before.  The workgroup's
     // live samples are first packed (order kept) into `live_list`; round u then works on entries u * 1024 + thread, and
     // a batch that is half dead takes two rounds of full waves instead of four of half-empty ones.
-    __shared__ uint32_t live_list[SC_BLOCK * SC_ROUTE_UNR];
-    __shared__ uint32_t wave_base[(SC_BLOCK / 64) * SC_ROUTE_UNR + 1];
+    __shared__ uint32_t live_list[RT_BLOCK * SC_ROUTE_UNR];
+    __shared__ uint32_t wave_base[(RT_BLOCK / 64) * SC_ROUTE_UNR + 1];
     {
         const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
         unsigned long long alive[SC_ROUTE_UNR];
 #pragma unroll
         for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u) {
-            const uint32_t i = s0 + u * SC_BLOCK + threadIdx.x;
+            const uint32_t i = s0 + u * RT_BLOCK + threadIdx.x;
             bool live = i < M;
             if (live && dout != nullptr) {
                 const float2 gy = *reinterpret_cast<const float2*>(dout + feat_index<LAYOUT>(i, level, M, plan.n_levels));
                 live = !(gy.x == 0.0f && gy.y == 0.0f);           // (NaN gradients stay live)
             }
             alive[u] = __ballot(live);
-            if (lane == 0) wave_base[1 + u * (SC_BLOCK / 64) + wave] = (uint32_t)__popcll(alive[u]);
+            if (lane == 0) wave_base[1 + u * (RT_BLOCK / 64) + wave] = (uint32_t)__popcll(alive[u]);
         }
         __syncthreads();
-        if (threadIdx.x < 64) {                      // inclusive prefix of the 64 (round, wave) counts
-            uint32_t v = wave_base[1 + threadIdx.x];
+        static_assert((RT_BLOCK / 64) * SC_ROUTE_UNR <= 64, "one wave scans the (round, wave) counts");
+        if (threadIdx.x < 64) {                      // inclusive prefix of the <= 64 (round, wave) counts
+            uint32_t v = threadIdx.x < (RT_BLOCK / 64) * SC_ROUTE_UNR ? wave_base[1 + threadIdx.x] : 0u;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
                 const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
                 v += (int)threadIdx.x >= d ? o : 0u;
             }
-            wave_base[1 + threadIdx.x] = v;
+            if (threadIdx.x < (RT_BLOCK / 64) * SC_ROUTE_UNR) wave_base[1 + threadIdx.x] = v;
             if (threadIdx.x == 0) wave_base[0] = 0u;
         }
         __syncthreads();
 #pragma unroll
         for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u)
             if (alive[u] >> lane & 1ull)
-                live_list[wave_base[u * (SC_BLOCK / 64) + wave] + (uint32_t)__popcll(alive[u] & ((1ull << lane) - 1ull))] =
-                    s0 + u * SC_BLOCK + threadIdx.x;
+                live_list[wave_base[u * (RT_BLOCK / 64) + wave] + (uint32_t)__popcll(alive[u] & ((1ull << lane) - 1ull))] =
+                    s0 + u * RT_BLOCK + threadIdx.x;
         __syncthreads();
     }
-    const uint32_t n_live = wave_base[(SC_BLOCK / 64) * SC_ROUTE_UNR];
+    const uint32_t n_live = wave_base[(RT_BLOCK / 64) * SC_ROUTE_UNR];
     // across the barrier, per sample: 8 slots of (slice < 512, rank < 4096) as 16-bit halves, masks as bytes
     uint32_t sp[SC_ROUTE_UNR][4], rp[SC_ROUTE_UNR][4], mp[SC_ROUTE_UNR][2];
     uint32_t mine[SC_ROUTE_UNR];                     // the sample this thread handles in round u
 #pragma unroll
     for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u) {
-        const uint32_t c = u * SC_BLOCK + threadIdx.x;
+        const uint32_t c = u * RT_BLOCK + threadIdx.x;
         const bool live = c < n_live;
         const uint32_t i = live ? live_list[c] : 0u;
         mine[u] = i;
@@ -520,7 +528,7 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __
         mp[u][1] = m[4] | (m[5] << 8) | (m[6] << 16) | (m[7] << 24);
     }
     __syncthreads();
-    for (uint32_t q = threadIdx.x; q < ns; q += SC_BLOCK)
+    for (uint32_t q = threadIdx.x; q < ns; q += RT_BLOCK)
         base[q] = cnt[q] ? atomicAdd(&cw[plan.w_count + bin0 + q], cnt[q]) : 0u;
     if (MIPSF_SC_STAGE && threadIdx.x < 64) {       // exclusive prefix of the bin counts: where a bin starts in `stage`
         constexpr uint32_t PER = SC_MAX_NS / 64;
@@ -574,7 +582,7 @@ __global__ __launch_bounds__(SC_BLOCK) void scatter_route_kernel(const float* __
     if (MIPSF_SC_STAGE) {
         __syncthreads();
         const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-        for (uint32_t q = wave; q < ns; q += SC_BLOCK / 64) {
+        for (uint32_t q = wave; q < ns; q += RT_BLOCK / 64) {
             const uint32_t n = cnt[q], src = lstart[q];
             uint32_t* dstp = rec + (size_t)(bin0 + q) * M + base[q];
             for (uint32_t p = lane; p < n && src + p < STAGE_CAP; p += 64) dstp[p] = stage[src + p];
@@ -1161,11 +1169,11 @@ static int launch_route(const float* x, const float* dout, int layout, uint32_t*
         const uint32_t nz = plan.w_nitems + 4;   // bin counts, queue head, tickets
         hipLaunchKernelGGL(scatter_zero_kernel, dim3((nz + 255) / 256), dim3(256), 0, s, cw, nz);
     }
-    const uint32_t rb = g.n_levels * ((M + SC_BLOCK * SC_ROUTE_UNR - 1) / (SC_BLOCK * SC_ROUTE_UNR));
+    const uint32_t rb = g.n_levels * ((M + RT_BLOCK * SC_ROUTE_UNR - 1) / (RT_BLOCK * SC_ROUTE_UNR));
     if (layout == MIPSF_FEAT_AOS)
-        hipLaunchKernelGGL(scatter_route_kernel<MIPSF_FEAT_AOS>, dim3(rb), dim3(SC_BLOCK), 0, s, x, dout, M, g, plan, ws, cw);
+        hipLaunchKernelGGL(scatter_route_kernel<MIPSF_FEAT_AOS>, dim3(rb), dim3(RT_BLOCK), 0, s, x, dout, M, g, plan, ws, cw);
     else
-        hipLaunchKernelGGL(scatter_route_kernel<MIPSF_FEAT_LEVEL_MAJOR>, dim3(rb), dim3(SC_BLOCK), 0, s, x, dout, M, g, plan, ws, cw);
+        hipLaunchKernelGGL(scatter_route_kernel<MIPSF_FEAT_LEVEL_MAJOR>, dim3(rb), dim3(RT_BLOCK), 0, s, x, dout, M, g, plan, ws, cw);
     return check_launch("hashgrid_route");
 }
 
@@ -1209,8 +1217,11 @@ static int hashgrid_bwd_impl(const float* x, const float* params, const float* d
         const uint32_t lds_bytes = plan.max_slice * 16 + plan.n_bins * 4;      // the slice + the bin counts
         const int cus = device_cus();
         if (cus <= 0) return 3;
-        // one workgroup per CU (its slice fills most of the CU's LDS), never more than there can be items
-        const uint32_t blocks = plan.max_items < (uint32_t)cus ? plan.max_items : (uint32_t)cus;
+        // as many workgroups per CU as their slices fit into its 160 KB of LDS (and 32 waves), never more than there can be items
+        uint32_t per_cu = (160u * 1024u) / (lds_bytes + 256u);
+        per_cu = per_cu < 1u ? 1u : (per_cu > 2048u / SC_BLOCK ? 2048u / SC_BLOCK : per_cu);
+        const uint32_t want = (uint32_t)cus * per_cu;
+        const uint32_t blocks = plan.max_items < want ? plan.max_items : want;
 #define SCATTER(LAY)                                                                                             \
     do {                                                                                                         \
         static uint32_t attr_bytes_dev[MAX_DEVICES] = {0};                                                       \
