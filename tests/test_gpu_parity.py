@@ -565,6 +565,100 @@ def test_fused_adam_small_groups_one_launch(dev):
     np.testing.assert_allclose(ta.detach().cpu().numpy(), tc.detach().numpy(), rtol=2e-5, atol=1e-8)
 
 
+def test_fused_adam_whole_step_in_one_launch(dev):
+    """capturable FusedAdam over tensors of ANY size takes mipsf_adam_step_all (one launch: every workgroup derives its
+    group's bias corrections from the device step counter or takes the pair the previous step's last workgroup left, a
+    two-level ticket finds the workgroup after which all have read; csrc/elementwise.hip): a large tensor (many
+    workgroups, all eight XCDs) + odd-sized small ones in two groups against torch.optim.Adam and against the multi-launch
+    path, over steps that include a learning-rate change (the left-behind scalars are tagged with step AND rate), a
+    reset() and a missing gradient round trip; the ticket block ends every step at zero."""
+    torch.manual_seed(8)
+    big0, w0, b0 = torch.randn(3_000_017) * 0.1, torch.randn(37, 5), torch.randn(3)
+    def mk(d):
+        return [torch.nn.Parameter(t.clone().to(d)) for t in (big0, w0, b0)]
+    pa, pb, pc = mk(dev), mk(dev), mk("cpu")
+    groups = lambda ps: [{"params": ps[1:], "weight_decay": 1e-6, "lr": 0.01}, {"params": ps[:1], "eps": 1e-15, "lr": 0.01}]   # noqa: E731
+    oa = FusedAdam(groups(pa), betas=(0.9, 0.99), capturable=True)
+    ob = FusedAdam(groups(pb), betas=(0.9, 0.99), capturable=False)
+    oc = torch.optim.Adam(groups(pc), betas=(0.9, 0.99))
+    launches = {"n": 0}
+    orig = ops.adam_step_all
+
+    def counted(*a, **k):
+        launches["n"] += 1
+        return orig(*a, **k)
+    ops.adam_step_all = counted
+    try:
+        for it in range(9):
+            if it == 4:                                   # a schedule changes the rate between two steps
+                for o in (oa, ob, oc):
+                    for gq in o.param_groups:
+                        gq["lr"] = 0.003
+            if it == 6:                                   # fresh optimiser state, in place
+                oa.reset(), ob.reset()
+                oc = torch.optim.Adam(groups(pc), betas=(0.9, 0.99))
+                for gq in oc.param_groups:
+                    gq["lr"] = 0.003
+            gs = [torch.randn_like(t) * (0.0 if (it == 2 and k == 0) else 1.0) for k, t in enumerate((big0, w0, b0))]
+            gs[0][::3] = 0.0                              # dense semantics: entries without a gradient still move
+            for ps, d in ((pa, dev), (pb, dev), (pc, "cpu")):
+                for p_, g_ in zip(ps, gs):
+                    p_.grad = g_.clone().to(d)
+            oa.step(zero_grad=True), ob.step(), oc.step()
+            assert int(oa._ticket[:528].abs().sum()) == 0, "tickets must end every step at zero"
+            assert all(float(p_.grad.abs().max()) == 0.0 for p_ in pa)
+    finally:
+        ops.adam_step_all = orig
+    assert launches["n"] == 9, "the capturable optimiser did not take the one-launch path"
+    for a, b, c in zip(pa, pb, pc):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=3e-7, atol=1e-9)
+        np.testing.assert_allclose(a.detach().cpu().numpy(), c.detach().numpy(), rtol=2e-5, atol=1e-8)
+
+
+def test_render_losses_finished_in_the_render_launch(dev):
+    """mipsf_render_fwd_ex2 (the last workgroup of the render kernel finishes the losses, one launch) against the
+    two-launch form mipsf_render_fwd_ex: every output and all eight loss entries, at ray counts that leave the last
+    16-ray workgroup partly empty and that need one / several workgroups; the ticket is left at zero and repeated calls
+    agree bit for bit."""
+    import ctypes as C
+    from mipsfusion_amd._lib import dptr, lib, stream_ptr
+    torch.manual_seed(12)
+    cfg = synth.config_headline()
+    S = 64
+    rc = ops.make_render_cfg(cfg, cfg["mapping"]["bound"], cfg["mapping"]["localMLP_max_len"], 43, 21, 0.01)
+    for N in (1, 15, 16, 17, 1000, 4096):
+        raw = torch.randn(N, S, 10, device=dev)
+        raw[..., 3] = torch.linspace(1.0, -1.0, S, device=dev)[None] + 0.1 * torch.randn(N, S, device=dev)
+        z = torch.sort(torch.rand(N, S, device=dev) * 4.0 + 0.1, dim=1).values
+        t_rgb, t_d = torch.rand(N, 3, device=dev), torch.rand(N, 1, device=dev) * 4.0
+        t_d[::7] = 0.0
+        counts = torch.randint(0, S, (N, 2), dtype=torch.int32, device=dev)
+        lw = torch.tensor([1.0, 0.0, 1000.0, 10.0], device=dev)
+
+        def run(ticket):
+            f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)      # noqa: E731
+            outs = [f(N, 3), f(N), f(N), f(N), f(N)]
+            losses, partial, total = f(8), f(N * 8), f(1)
+            rcode = lib().mipsf_render_fwd_ex2(dptr(raw), dptr(z), dptr(t_rgb), dptr(t_d), dptr(counts, torch.int32), C.byref(rc),
+                                               *[dptr(o) for o in outs], None, dptr(losses), dptr(partial), dptr(lw), dptr(total),
+                                               dptr(ticket, torch.int32) if ticket is not None else None, N, S, stream_ptr())
+            assert rcode == 0
+            return outs, losses, total
+        ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        o2, l2, t2 = run(None)
+        for rep in range(3):
+            o1, l1, t1 = run(ticket)
+            assert int(ticket[0]) == 0
+            for a, b in zip(o1, o2):
+                assert torch.equal(a, b)
+            # fp64 sums of the same fp32 rows in another (fixed) order: equal up to the last fp32 bit of the quotient
+            np.testing.assert_allclose(l1.cpu().numpy(), l2.cpu().numpy(), rtol=3e-7, equal_nan=True)
+            np.testing.assert_allclose(t1.cpu().numpy(), t2.cpu().numpy(), rtol=3e-7, equal_nan=True)
+            if rep:
+                assert torch.equal(l1, l_prev) or (torch.isnan(l1) == torch.isnan(l_prev)).all()
+            l_prev = l1
+
+
 def test_fused_adam_reset_equals_fresh_optimizer(dev):
     """FusedAdam.reset() (in place, also under capturable=True) must continue exactly like a newly built
     torch.optim.Adam -- the reference rebuilds its pose optimiser every frame (mipsfusion.py:472-475)."""
