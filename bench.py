@@ -255,10 +255,11 @@ class MappingLoop:
             rays_d_cam, target_s, target_d = ops.gather_rays(self.table, rows, split=True)  # fresh rows of the ray table
             rays_d = torch.sum(rays_d_cam[..., None, :] * self.poses_all[owner, :3, :3], -1)
             rays_o = self.poses_all[owner, :3, -1]
-        else:   # fresh rows of the ray table + the same pose arithmetic in one kernel (the pose gradients go straight to .grad)
-            rays_o, rays_d, target_s, target_d = ops.gather_pose_rays(self.table, rows, self.cur_rot, self.cur_trans,
-                                                                      self.pose_fixed, owner, accumulate_in_place=True)
-        ret = self.model.forward(rays_o, rays_d, target_s, target_d, noise=noise)
+            ret = self.model.forward(rays_o, rays_d, target_s, target_d, noise=noise)
+        else:   # fresh rows of the ray table, the same pose arithmetic and the sample placement in one kernel (the pose
+            #     gradients go straight to .grad, from one kernel as well)
+            ret = self.model.forward_from_table(self.table, rows, self.cur_rot, self.cur_trans, self.pose_fixed, owner, noise,
+                                                accumulate_in_place=True)
         loss = get_loss_from_ret(ret, cfg["training"])
         backward_from_one(loss, retain_graph=self.torch_pose)     # = loss.backward(), minus autograd's ones_like fill
         self.i += 1
@@ -1009,7 +1010,7 @@ def main():
                                "620x460 synthetic RGB-D (640x480 cropped by 10)",
                    "rays": N_RAYS, "samples_per_ray": N_SAMPLES, "hash_size": cfg["grid"]["hash_size"],
                    "parallelism": f"submap-per-gpu x{world}" if world > 1 else "single gpu",
-                   "ray_build": "torch eager ops" if args.torch_pose else "fused pose_rays kernel",
+                   "ray_build": "torch eager ops" if args.torch_pose else "row gather + pose rays + sample placement in one kernel",
                    "host_cpus": f"{len(HOST_CPUS)} least-busy CPUs of one NUMA node ({HOST_CPUS[0]}..{HOST_CPUS[-1]})" if HOST_CPUS else "unconfined"},
         "forward_only": {"value": round(fwd_rate, 1), "unit": "rays*samples/s", "ms": round(fwd_ms, 4)},
         "variants": variants,

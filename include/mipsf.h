@@ -306,6 +306,19 @@ int mipsf_render_bwd_ex(const float* raw, const float* z_vals, const float* targ
                         const uint32_t* counts, const float* losses, const mipsf_render_cfg* cfg_host,
                         const float* g_losses, const float* g_total, const float* loss_weights, const float* g_rgb,
                         const float* g_depth, float* draw, uint32_t N, uint32_t S, void* stream);
+/* Row gather of the ray table + ray construction from the pose parameters + sample placement in one launch
+ * (mipsf_gather_pose_rays_fwd + mipsf_sample_rays: keyframeSet.py:264-290, mipsfusion.py:320-322, scene_rep.py:156-179);
+ * rays_o / rays_d are not written.  Backward: d(xn) -> pose gradients in one launch (mipsf_rays_bwd + mipsf_pose_rays_bwd_ex);
+ * scratch: mipsf_place_pose_scratch_floats floats whose first word is a ticket (zero on entry, zero on return). */
+int mipsf_gather_pose_place_fwd(const float* db, uint64_t n_rows, const int64_t* idx, const float* fixed_poses,
+                                const float* rot, const float* trans, uint32_t F, uint32_t K, const int64_t* owner,
+                                const float* noise, const float* z_uniform, const float* z_near_offsets,
+                                const float* z_near_nodepth, const mipsf_render_cfg* cfg_host, float* d_cam, float* rgb,
+                                float* depth, float* z_vals, float* xn, uint32_t* counts, uint32_t N, void* stream);
+uint64_t mipsf_place_pose_scratch_floats(uint32_t F, uint32_t K, uint32_t N);
+int mipsf_place_pose_bwd(const float* dxn, const float* z_vals, const mipsf_render_cfg* cfg_host, const float* rot, uint32_t F,
+                         uint32_t K, const int64_t* owner, const float* d_cam, float* d_rot, float* d_trans, float* scratch,
+                         uint32_t N, uint32_t S, int accumulate, void* stream);
 /* dxn [N*S,3] -> d_rays_o [N,3], d_rays_d [N,3] (written) */
 int mipsf_rays_bwd(const float* dxn, const float* z_vals, const mipsf_render_cfg* cfg_host, float* d_rays_o,
                    float* d_rays_d, uint32_t N, uint32_t S, void* stream);

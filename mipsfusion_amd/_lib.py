@@ -130,6 +130,10 @@ SIGNATURES = {
     "mipsf_gather_pose_rays_fwd": (_I, [_P, C.c_uint64, _P, _P, _P, _P, _U32, _U32, _P, _P, _P, _P, _P, _P, _U32, _P]),
     "mipsf_pose_rays_bwd_ex": (_I, [_P, _P, _P, _U32, _U32, _P, _P, _P, _P, _P, _U32, _I, _P]),
     "mipsf_pose_rays_scratch_floats": (_U64, [_U32, _U32, _U32]),
+    "mipsf_gather_pose_place_fwd": (_I, [_P, _U64, _P, _P, _P, _P, _U32, _U32, _P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P,
+                                         _P, _P, _P, _P, _U32, _P]),
+    "mipsf_place_pose_scratch_floats": (_U64, [_U32, _U32, _U32]),
+    "mipsf_place_pose_bwd": (_I, [_P, _P, C.POINTER(RenderCfg), _P, _U32, _U32, _P, _P, _P, _P, _P, _U32, _U32, _I, _P]),
     "mipsf_adam_step": (_I, [_P, _P, _P, _P, _U64, _F, _F, _F, _F, _F, _U32, _I, _P]),
     "mipsf_adam_advance": (_I, [_P, _P, _F, _F, _F, _P]),
     "mipsf_adam_advance_n": (_I, [_P, _P, _P, _P, _P, _U32, _P]),

@@ -5,7 +5,7 @@
 //
 // Reference: model/scene_rep.py:58-103 (sdf2weights, raw2outputs), :156-179 (placement), :211-236 (losses);
 // helper_functions/utils.py:21-49, 71-111 (get_masks, get_sdf_loss).
-#include "common.h"
+#include "pose_dev.h"
 
 namespace mipsf {
 
@@ -23,24 +23,15 @@ struct PlaceCfg {
 // index plus the number of elements of the other list that precede it.  Values (not indices) are all the
 // reference keeps from torch.sort (scene_rep.py:164), so tie order is irrelevant and the result is
 // bit-identical to a sort.
-__global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void sample_rays_kernel(
-    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ target_d,
-    const float* __restrict__ noise, const float* __restrict__ z_uniform, const float* __restrict__ z_near_off,
-    const float* __restrict__ z_near_nodepth, PlaceCfg pc, NormCfg nc, float* __restrict__ z_vals,
-    float* __restrict__ xn, uint32_t* __restrict__ counts, uint32_t N) {
-    __shared__ float zs[RAYS_PER_BLOCK][MAX_S];
-    __shared__ float sb[RAYS_PER_BLOCK][MAX_S];   // this ray's depth-guided list
-    __shared__ float sa[MAX_S];                   // the uniform list (shared by the block's rays)
-    const uint32_t w = threadIdx.x / MIPSF_WAVE, lane = threadIdx.x & (MIPSF_WAVE - 1);
-    const uint32_t n = blockIdx.x * RAYS_PER_BLOCK + w;
+// One ray's samples: rays_o / rays_d / target depth in registers (o, dv, d; has_target: a depth was given at all), the
+// wave's two LDS rows (row: merged list, rb: this ray's depth-guided list), sa: the uniform list.
+__device__ __forceinline__ void place_ray(const float (&o)[3], const float (&dv)[3], float d, bool has_target,
+                                          const float* __restrict__ noise, const float* __restrict__ z_near_off,
+                                          const float* __restrict__ z_near_nodepth, const PlaceCfg& pc, const NormCfg& nc,
+                                          float* __restrict__ z_vals, float* __restrict__ xn, uint32_t* __restrict__ counts,
+                                          float* row, float* rb, const float* sa, uint32_t n, uint32_t lane) {
     const uint32_t nu = pc.n_uniform, nn = pc.n_near, S = nu + nn;
-    for (uint32_t e = threadIdx.x; e < nu; e += RAYS_PER_BLOCK * MIPSF_WAVE) sa[e] = z_uniform[e];
-    __syncthreads();
-    if (n >= N) return;   // whole wave exits together; no block-level barrier is used below
-    const float d = target_d ? target_d[n] : 0.f;
     const bool has_depth = d > 0.f;   // rows with d <= 0 fall back to linspace(near, far) (scene_rep.py:160)
-    float* row = zs[w];
-    float* rb = sb[w];
     for (uint32_t j = lane; j < nn; j += MIPSF_WAVE) rb[j] = has_depth ? z_near_off[j] + d : z_near_nodepth[j];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -73,8 +64,6 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void sample_rays_kerne
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
-    const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
     uint32_t n_front = 0, n_band = 0;
     for (uint32_t k = lane; k < S; k += MIPSF_WAVE) {
         float z = row[k];
@@ -84,19 +73,19 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void sample_rays_kerne
             z = lo + (hi - lo) * noise[(size_t)n * S + k];
         }
         z_vals[(size_t)n * S + k] = z;
-        const float px = ox + dx * z, py = oy + dy * z, pz = oz + dz * z;
-        float* o = xn + ((size_t)n * S + k) * 3;
-        o[0] = normalise1(px, nc.sub[0], nc.div[0], nc.norm_factor);
-        o[1] = normalise1(py, nc.sub[1], nc.div[1], nc.norm_factor);
-        o[2] = normalise1(pz, nc.sub[2], nc.div[2], nc.norm_factor);
-        if (target_d) {
+        const float px = o[0] + dv[0] * z, py = o[1] + dv[1] * z, pz = o[2] + dv[2] * z;
+        float* out = xn + ((size_t)n * S + k) * 3;
+        out[0] = normalise1(px, nc.sub[0], nc.div[0], nc.norm_factor);
+        out[1] = normalise1(py, nc.sub[1], nc.div[1], nc.norm_factor);
+        out[2] = normalise1(pz, nc.sub[2], nc.div[2], nc.norm_factor);
+        if (has_target) {
             const bool front = z < d - pc.trunc_total;
             const bool back = z > d + pc.trunc_total;
             n_front += front ? 1u : 0u;
             n_band += (!front && !back && has_depth) ? 1u : 0u;
         }
     }
-    if (target_d && counts) {
+    if (has_target && counts) {
         // per-ray counts (summed by loss_finalize): two global atomics per ray on two shared words serialise at
         // ~12 ns each -- 100 us for 4096 rays -- so nothing is accumulated here
         const float f = wave_sum((float)n_front), b = wave_sum((float)n_band);   // <= 256 each: exact in fp32
@@ -105,6 +94,70 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void sample_rays_kerne
             counts[2 * n + 1] = (uint32_t)b;
         }
     }
+}
+
+__global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void sample_rays_kernel(
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ target_d,
+    const float* __restrict__ noise, const float* __restrict__ z_uniform, const float* __restrict__ z_near_off,
+    const float* __restrict__ z_near_nodepth, PlaceCfg pc, NormCfg nc, float* __restrict__ z_vals,
+    float* __restrict__ xn, uint32_t* __restrict__ counts, uint32_t N) {
+    __shared__ float zs[RAYS_PER_BLOCK][MAX_S];
+    __shared__ float sb[RAYS_PER_BLOCK][MAX_S];   // this ray's depth-guided list
+    __shared__ float sa[MAX_S];                   // the uniform list (shared by the block's rays)
+    const uint32_t w = threadIdx.x / MIPSF_WAVE, lane = threadIdx.x & (MIPSF_WAVE - 1);
+    const uint32_t n = blockIdx.x * RAYS_PER_BLOCK + w;
+    for (uint32_t e = threadIdx.x; e < pc.n_uniform; e += RAYS_PER_BLOCK * MIPSF_WAVE) sa[e] = z_uniform[e];
+    __syncthreads();
+    if (n >= N) return;   // whole wave exits together; no block-level barrier is used below
+    const float d = target_d ? target_d[n] : 0.f;
+    const float o[3] = {rays_o[3 * n], rays_o[3 * n + 1], rays_o[3 * n + 2]};
+    const float dv[3] = {rays_d[3 * n], rays_d[3 * n + 1], rays_d[3 * n + 2]};
+    place_ray(o, dv, d, target_d != nullptr, noise, z_near_off, z_near_nodepth, pc, nc, z_vals, xn, counts, zs[w], sb[w], sa, n,
+              lane);
+}
+
+// Row gather of the ray table + ray construction from the pose parameters + sample placement in ONE launch (they were
+// gather_pose_rays_fwd_kernel + sample_rays_kernel, a 5 us launch each in every iteration; rays_o / rays_d never leave
+// the registers).  Same arithmetic and NaN conventions as the two kernels.  Wave per ray.
+__global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void gather_pose_place_kernel(
+    const float* __restrict__ db, uint64_t n_rows, const int64_t* __restrict__ idx, const float* __restrict__ fixed,
+    const float* __restrict__ rot, const float* __restrict__ trans, int F, int K, const int64_t* __restrict__ owner,
+    const float* __restrict__ noise, const float* __restrict__ z_uniform, const float* __restrict__ z_near_off,
+    const float* __restrict__ z_near_nodepth, PlaceCfg pc, NormCfg nc, float* __restrict__ d_cam, float* __restrict__ rgb,
+    float* __restrict__ depth, float* __restrict__ z_vals, float* __restrict__ xn, uint32_t* __restrict__ counts,
+    uint32_t N) {
+    __shared__ float zs[RAYS_PER_BLOCK][MAX_S];
+    __shared__ float sb[RAYS_PER_BLOCK][MAX_S];
+    __shared__ float sa[MAX_S];
+    const uint32_t w = threadIdx.x / MIPSF_WAVE, lane = threadIdx.x & (MIPSF_WAVE - 1);
+    const uint32_t n = blockIdx.x * RAYS_PER_BLOCK + w;
+    for (uint32_t e = threadIdx.x; e < pc.n_uniform; e += RAYS_PER_BLOCK * MIPSF_WAVE) sa[e] = z_uniform[e];
+    __syncthreads();
+    if (n >= N) return;
+    int64_t r = idx[n];
+    if (r < 0) r += (int64_t)n_rows;
+    const bool row_ok = r >= 0 && (uint64_t)r < n_rows;
+    const float* src = db + 7 * (size_t)(row_ok ? r : 0);
+    float v[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v[k] = row_ok ? src[k] : __builtin_nanf("");      // (wave-uniform address: one request)
+    if (lane == 0) {
+        d_cam[3 * (size_t)n] = v[0], d_cam[3 * (size_t)n + 1] = v[1], d_cam[3 * (size_t)n + 2] = v[2];
+        rgb[3 * (size_t)n] = v[3], rgb[3 * (size_t)n + 1] = v[4], rgb[3 * (size_t)n + 2] = v[5];
+        depth[n] = v[6];
+    }
+    int64_t p = owner[n];
+    if (p < 0) p += F + K;
+    const bool in_range = p >= 0 && p < F + K;
+    const Mat34 m = load_pose(fixed, rot, trans, F, in_range ? (int)p : 0);
+    const float dx = in_range ? v[0] : __builtin_nanf(""), dy = v[1], dz = v[2];
+    float o[3], dv[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        dv[j] = (dx * m.r[3 * j] + dy * m.r[3 * j + 1]) + dz * m.r[3 * j + 2];
+        o[j] = m.t[j];
+    }
+    place_ray(o, dv, v[6], true, noise, z_near_off, z_near_nodepth, pc, nc, z_vals, xn, counts, zs[w], sb[w], sa, n, lane);
 }
 
 // ------------------------------------------------------------------- compositing helpers
@@ -564,6 +617,54 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void rays_bwd_kernel(c
     }
 }
 
+// d(xn) -> pose gradients in ONE launch (rays_bwd_kernel + pose_rays_bwd_kernel: the per-ray {d o, d d} stay in
+// registers).  16 rays per workgroup: 256 tickets for 4096 rays (same-address device atomics retire at ~90 per us).
+constexpr int PPB = 16;
+__global__ __launch_bounds__(PPB * MIPSF_WAVE) void place_pose_bwd_kernel(
+    const float* __restrict__ dxn, const float* __restrict__ z_vals, NormCfg nc, const float* __restrict__ d_cam,
+    const int64_t* __restrict__ owner, const float* __restrict__ rot, int F, int K, float* __restrict__ part,
+    uint32_t* __restrict__ ticket, float* __restrict__ d_rot, float* __restrict__ d_trans, uint32_t N, uint32_t S,
+    int accumulate) {
+    __shared__ float sacc[PR_MAX_POSES * 12];
+    __shared__ bool is_last;
+    const int P = F + K;
+    for (int q = threadIdx.x; q < P * 12; q += PPB * MIPSF_WAVE) sacc[q] = 0.f;
+    __syncthreads();
+    const uint32_t w = threadIdx.x / MIPSF_WAVE, lane = threadIdx.x & (MIPSF_WAVE - 1);
+    const uint32_t n = blockIdx.x * PPB + w;
+    if (n < N) {
+        float so[3] = {0.f, 0.f, 0.f}, sd[3] = {0.f, 0.f, 0.f};
+        for (uint32_t k = lane; k < S; k += MIPSF_WAVE) {
+            const float z = z_vals[(size_t)n * S + k];
+            const float* g = dxn + ((size_t)n * S + k) * 3;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float gp = (float)(((double)g[d] / nc.norm_factor) / nc.div[d]);
+                so[d] += gp;
+                sd[d] += gp * z;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            so[d] = wave_sum(so[d]);
+            sd[d] = wave_sum(sd[d]);
+        }
+        int64_t p = owner[n];
+        if (p < 0) p += P;
+        if (p < 0 || p >= P) p = 0;              // (the forward already produced NaN rays for this owner)
+        const float dx = d_cam[3 * (size_t)n], dy = d_cam[3 * (size_t)n + 1], dz = d_cam[3 * (size_t)n + 2];
+        if (lane < 12) {                         // lane q adds entry q of this ray's {dR (9), dt (3)} to its pose's row
+            const int j = lane < 9 ? (int)lane / 3 : (int)lane - 9;
+            const float gd = j == 0 ? sd[0] : (j == 1 ? sd[1] : sd[2]);
+            const float go = j == 0 ? so[0] : (j == 1 ? so[1] : so[2]);
+            const int c = (int)lane % 3;
+            const float dc = c == 0 ? dx : (c == 1 ? dy : dz);
+            atomicAdd(&sacc[(int)p * 12 + (int)lane], lane < 9 ? gd * dc : go);
+        }
+    }
+    pose_block_finish<PPB * MIPSF_WAVE>(sacc, &is_last, P, F, K, part, ticket, rot, d_rot, d_trans, accumulate != 0);
+}
+
 static RenderCfg to_render_cfg(const mipsf_render_cfg& c) {
     RenderCfg r;
     r.trunc = c.trunc;
@@ -601,6 +702,49 @@ int mipsf_sample_rays(const float* rays_o, const float* rays_d, const float* tar
                        dim3(RAYS_PER_BLOCK * MIPSF_WAVE), 0, (hipStream_t)stream, rays_o, rays_d, target_d, noise,
                        z_uniform, z_near_offsets, z_near_nodepth, pc, make_norm(*cfg), z_vals, xn, counts, N);
     return check_launch("sample_rays");
+}
+
+int mipsf_gather_pose_place_fwd(const float* db, uint64_t n_rows, const int64_t* idx, const float* fixed_poses,
+                                const float* rot, const float* trans, uint32_t F, uint32_t K, const int64_t* owner,
+                                const float* noise, const float* z_uniform, const float* z_near_offsets,
+                                const float* z_near_nodepth, const mipsf_render_cfg* cfg, float* d_cam, float* rgb,
+                                float* depth, float* z_vals, float* xn, uint32_t* counts, uint32_t N, void* stream) {
+    if (N == 0) return 0;
+    MIPSF_REQUIRE(cfg && db && idx && owner && z_uniform && d_cam && rgb && depth && z_vals && xn, "null pointer");
+    MIPSF_REQUIRE((F == 0 || fixed_poses) && (K == 0 || (rot && trans)), "null pose pointer");
+    MIPSF_REQUIRE(F + K >= 1 && F + K <= (uint32_t)PR_MAX_POSES, "number of poses %u outside [1,%d]", F + K, PR_MAX_POSES);
+    const uint32_t S = cfg->n_uniform + cfg->n_near;
+    MIPSF_REQUIRE(S >= 1 && S <= MAX_S, "samples per ray %u outside [1,%d]", S, MAX_S);
+    MIPSF_REQUIRE(cfg->n_near == 0 || (z_near_offsets && z_near_nodepth), "depth-guided samples need the near tables");
+    MIPSF_REQUIRE(!cfg->perturb || noise, "perturb needs the noise tensor");
+    PlaceCfg pc;
+    pc.n_uniform = cfg->n_uniform;
+    pc.n_near = cfg->n_near;
+    pc.perturb = cfg->perturb;
+    pc.trunc_total = (float)((double)cfg->trunc * (double)cfg->sc_factor);
+    hipLaunchKernelGGL(gather_pose_place_kernel, dim3((N + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK),
+                       dim3(RAYS_PER_BLOCK * MIPSF_WAVE), 0, (hipStream_t)stream, db, n_rows, idx, fixed_poses, rot, trans,
+                       (int)F, (int)K, owner, noise, z_uniform, z_near_offsets, z_near_nodepth, pc, make_norm(*cfg), d_cam, rgb,
+                       depth, z_vals, xn, counts, N);
+    return check_launch("gather_pose_place");
+}
+
+uint64_t mipsf_place_pose_scratch_floats(uint32_t F, uint32_t K, uint32_t N) {
+    return 1ull + 12ull * (F + K) * ((N + PPB - 1) / PPB);
+}
+
+int mipsf_place_pose_bwd(const float* dxn, const float* z_vals, const mipsf_render_cfg* cfg, const float* rot, uint32_t F,
+                         uint32_t K, const int64_t* owner, const float* d_cam, float* d_rot, float* d_trans, float* scratch,
+                         uint32_t N, uint32_t S, int accumulate, void* stream) {
+    MIPSF_REQUIRE(K >= 1, "no optimisable pose");
+    MIPSF_REQUIRE(cfg && dxn && z_vals && rot && owner && d_cam && d_rot && d_trans && scratch, "null pointer");
+    MIPSF_REQUIRE(F + K <= (uint32_t)PR_MAX_POSES, "number of poses %u above %d", F + K, PR_MAX_POSES);
+    if (N == 0) return 0;
+    // scratch[0] = ticket (zero on entry, zero again on return), then one row of partials per workgroup
+    hipLaunchKernelGGL(place_pose_bwd_kernel, dim3((N + PPB - 1) / PPB), dim3(PPB * MIPSF_WAVE), 0, (hipStream_t)stream, dxn,
+                       z_vals, make_norm(*cfg), d_cam, owner, rot, (int)F, (int)K, scratch + 1,
+                       reinterpret_cast<uint32_t*>(scratch), d_rot, d_trans, N, S, accumulate);
+    return check_launch("place_pose_bwd");
 }
 
 int mipsf_render_fwd(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,

@@ -398,6 +398,37 @@ class JointEncoding(nn.Module):
             self._obj_w, self._obj_w_key = torch.tensor(vals, dtype=torch.float32, device=device), key
         return self._obj_w
 
+    def forward_from_table(self, table, rows, rot, trans, fixed_poses, owner, noise, EMD_w=0.01, accumulate_in_place=False):
+        """(extension, opt-in) The training branch of ``forward`` for rays that are ROWS of a device-resident ray table
+        ``[..., 7]`` = (direction in the camera frame | rgb | depth) seen from poses ``cat([fixed_poses,
+        qt_to_transform_matrix(rot, trans)])[owner]``: what ``ops.gather_pose_rays(...)`` followed by ``forward(rays_o,
+        rays_d, rgb, depth, noise=noise)`` computes (keyframeSet.py:264-290, mipsfusion.py:320-322, scene_rep.py:156-238),
+        with the row gather, the ray construction and the sample placement in ONE launch, and the ray + pose gradients of
+        the backward in another (two launches fewer per iteration).  noise: [N, S] uniforms (required: the rays never
+        exist on the host).  accumulate_in_place: as for ``ops.pose_rays``."""
+        if not self.training:
+            raise RuntimeError("forward_from_table is the training branch (use forward / render_rays for evaluation)")
+        tr = self.config["training"]
+        if tr["n_samples_d"] <= 0:
+            raise ValueError("training.n_samples_d must be > 0 (every reference config sets it)")
+        n_uniform, n_near = tr["n_samples_d"], tr["n_range_d"]
+        S, N = n_uniform + n_near, rows.shape[0]
+        rc = self._rc(n_uniform, n_near, float(EMD_w))
+        if rc.perturb and noise is None:
+            raise ValueError("forward_from_table needs the jitter noise as a device tensor")
+        tables = self._linspace_tables(table.device, True)
+        trgb, td, z_vals, xn, counts = ops.GatherPosePlaceFn.apply(rot, trans, fixed_poses, owner, table, rows,
+                                                                   ops._f32c(noise) if rc.perturb else None, tables, rc, S,
+                                                                   accumulate_in_place)
+        raw = self._query(xn)
+        res = _RenderFn.apply(raw, z_vals, trgb, td, counts, rc, N, S, True, self._objective_weights(raw.device))
+        rgb, depth, losses = res[0], res[1], res[5]
+        ret = {"rgb": rgb, "depth": depth, "rgb_loss": losses[0], "depth_loss": losses[1], "sdf_loss": losses[2],
+               "fs_loss": losses[3], "psnr": losses[4:5].detach(), "_loss_vec": losses}
+        if len(res) > 6:
+            ret["_loss_total"], ret["_loss_total_weights"] = res[6], self._obj_w_key[1]
+        return ret
+
     def render_rays(self, rays_o, rays_d, target_d=None, noise=None):
         (rgb, depth, var, disp, acc), z_vals, raw = self._render(rays_o, rays_d, None, target_d, noise, False, 0.0)
         return {"rgb": rgb, "depth": depth, "disp_map": disp, "acc_map": acc, "depth_var": var, "z_vals": z_vals,

@@ -635,6 +635,67 @@ def gather_pose_rays(table, rows, rot, trans, fixed_poses, owner, accumulate_in_
     return PoseRaysFn.apply(rot, trans, fixed_poses, owner, None, accumulate_in_place, table, rows.to(torch.int64).contiguous())
 
 
+class GatherPosePlaceFn(torch.autograd.Function):
+    """Row gather of the ray table + rays from the pose Parameters + sample placement (``gather_pose_rays`` followed by
+    ``JointEncoding``'s placement: keyframeSet.py:264-290, mipsfusion.py:320-322, scene_rep.py:156-179) as ONE launch
+    each way: -> (rgb [N,3], depth [N,1], z_vals [N,S], xn [N*S,3], counts [N,2]); the gradient of xn reaches rot / trans."""
+
+    @staticmethod
+    def forward(ctx, rot, trans, fixed, owner, table, rows, noise, tables, rc, S, in_place):
+        ctx.params = (rot, trans) if in_place else None
+        rot, trans = _f32c(rot), _f32c(trans)
+        fixed = _f32c(fixed) if fixed is not None and fixed.numel() else None
+        owner = owner.to(torch.int64).contiguous()
+        rows = rows.to(torch.int64).contiguous()
+        F = 0 if fixed is None else fixed.shape[0]
+        K, N, dev = rot.shape[0], rows.shape[0], rot.device
+        flat = table.reshape(-1, 7)
+        e = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)       # noqa: E731
+        d_cam, rgb, depth, z_vals, xn = e(N, 3), e(N, 3), e(N, 1), e(N, S), e(N * S, 3)
+        counts = torch.empty((N, 2), dtype=torch.int32, device=dev)
+        zu, zoff, znd = tables
+        with _timed("sample_rays"):
+            check(lib().mipsf_gather_pose_place_fwd(dptr(flat), flat.shape[0], dptr(rows, torch.int64), dptr(fixed), dptr(rot),
+                                                    dptr(trans), F, K, dptr(owner, torch.int64), dptr(noise), dptr(zu),
+                                                    dptr(zoff), dptr(znd), C.byref(rc), dptr(d_cam), dptr(rgb), dptr(depth),
+                                                    dptr(z_vals), dptr(xn), dptr(counts, torch.int32), N, stream_ptr()),
+                  "gather_pose_place_fwd")
+        ctx.F, ctx.K, ctx.N, ctx.S, ctx.rc = F, K, N, S, rc
+        ctx.save_for_backward(rot, owner, d_cam, z_vals)
+        ctx.mark_non_differentiable(rgb, depth, z_vals, counts)
+        ctx.set_materialize_grads(False)
+        return rgb, depth, z_vals, xn, counts
+
+    @staticmethod
+    def backward(ctx, _g_rgb, _g_depth, _g_z, dxn, _g_counts):
+        if dxn is None:
+            return (None,) * 11
+        rot, owner, d_cam, z_vals = ctx.saved_tensors
+        n = int(lib().mipsf_place_pose_scratch_floats(ctx.F, ctx.K, ctx.N))
+        key = (rot.device.index, stream_ptr(), "place", n)
+        scratch = _POSE_SCRATCH.get(key)
+        if scratch is None:
+            scratch = _POSE_SCRATCH[key] = torch.zeros(n, dtype=torch.float32, device=rot.device)
+        direct = ctx.params is not None and all(
+            p.is_leaf and p.requires_grad and not p._backward_hooks and p.dtype == torch.float32 and p.is_contiguous()
+            for p in ctx.params)
+        if direct:
+            for p in ctx.params:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            d_rot, d_trans = ctx.params[0].grad, ctx.params[1].grad
+        else:
+            d_rot = torch.empty((ctx.K, 4), dtype=torch.float32, device=rot.device)
+            d_trans = torch.empty((ctx.K, 3), dtype=torch.float32, device=rot.device)
+        with _timed("rays_bwd"):
+            check(lib().mipsf_place_pose_bwd(dptr(_f32c(dxn)), dptr(z_vals), C.byref(ctx.rc), dptr(rot), ctx.F, ctx.K,
+                                             dptr(owner, torch.int64), dptr(d_cam), dptr(d_rot), dptr(d_trans), dptr(scratch),
+                                             ctx.N, ctx.S, 1 if direct else 0, stream_ptr()), "place_pose_bwd")
+        if direct:
+            return (None,) * 11
+        return (d_rot, d_trans) + (None,) * 9
+
+
 # ----------------------------------------------------------------------------------- Adam
 def adam_advance(step_dev, hyper_dev, lr, beta1, beta2):
     check(lib().mipsf_adam_advance(dptr(step_dev, torch.int32), dptr(hyper_dev), lr, beta1, beta2, stream_ptr()),

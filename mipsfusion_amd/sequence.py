@@ -608,9 +608,8 @@ class GraphedSequence:
         rows, owner, noise = packed(self.ba_rows, n), packed(self.ba_owner, n), packed(self.ba_noise, n)
 
         def step(k):
-            rays_o, rays_d, rgb, depth = ops.gather_pose_rays(self.table, rows[k], self.ba_rot, self.ba_trans, self.fixed,
-                                                              owner[k], accumulate_in_place=True)
-            ret = self.model.forward(rays_o, rays_d, rgb, depth, noise=noise[k])
+            ret = self.model.forward_from_table(self.table, rows[k], self.ba_rot, self.ba_trans, self.fixed, owner[k], noise[k],
+                                                accumulate_in_place=True)
             backward_from_one(get_loss_from_ret(ret, tcfg))
             self.map_opt.step(zero_grad=True)
             if (k + 1) % mp["pose_accum_step"] == 0:
@@ -620,9 +619,8 @@ class GraphedSequence:
     def _go_step(self, k):
         if k == 0:
             self.model.frozen_weights(True)          # the map is frozen for the frame's tracking iterations: one pack
-        rays_o, rays_d, rgb, depth = ops.gather_pose_rays(self.cur, self.go_idx, self.go_rot, self.go_trans, None,
-                                                          self.go_own, accumulate_in_place=True)
-        ret = self.model.forward(rays_o, rays_d, rgb, depth, EMD_w=0., noise=self.go_noise[k])
+        ret = self.model.forward_from_table(self.cur, self.go_idx, self.go_rot, self.go_trans, None, self.go_own,
+                                            self.go_noise[k], EMD_w=0., accumulate_in_place=True)
         backward_from_one(get_loss_from_ret(ret, self.cfg["training"]))
         self.go_popt.step(zero_grad=True)
         if k == self.cfg["tracking"]["iter"] - 1:
@@ -637,9 +635,8 @@ class GraphedSequence:
     def _init_step(self, k):
         """One initialisation iteration of a sub-map (first_frame_mapping / initialize_new_localMLP, mipsfusion.py:172-190,
         206-221): mapping.sample pixels of the keyframe, its pose fixed (owner 0), map Adam step."""
-        rays_o, rays_d, rgb, depth = ops.gather_pose_rays(self.table, self.init_rows[k], self.ba_rot.detach(), self.ba_trans.detach(),
-                                                          self.fixed, self.init_owner)
-        ret = self.model.forward(rays_o, rays_d, rgb, depth, noise=self.init_noise[k])
+        ret = self.model.forward_from_table(self.table, self.init_rows[k], self.ba_rot.detach(), self.ba_trans.detach(),
+                                            self.fixed, self.init_owner, self.init_noise[k])
         backward_from_one(get_loss_from_ret(ret, self.cfg["training"]))
         self.map_opt.step(zero_grad=True)
 
@@ -654,9 +651,8 @@ class GraphedSequence:
         def step(k):
             if k == 0:
                 self.model.frozen_weights(True)
-            rays_o, rays_d, rgb, depth = ops.gather_pose_rays(self.table, rows[k], self.sw_rot, self.sw_trans, self.sw_fixed,
-                                                              owner[k], accumulate_in_place=True)
-            ret = self.model.forward(rays_o, rays_d, rgb, depth, noise=noise[k])
+            ret = self.model.forward_from_table(self.table, rows[k], self.sw_rot, self.sw_trans, self.sw_fixed, owner[k], noise[k],
+                                                accumulate_in_place=True)
             backward_from_one(get_loss_from_ret(ret, self.cfg["training"]))
             if (k + 1) % accum == 0:
                 self.sw_popt.step(zero_grad=True)

@@ -766,6 +766,68 @@ def test_pose_rays_matches_torch_composition(dev):
     assert_close(trans_c.grad, g["d_trans"], 2e-5, "d_trans vs reference autograd")
 
 
+def test_forward_from_table_equals_gather_then_forward(dev):
+    """JointEncoding.forward_from_table (row gather + ray construction + sample placement in one launch, ray + pose gradients
+    in another) against ops.gather_pose_rays followed by forward(): sample placement and every output bit for bit, the
+    pose gradients to fp32 rounding of their per-pose sums, the map gradients to the scatter's own reproducibility; ragged
+    ray counts (last 16-ray workgroup of the backward partly empty), python-style negative owners, in-place accumulation."""
+    from mipsfusion_amd.helper_functions.geometry_helper import qt_to_transform_matrix
+    from mipsfusion_amd.helper_functions.utils import get_loss_from_ret
+    torch.manual_seed(3)
+    cfg = synth.config_headline()
+    cfg["grid"]["hash_size"] = 14
+    bb = torch.from_numpy(np.array(cfg["mapping"]["bound"]))
+    nf = torch.from_numpy(np.array(cfg["mapping"]["localMLP_max_len"]))
+    m = JointEncoding(cfg, bb, nf).to(dev).train()
+    frame = synth.make_frame(cfg, seed=5)
+    table = torch.cat([frame["direction"], frame["rgb"], frame["depth"][..., None]], -1).reshape(-1, 7)[:50000].contiguous().to(dev)
+    S = cfg["training"]["n_samples_d"] + cfg["training"]["n_range_d"]
+    F, K = 1, 5
+    c2w = synth.default_pose(cfg)
+    fixed = c2w[None].to(dev)
+    rot0 = gh_quat(c2w[:3, :3])[None].repeat(K, 1).to(dev) + 0.01 * torch.randn(K, 4, device=dev)
+    trans0 = c2w[None, :3, 3].repeat(K, 1).to(dev) + 0.02 * torch.randn(K, 3, device=dev)
+    for N in (1, 17, 1000):
+        rows = torch.randint(-50000, 50000, (N,), device=dev)
+        owner = torch.randint(-(F + K), F + K, (N,), device=dev)
+        noise = torch.rand(N, S, device=dev)
+        outs = []
+        for fused in (False, True):
+            rot, trans = rot0.clone().requires_grad_(True), trans0.clone().requires_grad_(True)
+            m.zero_grad(set_to_none=True)
+            if fused:
+                ret = m.forward_from_table(table, rows, rot, trans, fixed, owner, noise)
+            else:
+                rays_o, rays_d, rgb, depth = ops.gather_pose_rays(table, rows, rot, trans, fixed, owner)
+                ret = m.forward(rays_o, rays_d, rgb, depth, noise=noise)
+            loss = get_loss_from_ret(ret, cfg["training"])
+            loss.backward()
+            outs.append((ret, loss.detach(), rot.grad.clone(), trans.grad.clone(), m.embed_fn.params.grad.clone(),
+                         m.decoder.pts_linear[0].weight.grad.clone()))
+        (ra, la, gra, gta, gga, gwa), (rb, lb, grb, gtb, ggb, gwb) = outs
+        for k in ("rgb", "depth", "rgb_loss", "depth_loss", "sdf_loss", "fs_loss"):
+            assert torch.equal(ra[k], rb[k]) or (torch.isnan(ra[k]).all() and torch.isnan(rb[k]).all()), k
+        assert torch.equal(la, lb) or (torch.isnan(la) and torch.isnan(lb))
+        if torch.isfinite(la):
+            assert_close(grb, gra, 2e-5, f"d quaternion, N={N}")
+            assert_close(gtb, gta, 2e-5, f"d translation, N={N}")
+            assert_close(ggb, gga, 1e-6, f"grid gradient, N={N}")
+            assert_close(gwb, gwa, 1e-6, f"decoder gradient, N={N}")
+    # in-place accumulation into the pose parameters' .grad (twice -> twice the gradient)
+    rot, trans = rot0.clone().requires_grad_(True), trans0.clone().requires_grad_(True)
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        get_loss_from_ret(m.forward_from_table(table, rows, rot, trans, fixed, owner, noise, accumulate_in_place=True),
+                          cfg["training"]).backward()
+    assert_close(rot.grad, 2 * grb, 2e-5, "d quaternion accumulated in place twice")
+    assert_close(trans.grad, 2 * gtb, 2e-5, "d translation accumulated in place twice")
+
+
+def gh_quat(R):
+    from mipsfusion_amd.helper_functions.geometry_helper import matrix_to_quaternion
+    return matrix_to_quaternion(R[None])[0]
+
+
 def test_pose_rays_bwd_ticket_reduction_under_load(dev):
     """The one-launch pose backward hands per-workgroup partial rows to the last workgroup through sc1 (write-through)
     stores, a `s_waitcnt vmcnt(0)` and a device-scope ticket -- no agent-scope fence (csrc/pose.hip).  Stress: 400
