@@ -10,6 +10,11 @@ import torch
 from . import _lib, ops
 
 
+import os
+
+_SPLIT_LAUNCHES = os.environ.get("MIPSF_ADAM_SPLIT", "0") == "1"      # A/B: advance + per-tensor launches instead of one
+
+
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
@@ -113,7 +118,7 @@ class FusedAdam(torch.optim.Optimizer):
                                  for gi, group, live, _ in work], zero_grad)
             return loss
         n_t = sum(len(live) for _, _, live, _ in work)
-        if (self.capturable and work and len(work) <= _lib.ADAM_MAX_GROUPS and n_t <= _lib.ADAM_MAX_TENSORS and
+        if (self.capturable and work and not _SPLIT_LAUNCHES and len(work) <= _lib.ADAM_MAX_GROUPS and n_t <= _lib.ADAM_MAX_TENSORS and
                 all(p.numel() < (1 << 32) and p.is_contiguous() for _, _, live, _ in work for p in live)):
             # any optimiser that fits one descriptor (the map optimiser: table + ten decoder tensors): ONE launch instead of
             # advance + one launch per large tensor + one multi-tensor launch per group
