@@ -467,18 +467,18 @@ def frame_estimate(cfg, model, loop, dev, ba_ms, stream=None):
 
     d_cam, t_rgb, t_d = rays[:, :3].contiguous(), rays[:, 3:6].contiguous(), rays[:, 6:7].contiguous()
     own = torch.zeros(ns, dtype=torch.int64, device=dev)
+    rows_go = loop.idx_rows[0][:ns].contiguous()
 
     def go():
-        popt.zero_grad(set_to_none=False)
         if loop.torch_pose:
             c2w = qt_to_transform_matrix(rot, trans)
             rays_o = c2w[..., :3, -1].repeat(ns, 1)
             rays_d = torch.sum(d_cam[..., None, :] * c2w[:, :3, :3], -1)
-        else:
-            rays_o, rays_d = ops.pose_rays(rot, trans, None, own, d_cam, accumulate_in_place=True)
-        ret = model.forward(rays_o, rays_d, t_rgb, t_d, EMD_w=0., noise=noise)
+            ret = model.forward(rays_o, rays_d, t_rgb, t_d, EMD_w=0., noise=noise)
+        else:       # the tracking iteration of the graphed sequences: rows of the ray table, one launch each way for the rays
+            ret = model.forward_from_table(loop.table, rows_go, rot, trans, None, own, noise, EMD_w=0., accumulate_in_place=True)
         get_loss_from_ret(ret, cfg["training"]).backward()
-        popt.step()
+        popt.step(zero_grad=True)       # (the pose gradients are cleared by the optimiser kernel itself)
     def time_go():
         for _ in range(3):
             go()

@@ -771,6 +771,17 @@ static W to_w16(const mipsf_decoder_weights& s) {
 
 using namespace mipsf;
 
+// tiles per CU from which the persistent (LDS-resident operand images) kernels are used (experiments: MIPSF_PERSIST_MIN)
+static uint32_t persist_min_tiles_per_cu() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MIPSF_PERSIST_MIN");
+        v = e ? atoi(e) : 16;
+        if (v < 1) v = 1;
+    }
+    return (uint32_t)v;
+}
+
 extern "C" {
 
 uint32_t mipsf_decoder_packed16_floats(void) { return (uint32_t)PACKED16_FLOATS; }
@@ -811,7 +822,7 @@ int mipsf_decoder_fwd16_ex2(const float* packed16, const float* feat, int feat_l
     hipStream_t s = (hipStream_t)stream;
     const int cus = device_cus();
     if (cus <= 0) return 3;
-    const bool persistent = n_tiles >= (uint32_t)cus * 8u * 2u;
+    const bool persistent = n_tiles >= (uint32_t)cus * persist_min_tiles_per_cu();
     const char* st_env = getenv("MIPSF_F16_STAGGER");
     const int stagger = st_env ? atoi(st_env) : 0;
 #define F16(LAY, SV, SDF, SPL)                                                                                     \
@@ -882,7 +893,7 @@ int mipsf_decoder_bwd_chain16_ex2(const float* packed16, int feat_layout, const 
     const uint32_t n_tiles = (uint32_t)(((uint64_t)M + 31) / 32);
     const int cus = device_cus();
     if (cus <= 0) return 3;
-    const bool persistent = n_tiles >= (uint32_t)cus * 8u * 2u && !getenv("MIPSF_B16_NO_LDS");
+    const bool persistent = n_tiles >= (uint32_t)cus * persist_min_tiles_per_cu() && !getenv("MIPSF_B16_NO_LDS");
     if (tile_live != nullptr && !header_is_clear && hipMemsetAsync(tile_live, 0, TL_HEADER * sizeof(uint32_t), s) != hipSuccess) {
         set_error("cannot clear the tile counters");
         return 4;
