@@ -172,6 +172,48 @@ def test_hashgrid_backward_routing_edge_sizes(dev, log2_t, M, sparse):
         assert float(dp0.abs().max()) == 0.0
 
 
+def test_scatter_counter_block_survives_many_alternating_calls(dev):
+    """The routed scatter keeps a small counter block between calls (bin counts, queue head, two tickets) that every call
+    must leave ready: 600 calls alternating between two batches of different size and sparsity while a second stream keeps
+    the memory system busy; every result must equal the first call's for the same batch to the scatter's own
+    reproducibility (fp64 slice sums: differences below 1e-6 of the maximum), and the block must read zero (counts, head,
+    tickets) after every call."""
+    torch.manual_seed(41)
+    meta = _lib.make_grid_meta(16, 2, 19, 16, PLS)
+    params = torch.zeros(meta.n_params, device=dev)
+    batches = []
+    for M in (20000, 4096 * 8 + 13):
+        x = torch.rand(M, 3, device=dev)
+        dy = torch.randn(16, M, 2, device=dev)
+        dy[:, torch.rand(M, device=dev) < 0.5] = 0.0
+        batches.append((x, dy))
+    counters = ops._scatter_counters(dev, meta)
+    n_bins_plus = int(_lib.lib().mipsf_hashgrid_counter_words(meta)) - 8
+    n_bins = n_bins_plus // 3
+    want = []
+    for x, dy in batches:
+        dp = torch.zeros(meta.n_params, device=dev)
+        ops.hashgrid_bwd(x, params, dy, dp, meta, _lib.FEAT_LEVEL_MAJOR, None)
+        want.append(dp)
+    busy = torch.empty(64 << 20, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for q in range(200):
+            busy[: (1 + q % 7) << 22].add_(1.0)
+    dp = torch.zeros(meta.n_params, device=dev)
+    worst = 0.0
+    for it in range(600):
+        k = it & 1
+        dp.zero_()
+        ops.hashgrid_bwd(batches[k][0], params, batches[k][1], dp, meta, _lib.FEAT_LEVEL_MAJOR, None)
+        if it % 50 == 0 or it > 590:
+            assert int(counters[: n_bins + 4].abs().sum()) == 0, f"counter block not left ready after call {it}"
+            worst = max(worst, rel_err(dp, want[k]))
+    torch.cuda.synchronize()
+    assert worst < 1e-6, f"a call saw another call's counters: {worst:.2e}"
+
+
 def test_hashgrid_empty_and_single(dev):
     meta = _lib.make_grid_meta(16, 2, 10, 16, PLS)
     params = torch.rand(meta.n_params, device=dev)
