@@ -387,6 +387,35 @@ def forward_only_rate(model, loop, dev, iters=10):
     return N_RAYS * N_SAMPLES / dt, dt * 1e3
 
 
+def decoder_gemm_rates(model, dev, M):
+    """The decoder's batched (rays*samples x feat) x (feat x hidden) products on their own: the forward kernel WITHOUT the
+    activation record of the backward pass (the evaluation branch / RandomOptimizer rounds), per arithmetic, with the
+    matrix-pipe utilisation = matrix-core FLOP issued / dense f16 peak (f16x3 issues three products per algorithmic one)."""
+    from mipsfusion_amd._lib import FEAT_LEVEL_MAJOR
+    ws = model.decoder.ordered_parameters()
+    packed16 = ops.decoder_pack16(ws)
+    x = torch.rand(M, 3, device=dev)
+    feat = torch.randn(16, M, 2, device=dev) * 1e-2
+    out = {}
+    for prec, mult in (("f16x3", 3), ("f16", 1)):
+        fn = lambda: ops.decoder_fwd(None, feat, FEAT_LEVEL_MAJOR, x, None, M, save=False, precision=prec, packed16=packed16)   # noqa: E731
+        for _ in range(3):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 20
+        issued = DECODER_FLOP_PER_SAMPLE * M * mult / (ms * 1e-3) / 1e12
+        out[prec] = {"ms": round(ms, 4), "algorithmic_tflops": round(issued / mult, 2), "issued_tflops": round(issued, 2),
+                     "peak_tflops": MFMA_F16_PEAK_TFLOPS, "utilisation": round(issued / MFMA_F16_PEAK_TFLOPS, 4)}
+    out["note"] = ("forward kernel without the activation record, 262 144 samples; the training forward (kernels.decoder_fwd) also "
+                   "writes 1 KB of record per sample and is priced against HBM")
+    return out
+
+
 def inference_rates(cfg, model, dev):
     """Logger.render_full_img-style full-frame render (10 000-ray chunks) and Mesher-style dense grid
     queries (16 384-point batches) through the eval / query_* entry points."""
@@ -1013,6 +1042,7 @@ def main():
                    "ray_build": "torch eager ops" if args.torch_pose else "row gather + pose rays + sample placement in one kernel",
                    "host_cpus": f"{len(HOST_CPUS)} least-busy CPUs of one NUMA node ({HOST_CPUS[0]}..{HOST_CPUS[-1]})" if HOST_CPUS else "unconfined"},
         "forward_only": {"value": round(fwd_rate, 1), "unit": "rays*samples/s", "ms": round(fwd_ms, 4)},
+        "decoder_gemm_forward": decoder_gemm_rates(model, dev, M),
         "variants": variants,
         "roofline": roofline, "kernels": kernels,
         "gradient_sparsity": {"live_32_sample_tiles": None if live_share is None else round(live_share, 4),
