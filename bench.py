@@ -155,6 +155,7 @@ def build_submap(cfg, dev, seed):
         model.embed_fn.params.copy_((torch.rand(model.embed_fn.params.shape, generator=g) * 2 - 1) * 1e-4)
     model = model.to(dev).train()
     model.accumulate_param_grads_in_place = True      # plain loss.backward() loop: opt in (scene_rep._QueryFn)
+    model.grid_grad_is_zero_at_backward = True        # one backward per step, map_opt.step(zero_grad=True) clears the gradients
     # keyframes on a small arc + the current frame
     frames, poses = [], []
     for k in range(5):
@@ -517,6 +518,7 @@ def frame_estimate(cfg, model, loop, dev, ba_ms, stream=None):
             go()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / 10 * 1e3
+    zero_promise, model.grid_grad_is_zero_at_backward = model.grid_grad_is_zero_at_backward, False    # (backward passes pile up here)
     go_ms_unfrozen = time_go()          # reference as shipped: freeze_model() is a no-op (typo `require_grad`)
     for prm in model.parameters():      # what freeze_model (mipsfusion.py:226-230) intends; pose results identical
         prm.requires_grad_(False)
@@ -535,6 +537,7 @@ def frame_estimate(cfg, model, loop, dev, ba_ms, stream=None):
     for prm in model.parameters():
         prm.requires_grad_(True)
     model.zero_grad()
+    model.grid_grad_is_zero_at_backward = zero_promise
     go_eager_ms = go_ms
     if go_graph_ms is not None:
         go_ms = go_graph_ms

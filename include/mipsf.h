@@ -93,6 +93,12 @@ uint64_t mipsf_hashgrid_counter_words(const mipsf_grid_meta* meta_host);
 int mipsf_hashgrid_bwd_keep(const float* x, const float* params, const float* dout, float* dparams, float* dx,
                             float* scratch, uint32_t* counters, uint32_t M, const mipsf_grid_meta* meta_host, int feat_layout,
                             void* stream);
+/* The same with flags.  MIPSF_HG_DPARAMS_ZERO: the caller vouches that dparams is all zero on entry (the gradient buffer of
+ * an optimiser that clears it, a fresh allocation): table slices are then stored instead of read-modify-written. */
+#define MIPSF_HG_DPARAMS_ZERO 1u
+int mipsf_hashgrid_bwd_keep_ex(const float* x, const float* params, const float* dout, float* dparams, float* dx,
+                               float* scratch, uint32_t* counters, uint32_t M, const mipsf_grid_meta* meta_host,
+                               int feat_layout, uint32_t flags, void* stream);
 /* The same in two halves.  The routing of the scatter (which table slices every sample touches: a third of the
  * backward's time) depends on x only: mipsf_hashgrid_route may run as soon as x exists -- e.g. on a second stream next
  * to the forward pass -- into the same scratch buffer, and mipsf_hashgrid_bwd_routed then does the rest. */

@@ -83,6 +83,7 @@ SIGNATURES = {
     "mipsf_hashgrid_bwd": (_I, [_P, _P, _P, _P, _P, _P, _U32, C.POINTER(GridMeta), _I, _P]),
     "mipsf_hashgrid_counter_words": (_U64, [C.POINTER(GridMeta)]),
     "mipsf_hashgrid_bwd_keep": (_I, [_P, _P, _P, _P, _P, _P, _P, _U32, C.POINTER(GridMeta), _I, _P]),
+    "mipsf_hashgrid_bwd_keep_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, _U32, C.POINTER(GridMeta), _I, _U32, _P]),
     "mipsf_hashgrid_route": (_I, [_P, _P, _U32, C.POINTER(GridMeta), _P]),
     "mipsf_hashgrid_bwd_routed": (_I, [_P, _P, _P, _P, _P, _P, _U32, C.POINTER(GridMeta), _I, _P]),
     "mipsf_hashgrid_indices": (_I, [_P, _P, _U32, C.POINTER(GridMeta), _P]),

@@ -259,6 +259,7 @@ struct ScatterPlan {
     uint32_t max_items;                           // upper bound on accumulate work items for this M
     uint32_t max_slice;                           // entries of the largest slice (= the accumulate kernel's LDS / 16)
     uint32_t dense_bins;                          // bins [0, dense_bins) belong to the dense levels (they come first)
+    uint32_t fresh;                               // 1: the caller vouches that dparams is all zero on entry: slices are stored, not added
     // scratch layout, in 4-byte words from the start of the scratch buffer
     uint32_t w_count, w_first, w_parts, w_nitems, w_items;
     uint64_t w_records, w_partial, w_end;         // records: n_bins regions of bin_cap words
@@ -629,7 +630,7 @@ __device__ __forceinline__ void scatter_item(const float* __restrict__ x, const 
     float2* dst = reinterpret_cast<float2*>(dparams) + off + begin;
     constexpr uint32_t FL = SC_MAX_SLICE / SC_BLOCK;
     float2 cur[FL];
-    if (single) {
+    if (single && !plan.fresh) {
 #pragma unroll
         for (uint32_t k = 0; k < FL; ++k) {
             const uint32_t e = threadIdx.x + k * SC_BLOCK;
@@ -728,6 +729,31 @@ __device__ __forceinline__ void scatter_item(const float* __restrict__ x, const 
                     for (int c = 0; c < 8; ++c) hit |= (idx[c] - begin < count) ? (1u << c) : 0u;
                 }
                 const float2 gy = pg[u];
+                if (mode == 1) {
+                    // power-of-two table: the corners come as x-pairs that share (cy P1) ^ (cz P2) and the y, z weights,
+                    // and the routing kernel's mask almost always holds whole pairs: one trip per PAIR (usually one,
+                    // at most four per record) instead of one per corner
+                    uint32_t pm = (hit | (hit >> 1)) & 0x55u;
+                    while (pm) {
+                        const int c = __ffs((int)pm) - 1;               // the pair's x corner: 0, 2, 4, 6
+                        pm &= pm - 1u;
+                        const uint32_t hz = ((cell.c[1] + ((c >> 1) & 1)) * P1) ^ ((cell.c[2] + ((c >> 2) & 1)) * P2);
+                        const float wy = (c & 2) ? cell.f[1] : 1.0f - cell.f[1], wz = (c & 4) ? cell.f[2] : 1.0f - cell.f[2];
+                        if (hit >> c & 1u) {
+                            const uint32_t e = ((cell.c[0] ^ hz) & (size - 1u)) - begin;
+                            const float wgt = ((1.0f - cell.f[0]) * wy) * wz;       // (the order of corner_weights)
+                            atomicAdd(&acc[2 * e], (double)(wgt * gy.x));
+                            atomicAdd(&acc[2 * e + 1], (double)(wgt * gy.y));
+                        }
+                        if (hit >> (c + 1) & 1u) {
+                            const uint32_t e = (((cell.c[0] + 1u) ^ hz) & (size - 1u)) - begin;
+                            const float wgt = (cell.f[0] * wy) * wz;
+                            atomicAdd(&acc[2 * e], (double)(wgt * gy.x));
+                            atomicAdd(&acc[2 * e + 1], (double)(wgt * gy.y));
+                        }
+                    }
+                    continue;
+                }
                 while (hit) {
                     const int c = __ffs((int)hit) - 1;
                     hit &= hit - 1u;
@@ -802,7 +828,8 @@ __device__ __forceinline__ void scatter_item(const float* __restrict__ x, const 
 #pragma unroll
         for (uint32_t k = 0; k < FL; ++k) {
             const uint32_t e = threadIdx.x + k * SC_BLOCK;
-            if (e < count) dst[e] = make_float2(cur[k].x + (float)a2[e].x, cur[k].y + (float)a2[e].y);
+            if (e < count) dst[e] = plan.fresh ? make_float2((float)a2[e].x, (float)a2[e].y)
+                                               : make_float2(cur[k].x + (float)a2[e].x, cur[k].y + (float)a2[e].y);
         }
     } else {
         float2* pdst = reinterpret_cast<float2*>(reinterpret_cast<float*>(ws) + plan.w_partial) +
@@ -943,7 +970,7 @@ __global__ __launch_bounds__(256) void hashgrid_scatter_reduce_kernel(float* __r
     const float2* p2 = reinterpret_cast<const float2*>(reinterpret_cast<const float*>(ws) + plan.w_partial) +
                        (size_t)cw[plan.w_first + bin] * SC_MAX_SLICE + e;
     float2* d = reinterpret_cast<float2*>(dparams) + g.offsets[level] + begin + e;
-    float2 cur = *d;
+    float2 cur = plan.fresh ? make_float2(0.f, 0.f) : *d;
     // eight partial slices in flight (a load per iteration was one memory round trip per part: 11 parts on the coarsest
     // levels, 10 us for 10 MB); the sum keeps the order part 0, 1, 2, ...
     float2 a = make_float2(0.f, 0.f);
@@ -1198,7 +1225,7 @@ uint64_t mipsf_hashgrid_counter_words(const mipsf_grid_meta* meta) {
 
 static int hashgrid_bwd_impl(const float* x, const float* params, const float* dout, float* dparams, float* dx,
                              float* scratch, uint32_t* counters, uint32_t M, const mipsf_grid_meta* meta, int layout,
-                             bool routed, void* stream) {
+                             bool routed, void* stream, bool fresh = false) {
     GridLevels g;
     if (int rc = to_levels(meta, g)) return rc;
     if (M == 0) return 0;
@@ -1206,7 +1233,8 @@ static int hashgrid_bwd_impl(const float* x, const float* params, const float* d
     MIPSF_REQUIRE(dparams || dx, "nothing to compute: dparams and dx are both null");
     MIPSF_REQUIRE(layout == MIPSF_FEAT_AOS || layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout %d", layout);
     hipStream_t s = (hipStream_t)stream;
-    const ScatterPlan plan = make_plan(g, M);
+    ScatterPlan plan = make_plan(g, M);
+    plan.fresh = fresh ? 1u : 0u;
     if (int rc = check_plan(plan, g, M)) return rc;
     uint32_t* ws = reinterpret_cast<uint32_t*>(scratch);
     uint32_t* cw = counters ? counters : ws;     // (without a kept block the counters sit at the front of the scratch)
@@ -1270,6 +1298,18 @@ int mipsf_hashgrid_bwd_keep(const float* x, const float* params, const float* do
                             void* stream) {
     MIPSF_REQUIRE(counters, "null counter block");
     return hashgrid_bwd_impl(x, params, dout, dparams, dx, scratch, counters, M, meta, layout, false, stream);
+}
+
+// the same with flags: MIPSF_HG_DPARAMS_ZERO = the caller vouches that dparams is all zero on entry (a gradient buffer the
+// optimiser cleared, a fresh torch.zeros): the table slices are stored instead of read-modify-written -- 36 MB less to read
+// on the headline table, and a work item of the accumulate kernel no longer waits for its slice's old values
+int mipsf_hashgrid_bwd_keep_ex(const float* x, const float* params, const float* dout, float* dparams, float* dx,
+                               float* scratch, uint32_t* counters, uint32_t M, const mipsf_grid_meta* meta, int layout,
+                               uint32_t flags, void* stream) {
+    MIPSF_REQUIRE(counters, "null counter block");
+    MIPSF_REQUIRE((flags & ~(uint32_t)MIPSF_HG_DPARAMS_ZERO) == 0u, "unknown flags 0x%x", flags);
+    return hashgrid_bwd_impl(x, params, dout, dparams, dx, scratch, counters, M, meta, layout, false, stream,
+                             (flags & MIPSF_HG_DPARAMS_ZERO) != 0u);
 }
 
 int mipsf_hashgrid_bwd_routed(const float* x, const float* params, const float* dout, float* dparams, float* dx,

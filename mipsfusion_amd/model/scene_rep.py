@@ -148,15 +148,19 @@ class _QueryFn(torch.autograd.Function):
                                               wgrad_precision="stream_f16x3" if ctx.lean else ctx.owner.wgrad_precision,
                                               recompute_h1=ctx.lean, return_tiles=True)
         dparams = None
+        fresh_grad = False
         if need_g:
             if direct:
                 if grid_params.grad is None:
                     grid_params.grad = torch.zeros_like(grid_params)
+                    fresh_grad = True
                 dparams = grid_params.grad
             else:
                 dparams = torch.zeros_like(grid_params)
         if need_g:
-            ops.hashgrid_bwd(xn, grid_params.detach(), dfeat, dparams, ctx.meta, FEAT_LEVEL_MAJOR, None, routed=ctx.routed)
+            # (a fresh zeros tensor, or the caller's word that the optimiser left .grad zero: slices are stored, not added)
+            ops.hashgrid_bwd(xn, grid_params.detach(), dfeat, dparams, ctx.meta, FEAT_LEVEL_MAJOR, None, routed=ctx.routed,
+                             dparams_zero=(not direct) or fresh_grad or ctx.owner.grid_grad_is_zero_at_backward)
             ctx.routed = None
         if need_x:
             ops.hashgrid_dx_from_jac(jac, dfeat, dx, ctx.meta, FEAT_LEVEL_MAJOR, tiles=tiles)   # (dfeat is untouched since the chain wrote it)
@@ -213,6 +217,11 @@ class JointEncoding(nn.Module):
         self._half64 = torch.as_tensor(coords_norm_factor).detach().to("cpu", torch.float64).reshape(-1).tolist()
         # extension, off by default: see _QueryFn (plain `loss.backward()` loops may opt in)
         self.accumulate_param_grads_in_place = False
+        # with accumulate_param_grads_in_place: the caller's word that the table's .grad is all zero whenever a backward
+        # pass starts (ONE backward per optimiser step, and the optimiser clears the gradients: FusedAdam.step(zero_grad=True)
+        # / the captured loops) -- the grid scatter then stores its slices instead of adding to the old values.  Wrong
+        # gradients if the promise is broken (several backward passes accumulated before a step): off by default.
+        self.grid_grad_is_zero_at_backward = False
         # arithmetic of the decoder's three hidden layers (csrc/decoder16.hip):
         #   "f16x3" f16 matrix cores on hi/lo split operands, fp32 accumulate: ~3e-7 relative, passes the reference
         #           goldens at the fp32 kernel's tolerances at 2.4x its speed (default)
@@ -297,6 +306,7 @@ class JointEncoding(nn.Module):
         new.load_state_dict(self.state_dict())
         new.initial_dict = copy.deepcopy(self.initial_dict)
         new.accumulate_param_grads_in_place = self.accumulate_param_grads_in_place
+        new.grid_grad_is_zero_at_backward = self.grid_grad_is_zero_at_backward
         new.decoder_precision = self.decoder_precision
         new.wgrad_precision = self.wgrad_precision
         new.lean_record = self.lean_record

@@ -170,8 +170,15 @@ def _scatter_counters(device, meta):
     return buf
 
 
-def hashgrid_bwd(x, params, dout, dparams, meta, layout=FEAT_AOS, dx: Optional[torch.Tensor] = None, routed=None):
-    """dparams (and dx when given) are accumulated into.  routed: (scratch, event) of hashgrid_route_ahead for this x."""
+HG_DPARAMS_ZERO = 1     # include/mipsf.h MIPSF_HG_DPARAMS_ZERO
+_HG_IGNORE_ZERO_HINT = bool(os.environ.get("MIPSF_HG_IGNORE_ZERO_HINT"))     # experiments: always read-modify-write
+
+
+def hashgrid_bwd(x, params, dout, dparams, meta, layout=FEAT_AOS, dx: Optional[torch.Tensor] = None, routed=None,
+                 dparams_zero=False):
+    """dparams (and dx when given) are accumulated into.  routed: (scratch, event) of hashgrid_route_ahead for this x.
+    dparams_zero: the caller vouches that dparams is all zero now (a fresh torch.zeros, a gradient buffer the optimiser
+    cleared): the table slices are stored instead of read-modify-written."""
     M = x.shape[0]
     if PROFILE is not None:
         global _LAST_SCATTER_DOUT
@@ -187,8 +194,9 @@ def hashgrid_bwd(x, params, dout, dparams, meta, layout=FEAT_AOS, dx: Optional[t
     scratch = torch.empty(n, dtype=torch.float32, device=x.device)
     counters = _scatter_counters(x.device, meta)
     with _timed("hashgrid_bwd"):
-        check(lib().mipsf_hashgrid_bwd_keep(dptr(x), dptr(params), dptr(dout), dptr(dparams), dptr(dx), dptr(scratch),
-                                            dptr(counters, torch.int32), M, C.byref(meta), layout, stream_ptr()), "hashgrid_bwd")
+        check(lib().mipsf_hashgrid_bwd_keep_ex(dptr(x), dptr(params), dptr(dout), dptr(dparams), dptr(dx), dptr(scratch),
+                                               dptr(counters, torch.int32), M, C.byref(meta), layout,
+                                               HG_DPARAMS_ZERO if (dparams_zero and not _HG_IGNORE_ZERO_HINT) else 0, stream_ptr()), "hashgrid_bwd")
 
 
 def hashgrid_indices(x, meta) -> torch.Tensor:
@@ -220,7 +228,7 @@ class HashGridFn(torch.autograd.Function):
         dparams = torch.zeros_like(params) if ctx.needs_input_grad[1] else None
         dx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
         if dparams is not None:
-            hashgrid_bwd(x, params.detach(), dout, dparams, ctx.meta, FEAT_AOS, None)
+            hashgrid_bwd(x, params.detach(), dout, dparams, ctx.meta, FEAT_AOS, None, dparams_zero=True)
         if dx is not None:
             hashgrid_dx_from_jac(jac[0], dout, dx, ctx.meta, FEAT_AOS)
         return dx, dparams, None

@@ -470,6 +470,7 @@ class GraphedSequence:
         nf = torch.from_numpy(np.array(mp["localMLP_max_len"]))
         self.model = JointEncoding(cfg, bb, nf).to(dev).train()
         self.model.accumulate_param_grads_in_place = True
+        self.model.grid_grad_is_zero_at_backward = True    # every map step is one backward + map_opt.step(zero_grad=True)
         # recover_initial_param() at a switch is a device-to-device copy (the reference's initial_dict sits where the model was built)
         self.model.initial_dict = {k: v.to(dev) for k, v in self.model.initial_dict.items()}
         self.host_rays = [frame_rays(f).pin_memory() for f in frames]        # what a capture thread hands over

@@ -166,6 +166,12 @@ def test_hashgrid_backward_routing_edge_sizes(dev, log2_t, M, sparse):
     ops.hashgrid_bwd(x.to(dev), params.to(dev), dy.reshape(M, 16, 2).permute(1, 0, 2).contiguous().to(dev), dp_lm, meta,
                      _lib.FEAT_LEVEL_MAJOR, None)
     assert_close(dp_lm, dp_ref, 2e-5, "level-major dparams")
+    # MIPSF_HG_DPARAMS_ZERO: a buffer the caller vouches to be zero takes stores instead of read-modify-writes -- same bits
+    dp_z = torch.zeros(ometa.n_params, device=dev)
+    ops.hashgrid_bwd(x.to(dev), params.to(dev), dy.reshape(M, 16, 2).permute(1, 0, 2).contiguous().to(dev), dp_z, meta,
+                     _lib.FEAT_LEVEL_MAJOR, None, dparams_zero=True)
+    assert_close(dp_z, dp_ref, 2e-5, "dparams into a buffer known to be zero")
+    assert float((dp_z - dp_lm).abs().max()) <= 1e-6 * float(dp_ref.abs().max()) + 1e-30
     if sparse and M > 1:        # an all-zero gradient: no records at all, nothing written
         dp0 = torch.zeros(ometa.n_params, device=dev)
         ops.hashgrid_bwd(x.to(dev), params.to(dev), torch.zeros(M, 32, device=dev), dp0, meta, _lib.FEAT_AOS, None)

@@ -51,6 +51,14 @@ for rep in range(3):
     ops.check(lib.mipsf_hashgrid_bwd(ops.dptr(x), ops.dptr(params), ops.dptr(dout), ops.dptr(dparams), None,
                                      ops.dptr(scratch), M, C.byref(meta), layout, ops.stream_ptr()), "bwd")
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for rep in range(20):
+    lib.mipsf_hashgrid_bwd(ops.dptr(x), ops.dptr(params), ops.dptr(dout), ops.dptr(dparams), None,
+                           ops.dptr(scratch), M, C.byref(meta), layout, ops.stream_ptr())
+e1.record()
+torch.cuda.synchronize()
+print(f"whole scatter (clear + route + accumulate + fold, with trace stores): {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per call")
 total = int(scratch[off - 1:off].view(torch.int32).item())
 tr = scratch[off:off + 8 * total].view(torch.int32).cpu().numpy().view(np.uint32).reshape(-1, 8)
 t0 = tr[:, 3].astype(np.int64)
@@ -61,17 +69,22 @@ end = start + dur
 bins = tr[:, 1] & 0xffff
 level = np.searchsorted(np.array(bin0[:L + 1]), bins, side="right") - 1
 print(f"{total} items; span {end.max():.1f} us; sum of item times {dur.sum():.0f} us = {dur.sum() / 256:.1f} us per CU")
+PART = int(os.environ.get("PART", "4096"))
+parts_of = tr[:, 7].astype(np.int64)
+recs_item = np.minimum(tr[:, 2].astype(np.int64) - (tr[:, 1] >> 16).astype(np.int64) * PART, PART)
+print(f"records {recs_item.sum()}; single-part items {(parts_of == 1).sum()}, items of split bins {(parts_of > 1).sum()}")
 for l in range(L):
     m = level == l
     if m.any():
-        print(f"  level {l:2d}: {m.sum():4d} items, records {tr[m, 2].sum() / max(1, (tr[m, 7]).mean()):9.0f}/bin-sum, "
-              f"per item: records {np.minimum(tr[m, 2], 12288 if l < 9 else 24576).mean():7.0f} time mean {dur[m].mean():6.1f} max {dur[m].max():6.1f} us, "
+        print(f"  level {l:2d}: {m.sum():4d} items, records {recs_item[m].sum():9d}, "
+              f"per item: records {recs_item[m].mean():7.0f} time mean {dur[m].mean():6.1f} max {dur[m].max():6.1f} us (sum {dur[m].sum():7.0f}), "
               f"started {start[m].min():6.1f}..{start[m].max():6.1f}")
 wg = tr[:, 6]
-busy = np.bincount(wg, weights=dur, minlength=256)
-nitem = np.bincount(wg, minlength=256)
-last = np.array([end[wg == w].max() if (wg == w).any() else 0 for w in range(256)])
-first = np.array([start[wg == w].min() if (wg == w).any() else 0 for w in range(256)])
+W = int(wg.max()) + 1
+busy = np.bincount(wg, weights=dur, minlength=W)
+nitem = np.bincount(wg, minlength=W)
+last = np.array([end[wg == w].max() if (wg == w).any() else 0 for w in range(W)])
+first = np.array([start[wg == w].min() if (wg == w).any() else 0 for w in range(W)])
 print(f"per workgroup: items {nitem.min()}..{nitem.max()}, busy {busy.min():.1f}..{busy.max():.1f} (mean {busy.mean():.1f}) us, "
       f"first item starts {first.min():.1f}..{first.max():.1f}, last item ends {last.min():.1f}..{last.max():.1f}")
 gaps = (last - first - busy)
