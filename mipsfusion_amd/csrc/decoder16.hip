@@ -33,6 +33,13 @@ __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
 // more v_cvt_pk_f16_f32 for the residuals = 2.5 vector instructions per value
 template <bool SPLIT>
 __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
+#if D16_ABL & 16
+    {
+        const _Float16 c = (_Float16)v[0];
+        hi = h8{c, c, c, c, c, c, c, c}, lo = hi;
+        return;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {
         const h2 p = {(_Float16)v[i], (_Float16)v[i + 1]};
@@ -50,8 +57,16 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
 // well: `buffer_store_dwordx4 v[168:171], .., s44 offen` followed by `v_pk_mul_f32 v[170:171]` stored the NEW values
 // (every first of two back-to-back scaled stores of the backward chain was wrong).  So: constant part of the address in
 // the vector offset (folds into the 12-bit immediate below 4 KB, one v_add above), soffset = 0.
+#ifndef D16_ABL
+#define D16_ABL 0   // experiments (wrong results; forward tile): 1 no heads, 2 no sin, 4 no record stores, 8 no LDS operand reads,
+#endif              // 16 no hi/lo conversions, 32 no ReLU / unscale passes, 64 no softmax
+// Cache policy of the forward's activation record stores: nt (aux bit 1).  The training forward is bound by its stores --
+// 268 MB of record per launch; matrix work + stores alone take as long as the whole kernel (tools/micro/fwd_probe.py with
+// -DD16_ABL=115: 102 us, the full kernel 98) -- and a CU gets through them at ~11 GB/s with the default policy (2.7 TB/s for
+// the device, well under the 6 TB/s a plain write stream reaches); nt stores are acknowledged sooner: the same launch takes
+// 72 us (skeleton) / 87 us (full kernel), the headline step 0.629 -> 0.623 ms.
 #ifndef D16_FWD_STORE_AUX
-#define D16_FWD_STORE_AUX 0      // cache policy of the forward's activation record stores (2 = nt)
+#define D16_FWD_STORE_AUX 2
 #endif
 #ifndef D16_BWD_STORE_AUX
 #define D16_BWD_STORE_AUX 0      // cache policy of the chain's gradient record stores (2 = nt)
@@ -64,10 +79,17 @@ __device__ __forceinline__ void buf_store16_nosoff(srd_t r, uint32_t lane16, uin
 }
 __device__ __forceinline__ void store_act_piece(srd_t sv, uint32_t lane16, int mat, const f32x16 (&acc)[4], int q) {
     const int rt = q >> 2, g = q & 3;
+    if (D16_ABL & 4) return;
     buf_store16_nosoff<D16_FWD_STORE_AUX>(sv, lane16, (mat * 16 + q) * 1024,
                        make_float4(acc[rt][4 * g], acc[rt][4 * g + 1], acc[rt][4 * g + 2], acc[rt][4 * g + 3]));
 }
 
+#ifdef D16_TRACE    // diagnosis builds (tools/micro/fwd_probe.py): cycles between the marks of a forward tile, summed per wave
+__device__ unsigned long long d16_trace[4096 * 16];
+#define D16_MARK(k) do { __builtin_amdgcn_sched_barrier(0); tr_t[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define D16_MARK(k) do { } while (0)
+#endif
 struct NoSide16 {
     __device__ __forceinline__ void operator()(int) const {}
 };
@@ -93,8 +115,13 @@ constexpr float GRID_UPSCALE = (float)(1 << G16_SHIFT);
 struct ImgLds {
     const h8* hi;
     const h8* lo;
+#if D16_ABL & 8
+    __device__ __forceinline__ h8 load_hi(int idx, int lane) const { const _Float16 c = (_Float16)(float)(idx + lane); return h8{c, c, c, c, c, c, c, c}; }
+    __device__ __forceinline__ h8 load_lo(int idx, int lane) const { const _Float16 c = (_Float16)(float)(idx - lane); return h8{c, c, c, c, c, c, c, c}; }
+#else
     __device__ __forceinline__ h8 load_hi(int idx, int lane) const { return hi[idx * 64 + lane]; }
     __device__ __forceinline__ h8 load_lo(int idx, int lane) const { return lo[idx * 64 + lane]; }
+#endif
     __device__ __forceinline__ ImgLds at(int hi_halves, int lo_halves) const { return ImgLds{hi + hi_halves / 8, lo + lo_halves / 8}; }
 };
 struct ImgBuf {
@@ -160,14 +187,36 @@ __device__ __forceinline__ void mfma16_layer(const Img img, int lane, int h, f32
     }
 }
 
-// one wave, one tile of 32 samples.  tail: fp32 head tables (LDS); img_hi / img_lo: the two operand image sets
+// A narrow head (decoder_layout.h, HEAD16): out = W_head * B over 8 k-steps, always hi/lo split (three MFMAs per k-step,
+// two accumulators so that no MFMA waits for the one in front of it: acc0 = hi*hi + lo*hi, acc1 = hi*lo).  himg: the head's
+// compact image in LDS ([t][plane][SLOTS] 16-byte operands), slot: this lane's operand slot.
+template <int SLOTS, typename BFn, typename SideFn = NoSide16>
+__device__ __forceinline__ void mfma16_head(const h8* himg, int slot, f32x16& acc0, f32x16& acc1, BFn bfn, SideFn side = SideFn()) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    h8 ah = himg[slot], al = himg[SLOTS + slot], nh, nl, bh, bl, nbh, nbl;
+    bfn(0, bh, bl);
+#pragma unroll
+    for (int t = 0; t < T16_HEAD; ++t) {
+        if (t + 1 < T16_HEAD) nh = himg[(2 * t + 2) * SLOTS + slot], nl = himg[(2 * t + 3) * SLOTS + slot];
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = mfma16(ah, bh, t == 0 ? zero : acc0);
+        acc1 = mfma16(ah, bl, t == 0 ? zero : acc1);
+        acc0 = mfma16(al, bh, acc0);
+        if (t + 1 < T16_HEAD) bfn(t + 1, nbh, nbl);
+        side(t);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < T16_HEAD) ah = nh, al = nl, bh = nbh, bl = nbl;
+    }
+}
+
+// one wave, one tile of 32 samples.  tail: head images + head biases (LDS); img_hi / img_lo: the two operand image sets
 // SAVE: 0 no record, 1 the full activation record, 2 the LEAN record -- H2, H3 and the ReLU masks; H1 (a third of the
 // record) is left out: the streaming weight-gradient kernel recomputes it from x (wgrad16.hip) and nothing else reads it
 template <int LAYOUT, int SAVE, bool SDF_ONLY, bool SPLIT, typename Img>
 __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img img,
                                                    const float* __restrict__ feat, const float* __restrict__ x,
                                                    float* __restrict__ out, float* __restrict__ saved, uint32_t M,
-                                                   int pin, int64_t tile, int lane) {
+                                                   int pin, int64_t tile, int lane, float (&xq)[3], int64_t next_tile) {
     const int j = lane & 31, h = lane >> 5;
     const uint32_t s_raw = (uint32_t)(tile * 32 + j);
     const bool live = s_raw < M;
@@ -175,9 +224,23 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
     const uint32_t lane16 = 16u * (uint32_t)lane;
     const srd_t sv = make_srd(SAVE ? saved + (size_t)tile * ACT_TILE_FLOATS : saved, SAVE ? ACT_TILE_FLOATS * 4 : 0);
 
+#ifdef D16_TRACE
+    unsigned long long tr_t[12];
+    const unsigned long long tr_w0 = wall_clock64();
+#endif
+    D16_MARK(0);
+    // xq: this tile's coordinates, loaded by the caller / by the previous tile of this wave BEFORE its record stores: memory
+    // operations retire in order, and a load issued behind the 16 + stores of a tile waits for all of them (the e phase of the
+    // training forward took 2800 cycles instead of 1600, tools/micro/fwd_probe.py)
     float ev[E_SLOTS];
-    load_e<true>(x, nullptr, s, h, ev);
+#if D16_ABL & 2
+#pragma unroll
+    for (int k = 0; k < E_SLOTS; ++k) ev[k] = xq[k % 3] * (float)(k + 1);
+#else
+    e_from_x(xq[0], xq[1], xq[2], h, ev);
+#endif
 
+    D16_MARK(1);
     // ---- layer 1: pts_linear.0 + ReLU   (bias: elements BIAS16_U, +1 of k-step BIAS16_T meet the constant 1.0)
     f32x16 H1[4];
     mfma16_layer<RT_F1, T16_F1, SPLIT, INIT_ZERO>(img.at(OFF16H_F1, OFF16L_F1), lane, h, H1,
@@ -190,13 +253,15 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
             }
             split8<SPLIT>(v, bh, bl);
         });
+    D16_MARK(2);
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) H1[rt][r] = relu1(H1[rt][r] * ACC_UNSCALE);
+        for (int r = 0; r < 16; ++r) if (!(D16_ABL & 32)) H1[rt][r] = relu1(H1[rt][r] * ACC_UNSCALE);
     uint32_t m1[2] = {0u, 0u};
     if (SAVE) relu_masks(H1, m1);
 
+    D16_MARK(3);
     // ---- layer 2: pts_linear.2 -> [sdf_emb | rgb_emb]   (H1 leaves in two 16-byte pieces per k-step)
     constexpr int RT2 = SDF_ONLY ? 2 : RT_F2;
     f32x16 H2[RT2];
@@ -214,10 +279,11 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
             }
         });
 
+    D16_MARK(4);
 #pragma unroll
     for (int rt = 0; rt < RT2; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) H2[rt][r] = H2[rt][r] * ACC_UNSCALE;
+        for (int r = 0; r < 16; ++r) if (!(D16_ABL & 32)) H2[rt][r] = H2[rt][r] * ACC_UNSCALE;
 
     // grid features of layer 3 (feature h of the 16 levels): requested before the rgb head, which covers the latency
     float gf[16];
@@ -227,43 +293,44 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
 #pragma unroll
         for (int u = 0; u < 16; ++u)
             gf[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(fs, voff, (uint32_t)u * M * 8u, 0));
+    } else if (LAYOUT == MIPSF_FEAT_AOS && M < (1u << 24)) {
+        const srd_t fs = make_srd(feat, M * 128u);        // [sample][level][feature]: one lane offset, 16 immediates
+        const uint32_t voff = s * 128u + (uint32_t)h * 4u;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) gf[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(fs, voff, (uint32_t)u * 8u, 0));
     } else {
 #pragma unroll
         for (int u = 0; u < 16; ++u) gf[u] = load_feat<LAYOUT>(feat, s, u, h, M);
     }
 
-    // ---- rgb_linear.0 on the vector ALU, fp32 (3 outputs): this lane's half of every dot product, then one swap
+    D16_MARK(5);
+    // ---- rgb_linear.0 (3 outputs from [rgb_emb = H2 row tiles 2, 3 | e]) on the matrix pipe: rows 0..2 of one tile
     float rgb[3] = {0.f, 0.f, 0.f};
     if constexpr (!SDF_ONLY) {
-        float pr[3];
-        const float4* trgb = reinterpret_cast<const float4*>(tail) + h * TRGB_SLOTS;
-        f32x2 p01 = {0.f, 0.f};
-        float p2 = 0.f;
+        f32x16 r0, r1;
+        mfma16_head<HEAD16_RGB_SLOTS>(reinterpret_cast<const h8*>(tail) + HEAD16_SDF_HALVES / 8, head16_rgb_slot(j, h), r0, r1,
+            [&](int t, h8& bh, h8& bl) {
+                float v[8];
 #pragma unroll
-        for (int slot = 0; slot < 32; ++slot) {
-            const float4 wv = trgb[slot];
-            const float v = H2[2 + (slot >> 4)][slot & 15];
-            p01 = __builtin_elementwise_fma(f32x2{wv.x, wv.y}, f32x2{v, v}, p01);
-            p2 = fmaf(wv.z, v, p2);
-        }
+                for (int u = 0; u < 8; ++u)
+                    v[u] = t < 4 ? H2[2 + (t >> 1)][8 * (t & 1) + u] : (8 * (t - 4) + u < E_SLOTS ? ev[8 * (t - 4) + u] : 0.0f);
+                split8<true>(v, bh, bl);
+            },
+            [&](int t) {       // the rgb_emb half of H2 leaves piece by piece behind the k-steps that read it: a burst of
+                               // 8 (and of 16 for H3 below) stalls on the store path's back pressure (1300 / 1900 cycles)
+                if constexpr (SAVE != 0) {
+                    if (t < 4) {
+                        store_act_piece(sv, lane16, 1, H2, 8 + 2 * t);
+                        store_act_piece(sv, lane16, 1, H2, 8 + 2 * t + 1);
+                    }
+                }
+            });
 #pragma unroll
-        for (int t = 0; t < E_SLOTS; ++t) {
-            const float4 wv = trgb[32 + t];
-            p01 = __builtin_elementwise_fma(f32x2{wv.x, wv.y}, f32x2{ev[t], ev[t]}, p01);
-            p2 = fmaf(wv.z, ev[t], p2);
-        }
-        pr[0] = p01.x, pr[1] = p01.y, pr[2] = p2;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) rgb[c] = (pr[c] + __shfl_xor(pr[c], 32, 64)) + tail[OFF_BSMALL - OFF_TRGB + c];
+        for (int c = 0; c < 3; ++c) rgb[c] = (r0[c] + r1[c]) * ACC_UNSCALE + tail[OFF16_BSMALL + c];      // (half 0's; half 1 holds zeros)
     }
 
-    // the rgb_emb half of H2 is dead after the head above: it leaves now (its 32 registers are free during layer 3;
-    // holding them for a trickled store pushed the SAVE variants into scratch spills)
-    if constexpr (SAVE && !SDF_ONLY) {
-#pragma unroll
-        for (int q = 8; q < 16; ++q) store_act_piece(sv, lane16, 1, H2, q);
-    }
-
+    D16_MARK(6);
+    D16_MARK(7);
     // ---- layer 3: sdf_linear.0 + ReLU on [sdf_emb (H2 tiles 0,1) | grid features]
     f32x16 H3[4];
     mfma16_layer<RT_F3, T16_F3, SPLIT, INIT_BIAS>(img.at(OFF16H_F3, OFF16L_F3), lane, h, H3,
@@ -282,13 +349,17 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
                 }
             }
         });
+    if (next_tile >= 0) {            // the next tile's coordinates, in front of this tile's remaining stores
+        const uint32_t sn_raw = (uint32_t)(next_tile * 32 + j);
+        const uint32_t sn = sn_raw < M ? sn_raw : M - 1;
+        xq[0] = x[3 * (size_t)sn], xq[1] = x[3 * (size_t)sn + 1], xq[2] = x[3 * (size_t)sn + 2];
+    }
+    D16_MARK(8);
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) H3[rt][r] = relu1(H3[rt][r] * ACC_UNSCALE);
+        for (int r = 0; r < 16; ++r) if (!(D16_ABL & 32)) H3[rt][r] = relu1(H3[rt][r] * ACC_UNSCALE);
     if (SAVE) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) store_act_piece(sv, lane16, 2, H3, q);
         uint32_t m3[2];
         relu_masks(H3, m3);
         uint2* mk = reinterpret_cast<uint2*>(saved + (((size_t)M + 127) / 128) * 4 * ACT_TILE_FLOATS) +
@@ -297,42 +368,55 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
         mk[64] = make_uint2(m3[0], m3[1]);
     }
 
-    // ---- sdf_linear.2 (5 logits) on the vector ALU in fp32, softmax, entropy, expected class -> SDF
-    float pl[N_CLASS];
-    {
-        const float4* ts2 = reinterpret_cast<const float4*>(tail) + (OFF_TS2 - OFF_TRGB) / 4 + h * 128;
-        f32x2 q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
-        float q4 = 0.f;
-#pragma unroll
-        for (int slot = 0; slot < 64; ++slot) {
-            const float4 w0 = ts2[2 * slot], w1 = ts2[2 * slot + 1];
-            const float v = H3[slot >> 4][slot & 15];
-            q01 = __builtin_elementwise_fma(f32x2{w0.x, w0.y}, f32x2{v, v}, q01);
-            q23 = __builtin_elementwise_fma(f32x2{w0.z, w0.w}, f32x2{v, v}, q23);
-            q4 = fmaf(w1.x, v, q4);
-        }
-        pl[0] = q01.x, pl[1] = q01.y, pl[2] = q23.x, pl[3] = q23.y, pl[4] = q4;
-    }
+    D16_MARK(9);
+    // ---- sdf_linear.2 (5 logits from H3) on the matrix pipe: logit c lands in register c of BOTH halves (decoder_layout.h);
+    // then softmax, entropy, expected class -> SDF
     float lg[N_CLASS], mx = -3.0e38f;
+    {
+        f32x16 s0, s1;
+        mfma16_head<HEAD16_SDF_SLOTS>(reinterpret_cast<const h8*>(tail), head16_sdf_slot(j, h), s0, s1,
+            [&](int t, h8& bh, h8& bl) {
+                float v[8];
 #pragma unroll
-    for (int c = 0; c < N_CLASS; ++c) {
-        lg[c] = (pl[c] + __shfl_xor(pl[c], 32, 64)) + tail[OFF_BSMALL - OFF_TRGB + 4 + c];
-        mx = fmaxf(mx, lg[c]);
+                for (int u = 0; u < 8; ++u) v[u] = H3[t >> 1][8 * (t & 1) + u];
+                split8<true>(v, bh, bl);
+            },
+            [&](int t) {
+                if constexpr (SAVE != 0) {
+                    store_act_piece(sv, lane16, 2, H3, 2 * t);
+                    store_act_piece(sv, lane16, 2, H3, 2 * t + 1);
+                }
+            });
+#pragma unroll
+        for (int c = 0; c < N_CLASS; ++c) {
+            lg[c] = (s0[c] + s1[c]) * ACC_UNSCALE + tail[OFF16_BSMALL + 4 + c];
+            mx = fmaxf(mx, lg[c]);
+        }
     }
+    D16_MARK(10);
     float p[N_CLASS], den = 0.f;
 #pragma unroll
     for (int c = 0; c < N_CLASS; ++c) {
-        p[c] = expf(lg[c] - mx);
+        p[c] = (D16_ABL & 64) ? lg[c] : expf(lg[c] - mx);
         den += p[c];
     }
     float ent = 0.f, cls = 0.f;
 #pragma unroll
     for (int c = 0; c < N_CLASS; ++c) {
         p[c] = p[c] / den;
-        ent += p[c] * log2f(p[c] + 1e-5f);
+        ent += (D16_ABL & 64) ? p[c] : p[c] * log2f(p[c] + 1e-5f);
         cls += p[c] * (float)c;
     }
     const float sdf = (cls / 4.0f - 0.5f) * 2.0f;
+#ifdef D16_TRACE
+    D16_MARK(11);
+    if (lane == 0) {
+        const unsigned w = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 4095u;
+        for (int k = 0; k < 11; ++k) d16_trace[w * 16 + k] += tr_t[k + 1] - tr_t[k];
+        d16_trace[w * 16 + 12] += wall_clock64() - tr_w0;       // 100 MHz
+        d16_trace[w * 16 + 15] += 1ull;
+    }
+#endif
     if (SDF_ONLY) {
         if (live && h == 0) out[s] = sdf;
         return;
@@ -359,22 +443,28 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_fwd_kernel(const float
     // forward: a memset in front of that kernel was a launch of its own (4.4 us of a step)
     if (clear_hdr != nullptr && blockIdx.x == 0)
         for (int q = threadIdx.x; q < (int)TL_HEADER; q += DEC_BLOCK) clear_hdr[q] = 0u;
-    __shared__ float4 tailbuf[TAIL_F4];
-    for (int q = threadIdx.x; q < TAIL_F4; q += DEC_BLOCK) tailbuf[q] = reinterpret_cast<const float4*>(packed16)[q];
+    __shared__ float4 tailbuf[TAIL16_FLOATS / 4];
+    for (int q = threadIdx.x; q < TAIL16_FLOATS / 4; q += DEC_BLOCK) tailbuf[q] = reinterpret_cast<const float4*>(packed16)[q];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (tile * 32 >= (int64_t)M) return;
-    const ImgBuf img{make_srd(packed16 + TAIL_FLOATS, (IMG16H_HALVES + IMG16L_HALVES) * 2), 0u, (uint32_t)IMG16H_HALVES * 2u};
+    const ImgBuf img{make_srd(packed16 + TAIL16_FLOATS, (IMG16H_HALVES + IMG16L_HALVES) * 2), 0u, (uint32_t)IMG16H_HALVES * 2u};
+    float xq[3];
+    {
+        const uint32_t s_raw = (uint32_t)(tile * 32 + (lane & 31));
+        const uint32_t s0 = s_raw < M ? s_raw : M - 1;
+        xq[0] = x[3 * (size_t)s0], xq[1] = x[3 * (size_t)s0 + 1], xq[2] = x[3 * (size_t)s0 + 2];
+    }
     decoder16_fwd_tile<LAYOUT, SAVE, SDF_ONLY, SPLIT>(reinterpret_cast<const float*>(tailbuf), img, feat, x, out, saved, M,
-                                                      pin, tile, lane);
+                                                      pin, tile, lane, xq, (int64_t)-1);
 }
 
 // Large batches: persistent, one 8-wave workgroup per CU with the operand images (80 KB hi, + 72 KB lo when SPLIT) and
 // the head tables in LDS for its whole share of the batch (cf. decoder_fwd_lds_kernel).
 constexpr int F16_LDS_BLOCK = 512;
 template <bool SPLIT>
-constexpr int f16_lds_bytes() { return TAIL_FLOATS * 4 + IMG16H_HALVES * 2 + (SPLIT ? IMG16L_HALVES * 2 : 0); }
+constexpr int f16_lds_bytes() { return TAIL16_FLOATS * 4 + IMG16H_HALVES * 2 + (SPLIT ? IMG16L_HALVES * 2 : 0); }
 template <int LAYOUT, int SAVE, bool SDF_ONLY, bool SPLIT>
 __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_fwd_lds_kernel(const float* __restrict__ packed16,
                                                                              const float* __restrict__ feat,
@@ -386,28 +476,57 @@ __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_fwd_lds_kernel(con
     if (clear_hdr != nullptr && blockIdx.x == 0)      // (see decoder16_fwd_kernel)
         for (int q = threadIdx.x; q < (int)TL_HEADER; q += F16_LDS_BLOCK) clear_hdr[q] = 0u;
     extern __shared__ __attribute__((aligned(16))) float4 wbuf[];
-    {
-        constexpr int N4 = f16_lds_bytes<SPLIT>() / 16;
-        const float4* src = reinterpret_cast<const float4*>(packed16);
-        for (int q = threadIdx.x; q < N4; q += F16_LDS_BLOCK) wbuf[q] = src[q];
+#ifdef D16_TRACE
+    const unsigned long long tr_k0 = wall_clock64();
+#endif
+    {   // 160 KB per workgroup: ten 16-byte loads in flight per thread, then their LDS stores (a load -> store loop waits
+        // out one L2 round trip per iteration: 20 of them, 6 us of a 70 us launch)
+        constexpr int N4 = f16_lds_bytes<SPLIT>() / 16, BATCH = 10;
+        const srd_t src = make_srd(packed16, (uint32_t)N4 * 16u);
+#pragma unroll 1
+        for (int q0 = threadIdx.x; q0 < N4; q0 += BATCH * F16_LDS_BLOCK) {
+            float4 r[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) r[k] = buf_load16(src, 16u * (uint32_t)(q0 + k * F16_LDS_BLOCK), 0u);   // (past the end: zeros)
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k)
+                if (q0 + k * F16_LDS_BLOCK < N4) wbuf[q0 + k * F16_LDS_BLOCK] = r[k];
+        }
     }
     __syncthreads();
+#ifdef D16_TRACE
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned w = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 4095u;
+        d16_trace[w * 16 + 13] = tr_k0, d16_trace[w * 16 + 14] = wall_clock64();
+    }
+#endif
     const int lane = threadIdx.x & 63;
     // EXPERIMENT (pin >> 8 = number of s_sleep(127)): delay the second wave of every SIMD so that the two co-resident
     // waves are not in the same phase (both converting, then both wanting the matrix pipe)
     if ((threadIdx.x >> 6) >= 4)
         for (int q = 0; q < (pin >> 8); ++q) __builtin_amdgcn_s_sleep(127);
     pin &= 255;
-    for (uint32_t tile = blockIdx.x * (F16_LDS_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-         tile < n_tiles; tile += gridDim.x * (F16_LDS_BLOCK / 64)) {
+    const uint32_t tile0 = blockIdx.x * (F16_LDS_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t stride = gridDim.x * (F16_LDS_BLOCK / 64);
+    float xq[3] = {0.f, 0.f, 0.f};
+    if (tile0 < n_tiles) {
+        const uint32_t s_raw = tile0 * 32u + (uint32_t)(lane & 31);
+        const uint32_t s0 = s_raw < M ? s_raw : M - 1;
+        xq[0] = x[3 * (size_t)s0], xq[1] = x[3 * (size_t)s0 + 1], xq[2] = x[3 * (size_t)s0 + 2];
+    }
+    for (uint32_t tile = tile0; tile < n_tiles; tile += stride) {
         uint32_t z = 0;                       // opaque zero: keeps the loop-invariant LDS operand reads inside the loop
         asm volatile("" : "+v"(z));
         const float4* w4 = wbuf + z;
-        const h8* imgp = reinterpret_cast<const h8*>(w4 + TAIL_FLOATS / 4);
+        const h8* imgp = reinterpret_cast<const h8*>(w4 + TAIL16_FLOATS / 4);
         decoder16_fwd_tile<LAYOUT, SAVE, SDF_ONLY, SPLIT>(reinterpret_cast<const float*>(w4),
                                                           ImgLds{imgp, imgp + IMG16H_HALVES / 8}, feat, x, out, saved, M,
-                                                          pin, (int64_t)tile, lane);
+                                                          pin, (int64_t)tile, lane, xq,
+                                                          tile + stride < n_tiles ? (int64_t)(tile + stride) : (int64_t)-1);
     }
+#ifdef D16_TRACE
+    if (lane == 0) d16_trace[((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 4095u) * 16 + 11] = wall_clock64();
+#endif
 }
 
 // ============================================================================ backward chain on the f16 matrix cores
@@ -672,7 +791,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_bwd_kernel(const float
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (tile * 32 >= (int64_t)M) return;
-    const ImgBuf bimg{make_srd(reinterpret_cast<const _Float16*>(packed16 + TAIL_FLOATS) + OFF16_BWD_HALVES,
+    const ImgBuf bimg{make_srd(reinterpret_cast<const _Float16*>(packed16 + TAIL16_FLOATS) + OFF16_BWD_HALVES,
                                IMG16B_HALVES * 4), 0u, (uint32_t)IMG16B_HALVES * 2u};
     decoder16_bwd_tile<LAYOUT>(bimg, x, out, dout, saved, dfeat, dx, dact, dsmall, M, tile, lane, tile_live);
 }
@@ -695,7 +814,7 @@ __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_bwd_lds_kernel(con
                                                                              uint32_t* __restrict__ tile_live) {
     extern __shared__ __attribute__((aligned(16))) float4 wbuf[];
     {
-        const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const _Float16*>(packed16 + TAIL_FLOATS) +
+        const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const _Float16*>(packed16 + TAIL16_FLOATS) +
                                                             OFF16_BWD_HALVES);
         for (int q = threadIdx.x; q < B16_LDS_BYTES / 16; q += F16_LDS_BLOCK) wbuf[q] = src[q];
     }
@@ -742,9 +861,15 @@ __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_bwd_lds_kernel(con
 
 __global__ __launch_bounds__(256) void decoder_pack16_kernel(W w, float* __restrict__ packed16) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < TAIL_FLOATS) packed16[idx] = packed_value(w, OFF_TRGB + idx);
+    if (idx < HEAD16_HALVES) {
+        int plane;
+        const float v = head16_weight(w, idx, plane);
+        const _Float16 hi = (_Float16)v;
+        reinterpret_cast<_Float16*>(packed16)[idx] = plane == 0 ? hi : (_Float16)(v - (float)hi);
+    }
+    if (idx < 12) packed16[OFF16_BSMALL + idx] = packed_value(w, OFF_BSMALL + idx);
     if (idx < IMG16H_HALVES) {
-        _Float16* img = reinterpret_cast<_Float16*>(packed16 + TAIL_FLOATS);
+        _Float16* img = reinterpret_cast<_Float16*>(packed16 + TAIL16_FLOATS);
         const float v = img16_weight(w, idx);
         const _Float16 hi = (_Float16)v;
         img[idx] = hi;
@@ -752,7 +877,7 @@ __global__ __launch_bounds__(256) void decoder_pack16_kernel(W w, float* __restr
         if (lo >= 0) img[IMG16H_HALVES + lo] = (_Float16)(v - (float)hi);
     }
     if (idx < IMG16B_HALVES) {
-        _Float16* img = reinterpret_cast<_Float16*>(packed16 + TAIL_FLOATS) + OFF16_BWD_HALVES;
+        _Float16* img = reinterpret_cast<_Float16*>(packed16 + TAIL16_FLOATS) + OFF16_BWD_HALVES;
         const float v = img16b_weight(w, idx);
         const _Float16 hi = (_Float16)v;
         img[idx] = hi;
@@ -784,11 +909,21 @@ static uint32_t persist_min_tiles_per_cu() {
 
 extern "C" {
 
+#ifdef D16_TRACE
+int mipsf_d16_trace_read(unsigned long long* host, int clear) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(d16_trace), sizeof(unsigned long long) * 4096 * 16) != hipSuccess) return 1;
+    if (clear) {
+        static unsigned long long z[4096 * 16];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(d16_trace), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 uint32_t mipsf_decoder_packed16_floats(void) { return (uint32_t)PACKED16_FLOATS; }
 
 int mipsf_decoder_pack16(const mipsf_decoder_weights* w, float* packed16, void* stream) {
     MIPSF_REQUIRE(w && packed16, "null pointer");
-    static_assert(IMG16H_HALVES >= TAIL_FLOATS && IMG16H_HALVES >= IMG16B_HALVES, "one thread per hi-image element covers all");
+    static_assert(IMG16H_HALVES >= HEAD16_HALVES && IMG16H_HALVES >= IMG16B_HALVES, "one thread per hi-image element covers all");
     static_assert(f16_lds_bytes<true>() <= 160 * 1024, "tail + both image sets must fit the 160 KB of LDS of a CU");
     hipLaunchKernelGGL(decoder_pack16_kernel, dim3((IMG16H_HALVES + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        to_w16(*w), packed16);

@@ -163,6 +163,17 @@ __device__ __forceinline__ float cos_reduced(float a) {
     f = fmaf(a, C_LO, f);
     return __builtin_amdgcn_cosf(f);
 }
+// the same from coordinates already in registers (in-kernel positional encoding)
+__device__ __forceinline__ void e_from_x(float x0, float x1, float x2, int h, float (&ev)[E_SLOTS]) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float xd = d == 0 ? x0 : (d == 1 ? x1 : x2);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ev[d * 8 + k] = sin_reduced(fmaf(ldexpf(xd, k), PI_F, h ? HALF_PI_F : 0.0f));
+    }
+    ev[24] = h ? x1 : x0;
+    ev[25] = h ? 0.0f : x2;
+}
 template <bool PE_INTERNAL>
 __device__ __forceinline__ void load_e(const float* __restrict__ x, const float* __restrict__ embed_pos,
                                        uint32_t s, int h, float (&ev)[E_SLOTS]) {

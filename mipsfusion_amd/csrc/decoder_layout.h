@@ -190,6 +190,29 @@ constexpr int OFF16L_F2 = OFF16L_F1 + img16_halves(RT_F1, T16_F1);
 constexpr int OFF16L_F3 = OFF16L_F2 + img16_halves(RT_F2, T16_F2);
 constexpr int IMG16L_HALVES = OFF16L_F3 + img16_halves(RT_F3, T16_F3);    // 36 864 halves = 72 KB
 constexpr int TAIL_FLOATS = PACKED_FLOATS - OFF_TRGB;                      // head tables (+ fp32 biases), as in `packed`
+// ---- the two narrow heads (rgb_linear.0: 3 outputs from [rgb_emb | e]; sdf_linear.2: 5 logits from H3) ride on the matrix
+// pipe as well: one accumulator tile each, 8 k-steps, f16x3.  (On the vector ALU -- ~500 fp32 fmas + 187 table reads from
+// LDS per tile -- they were 30 of the evaluation forward's 72 us: tools/micro/fwd_probe.py.)  Only a few of the 32 A-operand
+// rows carry weights, so the images are stored COMPACT: per (k-step, plane) `slots` 16-byte operands -- one per used
+// (row, half) -- plus one of zeros that every other lane reads (a broadcast).
+//   sdf head   rows 0..3 = classes 0..3 and rows 4..7 = classes 0..3 AGAIN, row 8 = row 12 = class 4: with the C/D layout
+//              (row = (r & 3) + 8 (r >> 2) + 4 h) BOTH halves of a lane pair end up with logit c in register c -- no exchange
+//   rgb head   rows 0..2 = colours (half 0 registers 0..2; half 1 does not need them)
+// [sdf: t][plane hi, lo][21 slots][8 halves], then [rgb: t][plane][7 slots][8], then 12 floats of head biases (fp32).
+constexpr int T16_HEAD = 8;
+constexpr int HEAD16_SDF_SLOTS = 21, HEAD16_RGB_SLOTS = 7;
+constexpr int HEAD16_SDF_HALVES = T16_HEAD * 2 * HEAD16_SDF_SLOTS * 8;    // 2688
+constexpr int HEAD16_RGB_HALVES = T16_HEAD * 2 * HEAD16_RGB_SLOTS * 8;    // 896
+constexpr int HEAD16_HALVES = HEAD16_SDF_HALVES + HEAD16_RGB_HALVES;
+constexpr int OFF16_BSMALL = HEAD16_HALVES / 2;                            // floats: b_rgb0[0..2], pad, b_sdf2[0..4], pad x 3
+constexpr int TAIL16_FLOATS = OFF16_BSMALL + 12;                           // the front of `packed16` (7216 bytes, LDS-resident)
+static_assert(TAIL16_FLOATS % 4 == 0 && HEAD16_HALVES % 8 == 0, "16-byte pieces");
+// operand slot of A-operand lane (row i, half hA) in the compact images
+MIPSF_HD int head16_sdf_slot(int i, int hA) {
+    const int ri = i < 8 ? i : (i == 8 ? 8 : (i == 12 ? 9 : 10));
+    return ri < 10 ? 2 * ri + hA : HEAD16_SDF_SLOTS - 1;
+}
+MIPSF_HD int head16_rgb_slot(int i, int hA) { return i < 3 ? 2 * i + hA : HEAD16_RGB_SLOTS - 1; }
 // ---- backward-chain images (decoder16.hip: decoder16_bwd_kernel), same element order [rt][t][lane][u]; hi set, then lo set
 //   S2T  dH3^T  = Ws2^T  dlogits^T      4 row tiles x 1 k-step  (k = class c: half 0, u = c < 5)
 //   B3   d[sdf_emb|grid]^T = Ws1^T dG3^T 3 x 8                  (k = hidden feature kfeat16)
@@ -234,8 +257,8 @@ MIPSF_HD float img16b_weight(const W& w, int idx) {
     }
 }
 constexpr int OFF16_BWD_HALVES = IMG16H_HALVES + IMG16L_HALVES;            // where the backward sets start (in halves)
-// [tail fp32 | fwd hi | fwd lo | bwd hi | bwd lo]
-constexpr int PACKED16_FLOATS = TAIL_FLOATS + (IMG16H_HALVES + IMG16L_HALVES + 2 * IMG16B_HALVES) / 2;
+// [head images + head biases (TAIL16) | fwd hi | fwd lo | bwd hi | bwd lo]
+constexpr int PACKED16_FLOATS = TAIL16_FLOATS + (IMG16H_HALVES + IMG16L_HALVES + 2 * IMG16B_HALVES) / 2;
 // the two halves a bias contributes: which = 0 -> rne16(b) as a float, 1 -> b - rne16(b)
 MIPSF_HD float bias16_part(float b, int which) {
     const float hi = (float)(_Float16)b;
@@ -266,6 +289,27 @@ MIPSF_HD float img16_weight(const W& w, int idx) {
     if (kind == 1) return w.w_pts2[row * HID + kfeat16(t - 1, h, u)] * sc;
     const int src = src16_f3(t - 1, h, u);
     return w.w_sdf0[row * N_SDF_IN + src] * (src < N_EMB ? sc : pow2f(W16_SHIFT - G16_SHIFT));
+}
+// fp32 value behind half idx of the compact head images (both planes hold the same value here: the packer stores rne16(v)
+// in plane 0 and rne16(v - rne16(v)) in plane 1); plane = which plane idx belongs to
+MIPSF_HD float head16_weight(const W& w, int idx, int& plane) {
+    const float sc = pow2f(W16_SHIFT);
+    const bool sdf = idx < HEAD16_SDF_HALVES;
+    const int rel = sdf ? idx : idx - HEAD16_SDF_HALVES;
+    const int slots = sdf ? HEAD16_SDF_SLOTS : HEAD16_RGB_SLOTS;
+    const int u = rel & 7, g = rel >> 3;
+    const int slot = g % slots, tp = g / slots;
+    plane = tp & 1;
+    const int t = tp >> 1;
+    if (slot == slots - 1) return 0.f;
+    const int ri = slot >> 1, hA = slot & 1;
+    if (sdf) {
+        const int c = ri < 8 ? (ri & 3) : 4;
+        return w.w_sdf2[c * HID + kfeat16(t, hA, u)] * sc;
+    }
+    if (t < 4) return w.w_rgb0[ri * N_RGB_IN + kfeat16(t, hA, u)] * sc;          // rgb_emb = H2 row tiles 2, 3
+    const int e = e16(t - 4, hA, u);
+    return e < 0 ? 0.f : w.w_rgb0[ri * N_RGB_IN + N_EMB + e] * sc;
 }
 // index in the LO image set of hi-image element idx, or -1 (bias k-steps have no lo part)
 MIPSF_HD int img16_lo_index(int idx) {

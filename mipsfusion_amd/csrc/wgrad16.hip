@@ -749,7 +749,7 @@ __global__ __launch_bounds__(W16_BLOCK, 2) void decoder_wgrad16_kernel(const flo
     static_assert(T16H_F1 == T16_F1, "layer 1 has no separate bias k-step");
     __shared__ h8 w1img[RECOMP ? 2 * W1_ENTRIES : 1];
     if constexpr (RECOMP) {
-        const h8* img = reinterpret_cast<const h8*>(packed16 + TAIL_FLOATS);
+        const h8* img = reinterpret_cast<const h8*>(packed16 + TAIL16_FLOATS);
         for (int q = tid; q < W1_ENTRIES; q += W16_BLOCK) {
             w1img[q] = img[OFF16H_F1 / 8 + q];
             w1img[W1_ENTRIES + q] = img[(IMG16H_HALVES + OFF16L_F1) / 8 + q];
