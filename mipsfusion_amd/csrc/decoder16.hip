@@ -431,6 +431,24 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
     }
 }
 
+// n16 16-byte pieces of src -> LDS, by a whole workgroup of BLOCK threads: ten loads in flight per thread, then their LDS
+// stores (a load -> store loop waits out one L2 round trip per iteration: 20 of them for the 160 KB of operand images, 6 us of
+// a 70 us launch; this form 3 us)
+template <int BLOCK>
+__device__ __forceinline__ void lds_preload(float4* dst, const void* src_base, int n16) {
+    constexpr int BATCH = 10;
+    const srd_t src = make_srd(src_base, (uint32_t)n16 * 16u);
+#pragma unroll 1
+    for (int q0 = threadIdx.x; q0 < n16; q0 += BATCH * BLOCK) {
+        float4 r[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) r[k] = buf_load16(src, 16u * (uint32_t)(q0 + k * BLOCK), 0u);   // (past the end: zeros)
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k)
+            if (q0 + k * BLOCK < n16) dst[q0 + k * BLOCK] = r[k];
+    }
+}
+
 // Small batches: four independent waves per workgroup, operand images from L2, head tables + biases in LDS.
 template <int LAYOUT, int SAVE, bool SDF_ONLY, bool SPLIT>
 __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_fwd_kernel(const float* __restrict__ packed16,
@@ -479,20 +497,7 @@ __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_fwd_lds_kernel(con
 #ifdef D16_TRACE
     const unsigned long long tr_k0 = wall_clock64();
 #endif
-    {   // 160 KB per workgroup: ten 16-byte loads in flight per thread, then their LDS stores (a load -> store loop waits
-        // out one L2 round trip per iteration: 20 of them, 6 us of a 70 us launch)
-        constexpr int N4 = f16_lds_bytes<SPLIT>() / 16, BATCH = 10;
-        const srd_t src = make_srd(packed16, (uint32_t)N4 * 16u);
-#pragma unroll 1
-        for (int q0 = threadIdx.x; q0 < N4; q0 += BATCH * F16_LDS_BLOCK) {
-            float4 r[BATCH];
-#pragma unroll
-            for (int k = 0; k < BATCH; ++k) r[k] = buf_load16(src, 16u * (uint32_t)(q0 + k * F16_LDS_BLOCK), 0u);   // (past the end: zeros)
-#pragma unroll
-            for (int k = 0; k < BATCH; ++k)
-                if (q0 + k * F16_LDS_BLOCK < N4) wbuf[q0 + k * F16_LDS_BLOCK] = r[k];
-        }
-    }
+    lds_preload<F16_LDS_BLOCK>(wbuf, packed16, f16_lds_bytes<SPLIT>() / 16);
     __syncthreads();
 #ifdef D16_TRACE
     if ((threadIdx.x & 63) == 0) {
@@ -600,6 +605,11 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
 #pragma unroll
         for (int c = 0; c < 5; ++c) o2[c] = o[c];
     }
+    // (the coordinates are needed last, but a load issued behind this tile's 48 record stores would wait for all of them:
+    // memory operations retire in order)
+#ifndef D16_BWD_X_LATE
+    const float x0 = x[3 * (size_t)s], x1 = x[3 * (size_t)s + 1], x2 = x[3 * (size_t)s + 2];
+#endif
     const uint2* mk = reinterpret_cast<const uint2*>(saved + (((size_t)M + 127) / 128) * 4 * ACT_TILE_FLOATS) +
                       (size_t)tile * (MASK_TILE_WORDS / 2) + lane;
     const uint2 mk1 = mk[0], mk3 = mk[64];
@@ -753,7 +763,9 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
             }
         });
 
+#ifdef D16_BWD_X_LATE      // experiments: the old place of the load
     const float x0 = x[3 * (size_t)s], x1 = x[3 * (size_t)s + 1], x2 = x[3 * (size_t)s + 2];
+#endif
     float de[E_SLOTS];
 #pragma unroll
     for (int t = 0; t < E_SLOTS; ++t) de[t] = dE[t >> 4][t & 15] * (down * ACC_UNSCALE);
@@ -813,11 +825,7 @@ __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_bwd_lds_kernel(con
                                                                              uint32_t n_tiles,
                                                                              uint32_t* __restrict__ tile_live) {
     extern __shared__ __attribute__((aligned(16))) float4 wbuf[];
-    {
-        const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const _Float16*>(packed16 + TAIL16_FLOATS) +
-                                                            OFF16_BWD_HALVES);
-        for (int q = threadIdx.x; q < B16_LDS_BYTES / 16; q += F16_LDS_BLOCK) wbuf[q] = src[q];
-    }
+    lds_preload<F16_LDS_BLOCK>(wbuf, reinterpret_cast<const _Float16*>(packed16 + TAIL16_FLOATS) + OFF16_BWD_HALVES, B16_LDS_BYTES / 16);
     __syncthreads();
     const int lane = threadIdx.x & 63;
     // Round k: the workgroup's 8 waves take 8 consecutive tiles, wave w the ((w + k) & 7)-th of them (every wave

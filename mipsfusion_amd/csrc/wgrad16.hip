@@ -715,6 +715,333 @@ __device__ __forceinline__ void w16_role_b(const W16Args& a, const typename A::v
     if (h == 0) rec[G_B_SDF0 + 32 * rt + j] = b3, rec[G_B_PTS0 + 32 * rt + j] = b1;
 }
 
+
+// ============================================================================ the EXCHANGE form (lean record, f16 hi/lo)
+// In the roles above every wave prepares all the operands its products need, and most of them are needed by four waves:
+// the four H1 column tiles (each of waves 0..3 recomputed all four: 48 of its ~100 MFMAs), the [sdf_emb | grid] and e
+// column tiles (transposed by each of waves 4..7), and the positional encoding itself (24 sines per lane, evaluated by all
+// eight waves).  Per SIMD and tile that came to 1504 vector + 158 matrix instructions; the kernel was bound by instruction
+// issue (~110 us at the 1.5 GHz the device sustains under this load, 141 us measured), not by its 0.4 GB of reads.
+// Here every shared operand is prepared ONCE per tile, by one wave, and handed to the others through LDS as ready MFMA
+// operand planes (16-byte pieces, lane-linear: conflict-free writes and reads), two buffers in rotation, ONE barrier per tile:
+//     XE  e as the forward's layer-1 operand: k-step t (hi, lo) by wave t          (for tile i + 1, written during tile i)
+//     XA  H1 column tile ct as the product's right-hand planes (yh0, yh1, yl0, yl1) by wave ct
+//     XB  transposed column tiles: sdf_emb 0, sdf_emb 1 (waves 4, 5), grid (wave 6), e 0, e 1 (wave 7, from XE's planes)
+// before the barrier a wave produces, transposes its own gradient blocks (unique to it) and reads nothing of this tile's
+// XA / XB; after it, it multiplies.
+struct W16X {
+    h8* xe;      // [2][4 k-steps][2 planes][64 lanes]
+    h8* xa;      // [2][4 column tiles][4][64]
+    h8* xb;      // [2][5 blocks][4][64]
+};
+constexpr int W16X_XE = 4 * 2 * 64, W16X_XA = 4 * 4 * 64, W16X_XB = 5 * 4 * 64;     // 16-byte entries per buffer
+
+// all LDS writes of this wave done, then the workgroup barrier (NOT __syncthreads: that also waits for every outstanding
+// global load, and the next tile's records are in flight here on purpose)
+__device__ __forceinline__ void w16x_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// k-step t of e (the forward's layer-1 B operand: 8 slots per half; t = 3: raw coordinates + the bias ones) as hi / lo planes
+template <typename A>
+__device__ __forceinline__ void w16x_e_step(int t, float x0, float x1, float x2, int h, typename A::v8& eh, typename A::v8& el) {
+    f32x8 ev;
+    if (t < 3) {
+        const float xd = t == 0 ? x0 : (t == 1 ? x1 : x2);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ev[k] = sin_reduced(fmaf(ldexpf(xd, k), PI_F, h ? HALF_PI_F : 0.0f));
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ev[k] = 0.0f;
+        ev[0] = h ? x1 : x0, ev[1] = h ? 0.0f : x2;                  // slots 24, 25: the raw coordinates
+        ev[BIAS16_U] = 1.0f, ev[BIAS16_U + 1] = 1.0f;                // slots 26, 27 meet the bias halves of the image
+    }
+    eh = next_plane<A, false>(ev), el = next_plane<A, true>(ev);
+}
+
+// acc += X^T Y for ready planes: Y = {yh[0], yh[1], yl[0], yl[1]} (k-steps 0, 1 of the hi / lo plane)
+template <typename A>
+__device__ __forceinline__ void w16x_mac(const typename A::v8 (&X)[2][2], const h8* y, int lane, f32x16& acc) {
+    const h8 yh0 = y[lane], yh1 = y[64 + lane], yl0 = y[128 + lane], yl1 = y[192 + lane];
+    acc = mfma16(X[0][0], yh0, acc);
+    acc = mfma16(X[1][0], yh0, acc);
+    acc = mfma16(X[0][0], yl0, acc);
+    acc = mfma16(X[0][1], yh1, acc);
+    acc = mfma16(X[1][1], yh1, acc);
+    acc = mfma16(X[0][1], yl1, acc);
+}
+template <typename A>
+__device__ __forceinline__ void w16x_put(h8* y, int lane, const typename A::v8 (&Y)[2][2]) {
+    y[lane] = Y[0][0], y[64 + lane] = Y[0][1], y[128 + lane] = Y[1][0], y[192 + lane] = Y[1][1];
+}
+
+// waves 0..3 (w): d w_pts2[w][0..3] = dH2[w]^T H1, d b_pts2; rows 0..15 of the fifth tile (small rows)^T H3[w] -> d w_sdf2,
+// rows 16..31 (small rows)^T {rgb_emb 0 | rgb_emb 1 | e 0 | e 1}[w] -> d w_rgb0.  Produces e k-step w and H1 column tile w.
+template <int LAYOUT, typename A>
+__device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X& lx, const typename A::v8 (&I)[2], int w, int lane) {
+    static_assert(A::SCALED && A::P == 2, "f16 hi/lo arithmetic only");
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t lane16 = 16u * (uint32_t)lane;
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) zero_tile(acc[t]);
+    float bsum = 0.f, bsmall = 0.f, dummy = 0.f;
+    int k_main = 0, k_small = 0;
+    auto act_srd = [&](const float* recs, uint32_t tile) {
+        return make_srd(recs + (size_t)tile * ACT_TILE_FLOATS, ACT_TILE_FLOATS * 4);
+    };
+    const srd_t small_srd = make_srd(a.dsmall, a.M * 32u), x_srd = make_srd(a.x, a.M * 12u);
+    auto load_small = [&](uint32_t tile, f32x8 (&v)[2]) {
+        const uint32_t off = h == 0 ? (tile * 32u + (uint32_t)j) * 32u : 0xfffffff0u;
+        const float4 p = buf_load16(small_srd, off, 0), q = buf_load16(small_srd, off, 16);
+        v[0][0] = p.x, v[0][1] = p.y, v[0][2] = p.z, v[0][3] = p.w, v[0][4] = q.x, v[0][5] = q.y, v[0][6] = q.z, v[0][7] = q.w;
+    };
+    auto load_x = [&](uint32_t tile, float (&v)[3]) {
+        const uint32_t s_raw = tile * 32u + (uint32_t)j;
+        const uint32_t off = (s_raw < a.M ? s_raw : a.M - 1) * 12u;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) v[d] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_srd, off, 4 * d, 0));
+    };
+    f32x8 bX[2], bS[2], bH3[2], bE[2];
+    float xn[3] = {0.f, 0.f, 0.f};           // coordinates of the NEXT tile (its e is produced during this one)
+    uint32_t it = blockIdx.x, par = 0;
+    if (it < a.n_tiles) {
+        const uint32_t t0 = w16_tile(a, it);
+        load_x(t0, xn);
+        load_tile_rows(act_srd(a.dact, t0), 1, w, lane16, bX);
+        load_small(t0, bS);
+        load_tile_rows(act_srd(a.saved, t0), 2, w, lane16, bH3);
+        if (w < 2) load_tile_rows(act_srd(a.saved, t0), 1, 2 + w, lane16, bE);
+        typename A::v8 eh, el;
+        w16x_e_step<A>(w, xn[0], xn[1], xn[2], h, eh, el);
+        lx.xe[(w * 2 + 0) * 64 + lane] = eh, lx.xe[(w * 2 + 1) * 64 + lane] = el;
+        if (it + gridDim.x < a.n_tiles) load_x(w16_tile(a, it + gridDim.x), xn);
+    }
+    w16x_barrier();
+#pragma clang loop unroll(disable)
+    for (; it < a.n_tiles; it += gridDim.x, par ^= 1u) {
+        const bool more = it + gridDim.x < a.n_tiles;
+        const uint32_t nt = more ? w16_tile(a, it + gridDim.x) : w16_tile(a, it);
+        h8* xe = lx.xe + par * W16X_XE;
+        h8* xa = lx.xa + par * W16X_XA;
+        const h8* xb = lx.xb + par * W16X_XB;
+        typename A::v8 X[2][2];
+        // ---- H1 column tile w = e W1[w]^T (the operands swapped: lane = feature, registers = 16 samples; the forward's H1
+        //      bit for bit), ReLU, planes -> XA
+        {
+            f32x16 hacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const h8 eh = xe[(t * 2 + 0) * 64 + lane], el = xe[(t * 2 + 1) * 64 + lane];
+                const h8 wh = a.w1_hi[(w * T16H_F1 + t) * 64 + lane], wl = a.w1_lo[(w * T16_F1 + t) * 64 + lane];
+                hacc = mfma16(eh, wh, hacc);
+                hacc = mfma16(el, wh, hacc);
+                hacc = mfma16(eh, wl, hacc);
+            }
+            typename A::v8 Y[2][2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                f32x8 r;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    r[u] = __builtin_amdgcn_fmed3f(hacc[8 * m + u] * (1.0f / (float)(1 << W16_SHIFT)), 0.0f, __builtin_inff());
+                Y[0][m] = next_plane<A, false>(r);
+                Y[1][m] = next_plane<A, true>(r);
+            }
+            w16x_put<A>(xa + w * 256, lane, Y);
+        }
+        W16_FENCE();
+        // ---- e k-step w of the NEXT tile -> the other XE buffer (read by everybody before the next barrier)
+        if (more) {
+            typename A::v8 eh, el;
+            w16x_e_step<A>(w, xn[0], xn[1], xn[2], h, eh, el);
+            h8* xen = lx.xe + (par ^ 1u) * W16X_XE;
+            xen[(w * 2 + 0) * 64 + lane] = eh, xen[(w * 2 + 1) * 64 + lane] = el;
+            if (it + 2 * gridDim.x < a.n_tiles) load_x(w16_tile(a, it + 2 * gridDim.x), xn);
+        }
+        W16_FENCE();
+        // ---- X = dH2[w]
+        {
+            float rs;
+            const float sx = w16_pick_scale(w16_block_max_bits(bX, 2), k_main, rs);
+            if (rs != 1.0f) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] *= rs;
+                bsum *= rs;
+            }
+            bX[0] *= sx, bX[1] *= sx;
+        }
+        transpose_block<A, true>(bX, I, X, bsum);
+        W16_FENCE();
+        load_tile_rows(act_srd(a.dact, nt), 1, w, lane16, bX);          // the next tile's dH2
+        W16_FENCE();
+        w16x_barrier();
+        // ---- the four H1 column tiles
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) w16x_mac<A>(X, xa + ct * 256, lane, acc[ct]);
+        W16_FENCE();
+        // ---- small rows: (d logits, d rgb)^T H3[w] (rows 0..15), ^T {rgb_emb | e} (rows 16..31)
+        f32x8 sv1[2], sv2[2];
+        {
+            float rs;
+            const float sx = w16_pick_scale(w16_block_max_bits(bS, 1), k_small, rs);
+            if (rs != 1.0f) acc[4] *= rs, bsmall *= rs;
+            bS[0] *= sx;
+        }
+        sv1[0] = bS[0], sv2[0] = bS[0], sv1[1] = bS[0], sv2[1] = bS[0];
+        transpose_block<A, true, 1>(sv1, I, X, bsmall);                             // X = small rows (columns 0..11)
+        W16_FENCE();
+        transpose_mac<A>(bH3, I, X, acc[4]);                                        // H3[w] -> rows 0..15
+        transpose_block<A, false, 1>(sv2, I, X, dummy, 1);                          // the small rows at columns 16..27
+        W16_FENCE();
+        if (w < 2) transpose_mac<A>(bE, I, X, acc[4]);                              // rgb_emb (waves 0, 1)
+        else w16x_mac<A>(X, xb + (3 + (w - 2)) * 256, lane, acc[4]);                // e column tile w - 2 (waves 2, 3)
+        W16_FENCE();
+        load_small(nt, bS);
+        load_tile_rows(act_srd(a.saved, nt), 2, w, lane16, bH3);
+        if (w < 2) load_tile_rows(act_srd(a.saved, nt), 1, 2 + w, lane16, bE);
+        W16_FENCE();
+    }
+    float* rec = a.rec;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+        flush_mapped(rec, G_W_PTS2, HID, lane, acc[ct], w16_unscale(k_main), [&](int i) { return 32 * w + i; }, [&](int c) { return 32 * ct + c; });
+    flush_mapped(rec, G_W_SDF2, HID, lane, acc[4], w16_unscale(k_small),
+                 [&](int i) { const int r = w16_small_row(i); return r < N_CLASS ? r : -1; }, [&](int c) { return 32 * w + c; });
+    auto rgb_row = [&](int i) { const int r = i >= 16 ? w16_small_row(i - 16) : -1; return r >= N_CLASS ? r - N_CLASS : -1; };
+    if (w < 2)
+        flush_mapped(rec, G_W_RGB0, N_RGB_IN, lane, acc[4], w16_unscale(k_small), rgb_row, [&](int c) { return 32 * w + c; });
+    else
+        flush_mapped(rec, G_W_RGB0, N_RGB_IN, lane, acc[4], w16_unscale(k_small), rgb_row,
+                     [&](int c) { const int e = w16_e_col(w - 2, c); return e >= 0 ? N_EMB + e : -1; });
+    const float b2 = (bsum + __shfl_xor(bsum, 32, 64)) * w16_unscale(k_main);
+    if (h == 0) rec[G_B_PTS2 + 32 * w + j] = b2;
+    if (w == 0) {
+        const float bs = (bsmall + __shfl_xor(bsmall, 32, 64)) * w16_unscale(k_small);
+        const int r = w16_small_row(j);
+        if (h == 0 && r >= 0 && r < N_CLASS) rec[G_B_SDF2 + r] = bs;
+        if (h == 0 && r >= N_CLASS) rec[G_B_RGB0 + r - N_CLASS] = bs;
+    }
+}
+
+// waves 4..7 (rt): d w_sdf0[rt][0..2] = dG3[rt]^T [sdf_emb | grid], d b_sdf0;  d w_pts0[rt][0..1] = dG1[rt]^T e, d b_pts0.
+// Produces the transposed column tiles: rt 0, 1 -> sdf_emb 0, 1; rt 2 -> grid; rt 3 -> e 0 and e 1 (from XE's planes).
+template <int LAYOUT, typename A>
+__device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X& lx, const typename A::v8 (&I)[2], int rt, int lane) {
+    static_assert(A::SCALED && A::P == 2, "f16 hi/lo arithmetic only");
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t lane16 = 16u * (uint32_t)lane;
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) zero_tile(acc[t]);
+    float bsum0 = 0.f, bsum1 = 0.f, dummy = 0.f;
+    int k3 = 0, k1 = 0;
+    f32x8 bG3[2], bG1[2], bY[2];
+    auto act_srd = [&](const float* recs, uint32_t tile) {
+        return make_srd(recs + (size_t)tile * ACT_TILE_FLOATS, ACT_TILE_FLOATS * 4);
+    };
+    const uint64_t feat_bytes = (uint64_t)a.M * N_GRID * 4;
+    const srd_t feat_srd = make_srd(a.feat, feat_bytes > 0xffffffffull ? 0xffffffffu : (uint32_t)feat_bytes);
+    auto load_grid = [&](uint32_t tile, f32x8 (&v)[2]) {
+        const uint32_t s_raw = tile * 32u + (uint32_t)j;
+        const uint32_t s_c = s_raw < a.M ? s_raw : a.M - 1;
+        const uint32_t voff = LAYOUT == MIPSF_FEAT_AOS ? s_c * (uint32_t)(N_GRID * 4) + 4u * (uint32_t)h : (s_c * 2u + (uint32_t)h) * 4u;
+        const uint32_t lstride = LAYOUT == MIPSF_FEAT_AOS ? 8u : a.M * 8u;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[q][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(feat_srd, voff, (uint32_t)(8 * q + u) * lstride, 0));
+    };
+    auto load_mine = [&](uint32_t tile) {                 // what this wave transposes for everybody
+        if (rt < 2) load_tile_rows(act_srd(a.saved, tile), 1, rt, lane16, bY);      // sdf_emb = H2 row tiles 0, 1
+        else if (rt == 2) load_grid(tile, bY);
+    };
+    uint32_t it = blockIdx.x, par = 0;
+    if (it < a.n_tiles) {
+        const uint32_t t0 = w16_tile(a, it);
+        load_mine(t0);
+        load_tile_rows(act_srd(a.dact, t0), 2, rt, lane16, bG3);
+        load_tile_rows(act_srd(a.dact, t0), 0, rt, lane16, bG1);
+    }
+    w16x_barrier();
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma clang loop unroll(disable)
+    for (; it < a.n_tiles; it += gridDim.x, par ^= 1u) {
+        const uint32_t nt = it + gridDim.x < a.n_tiles ? w16_tile(a, it + gridDim.x) : w16_tile(a, it);
+        const h8* xe = lx.xe + par * W16X_XE;
+        h8* xb = lx.xb + par * W16X_XB;
+        typename A::v8 X3[2][2], X1[2][2];
+        // ---- this wave's column tile(s) -> XB
+        if (rt < 3) {
+            if (rt == 2) bY[0] *= W16_GRID_SHIFT, bY[1] *= W16_GRID_SHIFT;
+            typename A::v8 Y[2][2];
+            transpose_block<A, false>(bY, I, Y, dummy);
+            w16x_put<A>(xb + rt * 256, lane, Y);
+        } else {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {           // e column tile blk = k-steps 2 blk, 2 blk + 1, plane by plane
+                typename A::v8 Y[2][2];
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) {
+                    f32x16 T = mfma16(xe[((2 * blk) * 2 + pb) * 64 + lane], I[0], zero);
+                    T = mfma16(xe[((2 * blk + 1) * 2 + pb) * 64 + lane], I[1], T);
+                    pack_T<A>(T, Y[pb]);
+                }
+                w16x_put<A>(xb + (3 + blk) * 256, lane, Y);
+            }
+        }
+        W16_FENCE();
+        load_mine(nt);
+        W16_FENCE();
+        // ---- X3 = dG3[rt], X1 = dG1[rt]
+        {
+            float rs;
+            const float sx = w16_pick_scale(w16_block_max_bits(bG3, 2), k3, rs);
+            if (rs != 1.0f) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[t] *= rs;
+                bsum0 *= rs;
+            }
+            bG3[0] *= sx, bG3[1] *= sx;
+        }
+        transpose_block<A, true>(bG3, I, X3, bsum0);
+        W16_FENCE();
+        load_tile_rows(act_srd(a.dact, nt), 2, rt, lane16, bG3);
+        W16_FENCE();
+        {
+            float rs;
+            const float sx = w16_pick_scale(w16_block_max_bits(bG1, 2), k1, rs);
+            if (rs != 1.0f) acc[3] *= rs, acc[4] *= rs, bsum1 *= rs;
+            bG1[0] *= sx, bG1[1] *= sx;
+        }
+        transpose_block<A, true>(bG1, I, X1, bsum1);
+        W16_FENCE();
+        load_tile_rows(act_srd(a.dact, nt), 0, rt, lane16, bG1);
+        W16_FENCE();
+        w16x_barrier();
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) w16x_mac<A>(X3, xb + ct * 256, lane, acc[ct]);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) w16x_mac<A>(X1, xb + (3 + ct) * 256, lane, acc[3 + ct]);
+        W16_FENCE();
+    }
+    float* rec = a.rec;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+        flush_mapped(rec, G_W_SDF0, N_SDF_IN, lane, acc[ct], w16_unscale(k3), [&](int i) { return 32 * rt + i; }, [&](int c) { return 32 * ct + c; });
+    flush_mapped(rec, G_W_SDF0, N_SDF_IN, lane, acc[2], w16_unscale(k3) / W16_GRID_SHIFT, [&](int i) { return 32 * rt + i; },
+                 [&](int c) { return N_EMB + 2 * (8 * (c >> 4) + 4 * ((c >> 3) & 1) + (c & 3)) + ((c >> 2) & 1); });
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+        flush_mapped(rec, G_W_PTS0, N_E, lane, acc[3 + ct], w16_unscale(k1), [&](int i) { return 32 * rt + i; },
+                     [&](int c) { return w16_e_col(ct, c); });
+    const float b3 = (bsum0 + __shfl_xor(bsum0, 32, 64)) * w16_unscale(k3), b1 = (bsum1 + __shfl_xor(bsum1, 32, 64)) * w16_unscale(k1);
+    if (h == 0) rec[G_B_SDF0 + 32 * rt + j] = b3, rec[G_B_PTS0 + 32 * rt + j] = b1;
+}
+
+#ifndef W16_EXCHANGE
+#define W16_EXCHANGE 1      // experiments: 0 = every wave prepares its own operands (the roles above) behind the lean record, too
+#endif
+
 template <int LAYOUT, typename A, bool RECOMP>
 __global__ __launch_bounds__(W16_BLOCK, 2) void decoder_wgrad16_kernel(const float* __restrict__ packed16,
                                                                        const float* __restrict__ feat,
@@ -747,7 +1074,9 @@ __global__ __launch_bounds__(W16_BLOCK, 2) void decoder_wgrad16_kernel(const flo
             I[q][u] = (j == 16 * q + 8 * (u >> 2) + 4 * h + (u & 3)) ? (typename A::elt)1.0f : (typename A::elt)0.0f;
     constexpr int W1_ENTRIES = RT_F1 * T16H_F1 * 64;          // 16-byte operands of one layer-1 image (hi; lo has as many)
     static_assert(T16H_F1 == T16_F1, "layer 1 has no separate bias k-step");
+    constexpr bool EXCH = RECOMP && W16_EXCHANGE;
     __shared__ h8 w1img[RECOMP ? 2 * W1_ENTRIES : 1];
+    __shared__ h8 xch[EXCH ? 2 * (W16X_XE + W16X_XA + W16X_XB) : 1];
     if constexpr (RECOMP) {
         const h8* img = reinterpret_cast<const h8*>(packed16 + TAIL16_FLOATS);
         for (int q = tid; q < W1_ENTRIES; q += W16_BLOCK) {
@@ -761,6 +1090,12 @@ __global__ __launch_bounds__(W16_BLOCK, 2) void decoder_wgrad16_kernel(const flo
                        {live_start[0], live_start[1], live_start[2], live_start[3], live_start[4], live_start[5],
                         live_start[6], live_start[7]},
                        RECOMP ? w1img : nullptr, RECOMP ? w1img + W1_ENTRIES : nullptr};
+    if constexpr (EXCH) {
+        const W16X lx = {xch, xch + 2 * W16X_XE, xch + 2 * (W16X_XE + W16X_XA)};
+        if (w < 4) w16x_role_a<LAYOUT, A>(a, lx, I, w, lane);
+        else w16x_role_b<LAYOUT, A>(a, lx, I, w - 4, lane);
+        return;
+    }
     if (w < 4) {
         if constexpr (RECOMP) w16_role_a_recompute<LAYOUT, A>(a, I, w, lane);
         else w16_role_a<LAYOUT, A>(a, I, w, lane);
