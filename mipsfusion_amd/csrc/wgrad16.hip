@@ -729,6 +729,23 @@ __device__ __forceinline__ void w16_role_b(const W16Args& a, const typename A::v
 //     XB  transposed column tiles: sdf_emb 0, sdf_emb 1 (waves 4, 5), grid (wave 6), e 0, e 1 (wave 7, from XE's planes)
 // before the barrier a wave produces, transposes its own gradient blocks (unique to it) and reads nothing of this tile's
 // XA / XB; after it, it multiplies.
+#ifdef W16_TRACE     // diagnosis builds (tools/micro/wgrad_probe.py): cycles between the marks of a tile, summed per wave
+__device__ unsigned long long w16_trace[2048 * 16];
+#define W16_MARK(k) do { __builtin_amdgcn_sched_barrier(0); tr_t[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define W16_TRACE_DECL unsigned long long tr_t[8]
+#define W16_TRACE_SUM(n, wave)                                                                                    \
+    do {                                                                                                          \
+        if (lane == 0) {                                                                                          \
+            const unsigned wi = (blockIdx.x * 8u + (unsigned)(wave)) & 2047u;                                     \
+            for (int k = 0; k < (n); ++k) w16_trace[wi * 16 + k] += tr_t[k + 1] - tr_t[k];                        \
+            w16_trace[wi * 16 + 15] += 1ull;                                                                      \
+        }                                                                                                         \
+    } while (0)
+#else
+#define W16_MARK(k) do { } while (0)
+#define W16_TRACE_DECL do { } while (0)
+#define W16_TRACE_SUM(n, wave) do { } while (0)
+#endif
 struct W16X {
     h8* xe;      // [2][4 k-steps][2 planes][64 lanes]
     h8* xa;      // [2][4 column tiles][4][64]
@@ -743,6 +760,13 @@ __device__ __forceinline__ void w16x_barrier() { asm volatile("s_waitcnt lgkmcnt
 // k-step t of e (the forward's layer-1 B operand: 8 slots per half; t = 3: raw coordinates + the bias ones) as hi / lo planes
 template <typename A>
 __device__ __forceinline__ void w16x_e_step(int t, float x0, float x1, float x2, int h, typename A::v8& eh, typename A::v8& el) {
+#ifdef W16_DBG_NO_COMPUTE
+    {
+        const _Float16 c = (_Float16)(x0 + x1 + x2);
+        eh = h8{c, c, c, c, c, c, c, c}, el = eh;
+        return;
+    }
+#endif
     f32x8 ev;
     if (t < 3) {
         const float xd = t == 0 ? x0 : (t == 1 ? x1 : x2);
@@ -760,6 +784,9 @@ __device__ __forceinline__ void w16x_e_step(int t, float x0, float x1, float x2,
 // acc += X^T Y for ready planes: Y = {yh[0], yh[1], yl[0], yl[1]} (k-steps 0, 1 of the hi / lo plane)
 template <typename A>
 __device__ __forceinline__ void w16x_mac(const typename A::v8 (&X)[2][2], const h8* y, int lane, f32x16& acc) {
+#ifdef W16_DBG_NO_COMPUTE
+    return;
+#endif
     const h8 yh0 = y[lane], yh1 = y[64 + lane], yl0 = y[128 + lane], yl1 = y[192 + lane];
     acc = mfma16(X[0][0], yh0, acc);
     acc = mfma16(X[1][0], yh0, acc);
@@ -800,6 +827,13 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X& lx, co
 #pragma unroll
         for (int d = 0; d < 3; ++d) v[d] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_srd, off, 4 * d, 0));
     };
+    // Every wave issues the SAME loads in the same order, whether it needs them or not (waves 2, 3 have no rgb_emb tile: their
+    // resource is empty, the loads return zeros without touching memory): the compiler counts outstanding loads per program
+    // path, and where paths with different counts meet it waits for the shortest one's count -- a wave on a longer path then
+    // waits for loads it has just issued (measured: 2700 instead of 900 cycles in the phase behind such a join).
+    auto e_srd = [&](uint32_t tile) {
+        return make_srd(a.saved + (size_t)tile * ACT_TILE_FLOATS, w < 2 ? ACT_TILE_FLOATS * 4 : 0);
+    };
     f32x8 bX[2], bS[2], bH3[2], bE[2];
     float xn[3] = {0.f, 0.f, 0.f};           // coordinates of the NEXT tile (its e is produced during this one)
     uint32_t it = blockIdx.x, par = 0;
@@ -809,11 +843,11 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X& lx, co
         load_tile_rows(act_srd(a.dact, t0), 1, w, lane16, bX);
         load_small(t0, bS);
         load_tile_rows(act_srd(a.saved, t0), 2, w, lane16, bH3);
-        if (w < 2) load_tile_rows(act_srd(a.saved, t0), 1, 2 + w, lane16, bE);
+        load_tile_rows(e_srd(t0), 1, 2 + (w & 1), lane16, bE);
         typename A::v8 eh, el;
         w16x_e_step<A>(w, xn[0], xn[1], xn[2], h, eh, el);
         lx.xe[(w * 2 + 0) * 64 + lane] = eh, lx.xe[(w * 2 + 1) * 64 + lane] = el;
-        if (it + gridDim.x < a.n_tiles) load_x(w16_tile(a, it + gridDim.x), xn);
+        load_x(w16_tile(a, it + gridDim.x < a.n_tiles ? it + gridDim.x : it), xn);
     }
     w16x_barrier();
 #pragma clang loop unroll(disable)
@@ -824,12 +858,17 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X& lx, co
         h8* xa = lx.xa + par * W16X_XA;
         const h8* xb = lx.xb + par * W16X_XB;
         typename A::v8 X[2][2];
+        W16_TRACE_DECL;
+        W16_MARK(0);
         // ---- H1 column tile w = e W1[w]^T (the operands swapped: lane = feature, registers = 16 samples; the forward's H1
         //      bit for bit), ReLU, planes -> XA
         {
             f32x16 hacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+#ifdef W16_DBG_NO_COMPUTE
+                break;
+#endif
                 const h8 eh = xe[(t * 2 + 0) * 64 + lane], el = xe[(t * 2 + 1) * 64 + lane];
                 const h8 wh = a.w1_hi[(w * T16H_F1 + t) * 64 + lane], wl = a.w1_lo[(w * T16_F1 + t) * 64 + lane];
                 hacc = mfma16(eh, wh, hacc);
@@ -849,15 +888,17 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X& lx, co
             w16x_put<A>(xa + w * 256, lane, Y);
         }
         W16_FENCE();
+        W16_MARK(1);
         // ---- e k-step w of the NEXT tile -> the other XE buffer (read by everybody before the next barrier)
         if (more) {
             typename A::v8 eh, el;
             w16x_e_step<A>(w, xn[0], xn[1], xn[2], h, eh, el);
             h8* xen = lx.xe + (par ^ 1u) * W16X_XE;
             xen[(w * 2 + 0) * 64 + lane] = eh, xen[(w * 2 + 1) * 64 + lane] = el;
-            if (it + 2 * gridDim.x < a.n_tiles) load_x(w16_tile(a, it + 2 * gridDim.x), xn);
         }
+        load_x(w16_tile(a, it + 2 * gridDim.x < a.n_tiles ? it + 2 * gridDim.x : it), xn);
         W16_FENCE();
+        W16_MARK(2);
         // ---- X = dH2[w]
         {
             float rs;
@@ -873,11 +914,14 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X& lx, co
         W16_FENCE();
         load_tile_rows(act_srd(a.dact, nt), 1, w, lane16, bX);          // the next tile's dH2
         W16_FENCE();
+        W16_MARK(3);
         w16x_barrier();
+        W16_MARK(4);
         // ---- the four H1 column tiles
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) w16x_mac<A>(X, xa + ct * 256, lane, acc[ct]);
         W16_FENCE();
+        W16_MARK(5);
         // ---- small rows: (d logits, d rgb)^T H3[w] (rows 0..15), ^T {rgb_emb | e} (rows 16..31)
         f32x8 sv1[2], sv2[2];
         {
@@ -897,8 +941,10 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X& lx, co
         W16_FENCE();
         load_small(nt, bS);
         load_tile_rows(act_srd(a.saved, nt), 2, w, lane16, bH3);
-        if (w < 2) load_tile_rows(act_srd(a.saved, nt), 1, 2 + w, lane16, bE);
+        load_tile_rows(e_srd(nt), 1, 2 + (w & 1), lane16, bE);
         W16_FENCE();
+        W16_MARK(6);
+        W16_TRACE_SUM(6, w);
     }
     float* rec = a.rec;
 #pragma unroll
@@ -940,7 +986,12 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X& lx, co
     };
     const uint64_t feat_bytes = (uint64_t)a.M * N_GRID * 4;
     const srd_t feat_srd = make_srd(a.feat, feat_bytes > 0xffffffffull ? 0xffffffffu : (uint32_t)feat_bytes);
-    auto load_grid = [&](uint32_t tile, f32x8 (&v)[2]) {
+    // what this wave transposes for everybody.  All four waves issue the same 4 + 16 loads (see w16x_role_a): sdf_emb row
+    // tile rt for rt < 2, the grid features for rt == 2, the rest against empty resources (zeros, no memory traffic)
+    f32x8 bGr[2];
+    const srd_t grid_srd = rt == 2 ? feat_srd : make_srd(a.feat, 0);
+    auto load_mine = [&](uint32_t tile) {
+        load_tile_rows(make_srd(a.saved + (size_t)tile * ACT_TILE_FLOATS, rt < 2 ? ACT_TILE_FLOATS * 4 : 0), 1, rt & 1, lane16, bY);
         const uint32_t s_raw = tile * 32u + (uint32_t)j;
         const uint32_t s_c = s_raw < a.M ? s_raw : a.M - 1;
         const uint32_t voff = LAYOUT == MIPSF_FEAT_AOS ? s_c * (uint32_t)(N_GRID * 4) + 4u * (uint32_t)h : (s_c * 2u + (uint32_t)h) * 4u;
@@ -949,11 +1000,7 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X& lx, co
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                v[q][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(feat_srd, voff, (uint32_t)(8 * q + u) * lstride, 0));
-    };
-    auto load_mine = [&](uint32_t tile) {                 // what this wave transposes for everybody
-        if (rt < 2) load_tile_rows(act_srd(a.saved, tile), 1, rt, lane16, bY);      // sdf_emb = H2 row tiles 0, 1
-        else if (rt == 2) load_grid(tile, bY);
+                bGr[q][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(grid_srd, voff, (uint32_t)(8 * q + u) * lstride, 0));
     };
     uint32_t it = blockIdx.x, par = 0;
     if (it < a.n_tiles) {
@@ -970,9 +1017,11 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X& lx, co
         const h8* xe = lx.xe + par * W16X_XE;
         h8* xb = lx.xb + par * W16X_XB;
         typename A::v8 X3[2][2], X1[2][2];
+        W16_TRACE_DECL;
+        W16_MARK(0);
         // ---- this wave's column tile(s) -> XB
         if (rt < 3) {
-            if (rt == 2) bY[0] *= W16_GRID_SHIFT, bY[1] *= W16_GRID_SHIFT;
+            if (rt == 2) bY[0] = bGr[0] * W16_GRID_SHIFT, bY[1] = bGr[1] * W16_GRID_SHIFT;
             typename A::v8 Y[2][2];
             transpose_block<A, false>(bY, I, Y, dummy);
             w16x_put<A>(xb + rt * 256, lane, Y);
@@ -982,6 +1031,10 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X& lx, co
                 typename A::v8 Y[2][2];
 #pragma unroll
                 for (int pb = 0; pb < 2; ++pb) {
+#ifdef W16_DBG_NO_COMPUTE
+                    Y[pb][0] = I[0], Y[pb][1] = I[1];
+                    continue;
+#endif
                     f32x16 T = mfma16(xe[((2 * blk) * 2 + pb) * 64 + lane], I[0], zero);
                     T = mfma16(xe[((2 * blk + 1) * 2 + pb) * 64 + lane], I[1], T);
                     pack_T<A>(T, Y[pb]);
@@ -992,6 +1045,7 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X& lx, co
         W16_FENCE();
         load_mine(nt);
         W16_FENCE();
+        W16_MARK(1);
         // ---- X3 = dG3[rt], X1 = dG1[rt]
         {
             float rs;
@@ -1005,6 +1059,7 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X& lx, co
         }
         transpose_block<A, true>(bG3, I, X3, bsum0);
         W16_FENCE();
+        W16_MARK(2);
         load_tile_rows(act_srd(a.dact, nt), 2, rt, lane16, bG3);
         W16_FENCE();
         {
@@ -1017,12 +1072,17 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X& lx, co
         W16_FENCE();
         load_tile_rows(act_srd(a.dact, nt), 0, rt, lane16, bG1);
         W16_FENCE();
+        W16_MARK(3);
         w16x_barrier();
+        W16_MARK(4);
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct) w16x_mac<A>(X3, xb + ct * 256, lane, acc[ct]);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) w16x_mac<A>(X1, xb + (3 + ct) * 256, lane, acc[3 + ct]);
         W16_FENCE();
+        W16_MARK(5);
+        W16_MARK(6);
+        W16_TRACE_SUM(6, 4 + rt);
     }
     float* rec = a.rec;
 #pragma unroll
@@ -1108,6 +1168,16 @@ __global__ __launch_bounds__(W16_BLOCK, 2) void decoder_wgrad16_kernel(const flo
 
 using namespace mipsf;
 
+#ifdef W16_TRACE
+extern "C" int mipsf_w16_trace_read(unsigned long long* host, int clear) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(w16_trace), sizeof(unsigned long long) * 2048 * 16) != hipSuccess) return 1;
+    if (clear) {
+        static unsigned long long z[2048 * 16];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(w16_trace), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 extern "C" uint64_t mipsf_decoder_tile_words(uint32_t M) {
     return TL_HEADER + 8ull * tl_cap((uint32_t)(((uint64_t)M + 31) / 32));
 }

@@ -49,6 +49,30 @@ def open_lib(path):
     return h
 
 
+def report_wgrad_trace(lname, h):
+    """-DW16_TRACE builds: cycles per tile between the marks of the exchange roles of wgrad16.hip, per role."""
+    try:
+        fn = h.mipsf_w16_trace_read
+    except AttributeError:
+        return
+    import numpy as np
+    buf = np.zeros(2048 * 16, dtype=np.uint64)
+    fn(buf.ctypes.data_as(C.c_void_p), 1)
+    t = buf.reshape(2048, 16).astype(np.float64)
+    names = {"A": ["H1[w] -> XA", "e(next)[w] -> XE", "X = dH2[w]^T", "barrier", "4 x mac", "small rows + next loads"],
+             "B": ["column tile -> XB", "X3 = dG3^T", "X1 = dG1^T", "barrier", "5 x mac", "-"]}
+    for role, sel in (("A", lambda w: w % 8 < 4), ("B", lambda w: w % 8 >= 4)):
+        rows = np.array([w for w in range(2048) if sel(w) and t[w, 15] > 0])
+        if rows.size == 0:
+            continue
+        per = t[rows, :6].sum(0) / t[rows, 15].sum()
+        print(f"  [{lname}] role {role}: {per.sum():.0f} cycles per tile: " + ", ".join(f"{n} {c:.0f}" for n, c in zip(names[role], per)))
+        for k in range(4):
+            r2 = rows[rows % 4 == k]
+            p2 = t[r2, :6].sum(0) / t[r2, 15].sum()
+            print(f"      wave {k + (0 if role == 'A' else 4)}: " + " ".join(f"{c:6.0f}" for c in p2))
+
+
 def main():
     names = [a for a in sys.argv[1:]]
     dev = torch.device("cuda", 0)
@@ -96,6 +120,7 @@ def main():
         for k, (n, _a) in enumerate(calls):
             us = sum(a.elapsed_time(b) for a, b in evs[k]) / len(evs[k]) * 1e3
             table_out.setdefault((k, n), {})[lname] = us
+        report_wgrad_trace(lname, h)
     w = max(len(n) for _, n in table_out) + 4
     print(" " * w + "".join(f"{l:>12s}" for l, _ in libs))
     tot = {l: 0.0 for l, _ in libs}
