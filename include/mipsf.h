@@ -159,8 +159,9 @@ int mipsf_decoder_fwd_sdf(const float* packed, const float* feat, int feat_layou
  * precision MIPSF_PREC_F16: plain f16 operands (11 bits), fp32 accumulate: forward-only consumers with a stated
  *   tolerance (RandomOptimizer fitness; BASELINE config 5 "fp16 decoder on CDNA4"), `saved` must be NULL.
  * Positional encoding is always computed in-kernel (pe_mode 0).  sdf_only != 0: out is [M] (column 3 only).
- * packed16: mipsf_decoder_packed16_floats() floats written by mipsf_decoder_pack16 (head tables + biases in fp32,
- * hi and lo operand images of the three hidden layers). */
+ * packed16: mipsf_decoder_packed16_floats() floats written by mipsf_decoder_pack16 (compact hi / lo operand images of the two
+ * narrow heads + their biases in fp32, hi and lo operand images of the three hidden layers, forward and backward sets); the
+ * layout is private to the library (csrc/decoder_layout.h): a buffer packed by one build is for that build's kernels. */
 #define MIPSF_PREC_F32 0
 #define MIPSF_PREC_F16X3 1
 #define MIPSF_PREC_F16 2
