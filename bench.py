@@ -524,8 +524,16 @@ def frame_estimate(cfg, model, loop, dev, ba_ms, stream=None):
         prm.requires_grad_(False)
     go_ms = time_go()
     go_graph_ms = None
-    if stream is not None and not loop.torch_pose:      # the same iteration as one hipGraph replay
-        g = GraphedSteps(lambda k: go(), 1, stream=stream)
+    if stream is not None and not loop.torch_pose:      # a frame's tracking iterations as one hipGraph replay, the map
+        n_go = max(1, cfg["tracking"]["iter"])           # frozen throughout: the operand images are packed once per replay
+
+        def go_k(k):                                     # (GraphedSequence._go_step: the pack is recorded at k == 0)
+            if k == 0:
+                model.frozen_weights(True)
+            go()
+            if k == n_go - 1:
+                model.frozen_weights(False)
+        g = GraphedSteps(go_k, n_go, stream=stream)
         for _ in range(3):
             g.replay()
         torch.cuda.synchronize()
@@ -533,7 +541,7 @@ def frame_estimate(cfg, model, loop, dev, ba_ms, stream=None):
         for _ in range(20):
             g.replay()
         torch.cuda.synchronize()
-        go_graph_ms = (time.perf_counter() - t0) / 20 * 1e3
+        go_graph_ms = (time.perf_counter() - t0) / 20 / n_go * 1e3
     for prm in model.parameters():
         prm.requires_grad_(True)
     model.zero_grad()

@@ -174,11 +174,14 @@ int mipsf_decoder_fwd16(const float* packed16, const float* feat, int feat_layou
 /* lean_record != 0 (f16x3 with `saved` only): the record keeps H2, H3 and the ReLU masks but NOT H1 -- a third of the
  * record's bytes; valid when the weight gradients come from mipsf_decoder_wgrad16 with `packed16` given (it recomputes H1
  * from x); the backward chain never reads H1.  The buffer keeps its size and layout (the H1 pieces stay unwritten). */
+/* lean_record == 2: only the ReLU masks are kept (32 B per sample): all the backward chain reads of the record; for callers
+ * that will not ask for weight gradients (a frozen decoder: tracking). */
 int mipsf_decoder_fwd16_ex(const float* packed16, const float* feat, int feat_layout, const float* x, float* out,
                            float* saved, int sdf_only, int precision, int lean_record, uint32_t M, void* stream);
 /* mipsf_decoder_bwd_chain on the f16 matrix cores (hi/lo split operands, fp32 accumulate; pe_mode 0 only): the same
  * outputs and the same `dact` record, so mipsf_decoder_wgrad follows it unchanged.  saved: as written by
- * mipsf_decoder_fwd / _fwd16 (only the ReLU masks are read). */
+ * mipsf_decoder_fwd / _fwd16 (only the ReLU masks are read).  dact may be NULL (all three entry points): no weight gradients
+ * will be asked for (a frozen decoder), the record is not written. */
 int mipsf_decoder_bwd_chain16(const float* packed16, int feat_layout, const float* x, const float* out, const float* dout,
                               const float* saved, float* dfeat, float* dx, float* dact, uint32_t M, void* stream);
 /* The same with ZERO-TILE flags.  Samples behind the truncation band receive an exactly zero gradient from the losses

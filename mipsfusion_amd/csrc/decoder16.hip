@@ -211,7 +211,9 @@ __device__ __forceinline__ void mfma16_head(const h8* himg, int slot, f32x16& ac
 
 // one wave, one tile of 32 samples.  tail: head images + head biases (LDS); img_hi / img_lo: the two operand image sets
 // SAVE: 0 no record, 1 the full activation record, 2 the LEAN record -- H2, H3 and the ReLU masks; H1 (a third of the
-// record) is left out: the streaming weight-gradient kernel recomputes it from x (wgrad16.hip) and nothing else reads it
+// record) is left out: the streaming weight-gradient kernel recomputes it from x (wgrad16.hip) and nothing else reads it;
+// 3 the ReLU MASKS only (32 B per sample instead of 1 KB): all the backward chain reads of the record -- for a frozen decoder
+// (tracking: pose-only optimisation) no weight gradients follow and the activations would be written for nobody
 template <int LAYOUT, int SAVE, bool SDF_ONLY, bool SPLIT, typename Img>
 __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img img,
                                                    const float* __restrict__ feat, const float* __restrict__ x,
@@ -318,7 +320,7 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
             },
             [&](int t) {       // the rgb_emb half of H2 leaves piece by piece behind the k-steps that read it: a burst of
                                // 8 (and of 16 for H3 below) stalls on the store path's back pressure (1300 / 1900 cycles)
-                if constexpr (SAVE != 0) {
+                if constexpr (SAVE == 1 || SAVE == 2) {
                     if (t < 4) {
                         store_act_piece(sv, lane16, 1, H2, 8 + 2 * t);
                         store_act_piece(sv, lane16, 1, H2, 8 + 2 * t + 1);
@@ -342,7 +344,7 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
             split8<SPLIT>(v, bh, bl);
         },
         [&](int t) {                                   // the sdf_emb half of H2 (8 pieces) over the first 4 k-steps
-            if constexpr (SAVE && !SDF_ONLY) {
+            if constexpr ((SAVE == 1 || SAVE == 2) && !SDF_ONLY) {
                 if (t < 4) {
                     store_act_piece(sv, lane16, 1, H2, 2 * t);
                     store_act_piece(sv, lane16, 1, H2, 2 * t + 1);
@@ -382,7 +384,7 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
                 split8<true>(v, bh, bl);
             },
             [&](int t) {
-                if constexpr (SAVE != 0) {
+                if constexpr (SAVE == 1 || SAVE == 2) {
                     store_act_piece(sv, lane16, 2, H3, 2 * t);
                     store_act_piece(sv, lane16, 2, H3, 2 * t + 1);
                 }
@@ -566,7 +568,9 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
     const bool live = s_raw < M;
     const uint32_t s = live ? s_raw : M - 1;
     const uint32_t lane16 = 16u * (uint32_t)lane;
-    const srd_t da = make_srd(dact + (size_t)tile * ACT_TILE_FLOATS, ACT_TILE_FLOATS * 4);
+    // dact == nullptr: nobody will ask for weight gradients (a frozen decoder: tracking) -- the 48 KB of pre-activation
+    // gradients per tile are not written (an empty buffer resource drops the stores: no branch around them)
+    const srd_t da = make_srd(dact ? dact + (size_t)tile * ACT_TILE_FLOATS : nullptr, dact ? ACT_TILE_FLOATS * 4 : 0);
 
     float2 o2[5], g2[5];
     {
@@ -634,7 +638,7 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
         for (int c = 0; c < N_CLASS; ++c) dlg[c] = p[c] * (dp[c] - dot);
 #pragma unroll
         for (int c = 0; c < 3; ++c) drgb[c] = live ? gv[c] : 0.f;
-        if (h == 0) {
+        if (h == 0 && dact != nullptr) {
             float4* d4 = reinterpret_cast<float4*>(dsmall + (size_t)(tile * 32 + j) * 8);
             d4[0] = make_float4(dlg[0], dlg[1], dlg[2], dlg[3]);
             d4[1] = make_float4(dlg[4], drgb[0], drgb[1], drgb[2]);
@@ -993,6 +997,7 @@ int mipsf_decoder_fwd16_ex2(const float* packed16, const float* feat, int feat_l
 #define F16_MODE(LAY, SPL)                                  \
     do {                                                    \
         if (sdf_only) F16(LAY, 0, true, SPL);               \
+        else if (saved != nullptr && lean_record == 2) F16(LAY, 3, false, true); \
         else if (saved != nullptr && lean_record) F16(LAY, 2, false, true); \
         else if (saved != nullptr) F16(LAY, 1, false, SPL); \
         else F16(LAY, 0, false, SPL);                       \
@@ -1027,11 +1032,11 @@ int mipsf_decoder_bwd_chain16_ex2(const float* packed16, int feat_layout, const 
                                   const float* dout, const float* saved, float* dfeat, float* dx, float* dact,
                                   uint32_t* tile_live, int header_is_clear, uint32_t M, void* stream) {
     if (M == 0) return 0;
-    MIPSF_REQUIRE(packed16 && x && out && dout && saved && dfeat && dx && dact, "null pointer");
+    MIPSF_REQUIRE(packed16 && x && out && dout && saved && dfeat && dx, "null pointer");      // (dact may be NULL: see the header)
     MIPSF_REQUIRE(feat_layout == MIPSF_FEAT_AOS || feat_layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout");
     const uint64_t n_bt = ((uint64_t)M + 127) / 128;
     const uint32_t blocks = (uint32_t)((((uint64_t)M + 31) / 32 + 3) / 4);
-    float* dsmall = dact + n_bt * 4 * ACT_TILE_FLOATS;
+    float* dsmall = dact ? dact + n_bt * 4 * ACT_TILE_FLOATS : nullptr;
     hipStream_t s = (hipStream_t)stream;
     const uint32_t n_tiles = (uint32_t)(((uint64_t)M + 31) / 32);
     const int cus = device_cus();

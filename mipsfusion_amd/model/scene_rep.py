@@ -107,9 +107,12 @@ class _QueryFn(torch.autograd.Function):
         # lean record: when the weight gradients will come from the streaming f16 kernel (the default behind the f16x3
         # chain) H1 is recomputed there from x and the forward does not write it (a third of the record)
         lean = bool(need and prec == "f16x3" and owner.wgrad_precision in ("auto", "stream_f16x3") and owner.lean_record)
-        out, saved = ops.decoder_fwd(packed, feat, FEAT_LEVEL_MAJOR, xn, None, M, save="lean" if lean else need,
-                                     precision=prec, packed16=packed16)
-        ctx.lean = lean
+        # a frozen decoder (tracking: only the points need a gradient): the chain reads the ReLU masks and nothing else of the
+        # record -- the 1 KB of activations per sample would be written for nobody
+        masks_only = bool(need and prec == "f16x3" and not any(ctx.needs_input_grad[3:]))
+        out, saved = ops.decoder_fwd(packed, feat, FEAT_LEVEL_MAJOR, xn, None, M,
+                                     save="masks" if masks_only else ("lean" if lean else need), precision=prec, packed16=packed16)
+        ctx.lean = lean and not masks_only
         ctx.tile_live = getattr(saved, "mipsf_tile_live", None)    # (python attributes do not travel with saved tensors)
         if packed is None:
             packed = packed16

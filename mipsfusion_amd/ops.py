@@ -294,11 +294,13 @@ def decoder_fwd(packed, feat, layout, x, embed_pos, M, save, precision: str = "f
     """precision "f32": fp32-input MFMA (exact fp32 products).  "f16x3": f16 MFMA on hi/lo split operands (~3e-7
     relative; same `saved` layout, so the backward kernels are unchanged).  "f16": plain f16 operands, forward only.
     The f16 modes need `packed16` (decoder_pack16) and the in-kernel positional encoding (embed_pos None).
-    save: False, True (the full activation record) or "lean" (f16x3: H1, a third of the record, is not written -- only
-    valid with ``decoder_bwd(..., wgrad_precision="stream_f16x3", recompute_h1=True)``, which recomputes it from x)."""
-    lean = save == "lean"
+    save: False, True (the full activation record), "lean" (f16x3: H1, a third of the record, is not written -- only
+    valid with ``decoder_bwd(..., wgrad_precision="stream_f16x3", recompute_h1=True)``, which recomputes it from x) or
+    "masks" (f16x3: only the ReLU masks, 32 B per sample -- all the backward CHAIN reads; ``decoder_bwd(grads=None)`` only)."""
+    lean = save in ("lean", "masks")
+    masks_only = save == "masks"
     if lean and precision != "f16x3":
-        raise RuntimeError('save="lean" belongs to precision "f16x3"')
+        raise RuntimeError('save="lean" / "masks" belong to precision "f16x3"')
     out = torch.empty((M, 10), dtype=torch.float32, device=x.device)
     saved = None
     if save:
@@ -315,10 +317,12 @@ def decoder_fwd(packed, feat, layout, x, embed_pos, M, save, precision: str = "f
             tile_live = torch.empty(lib().mipsf_decoder_tile_words(M), dtype=torch.int32, device=x.device)
         with _timed("decoder_fwd"):
             check(lib().mipsf_decoder_fwd16_ex2(dptr(packed16), dptr(feat), layout, dptr(x), dptr(out), dptr(saved), 0,
-                                                _lib.PREC[precision], 1 if lean else 0, dptr(tile_live, torch.int32), M,
+                                                _lib.PREC[precision], (2 if masks_only else 1) if lean else 0, dptr(tile_live, torch.int32), M,
                                                 stream_ptr()), "decoder_fwd16")
         if lean:
             saved.mipsf_lean_record = True          # decoder_bwd refuses to read H1 from such a record
+        if masks_only:
+            saved.mipsf_masks_only = True           # ... and to compute weight gradients at all from this one
         if tile_live is not None:
             saved.mipsf_tile_live = [tile_live, True]      # (buffer, its counters are still clear)
         return out, saved
@@ -350,6 +354,8 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
     ``hashgrid_dx_from_jac(..., tiles=)``."""
     if wgrad_precision == "auto":
         wgrad_precision = "stream_f16x3" if (precision == "f16x3" and embed_pos is None) else "f32"
+    if getattr(saved, "mipsf_masks_only", False) and grads is not None:
+        raise RuntimeError("this activation record holds the ReLU masks only (decoder_fwd(save='masks')): no weight gradients")
     if getattr(saved, "mipsf_lean_record", False) and grads is not None:
         if wgrad_precision != "stream_f16x3" or packed16 is None:
             raise RuntimeError("this activation record was saved lean (no H1): the weight gradients need "
@@ -359,7 +365,8 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
     dfeat = torch.empty_like(feat)
     dx = torch.empty((M, 3), dtype=torch.float32, device=dev)
     dpe = torch.empty((M, 48), dtype=torch.float32, device=dev) if embed_pos is not None else None
-    dact = torch.empty(lib().mipsf_decoder_dact_floats(M), dtype=torch.float32, device=dev)
+    # (a frozen decoder behind the f16x3 chain: the pre-activation gradients are for the weight-gradient kernel only)
+    dact = None if (grads is None and precision == "f16x3") else torch.empty(lib().mipsf_decoder_dact_floats(M), dtype=torch.float32, device=dev)
     pe_mode = 0 if embed_pos is None else 1
     tile_live = None
     if precision == "f16x3":

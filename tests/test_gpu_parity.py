@@ -1611,6 +1611,14 @@ def test_decoder_backward_short_cuts_zero_gradient_tiles_exactly(dev, M, layout)
         assert_close(a, b, 1e-6, "zero-tile short cut, grad " + k)
     df_frozen, dx_frozen, _ = run(True, None)
     assert torch.equal(df_frozen, df_all) and torch.equal(dx_frozen, dx_all)
+    # the record of a frozen decoder's forward: the ReLU masks only (all the chain reads of it) -- same outputs, same chain
+    out_m, saved_m = ops.decoder_fwd(None, feat, lay, x, None, M, save="masks", precision="f16x3", packed16=packed16)
+    assert torch.equal(out_m, out)
+    df_m, dx_m, _ = ops.decoder_bwd(None, feat, lay, x, None, out_m, dout, saved_m, None, M, precision="f16x3", packed16=packed16)
+    assert torch.equal(df_m, df_all) and torch.equal(dx_m, dx_all)
+    with pytest.raises(RuntimeError, match="masks only"):
+        ops.decoder_bwd(None, feat, lay, x, None, out_m, dout, saved_m, [torch.zeros_like(w) for w in ws], M,
+                        precision="f16x3", packed16=packed16)
     dout.zero_()
     g0 = [torch.zeros_like(w) for w in ws]
     df0, dx0, _ = run(True, g0)
