@@ -187,10 +187,11 @@ __device__ __forceinline__ void mfma16_layer(const Img img, int lane, int h, f32
     }
 }
 
-// A narrow head (decoder_layout.h, HEAD16): out = W_head * B over 8 k-steps, always hi/lo split (three MFMAs per k-step,
-// two accumulators so that no MFMA waits for the one in front of it: acc0 = hi*hi + lo*hi, acc1 = hi*lo).  himg: the head's
+// A narrow head (decoder_layout.h, HEAD16): out = W_head * B over 8 k-steps; HSPLIT: hi/lo split like the layers (three MFMAs
+// per k-step, two accumulators so that no MFMA waits for the one in front of it: acc0 = hi*hi + lo*hi, acc1 = hi*lo), else
+// the hi halves only (the plain f16 mode).  himg: the head's
 // compact image in LDS ([t][plane][SLOTS] 16-byte operands), slot: this lane's operand slot.
-template <int SLOTS, typename BFn, typename SideFn = NoSide16>
+template <int SLOTS, bool HSPLIT, typename BFn, typename SideFn = NoSide16>
 __device__ __forceinline__ void mfma16_head(const h8* himg, int slot, f32x16& acc0, f32x16& acc1, BFn bfn, SideFn side = SideFn()) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     h8 ah = himg[slot], al = himg[SLOTS + slot], nh, nl, bh, bl, nbh, nbl;
@@ -200,8 +201,12 @@ __device__ __forceinline__ void mfma16_head(const h8* himg, int slot, f32x16& ac
         if (t + 1 < T16_HEAD) nh = himg[(2 * t + 2) * SLOTS + slot], nl = himg[(2 * t + 3) * SLOTS + slot];
         __builtin_amdgcn_sched_barrier(0);
         acc0 = mfma16(ah, bh, t == 0 ? zero : acc0);
-        acc1 = mfma16(ah, bl, t == 0 ? zero : acc1);
-        acc0 = mfma16(al, bh, acc0);
+        if (HSPLIT) {
+            acc1 = mfma16(ah, bl, t == 0 ? zero : acc1);
+            acc0 = mfma16(al, bh, acc0);
+        } else if (t == 0) {
+            acc1 = zero;
+        }
         if (t + 1 < T16_HEAD) bfn(t + 1, nbh, nbl);
         side(t);
         __builtin_amdgcn_sched_barrier(0);
@@ -310,13 +315,13 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
     float rgb[3] = {0.f, 0.f, 0.f};
     if constexpr (!SDF_ONLY) {
         f32x16 r0, r1;
-        mfma16_head<HEAD16_RGB_SLOTS>(reinterpret_cast<const h8*>(tail) + HEAD16_SDF_HALVES / 8, head16_rgb_slot(j, h), r0, r1,
+        mfma16_head<HEAD16_RGB_SLOTS, SPLIT>(reinterpret_cast<const h8*>(tail) + HEAD16_SDF_HALVES / 8, head16_rgb_slot(j, h), r0, r1,
             [&](int t, h8& bh, h8& bl) {
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
                     v[u] = t < 4 ? H2[2 + (t >> 1)][8 * (t & 1) + u] : (8 * (t - 4) + u < E_SLOTS ? ev[8 * (t - 4) + u] : 0.0f);
-                split8<true>(v, bh, bl);
+                split8<SPLIT>(v, bh, bl);
             },
             [&](int t) {       // the rgb_emb half of H2 leaves piece by piece behind the k-steps that read it: a burst of
                                // 8 (and of 16 for H3 below) stalls on the store path's back pressure (1300 / 1900 cycles)
@@ -376,12 +381,12 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
     float lg[N_CLASS], mx = -3.0e38f;
     {
         f32x16 s0, s1;
-        mfma16_head<HEAD16_SDF_SLOTS>(reinterpret_cast<const h8*>(tail), head16_sdf_slot(j, h), s0, s1,
+        mfma16_head<HEAD16_SDF_SLOTS, SPLIT>(reinterpret_cast<const h8*>(tail), head16_sdf_slot(j, h), s0, s1,
             [&](int t, h8& bh, h8& bl) {
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) v[u] = H3[t >> 1][8 * (t & 1) + u];
-                split8<true>(v, bh, bl);
+                split8<SPLIT>(v, bh, bl);
             },
             [&](int t) {
                 if constexpr (SAVE == 1 || SAVE == 2) {
