@@ -200,9 +200,18 @@ int mipsf_decoder_bwd_chain16_ex(const float* packed16, int feat_layout, const f
 int mipsf_decoder_fwd16_ex2(const float* packed16, const float* feat, int feat_layout, const float* x, float* out,
                             float* saved, int sdf_only, int precision, int lean_record, uint32_t* tile_live_clear,
                             uint32_t M, void* stream);
+/* flags of mipsf_decoder_bwd_chain16_ex2 (its last int; 1 is the former header_is_clear):
+ *   MIPSF_CHAIN_HEADER_CLEAR  the forward cleared tile_live's counters (above)
+ *   MIPSF_CHAIN_LEAN_DACT     `dact` keeps dG1 and the sdf_emb half of dH2 only -- dG3 and the rgb_emb half of dH2, half of the
+ *                             record, are not written: each is ONE narrow product of the 5 logit / 3 colour gradients (kept in
+ *                             `dact`'s small-row part) and, for dG3, the ReLU masks of `saved`; the weight-gradient call that
+ *                             follows must be mipsf_decoder_wgrad16_tiles_ex with MIPSF_WGRAD_LEAN_DACT (f16x3, packed16 given),
+ *                             which recomputes them bit for bit. */
+#define MIPSF_CHAIN_HEADER_CLEAR 1
+#define MIPSF_CHAIN_LEAN_DACT 2
 int mipsf_decoder_bwd_chain16_ex2(const float* packed16, int feat_layout, const float* x, const float* out,
                                   const float* dout, const float* saved, float* dfeat, float* dx, float* dact,
-                                  uint32_t* tile_live, int header_is_clear, uint32_t M, void* stream);
+                                  uint32_t* tile_live, int flags, uint32_t M, void* stream);
 /* Backward.  dout [M,10].  Outputs: dfeat (layout as feat), dx [M,3] (pe_mode 0: includes the PE chain),
  * dembed_pos [M,48] (pe_mode 1 only).  Weight gradients are ACCUMULATED into `grads`.
  * dact / partial: scratch of the sizes above. */
@@ -249,6 +258,14 @@ int mipsf_decoder_wgrad16_tiles(const float* packed16, const float* feat, int fe
                                 const float* saved, const float* dact, const uint32_t* tile_live,
                                 const mipsf_decoder_grads* grads_host_struct, float* partial, int arithmetic, uint32_t M,
                                 void* stream);
+/* ... with flags.  MIPSF_WGRAD_LEAN_DACT: `dact` is the lean gradient record of mipsf_decoder_bwd_chain16_ex2 with
+ * MIPSF_CHAIN_LEAN_DACT (f16x3 with packed16 only): dG3 and the rgb_emb half of dH2 are recomputed from the small rows and the
+ * ReLU masks of `saved`. */
+#define MIPSF_WGRAD_LEAN_DACT 1u
+int mipsf_decoder_wgrad16_tiles_ex(const float* packed16, const float* feat, int feat_layout, const float* x,
+                                   const float* saved, const float* dact, const uint32_t* tile_live,
+                                   const mipsf_decoder_grads* grads_host_struct, float* partial, int arithmetic,
+                                   uint32_t flags, uint32_t M, void* stream);
 
 /* -------------------------------------------------- sample placement (a3 + a4) */
 typedef struct mipsf_render_cfg {

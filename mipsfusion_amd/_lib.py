@@ -114,6 +114,7 @@ SIGNATURES = {
     "mipsf_decoder_wgrad16": (_I, [_P, _I, _P, _P, _P, C.POINTER(DecoderGrads), _P, _I, _U32, _P]),
     "mipsf_decoder_wgrad16_ex": (_I, [_P, _P, _I, _P, _P, _P, C.POINTER(DecoderGrads), _P, _I, _U32, _P]),
     "mipsf_decoder_wgrad16_tiles": (_I, [_P, _P, _I, _P, _P, _P, _P, C.POINTER(DecoderGrads), _P, _I, _U32, _P]),
+    "mipsf_decoder_wgrad16_tiles_ex": (_I, [_P, _P, _I, _P, _P, _P, _P, C.POINTER(DecoderGrads), _P, _I, _U32, _U32, _P]),
     "mipsf_sample_rays": (_I, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _U32, _P]),
     "mipsf_normalise_points": (_I, [_P, C.POINTER(RenderCfg), _P, _U32, _P]),
     "mipsf_render_fwd": (_I, [_P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _U32, _U32,

@@ -189,7 +189,9 @@ __device__ __forceinline__ void mfma16_layer(const Img img, int lane, int h, f32
 
 // A narrow head (decoder_layout.h, HEAD16): out = W_head * B over 8 k-steps; HSPLIT: hi/lo split like the layers (three MFMAs
 // per k-step, two accumulators so that no MFMA waits for the one in front of it: acc0 = hi*hi + lo*hi, acc1 = hi*lo), else
-// the hi halves only (the plain f16 mode).  himg: the head's
+// the hi halves only.  Both arithmetic modes use the split heads: with hi halves only the plain f16 mode's forward error
+// doubles (4.3e-4 against its stated 2e-4, test_decoder_true_error_of_every_arithmetic_against_fp64) for 6 % of a
+// RandomOptimizer round.  himg: the head's
 // compact image in LDS ([t][plane][SLOTS] 16-byte operands), slot: this lane's operand slot.
 template <int SLOTS, bool HSPLIT, typename BFn, typename SideFn = NoSide16>
 __device__ __forceinline__ void mfma16_head(const h8* himg, int slot, f32x16& acc0, f32x16& acc1, BFn bfn, SideFn side = SideFn()) {
@@ -315,13 +317,13 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
     float rgb[3] = {0.f, 0.f, 0.f};
     if constexpr (!SDF_ONLY) {
         f32x16 r0, r1;
-        mfma16_head<HEAD16_RGB_SLOTS, SPLIT>(reinterpret_cast<const h8*>(tail) + HEAD16_SDF_HALVES / 8, head16_rgb_slot(j, h), r0, r1,
+        mfma16_head<HEAD16_RGB_SLOTS, true>(reinterpret_cast<const h8*>(tail) + HEAD16_SDF_HALVES / 8, head16_rgb_slot(j, h), r0, r1,
             [&](int t, h8& bh, h8& bl) {
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
                     v[u] = t < 4 ? H2[2 + (t >> 1)][8 * (t & 1) + u] : (8 * (t - 4) + u < E_SLOTS ? ev[8 * (t - 4) + u] : 0.0f);
-                split8<SPLIT>(v, bh, bl);
+                split8<true>(v, bh, bl);
             },
             [&](int t) {       // the rgb_emb half of H2 leaves piece by piece behind the k-steps that read it: a burst of
                                // 8 (and of 16 for H3 below) stalls on the store path's back pressure (1300 / 1900 cycles)
@@ -381,12 +383,12 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
     float lg[N_CLASS], mx = -3.0e38f;
     {
         f32x16 s0, s1;
-        mfma16_head<HEAD16_SDF_SLOTS, SPLIT>(reinterpret_cast<const h8*>(tail), head16_sdf_slot(j, h), s0, s1,
+        mfma16_head<HEAD16_SDF_SLOTS, true>(reinterpret_cast<const h8*>(tail), head16_sdf_slot(j, h), s0, s1,
             [&](int t, h8& bh, h8& bl) {
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) v[u] = H3[t >> 1][8 * (t & 1) + u];
-                split8<SPLIT>(v, bh, bl);
+                split8<true>(v, bh, bl);
             },
             [&](int t) {
                 if constexpr (SAVE == 1 || SAVE == 2) {
@@ -566,7 +568,7 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
                                                    const float* __restrict__ saved, float* __restrict__ dfeat,
                                                    float* __restrict__ dx, float* __restrict__ dact,
                                                    float* __restrict__ dsmall, uint32_t M, int64_t tile, int lane,
-                                                   uint32_t* __restrict__ tile_live = nullptr) {
+                                                   uint32_t* __restrict__ tile_live = nullptr, bool lean_dact = false) {
     constexpr bool SPLIT = true;
     const int j = lane & 31, h = lane >> 5;
     const uint32_t s_raw = (uint32_t)(tile * 32 + j);
@@ -576,6 +578,12 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
     // dact == nullptr: nobody will ask for weight gradients (a frozen decoder: tracking) -- the 48 KB of pre-activation
     // gradients per tile are not written (an empty buffer resource drops the stores: no branch around them)
     const srd_t da = make_srd(dact ? dact + (size_t)tile * ACT_TILE_FLOATS : nullptr, dact ? ACT_TILE_FLOATS * 4 : 0);
+    // LEAN gradient record (MIPSF_CHAIN_LEAN_DACT; the exchange form of the weight-gradient kernel follows): dG3 and the
+    // rgb_emb half of dH2 are not written -- half of the record's 48 KB per tile.  Both are one narrow product of values the
+    // weight-gradient kernel has anyway (dG3 = relu'(H3) (Ws2^T dlogits): the 5 logit gradients and the mask bits; d rgb_emb =
+    // Wrgb^T drgb: 3 values): it recomputes them with this function's own operations, bit for bit (wgrad16.hip).  This
+    // kernel is bound by its stores.
+    const srd_t da_opt = make_srd(dact ? dact + (size_t)tile * ACT_TILE_FLOATS : nullptr, (dact && !lean_dact) ? ACT_TILE_FLOATS * 4 : 0);
 
     float2 o2[5], g2[5];
     {
@@ -681,7 +689,7 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
     // a 16-byte piece of a (scaled) gradient tile, back at its true magnitude, into `dact`
     auto store_piece = [&](int mat, const f32x16 (&acc)[4], int q) {
         const int rt = q >> 2, g = q & 3;
-        buf_store16_nosoff<D16_BWD_STORE_AUX>(da, lane16, (mat * 16 + q) * 1024,
+        buf_store16_nosoff<D16_BWD_STORE_AUX>((mat == 2 || (mat == 1 && q >= 8)) ? da_opt : da, lane16, (mat * 16 + q) * 1024,
                            make_float4(acc[rt][4 * g] * down, acc[rt][4 * g + 1] * down, acc[rt][4 * g + 2] * down,
                                        acc[rt][4 * g + 3] * down));
     };
@@ -808,13 +816,13 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_bwd_kernel(const float
                                                                      const float* __restrict__ saved,
                                                                      float* __restrict__ dfeat, float* __restrict__ dx,
                                                                      float* __restrict__ dact, float* __restrict__ dsmall,
-                                                                     uint32_t M, uint32_t* __restrict__ tile_live) {
+                                                                     uint32_t M, uint32_t* __restrict__ tile_live, uint32_t lean_dact) {
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (tile * 32 >= (int64_t)M) return;
     const ImgBuf bimg{make_srd(reinterpret_cast<const _Float16*>(packed16 + TAIL16_FLOATS) + OFF16_BWD_HALVES,
                                IMG16B_HALVES * 4), 0u, (uint32_t)IMG16B_HALVES * 2u};
-    decoder16_bwd_tile<LAYOUT>(bimg, x, out, dout, saved, dfeat, dx, dact, dsmall, M, tile, lane, tile_live);
+    decoder16_bwd_tile<LAYOUT>(bimg, x, out, dout, saved, dfeat, dx, dact, dsmall, M, tile, lane, tile_live, lean_dact != 0u);
 }
 
 // Large batches: persistent, one 8-wave workgroup per CU holding BOTH backward image sets in LDS: 2 x 80 KB = all 160 KB
@@ -832,7 +840,7 @@ __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_bwd_lds_kernel(con
                                                                              float* __restrict__ dact,
                                                                              float* __restrict__ dsmall, uint32_t M,
                                                                              uint32_t n_tiles,
-                                                                             uint32_t* __restrict__ tile_live) {
+                                                                             uint32_t* __restrict__ tile_live, uint32_t lean_dact) {
     extern __shared__ __attribute__((aligned(16))) float4 wbuf[];
     lds_preload<F16_LDS_BLOCK>(wbuf, reinterpret_cast<const _Float16*>(packed16 + TAIL16_FLOATS) + OFF16_BWD_HALVES, B16_LDS_BYTES / 16);
     __syncthreads();
@@ -860,7 +868,7 @@ __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_bwd_lds_kernel(con
             asm volatile("" : "+v"(z));
             const h8* imgp = reinterpret_cast<const h8*>(wbuf + z);
             decoder16_bwd_tile<LAYOUT>(ImgLds{imgp, imgp + IMG16B_HALVES / 8}, x, out, dout, saved, dfeat, dx, dact, dsmall,
-                                       M, (int64_t)tile, lane, tile_live);
+                                       M, (int64_t)tile, lane, tile_live, lean_dact != 0u);
         }
         return;
     }
@@ -872,7 +880,7 @@ __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_bwd_lds_kernel(con
         asm volatile("" : "+v"(z));
         const h8* imgp = reinterpret_cast<const h8*>(wbuf + z);
         decoder16_bwd_tile<LAYOUT>(ImgLds{imgp, imgp + IMG16B_HALVES / 8}, x, out, dout, saved, dfeat, dx, dact, dsmall, M,
-                                   (int64_t)tile, lane, tile_live);
+                                   (int64_t)tile, lane, tile_live, lean_dact != 0u);
     }
 }
 
@@ -1032,11 +1040,15 @@ int mipsf_decoder_bwd_chain16_ex(const float* packed16, int feat_layout, const f
     return mipsf_decoder_bwd_chain16_ex2(packed16, feat_layout, x, out, dout, saved, dfeat, dx, dact, tile_live, 0, M, stream);
 }
 
-// header_is_clear: the counters of tile_live were cleared by the forward (mipsf_decoder_fwd16_ex2) and not used since
+// flags: MIPSF_CHAIN_HEADER_CLEAR = the counters of tile_live were cleared by the forward (mipsf_decoder_fwd16_ex2) and not
+// used since; MIPSF_CHAIN_LEAN_DACT = the lean gradient record (see decoder16_bwd_tile)
 int mipsf_decoder_bwd_chain16_ex2(const float* packed16, int feat_layout, const float* x, const float* out,
                                   const float* dout, const float* saved, float* dfeat, float* dx, float* dact,
-                                  uint32_t* tile_live, int header_is_clear, uint32_t M, void* stream) {
+                                  uint32_t* tile_live, int flags, uint32_t M, void* stream) {
     if (M == 0) return 0;
+    MIPSF_REQUIRE((flags & ~(MIPSF_CHAIN_HEADER_CLEAR | MIPSF_CHAIN_LEAN_DACT)) == 0, "unknown flags 0x%x", flags);
+    const int header_is_clear = flags & MIPSF_CHAIN_HEADER_CLEAR;
+    const uint32_t lean_dact = (flags & MIPSF_CHAIN_LEAN_DACT) ? 1u : 0u;
     MIPSF_REQUIRE(packed16 && x && out && dout && saved && dfeat && dx, "null pointer");      // (dact may be NULL: see the header)
     MIPSF_REQUIRE(feat_layout == MIPSF_FEAT_AOS || feat_layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout");
     const uint64_t n_bt = ((uint64_t)M + 127) / 128;
@@ -1065,10 +1077,11 @@ int mipsf_decoder_bwd_chain16_ex2(const float* packed16, int feat_layout, const 
                 attr_set = true;                                                                                   \
             }                                                                                                      \
             hipLaunchKernelGGL((decoder16_bwd_lds_kernel<LAY>), dim3(cus), dim3(F16_LDS_BLOCK), B16_LDS_BYTES, s,   \
-                               packed16, x, out, dout, saved, dfeat, dx, dact, dsmall, M, n_tiles, tile_live);     \
+                               packed16, x, out, dout, saved, dfeat, dx, dact, dsmall, M, n_tiles, tile_live,      \
+                               lean_dact);                                                                         \
         } else {                                                                                                   \
             hipLaunchKernelGGL((decoder16_bwd_kernel<LAY>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed16, x, out,  \
-                               dout, saved, dfeat, dx, dact, dsmall, M, tile_live);                                \
+                               dout, saved, dfeat, dx, dact, dsmall, M, tile_live, lean_dact);                     \
         }                                                                                                          \
     } while (0)
     if (feat_layout == MIPSF_FEAT_AOS) B16(MIPSF_FEAT_AOS); else B16(MIPSF_FEAT_LEVEL_MAJOR);

@@ -212,6 +212,9 @@ struct W16Args {
     uint32_t live_start[8];             // first visit index of each list
     const h8* w1_hi;                    // LDS copies of the forward's layer-1 operand images (recompute variant), else null
     const h8* w1_lo;
+    // lean gradient record (MIPSF_WGRAD_LEAN_DACT, exchange form only): dG3 and the rgb_emb half of dH2 are recomputed
+    const h8* gimg;                     // LDS: [S2T hi: 4 row tiles][S2T lo: 4][RGBT hi: 2][RGBT lo: 2] x 64 operands, or null
+    const uint2* masks;                 // the ReLU mask part of `saved`
 };
 
 // the it-th tile of a pass, last first: the records the chain kernel wrote last are still in the 256 MB Infinity Cache
@@ -746,6 +749,38 @@ __device__ unsigned long long w16_trace[2048 * 16];
 #define W16_TRACE_DECL do { } while (0)
 #define W16_TRACE_SUM(n, wave) do { } while (0)
 #endif
+// ---- the lean gradient record: what the chain kernel (decoder16.hip, decoder16_bwd_tile) computed and did not store, with its
+// own operations in its own order -- bit for bit what it would have stored.
+// sm: (d logit 0..4, d rgb 0..2) of this lane's sample.  The chain scales every sample's gradients by a power of two `up` that
+// brings the largest of them to [0.5, 1) and stores results multiplied by `down` = 1 / up.
+__device__ __forceinline__ void w16x_updown(const f32x8& sm, float& up, float& down) {
+    float mx = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) mx = fmaxf(mx, fabsf(sm[c]));
+    up = 1.0f, down = 1.0f;
+    if (mx > 0.0f && mx < 3.0e38f) {
+        const int e = __builtin_amdgcn_frexp_expf(mx);
+        up = ldexpf(1.0f, -e), down = ldexpf(1.0f, e);
+    }
+}
+// the narrow product's B operand: half 0 carries the n values sm[first .. first + n) x up in elements 0 .. n - 1, half 1 zeros
+template <typename A>
+__device__ __forceinline__ void w16x_small_operand(const f32x8& sm, int first, int n, float up, int h, typename A::v8& bh, typename A::v8& bl) {
+    f32x8 v;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (h == 0 && u < n) ? sm[(first + u) & 7] * up : 0.0f;
+    bh = next_plane<A, false>(v), bl = next_plane<A, true>(v);
+}
+// one row tile of a one-k-step product (hi*hi + hi*lo + lo*hi, the chain's order) -> the 16 accumulator registers
+__device__ __forceinline__ f32x16 w16x_narrow(const h8 ah, const h8 al, const h8 bh, const h8 bl) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 acc = mfma16(ah, bh, zero);
+    acc = mfma16(ah, bl, acc);
+    acc = mfma16(al, bh, acc);
+    return acc;
+}
+constexpr int W16G_S2T_HI = 0, W16G_S2T_LO = 4 * 64, W16G_RGBT_HI = 8 * 64, W16G_RGBT_LO = 10 * 64, W16G_ENTRIES = 12 * 64;
+
 struct W16X {
     h8* xe;      // [2][4 k-steps][2 planes][64 lanes]
     h8* xa;      // [2][4 column tiles][4][64]
@@ -816,10 +851,16 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X& lx, co
         return make_srd(recs + (size_t)tile * ACT_TILE_FLOATS, ACT_TILE_FLOATS * 4);
     };
     const srd_t small_srd = make_srd(a.dsmall, a.M * 32u), x_srd = make_srd(a.x, a.M * 12u);
+    // small rows: BOTH halves read their sample's 8 values (the recomputation below scales by the sample); only half 0's copy
+    // enters the small-row products (the other half's lanes contribute zeros)
     auto load_small = [&](uint32_t tile, f32x8 (&v)[2]) {
-        const uint32_t off = h == 0 ? (tile * 32u + (uint32_t)j) * 32u : 0xfffffff0u;
+        const uint32_t off = (tile * 32u + (uint32_t)j) * 32u;
         const float4 p = buf_load16(small_srd, off, 0), q = buf_load16(small_srd, off, 16);
         v[0][0] = p.x, v[0][1] = p.y, v[0][2] = p.z, v[0][3] = p.w, v[0][4] = q.x, v[0][5] = q.y, v[0][6] = q.z, v[0][7] = q.w;
+    };
+    const bool recompute_x = a.gimg != nullptr && w >= 2;       // lean gradient record: dH2[2], dH2[3] = Wrgb^T drgb are not stored
+    auto dh2_srd = [&](uint32_t tile) {
+        return make_srd(a.dact + (size_t)tile * ACT_TILE_FLOATS, recompute_x ? 0 : ACT_TILE_FLOATS * 4);
     };
     auto load_x = [&](uint32_t tile, float (&v)[3]) {
         const uint32_t s_raw = tile * 32u + (uint32_t)j;
@@ -840,7 +881,7 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X& lx, co
     if (it < a.n_tiles) {
         const uint32_t t0 = w16_tile(a, it);
         load_x(t0, xn);
-        load_tile_rows(act_srd(a.dact, t0), 1, w, lane16, bX);
+        load_tile_rows(dh2_srd(t0), 1, w, lane16, bX);
         load_small(t0, bS);
         load_tile_rows(act_srd(a.saved, t0), 2, w, lane16, bH3);
         load_tile_rows(e_srd(t0), 1, 2 + (w & 1), lane16, bE);
@@ -900,6 +941,18 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X& lx, co
         W16_FENCE();
         W16_MARK(2);
         // ---- X = dH2[w]
+        if (recompute_x) {          // = (Wrgb[:, :64]^T drgb)[row tile w - 2], as the chain kernel computed it
+            float up, down;
+            w16x_updown(bS[0], up, down);
+            typename A::v8 rh, rl;
+            w16x_small_operand<A>(bS[0], N_CLASS, 3, up, h, rh, rl);
+            const f32x16 acc = w16x_narrow(a.gimg[W16G_RGBT_HI + (w - 2) * 64 + lane], a.gimg[W16G_RGBT_LO + (w - 2) * 64 + lane], rh, rl);
+            const float unscale = 1.0f / (float)(1 << W16_SHIFT);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) bX[q][u] = (acc[8 * q + u] * unscale) * down;
+        }
         {
             float rs;
             const float sx = w16_pick_scale(w16_block_max_bits(bX, 2), k_main, rs);
@@ -912,7 +965,7 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X& lx, co
         }
         transpose_block<A, true>(bX, I, X, bsum);
         W16_FENCE();
-        load_tile_rows(act_srd(a.dact, nt), 1, w, lane16, bX);          // the next tile's dH2
+        load_tile_rows(dh2_srd(nt), 1, w, lane16, bX);                  // the next tile's dH2
         W16_FENCE();
         W16_MARK(3);
         w16x_barrier();
@@ -924,6 +977,10 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X& lx, co
         W16_MARK(5);
         // ---- small rows: (d logits, d rgb)^T H3[w] (rows 0..15), ^T {rgb_emb | e} (rows 16..31)
         f32x8 sv1[2], sv2[2];
+        if (h != 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bS[0][u] = 0.0f;
+        }
         {
             float rs;
             const float sx = w16_pick_scale(w16_block_max_bits(bS, 1), k_small, rs);
@@ -1002,11 +1059,27 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X& lx, co
             for (int u = 0; u < 8; ++u)
                 bGr[q][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(grid_srd, voff, (uint32_t)(8 * q + u) * lstride, 0));
     };
+    // lean gradient record: dG3[rt] = relu'(H3[rt]) (Ws2^T dlogits)[rt] is recomputed from the sample's 8 small-row values and
+    // its mask bits (loaded one tile ahead like everything else); the record's dG3 pieces are then read through an empty resource
+    const bool lean = a.gimg != nullptr;
+    const srd_t small_srd = make_srd(a.dsmall, a.M * 32u);
+    f32x8 bSm;
+    uint2 bMk = make_uint2(0u, 0u);
+    auto load_lean = [&](uint32_t tile) {
+        const uint32_t off = (tile * 32u + (uint32_t)j) * 32u;
+        const float4 p = buf_load16(small_srd, off, 0), q = buf_load16(small_srd, off, 16);
+        bSm[0] = p.x, bSm[1] = p.y, bSm[2] = p.z, bSm[3] = p.w, bSm[4] = q.x, bSm[5] = q.y, bSm[6] = q.z, bSm[7] = q.w;
+        if (lean) bMk = a.masks[(size_t)tile * (MASK_TILE_WORDS / 2) + 64 + lane];
+    };
+    auto g3_srd = [&](uint32_t tile) {
+        return make_srd(a.dact + (size_t)tile * ACT_TILE_FLOATS, lean ? 0 : ACT_TILE_FLOATS * 4);
+    };
     uint32_t it = blockIdx.x, par = 0;
     if (it < a.n_tiles) {
         const uint32_t t0 = w16_tile(a, it);
         load_mine(t0);
-        load_tile_rows(act_srd(a.dact, t0), 2, rt, lane16, bG3);
+        load_lean(t0);
+        load_tile_rows(g3_srd(t0), 2, rt, lane16, bG3);
         load_tile_rows(act_srd(a.dact, t0), 0, rt, lane16, bG1);
     }
     w16x_barrier();
@@ -1047,6 +1120,19 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X& lx, co
         W16_FENCE();
         W16_MARK(1);
         // ---- X3 = dG3[rt], X1 = dG1[rt]
+        if (lean) {
+            float up, down;
+            w16x_updown(bSm, up, down);
+            typename A::v8 lh, ll;
+            w16x_small_operand<A>(bSm, 0, N_CLASS, up, h, lh, ll);
+            const f32x16 acc = w16x_narrow(a.gimg[W16G_S2T_HI + rt * 64 + lane], a.gimg[W16G_S2T_LO + rt * 64 + lane], lh, ll);
+            const uint32_t m3[2] = {bMk.x, bMk.y};
+            const float unscale = 1.0f / (float)(1 << W16_SHIFT);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) bG3[q][u] = mask_apply(m3, rt, 8 * q + u, acc[8 * q + u] * unscale) * down;
+        }
         {
             float rs;
             const float sx = w16_pick_scale(w16_block_max_bits(bG3, 2), k3, rs);
@@ -1060,7 +1146,8 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X& lx, co
         transpose_block<A, true>(bG3, I, X3, bsum0);
         W16_FENCE();
         W16_MARK(2);
-        load_tile_rows(act_srd(a.dact, nt), 2, rt, lane16, bG3);
+        load_lean(nt);
+        load_tile_rows(g3_srd(nt), 2, rt, lane16, bG3);
         W16_FENCE();
         {
             float rs;
@@ -1111,7 +1198,7 @@ __global__ __launch_bounds__(W16_BLOCK, 2) void decoder_wgrad16_kernel(const flo
                                                                        const float* __restrict__ dsmall,
                                                                        float* __restrict__ partial, uint32_t M,
                                                                        uint32_t n_tiles_all,
-                                                                       const uint32_t* __restrict__ live) {
+                                                                       const uint32_t* __restrict__ live, uint32_t lean_dact) {
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     // live: the chain kernel's live-tile buffer (mipsf_decoder_bwd_chain16_ex): eight lists, visited one after the other
     uint32_t n_tiles = n_tiles_all, live_start[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1137,11 +1224,23 @@ __global__ __launch_bounds__(W16_BLOCK, 2) void decoder_wgrad16_kernel(const flo
     constexpr bool EXCH = RECOMP && W16_EXCHANGE;
     __shared__ h8 w1img[RECOMP ? 2 * W1_ENTRIES : 1];
     __shared__ h8 xch[EXCH ? 2 * (W16X_XE + W16X_XA + W16X_XB) : 1];
+    __shared__ h8 gimg[EXCH ? W16G_ENTRIES : 1];
     if constexpr (RECOMP) {
         const h8* img = reinterpret_cast<const h8*>(packed16 + TAIL16_FLOATS);
         for (int q = tid; q < W1_ENTRIES; q += W16_BLOCK) {
             w1img[q] = img[OFF16H_F1 / 8 + q];
             w1img[W1_ENTRIES + q] = img[(IMG16H_HALVES + OFF16L_F1) / 8 + q];
+        }
+        if constexpr (EXCH) {       // the chain's two narrow products: operand images of the backward set (hi, then lo)
+            const h8* bimg = img + OFF16_BWD_HALVES / 8;
+            for (int q = tid; q < 4 * 64; q += W16_BLOCK) {
+                gimg[W16G_S2T_HI + q] = bimg[OFF16B_S2T / 8 + q];
+                gimg[W16G_S2T_LO + q] = bimg[(IMG16B_HALVES + OFF16B_S2T) / 8 + q];
+            }
+            for (int q = tid; q < 2 * 64; q += W16_BLOCK) {
+                gimg[W16G_RGBT_HI + q] = bimg[OFF16B_RGBT / 8 + q];
+                gimg[W16G_RGBT_LO + q] = bimg[(IMG16B_HALVES + OFF16B_RGBT) / 8 + q];
+            }
         }
         __syncthreads();
     }
@@ -1149,7 +1248,9 @@ __global__ __launch_bounds__(W16_BLOCK, 2) void decoder_wgrad16_kernel(const flo
                        live, tl_cap(n_tiles_all),
                        {live_start[0], live_start[1], live_start[2], live_start[3], live_start[4], live_start[5],
                         live_start[6], live_start[7]},
-                       RECOMP ? w1img : nullptr, RECOMP ? w1img + W1_ENTRIES : nullptr};
+                       RECOMP ? w1img : nullptr, RECOMP ? w1img + W1_ENTRIES : nullptr,
+                       (EXCH && lean_dact) ? gimg : nullptr,
+                       reinterpret_cast<const uint2*>(saved + (((size_t)M + 127) / 128) * 4 * ACT_TILE_FLOATS)};
     if constexpr (EXCH) {
         const W16X lx = {xch, xch + 2 * W16X_XE, xch + 2 * (W16X_XE + W16X_XA)};
         if (w < 4) w16x_role_a<LAYOUT, A>(a, lx, I, w, lane);
@@ -1199,7 +1300,19 @@ extern "C" int mipsf_decoder_wgrad16_tiles(const float* packed16, const float* f
                                            const float* saved, const float* dact, const uint32_t* tile_live,
                                            const mipsf_decoder_grads* grads, float* partial, int arithmetic, uint32_t M,
                                            void* stream) {
+    return mipsf_decoder_wgrad16_tiles_ex(packed16, feat, feat_layout, x, saved, dact, tile_live, grads, partial, arithmetic, 0u,
+                                          M, stream);
+}
+
+extern "C" int mipsf_decoder_wgrad16_tiles_ex(const float* packed16, const float* feat, int feat_layout, const float* x,
+                                              const float* saved, const float* dact, const uint32_t* tile_live,
+                                              const mipsf_decoder_grads* grads, float* partial, int arithmetic,
+                                              uint32_t flags, uint32_t M, void* stream) {
     if (M == 0) return 0;
+    MIPSF_REQUIRE((flags & ~(uint32_t)MIPSF_WGRAD_LEAN_DACT) == 0u, "unknown flags 0x%x", flags);
+    const uint32_t lean_dact = (flags & MIPSF_WGRAD_LEAN_DACT) ? 1u : 0u;
+    MIPSF_REQUIRE(!lean_dact || (packed16 != nullptr && arithmetic == MIPSF_PREC_F16X3 && W16_EXCHANGE),
+                  "the lean gradient record is read by the f16x3 kernel with packed16 only");
     MIPSF_REQUIRE(packed16 == nullptr || arithmetic == MIPSF_PREC_F16X3, "H1 is recomputed by the f16x3 arithmetic only");
     MIPSF_REQUIRE(feat && x && saved && dact && partial && grads, "null pointer");
     MIPSF_REQUIRE(feat_layout == MIPSF_FEAT_AOS || feat_layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout");
@@ -1216,7 +1329,7 @@ extern "C" int mipsf_decoder_wgrad16_tiles(const float* packed16, const float* f
     if (blocks > (uint32_t)W16_MAX_BLOCKS) blocks = (uint32_t)W16_MAX_BLOCKS;
     const uint32_t* live = tile_live;
 #define W16(LAY, AR, RC) hipLaunchKernelGGL((decoder_wgrad16_kernel<LAY, AR, RC>), dim3(blocks), dim3(W16_BLOCK), 0, s, packed16, \
-                                            feat, x, saved, dact, dsmall, partial, M, n_tiles, live)
+                                            feat, x, saved, dact, dsmall, partial, M, n_tiles, live, lean_dact)
 #define W16_L(LAY) do { if (arithmetic == MIPSF_PREC_F16X3) { if (packed16) W16(LAY, ArF16, true); else W16(LAY, ArF16, false); } \
                         else if (arithmetic == MIPSF_PREC_BF16X6) W16(LAY, ArBF3, false); else W16(LAY, ArBF2, false); } while (0)
     if (feat_layout == MIPSF_FEAT_AOS) W16_L(MIPSF_FEAT_AOS); else W16_L(MIPSF_FEAT_LEVEL_MAJOR);

@@ -170,6 +170,8 @@ def _scatter_counters(device, meta):
     return buf
 
 
+# the chain kernel leaves out the half of its gradient record that the weight-gradient kernel can recompute (experiments: 0)
+LEAN_DACT = not bool(os.environ.get("MIPSF_FULL_DACT"))
 HG_DPARAMS_ZERO = 1     # include/mipsf.h MIPSF_HG_DPARAMS_ZERO
 _HG_IGNORE_ZERO_HINT = bool(os.environ.get("MIPSF_HG_IGNORE_ZERO_HINT"))     # experiments: always read-modify-write
 
@@ -369,10 +371,15 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
     dact = None if (grads is None and precision == "f16x3") else torch.empty(lib().mipsf_decoder_dact_floats(M), dtype=torch.float32, device=dev)
     pe_mode = 0 if embed_pos is None else 1
     tile_live = None
+    lean_dact = False
     if precision == "f16x3":
         if embed_pos is not None or packed16 is None:
             raise RuntimeError("the f16x3 backward chain takes packed16 and computes the positional encoding in-kernel")
         hdr_clear = 0
+        # the lean gradient record (half of `dact`): when the exchange form of the streaming f16 kernel follows, which
+        # recomputes dG3 and the rgb_emb half of dH2 from the small rows + the ReLU masks (csrc/wgrad16.hip)
+        lean_dact = bool(LEAN_DACT and grads is not None and wgrad_precision == "stream_f16x3" and recompute_h1
+                         and packed16 is not None)
         if SKIP_ZERO_TILES and (grads is None or wgrad_precision.startswith("stream_")):
             global _LAST_TILE_LIVE
             pre = getattr(saved, "mipsf_tile_live", None)
@@ -385,7 +392,7 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
         with _timed("decoder_bwd_chain"):
             check(lib().mipsf_decoder_bwd_chain16_ex2(dptr(packed16), layout, dptr(x), dptr(out), dptr(dout), dptr(saved),
                                                       dptr(dfeat), dptr(dx), dptr(dact), dptr(tile_live, torch.int32),
-                                                      hdr_clear, M, stream_ptr()), "decoder_bwd_chain16")
+                                                      hdr_clear | (2 if lean_dact else 0), M, stream_ptr()), "decoder_bwd_chain16")
     else:
         with _timed("decoder_bwd_chain"):
             check(lib().mipsf_decoder_bwd_chain(dptr(packed), layout, dptr(x), pe_mode, dptr(out), dptr(dout),
@@ -402,9 +409,10 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
             if recompute_h1 and (arith != _lib.PREC["f16x3"] or packed16 is None):
                 raise RuntimeError("recompute_h1 needs wgrad_precision 'stream_f16x3' and packed16")
             with _timed("decoder_wgrad"):
-                check(lib().mipsf_decoder_wgrad16_tiles(dptr(packed16) if recompute_h1 else None, dptr(feat), layout,
-                                                        dptr(x), dptr(saved), dptr(dact),
-                                                        dptr(tile_live, torch.int32), C.byref(st), dptr(partial), arith, M, stream_ptr()),
+                check(lib().mipsf_decoder_wgrad16_tiles_ex(dptr(packed16) if recompute_h1 else None, dptr(feat), layout,
+                                                           dptr(x), dptr(saved), dptr(dact),
+                                                           dptr(tile_live, torch.int32), C.byref(st), dptr(partial), arith,
+                                                           1 if lean_dact else 0, M, stream_ptr()),
                       "decoder_wgrad16")
             return (dfeat, dx, dpe, tile_live) if return_tiles else (dfeat, dx, dpe)
         if recompute_h1:

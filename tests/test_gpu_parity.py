@@ -1682,6 +1682,19 @@ def test_decoder_f16x3_backward_chain_matches_fp32_kernel(dev, M, layout):
     for k, a, b, c in zip(ops.DECODER_PARAM_ORDER, g_full, g_rc, g_lean):
         assert_close(b, a, 1e-6, "recomputed H1 vs stored H1, grad " + k)
         assert_close(c, b, 1e-6, "lean record vs full record (H1 is not read either way), grad " + k)
+    # the lean GRADIENT record (the default behind recompute_h1: the chain leaves out dG3 and the rgb_emb half of dH2, the
+    # exchange form of the weight-gradient kernel recomputes them with the chain's own operations) against the full one
+    # through the same kernel: the same values enter the same products (the final reduction adds its slices atomically)
+    g_fd = [torch.zeros_like(w) for w in ws]
+    keep = ops.LEAN_DACT
+    ops.LEAN_DACT = False
+    try:
+        ops.decoder_bwd(None, feat, lay, x, None, outl, dout, savedl, g_fd, M, precision="f16x3", packed16=packed16,
+                        wgrad_precision="stream_f16x3", recompute_h1=True)
+    finally:
+        ops.LEAN_DACT = keep
+    for k, a, b in zip(ops.DECODER_PARAM_ORDER, g_lean, g_fd):
+        assert_close(a, b, 1e-6, "lean gradient record vs full gradient record, grad " + k)
     # (g_full is not compared with g32 here: this block differentiates the f16x3 forward, whose ReLU masks differ from
     # the fp32 forward's in a few of 9 M decisions)
     gw = [torch.zeros_like(w) for w in ws]
