@@ -99,11 +99,13 @@ KERNEL_COST = {
     "hashgrid_dx": ("hbm", 536.0, 0.0, "tile", "f32", None),            # saved Jacobian (384) + dL/dy (128) + dx read-modify-write (24)
     # lean activation record: H2 + H3 (1024 B) + ReLU masks; H1 is recomputed by the weight-gradient kernel
     "decoder_fwd": ("hbm", 12.0 + 128.0 + 40.0 + 1024.0 + 32.0, 0.0, None, "f16x3 (f16 MFMA on hi/lo split operands, fp32 accumulate)", 3),
-    # chain: a dead tile costs the read of its incoming gradient (40) and the zero d feat / d x it leaves (128 + 12)
-    "decoder_bwd_chain": ("hbm", 40.0 + 40.0 + 32.0 + 12.0 + 1536.0 + 32.0 + 128.0 + 12.0, 40.0 + 128.0 + 12.0, "tile",
+    # chain: a dead tile costs the read of its incoming gradient (40) and the zero d feat / d x it leaves (128 + 12); the LEAN
+    # gradient record (dG1 + the sdf_emb half of dH2: 768 B; dG3 and the rgb_emb half are recomputed by the weight-gradient kernel)
+    "decoder_bwd_chain": ("hbm", 40.0 + 40.0 + 32.0 + 12.0 + 768.0 + 32.0 + 128.0 + 12.0, 40.0 + 128.0 + 12.0, "tile",
                           "f16x3 (f16 MFMA on hi/lo split operands, fp32 accumulate)", 3),
-    # streaming kernel (csrc/wgrad16.hip): reads H2, H3 and the gradient record once (H1 recomputed) -- 2.7 KB per sample
-    "decoder_wgrad": ("hbm", 1024.0 + 1536.0 + 32.0 + 128.0 + 12.0, 0.0, "tile",
+    # streaming kernel (csrc/wgrad16.hip): reads H2, H3, the lean gradient record, the small rows and H3's mask bits once
+    # (H1, dG3 and d rgb_emb recomputed) -- 2.0 KB per sample
+    "decoder_wgrad": ("hbm", 1024.0 + 768.0 + 32.0 + 16.0 + 128.0 + 12.0, 0.0, "tile",
                       "f16x3 (f16 MFMA on hi/lo split operands under per-block power-of-two scales, fp32 accumulate)", 3),
     "sample_rays": ("hbm", 20.0, 0.0, None, "f32+f64", None),
     "render_fwd": ("hbm", 44.0, 0.0, None, "f32", None),
