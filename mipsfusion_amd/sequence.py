@@ -982,6 +982,15 @@ class GraphedSequence:
                 init = prev
             else:                                                            # constant velocity, in numpy (see _set_pose)
                 init = torch.from_numpy(prev.numpy() @ np.linalg.inv(est[-2].numpy()) @ prev.numpy())
+            if self.producer is not None:
+                # the frame's host-drawn samples go up BEFORE the RandomOptimizer rounds (they depend on nothing the GPU
+                # computes: the uploads run while the host would otherwise sit in the rounds' read-back)
+                tw = time.perf_counter()
+                samples = self.producer.get()
+                wait_ms = (time.perf_counter() - tw) * 1e3
+                assert samples.frame_id == k
+                self.go_idx.copy_(samples.track_idx, non_blocking=True)
+                self.go_noise.copy_(samples.track_noise, non_blocking=True)
             if self.graph_ro:
                 pose = self.ro.optimize_graphed(self.cur[:, 6], init, waiting=waiting)
             else:
@@ -994,24 +1003,19 @@ class GraphedSequence:
             self._set_pose(self.go_rot, self.go_trans, 0, pose)
             ta = time.perf_counter()
             self.go_popt.reset()
-            if self.producer is not None:
-                tw = time.perf_counter()
-                samples = self.producer.get()
-                wait_ms = (time.perf_counter() - tw) * 1e3
-                assert samples.frame_id == k
-                tb = time.perf_counter()
-                self.go_idx.copy_(samples.track_idx, non_blocking=True)
-                self.go_noise.copy_(samples.track_noise, non_blocking=True)
-                detail.setdefault("go_fill_parts_ms", []).append([round((ta - t1) * 1e3, 2), round((tw - ta) * 1e3, 2),
-                                                                  round((tb - tw) * 1e3, 2), round((time.perf_counter() - tb) * 1e3, 2)])
-            else:
+            if self.producer is None:
                 self._fill_go_device()
+            else:
+                detail.setdefault("go_fill_parts_ms", []).append([round((ta - t1) * 1e3, 2), round((time.perf_counter() - ta) * 1e3, 2)])
             t1b = time.perf_counter()
             ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev_a.record()
             self.go_graph.replay()
             ev_b.record()
             t1c = time.perf_counter()
+            n_ba_loaded = None
+            if k % mp["map_every"] == 0 and samples is not None:
+                n_ba_loaded = self._load_ba(samples)        # (queued behind the tracking graph: the host is idle in the read-back)
             pose = waiting(lambda: self._get_pose(self.go_rot, self.go_trans, 0))     # the read-back synchronises
             t2 = time.perf_counter()
             detail["go_fill_ms"].append((t1b - t1) * 1e3), detail["go_replay_ms"].append((t2 - t1b) * 1e3)
@@ -1023,7 +1027,7 @@ class GraphedSequence:
                 assert slots == self._timeline[k][1], "the sub-map bookkeeping left the planned timeline"
                 self._set_pose(self.ba_rot, self.ba_trans, -1, pose)
                 self.ba_popt.reset()
-                n = self._load_ba(samples) if samples is not None else self._fill_ba_device(slots)
+                n = n_ba_loaded if n_ba_loaded is not None else self._fill_ba_device(slots)
                 t2b = time.perf_counter()
                 self._ba_graph(n).replay()
                 pose = waiting(lambda: self._get_pose(self.ba_rot, self.ba_trans, -1))
