@@ -1014,8 +1014,9 @@ class GraphedSequence:
             ev_b.record()
             t1c = time.perf_counter()
             n_ba_loaded = None
-            if k % mp["map_every"] == 0 and samples is not None:
-                n_ba_loaded = self._load_ba(samples)        # (queued behind the tracking graph: the host is idle in the read-back)
+            if k % mp["map_every"] == 0:                    # the BA batch is queued behind the tracking graph: the host would be idle
+                n_ba_loaded = (self._load_ba(samples) if samples is not None      # in the read-back (same draws in the same order)
+                               else self._fill_ba_device(self.submaps[self.active]["kfs"]))
             pose = waiting(lambda: self._get_pose(self.go_rot, self.go_trans, 0))     # the read-back synchronises
             t2 = time.perf_counter()
             detail["go_fill_ms"].append((t1b - t1) * 1e3), detail["go_replay_ms"].append((t2 - t1b) * 1e3)
@@ -1027,7 +1028,7 @@ class GraphedSequence:
                 assert slots == self._timeline[k][1], "the sub-map bookkeeping left the planned timeline"
                 self._set_pose(self.ba_rot, self.ba_trans, -1, pose)
                 self.ba_popt.reset()
-                n = n_ba_loaded if n_ba_loaded is not None else self._fill_ba_device(slots)
+                n = n_ba_loaded
                 t2b = time.perf_counter()
                 self._ba_graph(n).replay()
                 pose = waiting(lambda: self._get_pose(self.ba_rot, self.ba_trans, -1))
