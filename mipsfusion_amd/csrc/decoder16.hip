@@ -391,10 +391,12 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
                 split8<true>(v, bh, bl);
             },
             [&](int t) {
+#ifndef D16_ABL_NO_H3_STORE         // experiments: what the forward would take without H3 in its record
                 if constexpr (SAVE == 1 || SAVE == 2) {
                     store_act_piece(sv, lane16, 2, H3, 2 * t);
                     store_act_piece(sv, lane16, 2, H3, 2 * t + 1);
                 }
+#endif
             });
 #pragma unroll
         for (int c = 0; c < N_CLASS; ++c) {
