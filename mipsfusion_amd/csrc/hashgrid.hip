@@ -442,6 +442,13 @@ __global__ __launch_bounds__(RT_BLOCK) void scatter_route_kernel(const float* __
 #define MIPSF_SC_ROUTE_FAST 1   // experiments: 0 = the general grouping for every sample
 #endif
     const bool aggregate = ns <= MIPSF_SC_AGG_MAX;
+#ifdef MIPSF_RT_TRACE
+    unsigned long long tr_t[10];
+#define RT_MARK(k) do { __builtin_amdgcn_sched_barrier(0); tr_t[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define RT_MARK(k) do { } while (0)
+#endif
+    RT_MARK(0);
     for (uint32_t q = threadIdx.x; q < ns; q += RT_BLOCK) cnt[q] = 0u;
     __syncthreads();
     const uint32_t s0 = chunk * (RT_BLOCK * SC_ROUTE_UNR);
@@ -465,6 +472,7 @@ __global__ __launch_bounds__(RT_BLOCK) void scatter_route_kernel(const float* __
             alive[u] = __ballot(live);
             if (lane == 0) wave_base[1 + u * (RT_BLOCK / 64) + wave] = (uint32_t)__popcll(alive[u]);
         }
+        RT_MARK(1);
         __syncthreads();
         static_assert((RT_BLOCK / 64) * SC_ROUTE_UNR <= 64, "one wave scans the (round, wave) counts");
         if (threadIdx.x < 64) {                      // inclusive prefix of the <= 64 (round, wave) counts
@@ -485,6 +493,7 @@ __global__ __launch_bounds__(RT_BLOCK) void scatter_route_kernel(const float* __
                     s0 + u * RT_BLOCK + threadIdx.x;
         __syncthreads();
     }
+    RT_MARK(2);
     const uint32_t n_live = wave_base[(RT_BLOCK / 64) * SC_ROUTE_UNR];
     // across the barrier, per sample: 8 slots of (slice < 512, rank < 4096) as 16-bit halves, masks as bytes
     uint32_t sp[SC_ROUTE_UNR][4], rp[SC_ROUTE_UNR][4], mp[SC_ROUTE_UNR][2];
@@ -528,7 +537,9 @@ __global__ __launch_bounds__(RT_BLOCK) void scatter_route_kernel(const float* __
         mp[u][0] = m[0] | (m[1] << 8) | (m[2] << 16) | (m[3] << 24);
         mp[u][1] = m[4] | (m[5] << 8) | (m[6] << 16) | (m[7] << 24);
     }
+    RT_MARK(3);
     __syncthreads();
+    RT_MARK(4);
     for (uint32_t q = threadIdx.x; q < ns; q += RT_BLOCK)
         base[q] = cnt[q] ? atomicAdd(&cw[plan.w_count + bin0 + q], cnt[q]) : 0u;
     if (MIPSF_SC_STAGE && threadIdx.x < 64) {       // exclusive prefix of the bin counts: where a bin starts in `stage`
@@ -554,7 +565,9 @@ __global__ __launch_bounds__(RT_BLOCK) void scatter_route_kernel(const float* __
             run += c[k];
         }
     }
+    RT_MARK(5);
     __syncthreads();
+    RT_MARK(6);
     // record = sample index | (the corners of the sample's cell that fall into this slice) << 24: the accumulate kernel
     // then hashes those corners only (on a hashed level 2 of 8: the pair along x) instead of all 8 plus 8 membership tests
     const bool masked = M <= SC_MASKED_MAX_M;
@@ -580,8 +593,10 @@ __global__ __launch_bounds__(RT_BLOCK) void scatter_route_kernel(const float* __
             }
         }
     }
+    RT_MARK(7);
     if (MIPSF_SC_STAGE) {
         __syncthreads();
+        RT_MARK(8);
         const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
         for (uint32_t q = wave; q < ns; q += RT_BLOCK / 64) {
             const uint32_t n = cnt[q], src = lstart[q];
@@ -589,8 +604,15 @@ __global__ __launch_bounds__(RT_BLOCK) void scatter_route_kernel(const float* __
             for (uint32_t p = lane; p < n && src + p < STAGE_CAP; p += 64) dstp[p] = stage[src + p];
         }
     }
+#ifdef MIPSF_RT_TRACE
+    RT_MARK(9);
+    if ((threadIdx.x & 63u) == 0u) {
+        unsigned long long* tr = reinterpret_cast<unsigned long long*>(ws + plan.w_end + 64) + (size_t)(blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6)) * 10;
+        for (int k = 0; k < 9; ++k) tr[k] = tr_t[k + 1] - tr_t[k];
+        tr[9] = (unsigned long long)level;
+    }
+#endif
 }
-
 __device__ __forceinline__ uint32_t part_of(const ScatterPlan& plan, uint32_t bin) {
     return bin < plan.dense_bins ? SC_PART_DENSE : SC_PART;
 }
@@ -1163,6 +1185,9 @@ uint64_t mipsf_hashgrid_bwd_scratch_floats(const mipsf_grid_meta* meta, uint32_t
 #ifdef MIPSF_SC_TRACE
     return p.w_end + 64 + 8ull * p.max_items + 64;
 #endif
+#ifdef MIPSF_RT_TRACE
+    return p.w_end + 64 + 20ull * (RT_BLOCK / 64) * (g.n_levels * ((M + RT_BLOCK * SC_ROUTE_UNR - 1) / (RT_BLOCK * SC_ROUTE_UNR))) + 64;
+#endif
     return p.w_end + (need_dx ? (uint64_t)g.n_levels * M * 3 : 0) + 64;
 }
 
@@ -1178,6 +1203,17 @@ uint64_t mipsf_hashgrid_trace_words(const mipsf_grid_meta* meta, uint32_t M, uin
 }
 #endif
 
+
+#ifdef MIPSF_RT_TRACE
+// word offset of the routing kernel's trace rows (10 x 8 bytes per wave: 9 phase durations in cycles + the level) and their number
+uint64_t mipsf_hashgrid_rt_trace_words(const mipsf_grid_meta* meta, uint32_t M, uint32_t* n_rows) {
+    GridLevels g;
+    if (to_levels(meta, g)) return 0;
+    const ScatterPlan p = make_plan(g, M);
+    *n_rows = (RT_BLOCK / 64) * g.n_levels * ((M + RT_BLOCK * SC_ROUTE_UNR - 1) / (RT_BLOCK * SC_ROUTE_UNR));
+    return p.w_end + 64;
+}
+#endif
 
 static int check_plan(const ScatterPlan& plan, const GridLevels& g, uint32_t M) {
     MIPSF_REQUIRE(plan.n_bins <= SC_MAX_BINS && plan.n_bins <= 0xffffu, "grid too large: %u table slices", plan.n_bins);
