@@ -15,7 +15,7 @@ f = synth.make_frame(cfg, seed=1)
 H, W, fx, fy, cx, cy = synth.intrinsics_after_crop(cfg)
 ds = types.SimpleNamespace(H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy, rays_d=f["direction"])
 init = f["c2w"].to(dev).float()
-for prec in ("f16", "f16x3"):
+for prec in ("f16x3", "f16", "f16x3", "f16"):
     ro = RandomOptimizer(cfg, types.SimpleNamespace(dataset=ds, device=dev))
     ro.decoder_precision = prec
     for _ in range(3):
