@@ -56,7 +56,17 @@ __global__ __launch_bounds__(256) void ro_particles_kernel(const float* __restri
     for (int k = 0; k < 9; ++k) rot[k] = state[RO_ROT + k];
     quat_to_mat(qw, r[0], r[1], r[2], dR);
     mat_mul3(rot, dR, aR);                                            // get_abs_pose
-    const float t0 = state[RO_TRANS] + r[3], t1 = state[RO_TRANS + 1] + r[4], t2 = state[RO_TRANS + 2] + r[5];
+    float t0 = state[RO_TRANS] + r[3], t1 = state[RO_TRANS + 1] + r[4], t2 = state[RO_TRANS + 2] + r[5];
+    // The particle's pose is the same in all 64 lanes by construction; it is taken from lane 0 explicitly.  With TWO processes
+    // time-slicing one GPU (bench.py --gpus 2 on a single device: tests only) ~7 % of the frames had lanes 48..63 of a few
+    // wavefronts of this kernel leave the section above with another pose (tools/dbg_ro_determinism2.py: 0 of 3000 frames
+    // differ run to run with one process per GPU, ~55 of 800 with two; with this broadcast 0 of 3000 with two).  Cause not
+    // established (a stand-alone kernel with the same arithmetic did not reproduce it); the first lanes were never affected.
+#pragma unroll
+    for (int k = 0; k < 9; ++k) aR[k] = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(aR[k])));
+    t0 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(t0)));
+    t1 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(t1)));
+    t2 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(t2)));
     for (uint32_t i = lane; i < n; i += MIPSF_WAVE) {
         const float d = target_d[i];
         const float c0 = rays_d_cam[3 * i] * d, c1 = rays_d_cam[3 * i + 1] * d, c2 = rays_d_cam[3 * i + 2] * d;
