@@ -587,6 +587,11 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
     // kernel is bound by its stores.
     const srd_t da_opt = make_srd(dact ? dact + (size_t)tile * ACT_TILE_FLOATS : nullptr, (dact && !lean_dact) ? ACT_TILE_FLOATS * 4 : 0);
 
+#ifdef D16_TRACE          // (tools/replay.py prints these for a -DD16_TRACE build)
+    unsigned long long tr_t[12];
+    const unsigned long long tr_w0 = wall_clock64();
+#endif
+    D16_MARK(0);
     float2 o2[5], g2[5];
     {
         const float2* g = reinterpret_cast<const float2*>(dout + (size_t)s * 10);
@@ -619,6 +624,7 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
             return;
         }
     }
+    D16_MARK(1);
     {
         const float2* o = reinterpret_cast<const float2*>(out + (size_t)s * 10);
 #pragma unroll
@@ -634,6 +640,7 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
     const uint2 mk1 = mk[0], mk3 = mk[64];
     const uint32_t m1[2] = {mk1.x, mk1.y}, m3[2] = {mk3.x, mk3.y};
 
+    D16_MARK(2);
     // ---- softmax / entropy / expected-class backward -> d logits; d rgb is the incoming gradient itself
     float dlg[N_CLASS], drgb[3];
     {
@@ -696,6 +703,7 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
                                        acc[rt][4 * g + 3] * down));
     };
 
+    D16_MARK(3);
     // ---- dG3 = relu'(H3) * (Ws2^T dlogits)
     f32x16 dG3[4];
     mfma16_layer<RT16_S2T, T16_S2T, SPLIT, INIT_ZERO>(bimg.at(OFF16B_S2T, OFF16B_S2T), lane, h, dG3,
@@ -705,6 +713,7 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) dG3[rt][r] = mask_apply(m3, rt, r, dG3[rt][r] * ACC_UNSCALE);
 
+    D16_MARK(4);
     // ---- d[sdf_emb | grid] = Ws1^T dG3   (row tiles 0,1 -> d sdf_emb, 2 -> d grid features); dG3 leaves for `dact`
     f32x16 dIn3[3];
     mfma16_layer<RT16_B3, T16_B3, SPLIT, INIT_ZERO>(bimg.at(OFF16B_B3, OFF16B_B3), lane, h, dIn3,
@@ -734,6 +743,7 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
         }
     }
 
+    D16_MARK(5);
     // ---- dH2 = [d sdf_emb | d rgb_emb = Wrgb[:, :64]^T drgb]
     f32x16 dH2[4];
     dH2[0] = dIn3[0], dH2[1] = dIn3[1];
@@ -744,6 +754,7 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
         dH2[2] = dRgb[0] * ACC_UNSCALE, dH2[3] = dRgb[1] * ACC_UNSCALE;
     }
 
+    D16_MARK(6);
     // ---- dG1 = relu'(H1) * (W2^T dH2)
     f32x16 dG1[4];
     mfma16_layer<RT16_B2, T16_B2, SPLIT, INIT_ZERO>(bimg.at(OFF16B_B2, OFF16B_B2), lane, h, dG1,
@@ -762,6 +773,7 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) dG1[rt][r] = mask_apply(m1, rt, r, dG1[rt][r] * ACC_UNSCALE);
 
+    D16_MARK(7);
     // ---- d e = W1^T dG1 + Wrgb[:, 64:]^T drgb; rows are arranged so that e-slot (t, h) lands in THIS lane
     f32x16 dE[2];
     mfma16_layer<RT16_B1, T16_B1, SPLIT, INIT_ZERO>(bimg.at(OFF16B_B1, OFF16B_B1), lane, h, dE,
@@ -782,6 +794,7 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
             }
         });
 
+    D16_MARK(8);
 #ifdef D16_BWD_X_LATE      // experiments: the old place of the load
     const float x0 = x[3 * (size_t)s], x1 = x[3 * (size_t)s + 1], x2 = x[3 * (size_t)s + 2];
 #endif
@@ -807,6 +820,15 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
     if (live && h == 0) {
         dx[3 * (size_t)s] = g3[0], dx[3 * (size_t)s + 1] = g3[1], dx[3 * (size_t)s + 2] = g3[2];
     }
+#ifdef D16_TRACE
+    D16_MARK(9);
+    if (lane == 0) {
+        const unsigned w = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 4095u;
+        for (int k = 0; k < 9; ++k) d16_trace[w * 16 + k] += tr_t[k + 1] - tr_t[k];
+        d16_trace[w * 16 + 12] += wall_clock64() - tr_w0;
+        d16_trace[w * 16 + 15] += 1ull;
+    }
+#endif
 }
 
 // Small batches: four independent waves per workgroup, operand images from L2.

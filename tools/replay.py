@@ -73,6 +73,36 @@ def report_wgrad_trace(lname, h):
             print(f"      wave {k + (0 if role == 'A' else 4)}: " + " ".join(f"{c:6.0f}" for c in p2))
 
 
+def report_chain_trace(lname, h, calls):
+    """-DD16_TRACE builds: cycles per LIVE tile between the marks of the backward chain's tile (one more pass over the calls,
+    the trace cleared in front of the chain call and read behind it)."""
+    try:
+        fn = h.mipsf_d16_trace_read
+    except AttributeError:
+        return
+    import numpy as np
+    buf = np.zeros(4096 * 16, dtype=np.uint64)
+    for n, a in calls:
+        if "bwd_chain" in n:
+            torch.cuda.synchronize()
+            fn(buf.ctypes.data_as(C.c_void_p), 1)
+        getattr(h, n)(*a)
+        if "bwd_chain" in n:
+            torch.cuda.synchronize()
+            fn(buf.ctypes.data_as(C.c_void_p), 1)
+            t = buf.reshape(4096, 16).astype(np.float64)
+            used = t[:, 15] > 0
+            names = ["dout loads + liveness", "out / masks / x loads", "softmax backward + scales", "S2T + mask", "B3 (+ dG3 stores)",
+                     "unscale + dfeat stores", "RGBT + B2 (+ dH2 stores)", "mask + B1 (+ dG1 stores)", "de -> dx"]
+            per = t[used, :9].sum(0) / t[used, 15].sum()
+            ns = t[used, 12].sum() / t[used, 15].sum() * 10.0
+            print(f"  [{lname}] chain: {int(t[used, 15].sum())} live tiles, {per.sum():.0f} cycles per tile in {ns:.0f} ns ({per.sum() / ns:.2f} GHz), "
+                  f"tiles per wave {t[used, 15].mean():.2f} (max {t[used, 15].max():.0f})")
+            for nm, c in zip(names, per):
+                print(f"      {nm:34s} {c:7.0f} {100 * c / per.sum():5.1f} %")
+    torch.cuda.synchronize()
+
+
 def main():
     names = [a for a in sys.argv[1:]]
     dev = torch.device("cuda", 0)
@@ -121,6 +151,7 @@ def main():
             us = sum(a.elapsed_time(b) for a, b in evs[k]) / len(evs[k]) * 1e3
             table_out.setdefault((k, n), {})[lname] = us
         report_wgrad_trace(lname, h)
+        report_chain_trace(lname, h, calls)
     w = max(len(n) for _, n in table_out) + 4
     print(" " * w + "".join(f"{l:>12s}" for l, _ in libs))
     tot = {l: 0.0 for l, _ in libs}
