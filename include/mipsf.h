@@ -158,6 +158,12 @@ int mipsf_decoder_fwd_sdf(const float* packed, const float* feat, int feat_layou
  *   _wgrad read, results agree with mipsf_decoder_fwd to fp32 round-off class.
  * precision MIPSF_PREC_F16: plain f16 operands (11 bits), fp32 accumulate: forward-only consumers with a stated
  *   tolerance (RandomOptimizer fitness; BASELINE config 5 "fp16 decoder on CDNA4"), `saved` must be NULL.
+ * precision MIPSF_PREC_BF16X6: every fp32 operand -- weight and activation -- is carried EXACTLY as three bf16 pieces
+ *   (8 + 8 + 8 = fp32's 24 significant bits, fp32's exponent range: v_mfma_f32_32x32x16_bf16) and a product is SIX MFMAs
+ *   (p0*p0 + p0*p1 + p1*p0 + p1*p1 + p0*p2 + p2*p0); the dropped pairs are below 2^-23 of |a||w|, under the rounding of the
+ *   fp32 accumulation: the arithmetic of the reference's fp32 nn.Linear layers (model/decoder.py:32-50) on the 16-bit matrix
+ *   pipe.  Needs a buffer packed by mipsf_decoder_pack16_ex(..., MIPSF_PREC_BF16X6, ...) (_packed16_floats_ex floats: the f16
+ *   layout with bf16 planes 0, 1 in place of hi, lo + plane 2 behind it); training (`saved`, lean_record) as for f16x3.
  * Positional encoding is always computed in-kernel (pe_mode 0).  sdf_only != 0: out is [M] (column 3 only).
  * packed16: mipsf_decoder_packed16_floats() floats written by mipsf_decoder_pack16 (compact hi / lo operand images of the two
  * narrow heads + their biases in fp32, hi and lo operand images of the three hidden layers, forward and backward sets); the
@@ -169,6 +175,10 @@ int mipsf_decoder_fwd_sdf(const float* packed, const float* feat, int feat_layou
 #define MIPSF_PREC_BF16X6 4
 uint32_t mipsf_decoder_packed16_floats(void);
 int mipsf_decoder_pack16(const mipsf_decoder_weights* w_host_struct, float* packed16, void* stream);
+/* ... for a given arithmetic: MIPSF_PREC_F16X3 / MIPSF_PREC_F16 = the two calls above; MIPSF_PREC_BF16X6 = the three bf16
+ * planes.  A buffer packed for one family must not be handed to the kernels of the other. */
+uint32_t mipsf_decoder_packed16_floats_ex(int precision);
+int mipsf_decoder_pack16_ex(const mipsf_decoder_weights* w_host_struct, float* packed16, int precision, void* stream);
 int mipsf_decoder_fwd16(const float* packed16, const float* feat, int feat_layout, const float* x, float* out,
                         float* saved, int sdf_only, int precision, uint32_t M, void* stream);
 /* lean_record != 0 (f16x3 with `saved` only): the record keeps H2, H3 and the ReLU masks but NOT H1 -- a third of the
@@ -209,6 +219,9 @@ int mipsf_decoder_fwd16_ex2(const float* packed16, const float* feat, int feat_l
  *                             which recomputes them bit for bit. */
 #define MIPSF_CHAIN_HEADER_CLEAR 1
 #define MIPSF_CHAIN_LEAN_DACT 2
+/*   MIPSF_CHAIN_BF16X6        packed16 holds bf16 planes (mipsf_decoder_pack16_ex with MIPSF_PREC_BF16X6): the chain's products
+ *                             run in the six-product bf16 arithmetic of mipsf_decoder_fwd16 (fp32 operands carried exactly) */
+#define MIPSF_CHAIN_BF16X6 4
 int mipsf_decoder_bwd_chain16_ex2(const float* packed16, int feat_layout, const float* x, const float* out,
                                   const float* dout, const float* saved, float* dfeat, float* dx, float* dact,
                                   uint32_t* tile_live, int flags, uint32_t M, void* stream);

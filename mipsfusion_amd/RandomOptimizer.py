@@ -132,7 +132,7 @@ class RandomOptimizer:
 
         def rounds():
             ws = model.decoder.ordered_parameters()
-            packed = ops.decoder_pack(ws) if self.decoder_precision == "f32" else ops.decoder_pack16(ws)
+            packed = ops.decoder_pack(ws) if self.decoder_precision == "f32" else ops.decoder_pack16(ws, precision=self.decoder_precision)
             for i in range(n_iter):
                 o = i % 5
                 self._enqueue_round(model, self._g_state, self._g_td5[o], self._dirs[o], rc, packed)
@@ -185,7 +185,7 @@ class RandomOptimizer:
         state[12:18] = float(self.scaling_coefficient1)
         rc = model._rc(1, 0)
         ws = model.decoder.ordered_parameters()
-        packed = ops.decoder_pack(ws) if self.decoder_precision == "f32" else ops.decoder_pack16(ws)
+        packed = ops.decoder_pack(ws) if self.decoder_precision == "f32" else ops.decoder_pack16(ws, precision=self.decoder_precision)
         for i in range(n_iter):
             o = i % 5
             self._enqueue_round(model, state, td5[o], self._dirs[o], rc, packed)

@@ -99,6 +99,8 @@ SIGNATURES = {
     "mipsf_decoder_fwd_sdf": (_I, [_P, _P, _I, _P, _P, _I, _P, _U32, _P]),
     "mipsf_decoder_packed16_floats": (_U32, []),
     "mipsf_decoder_pack16": (_I, [C.POINTER(DecoderWeights), _P, _P]),
+    "mipsf_decoder_packed16_floats_ex": (_U32, [_I]),
+    "mipsf_decoder_pack16_ex": (_I, [C.POINTER(DecoderWeights), _P, _I, _P]),
     "mipsf_decoder_fwd16": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _U32, _P]),
     "mipsf_decoder_fwd16_ex": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _U32, _P]),
     "mipsf_decoder_bwd_chain16": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _U32, _P]),

@@ -1,32 +1,47 @@
-// SDF/colour decoder forward (model/decoder.py:53-75 of the reference) on the f16 matrix cores of gfx950
-// (v_mfma_f32_32x32x16_f16, fp32 accumulate): 16x the rate of the fp32-input MFMA the parity path of decoder.hip uses.
+// SDF/colour decoder forward (model/decoder.py:53-75 of the reference) on the 16-bit matrix cores of gfx950
+// (v_mfma_f32_32x32x16_{f16,bf16}, fp32 accumulate): 16x the rate of the fp32-input MFMA the parity path of decoder.hip uses.
 //
-// Two arithmetic modes, one kernel template:
-//   SPLIT  ("f16x3")  every fp32 operand -- weights and activations -- is carried as hi + lo halves
-//                     (hi = rne(v), lo = rne(v - hi): 22 significant bits) and a product is three MFMAs,
-//                     hi*hi + hi*lo + lo*hi, accumulated in fp32.  Relative error of a dot product ~3e-7 (fp32's own
-//                     rounding is 6e-8): the training path, it passes the reference goldens at the fp32 kernel's
-//                     tolerances.  3/16 of the fp32-MFMA time in the matrix pipe.
-//   plain  ("f16")    one MFMA on the hi halves: 11-bit operands, fp32 accumulate.  Forward-only consumers whose
+// Three arithmetic modes, one kernel template (NP = number of 16-bit planes an fp32 operand is cut into):
+//   NP = 3 ("bf16x6") every fp32 operand -- weights and activations -- is carried EXACTLY as three bf16 pieces
+//                     (p0 = rne(v), p1 = rne(v - p0), p2 = v - p0 - p1: 8 + 8 + 8 = the 24 significant bits of fp32, with
+//                     fp32's exponent range) and a product is SIX MFMAs, p0*p0 + p0*p1 + p1*p0 + p1*p1 + p0*p2 + p2*p0,
+//                     accumulated in fp32.  The three dropped pairs (p1*p2, p2*p1, p2*p2) are below 2^-23 of |a||w|, i.e.
+//                     under the rounding of the fp32 accumulation itself: the arithmetic of five fp32 nn.Linear layers.
+//                     6/16 of the fp32-MFMA time in the matrix pipe.
+//   NP = 2 ("f16x3")  hi + lo f16 halves (hi = rne(v), lo = rne(v - hi): 22-23 significant bits), three MFMAs per product,
+//                     hi*hi + hi*lo + lo*hi.  Relative error of a dot product ~3e-7 (fp32's own rounding is 6e-8): the
+//                     fast training mode.  3/16 of the fp32-MFMA time in the matrix pipe.
+//   NP = 1 ("f16")    one MFMA on the hi halves: 11-bit operands, fp32 accumulate.  Forward-only consumers whose
 //                     tolerance allows it (RandomOptimizer fitness, BASELINE config 5 "fp16 decoder").
 //
 // Same transposed, register-chained evaluation as decoder.hip (decoder_layout.h): the C/D register layout of the MFMA
 // does not depend on the operand type, so accumulator registers 8m..8m+7 of row tile q ARE the 8 B-operand elements
-// of k-step 2q+m of the next layer after a float -> half conversion; the saved-activation record (`saved`: H1, H2, H3
+// of k-step 2q+m of the next layer after a float -> 16-bit conversion; the saved-activation record (`saved`: H1, H2, H3
 // as accumulator images + ReLU masks) is bit-for-bit the layout the fp32 backward kernels read.
 //
-// Range: |activation| and |weight| must stay below 65504 (f16); the conversions saturate, they never produce inf.
+// Range (f16 modes): |activation| and |weight| must stay below 65504; the conversions saturate, they never produce inf.
+// Where the operand planes live: planes 0 and 1 of the weight images in LDS (persistent kernels: 152 / 160 KB), plane 2 of
+// the bf16 mode (used by ONE of the six products) in L2, requested five product groups ahead of its use.
 #include "decoder_dev.h"
 #include <stdlib.h>
 
 namespace mipsf {
 using namespace dl;
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));       // 16 bytes of operand: 8 halves (f16 modes) or 8 bf16 (NP = 3)
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+template <int NP>
+__device__ __forceinline__ f32x16 mfmaP(h8 a, h8 b, f32x16 c) {
+    if constexpr (NP == 3)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
 // 8 fp32 values -> hi (and lo) halves: v_cvt_pk_f16_f32 (rne) per pair, two v_cvt_f32_f16, one v_pk_add_f32, one
@@ -48,6 +63,30 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
             const h2 q = {(_Float16)(v[i] - (float)p.x), (_Float16)(v[i + 1] - (float)p.y)};
             lo[i] = q.x, lo[i + 1] = q.y;
         }
+    }
+}
+// 8 fp32 values -> the NP operand planes.  NP = 3: three bf16 pieces, exact (v = p0 + p1 + p2): per pair v_cvt_pk_bf16_f32,
+// the widening of the pair (a shift and a mask), v_pk_add_f32 -- twice -- and the last v_cvt_pk = 4.5 vector instructions per
+// value.  Written with vector types and conversions only (no inline asm: an asm that reads a fresh MFMA result is not
+// hazard-padded by hipcc).
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+template <int NP>
+__device__ __forceinline__ void cut8(const float (&v)[8], h8 (&pl)[3]) {
+    if constexpr (NP == 3) {
+        bf8 p0, p1, p2;
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            const f32x2v x = {v[i], v[i + 1]};
+            const bf2 a = __builtin_convertvector(x, bf2);
+            const f32x2v r = x - __builtin_convertvector(a, f32x2v);
+            const bf2 b = __builtin_convertvector(r, bf2);
+            const f32x2v q = r - __builtin_convertvector(b, f32x2v);
+            const bf2 c = __builtin_convertvector(q, bf2);
+            p0[i] = a.x, p0[i + 1] = a.y, p1[i] = b.x, p1[i + 1] = b.y, p2[i] = c.x, p2[i + 1] = c.y;
+        }
+        pl[0] = __builtin_bit_cast(h8, p0), pl[1] = __builtin_bit_cast(h8, p1), pl[2] = __builtin_bit_cast(h8, p2);
+    } else {
+        split8<NP == 2>(v, pl[0], pl[1]);
     }
 }
 
@@ -112,9 +151,13 @@ constexpr float GRID_UPSCALE = (float)(1 << G16_SHIFT);
 // img_hi: [rt][T + BIAS][lane], img_lo: [rt][T][lane] 16-byte operands (LDS in the persistent kernel, L2 otherwise).
 // Where a layer's A operands come from: LDS (persistent kernels) or L2 through ONE buffer resource (16-byte loads with
 // a scalar / immediate offset per operand: no 64-bit vector address arithmetic, cf. decoder_dev.h).
+// Plane 2 (bf16 mode only) comes from L2 in both: one buffer resource over the plane-2 extension of `packed16`
+// (decoder_layout.h, EXT16_*), byte offset `off_p2` of this layer's image inside it.
 struct ImgLds {
     const h8* hi;
     const h8* lo;
+    srd_t r2;
+    uint32_t off_p2;
 #if D16_ABL & 8
     __device__ __forceinline__ h8 load_hi(int idx, int lane) const { const _Float16 c = (_Float16)(float)(idx + lane); return h8{c, c, c, c, c, c, c, c}; }
     __device__ __forceinline__ h8 load_lo(int idx, int lane) const { const _Float16 c = (_Float16)(float)(idx - lane); return h8{c, c, c, c, c, c, c, c}; }
@@ -122,97 +165,197 @@ struct ImgLds {
     __device__ __forceinline__ h8 load_hi(int idx, int lane) const { return hi[idx * 64 + lane]; }
     __device__ __forceinline__ h8 load_lo(int idx, int lane) const { return lo[idx * 64 + lane]; }
 #endif
-    __device__ __forceinline__ ImgLds at(int hi_halves, int lo_halves) const { return ImgLds{hi + hi_halves / 8, lo + lo_halves / 8}; }
+    __device__ __forceinline__ h8 load_p2(int idx, int lane) const {
+        return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(r2, 16u * (uint32_t)lane, off_p2 + (uint32_t)idx * 1024u, 0));
+    }
+    // hi_halves / lo_halves: this layer's offsets in the plane-0 and plane-1 image sets; p2_halves: in the plane-2 set of the
+    // same direction (forward: = lo_halves, the data k-steps only; backward: the same offset in all three)
+    __device__ __forceinline__ ImgLds at(int hi_halves, int lo_halves) const {
+        return ImgLds{hi + hi_halves / 8, lo + lo_halves / 8, r2, off_p2 + 2u * (uint32_t)lo_halves};
+    }
 };
 struct ImgBuf {
     srd_t r;
     uint32_t off_hi, off_lo;      // byte offsets of the two image sets inside the resource
+    srd_t r2;
+    uint32_t off_p2;
     __device__ __forceinline__ h8 load_hi(int idx, int lane) const {
         return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(r, 16u * (uint32_t)lane, off_hi + (uint32_t)idx * 1024u, 0));
     }
     __device__ __forceinline__ h8 load_lo(int idx, int lane) const {
         return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(r, 16u * (uint32_t)lane, off_lo + (uint32_t)idx * 1024u, 0));
     }
+    __device__ __forceinline__ h8 load_p2(int idx, int lane) const {
+        return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(r2, 16u * (uint32_t)lane, off_p2 + (uint32_t)idx * 1024u, 0));
+    }
     __device__ __forceinline__ ImgBuf at(int hi_halves, int lo_halves) const {
-        return ImgBuf{r, off_hi + 2u * (uint32_t)hi_halves, off_lo + 2u * (uint32_t)lo_halves};
+        return ImgBuf{r, off_hi + 2u * (uint32_t)hi_halves, off_lo + 2u * (uint32_t)lo_halves, r2, off_p2 + 2u * (uint32_t)lo_halves};
     }
 };
+// the plane-2 extension of a bf16x6 `packed16` as a buffer resource (an empty one for the f16 modes: never read)
+template <int NP>
+__device__ __forceinline__ srd_t ext16_srd(const float* packed16) {
+    return make_srd(NP == 3 ? reinterpret_cast<const _Float16*>(packed16 + PACKED16_FLOATS) : nullptr, NP == 3 ? EXT16_HALVES * 2 : 0);
+}
 
 constexpr int INIT_ACC = 0, INIT_ZERO = 1, INIT_BIAS = 2;
-template <int RT, int T, bool SPLIT, int INIT, typename Img, typename BFn, typename SideFn = NoSide16>
+// number of B-operand elements of a bias k-step that are the constant 1.0 (the bias rides as that many pieces)
+template <int NP> constexpr int bias_ones() { return NP == 3 ? 3 : 2; }
+template <int RT, int T, int NP, int INIT, typename Img, typename BFn, typename SideFn = NoSide16>
 __device__ __forceinline__ void mfma16_layer(const Img img, int lane, int h, f32x16 (&acc)[RT],
                                              BFn bfn, SideFn side = SideFn()) {
     constexpr bool BIAS = INIT == INIT_BIAS;
+    constexpr bool SPLIT = NP >= 2;
     constexpr int TH = T + (BIAS ? 1 : 0);
-    // registers: the hi operands are double-buffered (requested one k-step ahead), the lo operands are requested at
-    // the top of their own k-step -- they are first needed two MFMA groups (8 MFMAs, 256 cycles) later
-    h8 ah[RT], al[RT], nh[RT], bh, bl, nbh, nbl;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) ah[rt] = img.load_hi(rt * TH + (BIAS ? 1 : 0), lane);
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (BIAS) {
-        const _Float16 one = h == 0 ? (_Float16)1.0f : (_Float16)0.0f;
-        const h8 ones = {one, one, 0, 0, 0, 0, 0, 0};
+    if constexpr (NP == 3) {
+        // SIX products per k-step, in three groups around the operand fetches (A = weight planes a0, a1, a2; B = activation
+        // planes b[0..2]):   a0*b0, a0*b1, a0*b2 | a1*b0, a1*b1 | a2*b0
+        // a1 (LDS) is requested at the top of its k-step and first used a group later; the NEXT k-step's a0 (LDS) is requested
+        // into the same registers once this k-step's a0 group has issued; the next k-step's a2 (L2: ~1 us away) right after
+        // this k-step's only use of a2 -- five product groups ahead of its own.  48 operand registers for RT = 4.
+        h8 a0[RT], a1[RT], a2[RT], b[3], nb[3];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(img.load_hi(rt * TH, lane), ones, zero);
-    }
-    bfn(0, bh, bl);
+        for (int rt = 0; rt < RT; ++rt) a0[rt] = img.load_hi(rt * TH + (BIAS ? 1 : 0), lane);
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-        if (SPLIT) {
+        for (int rt = 0; rt < RT; ++rt) a2[rt] = img.load_p2(rt * T, lane);
+        if (BIAS) {
+            const _Float16 one = h == 0 ? __builtin_bit_cast(_Float16, (unsigned short)0x3f80) : (_Float16)0.0f;    // bf16 1.0
+            const h8 ones = {one, one, one, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) al[rt] = img.load_lo(rt * T + t, lane);
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = mfmaP<3>(img.load_hi(rt * TH, lane), ones, zero);
         }
-        if (t + 1 < T) {
+        bfn(0, b);
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) nh[rt] = img.load_hi(rt * TH + t + 1 + (BIAS ? 1 : 0), lane);
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) a1[rt] = img.load_lo(rt * T + t, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = mfmaP<3>(a0[rt], b[0], (INIT == INIT_ZERO && t == 0) ? zero : acc[rt]);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = mfmaP<3>(a0[rt], b[1], acc[rt]);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = mfmaP<3>(a0[rt], b[2], acc[rt]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < T) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) a0[rt] = img.load_hi(rt * TH + t + 1 + (BIAS ? 1 : 0), lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = mfmaP<3>(a1[rt], b[1], acc[rt]);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = mfmaP<3>(a1[rt], b[0], acc[rt]);
+            __builtin_amdgcn_sched_barrier(0);
+            // the next B operand is cut here, under the MFMAs in flight: planes 1 and 2 of this k-step are dead by now (their
+            // registers take the new planes), only plane 0 is still wanted
+            if (t + 1 < T) bfn(t + 1, nb);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = mfmaP<3>(a2[rt], b[0], acc[rt]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < T) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) a2[rt] = img.load_p2(rt * T + t + 1, lane);
+            }
+            side(t);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < T) b[0] = nb[0], b[1] = nb[1], b[2] = nb[2];
         }
-        __builtin_amdgcn_sched_barrier(0);
+        return;
+    } else {
+        // registers: the hi operands are double-buffered (requested one k-step ahead), the lo operands are requested at
+        // the top of their own k-step -- they are first needed two MFMA groups (8 MFMAs, 256 cycles) later
+        h8 ah[RT], al[RT], nh[RT], b[3], nb[3];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(ah[rt], bh, (INIT == INIT_ZERO && t == 0) ? zero : acc[rt]);
-        if (SPLIT) {
+        for (int rt = 0; rt < RT; ++rt) ah[rt] = img.load_hi(rt * TH + (BIAS ? 1 : 0), lane);
+        if (BIAS) {
+            const _Float16 one = h == 0 ? (_Float16)1.0f : (_Float16)0.0f;
+            const h8 ones = {one, one, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(ah[rt], bl, acc[rt]);
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(al[rt], bh, acc[rt]);
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(img.load_hi(rt * TH, lane), ones, zero);
         }
-        if (t + 1 < T) bfn(t + 1, nbh, nbl);           // conversions of the next B operand ride under these MFMAs
-        side(t);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < T) {
+        bfn(0, b);
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) ah[rt] = nh[rt];
-            bh = nbh, bl = nbl;
+        for (int t = 0; t < T; ++t) {
+            if (SPLIT) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) al[rt] = img.load_lo(rt * T + t, lane);
+            }
+            if (t + 1 < T) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) nh[rt] = img.load_hi(rt * TH + t + 1 + (BIAS ? 1 : 0), lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(ah[rt], b[0], (INIT == INIT_ZERO && t == 0) ? zero : acc[rt]);
+            if (SPLIT) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(ah[rt], b[1], acc[rt]);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(al[rt], b[0], acc[rt]);
+            }
+            if (t + 1 < T) bfn(t + 1, nb);           // conversions of the next B operand ride under these MFMAs
+            side(t);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < T) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) ah[rt] = nh[rt];
+                b[0] = nb[0], b[1] = nb[1];
+            }
         }
     }
 }
 
-// A narrow head (decoder_layout.h, HEAD16): out = W_head * B over 8 k-steps; HSPLIT: hi/lo split like the layers (three MFMAs
-// per k-step, two accumulators so that no MFMA waits for the one in front of it: acc0 = hi*hi + lo*hi, acc1 = hi*lo), else
-// the hi halves only.  Both arithmetic modes use the split heads: with hi halves only the plain f16 mode's forward error
+// A narrow head (decoder_layout.h, HEAD16): out = W_head * B over 8 k-steps; NPH = 2: hi/lo split like the layers (three MFMAs
+// per k-step, two accumulators so that no MFMA waits for the one in front of it: acc0 = hi*hi + lo*hi, acc1 = hi*lo), NPH = 1
+// the hi halves only, NPH = 3 the six products of the bf16 mode (acc0 and acc1 in turn).  Both f16 modes use the split heads:
+// with hi halves only the plain f16 mode's forward error
 // doubles (4.3e-4 against its stated 2e-4, test_decoder_true_error_of_every_arithmetic_against_fp64) for 6 % of a
 // RandomOptimizer round.  himg: the head's
-// compact image in LDS ([t][plane][SLOTS] 16-byte operands), slot: this lane's operand slot.
-template <int SLOTS, bool HSPLIT, typename BFn, typename SideFn = NoSide16>
-__device__ __forceinline__ void mfma16_head(const h8* himg, int slot, f32x16& acc0, f32x16& acc1, BFn bfn, SideFn side = SideFn()) {
+// compact image in LDS ([t][plane 0, 1][SLOTS] 16-byte operands), slot: this lane's operand slot; plane 2 ([t][SLOTS]) at byte
+// offset off2 of the L2 resource r2.
+template <int SLOTS, int NPH, typename BFn, typename SideFn = NoSide16>
+__device__ __forceinline__ void mfma16_head(const h8* himg, int slot, srd_t r2, uint32_t off2, f32x16& acc0, f32x16& acc1, BFn bfn,
+                                            SideFn side = SideFn()) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    h8 ah = himg[slot], al = himg[SLOTS + slot], nh, nl, bh, bl, nbh, nbl;
-    bfn(0, bh, bl);
+    h8 ah = himg[slot], al = himg[SLOTS + slot], nh, nl, b[3], nb[3], a2, na2;
+    auto load2 = [&](int t) {
+        return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(r2, 16u * (uint32_t)slot, off2 + (uint32_t)(t * SLOTS) * 16u, 0));
+    };
+    if constexpr (NPH == 3) a2 = load2(0);
+    bfn(0, b);
 #pragma unroll
     for (int t = 0; t < T16_HEAD; ++t) {
         if (t + 1 < T16_HEAD) nh = himg[(2 * t + 2) * SLOTS + slot], nl = himg[(2 * t + 3) * SLOTS + slot];
-        __builtin_amdgcn_sched_barrier(0);
-        acc0 = mfma16(ah, bh, t == 0 ? zero : acc0);
-        if (HSPLIT) {
-            acc1 = mfma16(ah, bl, t == 0 ? zero : acc1);
-            acc0 = mfma16(al, bh, acc0);
-        } else if (t == 0) {
-            acc1 = zero;
+        if constexpr (NPH == 3) {
+            if (t + 1 < T16_HEAD) na2 = load2(t + 1);
         }
-        if (t + 1 < T16_HEAD) bfn(t + 1, nbh, nbl);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NPH == 3) {
+            acc0 = mfmaP<3>(ah, b[0], t == 0 ? zero : acc0);
+            acc1 = mfmaP<3>(ah, b[1], t == 0 ? zero : acc1);
+            acc0 = mfmaP<3>(al, b[0], acc0);
+            acc1 = mfmaP<3>(al, b[1], acc1);
+            acc0 = mfmaP<3>(ah, b[2], acc0);
+            acc1 = mfmaP<3>(a2, b[0], acc1);
+        } else {
+            acc0 = mfma16(ah, b[0], t == 0 ? zero : acc0);
+            if (NPH == 2) {
+                acc1 = mfma16(ah, b[1], t == 0 ? zero : acc1);
+                acc0 = mfma16(al, b[0], acc0);
+            } else if (t == 0) {
+                acc1 = zero;
+            }
+        }
+        if (t + 1 < T16_HEAD) bfn(t + 1, nb);
         side(t);
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < T16_HEAD) ah = nh, al = nl, bh = nbh, bl = nbl;
+        if (t + 1 < T16_HEAD) {
+            ah = nh, al = nl, b[0] = nb[0], b[1] = nb[1], b[2] = nb[2];
+            if constexpr (NPH == 3) a2 = na2;
+        }
     }
 }
 
@@ -221,11 +364,18 @@ __device__ __forceinline__ void mfma16_head(const h8* himg, int slot, f32x16& ac
 // record) is left out: the streaming weight-gradient kernel recomputes it from x (wgrad16.hip) and nothing else reads it;
 // 3 the ReLU MASKS only (32 B per sample instead of 1 KB): all the backward chain reads of the record -- for a frozen decoder
 // (tracking: pose-only optimisation) no weight gradients follow and the activations would be written for nobody
-template <int LAYOUT, int SAVE, bool SDF_ONLY, bool SPLIT, typename Img>
+template <int LAYOUT, int SAVE, bool SDF_ONLY, int NP, typename Img>
 __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img img,
                                                    const float* __restrict__ feat, const float* __restrict__ x,
                                                    float* __restrict__ out, float* __restrict__ saved, uint32_t M,
-                                                   int pin, int64_t tile, int lane, float (&xq)[3], int64_t next_tile) {
+                                                   int pin, int64_t tile, int lane_in, float (&xq)[3], int64_t next_tile) {
+    constexpr int NPH = NP == 3 ? 3 : 2;       // planes of the two narrow heads (the f16 modes both use the split heads)
+    // bf16 mode: the lane index is made opaque per tile, so that the dozen per-lane offsets derived from it (operand slots of
+    // the heads, LDS and record addresses) are recomputed by every tile -- a few vector instructions -- instead of living across
+    // the persistent kernel's tile loop: with 48 operand registers per layer there they were spilled, and a scratch reload waits
+    // for every memory operation in flight
+    int lane = lane_in;
+    if constexpr (NP == 3) asm volatile("" : "+v"(lane));
     const int j = lane & 31, h = lane >> 5;
     const uint32_t s_raw = (uint32_t)(tile * 32 + j);
     const bool live = s_raw < M;
@@ -241,26 +391,41 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
     // xq: this tile's coordinates, loaded by the caller / by the previous tile of this wave BEFORE its record stores: memory
     // operations retire in order, and a load issued behind the 16 + stores of a tile waits for all of them (the e phase of the
     // training forward took 2800 cycles instead of 1600, tools/micro/fwd_probe.py)
-    float ev[E_SLOTS];
+    // the f16 modes keep the 26 e values of this lane for layer 1 and the rgb head; the bf16 mode has no registers to spare
+    // for them (48 operand registers per layer) and evaluates the 8 values of a k-step where it cuts them -- twice per tile,
+    // under the MFMAs of the k-step in front
+    constexpr bool KEEP_E = NP != 3;
+    float ev[KEEP_E ? E_SLOTS : 1];
+    const float xe0 = xq[0], xe1 = xq[1], xe2 = xq[2];
+    auto e_step = [&](int t, int u) -> float {        // e slot 8 t + u of this half (0 beyond the 26 slots)
+        if constexpr (KEEP_E) {
+            return 8 * t + u < E_SLOTS ? ev[(8 * t + u) < E_SLOTS ? 8 * t + u : 0] : 0.0f;
+        } else {
+            if (t < 3) return sin_reduced(fmaf(ldexpf(t == 0 ? xe0 : (t == 1 ? xe1 : xe2), u), PI_F, h ? HALF_PI_F : 0.0f));
+            return u == 0 ? (h ? xe1 : xe0) : (u == 1 ? (h ? 0.0f : xe2) : 0.0f);
+        }
+    };
+    if constexpr (KEEP_E) {
 #if D16_ABL & 2
 #pragma unroll
-    for (int k = 0; k < E_SLOTS; ++k) ev[k] = xq[k % 3] * (float)(k + 1);
+        for (int k = 0; k < E_SLOTS; ++k) ev[k] = xq[k % 3] * (float)(k + 1);
 #else
-    e_from_x(xq[0], xq[1], xq[2], h, ev);
+        e_from_x(xq[0], xq[1], xq[2], h, ev);
 #endif
+    }
 
     D16_MARK(1);
     // ---- layer 1: pts_linear.0 + ReLU   (bias: elements BIAS16_U, +1 of k-step BIAS16_T meet the constant 1.0)
     f32x16 H1[4];
-    mfma16_layer<RT_F1, T16_F1, SPLIT, INIT_ZERO>(img.at(OFF16H_F1, OFF16L_F1), lane, h, H1,
-        [&](int t, h8& bh, h8& bl) {
+    mfma16_layer<RT_F1, T16_F1, NP, INIT_ZERO>(img.at(OFF16H_F1, OFF16L_F1), lane, h, H1,
+        [&](int t, h8 (&b)[3]) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                v[u] = 8 * t + u < E_SLOTS ? ev[8 * t + u] : 0.0f;
-                if (t == BIAS16_T && (u == BIAS16_U || u == BIAS16_U + 1)) v[u] = 1.0f;
+                v[u] = e_step(t, u);
+                if (t == BIAS16_T && u >= BIAS16_U && u < BIAS16_U + bias_ones<NP>()) v[u] = 1.0f;
             }
-            split8<SPLIT>(v, bh, bl);
+            cut8<NP>(v, b);
         });
     D16_MARK(2);
 #pragma unroll
@@ -274,12 +439,12 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
     // ---- layer 2: pts_linear.2 -> [sdf_emb | rgb_emb]   (H1 leaves in two 16-byte pieces per k-step)
     constexpr int RT2 = SDF_ONLY ? 2 : RT_F2;
     f32x16 H2[RT2];
-    mfma16_layer<RT2, T16_F2, SPLIT, INIT_BIAS>(img.at(OFF16H_F2, OFF16L_F2), lane, h, H2,
-        [&](int t, h8& bh, h8& bl) {
+    mfma16_layer<RT2, T16_F2, NP, INIT_BIAS>(img.at(OFF16H_F2, OFF16L_F2), lane, h, H2,
+        [&](int t, h8 (&b)[3]) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = H1[t >> 1][8 * (t & 1) + u];
-            split8<SPLIT>(v, bh, bl);
+            cut8<NP>(v, b);
         },
         [&](int t) {
             if constexpr (SAVE == 1) {
@@ -296,13 +461,14 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
 
     // grid features of layer 3 (feature h of the 16 levels): requested before the rgb head, which covers the latency
     float gf[16];
-    if (LAYOUT == MIPSF_FEAT_LEVEL_MAJOR && M < (1u << 24)) {
+    // (the bf16 mode's launcher requires M < 2^24: no flat-pointer path, whose hoisted 64-bit addresses would spill)
+    if (LAYOUT == MIPSF_FEAT_LEVEL_MAJOR && (NP == 3 || M < (1u << 24))) {
         const srd_t fs = make_srd(feat, M * 128u);
         const uint32_t voff = (2u * s + (uint32_t)h) * 4u;
 #pragma unroll
         for (int u = 0; u < 16; ++u)
             gf[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(fs, voff, (uint32_t)u * M * 8u, 0));
-    } else if (LAYOUT == MIPSF_FEAT_AOS && M < (1u << 24)) {
+    } else if (LAYOUT == MIPSF_FEAT_AOS && (NP == 3 || M < (1u << 24))) {
         const srd_t fs = make_srd(feat, M * 128u);        // [sample][level][feature]: one lane offset, 16 immediates
         const uint32_t voff = s * 128u + (uint32_t)h * 4u;
 #pragma unroll
@@ -317,13 +483,14 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
     float rgb[3] = {0.f, 0.f, 0.f};
     if constexpr (!SDF_ONLY) {
         f32x16 r0, r1;
-        mfma16_head<HEAD16_RGB_SLOTS, true>(reinterpret_cast<const h8*>(tail) + HEAD16_SDF_HALVES / 8, head16_rgb_slot(j, h), r0, r1,
-            [&](int t, h8& bh, h8& bl) {
+        mfma16_head<HEAD16_RGB_SLOTS, NPH>(reinterpret_cast<const h8*>(tail) + HEAD16_SDF_HALVES / 8, head16_rgb_slot(j, h),
+            img.r2, (uint32_t)EXT16_HEAD_RGB * 2u, r0, r1,
+            [&](int t, h8 (&b)[3]) {
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    v[u] = t < 4 ? H2[2 + (t >> 1)][8 * (t & 1) + u] : (8 * (t - 4) + u < E_SLOTS ? ev[8 * (t - 4) + u] : 0.0f);
-                split8<true>(v, bh, bl);
+                    v[u] = t < 4 ? H2[2 + (t >> 1)][8 * (t & 1) + u] : e_step(t < 4 ? 0 : t - 4, u);
+                cut8<NPH>(v, b);
             },
             [&](int t) {       // the rgb_emb half of H2 leaves piece by piece behind the k-steps that read it: a burst of
                                // 8 (and of 16 for H3 below) stalls on the store path's back pressure (1300 / 1900 cycles)
@@ -342,13 +509,13 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
     D16_MARK(7);
     // ---- layer 3: sdf_linear.0 + ReLU on [sdf_emb (H2 tiles 0,1) | grid features]
     f32x16 H3[4];
-    mfma16_layer<RT_F3, T16_F3, SPLIT, INIT_BIAS>(img.at(OFF16H_F3, OFF16L_F3), lane, h, H3,
-        [&](int t, h8& bh, h8& bl) {
+    mfma16_layer<RT_F3, T16_F3, NP, INIT_BIAS>(img.at(OFF16H_F3, OFF16L_F3), lane, h, H3,
+        [&](int t, h8 (&b)[3]) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 v[u] = t < 4 ? H2[(t >> 1) & 1][8 * (t & 1) + u] : gf[(8 * (t - 4) + u) & 15] * GRID_UPSCALE;
-            split8<SPLIT>(v, bh, bl);
+            cut8<NP>(v, b);
         },
         [&](int t) {                                   // the sdf_emb half of H2 (8 pieces) over the first 4 k-steps
             if constexpr ((SAVE == 1 || SAVE == 2) && !SDF_ONLY) {
@@ -383,12 +550,13 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
     float lg[N_CLASS], mx = -3.0e38f;
     {
         f32x16 s0, s1;
-        mfma16_head<HEAD16_SDF_SLOTS, true>(reinterpret_cast<const h8*>(tail), head16_sdf_slot(j, h), s0, s1,
-            [&](int t, h8& bh, h8& bl) {
+        mfma16_head<HEAD16_SDF_SLOTS, NPH>(reinterpret_cast<const h8*>(tail), head16_sdf_slot(j, h), img.r2,
+            (uint32_t)EXT16_HEAD_SDF * 2u, s0, s1,
+            [&](int t, h8 (&b)[3]) {
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) v[u] = H3[t >> 1][8 * (t & 1) + u];
-                split8<true>(v, bh, bl);
+                cut8<NPH>(v, b);
             },
             [&](int t) {
 #ifndef D16_ABL_NO_H3_STORE         // experiments: what the forward would take without H3 in its record
@@ -461,7 +629,7 @@ __device__ __forceinline__ void lds_preload(float4* dst, const void* src_base, i
 }
 
 // Small batches: four independent waves per workgroup, operand images from L2, head tables + biases in LDS.
-template <int LAYOUT, int SAVE, bool SDF_ONLY, bool SPLIT>
+template <int LAYOUT, int SAVE, bool SDF_ONLY, int NP>
 __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_fwd_kernel(const float* __restrict__ packed16,
                                                                      const float* __restrict__ feat,
                                                                      const float* __restrict__ x,
@@ -478,23 +646,24 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_fwd_kernel(const float
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (tile * 32 >= (int64_t)M) return;
-    const ImgBuf img{make_srd(packed16 + TAIL16_FLOATS, (IMG16H_HALVES + IMG16L_HALVES) * 2), 0u, (uint32_t)IMG16H_HALVES * 2u};
+    const ImgBuf img{make_srd(packed16 + TAIL16_FLOATS, (IMG16H_HALVES + IMG16L_HALVES) * 2), 0u, (uint32_t)IMG16H_HALVES * 2u,
+                     ext16_srd<NP>(packed16), (uint32_t)EXT16_FWD * 2u};
     float xq[3];
     {
         const uint32_t s_raw = (uint32_t)(tile * 32 + (lane & 31));
         const uint32_t s0 = s_raw < M ? s_raw : M - 1;
         xq[0] = x[3 * (size_t)s0], xq[1] = x[3 * (size_t)s0 + 1], xq[2] = x[3 * (size_t)s0 + 2];
     }
-    decoder16_fwd_tile<LAYOUT, SAVE, SDF_ONLY, SPLIT>(reinterpret_cast<const float*>(tailbuf), img, feat, x, out, saved, M,
+    decoder16_fwd_tile<LAYOUT, SAVE, SDF_ONLY, NP>(reinterpret_cast<const float*>(tailbuf), img, feat, x, out, saved, M,
                                                       pin, tile, lane, xq, (int64_t)-1);
 }
 
 // Large batches: persistent, one 8-wave workgroup per CU with the operand images (80 KB hi, + 72 KB lo when SPLIT) and
 // the head tables in LDS for its whole share of the batch (cf. decoder_fwd_lds_kernel).
 constexpr int F16_LDS_BLOCK = 512;
-template <bool SPLIT>
-constexpr int f16_lds_bytes() { return TAIL16_FLOATS * 4 + IMG16H_HALVES * 2 + (SPLIT ? IMG16L_HALVES * 2 : 0); }
-template <int LAYOUT, int SAVE, bool SDF_ONLY, bool SPLIT>
+template <int NP>
+constexpr int f16_lds_bytes() { return TAIL16_FLOATS * 4 + IMG16H_HALVES * 2 + (NP >= 2 ? IMG16L_HALVES * 2 : 0); }
+template <int LAYOUT, int SAVE, bool SDF_ONLY, int NP>
 __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_fwd_lds_kernel(const float* __restrict__ packed16,
                                                                              const float* __restrict__ feat,
                                                                              const float* __restrict__ x,
@@ -508,7 +677,7 @@ __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_fwd_lds_kernel(con
 #ifdef D16_TRACE
     const unsigned long long tr_k0 = wall_clock64();
 #endif
-    lds_preload<F16_LDS_BLOCK>(wbuf, packed16, f16_lds_bytes<SPLIT>() / 16);
+    lds_preload<F16_LDS_BLOCK>(wbuf, packed16, f16_lds_bytes<NP>() / 16);
     __syncthreads();
 #ifdef D16_TRACE
     if ((threadIdx.x & 63) == 0) {
@@ -535,8 +704,9 @@ __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_fwd_lds_kernel(con
         asm volatile("" : "+v"(z));
         const float4* w4 = wbuf + z;
         const h8* imgp = reinterpret_cast<const h8*>(w4 + TAIL16_FLOATS / 4);
-        decoder16_fwd_tile<LAYOUT, SAVE, SDF_ONLY, SPLIT>(reinterpret_cast<const float*>(w4),
-                                                          ImgLds{imgp, imgp + IMG16H_HALVES / 8}, feat, x, out, saved, M,
+        decoder16_fwd_tile<LAYOUT, SAVE, SDF_ONLY, NP>(reinterpret_cast<const float*>(w4),
+                                                          ImgLds{imgp, imgp + IMG16H_HALVES / 8, ext16_srd<NP>(packed16), (uint32_t)EXT16_FWD * 2u},
+                                                          feat, x, out, saved, M,
                                                           pin, (int64_t)tile, lane, xq,
                                                           tile + stride < n_tiles ? (int64_t)(tile + stride) : (int64_t)-1);
     }
@@ -564,14 +734,14 @@ __device__ __forceinline__ void tl_append(uint32_t* tl, uint32_t n_tiles, uint32
     tl[TL_HEADER + q * tl_cap(n_tiles) + atomicAdd(tl + 64 * q + 32, 1u)] = tile;
 }
 
-template <int LAYOUT, typename Img>
+template <int LAYOUT, int NP, typename Img>
 __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* __restrict__ x,
                                                    const float* __restrict__ out, const float* __restrict__ dout,
                                                    const float* __restrict__ saved, float* __restrict__ dfeat,
                                                    float* __restrict__ dx, float* __restrict__ dact,
                                                    float* __restrict__ dsmall, uint32_t M, int64_t tile, int lane,
                                                    uint32_t* __restrict__ tile_live = nullptr, bool lean_dact = false) {
-    constexpr bool SPLIT = true;
+    static_assert(NP == 2 || NP == 3, "the chain runs on split operands");
     const int j = lane & 31, h = lane >> 5;
     const uint32_t s_raw = (uint32_t)(tile * 32 + j);
     const bool live = s_raw < M;
@@ -684,7 +854,7 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
         }
     }
     // B operands of the two narrow products: half 0 carries the 5 (3) values in elements 0..4 (0..2), half 1 zeros
-    h8 lgh, lgl, rgh, rgl;
+    h8 lgp[3], rgp[3];
     {
         float v[8], r[8];
 #pragma unroll
@@ -692,8 +862,8 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
             v[u] = (h == 0 && u < N_CLASS) ? dlg[u < N_CLASS ? u : 0] * up : 0.0f;
             r[u] = (h == 0 && u < 3) ? drgb[u < 3 ? u : 0] * up : 0.0f;
         }
-        split8<SPLIT>(v, lgh, lgl);
-        split8<SPLIT>(r, rgh, rgl);
+        cut8<NP>(v, lgp);
+        cut8<NP>(r, rgp);
     }
     // a 16-byte piece of a (scaled) gradient tile, back at its true magnitude, into `dact`
     auto store_piece = [&](int mat, const f32x16 (&acc)[4], int q) {
@@ -706,8 +876,8 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
     D16_MARK(3);
     // ---- dG3 = relu'(H3) * (Ws2^T dlogits)
     f32x16 dG3[4];
-    mfma16_layer<RT16_S2T, T16_S2T, SPLIT, INIT_ZERO>(bimg.at(OFF16B_S2T, OFF16B_S2T), lane, h, dG3,
-        [&](int, h8& b0, h8& b1) { b0 = lgh, b1 = lgl; });
+    mfma16_layer<RT16_S2T, T16_S2T, NP, INIT_ZERO>(bimg.at(OFF16B_S2T, OFF16B_S2T), lane, h, dG3,
+        [&](int, h8 (&b)[3]) { b[0] = lgp[0], b[1] = lgp[1], b[2] = lgp[2]; });
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -716,12 +886,12 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
     D16_MARK(4);
     // ---- d[sdf_emb | grid] = Ws1^T dG3   (row tiles 0,1 -> d sdf_emb, 2 -> d grid features); dG3 leaves for `dact`
     f32x16 dIn3[3];
-    mfma16_layer<RT16_B3, T16_B3, SPLIT, INIT_ZERO>(bimg.at(OFF16B_B3, OFF16B_B3), lane, h, dIn3,
-        [&](int t, h8& b0, h8& b1) {
+    mfma16_layer<RT16_B3, T16_B3, NP, INIT_ZERO>(bimg.at(OFF16B_B3, OFF16B_B3), lane, h, dIn3,
+        [&](int t, h8 (&b)[3]) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = dG3[t >> 1][8 * (t & 1) + u];
-            split8<SPLIT>(v, b0, b1);
+            cut8<NP>(v, b);
         },
         [&](int t) {
             store_piece(2, dG3, 2 * t);
@@ -749,20 +919,20 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
     dH2[0] = dIn3[0], dH2[1] = dIn3[1];
     {
         f32x16 dRgb[2];
-        mfma16_layer<RT16_RGBT, T16_RGBT, SPLIT, INIT_ZERO>(bimg.at(OFF16B_RGBT, OFF16B_RGBT), lane, h, dRgb,
-            [&](int, h8& b0, h8& b1) { b0 = rgh, b1 = rgl; });
+        mfma16_layer<RT16_RGBT, T16_RGBT, NP, INIT_ZERO>(bimg.at(OFF16B_RGBT, OFF16B_RGBT), lane, h, dRgb,
+            [&](int, h8 (&b)[3]) { b[0] = rgp[0], b[1] = rgp[1], b[2] = rgp[2]; });
         dH2[2] = dRgb[0] * ACC_UNSCALE, dH2[3] = dRgb[1] * ACC_UNSCALE;
     }
 
     D16_MARK(6);
     // ---- dG1 = relu'(H1) * (W2^T dH2)
     f32x16 dG1[4];
-    mfma16_layer<RT16_B2, T16_B2, SPLIT, INIT_ZERO>(bimg.at(OFF16B_B2, OFF16B_B2), lane, h, dG1,
-        [&](int t, h8& b0, h8& b1) {
+    mfma16_layer<RT16_B2, T16_B2, NP, INIT_ZERO>(bimg.at(OFF16B_B2, OFF16B_B2), lane, h, dG1,
+        [&](int t, h8 (&b)[3]) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = dH2[t >> 1][8 * (t & 1) + u];
-            split8<SPLIT>(v, b0, b1);
+            cut8<NP>(v, b);
         },
         [&](int t) {
             store_piece(1, dH2, 2 * t);
@@ -776,15 +946,15 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
     D16_MARK(7);
     // ---- d e = W1^T dG1 + Wrgb[:, 64:]^T drgb; rows are arranged so that e-slot (t, h) lands in THIS lane
     f32x16 dE[2];
-    mfma16_layer<RT16_B1, T16_B1, SPLIT, INIT_ZERO>(bimg.at(OFF16B_B1, OFF16B_B1), lane, h, dE,
-        [&](int t, h8& b0, h8& b1) {
+    mfma16_layer<RT16_B1, T16_B1, NP, INIT_ZERO>(bimg.at(OFF16B_B1, OFF16B_B1), lane, h, dE,
+        [&](int t, h8 (&b)[3]) {
             if (t == 8) {
-                b0 = rgh, b1 = rgl;
+                b[0] = rgp[0], b[1] = rgp[1], b[2] = rgp[2];
             } else {
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) v[u] = dG1[(t >> 1) & 3][8 * (t & 1) + u];
-                split8<SPLIT>(v, b0, b1);
+                cut8<NP>(v, b);
             }
         },
         [&](int t) {
@@ -832,7 +1002,7 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
 }
 
 // Small batches: four independent waves per workgroup, operand images from L2.
-template <int LAYOUT>
+template <int LAYOUT, int NP>
 __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_bwd_kernel(const float* __restrict__ packed16,
                                                                      const float* __restrict__ x,
                                                                      const float* __restrict__ out,
@@ -845,15 +1015,15 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_bwd_kernel(const float
     const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (tile * 32 >= (int64_t)M) return;
     const ImgBuf bimg{make_srd(reinterpret_cast<const _Float16*>(packed16 + TAIL16_FLOATS) + OFF16_BWD_HALVES,
-                               IMG16B_HALVES * 4), 0u, (uint32_t)IMG16B_HALVES * 2u};
-    decoder16_bwd_tile<LAYOUT>(bimg, x, out, dout, saved, dfeat, dx, dact, dsmall, M, tile, lane, tile_live, lean_dact != 0u);
+                               IMG16B_HALVES * 4), 0u, (uint32_t)IMG16B_HALVES * 2u, ext16_srd<NP>(packed16), (uint32_t)EXT16_BWD * 2u};
+    decoder16_bwd_tile<LAYOUT, NP>(bimg, x, out, dout, saved, dfeat, dx, dact, dsmall, M, tile, lane, tile_live, lean_dact != 0u);
 }
 
 // Large batches: persistent, one 8-wave workgroup per CU holding BOTH backward image sets in LDS: 2 x 80 KB = all 160 KB
 // of the CU (the backward needs no tables besides them).
 constexpr int B16_LDS_BYTES = IMG16B_HALVES * 4;
 static_assert(B16_LDS_BYTES <= 160 * 1024, "the backward image sets must fit the LDS of a CU");
-template <int LAYOUT>
+template <int LAYOUT, int NP>
 __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_bwd_lds_kernel(const float* __restrict__ packed16,
                                                                              const float* __restrict__ x,
                                                                              const float* __restrict__ out,
@@ -891,7 +1061,8 @@ __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_bwd_lds_kernel(con
             uint32_t z = 0;
             asm volatile("" : "+v"(z));
             const h8* imgp = reinterpret_cast<const h8*>(wbuf + z);
-            decoder16_bwd_tile<LAYOUT>(ImgLds{imgp, imgp + IMG16B_HALVES / 8}, x, out, dout, saved, dfeat, dx, dact, dsmall,
+            decoder16_bwd_tile<LAYOUT, NP>(ImgLds{imgp, imgp + IMG16B_HALVES / 8, ext16_srd<NP>(packed16), (uint32_t)EXT16_BWD * 2u},
+                                       x, out, dout, saved, dfeat, dx, dact, dsmall,
                                        M, (int64_t)tile, lane, tile_live, lean_dact != 0u);
         }
         return;
@@ -903,34 +1074,47 @@ __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_bwd_lds_kernel(con
         uint32_t z = 0;
         asm volatile("" : "+v"(z));
         const h8* imgp = reinterpret_cast<const h8*>(wbuf + z);
-        decoder16_bwd_tile<LAYOUT>(ImgLds{imgp, imgp + IMG16B_HALVES / 8}, x, out, dout, saved, dfeat, dx, dact, dsmall, M,
+        decoder16_bwd_tile<LAYOUT, NP>(ImgLds{imgp, imgp + IMG16B_HALVES / 8, ext16_srd<NP>(packed16), (uint32_t)EXT16_BWD * 2u},
+                                   x, out, dout, saved, dfeat, dx, dact, dsmall, M,
                                    (int64_t)tile, lane, tile_live, lean_dact != 0u);
     }
 }
 
+// NP = 2: f16 hi / lo images (the f16x3 and plain f16 modes).  NP = 3: the three bf16 planes of the bf16x6 mode -- planes 0, 1
+// where the f16 layout has hi, lo, plane 2 in the extension behind it (decoder_layout.h, EXT16_*).
+template <int NP>
 __global__ __launch_bounds__(256) void decoder_pack16_kernel(W w, float* __restrict__ packed16) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    uint16_t* ext = reinterpret_cast<uint16_t*>(packed16 + PACKED16_FLOATS);
+    // element of plane `pl` behind the fp32 value v, as its 16 storage bits
+    auto piece = [&](float v, int pl) -> uint16_t {
+        if (NP == 3) return bf16_bits(bf16_piece(v, pl));
+        const _Float16 hi = (_Float16)v;
+        return __builtin_bit_cast(uint16_t, pl == 0 ? hi : (_Float16)(v - (float)hi));
+    };
     if (idx < HEAD16_HALVES) {
         int plane;
         const float v = head16_weight(w, idx, plane);
-        const _Float16 hi = (_Float16)v;
-        reinterpret_cast<_Float16*>(packed16)[idx] = plane == 0 ? hi : (_Float16)(v - (float)hi);
+        reinterpret_cast<uint16_t*>(packed16)[idx] = piece(v, plane);
+        if (NP == 3 && plane == 0) ext[head16_ext_index(idx)] = piece(v, 2);
     }
     if (idx < 12) packed16[OFF16_BSMALL + idx] = packed_value(w, OFF_BSMALL + idx);
     if (idx < IMG16H_HALVES) {
-        _Float16* img = reinterpret_cast<_Float16*>(packed16 + TAIL16_FLOATS);
-        const float v = img16_weight(w, idx);
-        const _Float16 hi = (_Float16)v;
-        img[idx] = hi;
+        uint16_t* img = reinterpret_cast<uint16_t*>(packed16 + TAIL16_FLOATS);
+        const float v = img16_weight(w, idx, NP);
+        img[idx] = piece(v, 0);
         const int lo = img16_lo_index(idx);
-        if (lo >= 0) img[IMG16H_HALVES + lo] = (_Float16)(v - (float)hi);
+        if (lo >= 0) {
+            img[IMG16H_HALVES + lo] = piece(v, 1);
+            if (NP == 3) ext[EXT16_FWD + lo] = piece(v, 2);
+        }
     }
     if (idx < IMG16B_HALVES) {
-        _Float16* img = reinterpret_cast<_Float16*>(packed16 + TAIL16_FLOATS) + OFF16_BWD_HALVES;
+        uint16_t* img = reinterpret_cast<uint16_t*>(packed16 + TAIL16_FLOATS) + OFF16_BWD_HALVES;
         const float v = img16b_weight(w, idx);
-        const _Float16 hi = (_Float16)v;
-        img[idx] = hi;
-        img[IMG16B_HALVES + idx] = (_Float16)(v - (float)hi);
+        img[idx] = piece(v, 0);
+        img[IMG16B_HALVES + idx] = piece(v, 1);
+        if (NP == 3) ext[EXT16_BWD + idx] = piece(v, 2);
     }
 }
 
@@ -969,13 +1153,29 @@ int mipsf_d16_trace_read(unsigned long long* host, int clear) {
 }
 #endif
 uint32_t mipsf_decoder_packed16_floats(void) { return (uint32_t)PACKED16_FLOATS; }
+uint32_t mipsf_decoder_packed16_floats_ex(int precision) {
+    return precision == MIPSF_PREC_BF16X6 ? (uint32_t)PACKED16X_FLOATS : (uint32_t)PACKED16_FLOATS;
+}
 
 int mipsf_decoder_pack16(const mipsf_decoder_weights* w, float* packed16, void* stream) {
+    return mipsf_decoder_pack16_ex(w, packed16, MIPSF_PREC_F16X3, stream);
+}
+
+// precision MIPSF_PREC_F16X3 / MIPSF_PREC_F16: the f16 hi / lo images (one buffer serves both modes);
+// MIPSF_PREC_BF16X6: the three bf16 planes (mipsf_decoder_packed16_floats_ex(MIPSF_PREC_BF16X6) floats) -- a buffer packed for
+// one family must not be handed to the kernels of the other
+int mipsf_decoder_pack16_ex(const mipsf_decoder_weights* w, float* packed16, int precision, void* stream) {
     MIPSF_REQUIRE(w && packed16, "null pointer");
+    MIPSF_REQUIRE(precision == MIPSF_PREC_F16X3 || precision == MIPSF_PREC_F16 || precision == MIPSF_PREC_BF16X6,
+                  "precision must be f16x3, f16 or bf16x6");
     static_assert(IMG16H_HALVES >= HEAD16_HALVES && IMG16H_HALVES >= IMG16B_HALVES, "one thread per hi-image element covers all");
-    static_assert(f16_lds_bytes<true>() <= 160 * 1024, "tail + both image sets must fit the 160 KB of LDS of a CU");
-    hipLaunchKernelGGL(decoder_pack16_kernel, dim3((IMG16H_HALVES + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       to_w16(*w), packed16);
+    static_assert(f16_lds_bytes<2>() <= 160 * 1024, "tail + both image sets must fit the 160 KB of LDS of a CU");
+    if (precision == MIPSF_PREC_BF16X6)
+        hipLaunchKernelGGL(decoder_pack16_kernel<3>, dim3((IMG16H_HALVES + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           to_w16(*w), packed16);
+    else
+        hipLaunchKernelGGL(decoder_pack16_kernel<2>, dim3((IMG16H_HALVES + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           to_w16(*w), packed16);
     return check_launch("decoder_pack16");
 }
 
@@ -997,10 +1197,13 @@ int mipsf_decoder_fwd16_ex2(const float* packed16, const float* feat, int feat_l
     uint32_t* clear_hdr = tile_live_clear;
     if (M == 0) return 0;
     MIPSF_REQUIRE(packed16 && feat && x && out, "null pointer");
-    MIPSF_REQUIRE(!lean_record || (saved && precision == MIPSF_PREC_F16X3), "the lean record belongs to the f16x3 training forward");
+    MIPSF_REQUIRE(!lean_record || (saved && (precision == MIPSF_PREC_F16X3 || precision == MIPSF_PREC_BF16X6)),
+                  "the lean record belongs to the f16x3 / bf16x6 training forward");
     MIPSF_REQUIRE(feat_layout == MIPSF_FEAT_AOS || feat_layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout");
-    MIPSF_REQUIRE(precision == MIPSF_PREC_F16X3 || precision == MIPSF_PREC_F16, "precision must be f16x3 or f16");
+    MIPSF_REQUIRE(precision == MIPSF_PREC_F16X3 || precision == MIPSF_PREC_F16 || precision == MIPSF_PREC_BF16X6,
+                  "precision must be f16x3, f16 or bf16x6");
     MIPSF_REQUIRE(!(sdf_only && saved), "the SDF-only forward keeps no activations");
+    MIPSF_REQUIRE(precision != MIPSF_PREC_BF16X6 || M < (1u << 24), "bf16x6: M = %u, at most 2^24 - 1 samples per call", M);
     const uint32_t n_tiles = (uint32_t)(((uint64_t)M + 31) / 32);
     const uint32_t blocks = (n_tiles + 3) / 4;
     hipStream_t s = (hipStream_t)stream;
@@ -1031,18 +1234,22 @@ int mipsf_decoder_fwd16_ex2(const float* packed16, const float* feat, int feat_l
                                packed16, feat, x, out, saved, M, 0, clear_hdr);                                    \
         }                                                                                                          \
     } while (0)
-#define F16_MODE(LAY, SPL)                                  \
+#define F16_MODE(LAY, SPL, SPLS)                            \
     do {                                                    \
         if (sdf_only) F16(LAY, 0, true, SPL);               \
-        else if (saved != nullptr && lean_record == 2) F16(LAY, 3, false, true); \
-        else if (saved != nullptr && lean_record) F16(LAY, 2, false, true); \
+        else if (saved != nullptr && lean_record == 2) F16(LAY, 3, false, SPLS); \
+        else if (saved != nullptr && lean_record) F16(LAY, 2, false, SPLS); \
         else if (saved != nullptr) F16(LAY, 1, false, SPL); \
         else F16(LAY, 0, false, SPL);                       \
     } while (0)
     if (feat_layout == MIPSF_FEAT_AOS) {
-        if (precision == MIPSF_PREC_F16X3) F16_MODE(MIPSF_FEAT_AOS, true); else F16_MODE(MIPSF_FEAT_AOS, false);
+        if (precision == MIPSF_PREC_BF16X6) F16_MODE(MIPSF_FEAT_AOS, 3, 3);
+        else if (precision == MIPSF_PREC_F16X3) F16_MODE(MIPSF_FEAT_AOS, 2, 2);
+        else F16_MODE(MIPSF_FEAT_AOS, 1, 2);
     } else {
-        if (precision == MIPSF_PREC_F16X3) F16_MODE(MIPSF_FEAT_LEVEL_MAJOR, true); else F16_MODE(MIPSF_FEAT_LEVEL_MAJOR, false);
+        if (precision == MIPSF_PREC_BF16X6) F16_MODE(MIPSF_FEAT_LEVEL_MAJOR, 3, 3);
+        else if (precision == MIPSF_PREC_F16X3) F16_MODE(MIPSF_FEAT_LEVEL_MAJOR, 2, 2);
+        else F16_MODE(MIPSF_FEAT_LEVEL_MAJOR, 1, 2);
     }
 #undef F16_MODE
 #undef F16
@@ -1070,7 +1277,8 @@ int mipsf_decoder_bwd_chain16_ex2(const float* packed16, int feat_layout, const 
                                   const float* dout, const float* saved, float* dfeat, float* dx, float* dact,
                                   uint32_t* tile_live, int flags, uint32_t M, void* stream) {
     if (M == 0) return 0;
-    MIPSF_REQUIRE((flags & ~(MIPSF_CHAIN_HEADER_CLEAR | MIPSF_CHAIN_LEAN_DACT)) == 0, "unknown flags 0x%x", flags);
+    MIPSF_REQUIRE((flags & ~(MIPSF_CHAIN_HEADER_CLEAR | MIPSF_CHAIN_LEAN_DACT | MIPSF_CHAIN_BF16X6)) == 0, "unknown flags 0x%x", flags);
+    const bool bf = (flags & MIPSF_CHAIN_BF16X6) != 0;
     const int header_is_clear = flags & MIPSF_CHAIN_HEADER_CLEAR;
     const uint32_t lean_dact = (flags & MIPSF_CHAIN_LEAN_DACT) ? 1u : 0u;
     MIPSF_REQUIRE(packed16 && x && out && dout && saved && dfeat && dx, "null pointer");      // (dact may be NULL: see the header)
@@ -1087,28 +1295,32 @@ int mipsf_decoder_bwd_chain16_ex2(const float* packed16, int feat_layout, const 
         set_error("cannot clear the tile counters");
         return 4;
     }
-#define B16(LAY)                                                                                                   \
+#define B16(LAY, NPL)                                                                                              \
     do {                                                                                                           \
         if (persistent) {                                                                                          \
             static bool attr_set_dev[MAX_DEVICES] = {false};                                                       \
             bool& attr_set = attr_set_dev[device_slot()];                                                          \
             if (!attr_set) {                                                                                       \
-                if (hipFuncSetAttribute((const void*)decoder16_bwd_lds_kernel<LAY>,                                \
+                if (hipFuncSetAttribute((const void*)decoder16_bwd_lds_kernel<LAY, NPL>,                           \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, B16_LDS_BYTES) != hipSuccess) { \
                     set_error("cannot raise dynamic LDS to %d bytes", B16_LDS_BYTES);                              \
                     return 4;                                                                                      \
                 }                                                                                                  \
                 attr_set = true;                                                                                   \
             }                                                                                                      \
-            hipLaunchKernelGGL((decoder16_bwd_lds_kernel<LAY>), dim3(cus), dim3(F16_LDS_BLOCK), B16_LDS_BYTES, s,   \
+            hipLaunchKernelGGL((decoder16_bwd_lds_kernel<LAY, NPL>), dim3(cus), dim3(F16_LDS_BLOCK), B16_LDS_BYTES, s, \
                                packed16, x, out, dout, saved, dfeat, dx, dact, dsmall, M, n_tiles, tile_live,      \
                                lean_dact);                                                                         \
         } else {                                                                                                   \
-            hipLaunchKernelGGL((decoder16_bwd_kernel<LAY>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed16, x, out,  \
+            hipLaunchKernelGGL((decoder16_bwd_kernel<LAY, NPL>), dim3(blocks), dim3(DEC_BLOCK), 0, s, packed16, x, out, \
                                dout, saved, dfeat, dx, dact, dsmall, M, tile_live, lean_dact);                     \
         }                                                                                                          \
     } while (0)
-    if (feat_layout == MIPSF_FEAT_AOS) B16(MIPSF_FEAT_AOS); else B16(MIPSF_FEAT_LEVEL_MAJOR);
+    if (feat_layout == MIPSF_FEAT_AOS) {
+        if (bf) B16(MIPSF_FEAT_AOS, 3); else B16(MIPSF_FEAT_AOS, 2);
+    } else {
+        if (bf) B16(MIPSF_FEAT_LEVEL_MAJOR, 3); else B16(MIPSF_FEAT_LEVEL_MAJOR, 2);
+    }
 #undef B16
     return check_launch("decoder_bwd_chain16");
 }

@@ -259,14 +259,47 @@ MIPSF_HD float img16b_weight(const W& w, int idx) {
 constexpr int OFF16_BWD_HALVES = IMG16H_HALVES + IMG16L_HALVES;            // where the backward sets start (in halves)
 // [head images + head biases (TAIL16) | fwd hi | fwd lo | bwd hi | bwd lo]
 constexpr int PACKED16_FLOATS = TAIL16_FLOATS + (IMG16H_HALVES + IMG16L_HALVES + 2 * IMG16B_HALVES) / 2;
-// the two halves a bias contributes: which = 0 -> rne16(b) as a float, 1 -> b - rne16(b)
-MIPSF_HD float bias16_part(float b, int which) {
+// ---- the bf16 mode ("bf16x6", NP = 3 planes): every fp32 value is carried EXACTLY as three bf16 pieces p0 = rne(v),
+// p1 = rne(v - p0), p2 = v - p0 - p1 (8 + 8 + 8 significant bits).  Planes 0 and 1 of every image sit where the f16 layout
+// has its hi and lo halves (same offsets, same sizes: the kernels address both alike); plane 2 follows the f16-sized buffer
+// as an EXTENSION that stays in L2 (it feeds one of the six products of a k-step):
+//     [head sdf p2: t][slots][8] [head rgb p2: t][slots][8] [forward p2: the lo image's shape] [backward p2: one image set]
+constexpr int EXT16_HEAD_SDF = 0;
+constexpr int EXT16_HEAD_RGB = EXT16_HEAD_SDF + T16_HEAD * HEAD16_SDF_SLOTS * 8;
+constexpr int EXT16_FWD = EXT16_HEAD_RGB + T16_HEAD * HEAD16_RGB_SLOTS * 8;
+constexpr int EXT16_BWD = EXT16_FWD + IMG16L_HALVES;
+constexpr int EXT16_HALVES = EXT16_BWD + IMG16B_HALVES;
+static_assert(EXT16_FWD % 8 == 0 && EXT16_HALVES % 8 == 0, "16-byte pieces");
+constexpr int PACKED16X_FLOATS = PACKED16_FLOATS + EXT16_HALVES / 2;       // size of a bf16x6 `packed16`
+// fp32 -> bf16, round to nearest even, as the upper 16 bits (finite inputs)
+MIPSF_HD uint16_t bf16_bits(float v) {
+    union { float f; uint32_t u; } c;
+    c.f = v;
+    return (uint16_t)((c.u + 0x7fffu + ((c.u >> 16) & 1u)) >> 16);
+}
+MIPSF_HD float bf16_value(uint16_t b) {
+    union { float f; uint32_t u; } c;
+    c.u = (uint32_t)b << 16;
+    return c.f;
+}
+// piece `which` (0, 1, 2) of the exact three-piece cut
+MIPSF_HD float bf16_piece(float v, int which) {
+    const float p0 = bf16_value(bf16_bits(v));
+    if (which == 0) return p0;
+    const float r = v - p0;
+    const float p1 = bf16_value(bf16_bits(r));
+    return which == 1 ? p1 : r - p1;
+}
+// the pieces a bias contributes (each meets a constant 1.0 of the B operand): f16 modes two, which = 0 -> rne16(b) as a
+// float, 1 -> b - rne16(b); bf16 mode (np = 3) the three bf16 pieces
+MIPSF_HD float bias16_part(float b, int which, int np = 2) {
+    if (np == 3) return bf16_piece(b, which);
     const float hi = (float)(_Float16)b;
     return which == 0 ? hi : b - hi;
 }
 // fp32 value behind element idx of the HI image set (the packer stores rne16 of it there and, for data k-steps, the
 // residual in the lo set at img16_lo_index)
-MIPSF_HD float img16_weight(const W& w, int idx) {
+MIPSF_HD float img16_weight(const W& w, int idx, int np = 2) {
     int base, T, kind;
     if (idx < OFF16H_F2) { base = OFF16H_F1; T = T16H_F1; kind = 0; }
     else if (idx < OFF16H_F3) { base = OFF16H_F2; T = T16H_F2; kind = 1; }
@@ -278,13 +311,13 @@ MIPSF_HD float img16_weight(const W& w, int idx) {
     const int row = 32 * rt + i;
     const float sc = pow2f(W16_SHIFT);
     if (kind == 0) {
-        if (t == BIAS16_T && h == 0 && (u == BIAS16_U || u == BIAS16_U + 1)) return bias16_part(w.b_pts0[row] * sc, u - BIAS16_U);
+        if (t == BIAS16_T && h == 0 && u >= BIAS16_U && u < BIAS16_U + np) return bias16_part(w.b_pts0[row] * sc, u - BIAS16_U, np);
         const int e = e16(t, h, u);
         return e < 0 ? 0.f : w.w_pts0[row * N_E + e] * sc;
     }
     if (t == 0) {                                                       // bias k-step
         const float* b = kind == 1 ? w.b_pts2 : w.b_sdf0;
-        return (h == 0 && u < 2) ? bias16_part(b[row] * sc, u) : 0.f;
+        return (h == 0 && u < np) ? bias16_part(b[row] * sc, u, np) : 0.f;
     }
     if (kind == 1) return w.w_pts2[row * HID + kfeat16(t - 1, h, u)] * sc;
     const int src = src16_f3(t - 1, h, u);
@@ -292,6 +325,15 @@ MIPSF_HD float img16_weight(const W& w, int idx) {
 }
 // fp32 value behind half idx of the compact head images (both planes hold the same value here: the packer stores rne16(v)
 // in plane 0 and rne16(v - rne16(v)) in plane 1); plane = which plane idx belongs to
+// index in the plane-2 extension (EXT16_HEAD_*) of the element behind half idx of the compact head images
+MIPSF_HD int head16_ext_index(int idx) {
+    const bool sdf = idx < HEAD16_SDF_HALVES;
+    const int rel = sdf ? idx : idx - HEAD16_SDF_HALVES;
+    const int slots = sdf ? HEAD16_SDF_SLOTS : HEAD16_RGB_SLOTS;
+    const int u = rel & 7, g = rel >> 3;
+    const int slot = g % slots, t = (g / slots) >> 1;
+    return (sdf ? EXT16_HEAD_SDF : EXT16_HEAD_RGB) + (t * slots + slot) * 8 + u;
+}
 MIPSF_HD float head16_weight(const W& w, int idx, int& plane) {
     const float sc = pow2f(W16_SHIFT);
     const bool sdf = idx < HEAD16_SDF_HALVES;

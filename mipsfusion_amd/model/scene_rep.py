@@ -91,7 +91,7 @@ class _QueryFn(torch.autograd.Function):
         need = any(ctx.needs_input_grad)
         prec = owner.decoder_precision
         if prec == "f16" and need:
-            raise RuntimeError('decoder_precision "f16" is forward-only (use "f16x3" or "f32" when gradients are needed)')
+            raise RuntimeError('decoder_precision "f16" is forward-only (use "bf16x6", "f16x3" or "f32" when gradients are needed)')
         # one operand-image buffer per arithmetic: `packed` (fp32 images) or `packed16` (f16 hi/lo images, forward and
         # backward chain); it is saved for the backward under the same name
         cache = owner._frozen_pack                  # see JointEncoding.frozen_weights(): the map does not change in here
@@ -101,7 +101,7 @@ class _QueryFn(torch.autograd.Function):
             if prec == "f32":
                 packed, packed16 = ops.decoder_pack(weights), None
             else:
-                packed, packed16 = None, ops.decoder_pack16(weights)
+                packed, packed16 = None, ops.decoder_pack16(weights, precision=prec)
             if cache is not None:
                 cache[prec] = (packed, packed16)
         # lean record: when the weight gradients will come from the streaming f16 kernel (the default behind the f16x3
@@ -109,7 +109,7 @@ class _QueryFn(torch.autograd.Function):
         lean = bool(need and prec == "f16x3" and owner.wgrad_precision in ("auto", "stream_f16x3") and owner.lean_record)
         # a frozen decoder (tracking: only the points need a gradient): the chain reads the ReLU masks and nothing else of the
         # record -- the 1 KB of activations per sample would be written for nobody
-        masks_only = bool(need and prec == "f16x3" and not any(ctx.needs_input_grad[3:]))
+        masks_only = bool(need and prec in ops.SPLIT_PRECISIONS and not any(ctx.needs_input_grad[3:]))
         out, saved = ops.decoder_fwd(packed, feat, FEAT_LEVEL_MAJOR, xn, None, M,
                                      save="masks" if masks_only else ("lean" if lean else need), precision=prec, packed16=packed16)
         ctx.lean = lean and not masks_only
@@ -334,7 +334,7 @@ class JointEncoding(nn.Module):
         prec = self.decoder_precision
         ws = self.decoder.ordered_parameters()
         packed = ops.decoder_pack(ws) if prec == "f32" else None
-        packed16 = ops.decoder_pack16(ws) if prec != "f32" else None
+        packed16 = ops.decoder_pack16(ws, precision=prec) if prec != "f32" else None
         return ops.decoder_fwd_sdf(packed, feat, FEAT_LEVEL_MAJOR, xn, None, xn.shape[0], precision=prec,
                                    packed16=packed16)[:, None]
 

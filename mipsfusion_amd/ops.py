@@ -280,16 +280,32 @@ def decoder_pack(weights, packed: Optional[torch.Tensor] = None) -> torch.Tensor
     return packed
 
 
-def decoder_pack16(weights, packed16: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """weights: the 10 nn.Linear tensors in DECODER_PARAM_ORDER -> f16 operand images (hi + lo halves of every weight
-    of the three hidden layers) + the fp32 head tables and biases, for decoder_fwd(..., precision="f16x3" | "f16")."""
+def decoder_pack16(weights, packed16: Optional[torch.Tensor] = None, precision: str = "f16x3") -> torch.Tensor:
+    """weights: the 10 nn.Linear tensors in DECODER_PARAM_ORDER -> 16-bit operand images of the three hidden layers and
+    the two heads, forward and backward sets.  precision "f16x3" / "f16": hi + lo f16 halves (one buffer serves both);
+    "bf16x6": the three bf16 pieces of every weight (another, larger buffer: it is for the bf16x6 kernels only)."""
     dev = weights[0].device
+    fam = _PACK16_FAMILY[precision]
+    n = lib().mipsf_decoder_packed16_floats_ex(_lib.PREC[fam])
     if packed16 is None:
-        packed16 = torch.empty(lib().mipsf_decoder_packed16_floats(), dtype=torch.float32, device=dev)
+        packed16 = torch.empty(n, dtype=torch.float32, device=dev)
+    elif packed16.numel() != n:
+        raise RuntimeError(f"packed16 has {packed16.numel()} floats, precision {precision!r} needs {n}")
     st = _decoder_struct([w.detach() for w in weights], _lib.DecoderWeights)
     with _timed("decoder_pack"):
-        check(lib().mipsf_decoder_pack16(C.byref(st), dptr(packed16), stream_ptr()), "decoder_pack16")
+        check(lib().mipsf_decoder_pack16_ex(C.byref(st), dptr(packed16), _lib.PREC[fam], stream_ptr()), "decoder_pack16")
+    packed16.mipsf_family = fam
     return packed16
+
+
+_PACK16_FAMILY = {"f16x3": "f16x3", "f16": "f16x3", "bf16x6": "bf16x6"}
+SPLIT_PRECISIONS = ("f16x3", "bf16x6")        # decoder arithmetics that keep activations (training)
+
+
+def _check_family(packed16, precision):
+    fam = getattr(packed16, "mipsf_family", None)
+    if fam is not None and fam != _PACK16_FAMILY[precision]:
+        raise RuntimeError(f"packed16 was packed for {fam!r}, the call asks for {precision!r}")
 
 
 def decoder_fwd(packed, feat, layout, x, embed_pos, M, save, precision: str = "f32", packed16=None):
@@ -301,8 +317,8 @@ def decoder_fwd(packed, feat, layout, x, embed_pos, M, save, precision: str = "f
     "masks" (f16x3: only the ReLU masks, 32 B per sample -- all the backward CHAIN reads; ``decoder_bwd(grads=None)`` only)."""
     lean = save in ("lean", "masks")
     masks_only = save == "masks"
-    if lean and precision != "f16x3":
-        raise RuntimeError('save="lean" / "masks" belong to precision "f16x3"')
+    if lean and precision not in SPLIT_PRECISIONS:
+        raise RuntimeError('save="lean" / "masks" belong to precision "f16x3" / "bf16x6"')
     out = torch.empty((M, 10), dtype=torch.float32, device=x.device)
     saved = None
     if save:
@@ -310,8 +326,9 @@ def decoder_fwd(packed, feat, layout, x, embed_pos, M, save, precision: str = "f
     if precision != "f32":
         if embed_pos is not None or packed16 is None:
             raise RuntimeError("the f16 decoder modes take packed16 and compute the positional encoding in-kernel")
-        if save and precision != "f16x3":
-            raise RuntimeError('only precision "f32" / "f16x3" keep activations for the backward pass')
+        if save and precision not in SPLIT_PRECISIONS:
+            raise RuntimeError('only precision "f32" / "f16x3" / "bf16x6" keep activations for the backward pass')
+        _check_family(packed16, precision)
         # the live-tile lists of the backward chain that will follow this record: allocated here so that THIS launch clears
         # their counters (a memset in front of the chain kernel was a launch of its own)
         tile_live = None
@@ -355,7 +372,7 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
     return_tiles: a 4th return value, the chain's live-tile lists (or None when no short cut was taken), for
     ``hashgrid_dx_from_jac(..., tiles=)``."""
     if wgrad_precision == "auto":
-        wgrad_precision = "stream_f16x3" if (precision == "f16x3" and embed_pos is None) else "f32"
+        wgrad_precision = ("stream_" + precision) if (precision in SPLIT_PRECISIONS and embed_pos is None) else "f32"
     if getattr(saved, "mipsf_masks_only", False) and grads is not None:
         raise RuntimeError("this activation record holds the ReLU masks only (decoder_fwd(save='masks')): no weight gradients")
     if getattr(saved, "mipsf_lean_record", False) and grads is not None:
@@ -368,23 +385,24 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
     dx = torch.empty((M, 3), dtype=torch.float32, device=dev)
     dpe = torch.empty((M, 48), dtype=torch.float32, device=dev) if embed_pos is not None else None
     # (a frozen decoder behind the f16x3 chain: the pre-activation gradients are for the weight-gradient kernel only)
-    dact = None if (grads is None and precision == "f16x3") else torch.empty(lib().mipsf_decoder_dact_floats(M), dtype=torch.float32, device=dev)
+    dact = None if (grads is None and precision in SPLIT_PRECISIONS) else torch.empty(lib().mipsf_decoder_dact_floats(M), dtype=torch.float32, device=dev)
     pe_mode = 0 if embed_pos is None else 1
     tile_live = None
     lean_dact = False
-    if precision == "f16x3":
+    if precision in SPLIT_PRECISIONS:
         if embed_pos is not None or packed16 is None:
-            raise RuntimeError("the f16x3 backward chain takes packed16 and computes the positional encoding in-kernel")
-        hdr_clear = 0
+            raise RuntimeError("the f16x3 / bf16x6 backward chain takes packed16 and computes the positional encoding in-kernel")
+        _check_family(packed16, precision)
+        hdr_clear = 4 if precision == "bf16x6" else 0        # MIPSF_CHAIN_BF16X6
         # the lean gradient record (half of `dact`): when the exchange form of the streaming f16 kernel follows, which
         # recomputes dG3 and the rgb_emb half of dH2 from the small rows + the ReLU masks (csrc/wgrad16.hip)
         lean_dact = bool(LEAN_DACT and grads is not None and wgrad_precision == "stream_f16x3" and recompute_h1
-                         and packed16 is not None)
+                         and packed16 is not None and precision == "f16x3")
         if SKIP_ZERO_TILES and (grads is None or wgrad_precision.startswith("stream_")):
             global _LAST_TILE_LIVE
             pre = getattr(saved, "mipsf_tile_live", None)
             if pre is not None and pre[1]:          # the forward of this record cleared the counters: use its buffer once
-                tile_live, hdr_clear = pre[0], 1
+                tile_live, hdr_clear = pre[0], hdr_clear | 1
                 pre[1] = False                      # (a second backward through the same record clears them itself)
             else:
                 tile_live = torch.empty(lib().mipsf_decoder_tile_words(M), dtype=torch.int32, device=dev)
@@ -432,6 +450,7 @@ def decoder_fwd_sdf(packed, feat, layout, x, embed_pos, M, precision: str = "f32
     if precision != "f32":
         if embed_pos is not None or packed16 is None:
             raise RuntimeError("the f16 decoder modes take packed16 and compute the positional encoding in-kernel")
+        _check_family(packed16, precision)
         with _timed("decoder_fwd"):
             check(lib().mipsf_decoder_fwd16(dptr(packed16), dptr(feat), layout, dptr(x), dptr(sdf), None, 1,
                                             _lib.PREC[precision], M, stream_ptr()), "decoder_fwd16")
