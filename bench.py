@@ -92,32 +92,62 @@ N_GRID_PARAMS, N_DEC_PARAMS = 9014144, 36577
 # The two f16x3 decoder kernels keep or leave the activation record of the backward pass: 1.7-1.8 KB of HBM traffic per
 # sample against 0.22 MFLOP at 2.5 PFLOP/s -- they are priced against the HBM roofline, their matrix-pipe utilisation is
 # reported next to it.
-KERNEL_COST = {
-    "hashgrid_fwd": ("hbm", 1164.0 + 384.0, 0.0, None, "f32", None),   # 8 corners x 16 levels gathered + features out + Jacobian out
-    # scatter: x + dL/dy + read-modify-write of the touched entries; a dead pair costs the 8-byte read that finds it dead
-    "hashgrid_bwd": ("hbm", 2188.0, 128.0, "pair", "f32+f64 LDS", None),
-    "hashgrid_dx": ("hbm", 536.0, 0.0, "tile", "f32", None),            # saved Jacobian (384) + dL/dy (128) + dx read-modify-write (24)
-    # lean activation record: H2 + H3 (1024 B) + ReLU masks; H1 is recomputed by the weight-gradient kernel
-    "decoder_fwd": ("hbm", 12.0 + 128.0 + 40.0 + 1024.0 + 32.0, 0.0, None, "f16x3 (f16 MFMA on hi/lo split operands, fp32 accumulate)", 3),
-    # chain: a dead tile costs the read of its incoming gradient (40) and the zero d feat / d x it leaves (128 + 12); the LEAN
-    # gradient record (dG1 + the sdf_emb half of dH2: 768 B; dG3 and the rgb_emb half are recomputed by the weight-gradient kernel)
-    "decoder_bwd_chain": ("hbm", 40.0 + 40.0 + 32.0 + 12.0 + 768.0 + 32.0 + 128.0 + 12.0, 40.0 + 128.0 + 12.0, "tile",
-                          "f16x3 (f16 MFMA on hi/lo split operands, fp32 accumulate)", 3),
-    # streaming kernel (csrc/wgrad16.hip): reads H2, H3, the lean gradient record, the small rows and H3's mask bits once
-    # (H1, dG3 and d rgb_emb recomputed) -- 2.0 KB per sample
-    "decoder_wgrad": ("hbm", 1024.0 + 768.0 + 32.0 + 16.0 + 128.0 + 12.0, 0.0, "tile",
-                      "f16x3 (f16 MFMA on hi/lo split operands under per-block power-of-two scales, fp32 accumulate)", 3),
-    "sample_rays": ("hbm", 20.0, 0.0, None, "f32+f64", None),
-    "render_fwd": ("hbm", 44.0, 0.0, None, "f32", None),
-    "render_bwd": ("hbm", 84.0, 0.0, None, "f32", None),
-    "rays_bwd": ("hbm", 16.0, 0.0, None, "f32+f64", None),
-}
+_F16X3 = "f16x3 (f16 MFMA on hi/lo split operands = 22-23 operand bits, fp32 accumulate)"
+_BF16X6 = "bf16x6 (fp32 operands carried exactly as three bf16 pieces, six bf16 MFMAs per product, fp32 accumulate)"
+_F32 = "f32 (fp32-input MFMA = exact fp32 products)"
+
+
+def kernel_cost(precision):
+    """name -> (bound, bytes per live unit, bytes per dead unit, liveness, dtype, matrix products issued per algorithmic one,
+    design bytes per unit on top of the algorithmic ones).  The decoder rows follow the arithmetic's records:
+      bf16x6 (default), f16x3 (fast mode)   lean records: H1 / dG3 / the rgb_emb half of dH2 are not written, the exchange
+                        form of the streaming weight-gradient kernel recomputes them
+      f32               the round-1 fp32-MFMA kernels: full records, no zero-tile short cut."""
+    cost = {
+        # SURVEY 8(d): 8 corners x 16 levels x 2 features gathered (1024) + coordinates (12) + features out (128); the
+        # Jacobian the design also writes for the backward (384 B) is reported as design_bytes, not priced
+        "hashgrid_fwd": ("hbm", 1164.0, 0.0, None, "f32", None, 384.0),
+        # scatter: x + dL/dy + read-modify-write of the touched entries; a dead pair costs the 8-byte read that finds it dead
+        "hashgrid_bwd": ("hbm", 2188.0, 128.0, "pair", "f32+f64 LDS", None, 0.0),
+        "hashgrid_dx": ("hbm", 536.0, 0.0, "tile", "f32", None, 0.0),   # saved Jacobian (384) + dL/dy (128) + dx read-modify-write (24)
+        "sample_rays": ("hbm", 20.0, 0.0, None, "f32+f64", None, 0.0),
+        "render_fwd": ("hbm", 44.0, 0.0, None, "f32", None, 0.0),
+        "render_bwd": ("hbm", 84.0, 0.0, None, "f32", None, 0.0),
+        "rays_bwd": ("hbm", 16.0, 0.0, None, "f32+f64", None, 0.0),
+    }
+    io_f, io_b, dead_b = 12.0 + 128.0 + 40.0, 40.0 + 40.0 + 32.0 + 12.0 + 128.0 + 12.0, 40.0 + 128.0 + 12.0
+    if precision == "f16x3":
+        cost["decoder_fwd"] = ("hbm", io_f + 1024.0 + 32.0, 0.0, None, _F16X3, 3, 0.0)             # H2 + H3 + masks
+        cost["decoder_bwd_chain"] = ("hbm", io_b + 768.0 + 32.0, dead_b, "tile", _F16X3, 3, 0.0)     # dG1 + sdf_emb half of dH2 + small rows
+        cost["decoder_wgrad"] = ("hbm", 1024.0 + 768.0 + 32.0 + 16.0 + 128.0 + 12.0, 0.0, "tile",
+                                 _F16X3 + ", gradient blocks under per-block power-of-two scales", 3, 0.0)
+    elif precision == "bf16x6":         # the same lean records, six products per algorithmic one
+        cost["decoder_fwd"] = ("hbm", io_f + 1024.0 + 32.0, 0.0, None, _BF16X6, 6, 0.0)
+        cost["decoder_bwd_chain"] = ("hbm", io_b + 768.0 + 32.0, dead_b, "tile", _BF16X6, 6, 0.0)
+        cost["decoder_wgrad"] = ("hbm", 1024.0 + 768.0 + 32.0 + 16.0 + 128.0 + 12.0, 0.0, "tile", _BF16X6, 6, 0.0)
+    else:
+        cost["decoder_fwd"] = ("mfma", DECODER_FLOP_PER_SAMPLE, 0.0, None, _F32, 1, 0.0)
+        cost["decoder_bwd_chain"] = ("mfma", DECODER_FLOP_PER_SAMPLE, 0.0, None, _F32, 1, 0.0)
+        cost["decoder_wgrad"] = ("mfma", DECODER_FLOP_PER_SAMPLE, 0.0, None, _F32, 1, 0.0)
+    return cost
+
+
+DECODER_FLOP_PER_SAMPLE = 72370.0
 # device streaming rates measured with hand-written kernels (tools/micro/stream.hip, 1 GiB, 16 B per lane, >= 32 KB in
 # flight per CU; profiles/r03_stream.txt): what "the HBM roofline" is worth on this part for each access mix
 STREAM_CEILINGS_TBS = {"read": 6.3, "read_nt": 7.0, "write": 6.0, "copy": 5.6, "spec": 8.0}
-DECODER_FLOP_PER_SAMPLE = 72370.0
 
 
+DTYPE_OF = {
+    "bf16x6": "f32 (parameters, activations, gradients, accumulators); the decoder's matrix products -- forward, "
+              "activation-gradient chain, weight gradients -- on the bf16 matrix cores with every fp32 operand carried "
+              "EXACTLY as three bf16 pieces (24 significant bits) and six MFMAs per product, fp32 accumulate: dropped "
+              "partial products < 2^-23 |a||w|, below the rounding of the fp32 accumulation (fp32-class against fp64 truth, "
+              "tests/test_gpu_parity.py::test_decoder_true_error_of_every_arithmetic_against_fp64)",
+    "f16x3": "f32 (parameters, activations, gradients, accumulators); the decoder's matrix products: f16 MFMA on "
+             "hi/lo split operands = 22-23-bit operands (forward, activation-gradient chain, weight gradients)",
+    "f32": "f32 everywhere (fp32-input MFMA = exact fp32 products)",
+}
 _T0 = time.time()
 
 
@@ -157,7 +187,8 @@ def build_submap(cfg, dev, seed):
         model.embed_fn.params.copy_((torch.rand(model.embed_fn.params.shape, generator=g) * 2 - 1) * 1e-4)
     model = model.to(dev).train()
     model.accumulate_param_grads_in_place = True      # plain loss.backward() loop: opt in (scene_rep._QueryFn)
-    model.grid_grad_is_zero_at_backward = True        # one backward per step, map_opt.step(zero_grad=True) clears the gradients
+    # one backward per map step and map_opt.step(zero_grad=True) clears the gradients: only then may the scatter store
+    model.grid_grad_is_zero_at_backward = cfg["mapping"]["map_accum_step"] == 1 and cfg["mapping"].get("map_wait_step", 0) == 0
     # keyframes on a small arc + the current frame
     frames, poses = [], []
     for k in range(5):
@@ -303,30 +334,46 @@ class UnchangedCallerLoop:
         self.poses_all = torch.cat([self.pose_fixed, qt_to_transform_matrix(self.cur_rot, self.cur_trans)], 0)
         self.i = 0
 
-    def iterate(self, predrawn=None):
+    def iterate(self, predrawn=None, marks=None):
+        """marks (a dict): wall-clock of every section, each closed by a device synchronisation (the breakdown pass only)"""
         cfg, dev = self.cfg, self.dev
+        t_prev = [time.perf_counter()]
+
+        def mark(name):
+            if marks is not None:
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                marks[name] = marks.get(name, 0.0) + (now - t_prev[0]) * 1e3
+                t_prev[0] = now
         if predrawn is None:
             rows, owner = draw_index_sets(cfg, self.frames, self.db, self.R, 1)
             rows, owner = rows[0], owner[0]
         else:
             rows, owner = predrawn
+        mark("host_pixel_sampling")
         rays = self.table_cpu[rows]                                         # CPU gather (keyframeSet.py:386-436)
         rays_d_cam, target_s, target_d = rays[..., :3].to(dev), rays[..., 3:6].to(dev), rays[..., 6:7].to(dev)
         owner = owner.to(dev)
+        mark("cpu_ray_gather_and_uploads")
         rays_d = torch.sum(rays_d_cam[..., None, :] * self.poses_all[owner, :3, :3], -1)
         rays_o = self.poses_all[owner, :3, -1]
-        ret = self.model.forward(rays_o, rays_d, target_s, target_d)        # jitter: torch.rand on the CPU + upload
+        mark("eager_torch_ray_ops")
+        ret = self.model.forward(rays_o, rays_d, target_s, target_d)        # jitter: the CPU generator's draw + upload
         ret = {k: v for k, v in ret.items() if not k.startswith("_")}       # the reference's dictionary keys only
         loss = get_loss_from_ret(ret, cfg["training"])
+        mark("forward_incl_cpu_jitter_draw_and_upload")
         loss.backward(retain_graph=True)
+        mark("backward_autograd_path_gradients")
         self.i += 1
         if self.i % cfg["mapping"]["map_accum_step"] == 0:
             self.map_opt.step()
             self.map_opt.zero_grad()
+        mark("torch_optim_adam_map_step_and_zero_grad")
         if self.i % cfg["mapping"]["pose_accum_step"] == 0:
             self.pose_opt.step()
             self.poses_all = torch.cat([self.pose_fixed, qt_to_transform_matrix(self.cur_rot, self.cur_trans)], 0)
             self.pose_opt.zero_grad()
+        mark("pose_step_and_pose_matrices")
         return loss
 
 
@@ -343,6 +390,16 @@ def unchanged_caller_rate(cfg, model, frames, poses, table, db, R, dev, steps):
             loop.iterate((pre_rows[k % 8], pre_owner[k % 8]) if pre else None)
         torch.cuda.synchronize()
         out[key] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+    # where the time goes: the same iteration with a device synchronisation behind every section (so the sections add up to
+    # MORE than the pipelined step above: host work no longer overlaps the GPU's)
+    marks, n_b = {}, 10
+    for k in range(n_b):
+        loop.iterate(None, marks)
+    out["breakdown_ms_per_step_serialised"] = {k: round(v / n_b, 4) for k, v in marks.items()}
+    t0 = time.perf_counter()
+    for _ in range(10):
+        torch.rand(N_RAYS, N_SAMPLES)
+    out["breakdown_ms_per_step_serialised"]["(of forward) cpu_jitter_draw_alone"] = round((time.perf_counter() - t0) / 10 * 1e3, 4)
     out["value"] = round(N_RAYS * N_SAMPLES / (out["ms_per_step"] * 1e-3), 1)
     out["unit"] = "rays*samples/s"
     out["what"] = ("the reference's own local_BA iteration (mipsfusion.py:293-342) over the drop-in modules and nothing "
@@ -393,15 +450,17 @@ def forward_only_rate(model, loop, dev, iters=10):
 def decoder_gemm_rates(model, dev, M):
     """The decoder's batched (rays*samples x feat) x (feat x hidden) products on their own: the forward kernel WITHOUT the
     activation record of the backward pass (the evaluation branch / RandomOptimizer rounds), per arithmetic, with the
-    matrix-pipe utilisation = matrix-core FLOP issued / dense f16 peak (f16x3 issues three products per algorithmic one)."""
+    matrix-pipe utilisation = matrix-core FLOP issued / dense 16-bit peak (bf16x6 issues six products per algorithmic one,
+    f16x3 three)."""
     from mipsfusion_amd._lib import FEAT_LEVEL_MAJOR
     ws = model.decoder.ordered_parameters()
-    packed16 = ops.decoder_pack16(ws)
+    packs = {"f16x3": ops.decoder_pack16(ws), "bf16x6": ops.decoder_pack16(ws, precision="bf16x6")}
+    packs["f16"] = packs["f16x3"]
     x = torch.rand(M, 3, device=dev)
     feat = torch.randn(16, M, 2, device=dev) * 1e-2
     out = {}
-    for prec, mult in (("f16x3", 3), ("f16", 1)):
-        fn = lambda: ops.decoder_fwd(None, feat, FEAT_LEVEL_MAJOR, x, None, M, save=False, precision=prec, packed16=packed16)   # noqa: E731
+    for prec, mult in (("bf16x6", 6), ("f16x3", 3), ("f16", 1)):
+        fn = lambda: ops.decoder_fwd(None, feat, FEAT_LEVEL_MAJOR, x, None, M, save=False, precision=prec, packed16=packs[prec])   # noqa: E731
         for _ in range(3):
             fn()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -475,19 +534,22 @@ def frame_estimate(cfg, model, loop, dev, ba_ms, stream=None):
     frame = synth.make_frame(cfg, seed=1)
     ds = types.SimpleNamespace(H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy, rays_d=frame["direction"])
     ro = RandomOptimizer(cfg, types.SimpleNamespace(dataset=ds, device=dev))
-    ro.decoder_precision = "f16"        # opt-in: BASELINE config 5 "fp16 decoder on CDNA4" (pose within 1e-3 of the reference's)
     n_ro = max(1, cfg["tracking"]["iter_RO"])
     init = frame["c2w"].clone()
     was_training = model.training
     model.eval()
-    for _ in range(2):
-        ro.optimize(model, frame["depth"], init, None, n_iter=n_ro)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(5):
-        ro.optimize(model, frame["depth"], init, None, n_iter=n_ro)
-    torch.cuda.synchronize()
-    ro_ms = (time.perf_counter() - t0) / 5 / n_ro * 1e3
+    ro_ms_by = {}
+    for prec in (model.decoder_precision, "f16x3", "f16"):   # the default arithmetic; the two opt-in fast ones next to it
+        ro.decoder_precision = prec                          # ("f16": BASELINE config 5 "fp16 decoder on CDNA4", pose within 1e-3)
+        for _ in range(2):
+            ro.optimize(model, frame["depth"], init, None, n_iter=n_ro)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ro.optimize(model, frame["depth"], init, None, n_iter=n_ro)
+        torch.cuda.synchronize()
+        ro_ms_by[prec] = (time.perf_counter() - t0) / 5 / n_ro * 1e3
+    ro_ms = ro_ms_by[model.decoder_precision]
     model.train(was_training)
     # GO: tracking.sample rays, pose-only Adam on one pose
     ns = cfg["tracking"]["sample"]
@@ -553,7 +615,9 @@ def frame_estimate(cfg, model, loop, dev, ba_ms, stream=None):
         go_ms = go_graph_ms
     tr, mp = cfg["tracking"], cfg["mapping"]
     total = tr["iter_RO"] * ro_ms + tr["iter"] * go_ms + mp["iters"] * ba_ms / mp["map_every"]
-    return {"ro_iter_ms": round(ro_ms, 4), "ro_decoder_arithmetic": "plain f16 (opt-in; the RandomOptimizer's default is f16x3)",
+    return {"ro_iter_ms": round(ro_ms, 4), "ro_decoder_arithmetic": f"{model.decoder_precision} (the RandomOptimizer's default)",
+            "ro_iter_ms_by_arithmetic": {k: round(v, 4) for k, v in ro_ms_by.items()},
+            "decoder_arithmetic": model.decoder_precision,
             "go_iter_ms": round(go_ms, 4),
             "go_iter_ms_eager": round(go_eager_ms, 4),
             "go_iter_ms_map_grads_computed_and_discarded": round(go_ms_unfrozen, 4), "ba_iter_ms": round(ba_ms, 4),
@@ -561,7 +625,7 @@ def frame_estimate(cfg, model, loop, dev, ba_ms, stream=None):
             "formula": "iter_RO*ro + tracking.iter*go + mapping.iters*ba/map_every (FastCaMo-synth cadence 5/10/15/3)"}
 
 
-def measured_sequence(n_frames, dev, stream):
+def measured_sequence(n_frames, dev, stream, samplers=("reference", "device"), **seq_kw):
     """tracking + mapping ms/frame MEASURED over a synthetic sequence at the reference cadence (5 RO rounds, 10
     tracking iterations, 15 mapping iterations every 3rd frame, keyframe every 15th, 500 initialisation iterations):
     mipsfusion_amd/sequence.py.  `reference`: pixel / keyframe-ray indices and jitter from the reference's own host
@@ -571,14 +635,15 @@ def measured_sequence(n_frames, dev, stream):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from run_sequence import trajectory
     out = {}
-    for sampler in ("reference", "device"):
+    for sampler in samplers:
         random.seed(0), np.random.seed(0), torch.manual_seed(0)
         cfg = synth.config_reference_defaults()                   # S = 50 + 25, sample 1800 + pixels_cur 800: as shipped
         gt = trajectory(cfg, n_frames)
         frames = [synth.make_frame(cfg, gt[k], seed=k, frame_id=k) for k in range(n_frames)]
-        seq = sequence.GraphedSequence(cfg, dev, frames, kf_every=15, sampler=sampler, stream=stream)
+        seq = sequence.GraphedSequence(cfg, dev, frames, kf_every=15, sampler=sampler, stream=stream, **seq_kw)
         res = seq.run(gt)
         out[sampler] = sequence.summarise(res, gt, cfg, "hipGraph replay per tracking frame / per BA round; RandomOptimizer rounds of a frame in one replay")
+        out[sampler]["decoder_arithmetic"] = {"model": seq.model.decoder_precision, "random_optimizer": seq.ro.decoder_precision}
         del seq
         torch.cuda.empty_cache()
     return out
@@ -599,6 +664,7 @@ def measured_config3(n_frames, dev, stream):
                                    schedule=schedule)
     res = seq.run(gt)
     out = sequence.summarise(res, gt, cfg, "hipGraph replay per tracking frame / BA round / 25 initialisation iterations / switch refinement")
+    out["decoder_arithmetic"] = {"model": seq.model.decoder_precision, "random_optimizer": seq.ro.decoder_precision}
     out["sampler"] = ("reference host generators (run ahead by producer threads) for tracking and local BA; the sub-map "
                       "initialisation and switch-refinement iterations draw pixels and jitter on the device")
     out.pop("frame_ms_all", None)
@@ -645,19 +711,12 @@ def multi_gpu_checks(cfg, model, dev, rank, world):
             pose = ro.optimize(replica, frame["depth"], init, None, n_iter=n_ro)
         torch.cuda.synchronize()
         return pose, (time.perf_counter() - t0) / 5 / n_ro * 1e3
-    # Ranks that SHARE a device (the two-process test on one GPU) preempt each other's wavefronts; on this platform a
-    # preempted wavefront can lose the last lanes of an in-flight sqrt / reciprocal (tools/dbg_ro_determinism2.py: 0 of 3000
-    # frames differ run to run with one process per GPU, ~7 % with two) -- the comparison is repeated then, and says so.
-    shared_device = world > 1 and torch.cuda.device_count() < world
-    for attempt in range(3 if shared_device else 1):
-        pose_one, ms_one = timed_ro(False)
-        pose_split, ms_split = timed_ro(True)
-        same = torch.tensor([1.0 if torch.equal(pose_one, pose_split) else 0.0], device=dev)
-        if world > 1:
-            mdist.all_reduce_sum_(same)           # every rank takes the same decision (the loop holds collectives)
-        if float(same) == world:
-            break
-    out["ro_split_check_attempts"] = attempt + 1
+    # ONE comparison, reported as it came out (ranks that share a device -- the two-process test on one GPU, a debugging
+    # topology -- have shown rare last-bit differences between runs of the same kernels: DESIGN.md 4h; the line says which
+    # topology this was)
+    pose_one, ms_one = timed_ro(False)
+    pose_split, ms_split = timed_ro(True)
+    out["ranks_share_a_device"] = bool(world > 1 and torch.cuda.device_count() < world)
     out["ro_round_ms_unsplit"] = round(mdist.max_over_ranks(ms_one, dev), 4)
     out["ro_round_ms_particle_split"] = round(mdist.max_over_ranks(ms_split, dev), 4)
     out["ro_split_pose_equals_unsplit"] = bool(torch.equal(pose_one, pose_split))
@@ -847,21 +906,123 @@ def pmc_traffic(key="traffic_bytes_per_launch"):
         return json.load(f).get(key, {})
 
 
+def kernel_table(prof, M, precision, live_share, pair_share, with_traffic=True):
+    """per-kernel roofline rows from the event pairs of an eager pass (`prof`: name -> (launches, mean ms)) and the dominant
+    kernel's row as `roofline`.  `achieved` = algorithmic bytes (or FLOP) of the units a launch PROCESSED / its mean duration."""
+    kernels = {}
+    traffic = pmc_traffic() if with_traffic else {}
+    traffic_raw = pmc_traffic("traffic_bytes_per_launch_uncorrected") if with_traffic else {}
+    cost = kernel_cost(precision)
+    hashgrid_route_ms = None
+    if "hashgrid_route" in prof and "hashgrid_bwd" in prof:
+        # the routing half of the scatter runs on a second stream next to the forward pass: its kernels' time is ADDED to
+        # the backward's for the roofline (the work is done, wherever it runs); `overlapped_ms` says how much is hidden
+        n_b, ms_b = prof["hashgrid_bwd"]
+        route_ms = prof["hashgrid_route"][1]
+        prof = dict(prof)
+        prof["hashgrid_bwd"] = (n_b, ms_b + route_ms)
+        del prof["hashgrid_route"]
+        hashgrid_route_ms = route_ms
+    shares = {"tile": live_share, "pair": pair_share, None: 1.0}
+    for name, (n_launch, ms) in prof.items():
+        mult, share, design = None, 1.0, 0.0
+        if name in cost:
+            bound, per_live, per_dead, liveness, dtype, mult, design = cost[name]
+            share = shares[liveness] if shares[liveness] is not None else 1.0
+            work = M * (share * per_live + (1.0 - share) * per_dead)
+            work_full = M * per_live
+        elif name == "adam_step":
+            bound, dtype, liveness = "hbm", "f32", None
+            work = work_full = 28.0 * N_GRID_PARAMS
+        else:
+            continue
+        if bound == "hbm":
+            scale, peak, unit = 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            scale, peak, unit = 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+        achieved = work / (ms * 1e-3) / scale
+        kernels[name] = {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+                         "frac": round(achieved / peak, 4), "avg_ms": round(ms, 4), "dtype": dtype,
+                         "launches": n_launch, "work_per_launch": round(work, 1),
+                         "traffic": traffic.get(name), "traffic_uncorrected": traffic_raw.get(name)}
+        if design:
+            kernels[name]["design_bytes_per_launch"] = round(M * design, 1)
+            kernels[name]["design_note"] = "bytes the design moves on top of the algorithmic ones (the Jacobian kept for the backward), not priced"
+        if liveness is not None:
+            kernels[name]["units"] = f"live {liveness}s: share {share:.4f} of the batch"
+            kernels[name]["frac_full_batch"] = round(work_full / (ms * 1e-3) / scale / peak, 4)
+        if mult is not None:        # matrix-pipe view of the decoder kernels (products of the units processed)
+            issued = DECODER_FLOP_PER_SAMPLE * M * share * mult / (ms * 1e-3) / 1e12
+            mpeak = MFMA_F32_PEAK_TFLOPS if mult == 1 else MFMA_F16_PEAK_TFLOPS
+            kernels[name]["matrix_pipe"] = {"algorithmic_tflops": round(issued / mult, 2), "issued_tflops": round(issued, 2),
+                                            "products_issued_per_algorithmic_product": mult,
+                                            "peak_tflops": mpeak, "utilisation": round(issued / mpeak, 4)}
+        if name == "hashgrid_bwd" and hashgrid_route_ms is not None:
+            kernels[name]["routing_on_second_stream_ms"] = round(hashgrid_route_ms, 4)
+    dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"]) if kernels else None
+    roofline = dict(kernels[dominant], kernel=dominant) if dominant else None
+    if roofline is not None:
+        roofline["traffic_source"] = ("profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                      "command on an earlier box (per launch, gfx950 x2 FETCH correction where the kernel "
+                                      "reads 16 B per lane); not collected in this run")
+        roofline["device_stream_ceilings_TBps"] = STREAM_CEILINGS_TBS
+    return kernels, roofline
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (torch.distributed.run, one process
+    per GPU, rendezvous on 127.0.0.1) before this process has touched the GPU, pass rank 0's JSON line through, and leave with
+    the children's exit code.  (Never an exec: a process that has initialised the GPU must not replace itself.)"""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: RCCL / cross-process GPU memory need it on this pool
+    for k in ("OMP_NUM_THREADS",):                              # every rank sizes its own pools (bench.py top)
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd[1:9])} ...")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    last_json = None
+    for line in proc.stdout:
+        if line.startswith("{"):
+            last_json = line.rstrip("\n")
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc != 0:
+        raise SystemExit(f"a rank failed (torch.distributed.run exit code {rc})")
+    if last_json is None:
+        raise SystemExit("the ranks printed no JSON line")
+    print(last_json, flush=True)
+    raise SystemExit(0)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)                                  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     backend = os.environ.get("MIPSF_BENCH_BACKEND", "nccl")      # "gloo" only to debug N>1 on a single GPU
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"--gpus {world} over RCCL needs {world} GPUs, this node shows {torch.cuda.device_count()} "
+                         "(MIPSF_BENCH_BACKEND=gloo shares a device between ranks: a debugging mode, not a measurement)")
     if backend != "nccl":
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    ranks_info = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -869,6 +1030,17 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        assert dist.get_backend() == backend
+        # which device every rank really sits on: (bus id, uuid) gathered over the group
+        props = torch.cuda.get_device_properties(local)
+        me = f"{local}:{getattr(props, 'pci_bus_id', '?')}:{getattr(props, 'uuid', '?')}"
+        everyone = [None] * world
+        dist.all_gather_object(everyone, me)
+        ranks_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend() + (" (= RCCL on ROCm)" if backend == "nccl" else ""),
+                      "device_of_rank": everyone, "distinct_devices": len(set(everyone))}
+        if backend == "nccl":
+            assert ranks_info["distinct_devices"] == world, f"ranks share devices: {everyone}"
 
     stream = work_stream(dev)        # everything (setup, eager pass, capture, replays) runs on this one stream
     cfg = synth.config_headline()
@@ -954,20 +1126,39 @@ def main():
                       "p95": round(float(np.percentile(per_step, 95)), 4), "max": round(float(per_step.max()), 4)}
     # ---- the same step under the two switches the headline depends on, and the unchanged caller (N = 1 only)
     variants = None
+    headline_precision = model.decoder_precision
     if use_graph and world == 1 and not args.no_variants:
         variants = {}
         M_ = N_RAYS * N_SAMPLES
-        model.decoder_precision = "f32"              # the reference's arithmetic: fp32 products (fp32-input MFMA), fp32 LDS weight-gradient kernel
-        ms = graphed_ms_per_step(loop, stream, n_inner, args.steps, args.warmup)
-        variants["decoder_precision_f32"] = {"ms_per_step": round(ms, 4), "value": round(M_ / (ms * 1e-3), 1),
-                                             "dtype": "f32 everywhere (fp32-input MFMA = exact fp32 products)"}
-        model.decoder_precision = "f16x3"
+
+        def variant(prec, what):
+            """the same graph-replayed step at another decoder arithmetic, with its own eager pass for the kernel table"""
+            model.decoder_precision = prec
+            for _ in range(3):
+                loop.step()
+            ops.PROFILE = {}
+            for _ in range(20):
+                loop.step()
+            torch.cuda.synchronize()
+            vprof = ops.profile_summary()
+            ops.PROFILE = None
+            vk, vroof = kernel_table(vprof, M_, prec, ops.last_live_tile_share() if prec != "f32" else None,
+                                     ops.last_live_record_share(), with_traffic=False)
+            ms = graphed_ms_per_step(loop, stream, n_inner, args.steps, args.warmup)
+            model.decoder_precision = headline_precision
+            return {"ms_per_step": round(ms, 4), "value": round(M_ / (ms * 1e-3), 1), "dtype": what, "roofline": vroof,
+                    "kernels": {k: v for k, v in vk.items() if k.startswith("decoder_")}}
+        variants["decoder_precision_f16x3_fast_mode"] = variant(
+            "f16x3", "fast mode (opt-in, JointEncoding.decoder_precision = 'f16x3'): f16 MFMA on hi/lo split operands, 22-23 "
+                     "operand bits, lean records; 2-3x the fp32 kernels' error against fp64 truth")
+        variants["decoder_precision_f32"] = variant(
+            "f32", "f32 everywhere (fp32-input MFMA = exact fp32 products, the round-1 kernels: full records, no tile short cut)")
         ops.SKIP_ZERO_TILES = False                  # = MIPSF_NO_TILE_SKIP=1: chain, weight gradients and dx visit every tile
         ms = graphed_ms_per_step(loop, stream, n_inner, args.steps, args.warmup)
         variants["dense_no_tile_skip"] = {"ms_per_step": round(ms, 4), "value": round(M_ / (ms * 1e-3), 1),
                                           "note": "MIPSF_NO_TILE_SKIP=1: zero-gradient tiles are processed like live ones"}
         ops.SKIP_ZERO_TILES = True
-        log(f"variants: {variants}")
+        log(f"variants: { {k: v['ms_per_step'] for k, v in variants.items()} }")
         variants["unchanged_caller"] = unchanged_caller_rate(cfg, model, frames, poses, table, db, R, dev, min(args.steps, 20))
         log(f"unchanged caller: {variants['unchanged_caller']}")
     per_rank_ms = None
@@ -990,62 +1181,9 @@ def main():
     ms_step = elapsed / args.steps * 1e3
     value = M * args.steps * world / elapsed
 
-    kernels = {}
-    traffic = pmc_traffic()
-    traffic_raw = pmc_traffic("traffic_bytes_per_launch_uncorrected")
-    if "hashgrid_route" in prof and "hashgrid_bwd" in prof:
-        # the routing half of the scatter runs on a second stream next to the forward pass: its kernels' time is ADDED to
-        # the backward's for the roofline (the work is done, wherever it runs); `overlapped_ms` says how much is hidden
-        n_b, ms_b = prof["hashgrid_bwd"]
-        route_ms = prof["hashgrid_route"][1]
-        prof = dict(prof)
-        prof["hashgrid_bwd"] = (n_b, ms_b + route_ms)
-        del prof["hashgrid_route"]
-        hashgrid_route_ms = route_ms
-    else:
-        hashgrid_route_ms = None
-    # what the backward pass found sparse in the last timed (eager) step: the units each skipping kernel processed
     live_share = ops.last_live_tile_share()
     pair_share = ops.last_live_record_share()
-    shares = {"tile": live_share, "pair": pair_share, None: 1.0}
-    for name, (n_launch, ms) in prof.items():
-        mult, share = None, 1.0
-        if name in KERNEL_COST:
-            bound, per_live, per_dead, liveness, dtype, mult = KERNEL_COST[name]
-            share = shares[liveness] if shares[liveness] is not None else 1.0
-            work = M * (share * per_live + (1.0 - share) * per_dead)
-            work_full = M * per_live
-        elif name == "adam_step":
-            bound, dtype, liveness = "hbm", "f32", None
-            work = work_full = 28.0 * N_GRID_PARAMS
-        else:
-            continue
-        if bound == "hbm":
-            scale, peak, unit = 1e9, HBM_PEAK_GBS, "GB/s"
-        else:
-            scale, peak, unit = 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
-        achieved = work / (ms * 1e-3) / scale
-        kernels[name] = {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
-                         "frac": round(achieved / peak, 4), "avg_ms": round(ms, 4), "dtype": dtype,
-                         "launches": n_launch, "work_per_launch": round(work, 1),
-                         "traffic": traffic.get(name), "traffic_uncorrected": traffic_raw.get(name)}
-        if liveness is not None:
-            kernels[name]["units"] = f"live {liveness}s: share {share:.4f} of the batch"
-            kernels[name]["frac_full_batch"] = round(work_full / (ms * 1e-3) / scale / peak, 4)
-        if mult is not None:        # matrix-pipe view of the decoder kernels (products of the units processed)
-            issued = DECODER_FLOP_PER_SAMPLE * M * share * mult / (ms * 1e-3) / 1e12
-            mpeak = MFMA_F32_PEAK_TFLOPS if mult == 1 else MFMA_F16_PEAK_TFLOPS
-            kernels[name]["matrix_pipe"] = {"algorithmic_tflops": round(issued / mult, 2), "issued_tflops": round(issued, 2),
-                                            "peak_tflops": mpeak, "utilisation": round(issued / mpeak, 4)}
-        if name == "hashgrid_bwd" and hashgrid_route_ms is not None:
-            kernels[name]["routing_on_second_stream_ms"] = round(hashgrid_route_ms, 4)
-    dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"]) if kernels else None
-    roofline = dict(kernels[dominant], kernel=dominant) if dominant else None
-    if roofline is not None:
-        roofline["traffic_source"] = ("profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                      "command on an earlier box (per launch, gfx950 x2 FETCH correction where the kernel "
-                                      "reads 16 B per lane); not collected in this run")
-        roofline["device_stream_ceilings_TBps"] = STREAM_CEILINGS_TBS
+    kernels, roofline = kernel_table(prof, M, headline_precision, live_share, pair_share)
 
     fwd_rate, fwd_ms = forward_only_rate(model, loop, dev)
     log(f"forward-only {fwd_ms:.3f} ms")
@@ -1060,8 +1198,7 @@ def main():
                    "+ current frame) by host-drawn index sets (reference samplers), indices and jitter resident in HBM",
         "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32 (parameters, activations, gradients, accumulators); the decoder's matrix products: f16 MFMA on "
-                 "hi/lo split operands = 22-bit operands (forward, activation-gradient chain, weight gradients)",
+        "dtype": DTYPE_OF[headline_precision],
         "data": "synthetic",
         "config": {"workload": "BASELINE config 2: FastCaMo-synth apartment_2 bound, 1 active submap per GPU, "
                                "4096 rays x 64 samples (43 uniform + 21 depth-guided), hash grid 2^19 x 16 levels x 2, "
@@ -1088,6 +1225,9 @@ def main():
         if args.seq_frames > 1 and use_graph:
             seq = measured_sequence(args.seq_frames, dev, stream)
             out["frame"]["measured_sequence"] = seq
+            # the opt-in fast arithmetics next to it: f16x3 training, plain-f16 RandomOptimizer rounds (round 3's headline mode)
+            fast = measured_sequence(args.seq_frames, dev, stream, samplers=("reference",), decoder_precision="f16x3", ro_precision="f16")
+            out["frame"]["measured_sequence_fast_mode"] = fast["reference"]
             out["frame"]["ms_per_frame_reference_sampling"] = seq["reference"]["ms_per_frame_mean"]
             out["frame"]["ms_per_frame_device_sampling"] = seq["device"]["ms_per_frame_mean"]
             out["frame"]["tracking_plus_mapping_ms_per_frame"] = seq["reference"]["ms_per_frame_mean"]
@@ -1098,7 +1238,10 @@ def main():
         out["inference"] = inference_rates(cfg, model, dev)
         log("inference consumers done")
     if multi is not None:
+        multi["ranks"] = ranks_info
         out["multi_gpu"] = multi
+    out["scaling_curve"] = ("unmeasured: no multi-GPU node has been available to this build; N > 1 has run only as two gloo "
+                            "ranks sharing one GPU (tests/test_gpu_configs.py)") if world == 1 else "this line is one point of it"
     if world == 1 and args.cpu_rays > 0:
         out["cpu_baseline"] = cpu_baseline(cfg, loop, args.cpu_rays, args.cpu_iters, args.cpu_warmup)
     print(json.dumps(out), flush=True)

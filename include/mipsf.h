@@ -334,6 +334,20 @@ int mipsf_render_fwd_ex2(const float* raw, const float* z_vals, const float* tar
                          float* depth_var, float* disp, float* acc, float* weights, float* losses,
                          float* partial, const float* loss_weights, float* loss_total, uint32_t* ticket, uint32_t N,
                          uint32_t S, void* stream);
+/* floats of `partial` that mipsf_render_fwd* need for N rays: max(8 N, 18 ceil(N / 16)) -- the one-launch form keeps one row
+ * of nine doubles per 16-ray workgroup there, which exceeds 8 N floats for N < 3 */
+uint64_t mipsf_render_partial_floats(uint32_t N);
+/* A SHARE of a ray-data-parallel batch (helper_functions/utils.py:43-47 forms fs_weight / sdf_weight from
+ * counts over the WHOLE batch, scene_rep.py:218 averages depth_loss over the batch's valid rays): the per-ray maps of this
+ * share and the nine fp64 sums its losses are made of -- {rgb_sq, depth_sq(valid), fs_sq, sdf_sq, fs_emd, sdf_emd, n_valid,
+ * n_front, n_band} -- in sums[9] (device).  The caller adds the shares' sums (72 bytes) and finishes the losses of the whole
+ * batch with mipsf_loss_finalize_sums(N_total); mipsf_render_bwd_ex2(N_norm = N_total) differentiates the share. */
+int mipsf_render_fwd_sums(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
+                          const uint32_t* counts, const mipsf_render_cfg* cfg_host, float* rgb, float* depth,
+                          float* depth_var, float* disp, float* acc, float* weights, float* partial, double* sums,
+                          uint32_t* ticket, uint32_t N, uint32_t S, void* stream);
+int mipsf_loss_finalize_sums(const double* sums, const mipsf_render_cfg* cfg_host, uint32_t N_total, uint32_t S,
+                             float* losses, const float* loss_weights, float* loss_total, void* stream);
 /* Gradients wrt raw.  g_losses[4] (device): d total / d {rgb_loss, depth_loss, sdf_loss, fs_loss};
  * g_rgb [N,3], g_depth [N] nullable extra gradients on the rendered maps.  draw [N,S,10] is written. */
 int mipsf_render_bwd(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
@@ -346,6 +360,11 @@ int mipsf_render_bwd_ex(const float* raw, const float* z_vals, const float* targ
                         const uint32_t* counts, const float* losses, const mipsf_render_cfg* cfg_host,
                         const float* g_losses, const float* g_total, const float* loss_weights, const float* g_rgb,
                         const float* g_depth, float* draw, uint32_t N, uint32_t S, void* stream);
+/* ... of a SHARE of a batch: N rays here, losses normalised over N_norm >= N rays (mipsf_loss_finalize_sums) */
+int mipsf_render_bwd_ex2(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
+                         const uint32_t* counts, const float* losses, const mipsf_render_cfg* cfg_host,
+                         const float* g_losses, const float* g_total, const float* loss_weights, const float* g_rgb,
+                         const float* g_depth, float* draw, uint32_t N, uint32_t N_norm, uint32_t S, void* stream);
 /* Row gather of the ray table + ray construction from the pose parameters + sample placement in one launch
  * (mipsf_gather_pose_rays_fwd + mipsf_sample_rays: keyframeSet.py:264-290, mipsfusion.py:320-322, scene_rep.py:156-179);
  * rays_o / rays_d are not written.  Backward: d(xn) -> pose gradients in one launch (mipsf_rays_bwd + mipsf_pose_rays_bwd_ex);

@@ -35,13 +35,14 @@ class RandomOptimizer:
         self.trunc_value = cfg["training"]["trunc"]
         # extension: split the swarm over the ranks of the default process group (each holds a replica of the sub-map)
         self.particle_split = False
-        # arithmetic of the decoder inside a round.  Default "f16x3" (f16 matrix cores on hi/lo split operands, fp32
-        # class): the update compares fitness values (`fitness < fitness[0]`) and weighs particles by differences of them,
-        # so the default reproduces the reference's pose to 1e-4 (tests/golden/ro.npz).  "f16" (plain f16 operands,
-        # BASELINE config 5 "fp16 decoder on CDNA4", 2.7x faster rounds) is an explicit opt-in: its 2e-3 fitness noise can
+        # arithmetic of the decoder inside a round.  Default "bf16x6" (fp32 operands carried exactly as three bf16 pieces,
+        # six products: the reference's fp32 arithmetic): the update compares fitness values (`fitness < fitness[0]`) and
+        # weighs particles by differences of them, so the default reproduces the reference's pose to 1e-4
+        # (tests/golden/ro.npz).  "f16x3" (hi/lo f16 operands, 22-23 bits, 1.6x faster rounds) does too.  "f16" (plain f16
+        # operands, BASELINE config 5 "fp16 decoder on CDNA4", fastest) is an explicit opt-in: its 2e-3 fitness noise can
         # flip which particles count as advanced; the tracked pose stays within 1e-3 of the reference's
         # (test_random_optimizer_f16_rounds_track_the_reference_pose) -- callers that choose it state that tolerance.
-        self.decoder_precision = "f16x3"
+        self.decoder_precision = "bf16x6"
 
         # particle swarm template, same draw as RandomOptimizer.py:26-33 (numpy global RNG)
         pst = np.random.multivariate_normal(np.zeros(6), np.eye(6), self.particle_size).astype(np.float32)

@@ -127,6 +127,10 @@ SIGNATURES = {
     "mipsf_render_fwd_ex2": (_I, [_P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                   _U32, _U32, _P]),
     "mipsf_render_bwd_ex": (_I, [_P, _P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _P, _P, _U32, _U32, _P]),
+    "mipsf_render_bwd_ex2": (_I, [_P, _P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _P, _P, _U32, _U32, _U32, _P]),
+    "mipsf_render_partial_floats": (_U64, [_U32]),
+    "mipsf_render_fwd_sums": (_I, [_P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _U32, _U32, _P]),
+    "mipsf_loss_finalize_sums": (_I, [_P, C.POINTER(RenderCfg), _U32, _U32, _P, _P, _P, _P]),
     "mipsf_rays_bwd": (_I, [_P, _P, C.POINTER(RenderCfg), _P, _P, _U32, _U32, _P]),
     "mipsf_normalise_bwd": (_I, [_P, C.POINTER(RenderCfg), _P, _U32, _P]),
     "mipsf_pose_rays_fwd": (_I, [_P, _P, _P, _U32, _U32, _P, _P, _P, _P, _U32, _P]),

@@ -198,7 +198,8 @@ struct LossFinalize {           // FUSED: the last workgroup of render_fwd_kerne
     float* losses;
     const float* loss_weights;
     float* loss_total;
-};
+    double* sums_out;           // != null: the nine sums of THIS batch are left here and the losses are NOT finished (a share of
+};                              // a ray-data-parallel batch: mipsf_render_fwd_sums; the sums of all shares go to mipsf_loss_finalize_sums)
 
 __device__ void finalize_losses(const double (&t)[9], float emd_w, uint32_t N, uint32_t S, float* __restrict__ losses,
                                 const float* __restrict__ loss_weights, float* __restrict__ loss_total);
@@ -383,7 +384,12 @@ __global__ __launch_bounds__(RPB * MIPSF_WAVE) void render_fwd_kernel(
         double t[9];
 #pragma unroll
         for (int c = 0; c < 9; ++c) t[c] = red[0][c];
-        finalize_losses(t, rc.emd_w, N, S, fin.losses, fin.loss_weights, fin.loss_total);
+        if (fin.sums_out != nullptr) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) fin.sums_out[c] = t[c];
+        } else {
+            finalize_losses(t, rc.emd_w, N, S, fin.losses, fin.loss_weights, fin.loss_total);
+        }
         __hip_atomic_store(fin.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -471,13 +477,25 @@ __device__ void finalize_losses(const double (&t)[9], float emd_w, uint32_t N, u
     }
 }
 
+// the losses of a batch whose nine sums were formed elsewhere (the all-reduced sums of a ray-data-parallel batch's shares)
+__global__ void loss_finalize_sums_kernel(const double* __restrict__ sums, float emd_w, uint32_t N, uint32_t S,
+                                          float* __restrict__ losses, const float* __restrict__ loss_weights,
+                                          float* __restrict__ loss_total) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double t[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) t[c] = sums[c];
+    finalize_losses(t, emd_w, N, S, losses, loss_weights, loss_total);
+}
+
 // ------------------------------------------------------------------------ backward
+// N_norm: the ray count the losses were normalised by (= N unless this launch differentiates a SHARE of a larger batch)
 __global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void render_bwd_kernel(
     const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ target_rgb,
     const float* __restrict__ target_d, const float* __restrict__ losses, RenderCfg rc, int train,
     const float* __restrict__ g_losses, const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
     float* __restrict__ draw, uint32_t N, uint32_t S, const float* __restrict__ g_total,
-    const float* __restrict__ loss_weights) {
+    const float* __restrict__ loss_weights, uint32_t N_norm) {
     __shared__ float ssdf[RAYS_PER_BLOCK][MAX_S];
     const uint32_t w = threadIdx.x / MIPSF_WAVE, lane = threadIdx.x & (MIPSF_WAVE - 1);
     const uint32_t n = blockIdx.x * RAYS_PER_BLOCK + w;
@@ -516,7 +534,7 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void render_bwd_kernel
     float G_r = g_rgb ? g_rgb[3 * n] : 0.f, G_g = g_rgb ? g_rgb[3 * n + 1] : 0.f, G_b = g_rgb ? g_rgb[3 * n + 2] : 0.f;
     float G_d = g_depth ? g_depth[n] : 0.f;
     float d = 0.f, gS = 0.f, gF = 0.f, fs_w = 0.f, sdf_w = 0.f;
-    const float NS = (float)N * (float)S;
+    const float NS = (float)N_norm * (float)S;
     if (train) {
         d = target_d[n];
         const bool valid = (d > 0.f) && (d < rc.depth_trunc);
@@ -528,7 +546,7 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void render_bwd_kernel
         const float gR = gl[0], gD = gl[1];
         gS = gl[2], gF = gl[3];
         fs_w = losses[5], sdf_w = losses[6];
-        const float k_rgb = gR * 2.f * cw * cw / (3.f * (float)N);
+        const float k_rgb = gR * 2.f * cw * cw / (3.f * (float)N_norm);
         G_r += k_rgb * (a_r - target_rgb[3 * n]);
         G_g += k_rgb * (a_g - target_rgb[3 * n + 1]);
         G_b += k_rgb * (a_b - target_rgb[3 * n + 2]);
@@ -776,7 +794,7 @@ int mipsf_render_fwd_ex2(const float* raw, const float* z_vals, const float* tar
     const RenderCfg rc = to_render_cfg(*cfg);
     const dim3 grid((N + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK), block(RAYS_PER_BLOCK * MIPSF_WAVE);
     hipStream_t s = (hipStream_t)stream;
-    const LossFinalize fin = {counts, ticket, losses, loss_weights, loss_total};
+    const LossFinalize fin = {counts, ticket, losses, loss_weights, loss_total, nullptr};
     if (losses) {
         MIPSF_REQUIRE(target_rgb && target_d && counts && partial, "training mode needs targets, counts, partial");
         if (ticket) {       // one launch: the last workgroup finishes the losses
@@ -797,6 +815,43 @@ int mipsf_render_fwd_ex2(const float* raw, const float* z_vals, const float* tar
     return check_launch("render_fwd");
 }
 
+uint64_t mipsf_render_partial_floats(uint32_t N) {
+    // per-ray rows of the two-launch form (8 floats per ray) or one row of nine doubles per 16-ray workgroup of the fused form
+    const uint64_t rows = 8ull * N, fused = 18ull * (((uint64_t)N + 15) / 16);
+    return rows > fused ? rows : fused;
+}
+
+// A SHARE of a batch (ray-data-parallel training): the per-ray maps of this share and the nine fp64 sums its losses are made
+// of -- {rgb_sq, depth_sq(valid), fs_sq, sdf_sq, fs_emd, sdf_emd, n_valid, n_front, n_band} -- in sums[9] (device).  The
+// caller adds the shares' sums (an all-reduce of 72 bytes) and finishes the losses with mipsf_loss_finalize_sums.
+int mipsf_render_fwd_sums(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
+                          const uint32_t* counts, const mipsf_render_cfg* cfg, float* rgb, float* depth, float* depth_var,
+                          float* disp, float* acc, float* weights, float* partial, double* sums, uint32_t* ticket, uint32_t N,
+                          uint32_t S, void* stream) {
+    MIPSF_REQUIRE(cfg && raw && z_vals && rgb && depth && target_rgb && target_d && counts && partial && sums && ticket, "null pointer");
+    MIPSF_REQUIRE(S >= 1 && S <= MAX_S, "samples per ray %u outside [1,%d]", S, MAX_S);
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) {
+        if (hipMemsetAsync(sums, 0, 9 * sizeof(double), s) != hipSuccess) return 4;
+        return 0;
+    }
+    const LossFinalize fin = {counts, ticket, nullptr, nullptr, nullptr, sums};
+    constexpr int RPB = 16;
+    hipLaunchKernelGGL((render_fwd_kernel<true, true, RPB>), dim3((N + RPB - 1) / RPB), dim3(RPB * MIPSF_WAVE), 0, s, raw, z_vals,
+                       target_rgb, target_d, to_render_cfg(*cfg), rgb, depth, depth_var, disp, acc, weights, partial, N, S, fin);
+    return check_launch("render_fwd_sums");
+}
+
+// losses[8] (and loss_total, as in mipsf_render_fwd_ex) of a batch of N_total rays from its nine sums
+int mipsf_loss_finalize_sums(const double* sums, const mipsf_render_cfg* cfg, uint32_t N_total, uint32_t S, float* losses,
+                             const float* loss_weights, float* loss_total, void* stream) {
+    MIPSF_REQUIRE(sums && cfg && losses, "null pointer");
+    MIPSF_REQUIRE((loss_weights == nullptr) == (loss_total == nullptr), "loss_weights and loss_total come together");
+    hipLaunchKernelGGL(loss_finalize_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, to_render_cfg(*cfg).emd_w,
+                       N_total, S, losses, loss_weights, loss_total);
+    return check_launch("loss_finalize_sums");
+}
+
 int mipsf_render_bwd(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
                      const uint32_t* counts, const float* losses, const mipsf_render_cfg* cfg,
                      const float* g_losses, const float* g_rgb, const float* g_depth, float* draw, uint32_t N,
@@ -809,8 +864,17 @@ int mipsf_render_bwd_ex(const float* raw, const float* z_vals, const float* targ
                         const uint32_t* counts, const float* losses, const mipsf_render_cfg* cfg,
                         const float* g_losses, const float* g_total, const float* loss_weights, const float* g_rgb,
                         const float* g_depth, float* draw, uint32_t N, uint32_t S, void* stream) {
+    return mipsf_render_bwd_ex2(raw, z_vals, target_rgb, target_d, counts, losses, cfg, g_losses, g_total, loss_weights, g_rgb,
+                                g_depth, draw, N, N, S, stream);
+}
+
+int mipsf_render_bwd_ex2(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
+                         const uint32_t* counts, const float* losses, const mipsf_render_cfg* cfg,
+                         const float* g_losses, const float* g_total, const float* loss_weights, const float* g_rgb,
+                         const float* g_depth, float* draw, uint32_t N, uint32_t N_norm, uint32_t S, void* stream) {
     (void)counts;
     if (N == 0) return 0;
+    MIPSF_REQUIRE(N_norm >= N, "N_norm = %u: the normalising ray count cannot be below this launch's %u rays", N_norm, N);
     MIPSF_REQUIRE(cfg && raw && z_vals && draw, "null pointer");
     MIPSF_REQUIRE(S >= 1 && S <= MAX_S, "samples per ray %u outside [1,%d]", S, MAX_S);
     MIPSF_REQUIRE(g_total == nullptr || loss_weights != nullptr, "g_total needs the loss weights");
@@ -818,7 +882,7 @@ int mipsf_render_bwd_ex(const float* raw, const float* z_vals, const float* targ
     MIPSF_REQUIRE(!train || (target_rgb && target_d && losses), "training backward needs targets and losses");
     hipLaunchKernelGGL(render_bwd_kernel, dim3((N + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK),
                        dim3(RAYS_PER_BLOCK * MIPSF_WAVE), 0, (hipStream_t)stream, raw, z_vals, target_rgb, target_d,
-                       losses, to_render_cfg(*cfg), train, g_losses, g_rgb, g_depth, draw, N, S, g_total, loss_weights);
+                       losses, to_render_cfg(*cfg), train, g_losses, g_rgb, g_depth, draw, N, S, g_total, loss_weights, N_norm);
     return check_launch("render_bwd");
 }
 

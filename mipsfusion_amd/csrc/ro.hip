@@ -30,6 +30,11 @@ __device__ __forceinline__ void mat_mul3(const float (&a)[9], const float (&b)[9
         for (int j = 0; j < 3; ++j) c[3 * i + j] = (a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j]) + a[3 * i + 2] * b[6 + j];
 }
 
+#ifdef MIPSF_RO_LANE_CHECK      // diagnosis build (tools/dbg_ro_lanes.py): which intermediate of the pose section differs between lanes
+__device__ unsigned ro_chk_count;
+__device__ float ro_chk_dump[32][64][24];
+#endif
+
 // one wave per particle; every lane derives the particle's pose (60 flops) and then walks the lattice points
 __global__ __launch_bounds__(256) void ro_particles_kernel(const float* __restrict__ pst,
                                                            const float* __restrict__ state,
@@ -62,6 +67,32 @@ __global__ __launch_bounds__(256) void ro_particles_kernel(const float* __restri
     // wavefronts of this kernel leave the section above with another pose (tools/dbg_ro_determinism2.py: 0 of 3000 frames
     // differ run to run with one process per GPU, ~55 of 800 with two; with this broadcast 0 of 3000 with two).  Cause not
     // established (a stand-alone kernel with the same arithmetic did not reproduce it); the first lanes were never affected.
+#ifdef MIPSF_RO_LANE_CHECK
+    {
+        unsigned long long differ = 0ull;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            differ |= __ballot(__float_as_uint(aR[k]) != (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(aR[k])));
+        differ |= __ballot(__float_as_uint(t0) != (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(t0)));
+        differ |= __ballot(__float_as_uint(t1) != (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(t1)));
+        differ |= __ballot(__float_as_uint(t2) != (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(t2)));
+        if (differ) {
+            unsigned slot = 0;
+            if (lane == 0) slot = atomicAdd(&ro_chk_count, 1u);
+            slot = (unsigned)__builtin_amdgcn_readfirstlane((int)slot);
+            if (slot < 32u) {
+                float* o = ro_chk_dump[slot][lane];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o[k] = r[k];
+                o[6] = s, o[7] = qw;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) o[8 + k] = aR[k];
+                o[17] = t0, o[18] = t1, o[19] = t2;
+                o[20] = pst[6 * (size_t)p], o[21] = state[RO_SEARCH], o[22] = dR[0], o[23] = (float)p;
+            }
+        }
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < 9; ++k) aR[k] = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(aR[k])));
     t0 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(t0)));
@@ -183,6 +214,14 @@ int mipsf_ro_particles_pm(const float* pst, const float* state, const float* ray
                        rays_d_cam, target_d, make_norm(*cfg), xn, pst7, P, n, 1);
     return check_launch("ro_particles");
 }
+
+#ifdef MIPSF_RO_LANE_CHECK
+int mipsf_ro_chk_read(unsigned* count, float* dump) {
+    if (hipMemcpyFromSymbol(count, HIP_SYMBOL(ro_chk_count), sizeof(unsigned)) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(dump, HIP_SYMBOL(ro_chk_dump), sizeof(float) * 32 * 64 * 24) != hipSuccess) return 1;
+    return 0;
+}
+#endif
 
 int mipsf_ro_update(const float* mean_masked, const float* pst7, float* state, float sdf_weight, float rescale,
                     uint32_t P, void* stream) {

@@ -70,6 +70,20 @@ __device__ __forceinline__ typename A::v8 next_plane(f32x8& r) {
             asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(hi) : "v"(t), "v"(r[i + 1]));
             r[i] = lo, r[i + 1] = hi;
         }
+    } else if constexpr (std::is_same<typename A::elt, __bf16>::value) {
+        // bf16: a PAIR per v_cvt_pk_bf16_f32, widened by a shift and a mask, residual by one v_pk_add_f32
+        typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+        typedef float f2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            const f2_t x = {r[i], r[i + 1]};
+            const bf2_t t = __builtin_convertvector(x, bf2_t);
+            pl[i] = t.x, pl[i + 1] = t.y;
+            if (!LAST) {
+                const f2_t q = x - __builtin_convertvector(t, f2_t);
+                r[i] = q.x, r[i + 1] = q.y;
+            }
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -210,8 +224,8 @@ struct W16Args {
     const uint32_t* live;               // the live-tile buffer of the chain kernel (decoder16.hip), or null = every tile
     uint32_t live_cap;                  // capacity of one of its eight lists
     uint32_t live_start[8];             // first visit index of each list
-    const h8* w1_hi;                    // LDS copies of the forward's layer-1 operand images (recompute variant), else null
-    const h8* w1_lo;
+    const h8* w1_hi;                    // LDS copies of the forward's layer-1 operand images (recompute variant: P planes of
+    const h8* w1_lo;                    // RT_F1 x T16_F1 x 64 entries each, plane 0 first), else null
     // lean gradient record (MIPSF_WGRAD_LEAN_DACT, exchange form only): dG3 and the rgb_emb half of dH2 are recomputed
     const h8* gimg;                     // LDS: [S2T hi: 4 row tiles][S2T lo: 4][RGBT hi: 2][RGBT lo: 2] x 64 operands, or null
     const uint2* masks;                 // the ReLU mask part of `saved`
@@ -765,40 +779,68 @@ __device__ __forceinline__ void w16x_updown(const f32x8& sm, float& up, float& d
 }
 // the narrow product's B operand: half 0 carries the n values sm[first .. first + n) x up in elements 0 .. n - 1, half 1 zeros
 template <typename A>
-__device__ __forceinline__ void w16x_small_operand(const f32x8& sm, int first, int n, float up, int h, typename A::v8& bh, typename A::v8& bl) {
+__device__ __forceinline__ void w16x_small_operand(const f32x8& sm, int first, int n, float up, int h, typename A::v8 (&b)[A::P]) {
     f32x8 v;
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = (h == 0 && u < n) ? sm[(first + u) & 7] * up : 0.0f;
-    bh = next_plane<A, false>(v), bl = next_plane<A, true>(v);
+#pragma unroll
+    for (int p = 0; p < A::P; ++p) b[p] = p == A::P - 1 ? next_plane<A, true>(v) : next_plane<A, false>(v);
 }
-// one row tile of a one-k-step product (hi*hi + hi*lo + lo*hi, the chain's order) -> the 16 accumulator registers
-__device__ __forceinline__ f32x16 w16x_narrow(const h8 ah, const h8 al, const h8 bh, const h8 bl) {
+// one row tile of a one-k-step product, in the CHAIN kernel's order (decoder16.hip, mfma16_layer): a = weight planes (LDS),
+// b = the small operand's planes.  P = 2: a0 b0 + a0 b1 + a1 b0;  P = 3: a0 b0, a0 b1, a0 b2, a1 b1, a1 b0, a2 b0.
+template <typename A>
+__device__ __forceinline__ f32x16 w16x_narrow(const typename A::v8* img, int entry, int plane_stride, const typename A::v8 (&b)[A::P]) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 acc = mfma16(ah, bh, zero);
-    acc = mfma16(ah, bl, acc);
-    acc = mfma16(al, bh, acc);
+    const typename A::v8 a0 = img[entry], a1 = img[plane_stride + entry];
+    f32x16 acc = mfma16(a0, b[0], zero);
+    acc = mfma16(a0, b[1], acc);
+    if constexpr (A::P == 3) {
+        const typename A::v8 a2 = img[2 * plane_stride + entry];
+        acc = mfma16(a0, b[2], acc);
+        acc = mfma16(a1, b[1], acc);
+        acc = mfma16(a1, b[0], acc);
+        acc = mfma16(a2, b[0], acc);
+    } else {
+        acc = mfma16(a1, b[0], acc);
+    }
     return acc;
 }
-constexpr int W16G_S2T_HI = 0, W16G_S2T_LO = 4 * 64, W16G_RGBT_HI = 8 * 64, W16G_RGBT_LO = 10 * 64, W16G_ENTRIES = 12 * 64;
-
-struct W16X {
-    h8* xe;      // [2][4 k-steps][2 planes][64 lanes]
-    h8* xa;      // [2][4 column tiles][4][64]
-    h8* xb;      // [2][5 blocks][4][64]
+// LDS layout of the exchange form, in 16-byte entries (P planes):
+//   gimg   the chain's two narrow products' operand images: S2T plane p, row tile rt at (4 p + rt) x 64; RGBT plane p, row tile
+//          q at (4 P + 2 p + q) x 64
+//   XE     e as the forward's layer-1 operand: k-step t, plane p at (t P + p) x 64
+//   XA/XB  column tile ct: plane p, k-step m at (ct 2 P + 2 p + m) x 64
+// P = 2 (f16 hi / lo): every hand-over buffer exists TWICE (tile parity) and a tile needs ONE barrier; 134 KB.  P = 3 (bf16):
+// 201 KB that way -- single buffers and a SECOND barrier at the end of a tile instead (132 KB): XE for the next tile is then
+// written in the multiply phase, behind the first barrier.
+template <typename A>
+struct W16XL {
+    static constexpr int P = A::P;
+    static constexpr int G_ENTRIES = (4 * P + 2 * P) * 64;
+    static constexpr int G_PLANE_S2T = 4 * 64, G_RGBT = 4 * P * 64, G_PLANE_RGBT = 2 * 64;
+    static constexpr int XE = 4 * P * 64, XA = 4 * 2 * P * 64, XB = 5 * 2 * P * 64, CT = 2 * P * 64;
+    static constexpr int NBUF = P == 3 ? 1 : 2;
 };
-constexpr int W16X_XE = 4 * 2 * 64, W16X_XA = 4 * 4 * 64, W16X_XB = 5 * 4 * 64;     // 16-byte entries per buffer
+
+template <typename A>
+struct W16X {
+    typename A::v8* xe;      // [NBUF][4 k-steps][P planes][64 lanes]
+    typename A::v8* xa;      // [NBUF][4 column tiles][2 P][64]
+    typename A::v8* xb;      // [NBUF][5 blocks][2 P][64]
+};
 
 // all LDS writes of this wave done, then the workgroup barrier (NOT __syncthreads: that also waits for every outstanding
 // global load, and the next tile's records are in flight here on purpose)
 __device__ __forceinline__ void w16x_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// k-step t of e (the forward's layer-1 B operand: 8 slots per half; t = 3: raw coordinates + the bias ones) as hi / lo planes
+// k-step t of e (the forward's layer-1 B operand: 8 slots per half; t = 3: raw coordinates + the bias ones) as P planes
 template <typename A>
-__device__ __forceinline__ void w16x_e_step(int t, float x0, float x1, float x2, int h, typename A::v8& eh, typename A::v8& el) {
+__device__ __forceinline__ void w16x_e_step(int t, float x0, float x1, float x2, int h, typename A::v8 (&e)[A::P]) {
 #ifdef W16_DBG_NO_COMPUTE
     {
-        const _Float16 c = (_Float16)(x0 + x1 + x2);
-        eh = h8{c, c, c, c, c, c, c, c}, el = eh;
+        f32x8 c;
+        for (int k = 0; k < 8; ++k) c[k] = x0 + x1 + x2;
+        for (int p = 0; p < A::P; ++p) e[p] = next_plane<A, true>(c);
         return;
     }
 #endif
@@ -811,35 +853,71 @@ __device__ __forceinline__ void w16x_e_step(int t, float x0, float x1, float x2,
 #pragma unroll
         for (int k = 0; k < 8; ++k) ev[k] = 0.0f;
         ev[0] = h ? x1 : x0, ev[1] = h ? 0.0f : x2;                  // slots 24, 25: the raw coordinates
-        ev[BIAS16_U] = 1.0f, ev[BIAS16_U + 1] = 1.0f;                // slots 26, 27 meet the bias halves of the image
+#pragma unroll
+        for (int k = 0; k < A::P; ++k) ev[BIAS16_U + k] = 1.0f;      // slots 26.. meet the bias pieces of the image (2 or 3)
     }
-    eh = next_plane<A, false>(ev), el = next_plane<A, true>(ev);
+#pragma unroll
+    for (int p = 0; p < A::P; ++p) e[p] = p == A::P - 1 ? next_plane<A, true>(ev) : next_plane<A, false>(ev);
 }
 
-// acc += X^T Y for ready planes: Y = {yh[0], yh[1], yl[0], yl[1]} (k-steps 0, 1 of the hi / lo plane)
+// acc += X^T Y for ready planes: y = one column tile of XA / XB (plane pb, k-step m at (2 pb + m) x 64); the plane pairs with
+// pa + pb <= P - 1, k-step by k-step
 template <typename A>
-__device__ __forceinline__ void w16x_mac(const typename A::v8 (&X)[2][2], const h8* y, int lane, f32x16& acc) {
+__device__ __forceinline__ void w16x_mac(const typename A::v8 (&X)[A::P][2], const typename A::v8* y, int lane, f32x16& acc) {
 #ifdef W16_DBG_NO_COMPUTE
     return;
 #endif
-    const h8 yh0 = y[lane], yh1 = y[64 + lane], yl0 = y[128 + lane], yl1 = y[192 + lane];
-    acc = mfma16(X[0][0], yh0, acc);
-    acc = mfma16(X[1][0], yh0, acc);
-    acc = mfma16(X[0][0], yl0, acc);
-    acc = mfma16(X[0][1], yh1, acc);
-    acc = mfma16(X[1][1], yh1, acc);
-    acc = mfma16(X[0][1], yl1, acc);
+    constexpr int P = A::P;
+    typename A::v8 Y[P][2];
+#pragma unroll
+    for (int pb = 0; pb < P; ++pb)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) Y[pb][m] = y[(2 * pb + m) * 64 + lane];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int pb = 0; pb < P; ++pb)
+#pragma unroll
+            for (int pa = 0; pa + pb < P; ++pa) acc = mfma16(X[pa][m], Y[pb][m], acc);
+}
+// two such products side by side (acc_a += Xa^T Ya, acc_b += Xb^T Yb), their MFMAs in turn: a chain of MFMAs on ONE
+// accumulator issues every ~82 cycles instead of every 32 (each waits for the one in front of it); with two chains per wave
+// and two waves per SIMD the matrix pipe always finds an independent instruction
+template <typename A>
+__device__ __forceinline__ void w16x_mac2(const typename A::v8 (&Xa)[A::P][2], const typename A::v8* ya, f32x16& acc_a,
+                                          const typename A::v8 (&Xb)[A::P][2], const typename A::v8* yb, f32x16& acc_b, int lane) {
+#ifdef W16_DBG_NO_COMPUTE
+    return;
+#endif
+    constexpr int P = A::P;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int pb = 0; pb < P; ++pb) {
+            const typename A::v8 Ya = ya[(2 * pb + m) * 64 + lane], Yb = yb[(2 * pb + m) * 64 + lane];
+#pragma unroll
+            for (int pa = 0; pa + pb < P; ++pa) {
+                acc_a = mfma16(Xa[pa][m], Ya, acc_a);
+                acc_b = mfma16(Xb[pa][m], Yb, acc_b);
+            }
+        }
 }
 template <typename A>
-__device__ __forceinline__ void w16x_put(h8* y, int lane, const typename A::v8 (&Y)[2][2]) {
-    y[lane] = Y[0][0], y[64 + lane] = Y[0][1], y[128 + lane] = Y[1][0], y[192 + lane] = Y[1][1];
+__device__ __forceinline__ void w16x_put(typename A::v8* y, int lane, const typename A::v8 (&Y)[A::P][2]) {
+#pragma unroll
+    for (int p = 0; p < A::P; ++p)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) y[(2 * p + m) * 64 + lane] = Y[p][m];
 }
 
 // waves 0..3 (w): d w_pts2[w][0..3] = dH2[w]^T H1, d b_pts2; rows 0..15 of the fifth tile (small rows)^T H3[w] -> d w_sdf2,
 // rows 16..31 (small rows)^T {rgb_emb 0 | rgb_emb 1 | e 0 | e 1}[w] -> d w_rgb0.  Produces e k-step w and H1 column tile w.
 template <int LAYOUT, typename A>
-__device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X& lx, const typename A::v8 (&I)[2], int w, int lane) {
-    static_assert(A::SCALED && A::P == 2, "f16 hi/lo arithmetic only");
+__device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X<A>& lx, const typename A::v8 (&I)[2], int w, int lane) {
+    typedef W16XL<A> L;
+    typedef typename A::v8 v8;
+    constexpr int P = A::P;
+    constexpr bool TWO_BARRIERS = L::NBUF == 1;
     const int j = lane & 31, h = lane >> 5;
     const uint32_t lane16 = 16u * (uint32_t)lane;
     f32x16 acc[5];
@@ -858,6 +936,9 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X& lx, co
         const float4 p = buf_load16(small_srd, off, 0), q = buf_load16(small_srd, off, 16);
         v[0][0] = p.x, v[0][1] = p.y, v[0][2] = p.z, v[0][3] = p.w, v[0][4] = q.x, v[0][5] = q.y, v[0][6] = q.z, v[0][7] = q.w;
     };
+    const v8* gimg = reinterpret_cast<const v8*>(a.gimg);
+    const v8* w1 = reinterpret_cast<const v8*>(a.w1_hi);     // [P planes][RT_F1 x T16_F1 x 64]
+    constexpr int W1_PLANE = RT_F1 * T16H_F1 * 64;
     const bool recompute_x = a.gimg != nullptr && w >= 2;       // lean gradient record: dH2[2], dH2[3] = Wrgb^T drgb are not stored
     auto dh2_srd = [&](uint32_t tile) {
         return make_srd(a.dact + (size_t)tile * ACT_TILE_FLOATS, recompute_x ? 0 : ACT_TILE_FLOATS * 4);
@@ -875,6 +956,12 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X& lx, co
     auto e_srd = [&](uint32_t tile) {
         return make_srd(a.saved + (size_t)tile * ACT_TILE_FLOATS, w < 2 ? ACT_TILE_FLOATS * 4 : 0);
     };
+    auto put_e = [&](v8* xe, const float (&xv)[3]) {
+        v8 e[P];
+        w16x_e_step<A>(w, xv[0], xv[1], xv[2], h, e);
+#pragma unroll
+        for (int p = 0; p < P; ++p) xe[(w * P + p) * 64 + lane] = e[p];
+    };
     f32x8 bX[2], bS[2], bH3[2], bE[2];
     float xn[3] = {0.f, 0.f, 0.f};           // coordinates of the NEXT tile (its e is produced during this one)
     uint32_t it = blockIdx.x, par = 0;
@@ -885,24 +972,22 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X& lx, co
         load_small(t0, bS);
         load_tile_rows(act_srd(a.saved, t0), 2, w, lane16, bH3);
         load_tile_rows(e_srd(t0), 1, 2 + (w & 1), lane16, bE);
-        typename A::v8 eh, el;
-        w16x_e_step<A>(w, xn[0], xn[1], xn[2], h, eh, el);
-        lx.xe[(w * 2 + 0) * 64 + lane] = eh, lx.xe[(w * 2 + 1) * 64 + lane] = el;
+        put_e(lx.xe, xn);
         load_x(w16_tile(a, it + gridDim.x < a.n_tiles ? it + gridDim.x : it), xn);
     }
     w16x_barrier();
 #pragma clang loop unroll(disable)
-    for (; it < a.n_tiles; it += gridDim.x, par ^= 1u) {
+    for (; it < a.n_tiles; it += gridDim.x, par ^= (L::NBUF == 2 ? 1u : 0u)) {
         const bool more = it + gridDim.x < a.n_tiles;
         const uint32_t nt = more ? w16_tile(a, it + gridDim.x) : w16_tile(a, it);
-        h8* xe = lx.xe + par * W16X_XE;
-        h8* xa = lx.xa + par * W16X_XA;
-        const h8* xb = lx.xb + par * W16X_XB;
-        typename A::v8 X[2][2];
+        v8* xe = lx.xe + par * L::XE;
+        v8* xa = lx.xa + par * L::XA;
+        const v8* xb = lx.xb + par * L::XB;
+        v8 X[P][2];
         W16_TRACE_DECL;
         W16_MARK(0);
         // ---- H1 column tile w = e W1[w]^T (the operands swapped: lane = feature, registers = 16 samples; the forward's H1
-        //      bit for bit), ReLU, planes -> XA
+        //      bit for bit: the forward's products in the forward's order), ReLU, planes -> XA
         {
             f32x16 hacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -910,50 +995,56 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X& lx, co
 #ifdef W16_DBG_NO_COMPUTE
                 break;
 #endif
-                const h8 eh = xe[(t * 2 + 0) * 64 + lane], el = xe[(t * 2 + 1) * 64 + lane];
-                const h8 wh = a.w1_hi[(w * T16H_F1 + t) * 64 + lane], wl = a.w1_lo[(w * T16_F1 + t) * 64 + lane];
-                hacc = mfma16(eh, wh, hacc);
-                hacc = mfma16(el, wh, hacc);
-                hacc = mfma16(eh, wl, hacc);
+                v8 e[P], wp[P];
+#pragma unroll
+                for (int p = 0; p < P; ++p) e[p] = xe[(t * P + p) * 64 + lane], wp[p] = w1[p * W1_PLANE + (w * T16H_F1 + t) * 64 + lane];
+                hacc = mfma16(e[0], wp[0], hacc);
+                hacc = mfma16(e[1], wp[0], hacc);
+                if constexpr (P == 3) {
+                    hacc = mfma16(e[2], wp[0], hacc);
+                    hacc = mfma16(e[1], wp[1], hacc);
+                    hacc = mfma16(e[0], wp[1], hacc);
+                    hacc = mfma16(e[0], wp[2], hacc);
+                } else {
+                    hacc = mfma16(e[0], wp[1], hacc);
+                }
             }
-            typename A::v8 Y[2][2];
+            v8 Y[P][2];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 f32x8 r;
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
                     r[u] = __builtin_amdgcn_fmed3f(hacc[8 * m + u] * (1.0f / (float)(1 << W16_SHIFT)), 0.0f, __builtin_inff());
-                Y[0][m] = next_plane<A, false>(r);
-                Y[1][m] = next_plane<A, true>(r);
+#pragma unroll
+                for (int p = 0; p < P; ++p) Y[p][m] = p == P - 1 ? next_plane<A, true>(r) : next_plane<A, false>(r);
             }
-            w16x_put<A>(xa + w * 256, lane, Y);
+            w16x_put<A>(xa + w * L::CT, lane, Y);
         }
         W16_FENCE();
         W16_MARK(1);
-        // ---- e k-step w of the NEXT tile -> the other XE buffer (read by everybody before the next barrier)
-        if (more) {
-            typename A::v8 eh, el;
-            w16x_e_step<A>(w, xn[0], xn[1], xn[2], h, eh, el);
-            h8* xen = lx.xe + (par ^ 1u) * W16X_XE;
-            xen[(w * 2 + 0) * 64 + lane] = eh, xen[(w * 2 + 1) * 64 + lane] = el;
+        // ---- e k-step w of the NEXT tile.  Two buffers: into the other one, now (it is read by everybody before the next
+        //      barrier).  One buffer: behind this tile's first barrier (below).
+        if (!TWO_BARRIERS) {
+            if (more) put_e(lx.xe + (par ^ 1u) * L::XE, xn);
+            load_x(w16_tile(a, it + 2 * gridDim.x < a.n_tiles ? it + 2 * gridDim.x : it), xn);
         }
-        load_x(w16_tile(a, it + 2 * gridDim.x < a.n_tiles ? it + 2 * gridDim.x : it), xn);
         W16_FENCE();
         W16_MARK(2);
         // ---- X = dH2[w]
         if (recompute_x) {          // = (Wrgb[:, :64]^T drgb)[row tile w - 2], as the chain kernel computed it
             float up, down;
             w16x_updown(bS[0], up, down);
-            typename A::v8 rh, rl;
-            w16x_small_operand<A>(bS[0], N_CLASS, 3, up, h, rh, rl);
-            const f32x16 acc = w16x_narrow(a.gimg[W16G_RGBT_HI + (w - 2) * 64 + lane], a.gimg[W16G_RGBT_LO + (w - 2) * 64 + lane], rh, rl);
+            v8 rp[P];
+            w16x_small_operand<A>(bS[0], N_CLASS, 3, up, h, rp);
+            const f32x16 ac = w16x_narrow<A>(gimg, L::G_RGBT + (w - 2) * 64 + lane, L::G_PLANE_RGBT, rp);
             const float unscale = 1.0f / (float)(1 << W16_SHIFT);
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) bX[q][u] = (acc[8 * q + u] * unscale) * down;
+                for (int u = 0; u < 8; ++u) bX[q][u] = (ac[8 * q + u] * unscale) * down;
         }
-        {
+        if (A::SCALED) {
             float rs;
             const float sx = w16_pick_scale(w16_block_max_bits(bX, 2), k_main, rs);
             if (rs != 1.0f) {
@@ -970,9 +1061,18 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X& lx, co
         W16_MARK(3);
         w16x_barrier();
         W16_MARK(4);
+        if (TWO_BARRIERS) {         // everybody has read this tile's e: the next tile's goes into the same buffer
+            if (more) put_e(lx.xe, xn);
+            load_x(w16_tile(a, it + 2 * gridDim.x < a.n_tiles ? it + 2 * gridDim.x : it), xn);
+        }
         // ---- the four H1 column tiles
+        if constexpr (P == 3) {
+            w16x_mac2<A>(X, xa, acc[0], X, xa + L::CT, acc[1], lane);
+            w16x_mac2<A>(X, xa + 2 * L::CT, acc[2], X, xa + 3 * L::CT, acc[3], lane);
+        } else {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) w16x_mac<A>(X, xa + ct * 256, lane, acc[ct]);
+            for (int ct = 0; ct < 4; ++ct) w16x_mac<A>(X, xa + ct * L::CT, lane, acc[ct]);
+        }
         W16_FENCE();
         W16_MARK(5);
         // ---- small rows: (d logits, d rgb)^T H3[w] (rows 0..15), ^T {rgb_emb | e} (rows 16..31)
@@ -981,7 +1081,7 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X& lx, co
 #pragma unroll
             for (int u = 0; u < 8; ++u) bS[0][u] = 0.0f;
         }
-        {
+        if (A::SCALED) {
             float rs;
             const float sx = w16_pick_scale(w16_block_max_bits(bS, 1), k_small, rs);
             if (rs != 1.0f) acc[4] *= rs, bsmall *= rs;
@@ -994,13 +1094,14 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X& lx, co
         transpose_block<A, false, 1>(sv2, I, X, dummy, 1);                          // the small rows at columns 16..27
         W16_FENCE();
         if (w < 2) transpose_mac<A>(bE, I, X, acc[4]);                              // rgb_emb (waves 0, 1)
-        else w16x_mac<A>(X, xb + (3 + (w - 2)) * 256, lane, acc[4]);                // e column tile w - 2 (waves 2, 3)
+        else w16x_mac<A>(X, xb + (3 + (w - 2)) * L::CT, lane, acc[4]);              // e column tile w - 2 (waves 2, 3)
         W16_FENCE();
         load_small(nt, bS);
         load_tile_rows(act_srd(a.saved, nt), 2, w, lane16, bH3);
         load_tile_rows(e_srd(nt), 1, 2 + (w & 1), lane16, bE);
         W16_FENCE();
         W16_MARK(6);
+        if (TWO_BARRIERS) w16x_barrier();      // this tile's XA / XB have been read: the next tile may overwrite them
         W16_TRACE_SUM(6, w);
     }
     float* rec = a.rec;
@@ -1028,8 +1129,11 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X& lx, co
 // waves 4..7 (rt): d w_sdf0[rt][0..2] = dG3[rt]^T [sdf_emb | grid], d b_sdf0;  d w_pts0[rt][0..1] = dG1[rt]^T e, d b_pts0.
 // Produces the transposed column tiles: rt 0, 1 -> sdf_emb 0, 1; rt 2 -> grid; rt 3 -> e 0 and e 1 (from XE's planes).
 template <int LAYOUT, typename A>
-__device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X& lx, const typename A::v8 (&I)[2], int rt, int lane) {
-    static_assert(A::SCALED && A::P == 2, "f16 hi/lo arithmetic only");
+__device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X<A>& lx, const typename A::v8 (&I)[2], int rt, int lane) {
+    typedef W16XL<A> L;
+    typedef typename A::v8 v8;
+    constexpr int P = A::P;
+    constexpr bool TWO_BARRIERS = L::NBUF == 1;
     const int j = lane & 31, h = lane >> 5;
     const uint32_t lane16 = 16u * (uint32_t)lane;
     f32x16 acc[5];
@@ -1062,6 +1166,7 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X& lx, co
     // lean gradient record: dG3[rt] = relu'(H3[rt]) (Ws2^T dlogits)[rt] is recomputed from the sample's 8 small-row values and
     // its mask bits (loaded one tile ahead like everything else); the record's dG3 pieces are then read through an empty resource
     const bool lean = a.gimg != nullptr;
+    const v8* gimg = reinterpret_cast<const v8*>(a.gimg);
     const srd_t small_srd = make_srd(a.dsmall, a.M * 32u);
     f32x8 bSm;
     uint2 bMk = make_uint2(0u, 0u);
@@ -1085,34 +1190,34 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X& lx, co
     w16x_barrier();
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma clang loop unroll(disable)
-    for (; it < a.n_tiles; it += gridDim.x, par ^= 1u) {
+    for (; it < a.n_tiles; it += gridDim.x, par ^= (L::NBUF == 2 ? 1u : 0u)) {
         const uint32_t nt = it + gridDim.x < a.n_tiles ? w16_tile(a, it + gridDim.x) : w16_tile(a, it);
-        const h8* xe = lx.xe + par * W16X_XE;
-        h8* xb = lx.xb + par * W16X_XB;
-        typename A::v8 X3[2][2], X1[2][2];
+        const v8* xe = lx.xe + par * L::XE;
+        v8* xb = lx.xb + par * L::XB;
+        v8 X3[P][2], X1[P][2];
         W16_TRACE_DECL;
         W16_MARK(0);
         // ---- this wave's column tile(s) -> XB
         if (rt < 3) {
             if (rt == 2) bY[0] = bGr[0] * W16_GRID_SHIFT, bY[1] = bGr[1] * W16_GRID_SHIFT;
-            typename A::v8 Y[2][2];
+            v8 Y[P][2];
             transpose_block<A, false>(bY, I, Y, dummy);
-            w16x_put<A>(xb + rt * 256, lane, Y);
+            w16x_put<A>(xb + rt * L::CT, lane, Y);
         } else {
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {           // e column tile blk = k-steps 2 blk, 2 blk + 1, plane by plane
-                typename A::v8 Y[2][2];
+                v8 Y[P][2];
 #pragma unroll
-                for (int pb = 0; pb < 2; ++pb) {
+                for (int pb = 0; pb < P; ++pb) {
 #ifdef W16_DBG_NO_COMPUTE
                     Y[pb][0] = I[0], Y[pb][1] = I[1];
                     continue;
 #endif
-                    f32x16 T = mfma16(xe[((2 * blk) * 2 + pb) * 64 + lane], I[0], zero);
-                    T = mfma16(xe[((2 * blk + 1) * 2 + pb) * 64 + lane], I[1], T);
+                    f32x16 T = mfma16(xe[((2 * blk) * P + pb) * 64 + lane], I[0], zero);
+                    T = mfma16(xe[((2 * blk + 1) * P + pb) * 64 + lane], I[1], T);
                     pack_T<A>(T, Y[pb]);
                 }
-                w16x_put<A>(xb + (3 + blk) * 256, lane, Y);
+                w16x_put<A>(xb + (3 + blk) * L::CT, lane, Y);
             }
         }
         W16_FENCE();
@@ -1123,17 +1228,17 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X& lx, co
         if (lean) {
             float up, down;
             w16x_updown(bSm, up, down);
-            typename A::v8 lh, ll;
-            w16x_small_operand<A>(bSm, 0, N_CLASS, up, h, lh, ll);
-            const f32x16 acc = w16x_narrow(a.gimg[W16G_S2T_HI + rt * 64 + lane], a.gimg[W16G_S2T_LO + rt * 64 + lane], lh, ll);
+            v8 lp[P];
+            w16x_small_operand<A>(bSm, 0, N_CLASS, up, h, lp);
+            const f32x16 ac = w16x_narrow<A>(gimg, rt * 64 + lane, L::G_PLANE_S2T, lp);
             const uint32_t m3[2] = {bMk.x, bMk.y};
             const float unscale = 1.0f / (float)(1 << W16_SHIFT);
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) bG3[q][u] = mask_apply(m3, rt, 8 * q + u, acc[8 * q + u] * unscale) * down;
+                for (int u = 0; u < 8; ++u) bG3[q][u] = mask_apply(m3, rt, 8 * q + u, ac[8 * q + u] * unscale) * down;
         }
-        {
+        if (A::SCALED) {
             float rs;
             const float sx = w16_pick_scale(w16_block_max_bits(bG3, 2), k3, rs);
             if (rs != 1.0f) {
@@ -1149,7 +1254,7 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X& lx, co
         load_lean(nt);
         load_tile_rows(g3_srd(nt), 2, rt, lane16, bG3);
         W16_FENCE();
-        {
+        if (A::SCALED) {
             float rs;
             const float sx = w16_pick_scale(w16_block_max_bits(bG1, 2), k1, rs);
             if (rs != 1.0f) acc[3] *= rs, acc[4] *= rs, bsum1 *= rs;
@@ -1162,13 +1267,20 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X& lx, co
         W16_MARK(3);
         w16x_barrier();
         W16_MARK(4);
+        if constexpr (P == 3) {
+            w16x_mac2<A>(X3, xb, acc[0], X3, xb + L::CT, acc[1], lane);
+            w16x_mac2<A>(X3, xb + 2 * L::CT, acc[2], X1, xb + 3 * L::CT, acc[3], lane);
+            w16x_mac<A>(X1, xb + 4 * L::CT, lane, acc[4]);
+        } else {
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) w16x_mac<A>(X3, xb + ct * 256, lane, acc[ct]);
+            for (int ct = 0; ct < 3; ++ct) w16x_mac<A>(X3, xb + ct * L::CT, lane, acc[ct]);
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) w16x_mac<A>(X1, xb + (3 + ct) * 256, lane, acc[3 + ct]);
+            for (int ct = 0; ct < 2; ++ct) w16x_mac<A>(X1, xb + (3 + ct) * L::CT, lane, acc[3 + ct]);
+        }
         W16_FENCE();
         W16_MARK(5);
         W16_MARK(6);
+        if (TWO_BARRIERS) w16x_barrier();
         W16_TRACE_SUM(6, 4 + rt);
     }
     float* rec = a.rec;
@@ -1222,24 +1334,33 @@ __global__ __launch_bounds__(W16_BLOCK, 2) void decoder_wgrad16_kernel(const flo
     constexpr int W1_ENTRIES = RT_F1 * T16H_F1 * 64;          // 16-byte operands of one layer-1 image (hi; lo has as many)
     static_assert(T16H_F1 == T16_F1, "layer 1 has no separate bias k-step");
     constexpr bool EXCH = RECOMP && W16_EXCHANGE;
-    __shared__ h8 w1img[RECOMP ? 2 * W1_ENTRIES : 1];
-    __shared__ h8 xch[EXCH ? 2 * (W16X_XE + W16X_XA + W16X_XB) : 1];
-    __shared__ h8 gimg[EXCH ? W16G_ENTRIES : 1];
+    typedef W16XL<A> L;
+    constexpr int P = A::P;
+    __shared__ h8 w1img[RECOMP ? P * W1_ENTRIES : 1];
+    __shared__ h8 xch[EXCH ? L::NBUF * (L::XE + L::XA + L::XB) : 1];
+    __shared__ h8 gimg[EXCH ? L::G_ENTRIES : 1];
+    static_assert(!EXCH || sizeof(h8) * (P * W1_ENTRIES + L::NBUF * (L::XE + L::XA + L::XB) + L::G_ENTRIES) <= 160 * 1024,
+                  "the exchange form's images and hand-over buffers must fit the LDS of a CU");
     if constexpr (RECOMP) {
+        // planes 0 and 1 of an image sit where the f16 layout has hi and lo; plane 2 (bf16 only) in the buffer's extension
         const h8* img = reinterpret_cast<const h8*>(packed16 + TAIL16_FLOATS);
+        const h8* ext = reinterpret_cast<const h8*>(packed16 + PACKED16_FLOATS);
         for (int q = tid; q < W1_ENTRIES; q += W16_BLOCK) {
             w1img[q] = img[OFF16H_F1 / 8 + q];
             w1img[W1_ENTRIES + q] = img[(IMG16H_HALVES + OFF16L_F1) / 8 + q];
+            if constexpr (P == 3) w1img[2 * W1_ENTRIES + q] = ext[(EXT16_FWD + OFF16L_F1) / 8 + q];
         }
-        if constexpr (EXCH) {       // the chain's two narrow products: operand images of the backward set (hi, then lo)
+        if constexpr (EXCH) {       // the chain's two narrow products: operand images of the backward sets, plane by plane
             const h8* bimg = img + OFF16_BWD_HALVES / 8;
             for (int q = tid; q < 4 * 64; q += W16_BLOCK) {
-                gimg[W16G_S2T_HI + q] = bimg[OFF16B_S2T / 8 + q];
-                gimg[W16G_S2T_LO + q] = bimg[(IMG16B_HALVES + OFF16B_S2T) / 8 + q];
+                gimg[q] = bimg[OFF16B_S2T / 8 + q];
+                gimg[L::G_PLANE_S2T + q] = bimg[(IMG16B_HALVES + OFF16B_S2T) / 8 + q];
+                if constexpr (P == 3) gimg[2 * L::G_PLANE_S2T + q] = ext[(EXT16_BWD + OFF16B_S2T) / 8 + q];
             }
             for (int q = tid; q < 2 * 64; q += W16_BLOCK) {
-                gimg[W16G_RGBT_HI + q] = bimg[OFF16B_RGBT / 8 + q];
-                gimg[W16G_RGBT_LO + q] = bimg[(IMG16B_HALVES + OFF16B_RGBT) / 8 + q];
+                gimg[L::G_RGBT + q] = bimg[OFF16B_RGBT / 8 + q];
+                gimg[L::G_RGBT + L::G_PLANE_RGBT + q] = bimg[(IMG16B_HALVES + OFF16B_RGBT) / 8 + q];
+                if constexpr (P == 3) gimg[L::G_RGBT + 2 * L::G_PLANE_RGBT + q] = ext[(EXT16_BWD + OFF16B_RGBT) / 8 + q];
             }
         }
         __syncthreads();
@@ -1252,16 +1373,17 @@ __global__ __launch_bounds__(W16_BLOCK, 2) void decoder_wgrad16_kernel(const flo
                        (EXCH && lean_dact) ? gimg : nullptr,
                        reinterpret_cast<const uint2*>(saved + (((size_t)M + 127) / 128) * 4 * ACT_TILE_FLOATS)};
     if constexpr (EXCH) {
-        const W16X lx = {xch, xch + 2 * W16X_XE, xch + 2 * (W16X_XE + W16X_XA)};
+        typename A::v8* xp = reinterpret_cast<typename A::v8*>(xch);
+        const W16X<A> lx = {xp, xp + L::NBUF * L::XE, xp + L::NBUF * (L::XE + L::XA)};
         if (w < 4) w16x_role_a<LAYOUT, A>(a, lx, I, w, lane);
         else w16x_role_b<LAYOUT, A>(a, lx, I, w - 4, lane);
-        return;
-    }
-    if (w < 4) {
-        if constexpr (RECOMP) w16_role_a_recompute<LAYOUT, A>(a, I, w, lane);
-        else w16_role_a<LAYOUT, A>(a, I, w, lane);
     } else {
-        w16_role_b<LAYOUT, A>(a, I, w - 4, lane);
+        if (w < 4) {
+            if constexpr (RECOMP) w16_role_a_recompute<LAYOUT, A>(a, I, w, lane);
+            else w16_role_a<LAYOUT, A>(a, I, w, lane);
+        } else {
+            w16_role_b<LAYOUT, A>(a, I, w - 4, lane);
+        }
     }
 }
 
@@ -1311,9 +1433,10 @@ extern "C" int mipsf_decoder_wgrad16_tiles_ex(const float* packed16, const float
     if (M == 0) return 0;
     MIPSF_REQUIRE((flags & ~(uint32_t)MIPSF_WGRAD_LEAN_DACT) == 0u, "unknown flags 0x%x", flags);
     const uint32_t lean_dact = (flags & MIPSF_WGRAD_LEAN_DACT) ? 1u : 0u;
-    MIPSF_REQUIRE(!lean_dact || (packed16 != nullptr && arithmetic == MIPSF_PREC_F16X3 && W16_EXCHANGE),
-                  "the lean gradient record is read by the f16x3 kernel with packed16 only");
-    MIPSF_REQUIRE(packed16 == nullptr || arithmetic == MIPSF_PREC_F16X3, "H1 is recomputed by the f16x3 arithmetic only");
+    MIPSF_REQUIRE(!lean_dact || (packed16 != nullptr && (arithmetic == MIPSF_PREC_F16X3 || arithmetic == MIPSF_PREC_BF16X6) && W16_EXCHANGE),
+                  "the lean gradient record is read by the f16x3 / bf16x6 kernel with packed16 only");
+    MIPSF_REQUIRE(packed16 == nullptr || arithmetic == MIPSF_PREC_F16X3 || arithmetic == MIPSF_PREC_BF16X6,
+                  "H1 is recomputed by the f16x3 / bf16x6 arithmetic only (packed16 of the same family)");
     MIPSF_REQUIRE(feat && x && saved && dact && partial && grads, "null pointer");
     MIPSF_REQUIRE(feat_layout == MIPSF_FEAT_AOS || feat_layout == MIPSF_FEAT_LEVEL_MAJOR, "bad layout");
     MIPSF_REQUIRE(arithmetic == MIPSF_PREC_F16X3 || arithmetic == MIPSF_PREC_BF16X6 || arithmetic == MIPSF_PREC_BF16X3,
@@ -1331,7 +1454,8 @@ extern "C" int mipsf_decoder_wgrad16_tiles_ex(const float* packed16, const float
 #define W16(LAY, AR, RC) hipLaunchKernelGGL((decoder_wgrad16_kernel<LAY, AR, RC>), dim3(blocks), dim3(W16_BLOCK), 0, s, packed16, \
                                             feat, x, saved, dact, dsmall, partial, M, n_tiles, live, lean_dact)
 #define W16_L(LAY) do { if (arithmetic == MIPSF_PREC_F16X3) { if (packed16) W16(LAY, ArF16, true); else W16(LAY, ArF16, false); } \
-                        else if (arithmetic == MIPSF_PREC_BF16X6) W16(LAY, ArBF3, false); else W16(LAY, ArBF2, false); } while (0)
+                        else if (arithmetic == MIPSF_PREC_BF16X6) { if (packed16) W16(LAY, ArBF3, true); else W16(LAY, ArBF3, false); } \
+                        else W16(LAY, ArBF2, false); } while (0)
     if (feat_layout == MIPSF_FEAT_AOS) W16_L(MIPSF_FEAT_AOS); else W16_L(MIPSF_FEAT_LEVEL_MAJOR);
 #undef W16_L
 #undef W16

@@ -106,7 +106,7 @@ class _QueryFn(torch.autograd.Function):
                 cache[prec] = (packed, packed16)
         # lean record: when the weight gradients will come from the streaming f16 kernel (the default behind the f16x3
         # chain) H1 is recomputed there from x and the forward does not write it (a third of the record)
-        lean = bool(need and prec == "f16x3" and owner.wgrad_precision in ("auto", "stream_f16x3") and owner.lean_record)
+        lean = bool(need and prec in ops.SPLIT_PRECISIONS and owner.wgrad_precision in ("auto", "stream_" + prec) and owner.lean_record)
         # a frozen decoder (tracking: only the points need a gradient): the chain reads the ReLU masks and nothing else of the
         # record -- the 1 KB of activations per sample would be written for nobody
         masks_only = bool(need and prec in ops.SPLIT_PRECISIONS and not any(ctx.needs_input_grad[3:]))
@@ -148,7 +148,7 @@ class _QueryFn(torch.autograd.Function):
                     grads.append(torch.zeros_like(w))
         dfeat, dx, _, tiles = ops.decoder_bwd(packed, feat, FEAT_LEVEL_MAJOR, xn, None, out, ops._f32c(dout), saved, grads,
                                               ctx.M, precision=ctx.prec, packed16=packed if ctx.prec != "f32" else None,
-                                              wgrad_precision="stream_f16x3" if ctx.lean else ctx.owner.wgrad_precision,
+                                              wgrad_precision=("stream_" + ctx.prec) if ctx.lean else ctx.owner.wgrad_precision,
                                               recompute_h1=ctx.lean, return_tiles=True)
         dparams = None
         fresh_grad = False
@@ -177,10 +177,14 @@ class _RenderFn(torch.autograd.Function):
     """raw2outputs / sdf2weights (+ the four training losses): scene_rep.py:58-103, 211-236."""
 
     @staticmethod
-    def forward(ctx, raw, z_vals, target_rgb, target_d, counts, rc, N, S, train, loss_w=None):
+    def forward(ctx, raw, z_vals, target_rgb, target_d, counts, rc, N, S, train, loss_w=None, share_of=None):
         raw = ops._f32c(raw)
         total = None
-        if train and loss_w is not None:     # the weighted objective comes out of the loss kernel itself
+        ctx.n_norm = None
+        if train and share_of is not None:   # a share of a ray-data-parallel batch: the losses of the WHOLE batch
+            rgb, depth, var, disp, acc, _, losses, total, ctx.n_norm = ops.render_fwd(
+                raw, z_vals, target_rgb, target_d, counts, rc, N, S, train, loss_weights=loss_w, share_of=share_of)
+        elif train and loss_w is not None:     # the weighted objective comes out of the loss kernel itself
             rgb, depth, var, disp, acc, _, losses, total = ops.render_fwd(raw, z_vals, target_rgb, target_d, counts, rc, N,
                                                                           S, train, loss_weights=loss_w)
         else:
@@ -206,8 +210,8 @@ class _RenderFn(torch.autograd.Function):
             g_losses = torch.zeros(8, dtype=torch.float32, device=raw.device)
         draw = ops.render_bwd(raw, z_vals, target_rgb, target_d, counts, losses, ctx.rc,
                               ops._f32c(g_losses) if (ctx.train and g_losses is not None) else None, g_rgb, g_depth,
-                              ctx.N, ctx.S, g_total=g_total, loss_weights=loss_w)
-        return draw, None, None, None, None, None, None, None, None, None
+                              ctx.N, ctx.S, g_total=g_total, loss_weights=loss_w, n_norm=ctx.n_norm)
+        return draw, None, None, None, None, None, None, None, None, None, None
 
 
 class JointEncoding(nn.Module):
@@ -225,12 +229,16 @@ class JointEncoding(nn.Module):
         # / the captured loops) -- the grid scatter then stores its slices instead of adding to the old values.  Wrong
         # gradients if the promise is broken (several backward passes accumulated before a step): off by default.
         self.grid_grad_is_zero_at_backward = False
-        # arithmetic of the decoder's three hidden layers (csrc/decoder16.hip):
-        #   "f16x3" f16 matrix cores on hi/lo split operands, fp32 accumulate: ~3e-7 relative, passes the reference
-        #           goldens at the fp32 kernel's tolerances at 2.4x its speed (default)
+        # arithmetic of the decoder (csrc/decoder16.hip, csrc/decoder.hip):
+        #   "bf16x6" (default) every fp32 operand -- weight and activation -- carried EXACTLY as three bf16 pieces, a product =
+        #           six MFMAs on the bf16 matrix cores, fp32 accumulate: the arithmetic of the reference's fp32 nn.Linear
+        #           layers (model/decoder.py:32-50); passes the reference goldens at the fp32 kernels' own gates and sits
+        #           where they sit against fp64 truth, at 1.6x their speed
+        #   "f16x3" the fast mode: f16 matrix cores on hi/lo split operands (22-23 significant bits), three MFMAs per
+        #           product, fp32 accumulate: ~3e-7 relative (2-3x the fp32 error), 1.5x faster than "bf16x6" again
         #   "f32"   fp32-input matrix cores: exact fp32 products (the round-1 path)
         #   "f16"   plain f16 operands, forward-only (2e-3 of the output range): set by consumers that state a tolerance
-        self.decoder_precision = "f16x3"
+        self.decoder_precision = "bf16x6"
         # weight-gradient kernel (ops.decoder_bwd): "auto" = the streaming f16 hi/lo kernel behind the f16x3 chain
         # (fp32-class, read-bandwidth bound), the fp32 LDS kernel otherwise; "f32" / "stream_bf16x6" / ... force one.
         # (The ~5e-6 arithmetics "bf16x3" / "stream_bf16x3" pass every per-step tolerance, but the chaotic 51-iteration
@@ -243,8 +251,14 @@ class JointEncoding(nn.Module):
         # beside the persistent decoder forward, take 211 us instead of 70 and slow that kernel from 99 to 137 us -- the
         # step gets 40 us LONGER (0.88 -> 0.92 ms).  It pays only where the forward leaves CUs idle.
         self.route_ahead = False
+        # ray-data-parallel training (mipsfusion_amd/ray_dp.py sets it): the rays handed to forward() are ONE SHARE of the
+        # iteration's batch; the callable sums a small fp64 vector over the ranks, the losses (and their gradients) are then
+        # those of the WHOLE batch -- fs_weight / sdf_weight from the batch's counts (helper_functions/utils.py:43-47), the
+        # depth loss over the batch's valid rays (scene_rep.py:218), every mean over all N rays -- on every rank
+        self.ray_share_reduce = None
         self._frozen_pack = None
         self._tables = {}
+        self._jitter_ring = {}
         self.get_resolution()
         self.get_encoding(config)
         self.get_decoder(config)
@@ -296,6 +310,11 @@ class JointEncoding(nn.Module):
 
     def _query(self, x32):
         return _QueryFn.apply(x32, self, self.embed_fn.params, *self.decoder.ordered_parameters())
+
+    def __getstate__(self):
+        d = self.__dict__.copy()        # (pinned staging buffers and their events stay with this process)
+        d["_jitter_ring"], d["_frozen_pack"], d["ray_share_reduce"] = {}, None, None
+        return d
 
     def __deepcopy__(self, memo):
         # a copy must not advance the CPU RNG (the constructor's nn.Linear initialisation would): the reference's
@@ -379,7 +398,7 @@ class JointEncoding(nn.Module):
             if noise is None:
                 # the reference draws this on the CPU default generator (scene_rep.py:176); doing the same keeps
                 # the CPU RNG stream -- and therefore every later pixel-sampling call -- bit-identical
-                noise = torch.rand(N, S).to(rays_o)
+                noise = self._draw_jitter(N, S, rays_o.device)
             noise = ops._f32c(noise)
         else:
             noise = None
@@ -389,8 +408,32 @@ class JointEncoding(nn.Module):
         raw = self._query(xn)
         trgb = ops._f32c(target_rgb) if train else None
         res = _RenderFn.apply(raw, z_vals, trgb, td if train else None, counts if train else None, rc, N, S, train,
-                              self._objective_weights(raw.device) if train else None)
+                              self._objective_weights(raw.device) if train else None, self.ray_share_reduce if train else None)
         return res, z_vals, raw.reshape(N, S, 10)
+
+    def _draw_jitter(self, N, S, device):
+        """``torch.rand(N, S)`` of the default CPU generator, on the device.  The draw itself is made by the C replica of
+        torch's generator (mipsfusion_amd/hostrng.py: bit-identical, checked against torch.rand at start-up, torch's own
+        routine otherwise; 0.12 ms instead of 0.5-1.6 ms for 262 144 values) straight into one of four pinned buffers and goes
+        up as an asynchronous copy -- the caller's thread does not wait for a pageable-memory staging copy."""
+        from .. import hostrng
+        key = (N, S, str(device))
+        ring = self._jitter_ring.get(key)
+        if ring is None:
+            ring = self._jitter_ring[key] = {"bufs": [torch.empty(N, S, dtype=torch.float32).pin_memory() for _ in range(4)],
+                                             "events": [None] * 4, "i": 0}
+        i = ring["i"]
+        ring["i"] = (i + 1) % 4
+        if ring["events"][i] is not None:
+            ring["events"][i].synchronize()          # the upload that last read this buffer (four draws ago) is done
+        buf = ring["bufs"][i]
+        with hostrng.session() as sess:
+            sess.rand_(buf)
+        out = buf.to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        ring["events"][i] = ev
+        return out
 
     def frozen_weights(self, begin: bool):
         """``frozen_weights(True)`` ... ``frozen_weights(False)`` brackets a stretch in which the decoder's weights do not
@@ -434,7 +477,8 @@ class JointEncoding(nn.Module):
                                                                    ops._f32c(noise) if rc.perturb else None, tables, rc, S,
                                                                    accumulate_in_place)
         raw = self._query(xn)
-        res = _RenderFn.apply(raw, z_vals, trgb, td, counts, rc, N, S, True, self._objective_weights(raw.device))
+        res = _RenderFn.apply(raw, z_vals, trgb, td, counts, rc, N, S, True, self._objective_weights(raw.device),
+                              self.ray_share_reduce)
         rgb, depth, losses = res[0], res[1], res[5]
         ret = {"rgb": rgb, "depth": depth, "rgb_loss": losses[0], "depth_loss": losses[1], "sdf_loss": losses[2],
                "fs_loss": losses[3], "psnr": losses[4:5].detach(), "_loss_vec": losses}

@@ -376,9 +376,10 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
     if getattr(saved, "mipsf_masks_only", False) and grads is not None:
         raise RuntimeError("this activation record holds the ReLU masks only (decoder_fwd(save='masks')): no weight gradients")
     if getattr(saved, "mipsf_lean_record", False) and grads is not None:
-        if wgrad_precision != "stream_f16x3" or packed16 is None:
-            raise RuntimeError("this activation record was saved lean (no H1): the weight gradients need "
-                               "wgrad_precision='stream_f16x3' with packed16 (H1 is recomputed from x)")
+        if wgrad_precision not in ("stream_f16x3", "stream_bf16x6") or packed16 is None or wgrad_precision != "stream_" + precision:
+            raise RuntimeError("this activation record was saved lean (no H1): the weight gradients need the streaming kernel "
+                               "of the forward's arithmetic (wgrad_precision='stream_f16x3' / 'stream_bf16x6') with packed16 "
+                               "(H1 is recomputed from x)")
         recompute_h1 = True
     dev = x.device
     dfeat = torch.empty_like(feat)
@@ -396,8 +397,8 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
         hdr_clear = 4 if precision == "bf16x6" else 0        # MIPSF_CHAIN_BF16X6
         # the lean gradient record (half of `dact`): when the exchange form of the streaming f16 kernel follows, which
         # recomputes dG3 and the rgb_emb half of dH2 from the small rows + the ReLU masks (csrc/wgrad16.hip)
-        lean_dact = bool(LEAN_DACT and grads is not None and wgrad_precision == "stream_f16x3" and recompute_h1
-                         and packed16 is not None and precision == "f16x3")
+        lean_dact = bool(LEAN_DACT and grads is not None and wgrad_precision == "stream_" + precision and recompute_h1
+                         and packed16 is not None)
         if SKIP_ZERO_TILES and (grads is None or wgrad_precision.startswith("stream_")):
             global _LAST_TILE_LIVE
             pre = getattr(saved, "mipsf_tile_live", None)
@@ -424,8 +425,10 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
             if embed_pos is not None:
                 raise RuntimeError("the streaming weight-gradient kernel computes the positional encoding in-kernel")
             arith = _lib.PREC[wgrad_precision[len("stream_"):]]
-            if recompute_h1 and (arith != _lib.PREC["f16x3"] or packed16 is None):
-                raise RuntimeError("recompute_h1 needs wgrad_precision 'stream_f16x3' and packed16")
+            if recompute_h1 and (wgrad_precision not in ("stream_f16x3", "stream_bf16x6") or packed16 is None):
+                raise RuntimeError("recompute_h1 needs wgrad_precision 'stream_f16x3' / 'stream_bf16x6' and packed16")
+            if recompute_h1:
+                _check_family(packed16, wgrad_precision[len("stream_"):])
             with _timed("decoder_wgrad"):
                 check(lib().mipsf_decoder_wgrad16_tiles_ex(dptr(packed16) if recompute_h1 else None, dptr(feat), layout,
                                                            dptr(x), dptr(saved), dptr(dact),
@@ -532,17 +535,38 @@ def sample_rays(rays_o, rays_d, target_d, noise, tables, rc, N, S):
     return z_vals, xn, counts
 
 
-def render_fwd(raw, z_vals, target_rgb, target_d, counts, rc, N, S, train: bool, want_weights=False, loss_weights=None):
+def render_fwd(raw, z_vals, target_rgb, target_d, counts, rc, N, S, train: bool, want_weights=False, loss_weights=None,
+               share_of=None):
     """loss_weights (train only): device tensor of the 4 loss weights -> an 8th return value, the objective
-    sum_k w_k * losses[k] formed inside the loss kernel (one float)."""
+    sum_k w_k * losses[k] formed inside the loss kernel (one float).
+    share_of (train only): ``reduce(t)`` -- these N rays are ONE SHARE of a ray-data-parallel batch; ``reduce`` receives the
+    share's ten fp64 numbers (the nine loss sums + its ray count) and must return their sums over all shares (an all-reduce
+    of 80 bytes); the losses are those of the WHOLE batch, identical on every rank, and a 9th value is returned: the whole
+    batch's ray count (for render_bwd's n_norm)."""
     dev = raw.device
     f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)   # noqa: E731
     rgb, depth, var, disp, acc = f(N, 3), f(N), f(N), f(N), f(N)
     weights = f(N, S) if want_weights else None
     losses = f(8) if train else None
-    partial = f(N * 8) if train else None
+    partial = f(int(lib().mipsf_render_partial_floats(N))) if train else None
     total = f(1) if (train and loss_weights is not None) else None
     ticket = _zeroed_words(dev, 1, "render_fwd") if train else None    # the last workgroup finishes the losses: one launch
+    if train and share_of is not None:
+        sums = torch.zeros(10, dtype=torch.float64, device=dev)
+        with _timed("render_fwd"):
+            check(lib().mipsf_render_fwd_sums(dptr(raw), dptr(z_vals), dptr(target_rgb), dptr(target_d),
+                                              dptr(counts, torch.int32), C.byref(rc), dptr(rgb), dptr(depth), dptr(var),
+                                              dptr(disp), dptr(acc), dptr(weights), dptr(partial), dptr(sums, torch.float64),
+                                              dptr(ticket, torch.int32), N, S, stream_ptr()), "render_fwd_sums")
+        sums[9] = float(N)
+        sums = share_of(sums)
+        n_total = int(round(float(sums[9])))            # (one small read-back per step: the collective synchronises anyway)
+        check(lib().mipsf_loss_finalize_sums(dptr(sums, torch.float64), C.byref(rc), n_total, S, dptr(losses),
+                                             dptr(loss_weights) if total is not None else None, dptr(total), stream_ptr()),
+              "loss_finalize_sums")
+        if loss_weights is not None:
+            return rgb, depth, var, disp, acc, weights, losses, total, n_total
+        return rgb, depth, var, disp, acc, weights, losses, None, n_total
     with _timed("render_fwd"):
         check(lib().mipsf_render_fwd_ex2(dptr(raw), dptr(z_vals), dptr(target_rgb), dptr(target_d),
                                          dptr(counts, torch.int32) if counts is not None else None, C.byref(rc), dptr(rgb),
@@ -555,15 +579,16 @@ def render_fwd(raw, z_vals, target_rgb, target_d, counts, rc, N, S, train: bool,
 
 
 def render_bwd(raw, z_vals, target_rgb, target_d, counts, losses, rc, g_losses, g_rgb, g_depth, N, S, g_total=None,
-               loss_weights=None):
-    """g_total / loss_weights: gradient of render_fwd's objective and its weights (the kernel forms g_total * w itself)."""
+               loss_weights=None, n_norm=None):
+    """g_total / loss_weights: gradient of render_fwd's objective and its weights (the kernel forms g_total * w itself).
+    n_norm: the ray count the losses were normalised by when these N rays are a share of a larger batch (render_fwd(share_of=))."""
     draw = torch.empty_like(raw)
     with _timed("render_bwd"):
-        check(lib().mipsf_render_bwd_ex(dptr(raw), dptr(z_vals), dptr(target_rgb), dptr(target_d),
-                                        dptr(counts, torch.int32) if counts is not None else None, dptr(losses),
-                                        C.byref(rc), dptr(g_losses), dptr(g_total),
-                                        dptr(loss_weights) if g_total is not None else None, dptr(g_rgb), dptr(g_depth),
-                                        dptr(draw), N, S, stream_ptr()), "render_bwd")
+        check(lib().mipsf_render_bwd_ex2(dptr(raw), dptr(z_vals), dptr(target_rgb), dptr(target_d),
+                                         dptr(counts, torch.int32) if counts is not None else None, dptr(losses),
+                                         C.byref(rc), dptr(g_losses), dptr(g_total),
+                                         dptr(loss_weights) if g_total is not None else None, dptr(g_rgb), dptr(g_depth),
+                                         dptr(draw), N, N if n_norm is None else int(n_norm), S, stream_ptr()), "render_bwd")
     return draw
 
 

@@ -8,9 +8,14 @@ gradients are dense (the hash table's 36 MB, the decoder's 146 KB, the pose para
     decoder   all-reduce of its ten small gradients, the identical (replicated) Adam step on every rank
     poses     all-reduce of the pose gradients, identical step on every rank
 
--- the bytes of one all-reduce, with the optimiser's work and state divided by the world size.  The objective is the MEAN
-of the ranks' objectives (each rank normalises its losses by its own N/world rays and its own front / band counts, as
-``pose_accum_step``-style gradient accumulation over sub-batches does in the reference, mipsfusion.py:327-342).
+-- the bytes of one all-reduce, with the optimiser's work and state divided by the world size.  The objective is the ONE
+objective of the whole batch, the step the step of mipsfusion.py:325-335 on the same rays: the loss kernel of every rank
+leaves the nine sums its losses are made of (squared errors, front / band / valid-depth counts), one 80-byte all-reduce adds
+them (``JointEncoding.ray_share_reduce``), every rank finishes the SAME losses from the batch's sums -- fs_weight / sdf_weight
+from the batch's counts (helper_functions/utils.py:43-47), depth_loss over the batch's valid rays (scene_rep.py:218), means
+over all N rays -- and differentiates them with respect to its own rays; the ranks' gradients are then SUMMED.  Equal to the
+single-process step up to the order of fp32 additions (tests/test_dist_cpu.py on the oracle's modules, the two-process GPU
+test on the real JointEncoding).
 
 xGMI is point-to-point: with 8 GPUs a direct schedule moves 7 x 4.5 MB per phase per GPU (~30 us per phase at 153 GB/s per
 link), a ring would be per-link bound at ~0.4 ms -- against ~0.1 ms of per-rank compute for 512 rays x 64 samples.  At the
@@ -36,7 +41,7 @@ class ShardedFlatAdam:
     param: the replicated flat parameter (a leaf with ``.grad`` accumulated by the caller's backward passes).
     make_optimizer(shard_param) -> an optimiser with ``step()`` over the 1-D slice parameter it is given (FusedAdam on the
     GPU: the slice is a VIEW of ``param``'s storage, so the kernel updates the replica in place; torch.optim.Adam in the CPU
-    test).  Gradients arrive as the SUM over ranks divided by world (mean objective)."""
+    test).  Gradients arrive as the SUM over ranks (every rank differentiated the whole batch's objective over its rays)."""
 
     def __init__(self, param: torch.Tensor, make_optimizer: Callable[[torch.nn.Parameter], torch.optim.Optimizer], group=None):
         self.group = group
@@ -54,6 +59,7 @@ class ShardedFlatAdam:
         else:       # padded copy: parameters are exchanged through it (one extra copy per step; the table sizes of the
             self._buf = torch.zeros(self.n_pad, dtype=flat.dtype, device=flat.device)      # reference's configs divide by 8)
             self._buf[:n].copy_(flat)
+        self._flat = flat
         self.shard = torch.nn.Parameter(self._buf[self.begin:self.begin + self.per])
         self.shard.grad = torch.zeros_like(self.shard)
         self._grad_pad = None if self.n_pad == n else torch.zeros(self.n_pad, dtype=flat.dtype, device=flat.device)
@@ -67,6 +73,9 @@ class ShardedFlatAdam:
         """Consumes ``param.grad`` (sum of this rank's backward passes since the last step), leaves it zero."""
         g = self.param.grad.view(-1)
         if self._grad_pad is not None:
+            # (padded table: parameters travel through a private copy -- re-read the replica first, it may have been
+            # reloaded since the last step: recover_initial_param / load_state_dict)
+            self._buf[:self.n].copy_(self.param.data.view(-1))
             self._grad_pad[:self.n].copy_(g)
             g_full = self._grad_pad
         else:
@@ -81,8 +90,6 @@ class ShardedFlatAdam:
             out.copy_(h[self.begin:self.begin + self.per])
         else:
             dist.reduce_scatter_tensor(out, g_full, op=dist.ReduceOp.SUM, group=self.group)
-        if self.world > 1:
-            out.mul_(1.0 / self.world)
         self.opt.step()
         g.zero_()
         if self.world > 1:
@@ -106,9 +113,11 @@ class RayDataParallelStep:
             loss = objective(model.forward(*rays)); loss.backward()
             rdp.step(pose=(it + 1) % pose_accum_step == 0)
 
-    ``step`` averages the gradients over the ranks (grid: reduce-scatter into this rank's slice; decoder and poses:
+    The constructor sets ``model.ray_share_reduce``: the model's training forward then returns the losses of the WHOLE batch
+    (one 80-byte all-reduce inside forward), so ``loss.backward()`` leaves every rank with its rays' part of the batch's
+    gradient.  ``step`` SUMS the gradients over the ranks (grid: reduce-scatter into this rank's slice; decoder and poses:
     all-reduce), runs the optimisers, and hands every rank the updated table (all-gather).  All ranks end every step with
-    bit-identical parameters (asserted in the tests)."""
+    bit-identical parameters, equal to the single-process step on the same rays up to fp32 addition order."""
 
     def __init__(self, model, make_grid_opt, make_decoder_opt, pose_params: Sequence[torch.nn.Parameter] = (),
                  make_pose_opt: Optional[Callable[[List[torch.nn.Parameter]], torch.optim.Optimizer]] = None, group=None):
@@ -121,12 +130,20 @@ class RayDataParallelStep:
         self.pose_params = list(pose_params)
         self.pose_opt = make_pose_opt(self.pose_params) if (self.pose_params and make_pose_opt) else None
         self._dec_flat = None
+        if hasattr(model, "ray_share_reduce"):
+            model.ray_share_reduce = self.reduce_share
+
+    def reduce_share(self, t: torch.Tensor) -> torch.Tensor:
+        """sum of a small fp64 vector over the ranks (the nine loss sums + the ray count of every share)"""
+        if self.world > 1:
+            all_reduce_sum_(t, self.group)
+        return t
 
     def my_share(self, n: int):
         return share_of(n, self.rank, self.world)
 
     @torch.no_grad()
-    def _mean_grads(self, params):
+    def _sum_grads(self, params):
         """one all-reduce for a list of small gradients (flattened into one buffer: a collective per tensor would be ten
         latency-bound calls)"""
         if self.world == 1:
@@ -136,7 +153,6 @@ class RayDataParallelStep:
             return
         flat = torch.cat([g.reshape(-1) for g in grads])
         all_reduce_sum_(flat, self.group)
-        flat.mul_(1.0 / self.world)
         off = 0
         for g in grads:
             g.copy_(flat[off:off + g.numel()].view_as(g))
@@ -147,10 +163,10 @@ class RayDataParallelStep:
         if self.model.embed_fn.params.grad is None:
             raise RuntimeError("RayDataParallelStep.step() needs a backward pass first (the table has no gradient)")
         self.grid.step()
-        self._mean_grads(self.dec_params)
+        self._sum_grads(self.dec_params)
         self.dec_opt.step()
         torch._foreach_zero_([p.grad for p in self.dec_params if p.grad is not None])
         if pose and self.pose_opt is not None:
-            self._mean_grads(self.pose_params)
+            self._sum_grads(self.pose_params)
             self.pose_opt.step()
             torch._foreach_zero_([p.grad for p in self.pose_params if p.grad is not None])

@@ -442,12 +442,15 @@ class GraphedSequence:
     INIT_INNER = 25          # iterations per replay of the sub-map initialisation graph (500 = 20 replays)
 
     def __init__(self, cfg, dev, frames, kf_every=15, sampler="reference", first_iters=None, stream=None,
-                 lookahead=None, graph_ro=True, gate_producer=True, ro_precision="f16", schedule=None):
+                 lookahead=None, graph_ro=True, gate_producer=True, ro_precision=None, schedule=None, decoder_precision=None):
         """lookahead: how many frames the sample producer runs ahead of the GPU (default: ``map_every``, one whole
         mapping period -- a BA round needs ~40 ms of serial generator work, a frame without BA ~4 ms, so the work only
         evens out over a period; the reference's own DataLoader prefetches 8 frames, mipsfusion.py:672).
         first_iters: initialisation iterations of a sub-map (default: mapping.first_iters, 500 in the reference's configs).
-        schedule: {frame: ("new",) | ("back", submap)} at keyframe frames (see the class docstring)."""
+        schedule: {frame: ("new",) | ("back", submap)} at keyframe frames (see the class docstring).
+        decoder_precision: arithmetic of the model's decoder (default: JointEncoding's own default, "bf16x6" = the reference's
+        fp32 arithmetic; "f16x3" = the fast mode).  ro_precision: arithmetic of the RandomOptimizer rounds (default: the
+        model's; "f16" = the opt-in plain-f16 rounds of BASELINE config 5, pose within 1e-3 of the reference's)."""
         from .RandomOptimizer import RandomOptimizer
         from .graph import GraphedSteps, work_stream
         from .model import JointEncoding
@@ -469,16 +472,24 @@ class GraphedSequence:
         bb = torch.from_numpy(np.array(mp["bound"]))
         nf = torch.from_numpy(np.array(mp["localMLP_max_len"]))
         self.model = JointEncoding(cfg, bb, nf).to(dev).train()
+        if decoder_precision is not None:
+            self.model.decoder_precision = decoder_precision
         self.model.accumulate_param_grads_in_place = True
+        # the captured loops run ONE backward per map step and the optimiser kernel clears the gradients (map_accum_step 1,
+        # map_wait_step 0: what every shipped configuration of the reference uses, mipsfusion.py:330-335); gradient
+        # accumulation over several backward passes is not recorded by these graphs -- refuse instead of training wrongly
+        if mp.get("map_accum_step", 1) != 1 or mp.get("map_wait_step", 0) != 0:
+            raise ValueError("GraphedSequence records one backward pass per map step: mapping.map_accum_step must be 1 and "
+                             "mapping.map_wait_step 0 (use the eager loop for accumulated map gradients)")
         self.model.grid_grad_is_zero_at_backward = True    # every map step is one backward + map_opt.step(zero_grad=True)
         # recover_initial_param() at a switch is a device-to-device copy (the reference's initial_dict sits where the model was built)
         self.model.initial_dict = {k: v.to(dev) for k, v in self.model.initial_dict.items()}
         self.host_rays = [frame_rays(f).pin_memory() for f in frames]        # what a capture thread hands over
         ds = types.SimpleNamespace(H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy, rays_d=frames[0]["direction"])
         self.ro = RandomOptimizer(cfg, types.SimpleNamespace(dataset=ds, device=dev))
-        # explicit opt-in to the plain-f16 decoder for the particle rounds (BASELINE config 5 "fp16 decoder"; tolerance: the
-        # tracked pose stays within 1e-3 of the reference's, test_random_optimizer_f16_rounds_track_the_reference_pose)
-        self.ro.decoder_precision = ro_precision
+        # particle rounds: the model's arithmetic unless the caller opts in to a faster one ("f16": BASELINE config 5 "fp16
+        # decoder"; the tracked pose stays within 1e-3 of the reference's, test_random_optimizer_f16_rounds_track_the_reference_pose)
+        self.ro.decoder_precision = self.model.decoder_precision if ro_precision is None else ro_precision
         kr, kc = sh.sample_pixels_uniformly(H, W, 100, 300 if W >= 300 else W // 2)  # 30 000 rays per keyframe
         self.kf_rows, self.kf_cols = kr.to(dev), kc.to(dev)
         self.R = kr.shape[0]
@@ -1068,7 +1079,10 @@ def summarise(res, gt_poses, cfg, launch):
     fm = np.array(res["frame_ms"])
     err = [float((res["est"][k][:3, 3].cpu().float() - gt_poses[k][:3, 3].float()).norm()) for k in range(len(res["est"]))]
     ba = [t for t in res["ba_ms"] if t > 0]
-    out = {"frames": len(res["est"]), "ms_per_frame_mean": round(float(fm.mean()), 3),
+    out = {"frames": len(res["est"]), "frames_timed": len(fm),
+           "frames_timed_note": "frame 0 (its mapping.first_iters initialisation iterations, graph captures) is set-up and not "
+                                "among the timed frames; every later frame counts",
+           "ms_per_frame_mean": round(float(fm.mean()), 3),
            "ms_per_frame_median": round(float(np.median(fm)), 3), "ms_per_frame_p95": round(float(np.percentile(fm, 95)), 3),
            "ro_ms_mean": round(float(np.mean(res["ro_ms"])), 3), "go_ms_mean": round(float(np.mean(res["go_ms"])), 3),
            "ba_ms_per_round_median": round(float(np.median(ba)), 3) if ba else None,

@@ -174,7 +174,10 @@ def test_sharded_global_ba_world2_equals_single_process_and_oracle():
 
 # ------------------------------------------------------------------------ ray-data-parallel training
 class _ToyScene(torch.nn.Module):
-    """the two parameter families of a sub-map: one flat table (embed_fn.params) and a few small decoder tensors"""
+    """the two parameter families of a sub-map -- one flat table (embed_fn.params) and a few small decoder tensors -- under an
+    objective built like the reference's (helper_functions/utils.py:43-47, scene_rep.py:218): per-ray squared errors summed
+    over the BATCH, one term weighted by 1 - n_front / n_rays with an integer count over the batch, one term averaged over the
+    batch's `valid` rays only.  ``ray_share_reduce`` (set by RayDataParallelStep) sums the share's numbers over the ranks."""
 
     def __init__(self, n_table):
         super().__init__()
@@ -185,10 +188,18 @@ class _ToyScene(torch.nn.Module):
         with torch.no_grad():
             for p in self.decoder.parameters():
                 p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+        self.ray_share_reduce = None
 
-    def objective(self, x):          # x [n, 3]: a per-ray loss, MEAN over the rays given
-        feat = self.embed_fn.params[(x[:, 0].abs() * 1000).long() % self.embed_fn.params.numel()]
-        return ((self.decoder(x) * feat[:, None]).pow(2).sum(-1) + feat.pow(2)).mean()
+    def objective(self, x, x_raw):          # x [n, 3] (posed), x_raw: the rays as drawn (masks are decided on the data)
+        feat = self.embed_fn.params[(x_raw[:, 0].abs() * 1000).long() % self.embed_fn.params.numel()]
+        per_ray = (self.decoder(x) * feat[:, None]).pow(2).sum(-1) + feat.pow(2)
+        front, valid = x_raw[:, 1] > 0, x_raw[:, 2] > -0.5
+        s_front, s_valid = (per_ray * front).sum(), (per_ray.sqrt() * valid).sum()
+        counts = torch.tensor([float(front.sum()), float(valid.sum()), float(x.shape[0])], dtype=torch.float64)
+        if self.ray_share_reduce is not None:
+            counts = self.ray_share_reduce(counts)          # the batch's counts; the sums stay this share's (their
+        n_front, n_valid, n = (float(c) for c in counts)    # gradients are added over the ranks by step())
+        return s_front * ((1.0 - n_front / n) / n) + s_valid / n_valid
 
 
 def _toy_optimisers():
@@ -208,11 +219,15 @@ def _ray_dp_worker(rank, world, port, q, n_table):
         pose = torch.nn.Parameter(torch.tensor([0.1, -0.2, 0.3]))
         g_opt, d_opt, p_opt = _toy_optimisers()
         rdp = RayDataParallelStep(m, g_opt, d_opt, [pose], p_opt)
+        assert m.ray_share_reduce is not None
         gen = torch.Generator().manual_seed(9)
         for it in range(4):
-            x = torch.randn(10, 3, generator=gen)                 # the SAME batch on every rank ...
-            b, e = rdp.my_share(10)                               # ... of which each renders its share
-            (m.objective(x[b:e] + pose)).backward()
+            x = torch.randn(11, 3, generator=gen)                 # the SAME batch on every rank ...
+            b, e = rdp.my_share(11)                               # ... of which each renders its (ragged) share
+            (m.objective(x[b:e] + pose, x[b:e])).backward()
+            if it == 2:                                           # the replica is reloaded between steps (recover_initial_param)
+                with torch.no_grad():
+                    m.embed_fn.params.mul_(0.5)
             rdp.step(pose=(it + 1) % 2 == 0)
         q.put((rank, m.embed_fn.params.detach().numpy().copy(), [p.detach().numpy().copy() for p in m.decoder.parameters()],
                pose.detach().numpy().copy()))
@@ -221,9 +236,11 @@ def _ray_dp_worker(rank, world, port, q, n_table):
 
 
 @pytest.mark.parametrize("n_table", [12, 11])
-def test_ray_data_parallel_step_world2_equals_mean_gradient_adam(n_table):
-    """reduce-scatter -> sharded Adam -> all-gather over two gloo ranks: both ranks end with bit-identical parameters, equal
-    to ONE process that averages the two shares' gradients and runs the plain optimisers (n_table 11: the padded path)."""
+def test_ray_data_parallel_step_world2_equals_the_single_process_step(n_table):
+    """RayDataParallelStep over two gloo ranks (reduce-scatter -> sharded Adam -> all-gather; the batch's counts summed inside
+    the forward, the shares' gradients SUMMED): both ranks end with bit-identical parameters, equal to ONE process that runs
+    the same objective on the WHOLE batch and the plain optimisers -- the step mipsfusion.py:325-335 takes (n_table 11: the
+    padded path, whose private copy must follow a reload of the replica)."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -236,7 +253,6 @@ def test_ray_data_parallel_step_world2_equals_mean_gradient_adam(n_table):
         assert p.exitcode == 0
     (_, t0, d0, p0), (_, t1, d1, p1) = res
     assert (t0 == t1).all() and all((a == b).all() for a, b in zip(d0, d1)) and (p0 == p1).all(), "ranks diverged"
-    # one process, table and decoder only (the pose of the single-process run accumulates differently by construction)
     torch.manual_seed(0)
     m = _ToyScene(n_table)
     pose = torch.nn.Parameter(torch.tensor([0.1, -0.2, 0.3]))
@@ -244,20 +260,16 @@ def test_ray_data_parallel_step_world2_equals_mean_gradient_adam(n_table):
     og, od, op_ = g_opt(m.embed_fn.params), d_opt(list(m.decoder.parameters())), p_opt([pose])
     gen = torch.Generator().manual_seed(9)
     for it in range(4):
-        x = torch.randn(10, 3, generator=gen)
-        params = [m.embed_fn.params] + list(m.decoder.parameters()) + [pose]
-        total = None
-        for r in range(world):
-            b, e = mdist.share_of(10, r, world)
-            gs = torch.autograd.grad(m.objective(x[b:e] + pose), params)
-            total = list(gs) if total is None else [a + g for a, g in zip(total, gs)]
-        for p, g in zip(params[:-1], total[:-1]):
-            p.grad = g * (1.0 / world)
-        pose.grad = total[-1] * (1.0 / world) if pose.grad is None else pose.grad + total[-1] * (1.0 / world)
+        x = torch.randn(11, 3, generator=gen)
+        m.objective(x + pose, x).backward()                       # the whole batch, one process
+        if it == 2:
+            with torch.no_grad():
+                m.embed_fn.params.mul_(0.5)
         og.step(), od.step()
+        og.zero_grad(), od.zero_grad()
         if (it + 1) % 2 == 0:
             op_.step()
-            pose.grad = None
+            op_.zero_grad()
     import numpy as np
     np.testing.assert_allclose(t0, m.embed_fn.params.detach().numpy(), rtol=0, atol=1e-7)
     for a, b in zip(d0, m.decoder.parameters()):

@@ -250,7 +250,7 @@ def test_config5_scannet_random_optimizer_slice_vs_oracle(dev):
     m.eval()
     f = synth.make_frame(cfg, seed=6)
     ro = _scannet_ro(cfg, dev, f)
-    assert ro.decoder_precision == "f16x3"         # the default: parity arithmetic; the opt-in plain f16 is checked at the end
+    assert ro.decoder_precision == "bf16x6"        # the default: the reference's fp32 arithmetic; the opt-in plain f16 is checked at the end
     init = f["c2w"].clone()
     init[:3, 3] += torch.tensor([0.02, -0.015, 0.01])
     P, n = ro.particle_size, ro.row_indices.shape[0]
@@ -261,7 +261,7 @@ def test_config5_scannet_random_optimizer_slice_vs_oracle(dev):
     td = f["depth"][ro.row_indices, ro.col_indices].to(dev).contiguous()
     with torch.no_grad():
         mm = ro._enqueue_round(m, state.clone(), td, ro._dirs[0], m._rc(1, 0),
-                               ops.decoder_pack16(m.decoder.ordered_parameters()))
+                               ops.decoder_pack16(m.decoder.ordered_parameters(), precision=ro.decoder_precision))
         pst7 = ro_cpu.pose_6d_to_7d(ro.pre_sampled_particle.cpu() * 0.02)
         cam = f["direction"][ro.row_indices, ro.col_indices, :] * td.cpu()[:, None]
         world, _, _ = ro_cpu.particle_points(init[:3, :3], init[:3, 3:], pst7, cam)
@@ -281,7 +281,7 @@ def test_config5_scannet_random_optimizer_slice_vs_oracle(dev):
     ro.decoder_precision = "f16"
     with torch.no_grad():
         mm16 = ro._enqueue_round(m, state.clone(), td, ro._dirs[0], m._rc(1, 0),
-                                 ops.decoder_pack16(m.decoder.ordered_parameters()))
+                                 ops.decoder_pack16(m.decoder.ordered_parameters(), precision=ro.decoder_precision))
     pose16 = ro.optimize(m, f["depth"], init, None, n_iter=3)
     e_fit = float((mm16.cpu() - mm_ref).abs().max() / mm_ref.abs().max())
     e_pose = float((pose16.cpu() - ref_pose).abs().max())
@@ -337,23 +337,239 @@ def test_config4_global_ba_single_rank_vs_oracle(dev):
     assert err < 2e-5 + 1e-2 * moved
 
 
-def test_two_process_run_exercises_every_sharding(dev):
-    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), here with both
-    ranks on this one GPU and the gloo backend (RCCL needs one GPU per rank): sub-map-per-rank mapping steps + pose
-    all_gather, the RandomOptimizer particle split and the global-BA pose-gradient all-reduce (bench.multi_gpu_checks)."""
-    import json
+# ------------------------------------------------------------------------ the reference's process topology: two processes, one GPU
+def test_mapping_and_tracking_beside_a_second_process_on_the_same_gpu(dev):
+    """The reference runs TWO processes on one GPU: the active map's tracking + mapping and the InactiveMap process's local BA
+    (mipsfusion.py:661-667, shared modules :107-124, InactiveMap.py:203-308).  Here process B (tools/ba_load.py) runs mapping
+    steps back to back on this device while THIS process takes (a) the complete config-2 mapping iteration and (b) the config-5
+    tracking iteration against the oracle at their normal gates, and (c) repeats a pose-only tracking iteration and a
+    RandomOptimizer frame 200 times each: everything on that path is deterministic (no float atomics: fixed-order reductions,
+    fp64 LDS accumulation rounded once), so every repetition must reproduce the first BIT FOR BIT -- a wavefront disturbed by
+    the neighbour process would show here (round 3 saw lanes 48..63 of a few wavefronts hold another pose under
+    exactly this sharing on one box; not reproduced since, this test keeps watching)."""
     import os
-    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    other = subprocess.Popen([sys.executable, os.path.join(root, "tools", "ba_load.py"), "--seconds", "240"], cwd=root, env=env,
+                             stdout=subprocess.PIPE, text=True)
+    try:
+        line = other.stdout.readline()
+        assert line.strip() == "READY", f"the second process did not start: {line!r}"
+        test_config2_full_iteration_vs_oracle(dev)                       # (a)
+        test_config5_scannet_tracking_iteration_vs_oracle(dev)           # (b)
+        # (c) run-to-run identity under sharing
+        cfg = synth.config_headline()
+        m, _ = build(cfg, dev, seed=9)
+        m.train()
+        for p in m.parameters():
+            p.requires_grad_(False)                                      # tracking: the map is frozen (mipsfusion.py:226-230)
+        f = synth.make_frame(cfg, seed=9)
+        H, W = f["depth"].shape
+        g = torch.Generator().manual_seed(3)
+        idx = torch.randperm(H * W, generator=g)[:cfg["tracking"]["sample"]]
+        r, c = torch.div(idx, W, rounding_mode="floor"), torch.remainder(idx, W)
+        d_cam, rgb, d = f["direction"][r, c].to(dev), f["rgb"][r, c].contiguous().to(dev), f["depth"][r, c][:, None].contiguous().to(dev)
+        noise = torch.rand(idx.numel(), 64, generator=g).to(dev)
+        q0, t0 = matrix_to_quaternion(f["c2w"][None, :3, :3]).to(dev), f["c2w"][None, :3, 3].clone().to(dev)
+        owner = torch.zeros(idx.numel(), dtype=torch.int64, device=dev)
+
+        def tracking_iteration():
+            rot, trans = torch.nn.Parameter(q0.clone()), torch.nn.Parameter(t0.clone())
+            ro, rd = ops.pose_rays(rot, trans, None, owner, d_cam)
+            ret = m.forward(ro, rd, rgb, d, EMD_w=0.0, noise=noise)
+            path_cpu.total_loss(ret, cfg["training"]).backward()
+            return torch.cat([rot.grad.reshape(-1), trans.grad.reshape(-1), ret["depth"].detach().reshape(-1)])
+        first = tracking_iteration()
+        n_diff = sum(0 if torch.equal(tracking_iteration(), first) else 1 for _ in range(200))
+        print(f"\n  beside a second process: {n_diff} of 200 tracking iterations differ from the first")
+        assert n_diff == 0
+        from mipsfusion_amd.RandomOptimizer import RandomOptimizer
+        cfg["tracking"]["RO"].update(initial_scaling_factor=0.02, rescaling_factor=0.5)
+        cfg["tracking"]["ignore_edge_W"] = cfg["tracking"]["ignore_edge_H"] = 20
+        Hc, Wc, fx, fy, cx, cy = synth.intrinsics_after_crop(cfg)
+        ds = types.SimpleNamespace(H=Hc, W=Wc, fx=fx, fy=fy, cx=cx, cy=cy, rays_d=f["direction"])
+        np.random.seed(5)
+        ro_ = RandomOptimizer(cfg, types.SimpleNamespace(dataset=ds, device=dev))
+        m.eval()
+        init = f["c2w"].clone()
+        init[:3, 3] += torch.tensor([0.02, -0.015, 0.01])
+        p_first = ro_.optimize(m, f["depth"], init, None, n_iter=5).clone()
+        n_diff = sum(0 if torch.equal(ro_.optimize(m, f["depth"], init, None, n_iter=5), p_first) else 1 for _ in range(200))
+        print(f"  beside a second process: {n_diff} of 200 RandomOptimizer frames (5 rounds each) differ from the first")
+        assert n_diff == 0
+        assert other.poll() is None, "the second process ended before the checks did"
+    finally:
+        other.terminate()
+        try:
+            other.wait(30)
+        except subprocess.TimeoutExpired:
+            other.kill()
+
+
+# ------------------------------------------------------------------------ ray-data-parallel training == the single-process step
+RDP_STEPS, RDP_N, RDP_S = 5, 4096, 64
+
+
+def _rdp_batches(cfg):
+    """five batches of 4096 rays of one synthetic frame + their jitter: the same on every rank, in the oracle and in the parent"""
+    f = synth.make_frame(cfg, seed=11)
+    H, W = f["depth"].shape
+    g = torch.Generator().manual_seed(123)
+    out = []
+    for _ in range(RDP_STEPS):
+        idx = torch.randperm(H * W, generator=g)[:RDP_N]
+        ro, rd, rgb, d = synth.ray_batch(f, idx, f["c2w"])
+        out.append((ro, rd, rgb, d, torch.rand(RDP_N, RDP_S, generator=g)))
+    return out
+
+
+def _rdp_gpu_worker(rank, world, port, out_dir):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)        # (both ranks sit on the one GPU of the box)
+    try:
+        from mipsfusion_amd.ray_dp import RayDataParallelStep
+        dev = torch.device("cuda:0")
+        cfg = synth.config_headline()
+        m, _ = build(cfg, dev, seed=21)
+        m.train()
+        mp_ = cfg["mapping"]
+        rdp = RayDataParallelStep(
+            m, lambda shard: FusedAdam([{"params": [shard], "eps": 1e-15, "lr": mp_["lr_embed"]}], betas=(0.9, 0.99)),
+            lambda ps: FusedAdam([{"params": ps, "weight_decay": 1e-6, "lr": mp_["lr_decoder"]}], betas=(0.9, 0.99)))
+        b, e = rdp.my_share(RDP_N)
+        losses, first_grads = [], None
+        for ro, rd, rgb, d, noise in _rdp_batches(cfg):
+            ret = m.forward(ro[b:e].to(dev), rd[b:e].to(dev), rgb[b:e].contiguous().to(dev), d[b:e].contiguous().to(dev),
+                            EMD_w=0.01, noise=noise[b:e].to(dev))
+            loss = path_cpu.total_loss(ret, cfg["training"])
+            loss.backward()
+            if first_grads is None:         # this rank's part of the first step's gradient (the parent adds the two parts)
+                first_grads = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters() if p.grad is not None}
+            rdp.step()
+            losses.append([float(loss.detach())] + [float(ret[k].detach()) for k in ("rgb_loss", "depth_loss", "sdf_loss", "fs_loss")])
+        torch.save({"state": {k: v.cpu() for k, v in m.state_dict().items()}, "losses": losses, "first_grads": first_grads},
+                   os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ray_data_parallel_two_ranks_equal_the_single_process_step_and_the_oracle(dev):
+    """SURVEY 8e row 2 on the real JointEncoding at BASELINE config 2: two processes (here both on this GPU, gloo) render
+    2048 rays each of the SAME 4096-ray batches for five steps -- the batch's nine loss sums all-reduced inside forward
+    (helper_functions/utils.py:43-47: fs_weight / sdf_weight from counts over the WHOLE batch; scene_rep.py:218: depth_loss over
+    the batch's valid rays), gradients summed, reduce-scatter -> Adam on half the table each -> all-gather -- against ONE
+    process that takes the same five steps on the whole batches (mipsfusion.py:325-335), and against the oracle's
+    train_forward + torch.optim.Adam.  Both ranks must hold bit-identical parameters; the losses of every step must be the
+    whole batch's on both."""
+    import socket
+    import tempfile
+    import torch.multiprocessing as tmp
+    cfg = synth.config_headline()
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    with tempfile.TemporaryDirectory() as out_dir:
+        ctx = tmp.get_context("spawn")
+        procs = [ctx.Process(target=_rdp_gpu_worker, args=(r, 2, port, out_dir)) for r in range(2)]
+        for p in procs:
+            p.start()
+        import time as _time
+        deadline = _time.time() + 420
+        while _time.time() < deadline and any(p.is_alive() for p in procs) and all(p.exitcode in (None, 0) for p in procs):
+            _time.sleep(0.5)
+        codes = [p.exitcode for p in procs]
+        for p in procs:                      # (a rank that died leaves the other waiting in a collective: do not wait for it)
+            if p.is_alive():
+                p.terminate()
+            p.join(30)
+        assert codes == [0, 0], f"ray-DP ranks ended with exit codes {codes}"
+        r0, r1 = (torch.load(f"{out_dir}/rank{r}.pt") for r in range(2))
+    for k in r0["state"]:
+        assert torch.equal(r0["state"][k], r1["state"][k]), f"ranks diverged: {k}"
+    assert r0["losses"] == r1["losses"], "every rank must report the whole batch's losses"
+    # ---- one process, whole batches
+    m, cpu = build(cfg, dev, seed=21)
+    m.train()
+    mp_ = cfg["mapping"]
+    opt = FusedAdam(map_groups(m, cfg), betas=(0.9, 0.99))
+    copt = torch.optim.Adam(map_groups(cpu, cfg), betas=(0.9, 0.99))
+    one_losses, ref_losses, one_first = [], [], None
+    for ro, rd, rgb, d, noise in _rdp_batches(cfg):
+        ret = m.forward(ro.to(dev), rd.to(dev), rgb.to(dev), d.to(dev), EMD_w=0.01, noise=noise.to(dev))
+        loss = path_cpu.total_loss(ret, cfg["training"])
+        loss.backward()
+        if one_first is None:
+            one_first = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters() if p.grad is not None}
+        opt.step()
+        opt.zero_grad()
+        one_losses.append([float(loss.detach())] + [float(ret[k].detach()) for k in ("rgb_loss", "depth_loss", "sdf_loss", "fs_loss")])
+        ref = cpu.train_forward(ro, rd, rgb, d, noise, 0.01)
+        rl = path_cpu.total_loss(ref, cfg["training"])
+        copt.zero_grad()
+        rl.backward()
+        copt.step()
+        ref_losses.append([float(rl)] + [float(ref[k]) for k in ("rgb_loss", "depth_loss", "sdf_loss", "fs_loss")])
+    print("\nray-DP (2 ranks x 2048 rays) vs one process vs oracle, 5 steps at config 2:")
+    lo_dp, lo_one, lo_ref = (np.array(x) for x in (r0["losses"], one_losses, ref_losses))
+    print(f"  losses: worst |dp - one| / one {np.abs(lo_dp / lo_one - 1).max():.2e}, worst |dp - oracle| / oracle "
+          f"{np.abs(lo_dp / lo_ref - 1).max():.2e}")
+    assert np.abs(lo_dp / lo_one - 1).max() < 2e-5 and np.abs(lo_dp / lo_ref - 1).max() < 1e-4
+
+    def compare(a, b, what, tol, frac):
+        a, b = _np(a).ravel(), _np(b).ravel()
+        scale = np.abs(b).max() + 1e-30
+        off = np.abs(a - b) > tol * scale
+        print(f"  {what:44s} max |diff| / max {np.abs(a - b).max() / scale:.2e}, entries off by > {tol:g} of max: "
+              f"{int(off.sum())} of {off.size}")
+        assert off.mean() <= frac, f"{what}: {int(off.sum())} entries off"
+    # ---- the GRADIENT of the first step: the two ranks' parts added = the single process's, to the order of fp32 additions
+    #      (EVERY entry within 1e-5 of the tensor's maximum)
+    for k, g_one in one_first.items():
+        g_dp = r0["first_grads"][k] + r1["first_grads"][k]
+        compare(g_dp, g_one, "first-step gradient, dp sum vs one process: " + k, 1e-5, 0.0)
+    one = {k: v.cpu() for k, v in m.state_dict().items()}
+    ora = {k: v for k, v in cpu.state_dict().items()}
+    for k in r0["state"]:
+        if r0["state"][k].numel() == 0:
+            continue
+        # ---- the PARAMETERS after five Adam steps.  Adam turns the SIGN of a gradient entry into a step of lr: a table entry
+        # whose gradient is rounding noise around zero (the far corner of a cell a single sample grazed) moves by +-0.01 per step
+        # in ANY two fp32 evaluations that add in a different order -- 2e-4 of the 9 M entries here; every other entry must
+        # agree to 1e-5 of the tensor's maximum, and the update as a whole to 1 % in the L2 norm.  Against the fp32 oracle the
+        # usual gates.
+        # (the decoder's 36 577 weights all have solid gradients, but Adam divides by sqrt(v): a weight whose gradient is 1e-3 of
+        # its tensor's largest carries the 1e-6 relative reordering noise of that largest one as 1e-3 of its own step)
+        grid = k.startswith("embed_fn")
+        compare(r0["state"][k], one[k], "dp vs one process: " + k, 1e-5 if grid else 2e-4, 1e-3)
+        compare(r0["state"][k], ora[k], "dp vs oracle + torch Adam: " + k, 1e-3, 2e-3)
+    init, _ = build(cfg, dev, seed=21)
+    p0 = init.embed_fn.params.detach().cpu()
+    upd_dp, upd_one = r0["state"]["embed_fn.params"] - p0, one["embed_fn.params"] - p0
+    rel = float((upd_dp - upd_one).norm() / upd_one.norm())
+    print(f"  table update over the five steps: |dp - one| / |one| = {rel:.2e} (L2)")
+    assert rel < 1e-2
+
+
+def test_two_process_run_exercises_every_sharding(dev):
+    """`python bench.py --gpus 2` WITHOUT a launcher: bench.py starts its two ranks itself (child processes of
+    torch.distributed.run, before it touches the GPU) and passes rank 0's line through; here both ranks sit on this one GPU
+    over gloo (RCCL needs one GPU per rank): sub-map-per-rank mapping steps + pose all_gather, the RandomOptimizer particle
+    split and the global-BA pose-gradient all-reduce (bench.multi_gpu_checks)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MIPSF_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10",
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10",
            "--warmup", "5", "--setup-iters", "10", "--cpu-rays", "0", "--no-frame-estimate"]
     res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
@@ -361,6 +577,7 @@ def test_two_process_run_exercises_every_sharding(dev):
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     mg = out["multi_gpu"]
+    assert mg["ranks"]["world_size"] == 2 and mg["ranks"]["backend"] == "gloo" and len(mg["ranks"]["device_of_rank"]) == 2
     print("\ntwo ranks on one GPU (gloo):", json.dumps(mg))
     assert mg["ro_split_pose_equals_unsplit"] is True
     assert mg["ro_particles_per_rank"] == 1000

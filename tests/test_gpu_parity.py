@@ -351,7 +351,7 @@ def test_scene_train_golden(dev, name, tag, emd, precision):
     g = load_golden(name)
     cfg = cfg_for(name)
     m = make_scene(g, cfg, dev).train()
-    assert m.decoder_precision == "f16x3", "the split-precision f16 matrix-core decoder is the default training path"
+    assert m.decoder_precision == "bf16x6", "fp32 operands carried exactly (three bf16 pieces) are the default training path"
     m.decoder_precision = precision
     ro = T(g["rays_o"]).to(dev).requires_grad_(True)
     rd = T(g["rays_d"]).to(dev).requires_grad_(True)
@@ -1131,7 +1131,7 @@ def test_random_optimizer_matches_reference_golden(dev):
     reference's own RandomOptimizer.optimize produced (tests/golden/ro.npz), round by round."""
     g = load_golden("ro.npz")
     cfg, ro = _ro_setup(g, dev)
-    assert ro.decoder_precision == "f16x3", "the reference-faithful arithmetic is the RandomOptimizer's default"
+    assert ro.decoder_precision == "bf16x6", "the reference-faithful arithmetic is the RandomOptimizer's default"
     assert np.array_equal(ro.row_indices.numpy(), g["rows"]) and np.array_equal(ro.col_indices.numpy(), g["cols"])
     ro.pre_sampled_particle = T(g["pst"]).to(dev).contiguous()
     m = make_scene(g, cfg, dev)
@@ -1157,12 +1157,12 @@ def test_random_optimizer_matches_reference_golden(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["f16", "f32"])
+@pytest.mark.parametrize("precision", ["f16", "f32", "f16x3"])
 def test_random_optimizer_f16_rounds_track_the_reference_pose(dev, precision):
     """The opt-in plain-f16 matrix-core decoder (BASELINE config 5 "fp16 decoder on CDNA4"; bench.py and the measured
     sequences select it and say so): the pose tracked over 5 rounds (and every other round count of ro.npz) must stay
-    within 1e-3 of the pose the reference's own class produced; "f32" (fp32-input MFMA) is held to 1e-4 like the default
-    "f16x3" above."""
+    within 1e-3 of the pose the reference's own class produced; "f32" (fp32-input MFMA) and "f16x3" (hi/lo f16 operands) are
+    held to 1e-4 like the default "bf16x6" above."""
     g = load_golden("ro.npz")
     cfg, ro = _ro_setup(g, dev)
     ro.decoder_precision = precision
@@ -1780,6 +1780,30 @@ def test_decoder_bf16x6_matches_fp32_kernel_and_oracle(dev, M, layout):
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1]), "short cut: same d feat / d x"
     for k, a, b in zip(ops.DECODER_PARAM_ORDER, res[True][2], res[False][2]):
         assert_close(a, b, 1e-6, "short cut, grad " + k)
+    # ---- the lean records (the default of JointEncoding): the forward leaves H1 out, the chain dG3 and the rgb_emb half of dH2;
+    #      the exchange form of the weight-gradient kernel (csrc/wgrad16.hip, three bf16 planes) recomputes all three with the
+    #      forward's / the chain's own products in their own order.  Full record through the plain streaming kernel, full record
+    #      with H1 recomputed, lean activation record, lean activation + full gradient record: the same gradients
+    ol, sl = ops.decoder_fwd(None, feat, lay, x, None, M, save="lean", precision="bf16x6", packed16=pk)
+    assert torch.equal(ol, ob)
+    kw = dict(precision="bf16x6", packed16=pk, wgrad_precision="stream_bf16x6")
+    g_full, g_rc, g_lean, g_fd = ([torch.zeros_like(w_) for w_ in ws] for _ in range(4))
+    ops.decoder_bwd(None, feat, lay, x, None, ob, dout, sb, g_full, M, **kw)
+    ops.decoder_bwd(None, feat, lay, x, None, ob, dout, sb, g_rc, M, recompute_h1=True, **kw)
+    df_l, dx_l, _ = ops.decoder_bwd(None, feat, lay, x, None, ol, dout, sl, g_lean, M, recompute_h1=True, **kw)
+    keep_ld = ops.LEAN_DACT
+    ops.LEAN_DACT = False
+    try:
+        ops.decoder_bwd(None, feat, lay, x, None, ol, dout, sl, g_fd, M, recompute_h1=True, **kw)
+    finally:
+        ops.LEAN_DACT = keep_ld
+    with pytest.raises(RuntimeError, match="lean"):            # a kernel that reads H1 must refuse the lean record
+        ops.decoder_bwd(None, feat, lay, x, None, ol, dout, sl, [torch.zeros_like(w_) for w_ in ws], M, precision="bf16x6",
+                        packed16=pk, wgrad_precision="f32")
+    for k, a, b, c, d in zip(ops.DECODER_PARAM_ORDER, g_full, g_rc, g_lean, g_fd):
+        assert_close(b, a, 1e-6, "recomputed H1 vs stored H1, grad " + k)
+        assert_close(c, b, 1e-6, "lean records vs full records, grad " + k)
+        assert_close(d, c, 1e-6, "full gradient record vs lean gradient record, grad " + k)
     # ---- a frozen decoder: masks-only record, no gradient record, no weight gradients
     om, sm = ops.decoder_fwd(None, feat, lay, x, None, M, save="masks", precision="bf16x6", packed16=pk)
     dfm, dxm, _ = ops.decoder_bwd(None, feat, lay, x, None, om, dz, sm, None, M, precision="bf16x6", packed16=pk)
