@@ -334,8 +334,9 @@ class UnchangedCallerLoop:
         self.poses_all = torch.cat([self.pose_fixed, qt_to_transform_matrix(self.cur_rot, self.cur_trans)], 0)
         self.i = 0
 
-    def iterate(self, predrawn=None, marks=None):
-        """marks (a dict): wall-clock of every section, each closed by a device synchronisation (the breakdown pass only)"""
+    def iterate(self, predrawn=None, marks=None, detach_rays=False):
+        """marks (a dict): wall-clock of every section, each closed by a device synchronisation (the breakdown pass only);
+        detach_rays: the poses get no gradient (prices the backward of the caller's own eager ray ops, mipsfusion.py:320-322)"""
         cfg, dev = self.cfg, self.dev
         t_prev = [time.perf_counter()]
 
@@ -357,6 +358,8 @@ class UnchangedCallerLoop:
         mark("cpu_ray_gather_and_uploads")
         rays_d = torch.sum(rays_d_cam[..., None, :] * self.poses_all[owner, :3, :3], -1)
         rays_o = self.poses_all[owner, :3, -1]
+        if detach_rays:
+            rays_d, rays_o = rays_d.detach(), rays_o.detach()
         mark("eager_torch_ray_ops")
         ret = self.model.forward(rays_o, rays_d, target_s, target_d)        # jitter: the CPU generator's draw + upload
         ret = {k: v for k, v in ret.items() if not k.startswith("_")}       # the reference's dictionary keys only
@@ -396,6 +399,14 @@ def unchanged_caller_rate(cfg, model, frames, poses, table, db, R, dev, steps):
     for k in range(n_b):
         loop.iterate(None, marks)
     out["breakdown_ms_per_step_serialised"] = {k: round(v / n_b, 4) for k, v in marks.items()}
+    marks2 = {}
+    for k in range(n_b):
+        loop.iterate(None, marks2, detach_rays=True)
+    out["breakdown_ms_per_step_serialised"]["(of backward) without the caller's eager ray ops in the graph"] = round(
+        marks2["backward_autograd_path_gradients"] / n_b, 4)
+    out["breakdown_note"] = ("the backward section contains the autograd of the CALLER's own eager torch ray ops (poses_all[indices] gather -> "
+                             "index_put with a sort, the quaternion chain: ~150 small launches) next to the modules' six kernels; the "
+                             "line above it without them is what the drop-in modules themselves cost")
     t0 = time.perf_counter()
     for _ in range(10):
         torch.rand(N_RAYS, N_SAMPLES)

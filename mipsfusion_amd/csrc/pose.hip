@@ -96,19 +96,43 @@ __global__ __launch_bounds__(PR_BLOCK) void pose_rays_bwd_kernel(const float* __
         v[3 * j] = g * dx, v[3 * j + 1] = g * dy, v[3 * j + 2] = g * dz;
         v[9 + j] = (valid && g_o) ? g_o[3 * nn + j] : 0.f;
     }
-    // rays of one pose are contiguous in practice: combine equal owners inside the wave before touching LDS
-    // (tail lanes carry zeros and the last valid ray's owner, so every lane takes part in the shuffles)
-    const int lane = threadIdx.x & 63;
-    const int64_t p0 = __shfl(p, 0, 64);
-    if (__all(p == p0)) {
+    // Rays of one pose are contiguous in practice.  Every wave reduces its rays pose by pose (one pass per distinct owner: one
+    // in practice, two at a pose boundary) with the fixed tree of wave_sum and leaves the sums in ITS OWN slots; one thread
+    // per entry then adds the waves' slots in wave order.  (LDS float atomics from four waves arrive in any order: the pose
+    // gradients of two identical launches used to differ in the last bit -- tools/dbg_tracking_determinism.py.)  A wave
+    // with more than PR_MAXSEG distinct owners (scattered owners: not the reference's batches) falls back to atomics.
+    constexpr int PR_WAVES = PR_BLOCK / 64, PR_MAXSEG = 4;
+    __shared__ float wv[PR_WAVES][PR_MAXSEG][12];
+    __shared__ int wp[PR_WAVES][PR_MAXSEG], wn[PR_WAVES];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    {
+        unsigned long long remaining = __ballot(1);
+        int nseg = 0;
+        while (remaining) {
+            const int src = __ffsll((long long)remaining) - 1;
+            const int64_t pv = __shfl(p, src, 64);
+            const bool mine = p == pv;
+            const unsigned long long mask = __ballot(mine) & remaining;
+            remaining &= ~mask;
+            if (nseg < PR_MAXSEG) {
 #pragma unroll
-        for (int q = 0; q < 12; ++q) {
-            const float s = wave_sum(v[q]);
-            if (lane == 0) atomicAdd(&sacc[(int)p * 12 + q], s);
+                for (int q = 0; q < 12; ++q) {
+                    const float sq = wave_sum(mine ? v[q] : 0.0f);
+                    if (lane == 0) wv[w][nseg][q] = sq;
+                }
+                if (lane == 0) wp[w][nseg] = (int)pv;
+                ++nseg;
+            } else if (mine) {
+#pragma unroll
+                for (int q = 0; q < 12; ++q) atomicAdd(&sacc[(int)p * 12 + q], v[q]);
+            }
         }
-    } else {
-#pragma unroll
-        for (int q = 0; q < 12; ++q) atomicAdd(&sacc[(int)p * 12 + q], v[q]);
+        if (lane == 0) wn[w] = nseg < PR_MAXSEG ? nseg : PR_MAXSEG;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        for (int ww = 0; ww < PR_WAVES; ++ww)
+            for (int sg = 0; sg < wn[ww]; ++sg) sacc[wp[ww][sg] * 12 + (int)threadIdx.x] += wv[ww][sg][threadIdx.x];
     }
     pose_block_finish<PR_BLOCK>(sacc, &is_last, P, F, K, part, ticket, rot, d_rot, d_trans, accumulate != 0);
 }

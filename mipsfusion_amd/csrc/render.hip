@@ -644,6 +644,8 @@ __global__ __launch_bounds__(PPB * MIPSF_WAVE) void place_pose_bwd_kernel(
     uint32_t* __restrict__ ticket, float* __restrict__ d_rot, float* __restrict__ d_trans, uint32_t N, uint32_t S,
     int accumulate) {
     __shared__ float sacc[PR_MAX_POSES * 12];
+    __shared__ float wv[PPB][12];
+    __shared__ int wp[PPB];
     __shared__ bool is_last;
     const int P = F + K;
     for (int q = threadIdx.x; q < P * 12; q += PPB * MIPSF_WAVE) sacc[q] = 0.f;
@@ -671,14 +673,24 @@ __global__ __launch_bounds__(PPB * MIPSF_WAVE) void place_pose_bwd_kernel(
         if (p < 0) p += P;
         if (p < 0 || p >= P) p = 0;              // (the forward already produced NaN rays for this owner)
         const float dx = d_cam[3 * (size_t)n], dy = d_cam[3 * (size_t)n + 1], dz = d_cam[3 * (size_t)n + 2];
-        if (lane < 12) {                         // lane q adds entry q of this ray's {dR (9), dt (3)} to its pose's row
+        if (lane < 12) {                         // lane q: entry q of this ray's {dR (9), dt (3)}, left in the wave's own slot
             const int j = lane < 9 ? (int)lane / 3 : (int)lane - 9;
             const float gd = j == 0 ? sd[0] : (j == 1 ? sd[1] : sd[2]);
             const float go = j == 0 ? so[0] : (j == 1 ? so[1] : so[2]);
             const int c = (int)lane % 3;
             const float dc = c == 0 ? dx : (c == 1 ? dy : dz);
-            atomicAdd(&sacc[(int)p * 12 + (int)lane], lane < 9 ? gd * dc : go);
+            wv[w][lane] = lane < 9 ? gd * dc : go;
         }
+        if (lane == 0) wp[w] = (int)p;
+    } else if (lane == 0) {
+        wp[w] = -1;
+    }
+    // the rays' entries are added pose row by pose row in RAY order by one thread per entry (LDS float atomics from 16 waves
+    // arrive in any order: two identical launches used to differ in the last bit of the pose gradients)
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        for (int ww = 0; ww < PPB; ++ww)
+            if (wp[ww] >= 0) sacc[wp[ww] * 12 + (int)threadIdx.x] += wv[ww][threadIdx.x];
     }
     pose_block_finish<PPB * MIPSF_WAVE>(sacc, &is_last, P, F, K, part, ticket, rot, d_rot, d_trans, accumulate != 0);
 }
