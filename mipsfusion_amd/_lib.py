@@ -180,9 +180,18 @@ def lib() -> C.CDLL:
     return _lib
 
 
+# Caches of caller-kept counter / ticket blocks (ops._scatter_counters, ops._zeroed_words, ops._pose_scratch, FusedAdam's
+# ticket): a kernel finds them at zero and leaves them at zero -- IF it runs to completion.  A call that failed after launching
+# part of its work may have left counts or tickets behind; every cache registered here is emptied when a call fails, so the
+# next call starts from freshly zeroed blocks instead of silently miscounting.
+KEPT_BLOCK_CACHES = []
+
+
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = lib().mipsf_last_error().decode(errors="replace")
+        for cache in KEPT_BLOCK_CACHES:
+            cache.clear()
         raise RuntimeError(f"libmipsf_hip {what} failed (code {rc}): {msg}")
 
 

@@ -138,8 +138,9 @@ struct NoSide16 {
 // be read by asm without the 12 wait states of the 8-pass XDL, and the first version of this file read stale values.)
 __device__ __forceinline__ float relu1(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff()); }
 // 2^-W16_SHIFT: takes a completed accumulator back to its true magnitude (decoder_layout.h, RANGE)
-constexpr float ACC_UNSCALE = 1.0f / (float)(1 << W16_SHIFT);
-constexpr float GRID_UPSCALE = (float)(1 << G16_SHIFT);
+// (the bf16 mode's images are unscaled: both factors are 1 there and the multiplications fold away)
+template <int NP> constexpr float acc_unscale() { return NP == 3 ? 1.0f : 1.0f / (float)(1 << W16_SHIFT); }
+template <int NP> constexpr float grid_upscale() { return NP == 3 ? 1.0f : (float)(1 << G16_SHIFT); }
 
 // acc[rt] (+)= A_image(rt, t) * B(t) over a layer's k-steps, software-pipelined and FENCED: the A operands of k-step
 // t+1 are requested and the B operand of k-step t+1 is converted while the MFMAs of k-step t run; the
@@ -431,7 +432,7 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) if (!(D16_ABL & 32)) H1[rt][r] = relu1(H1[rt][r] * ACC_UNSCALE);
+        for (int r = 0; r < 16; ++r) if (!(D16_ABL & 32)) H1[rt][r] = relu1(H1[rt][r] * acc_unscale<NP>());
     uint32_t m1[2] = {0u, 0u};
     if (SAVE) relu_masks(H1, m1);
 
@@ -457,7 +458,7 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
 #pragma unroll
     for (int rt = 0; rt < RT2; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) if (!(D16_ABL & 32)) H2[rt][r] = H2[rt][r] * ACC_UNSCALE;
+        for (int r = 0; r < 16; ++r) if (!(D16_ABL & 32)) H2[rt][r] = H2[rt][r] * acc_unscale<NP>();
 
     // grid features of layer 3 (feature h of the 16 levels): requested before the rgb head, which covers the latency
     float gf[16];
@@ -502,7 +503,7 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
                 }
             });
 #pragma unroll
-        for (int c = 0; c < 3; ++c) rgb[c] = (r0[c] + r1[c]) * ACC_UNSCALE + tail[OFF16_BSMALL + c];      // (half 0's; half 1 holds zeros)
+        for (int c = 0; c < 3; ++c) rgb[c] = (r0[c] + r1[c]) * acc_unscale<NP>() + tail[OFF16_BSMALL + c];      // (half 0's; half 1 holds zeros)
     }
 
     D16_MARK(6);
@@ -514,7 +515,7 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                v[u] = t < 4 ? H2[(t >> 1) & 1][8 * (t & 1) + u] : gf[(8 * (t - 4) + u) & 15] * GRID_UPSCALE;
+                v[u] = t < 4 ? H2[(t >> 1) & 1][8 * (t & 1) + u] : gf[(8 * (t - 4) + u) & 15] * grid_upscale<NP>();
             cut8<NP>(v, b);
         },
         [&](int t) {                                   // the sdf_emb half of H2 (8 pieces) over the first 4 k-steps
@@ -534,7 +535,7 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) if (!(D16_ABL & 32)) H3[rt][r] = relu1(H3[rt][r] * ACC_UNSCALE);
+        for (int r = 0; r < 16; ++r) if (!(D16_ABL & 32)) H3[rt][r] = relu1(H3[rt][r] * acc_unscale<NP>());
     if (SAVE) {
         uint32_t m3[2];
         relu_masks(H3, m3);
@@ -568,7 +569,7 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
             });
 #pragma unroll
         for (int c = 0; c < N_CLASS; ++c) {
-            lg[c] = (s0[c] + s1[c]) * ACC_UNSCALE + tail[OFF16_BSMALL + 4 + c];
+            lg[c] = (s0[c] + s1[c]) * acc_unscale<NP>() + tail[OFF16_BSMALL + 4 + c];
             mx = fmaxf(mx, lg[c]);
         }
     }
@@ -739,9 +740,11 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
                                                    const float* __restrict__ out, const float* __restrict__ dout,
                                                    const float* __restrict__ saved, float* __restrict__ dfeat,
                                                    float* __restrict__ dx, float* __restrict__ dact,
-                                                   float* __restrict__ dsmall, uint32_t M, int64_t tile, int lane,
+                                                   float* __restrict__ dsmall, uint32_t M, int64_t tile, int lane_in,
                                                    uint32_t* __restrict__ tile_live = nullptr, bool lean_dact = false) {
     static_assert(NP == 2 || NP == 3, "the chain runs on split operands");
+    int lane = lane_in;                        // opaque per tile: per-lane offsets are recomputed by every tile instead of being
+    asm volatile("" : "+v"(lane));             // kept (and spilled) across the persistent kernel's tile loop (cf. the forward)
     const int j = lane & 31, h = lane >> 5;
     const uint32_t s_raw = (uint32_t)(tile * 32 + j);
     const bool live = s_raw < M;
@@ -789,7 +792,9 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
                     else
                         *reinterpret_cast<float2*>(dfeat + ((size_t)(row >> 1) * M + s) * 2) = make_float2(0.f, 0.f);
                 }
-                if (h == 0) dx[3 * (size_t)s] = 0.f, dx[3 * (size_t)s + 1] = 0.f, dx[3 * (size_t)s + 2] = 0.f;
+                float z0 = 0.f;                       // (made here: a loop-invariant zero triple was hoisted out of the tile
+                asm volatile("" : "+v"(z0));          // loop and spilled; its reload waits for every memory operation in flight)
+                if (h == 0) dx[3 * (size_t)s] = z0, dx[3 * (size_t)s + 1] = z0, dx[3 * (size_t)s + 2] = z0;
             }
             return;
         }
@@ -881,7 +886,7 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dG3[rt][r] = mask_apply(m3, rt, r, dG3[rt][r] * ACC_UNSCALE);
+        for (int r = 0; r < 16; ++r) dG3[rt][r] = mask_apply(m3, rt, r, dG3[rt][r] * acc_unscale<NP>());
 
     D16_MARK(4);
     // ---- d[sdf_emb | grid] = Ws1^T dG3   (row tiles 0,1 -> d sdf_emb, 2 -> d grid features); dG3 leaves for `dact`
@@ -900,7 +905,7 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
 #pragma unroll
     for (int rt = 0; rt < 3; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dIn3[rt][r] = dIn3[rt][r] * ACC_UNSCALE;
+        for (int r = 0; r < 16; ++r) dIn3[rt][r] = dIn3[rt][r] * acc_unscale<NP>();
     if (live) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
@@ -921,7 +926,7 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
         f32x16 dRgb[2];
         mfma16_layer<RT16_RGBT, T16_RGBT, NP, INIT_ZERO>(bimg.at(OFF16B_RGBT, OFF16B_RGBT), lane, h, dRgb,
             [&](int, h8 (&b)[3]) { b[0] = rgp[0], b[1] = rgp[1], b[2] = rgp[2]; });
-        dH2[2] = dRgb[0] * ACC_UNSCALE, dH2[3] = dRgb[1] * ACC_UNSCALE;
+        dH2[2] = dRgb[0] * acc_unscale<NP>(), dH2[3] = dRgb[1] * acc_unscale<NP>();
     }
 
     D16_MARK(6);
@@ -941,7 +946,7 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dG1[rt][r] = mask_apply(m1, rt, r, dG1[rt][r] * ACC_UNSCALE);
+        for (int r = 0; r < 16; ++r) dG1[rt][r] = mask_apply(m1, rt, r, dG1[rt][r] * acc_unscale<NP>());
 
     D16_MARK(7);
     // ---- d e = W1^T dG1 + Wrgb[:, 64:]^T drgb; rows are arranged so that e-slot (t, h) lands in THIS lane
@@ -970,7 +975,7 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
 #endif
     float de[E_SLOTS];
 #pragma unroll
-    for (int t = 0; t < E_SLOTS; ++t) de[t] = dE[t >> 4][t & 15] * (down * ACC_UNSCALE);
+    for (int t = 0; t < E_SLOTS; ++t) de[t] = dE[t >> 4][t & 15] * (down * acc_unscale<NP>());
     float g3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -1094,7 +1099,7 @@ __global__ __launch_bounds__(256) void decoder_pack16_kernel(W w, float* __restr
     };
     if (idx < HEAD16_HALVES) {
         int plane;
-        const float v = head16_weight(w, idx, plane);
+        const float v = head16_weight(w, idx, plane, NP);
         reinterpret_cast<uint16_t*>(packed16)[idx] = piece(v, plane);
         if (NP == 3 && plane == 0) ext[head16_ext_index(idx)] = piece(v, 2);
     }
@@ -1111,7 +1116,7 @@ __global__ __launch_bounds__(256) void decoder_pack16_kernel(W w, float* __restr
     }
     if (idx < IMG16B_HALVES) {
         uint16_t* img = reinterpret_cast<uint16_t*>(packed16 + TAIL16_FLOATS) + OFF16_BWD_HALVES;
-        const float v = img16b_weight(w, idx);
+        const float v = img16b_weight(w, idx, NP);
         img[idx] = piece(v, 0);
         img[IMG16B_HALVES + idx] = piece(v, 1);
         if (NP == 3) ext[EXT16_BWD + idx] = piece(v, 2);

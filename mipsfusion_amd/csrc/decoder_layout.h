@@ -170,6 +170,11 @@ MIPSF_HD float packed_value(const W& w, int idx) {
 // weight columns stored as weight * 2^(W16_SHIFT - G16_SHIFT).
 constexpr int W16_SHIFT = 10, G16_SHIFT = 12;
 MIPSF_HD float pow2f(int e) { float r = 1.0f; for (int i = 0; i < (e < 0 ? -e : e); ++i) r *= (e < 0 ? 0.5f : 2.0f); return r; }
+// The bf16 mode (np = 3 planes) has fp32's exponent range: its images hold the weights themselves and its kernels neither
+// unscale accumulators nor upscale the grid features (a power-of-two scale commutes with the cut into bf16 pieces, so the
+// results would be bit-identical with it -- only the multiplications go).
+MIPSF_HD float w16_scale(int np) { return np == 3 ? 1.0f : pow2f(W16_SHIFT); }
+MIPSF_HD float w16_grid_col_scale(int np) { return np == 3 ? 1.0f : pow2f(W16_SHIFT - G16_SHIFT); }
 constexpr int T16_F1 = 4, T16_F2 = 8, T16_F3 = 6;          // data k-steps (x16 inputs): e (52 -> 64), H1 (128), [sdf_emb | grid] (96)
 constexpr int T16H_F1 = 4, T16H_F2 = 9, T16H_F3 = 7;       // k-steps of the hi images (bias k-step first for layers 2, 3)
 constexpr int BIAS16_T = 3, BIAS16_U = 2;                  // layer 1: where the two bias elements sit (half 0)
@@ -228,7 +233,7 @@ constexpr int OFF16B_RGBT = OFF16B_B3 + img16_halves(RT16_B3, T16_B3);
 constexpr int OFF16B_B2 = OFF16B_RGBT + img16_halves(RT16_RGBT, T16_RGBT);
 constexpr int OFF16B_B1 = OFF16B_B2 + img16_halves(RT16_B2, T16_B2);
 constexpr int IMG16B_HALVES = OFF16B_B1 + img16_halves(RT16_B1, T16_B1);   // 40 960 halves = 80 KB per set
-MIPSF_HD float img16b_weight(const W& w, int idx) {
+MIPSF_HD float img16b_weight(const W& w, int idx, int np = 2) {
     int base, T, kind;
     if (idx < OFF16B_B3) { base = OFF16B_S2T; T = T16_S2T; kind = 0; }
     else if (idx < OFF16B_RGBT) { base = OFF16B_B3; T = T16_B3; kind = 1; }
@@ -240,7 +245,7 @@ MIPSF_HD float img16b_weight(const W& w, int idx) {
     const int rt = g / T, t = g - rt * T;
     const int i = lane & 31, h = lane >> 5;
     const int row = 32 * rt + i;
-    const float sc = pow2f(W16_SHIFT);                 // every backward image is scaled alike (see RANGE above)
+    const float sc = w16_scale(np);                    // every backward image is scaled alike (see RANGE above)
     switch (kind) {
         case 0: return (h == 0 && u < N_CLASS) ? w.w_sdf2[u * HID + row] * sc : 0.f;
         case 1: return w.w_sdf0[kfeat16(t, h, u) * N_SDF_IN + row] * sc;
@@ -309,7 +314,7 @@ MIPSF_HD float img16_weight(const W& w, int idx, int np = 2) {
     const int rt = g / T, t = g - rt * T;
     const int i = lane & 31, h = lane >> 5;
     const int row = 32 * rt + i;
-    const float sc = pow2f(W16_SHIFT);
+    const float sc = w16_scale(np);
     if (kind == 0) {
         if (t == BIAS16_T && h == 0 && u >= BIAS16_U && u < BIAS16_U + np) return bias16_part(w.b_pts0[row] * sc, u - BIAS16_U, np);
         const int e = e16(t, h, u);
@@ -321,7 +326,7 @@ MIPSF_HD float img16_weight(const W& w, int idx, int np = 2) {
     }
     if (kind == 1) return w.w_pts2[row * HID + kfeat16(t - 1, h, u)] * sc;
     const int src = src16_f3(t - 1, h, u);
-    return w.w_sdf0[row * N_SDF_IN + src] * (src < N_EMB ? sc : pow2f(W16_SHIFT - G16_SHIFT));
+    return w.w_sdf0[row * N_SDF_IN + src] * (src < N_EMB ? sc : w16_grid_col_scale(np));
 }
 // fp32 value behind half idx of the compact head images (both planes hold the same value here: the packer stores rne16(v)
 // in plane 0 and rne16(v - rne16(v)) in plane 1); plane = which plane idx belongs to
@@ -334,8 +339,8 @@ MIPSF_HD int head16_ext_index(int idx) {
     const int slot = g % slots, t = (g / slots) >> 1;
     return (sdf ? EXT16_HEAD_SDF : EXT16_HEAD_RGB) + (t * slots + slot) * 8 + u;
 }
-MIPSF_HD float head16_weight(const W& w, int idx, int& plane) {
-    const float sc = pow2f(W16_SHIFT);
+MIPSF_HD float head16_weight(const W& w, int idx, int& plane, int np = 2) {
+    const float sc = w16_scale(np);
     const bool sdf = idx < HEAD16_SDF_HALVES;
     const int rel = sdf ? idx : idx - HEAD16_SDF_HALVES;
     const int slots = sdf ? HEAD16_SDF_SLOTS : HEAD16_RGB_SLOTS;

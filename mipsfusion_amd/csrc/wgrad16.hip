@@ -48,6 +48,9 @@ struct ArF16 { typedef h8 v8; typedef _Float16 elt; static constexpr int P = 2; 
 struct ArBF3 { typedef bf8 v8; typedef __bf16 elt; static constexpr int P = 3; static constexpr bool SCALED = false; };
 struct ArBF2 { typedef bf8 v8; typedef __bf16 elt; static constexpr int P = 2; static constexpr bool SCALED = false; };
 constexpr float W16_GRID_SHIFT = 4096.0f;      // 2^G16_SHIFT
+// the bf16 planes ride unscaled (decoder_layout.h, w16_scale): both factors are 1 for the unscaled arithmetics
+template <typename A> constexpr float w16_acc_unscale() { return A::SCALED ? 1.0f / (float)(1 << W16_SHIFT) : 1.0f; }
+template <typename A> constexpr float w16_grid_shift() { return A::SCALED ? W16_GRID_SHIFT : 1.0f; }
 
 __device__ __forceinline__ f32x16 mfma16(bf8 a, bf8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
@@ -1015,7 +1018,7 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X<A>& lx,
                 f32x8 r;
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    r[u] = __builtin_amdgcn_fmed3f(hacc[8 * m + u] * (1.0f / (float)(1 << W16_SHIFT)), 0.0f, __builtin_inff());
+                    r[u] = __builtin_amdgcn_fmed3f(hacc[8 * m + u] * w16_acc_unscale<A>(), 0.0f, __builtin_inff());
 #pragma unroll
                 for (int p = 0; p < P; ++p) Y[p][m] = p == P - 1 ? next_plane<A, true>(r) : next_plane<A, false>(r);
             }
@@ -1038,7 +1041,7 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X<A>& lx,
             v8 rp[P];
             w16x_small_operand<A>(bS[0], N_CLASS, 3, up, h, rp);
             const f32x16 ac = w16x_narrow<A>(gimg, L::G_RGBT + (w - 2) * 64 + lane, L::G_PLANE_RGBT, rp);
-            const float unscale = 1.0f / (float)(1 << W16_SHIFT);
+            const float unscale = w16_acc_unscale<A>();
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -1199,7 +1202,7 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X<A>& lx,
         W16_MARK(0);
         // ---- this wave's column tile(s) -> XB
         if (rt < 3) {
-            if (rt == 2) bY[0] = bGr[0] * W16_GRID_SHIFT, bY[1] = bGr[1] * W16_GRID_SHIFT;
+            if (rt == 2) bY[0] = bGr[0] * w16_grid_shift<A>(), bY[1] = bGr[1] * w16_grid_shift<A>();
             v8 Y[P][2];
             transpose_block<A, false>(bY, I, Y, dummy);
             w16x_put<A>(xb + rt * L::CT, lane, Y);
@@ -1232,7 +1235,7 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X<A>& lx,
             w16x_small_operand<A>(bSm, 0, N_CLASS, up, h, lp);
             const f32x16 ac = w16x_narrow<A>(gimg, rt * 64 + lane, L::G_PLANE_S2T, lp);
             const uint32_t m3[2] = {bMk.x, bMk.y};
-            const float unscale = 1.0f / (float)(1 << W16_SHIFT);
+            const float unscale = w16_acc_unscale<A>();
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -1287,7 +1290,7 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X<A>& lx,
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
         flush_mapped(rec, G_W_SDF0, N_SDF_IN, lane, acc[ct], w16_unscale(k3), [&](int i) { return 32 * rt + i; }, [&](int c) { return 32 * ct + c; });
-    flush_mapped(rec, G_W_SDF0, N_SDF_IN, lane, acc[2], w16_unscale(k3) / W16_GRID_SHIFT, [&](int i) { return 32 * rt + i; },
+    flush_mapped(rec, G_W_SDF0, N_SDF_IN, lane, acc[2], w16_unscale(k3) / w16_grid_shift<A>(), [&](int i) { return 32 * rt + i; },
                  [&](int c) { return N_EMB + 2 * (8 * (c >> 4) + 4 * ((c >> 3) & 1) + (c & 3)) + ((c >> 2) & 1); });
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)

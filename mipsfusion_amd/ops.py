@@ -143,6 +143,7 @@ def hashgrid_route_ahead(x, meta):
 
 
 _ZEROED = {}
+_lib.KEPT_BLOCK_CACHES.append(_ZEROED)
 
 
 def _zeroed_words(device, n, tag):
@@ -156,12 +157,15 @@ def _zeroed_words(device, n, tag):
 
 
 _SCATTER_COUNTERS = {}
+_lib.KEPT_BLOCK_CACHES.append(_SCATTER_COUNTERS)
 
 
 def _scatter_counters(device, meta):
     """The routed scatter's counter block (bin counts, queue head, tickets): zero once, left ready by every call
     (mipsf_hashgrid_bwd_keep), so one zero-initialised block per (device, stream, size) is kept -- calls on one stream are
-    ordered -- and no call launches a clearing kernel."""
+    ordered -- and no call launches a clearing kernel.  One stream per block: a graph captured on stream A must not be
+    replayed concurrently on two streams (both replays would count in the same block); a failed call empties the cache
+    (_lib.check)."""
     n = int(lib().mipsf_hashgrid_counter_words(C.byref(meta)))
     key = (device.index, stream_ptr(), n)
     buf = _SCATTER_COUNTERS.get(key)
@@ -603,6 +607,7 @@ def rays_bwd(dxn, z_vals, rc, N, S):
 
 # ------------------------------------------------------------------------- rays from poses
 _POSE_SCRATCH = {}
+_lib.KEPT_BLOCK_CACHES.append(_POSE_SCRATCH)
 
 
 def _pose_scratch(device, F, K, N):

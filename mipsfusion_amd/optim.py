@@ -124,10 +124,14 @@ class FusedAdam(torch.optim.Optimizer):
             # advance + one launch per large tensor + one multi-tensor launch per group
             if getattr(self, "_ticket", None) is None or self._ticket.device != work[0][2][0].device:
                 self._ticket = torch.zeros(576, dtype=torch.int32, device=work[0][2][0].device)    # MIPSF_ADAM_TICKET_WORDS
-            ops.adam_step_all([(self._dev[gi][0], self._dev[gi][1], group["lr"], group["betas"][0], group["betas"][1],
-                                group["eps"], group["weight_decay"],
-                                [(p.data, p.grad, self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"]) for p in live])
-                               for gi, group, live, _ in work], self._ticket, zero_grad)
+            try:
+                ops.adam_step_all([(self._dev[gi][0], self._dev[gi][1], group["lr"], group["betas"][0], group["betas"][1],
+                                    group["eps"], group["weight_decay"],
+                                    [(p.data, p.grad, self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"]) for p in live])
+                                   for gi, group, live, _ in work], self._ticket, zero_grad)
+            except RuntimeError:
+                self._ticket = None            # a failed launch may have left tickets behind: start from a zeroed block
+                raise
             return loss
         if self.capturable and work:       # all groups' step counters / bias corrections in ONE launch
             adv = [(self._dev[gi][0], self._dev[gi][1], group["lr"], group["betas"][0], group["betas"][1])

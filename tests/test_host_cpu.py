@@ -40,6 +40,21 @@ def test_abi_version_and_error_channel():
         _lib.check(rc, "meta")
 
 
+def test_size_queries_and_failed_calls_reset_the_kept_blocks():
+    """Pure host entry points: the loss kernel's scratch is sized for BOTH of its forms (8 floats per ray, or one row of nine
+    doubles per 16-ray workgroup: the larger for N < 3 -- a caller with exact allocations used to be overrun), the bf16x6 operand
+    buffer is the f16 one plus its plane-2 extension; a failed call empties every cache of caller-kept counter blocks."""
+    lib = _lib.lib()
+    assert [int(lib.mipsf_render_partial_floats(n)) for n in (1, 2, 3, 16, 17, 4096)] == [18, 18, 24, 128, 136, 32768]
+    f16, bf = lib.mipsf_decoder_packed16_floats_ex(_lib.PREC["f16x3"]), lib.mipsf_decoder_packed16_floats_ex(_lib.PREC["bf16x6"])
+    assert f16 == lib.mipsf_decoder_packed16_floats() == lib.mipsf_decoder_packed16_floats_ex(_lib.PREC["f16"]) and bf > f16
+    from mipsfusion_amd import ops
+    ops._ZEROED[("probe",)] = object()
+    with pytest.raises(RuntimeError):
+        _lib.check(lib.mipsf_hashgrid_meta_init(C.byref(_lib.GridMeta()), 16, 4, 19, 16, 1.2), "meta")
+    assert not ops._ZEROED and not ops._SCATTER_COUNTERS and not ops._POSE_SCRATCH
+
+
 @pytest.mark.parametrize("log2_t", [10, 16, 19])
 def test_level_table_equals_oracle(log2_t):
     pls = float(2.0 ** (math.log2(256 / 16) / 15))
