@@ -84,7 +84,7 @@ N_GRID_PARAMS, N_DEC_PARAMS = 9014144, 36577
 
 # algorithmic cost per unit (SURVEY.md 8d / BASELINE.md 3); unit = 1 ray*sample.
 # (bound, bytes per LIVE unit, bytes per DEAD unit, liveness that applies, arithmetic type, matrix products issued per
-#  algorithmic product or None).  A sample behind the truncation band has an exactly zero gradient: the
+#  algorithmic product or None).  A sample behind the truncation band has an exactly zero gradient (DESIGN_NOTES 4e): the
 # backward chain short-cuts its 32-sample tile, the weight-gradient and dx kernels never visit it, the scatter makes no
 # record for a (sample, level) pair with a zero feature gradient.  `work` of a launch = the units it PROCESSED:
 #   liveness "tile": share of live 32-sample tiles of the step (the chain kernel's own lists), "pair": share of live
@@ -121,10 +121,16 @@ def kernel_cost(precision):
         cost["decoder_bwd_chain"] = ("hbm", io_b + 768.0 + 32.0, dead_b, "tile", _F16X3, 3, 0.0)     # dG1 + sdf_emb half of dH2 + small rows
         cost["decoder_wgrad"] = ("hbm", 1024.0 + 768.0 + 32.0 + 16.0 + 128.0 + 12.0, 0.0, "tile",
                                  _F16X3 + ", gradient blocks under per-block power-of-two scales", 3, 0.0)
-    elif precision == "bf16x6":         # the same lean records, six products per algorithmic one
-        cost["decoder_fwd"] = ("hbm", io_f + 1024.0 + 32.0, 0.0, None, _BF16X6, 6, 0.0)
-        cost["decoder_bwd_chain"] = ("hbm", io_b + 768.0 + 32.0, dead_b, "tile", _BF16X6, 6, 0.0)
-        cost["decoder_wgrad"] = ("hbm", 1024.0 + 768.0 + 32.0 + 16.0 + 128.0 + 12.0, 0.0, "tile", _BF16X6, 6, 0.0)
+    elif precision == "bf16x6":
+        # SURVEY 8(d) prices the decoder in FLOPs against the MFMA roofline.  In this arithmetic an fp32-exact product IS six
+        # bf16 MFMAs, and the kernels are bound by instruction issue (PMC, profiles/r04_*: matrix pipe 36-50 % busy, the vector
+        # ALU as long again, the two barely overlap within a SIMD), not by their lean records (2.0-2.4 TB/s): bound "mfma",
+        # achieved = ISSUED matrix FLOP/s of the units processed against the dense 16-bit peak; the algorithmic figure and the
+        # HBM view of the same launch sit next to it (matrix_pipe / hbm_view).
+        cost["decoder_fwd"] = ("mfma", DECODER_FLOP_PER_SAMPLE, 0.0, None, _BF16X6, 6, 0.0, io_f + 1024.0 + 32.0, 0.0)
+        cost["decoder_bwd_chain"] = ("mfma", DECODER_FLOP_PER_SAMPLE, 0.0, "tile", _BF16X6, 6, 0.0, io_b + 768.0 + 32.0, dead_b)
+        cost["decoder_wgrad"] = ("mfma", DECODER_FLOP_PER_SAMPLE, 0.0, "tile", _BF16X6, 6, 0.0,
+                                 1024.0 + 768.0 + 32.0 + 16.0 + 128.0 + 12.0, 0.0)
     else:
         cost["decoder_fwd"] = ("mfma", DECODER_FLOP_PER_SAMPLE, 0.0, None, _F32, 1, 0.0)
         cost["decoder_bwd_chain"] = ("mfma", DECODER_FLOP_PER_SAMPLE, 0.0, None, _F32, 1, 0.0)
@@ -937,11 +943,18 @@ def kernel_table(prof, M, precision, live_share, pair_share, with_traffic=True):
     shares = {"tile": live_share, "pair": pair_share, None: 1.0}
     for name, (n_launch, ms) in prof.items():
         mult, share, design = None, 1.0, 0.0
+        hbm_view = None
         if name in cost:
-            bound, per_live, per_dead, liveness, dtype, mult, design = cost[name]
+            bound, per_live, per_dead, liveness, dtype, mult, design = cost[name][:7]
             share = shares[liveness] if shares[liveness] is not None else 1.0
             work = M * (share * per_live + (1.0 - share) * per_dead)
             work_full = M * per_live
+            if bound == "mfma" and mult and mult > 1:           # issued products on the 16-bit pipe
+                work, work_full = work * mult, work_full * mult
+            if len(cost[name]) > 7:
+                hbm_bytes = M * (share * cost[name][7] + (1.0 - share) * cost[name][8])
+                hbm_view = {"algorithmic_bytes_per_launch": round(hbm_bytes, 1), "achieved_GBps": round(hbm_bytes / (ms * 1e-3) / 1e9, 2),
+                            "frac_of_8_TBps": round(hbm_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         elif name == "adam_step":
             bound, dtype, liveness = "hbm", "f32", None
             work = work_full = 28.0 * N_GRID_PARAMS
@@ -950,12 +963,15 @@ def kernel_table(prof, M, precision, live_share, pair_share, with_traffic=True):
         if bound == "hbm":
             scale, peak, unit = 1e9, HBM_PEAK_GBS, "GB/s"
         else:
-            scale, peak, unit = 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+            scale, peak, unit = 1e12, (MFMA_F32_PEAK_TFLOPS if (mult or 1) == 1 else MFMA_F16_PEAK_TFLOPS), "TFLOP/s"
         achieved = work / (ms * 1e-3) / scale
         kernels[name] = {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
                          "frac": round(achieved / peak, 4), "avg_ms": round(ms, 4), "dtype": dtype,
                          "launches": n_launch, "work_per_launch": round(work, 1),
                          "traffic": traffic.get(name), "traffic_uncorrected": traffic_raw.get(name)}
+        if hbm_view is not None:
+            kernels[name]["hbm_view"] = hbm_view
+            kernels[name]["achieved_is"] = f"issued matrix FLOP/s: {mult} bf16 MFMA products per fp32-exact product"
         if design:
             kernels[name]["design_bytes_per_launch"] = round(M * design, 1)
             kernels[name]["design_note"] = "bytes the design moves on top of the algorithmic ones (the Jacobian kept for the backward), not priced"

@@ -15,7 +15,7 @@
 //   (decoder_fwd_lds_kernel: persistent forward with the weight images in LDS for large batches; both forward
 //    kernels also exist in an SDF-only form (JointEncoding.query_sdf, scene_rep.py:106-107), see decoder_fwd_tile.)
 //
-// What these kernels are written around: a wave's vector instructions are NOT hidden behind its own
+// What these kernels are written around (DESIGN_NOTES.md 4b): a wave's vector instructions are NOT hidden behind its own
 // MFMAs (5.7 cycles of kernel time each at one wave per SIMD, 2.5 at two), so everything between the MFMAs is kept
 // to as few instructions as possible: scalar tile bases, buffer addressing, ReLU masks as bits, hardware sin/cos
 // after a two-constant range reduction, packed fp32 fma in the narrow heads, bias gradients from a ones row.
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     // the wave index is made a scalar so that every per-tile base address below is scalar arithmetic: vector
-    // instructions are only partly hidden behind the other wave's MFMAs
+    // instructions are only partly hidden behind the other wave's MFMAs (DESIGN_NOTES.md 4b)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t tile = (int64_t)blockIdx.x * (DEC_BLOCK / 64) + wv;
     if (tile * 32 >= (int64_t)M) return;
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
     auto row_sum = [&](const float* T, int row, int c0, int n) {
         // four 16-byte reads in flight at a time (fully unrolled, the loads of a row sum are all hoisted in front of the
         // adds and their registers, on top of the 128 prefetch registers, push loop invariants into scratch -- and
-        // every scratch reload waits on vmcnt, i.e. for the whole prefetch it was meant to overlap)
+        // every scratch reload waits on vmcnt, i.e. for the whole prefetch it was meant to overlap; DESIGN_NOTES.md 4b)
         const float4* T4 = reinterpret_cast<const float4*>(T + row * WG_LDW + c0);
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll 1
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(DEC_BLOCK, 1) void decoder_wgrad_kernel(
     float4 nx[16], ny[16], nsm;
     float ngf[16];
     // Everything that selects a tile is kept in scalar registers (w is wave-uniform): with one wave per SIMD a
-    // vector instruction is never hidden behind this wave's own MFMAs, so per-load address
+    // vector instruction is never hidden behind this wave's own MFMAs (DESIGN_NOTES.md 4b), so per-load address
     // arithmetic, per-load liveness selects and zero-fills were costing as much as the matrix work they fed.
     // Loads are unconditional from a tile that exists; a dead wave tile (tail of M) zeroes its X operand instead.
     const int n_wtiles = (int)((M + 31u) / 32u);

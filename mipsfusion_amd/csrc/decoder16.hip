@@ -68,7 +68,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
 // 8 fp32 values -> the NP operand planes.  NP = 3: three bf16 pieces, exact (v = p0 + p1 + p2): per pair v_cvt_pk_bf16_f32,
 // the widening of the pair (a shift and a mask), v_pk_add_f32 -- twice -- and the last v_cvt_pk = 4.5 vector instructions per
 // value.  Written with vector types and conversions only (no inline asm: an asm that reads a fresh MFMA result is not
-// hazard-padded by hipcc).
+// hazard-padded by hipcc, DESIGN_NOTES.md 4c).
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 template <int NP>
 __device__ __forceinline__ void cut8(const float (&v)[8], h8 (&pl)[3]) {
@@ -374,7 +374,7 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
     // bf16 mode: the lane index is made opaque per tile, so that the dozen per-lane offsets derived from it (operand slots of
     // the heads, LDS and record addresses) are recomputed by every tile -- a few vector instructions -- instead of living across
     // the persistent kernel's tile loop: with 48 operand registers per layer there they were spilled, and a scratch reload waits
-    // for every memory operation in flight
+    // for every memory operation in flight (DESIGN_NOTES.md 4b)
     int lane = lane_in;
     if constexpr (NP == 3) asm volatile("" : "+v"(lane));
     const int j = lane & 31, h = lane >> 5;

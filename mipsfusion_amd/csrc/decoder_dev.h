@@ -106,7 +106,7 @@ __device__ __forceinline__ void load_bias(const float* tail, int layer, int h, f
 // Buffer addressing: one 128-bit resource (scalar) + a 32-bit lane offset (vector, computed once) + a scalar /
 // immediate offset per access.  A flat `ptr[const + lane]` costs one or two 64-bit vector adds per access as soon as
 // the constant leaves the 4 KB immediate range -- 350 vector instructions per tile in the backward chain, and vector
-// instructions are what the matrix pipe waits for.
+// instructions are what the matrix pipe waits for (DESIGN_NOTES.md 4b).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t srd_t;
 __device__ __forceinline__ srd_t make_srd(const void* base_u, uint32_t bytes) {
