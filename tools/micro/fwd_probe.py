@@ -1,4 +1,4 @@
-"""Forward decoder kernel alone (f16x3) at the headline batch: the evaluation form and the training form (lean record).
+"""Forward decoder kernel alone (MIPSF_PROBE_PREC: bf16x6 | f16x3 | f16) at the headline batch: the evaluation form and the training form (lean record).
 MIPSF_LIB selects an experiment library (tools/micro/variant.sh <name> decoder16 -DD16_ABL=<bits>)."""
 import os
 import sys
@@ -15,7 +15,8 @@ torch.cuda.set_device(0)
 cfg = synth.config_headline()
 model, frames, poses = bench.build_submap(cfg, dev, seed=0)
 M = 262144
-packed16 = ops.decoder_pack16(model.decoder.ordered_parameters())
+PREC = os.environ.get("MIPSF_PROBE_PREC", "bf16x6")
+packed16 = ops.decoder_pack16(model.decoder.ordered_parameters(), precision=PREC)
 x = torch.rand(M, 3, device=dev)
 feat = torch.randn(16, M, 2, device=dev) * 1e-2
 import ctypes as C
@@ -25,7 +26,7 @@ PHASES = ["e (sin)", "layer 1", "relu 1 + masks", "layer 2 (+H1 stores)", "unsca
           "layer 3 (+H2 stores)", "relu 3 + H3 stores + masks", "sdf head", "softmax + out"]
 tracer = getattr(C.CDLL(_lib.LIB_PATH), "mipsf_d16_trace_read", None) if os.environ.get("MIPSF_LIB") else None
 for save in (False, "lean"):
-    fn = lambda: ops.decoder_fwd(None, feat, FEAT_LEVEL_MAJOR, x, None, M, save=save, precision="f16x3", packed16=packed16)   # noqa: E731
+    fn = lambda: ops.decoder_fwd(None, feat, FEAT_LEVEL_MAJOR, x, None, M, save=save, precision=PREC, packed16=packed16)   # noqa: E731
     for _ in range(3):
         fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
