@@ -480,9 +480,39 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
     }
 
     D16_MARK(5);
-    // ---- rgb_linear.0 (3 outputs from [rgb_emb = H2 row tiles 2, 3 | e]) on the matrix pipe: rows 0..2 of one tile
+    // ---- rgb_linear.0 (3 outputs from [rgb_emb = H2 row tiles 2, 3 | e]).  f16 modes: on the matrix pipe, rows 0..2 of one
+    // tile.  bf16 mode: on the VECTOR ALU in plain fp32 fmas against the fp32 table in LDS (this lane's half of every dot product,
+    // then one swap) -- that kernel is bound by the matrix pipe (94 % busy at the sustained clock), the two heads were 96 of its
+    // 544 MFMAs per tile for 8 useful output rows, and the vector ALU has the room: 308 instructions + 186 broadcast LDS reads.
     float rgb[3] = {0.f, 0.f, 0.f};
-    if constexpr (!SDF_ONLY) {
+    if constexpr (!SDF_ONLY && NP == 3) {
+        const float4* trgb = reinterpret_cast<const float4*>(tail) + h * TRGB_SLOTS;
+        f32x2 p01 = {0.f, 0.f};
+        float p2 = 0.f;
+#pragma unroll
+        for (int slot = 0; slot < 32; ++slot) {
+            const float4 wv = trgb[slot];
+            const float v = H2[2 + (slot >> 4)][slot & 15];
+            p01 = __builtin_elementwise_fma(f32x2{wv.x, wv.y}, f32x2{v, v}, p01);
+            p2 = fmaf(wv.z, v, p2);
+            if constexpr (SAVE == 1 || SAVE == 2) {        // the rgb_emb half of H2 leaves piece by piece, as under the MFMA head
+                if ((slot & 7) == 7) {
+                    store_act_piece(sv, lane16, 1, H2, 8 + 2 * (slot >> 3));
+                    store_act_piece(sv, lane16, 1, H2, 8 + 2 * (slot >> 3) + 1);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < E_SLOTS; ++t) {
+            const float4 wv = trgb[32 + t];
+            const float ev_t = e_step(t >> 3, t & 7);
+            p01 = __builtin_elementwise_fma(f32x2{wv.x, wv.y}, f32x2{ev_t, ev_t}, p01);
+            p2 = fmaf(wv.z, ev_t, p2);
+        }
+        const float pr[3] = {p01.x, p01.y, p2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb[c] = (pr[c] + __shfl_xor(pr[c], 32, 64)) + tail[OFF16_BSMALL + c];
+    } else if constexpr (!SDF_ONLY) {
         f32x16 r0, r1;
         mfma16_head<HEAD16_RGB_SLOTS, NPH>(reinterpret_cast<const h8*>(tail) + HEAD16_SDF_HALVES / 8, head16_rgb_slot(j, h),
             img.r2, (uint32_t)EXT16_HEAD_RGB * 2u, r0, r1,
@@ -546,10 +576,36 @@ __device__ __forceinline__ void decoder16_fwd_tile(const float* tail, const Img 
     }
 
     D16_MARK(9);
-    // ---- sdf_linear.2 (5 logits from H3) on the matrix pipe: logit c lands in register c of BOTH halves (decoder_layout.h);
-    // then softmax, entropy, expected class -> SDF
+    // ---- sdf_linear.2 (5 logits from H3): f16 modes on the matrix pipe -- logit c lands in register c of BOTH halves
+    // (decoder_layout.h) --, bf16 mode on the vector ALU (see the rgb head); then softmax, entropy, expected class -> SDF
     float lg[N_CLASS], mx = -3.0e38f;
-    {
+    if constexpr (NP == 3) {
+        const float4* ts2 = reinterpret_cast<const float4*>(tail) + (OFF_TS2 - OFF_TRGB) / 4 + h * 128;
+        f32x2 q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
+        float q4 = 0.f;
+#pragma unroll
+        for (int slot = 0; slot < 64; ++slot) {
+            const float4 w0 = ts2[2 * slot], w1 = ts2[2 * slot + 1];
+            const float v = H3[slot >> 4][slot & 15];
+            q01 = __builtin_elementwise_fma(f32x2{w0.x, w0.y}, f32x2{v, v}, q01);
+            q23 = __builtin_elementwise_fma(f32x2{w0.z, w0.w}, f32x2{v, v}, q23);
+            q4 = fmaf(w1.x, v, q4);
+#ifndef D16_ABL_NO_H3_STORE
+            if constexpr (SAVE == 1 || SAVE == 2) {
+                if ((slot & 7) == 7) {
+                    store_act_piece(sv, lane16, 2, H3, 2 * (slot >> 3));
+                    store_act_piece(sv, lane16, 2, H3, 2 * (slot >> 3) + 1);
+                }
+            }
+#endif
+        }
+        const float pl[N_CLASS] = {q01.x, q01.y, q23.x, q23.y, q4};
+#pragma unroll
+        for (int c = 0; c < N_CLASS; ++c) {
+            lg[c] = (pl[c] + __shfl_xor(pl[c], 32, 64)) + tail[OFF16_BSMALL + 4 + c];
+            mx = fmaxf(mx, lg[c]);
+        }
+    } else {
         f32x16 s0, s1;
         mfma16_head<HEAD16_SDF_SLOTS, NPH>(reinterpret_cast<const h8*>(tail), head16_sdf_slot(j, h), img.r2,
             (uint32_t)EXT16_HEAD_SDF * 2u, s0, s1,
@@ -1097,11 +1153,15 @@ __global__ __launch_bounds__(256) void decoder_pack16_kernel(W w, float* __restr
         const _Float16 hi = (_Float16)v;
         return __builtin_bit_cast(uint16_t, pl == 0 ? hi : (_Float16)(v - (float)hi));
     };
-    if (idx < HEAD16_HALVES) {
+    if (NP == 3) {
+        // the bf16 mode runs its two narrow heads on the VECTOR ALU in plain fp32 (the matrix pipe is what bounds that kernel):
+        // the head region holds the fp32 tables of decoder.hip (rgb: [half][58 slots][4], sdf: [half][64 slots][8])
+        static_assert(OFF_BIAS - OFF_TRGB <= HEAD16_HALVES / 2, "the fp32 head tables fit the head region of the tail");
+        if (idx < OFF_BIAS - OFF_TRGB) packed16[idx] = packed_value(w, OFF_TRGB + idx);
+    } else if (idx < HEAD16_HALVES) {
         int plane;
         const float v = head16_weight(w, idx, plane, NP);
         reinterpret_cast<uint16_t*>(packed16)[idx] = piece(v, plane);
-        if (NP == 3 && plane == 0) ext[head16_ext_index(idx)] = piece(v, 2);
     }
     if (idx < 12) packed16[OFF16_BSMALL + idx] = packed_value(w, OFF_BSMALL + idx);
     if (idx < IMG16H_HALVES) {
