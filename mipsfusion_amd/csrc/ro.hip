@@ -62,11 +62,10 @@ __global__ __launch_bounds__(256) void ro_particles_kernel(const float* __restri
     quat_to_mat(qw, r[0], r[1], r[2], dR);
     mat_mul3(rot, dR, aR);                                            // get_abs_pose
     float t0 = state[RO_TRANS] + r[3], t1 = state[RO_TRANS + 1] + r[4], t2 = state[RO_TRANS + 2] + r[5];
-    // The particle's pose is the same in all 64 lanes by construction; it is taken from lane 0 explicitly.  With TWO processes
-    // time-slicing one GPU (bench.py --gpus 2 on a single device: tests only) ~7 % of the frames had lanes 48..63 of a few
-    // wavefronts of this kernel leave the section above with another pose (tools/dbg_ro_determinism2.py: 0 of 3000 frames
-    // differ run to run with one process per GPU, ~55 of 800 with two; with this broadcast 0 of 3000 with two).  Cause not
-    // established (a stand-alone kernel with the same arithmetic did not reproduce it); the first lanes were never affected.
+    // The particle's pose is the same in all 64 lanes by construction; it is taken from lane 0 explicitly.  The section above
+    // holds packed multiplies (v_pk_mul_f32 of r[] by the search size), and with a second process's wavefronts on the same CUs
+    // their high halves can come back wrong in lanes 48..63 -- never in the first lanes (the note in the loop below; round 3 saw
+    // ~55 of 800 frames leave this section with another pose in those lanes).
 #ifdef MIPSF_RO_LANE_CHECK
     {
         unsigned long long differ = 0ull;
@@ -98,12 +97,80 @@ __global__ __launch_bounds__(256) void ro_particles_kernel(const float* __restri
     t0 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(t0)));
     t1 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(t1)));
     t2 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(t2)));
+#if MIPSF_RO_PACKED == 2   // reproducer build: the rotation back in VGPRs (hipcc then packs the multiplies from VGPR pairs)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) asm volatile("v_mov_b32 %0, %0" : "+v"(aR[k]));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(t0));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(t1));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(t2));
+#endif
     for (uint32_t i = lane; i < n; i += MIPSF_WAVE) {
         const float d = target_d[i];
         const float c0 = rays_d_cam[3 * i] * d, c1 = rays_d_cam[3 * i + 1] * d, c2 = rays_d_cam[3 * i + 2] * d;
+#if MIPSF_RO_PACKED >= 3   // diagnosis builds: hipcc's instruction sequence for the transform verbatim (3), and with ONE change each:
+                           // 4 the packed add with the crossed op_sel as two single adds; 5 the packed multiply that feeds it as two
+                           // single multiplies; 6 verbatim after 32 idle cycles; 7 the packed multiply's result copied before use
+        float w0, w1, w2;
+        {
+            const float r0 = rays_d_cam[3 * i], r1 = rays_d_cam[3 * i + 1], r2 = rays_d_cam[3 * i + 2];
+#define RO_S(k) (int)__float_as_uint(aR[k])
+            asm volatile(
+                "s_mov_b32 s68, %[a1]\n s_mov_b32 s69, %[a3]\n s_mov_b32 s62, %[a4]\n s_mov_b32 s63, %[a0]\n"
+                "s_mov_b32 s70, %[a2]\n s_mov_b32 s71, %[a5]\n s_mov_b32 s73, %[a6]\n s_mov_b32 s82, %[a7]\n"
+                "s_mov_b32 s83, %[a8]\n s_mov_b32 s74, %[t0]\n s_mov_b32 s75, %[t1]\n s_mov_b32 s84, %[t2]\n"
+                "v_mov_b32 v112, %[d]\n v_mov_b32 v113, %[r2]\n v_mov_b32 v114, %[r1]\n v_mov_b32 v115, %[r0]\n v_mov_b32 v117, 0\n"
+#if MIPSF_RO_PACKED == 6
+                "s_nop 15\n s_nop 15\n"
+#endif
+                "v_mul_f32_e32 v116, v112, v113\n"
+                "v_pk_mul_f32 v[112:113], v[112:113], v[114:115] op_sel_hi:[0,1]\n"
+                "v_pk_mul_f32 v[114:115], s[68:69], v[112:113]\n"
+#if MIPSF_RO_PACKED == 5
+                "v_mul_f32_e32 v118, s62, v112\n v_mul_f32_e32 v119, s63, v113\n"
+#else
+                "v_pk_mul_f32 v[118:119], s[62:63], v[112:113]\n"
+#endif
+                "v_mul_f32_e32 v113, s73, v113\n"
+#if MIPSF_RO_PACKED == 4
+                "v_add_f32_e32 v114, v114, v119\n v_add_f32_e32 v115, v115, v118\n"
+#elif MIPSF_RO_PACKED == 7
+                "v_mov_b32 v120, v119\n v_mov_b32 v121, v118\n"
+                "v_pk_add_f32 v[114:115], v[114:115], v[120:121]\n"
+#else
+                "v_pk_add_f32 v[114:115], v[114:115], v[118:119] op_sel:[0,1] op_sel_hi:[1,0]\n"
+#endif
+                "v_pk_mul_f32 v[118:119], s[70:71], v[116:117] op_sel_hi:[1,0]\n"
+                "v_mul_f32_e32 v112, s82, v112\n"
+                "v_pk_add_f32 v[114:115], v[114:115], v[118:119]\n"
+                "v_add_f32_e32 v112, v113, v112\n"
+                "v_mul_f32_e32 v113, s83, v116\n"
+                "v_pk_add_f32 v[114:115], s[74:75], v[114:115]\n"
+                "v_add_f32_e32 v112, v112, v113\n"
+                "v_add_f32_e32 v130, s84, v112\n"
+                "v_mov_b32 %[o0], v114\n v_mov_b32 %[o1], v115\n v_mov_b32 %[o2], v130\n"
+                : [o0] "=v"(w0), [o1] "=v"(w1), [o2] "=v"(w2)
+                : [d] "v"(d), [r0] "v"(r0), [r1] "v"(r1), [r2] "v"(r2), [a0] "s"(RO_S(0)), [a1] "s"(RO_S(1)), [a2] "s"(RO_S(2)),
+                  [a3] "s"(RO_S(3)), [a4] "s"(RO_S(4)), [a5] "s"(RO_S(5)), [a6] "s"(RO_S(6)), [a7] "s"(RO_S(7)), [a8] "s"(RO_S(8)),
+                  [t0] "s"((int)__float_as_uint(t0)), [t1] "s"((int)__float_as_uint(t1)), [t2] "s"((int)__float_as_uint(t2))
+                : "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v130", "s62", "s63", "s68", "s69",
+                  "s70", "s71", "s73", "s74", "s75", "s82", "s83", "s84");
+#undef RO_S
+        }
+#elif MIPSF_RO_PACKED      // reproducer builds (tools/micro/ro_diag.sh): the products as hipcc packs them (v_pk_mul_f32)
         const float w0 = ((aR[0] * c0 + aR[1] * c1) + aR[2] * c2) + t0;     // batch_points_trans
         const float w1 = ((aR[3] * c0 + aR[4] * c1) + aR[5] * c2) + t1;
         const float w2 = ((aR[6] * c0 + aR[7] * c1) + aR[8] * c2) + t2;
+#else
+        // The nine products are issued as single v_mul_f32.  Left to hipcc they become v_pk_mul_f32 pairs, and with a SECOND
+        // PROCESS's wavefronts on the same CUs the high half of such a product came back as 0 in lanes 48..63 of about one
+        // wavefront-iteration in 10^6 (182 of 12000 launches with the packed form -- SGPR-pair or VGPR-pair sources
+        // alike --, 0 of 12000 with this one, same box, alternating builds; never with one process on the GPU).
+        float m[9];
+#define RO_MUL(k, c) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m[k]) : "s"(aR[k]), "v"(c))
+        RO_MUL(0, c0); RO_MUL(1, c1); RO_MUL(2, c2); RO_MUL(3, c0); RO_MUL(4, c1); RO_MUL(5, c2); RO_MUL(6, c0); RO_MUL(7, c1); RO_MUL(8, c2);
+#undef RO_MUL
+        const float w0 = ((m[0] + m[1]) + m[2]) + t0, w1 = ((m[3] + m[4]) + m[5]) + t1, w2 = ((m[6] + m[7]) + m[8]) + t2;   // batch_points_trans
+#endif
         // point_major: sample index = point * P + particle -- the 64 samples of a hash-grid wavefront are then 64
         // particles' copies of ONE lattice point (a few cm apart: same or neighbouring cells on every level)
         // instead of 64 lattice points scattered over the depth image

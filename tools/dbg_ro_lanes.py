@@ -18,6 +18,12 @@ from mipsfusion_amd.RandomOptimizer import RandomOptimizer, _POINT_MAJOR
 N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 3000
 load = "--load" in sys.argv
 dev = torch.device("cuda:0")
+other = None
+if "--beside" in sys.argv:        # a second process that runs local-BA mapping steps on the same GPU (persistent kernels that
+    import subprocess             # hold a CU's whole LDS: the two processes are time-sliced)
+    other = subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "ba_load.py"), "--seconds", "200"],
+                             stdout=subprocess.PIPE, text=True, env={k: v for k, v in os.environ.items() if k != "MIPSF_LIB"})
+    assert other.stdout.readline().strip() == "READY"
 cfg = synth.config_headline()
 cfg["tracking"]["RO"].setdefault("initial_scaling_factor", 0.02)
 cfg["tracking"]["RO"].setdefault("rescaling_factor", 0.5)
@@ -39,18 +45,67 @@ rc = model._rc(1, 0)
 ws = model.decoder.ordered_parameters()
 pk = ops.decoder_pack16(ws, precision="f16x3")
 first = None
-bad = 0
+cnt = {"xn": 0, "pst7": 0, "feat": 0, "sdf": 0, "fit": 0}
+detail = []
+faulty = []
 for k in range(N):
     xn, pst7 = ops.ro_particles(ro.pre_sampled_particle, state.clone(), ro._dirs[0], td, rc, point_major=_POINT_MAJOR)
+    cur = {"xn": xn, "pst7": pst7}
     if load:
         feat = ops.hashgrid_fwd(xn, model.embed_fn.params.detach(), model.embed_fn.meta, FEAT_LEVEL_MAJOR)
-        ops.decoder_fwd_sdf(None, feat, FEAT_LEVEL_MAJOR, xn, None, xn.shape[0], precision="f16x3", packed16=pk)
+        sdf = ops.decoder_fwd_sdf(None, feat, FEAT_LEVEL_MAJOR, xn, None, xn.shape[0], precision="f16x3", packed16=pk)
+        fit = ops.ro_fitness(sdf.view(ro.particle_size, -1, 1), td, ro.trunc_value, point_major=_POINT_MAJOR)
+        cur.update(feat=feat, sdf=sdf, fit=fit)
     if first is None:
-        first = xn.clone()
-    elif not torch.equal(xn, first):
-        bad += 1
+        first = {a: b.clone() for a, b in cur.items()}
+        continue
+    for a, b in cur.items():
+        if not torch.equal(b, first[a]):
+            cnt[a] += 1
+            if len(detail) < 8:
+                d = (b.float() - first[a].float()).abs().reshape(-1)
+                nz = (d > 0).nonzero().reshape(-1)
+                detail.append(f"launch {k}: {a}: {int(nz.numel())} elements differ (max {float(d.max()):.3e}), flat indices {nz[:6].tolist()} .. {int(nz[-1])}")
+            if a == "xn" and len(faulty) < 64:
+                faulty.append((k, b.clone()))
 torch.cuda.synchronize()
-print(f"pid {os.getpid()}: {bad} of {N} launches produced points that differ from the first launch's")
+print(f"pid {os.getpid()}{' beside ba_load' if other else ''}: of {N} launches, stage outputs differing from the first launch's: {cnt}")
+for ln in detail:
+    print("   ", ln)
+if other is not None:
+    other.terminate()
+if faulty:
+    # what the wrong lanes computed: undo the normalisation (world = xn * norm_factor * div + sub) and fit the difference from the
+    # right world coordinate as  da . c + dt  over the faulty lanes (c = the lattice point in camera coordinates): a wave-uniform
+    # wrong operand (a rotation row or the translation) fits exactly, a per-lane arithmetic error does not
+    P, n = ro.pre_sampled_particle.shape[0], td.shape[0]
+    sub = np.array([-rc.half_len[d] for d in range(3)]) if not rc.use_bound else np.array([rc.bound_min[d] for d in range(3)])
+    div = np.array([2 * rc.half_len[d] for d in range(3)]) if not rc.use_bound else np.array([rc.bound_max[d] - rc.bound_min[d] for d in range(3)])
+    nf = rc.norm_factor
+    cam = (ro._dirs[0].double() * td.double()[:, None]).cpu().numpy()             # [n,3]
+    good = first["xn"].double().cpu().numpy().reshape(n, P, 3) if _POINT_MAJOR else first["xn"].double().cpu().numpy().reshape(P, n, 3).transpose(1, 0, 2)
+    world_good = good * nf * div + sub                                            # [n,P,3]
+    print(f"  P {P} particles, n {n} lattice points, norm sub {sub.tolist()} div {div.tolist()} factor {nf}")
+    for k, b in faulty[:24]:
+        bad = b.double().cpu().numpy().reshape(n, P, 3) if _POINT_MAJOR else b.double().cpu().numpy().reshape(P, n, 3).transpose(1, 0, 2)
+        ii, pp, cc = np.nonzero(bad != good)
+        world_bad = bad * nf * div + sub
+        for p_ in sorted(set(pp.tolist())):
+            for c_ in sorted(set(cc[pp == p_].tolist())):
+                pts = np.sort(ii[(pp == p_) & (cc == c_)])
+                dw = world_bad[pts, p_, c_] - world_good[pts, p_, c_]
+                A = np.concatenate([cam[pts], np.ones((len(pts), 1))], axis=1)
+                sol, res, *_ = np.linalg.lstsq(A, dw, rcond=None)
+                fit_err = np.abs(A @ sol - dw).max()
+                # does another particle's pose give these values?
+                other_match = [int(q) for q in range(P) if np.abs(world_good[pts, q, c_] - world_bad[pts, p_, c_]).max() < 1e-6]
+                other_comp = [c2 for c2 in range(3) if np.abs(world_good[pts, p_, c2] - world_bad[pts, p_, c_]).max() < 1e-6]
+                Aall = np.concatenate([cam, np.ones((n, 1))], axis=1)
+                rows = [np.linalg.lstsq(Aall, world_good[:, p_, c2], rcond=None)[0] for c2 in range(3)]   # the particle's aR rows | t
+                print(f"      the particle's pose: row0 {np.round(rows[0], 5).tolist()} row1 {np.round(rows[1], 5).tolist()} row2 {np.round(rows[2], 5).tolist()}")
+                print(f"    launch {k}: particle {p_} (wave {p_ % 4} of block {p_ // 4}), component {c_}, points {pts[0]}..{pts[-1]} ({len(pts)}): "
+                      f"world diff {dw.min():+.4f}..{dw.max():+.4f}; fit da {np.round(sol[:3], 5).tolist()} dt {sol[3]:+.5f} max error {fit_err:.2e}; "
+                      f"equals particle(s) {other_match} same component; equals own component(s) {other_comp}")
 lib = _lib.lib()
 if hasattr(lib, "mipsf_ro_chk_read"):
     cnt = C.c_uint(0)

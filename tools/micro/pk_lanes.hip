@@ -1,0 +1,271 @@
+// Stand-alone reproducer for the "lanes 48..63" fault: a kernel shaped like ro_particles_kernel -- one wavefront per
+// particle, four global loads per lattice point, the rigid transform as hipcc packs it (v_pk_mul_f32 / v_pk_add_f32), three fp64
+// normalisations, a 12-byte store -- launched over and over on the same inputs; every launch's output is compared with the first
+// launch's on the device.  With one process on the GPU no launch ever differs.  Beside a SECOND PROCESS whose kernels hold the CUs'
+// LDS and keep the matrix cores busy (this program's `neighbour` mode, or tools/ba_load.py) some launches differ: 16 values, the
+// x coordinate of lanes 48..63 of one wavefront-iteration, short of exactly the product that hipcc placed in the HIGH half of a
+// v_pk_mul_f32.
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o pk_lanes pk_lanes.hip
+//   ./pk_lanes neighbour 60 &            # second process: persistent 160 KB-LDS MFMA kernels for 60 s
+//   ./pk_lanes packed 20                 # 20 s of launches, packed multiplies      -> "N of M launches differ"
+//   ./pk_lanes single 20                 # the same with nine single v_mul_f32      -> 0
+//   ./pk_lanes packed 20 inproc[:kind]   # neighbour kernels on a second stream of THIS process instead of a second process
+//   ./pk_lanes neighbour 60 kind:6       # (kinds: see neighbour<KIND>)
+//   ./pk_lanes lib:<path to a libmipsf_hip build> 20     # the library's own mipsf_ro_particles_pm on the same inputs
+//                                          (tools/micro/libv_ropk1.so = the packed build, mipsfusion_amd/libmipsf_hip.so = the product)
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include "mipsf.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <unistd.h>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
+
+struct Norm { double sub[3], div[3], nf; };
+
+template <bool PACKED>
+__global__ __launch_bounds__(256) void particles(const float* __restrict__ pose, const float* __restrict__ dirs,
+                                                 const float* __restrict__ depth, Norm nc, float* __restrict__ xn,
+                                                 unsigned P, unsigned n) {
+    const unsigned p = (blockIdx.x * blockDim.x + threadIdx.x) / 64u, lane = threadIdx.x & 63u;
+    if (p >= P) return;
+    float a[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a[k] = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(pose[12 * p + k])));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(pose[12 * p + 9 + k])));
+    for (unsigned i = lane; i < n; i += 64u) {
+        const float d = depth[i];
+        const float c0 = dirs[3 * i] * d, c1 = dirs[3 * i + 1] * d, c2 = dirs[3 * i + 2] * d;
+        float w0, w1, w2;
+        if (PACKED) {
+            w0 = ((a[0] * c0 + a[1] * c1) + a[2] * c2) + t[0];
+            w1 = ((a[3] * c0 + a[4] * c1) + a[5] * c2) + t[1];
+            w2 = ((a[6] * c0 + a[7] * c1) + a[8] * c2) + t[2];
+        } else {
+            float m[9];
+#define MUL(k, c) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m[k]) : "s"(a[k]), "v"(c))
+            MUL(0, c0); MUL(1, c1); MUL(2, c2); MUL(3, c0); MUL(4, c1); MUL(5, c2); MUL(6, c0); MUL(7, c1); MUL(8, c2);
+#undef MUL
+            w0 = ((m[0] + m[1]) + m[2]) + t[0], w1 = ((m[3] + m[4]) + m[5]) + t[1], w2 = ((m[6] + m[7]) + m[8]) + t[2];
+        }
+        float* o = xn + 3 * ((size_t)i * P + p);
+        o[0] = (float)((((double)w0 - nc.sub[0]) / nc.div[0]) / nc.nf);
+        o[1] = (float)((((double)w1 - nc.sub[1]) / nc.div[1]) / nc.nf);
+        o[2] = (float)((((double)w2 - nc.sub[2]) / nc.div[2]) / nc.nf);
+    }
+}
+
+// how many values differ from the reference output, and which (component, lane-of-wavefront) they are
+__global__ void compare(const float* __restrict__ got, const float* __restrict__ ref, size_t count, unsigned P,
+                        unsigned long long* __restrict__ out) {
+    for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < count; k += (size_t)gridDim.x * blockDim.x)
+        if (__float_as_uint(got[k]) != __float_as_uint(ref[k])) {
+            const unsigned comp = (unsigned)(k % 3), point = (unsigned)((k / 3) / P);
+            atomicAdd(out, 1ull);
+            atomicOr(out + 1, 1ull << (point & 63u));
+            atomicOr(out + 2, 1ull << comp);
+        }
+}
+
+typedef short bf8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+// the neighbour: one workgroup per CU, the CU's whole LDS, two wavefronts per SIMD.  KIND selects the instruction mix of its loop:
+//   0 LDS reads feeding a chain of bf16 MFMAs      1 v_cvt_pk_bf16_f32      2 v_pk_fma_f32      3 v_pk_add_f32 with a crossed op_sel
+//   4 v_sin_f32      5 ds_bpermute_b32      6 MFMA + cvt_pk + pk_fma (the decoder's mix)      7 ds_read/ds_write_b128 + s_barrier
+//   8 global loads and stores      9 straight-line code twice the size of the instruction cache
+template <int KIND>
+__global__ __launch_bounds__(512) void neighbour(unsigned iters, float* __restrict__ sink) {
+    extern __shared__ bf8 tile[];
+    const unsigned T = 160 * 1024 / 16;
+    for (unsigned k = threadIdx.x; k < T; k += 512) {
+        bf8 v;
+        for (int j = 0; j < 8; ++j) v[j] = (short)(0x3c00 + ((k + j) & 63));
+        tile[k] = v;
+    }
+    __syncthreads();
+    f16v acc = {};
+    float a = 1.0f + threadIdx.x * 1e-3f, b = 0.5f, c = 0.25f, e = 2.0f;
+    for (unsigned i = 0; i < iters; ++i) {
+        if (KIND == 0 || KIND == 6) {
+            const bf8 x = tile[(threadIdx.x + 61u * i) % T], y = tile[(threadIdx.x * 3u + 17u * i) % T];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, x, acc, 0, 0, 0);
+        }
+        if (KIND == 1 || KIND == 6)
+            asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n v_cvt_pk_bf16_f32 %1, %0, %2\n v_cvt_pk_bf16_f32 %0, %1, %2\n v_cvt_pk_bf16_f32 %1, %0, %2"
+                         : "+v"(a), "+v"(b) : "v"(c));
+        if (KIND == 2 || KIND == 6) {
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 x = {a, b}, y = {c, e};
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %1\n v_pk_fma_f32 %0, %0, %1, %1\n v_pk_fma_f32 %0, %0, %1, %1\n v_pk_fma_f32 %0, %0, %1, %1"
+                         : "+v"(x) : "v"(y));
+            a = x[0] * 1e-30f + 1.0f, b = x[1] * 1e-30f + 0.5f;
+        }
+        if (KIND == 3) {
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 x = {a, b}, y = {c, e};
+            asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]\n v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]\n"
+                         "v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]\n v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]"
+                         : "+v"(x) : "v"(y));
+            a = x[0] * 1e-30f + 1.0f, b = x[1] * 1e-30f + 0.5f;
+        }
+        if (KIND == 4) asm volatile("v_sin_f32 %0, %0\n v_sin_f32 %1, %1\n v_sin_f32 %0, %0\n v_sin_f32 %1, %1" : "+v"(a), "+v"(b));
+        if (KIND == 5) {
+            int idx = (int)((threadIdx.x * 4u + 128u) & 255u), v = (int)__float_as_uint(a);
+            asm volatile("ds_bpermute_b32 %0, %1, %0\n s_waitcnt lgkmcnt(0)\n ds_bpermute_b32 %0, %1, %0\n s_waitcnt lgkmcnt(0)" : "+v"(v) : "v"(idx));
+            a = __uint_as_float((unsigned)v);
+        }
+        if (KIND == 7) {
+            bf8 x = tile[(threadIdx.x + 61u * i) % T];
+            __syncthreads();
+            tile[(threadIdx.x * 5u + 13u * i) % T] = x;
+            __syncthreads();
+        }
+        if (KIND == 9) {      // 128 KB of straight-line code, run through over and over: twice the instruction cache the CUs share
+#define R4(x) x x x x
+#define R16(x) R4(R4(x))
+#define R256(x) R16(R16(x))
+            R16(R256(asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %1, %1, %0, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %1, %1, %0, %2" : "+v"(a), "+v"(b) : "v"(c));))
+        }
+        if (KIND == 8) {
+            float* q = sink + 1024 + ((threadIdx.x + blockIdx.x * 512u + i * 7919u) & ((1u << 22) - 1u));
+            *q = *q + 1.0f;
+        }
+    }
+    float s = a + b;
+    for (int j = 0; j < 16; ++j) s += acc[j];
+    if (s == 12345.f) sink[threadIdx.x] = s;
+}
+
+typedef void (*neighbour_fn)(unsigned, float*);
+static neighbour_fn neighbour_of(int kind) {
+    switch (kind) {
+        case 1: return neighbour<1>; case 2: return neighbour<2>; case 3: return neighbour<3>; case 4: return neighbour<4>;
+        case 5: return neighbour<5>; case 6: return neighbour<6>; case 7: return neighbour<7>; case 8: return neighbour<8>;
+        case 9: return neighbour<9>;
+        default: return neighbour<0>;
+    }
+}
+
+int main(int argc, char** argv) {
+    const char* mode = argc > 1 ? argv[1] : "packed";
+    const double seconds = argc > 2 ? atof(argv[2]) : 10.0;
+    const bool inproc = argc > 3 && !strncmp(argv[3], "inproc", 6);
+    const int kind = argc > 3 && strchr(argv[3], ':') ? atoi(strchr(argv[3], ':') + 1) : 0;       // "inproc:6", "kind:6" (neighbour mode)
+    const neighbour_fn nb = neighbour_of(kind);
+    const unsigned nb_iters = kind == 7 ? 3000u : kind == 8 ? 4000u : kind == 9 ? 10u : 20000u;
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    float* sink;
+    CHECK(hipMalloc(&sink, 4096 + (sizeof(float) << 22)));
+    CHECK(hipFuncSetAttribute((const void*)nb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const auto t0 = std::chrono::steady_clock::now();
+    auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    if (!strcmp(mode, "neighbour")) {
+        unsigned launches = 0;
+        while (elapsed() < seconds) {
+            for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(nb, dim3(prop.multiProcessorCount), dim3(512), 160 * 1024, 0, nb_iters, sink);
+            CHECK(hipDeviceSynchronize());
+            launches += 8;
+        }
+        printf("neighbour kind %d pid %d: %u launches in %.1f s\n", kind, (int)getpid(), launches, elapsed());
+        return 0;
+    }
+    const bool packed = !strcmp(mode, "packed");
+    typedef int (*ro_fn)(const float*, const float*, const float*, const float*, const mipsf_render_cfg*, float*, float*, uint32_t,
+                         uint32_t, void*);
+    ro_fn ro = nullptr;
+    if (!strncmp(mode, "lib:", 4)) {
+        void* h = dlopen(mode + 4, RTLD_NOW);
+        if (!h) { fprintf(stderr, "%s\n", dlerror()); return 2; }
+        ro = (ro_fn)dlsym(h, "mipsf_ro_particles_pm");
+        if (!ro) { fprintf(stderr, "no mipsf_ro_particles_pm in %s\n", mode + 4); return 2; }
+    }
+    const unsigned P = 2000, n = 384;
+    std::vector<float> pose(12 * P), dirs(3 * n), depth(n);
+    srand(1);
+    auto rnd = [] { return (float)rand() / (float)RAND_MAX; };
+    for (unsigned p = 0; p < P; ++p) {
+        const float base[12] = {0.962f, -0.059f, 0.266f, 0.011f, 0.984f, 0.178f, -0.272f, -0.169f, 0.947f, 1.168f, 3.796f, 0.946f};
+        for (int k = 0; k < 12; ++k) pose[12 * p + k] = base[k] + 0.02f * (rnd() - 0.5f);
+    }
+    for (unsigned i = 0; i < n; ++i) {
+        dirs[3 * i] = rnd() - 0.5f, dirs[3 * i + 1] = 0.8f * (rnd() - 0.5f), dirs[3 * i + 2] = 1.0f;
+        depth[i] = 0.8f + 2.2f * rnd();
+    }
+    float *d_pose, *d_dirs, *d_depth, *d_xn, *d_ref;
+    unsigned long long* d_out;
+    const size_t count = (size_t)3 * P * n;
+    CHECK(hipMalloc(&d_pose, pose.size() * 4));
+    CHECK(hipMalloc(&d_dirs, dirs.size() * 4));
+    CHECK(hipMalloc(&d_depth, depth.size() * 4));
+    CHECK(hipMalloc(&d_xn, count * 4));
+    CHECK(hipMalloc(&d_ref, count * 4));
+    CHECK(hipMalloc(&d_out, 32));
+    CHECK(hipMemcpy(d_pose, pose.data(), pose.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_dirs, dirs.data(), dirs.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_depth, depth.data(), depth.size() * 4, hipMemcpyHostToDevice));
+    const Norm nc = {{-0.6, 0.5, -1.15}, {3.5500000000000003, 6.55, 4.199999999999999}, 1.0};
+    hipStream_t side;
+    CHECK(hipStreamCreate(&side));
+    // library mode: a 6-D particle template, the search state (rotation, translation, search size) and the render configuration
+    std::vector<float> pst(6 * P), state(MIPSF_RO_STATE_FLOATS, 0.f);
+    for (auto& v : pst) v = 2.f * rnd() - 1.f;
+    for (int k = 0; k < 6; ++k) pst[k] = 0.f;
+    const float base[12] = {0.962f, -0.059f, 0.266f, 0.011f, 0.984f, 0.178f, -0.272f, -0.169f, 0.947f, 1.168f, 3.796f, 0.946f};
+    for (int k = 0; k < 12; ++k) state[k] = base[k];
+    for (int k = 0; k < 6; ++k) state[12 + k] = 0.02f;
+    mipsf_render_cfg rc;
+    memset(&rc, 0, sizeof rc);
+    rc.n_uniform = 1, rc.use_bound = 0, rc.norm_factor = 1.0;
+    rc.half_len[0] = 0.6, rc.half_len[1] = 3.275, rc.half_len[2] = 2.1;
+    float *d_pst, *d_state, *d_pst7;
+    CHECK(hipMalloc(&d_pst, pst.size() * 4));
+    CHECK(hipMalloc(&d_state, state.size() * 4));
+    CHECK(hipMalloc(&d_pst7, 7 * P * 4));
+    CHECK(hipMemcpy(d_pst, pst.data(), pst.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_state, state.data(), state.size() * 4, hipMemcpyHostToDevice));
+    auto launch = [&](float* dst) {
+        if (ro) {
+            if (ro(d_pst, d_state, d_dirs, d_depth, &rc, dst, d_pst7, P, n, nullptr) != 0) { fprintf(stderr, "mipsf_ro_particles_pm failed\n"); exit(2); }
+            return;
+        }
+        if (packed) hipLaunchKernelGGL(particles<true>, dim3(P / 4), dim3(256), 0, 0, d_pose, d_dirs, d_depth, nc, dst, P, n);
+        else hipLaunchKernelGGL(particles<false>, dim3(P / 4), dim3(256), 0, 0, d_pose, d_dirs, d_depth, nc, dst, P, n);
+    };
+    for (int tries = 0;; ++tries) {      // the reference output: one that two consecutive launches agree on
+        launch(d_ref);
+        launch(d_xn);
+        CHECK(hipMemset(d_out, 0, 32));
+        hipLaunchKernelGGL(compare, dim3(1024), dim3(256), 0, 0, d_xn, d_ref, count, P, d_out);
+        unsigned long long h[4];
+        CHECK(hipMemcpy(h, d_out, 32, hipMemcpyDeviceToHost));
+        if (!h[0]) break;
+        if (tries == 20) { fprintf(stderr, "no two consecutive launches agree\n"); return 3; }
+    }
+    unsigned launches = 0, differing = 0;
+    unsigned long long values = 0, lanes = 0, comps = 0;
+    while (elapsed() < seconds) {
+        if (inproc) hipLaunchKernelGGL(nb, dim3(prop.multiProcessorCount), dim3(512), 160 * 1024, side, nb_iters, sink);
+        for (int k = 0; k < 16; ++k) {
+            CHECK(hipMemsetAsync(d_out, 0, 32, 0));
+            launch(d_xn);
+            hipLaunchKernelGGL(compare, dim3(1024), dim3(256), 0, 0, d_xn, d_ref, count, P, d_out);
+            unsigned long long h[4];
+            CHECK(hipMemcpy(h, d_out, 32, hipMemcpyDeviceToHost));
+            ++launches;
+            if (h[0]) ++differing, values += h[0], lanes |= h[1], comps |= h[2];
+        }
+    }
+    CHECK(hipDeviceSynchronize());
+    if (inproc) printf("[neighbour kind %d] ", kind);
+    printf("%s%s pid %d: %u of %u launches differ from the first launch (%llu values; lanes 0x%016llx, components 0x%llx) in %.1f s\n",
+           mode, inproc ? " (neighbour kernels in this process)" : "", (int)getpid(), differing, launches, values, lanes, comps, elapsed());
+    return 0;
+}
