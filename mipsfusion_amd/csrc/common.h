@@ -64,6 +64,18 @@ inline NormCfg make_norm(const mipsf_render_cfg& c) {
     return n;
 }
 
+// MIPSF_SINGLE_FP32 on a kernel: no packed fp32 instructions in it (v_pk_{add,mul,fma}_f32; everything inlined into the kernel
+// follows).  It marks every kernel in which hipcc would otherwise emit a packed operation whose LOW result reads the HIGH half of a
+// source (a 1 in op_sel): on gfx950 that operand was read as 0 in lanes 48..63 of about one wavefront-iteration in 10^5..10^6 while
+// the decoder's forward and backward kernels alternated on the same CUs -- another stream or another process; DESIGN.md 4h,
+// reproducers tools/dbg_ro_inproc.py and tools/micro/pk_lanes.hip.  tools/audit_packed.py (run by tests/test_host_cpu.py) lists
+// the kernels that hold such an operation: none may.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MIPSF_KEEP_PACKED_FP32)
+#define MIPSF_SINGLE_FP32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define MIPSF_SINGLE_FP32
+#endif
+
 __device__ __forceinline__ float normalise1(float p, double sub, double div, double nf) {
     return (float)((((double)p - sub) / div) / nf);
 }

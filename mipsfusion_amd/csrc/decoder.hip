@@ -189,7 +189,7 @@ __device__ __forceinline__ void decoder_fwd_tile(const float* tail, const float4
 }
 
 template <bool PE_INTERNAL, int LAYOUT, bool SAVE, bool SDF_ONLY = false>
-__global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_fwd_kernel(const float* __restrict__ packed,
+MIPSF_SINGLE_FP32 __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_fwd_kernel(const float* __restrict__ packed,
                                                                 const float* __restrict__ feat,
                                                                 const float* __restrict__ x,
                                                                 const float* __restrict__ embed_pos,
@@ -216,7 +216,7 @@ constexpr int FWD_LDS_FLOATS = OFF_B3 - OFF_F1;
 constexpr int FWD_LDS_BYTES = FWD_LDS_FLOATS * 4 + TAIL_F4 * 16;
 constexpr int FWD_LDS_BLOCK = 512;
 template <bool PE_INTERNAL, int LAYOUT, bool SAVE, bool SDF_ONLY = false>
-__global__ __launch_bounds__(FWD_LDS_BLOCK, 1) void decoder_fwd_lds_kernel(const float* __restrict__ packed,
+MIPSF_SINGLE_FP32 __global__ __launch_bounds__(FWD_LDS_BLOCK, 1) void decoder_fwd_lds_kernel(const float* __restrict__ packed,
                                                                         const float* __restrict__ feat,
                                                                         const float* __restrict__ x,
                                                                         const float* __restrict__ embed_pos,
@@ -312,7 +312,7 @@ __device__ __forceinline__ void mfma_layer_b4(srd_t wsrd, uint32_t img_off, uint
 }
 
 template <bool PE_INTERNAL, int LAYOUT>
-__global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
+MIPSF_SINGLE_FP32 __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder_bwd_lds_kernel(
     const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ out,
     const float* __restrict__ dout, const float* __restrict__ saved, float* __restrict__ dfeat,
     float* __restrict__ dx, float* __restrict__ dembed_pos, float* __restrict__ dact, float* __restrict__ dsmall,

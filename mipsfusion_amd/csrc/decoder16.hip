@@ -687,7 +687,7 @@ __device__ __forceinline__ void lds_preload(float4* dst, const void* src_base, i
 
 // Small batches: four independent waves per workgroup, operand images from L2, head tables + biases in LDS.
 template <int LAYOUT, int SAVE, bool SDF_ONLY, int NP>
-__global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_fwd_kernel(const float* __restrict__ packed16,
+MIPSF_SINGLE_FP32 __global__ __launch_bounds__(DEC_BLOCK, 2) void decoder16_fwd_kernel(const float* __restrict__ packed16,
                                                                      const float* __restrict__ feat,
                                                                      const float* __restrict__ x,
                                                                      float* __restrict__ out,
@@ -721,7 +721,7 @@ constexpr int F16_LDS_BLOCK = 512;
 template <int NP>
 constexpr int f16_lds_bytes() { return TAIL16_FLOATS * 4 + IMG16H_HALVES * 2 + (NP >= 2 ? IMG16L_HALVES * 2 : 0); }
 template <int LAYOUT, int SAVE, bool SDF_ONLY, int NP>
-__global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_fwd_lds_kernel(const float* __restrict__ packed16,
+MIPSF_SINGLE_FP32 __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_fwd_lds_kernel(const float* __restrict__ packed16,
                                                                              const float* __restrict__ feat,
                                                                              const float* __restrict__ x,
                                                                              float* __restrict__ out,

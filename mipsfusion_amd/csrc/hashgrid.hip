@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(256) void hashgrid_scatter_reduce_kernel(float* __r
 
 // dL/dx of one level per thread (tcnn kernel_grid_backward_input); written to per-level partials, no atomics
 template <int LAYOUT>
-__global__ __launch_bounds__(HG_BLOCK) void hashgrid_dx_kernel(const float* __restrict__ x,
+MIPSF_SINGLE_FP32 __global__ __launch_bounds__(HG_BLOCK) void hashgrid_dx_kernel(const float* __restrict__ x,
                                                                const float2* __restrict__ table,
                                                                const float* __restrict__ dout,
                                                                float* __restrict__ dxl, uint32_t M, GridLevels g,
@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(256) void hashgrid_dx_reduce_kernel(const float* __
 // works on sample 32 * tile(t / 32) + t % 32 of the listed tiles only: the others have a zero feature gradient, add
 // nothing, and their 384 bytes of Jacobian per sample stay unread.
 template <int LAYOUT>
-__global__ __launch_bounds__(256) void hashgrid_dx_jac_kernel(const float* __restrict__ jac,
+MIPSF_SINGLE_FP32 __global__ __launch_bounds__(256) void hashgrid_dx_jac_kernel(const float* __restrict__ jac,
                                                               const float* __restrict__ dout, float* __restrict__ dx,
                                                               uint32_t M, uint32_t L,
                                                               const uint32_t* __restrict__ tiles) {

@@ -12,7 +12,7 @@
 
 namespace mipsf {
 
-__global__ __launch_bounds__(PR_BLOCK) void pose_rays_fwd_kernel(const float* __restrict__ fixed,
+MIPSF_SINGLE_FP32 __global__ __launch_bounds__(PR_BLOCK) void pose_rays_fwd_kernel(const float* __restrict__ fixed,
                                                                  const float* __restrict__ rot,
                                                                  const float* __restrict__ trans, int F, int K,
                                                                  const int64_t* __restrict__ owner,
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(PR_BLOCK) void pose_rays_fwd_kernel(const float* __
 // The row gather of the ray table (mipsf_gather_rays, ro.hip) and the ray construction in ONE launch: both are one
 // thread per ray and each was a 5 us launch of every iteration.  Writes d_cam / rgb / depth (the gather's outputs: d_cam
 // is what the backward needs) and rays_o / rays_d; same arithmetic and the same NaN conventions as the two kernels.
-__global__ __launch_bounds__(PR_BLOCK) void gather_pose_rays_fwd_kernel(
+MIPSF_SINGLE_FP32 __global__ __launch_bounds__(PR_BLOCK) void gather_pose_rays_fwd_kernel(
     const float* __restrict__ db, uint64_t n_rows, const int64_t* __restrict__ idx, const float* __restrict__ fixed,
     const float* __restrict__ rot, const float* __restrict__ trans, int F, int K, const int64_t* __restrict__ owner,
     float* __restrict__ d_cam, float* __restrict__ rgb, float* __restrict__ depth, float* __restrict__ rays_o,
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(PR_BLOCK) void gather_pose_rays_fwd_kernel(
 // every workgroup writes its per-pose partial {dR, dt} to its own row of `part`, the LAST one to finish (ticket
 // counter) sums the rows in workgroup order -- no float atomics on global memory --, runs the
 // quaternion chain and puts the ticket back to zero for the next call.
-__global__ __launch_bounds__(PR_BLOCK) void pose_rays_bwd_kernel(const float* __restrict__ g_o,
+MIPSF_SINGLE_FP32 __global__ __launch_bounds__(PR_BLOCK) void pose_rays_bwd_kernel(const float* __restrict__ g_o,
                                                                  const float* __restrict__ g_d,
                                                                  const float* __restrict__ d_cam,
                                                                  const int64_t* __restrict__ owner,

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void sample_rays_kerne
 // Row gather of the ray table + ray construction from the pose parameters + sample placement in ONE launch (they were
 // gather_pose_rays_fwd_kernel + sample_rays_kernel, a 5 us launch each in every iteration; rays_o / rays_d never leave
 // the registers).  Same arithmetic and NaN conventions as the two kernels.  Wave per ray.
-__global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void gather_pose_place_kernel(
+MIPSF_SINGLE_FP32 __global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void gather_pose_place_kernel(
     const float* __restrict__ db, uint64_t n_rows, const int64_t* __restrict__ idx, const float* __restrict__ fixed,
     const float* __restrict__ rot, const float* __restrict__ trans, int F, int K, const int64_t* __restrict__ owner,
     const float* __restrict__ noise, const float* __restrict__ z_uniform, const float* __restrict__ z_near_off,
@@ -201,7 +201,7 @@ struct LossFinalize {           // FUSED: the last workgroup of render_fwd_kerne
     double* sums_out;           // != null: the nine sums of THIS batch are left here and the losses are NOT finished (a share of
 };                              // a ray-data-parallel batch: mipsf_render_fwd_sums; the sums of all shares go to mipsf_loss_finalize_sums)
 
-__device__ void finalize_losses(const double (&t)[9], float emd_w, uint32_t N, uint32_t S, float* __restrict__ losses,
+MIPSF_SINGLE_FP32 __device__ void finalize_losses(const double (&t)[9], float emd_w, uint32_t N, uint32_t S, float* __restrict__ losses,
                                 const float* __restrict__ loss_weights, float* __restrict__ loss_total);
 
 template <bool TRAIN, bool FUSED>
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(LF_BLOCK) void loss_finalize_kernel(const float* __
     if (lane == 0) finalize_losses(t, emd_w, N, S, losses, loss_weights, loss_total);
 }
 
-__device__ void finalize_losses(const double (&t)[9], float emd_w, uint32_t N, uint32_t S, float* __restrict__ losses,
+MIPSF_SINGLE_FP32 __device__ void finalize_losses(const double (&t)[9], float emd_w, uint32_t N, uint32_t S, float* __restrict__ losses,
                                 const float* __restrict__ loss_weights, float* __restrict__ loss_total) {
     const double NS = (double)N * (double)S;
     const float n_front = (float)t[7], n_band = (float)t[8];
@@ -478,7 +478,7 @@ __device__ void finalize_losses(const double (&t)[9], float emd_w, uint32_t N, u
 }
 
 // the losses of a batch whose nine sums were formed elsewhere (the all-reduced sums of a ray-data-parallel batch's shares)
-__global__ void loss_finalize_sums_kernel(const double* __restrict__ sums, float emd_w, uint32_t N, uint32_t S,
+MIPSF_SINGLE_FP32 __global__ void loss_finalize_sums_kernel(const double* __restrict__ sums, float emd_w, uint32_t N, uint32_t S,
                                           float* __restrict__ losses, const float* __restrict__ loss_weights,
                                           float* __restrict__ loss_total) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -490,7 +490,7 @@ __global__ void loss_finalize_sums_kernel(const double* __restrict__ sums, float
 
 // ------------------------------------------------------------------------ backward
 // N_norm: the ray count the losses were normalised by (= N unless this launch differentiates a SHARE of a larger batch)
-__global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void render_bwd_kernel(
+MIPSF_SINGLE_FP32 __global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void render_bwd_kernel(
     const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ target_rgb,
     const float* __restrict__ target_d, const float* __restrict__ losses, RenderCfg rc, int train,
     const float* __restrict__ g_losses, const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void rays_bwd_kernel(c
 // d(xn) -> pose gradients in ONE launch (rays_bwd_kernel + pose_rays_bwd_kernel: the per-ray {d o, d d} stay in
 // registers).  16 rays per workgroup: 256 tickets for 4096 rays (same-address device atomics retire at ~90 per us).
 constexpr int PPB = 16;
-__global__ __launch_bounds__(PPB * MIPSF_WAVE) void place_pose_bwd_kernel(
+MIPSF_SINGLE_FP32 __global__ __launch_bounds__(PPB * MIPSF_WAVE) void place_pose_bwd_kernel(
     const float* __restrict__ dxn, const float* __restrict__ z_vals, NormCfg nc, const float* __restrict__ d_cam,
     const int64_t* __restrict__ owner, const float* __restrict__ rot, int F, int K, float* __restrict__ part,
     uint32_t* __restrict__ ticket, float* __restrict__ d_rot, float* __restrict__ d_trans, uint32_t N, uint32_t S,

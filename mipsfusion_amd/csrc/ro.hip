@@ -36,7 +36,7 @@ __device__ float ro_chk_dump[32][64][24];
 #endif
 
 // one wave per particle; every lane derives the particle's pose (60 flops) and then walks the lattice points
-__global__ __launch_bounds__(256) void ro_particles_kernel(const float* __restrict__ pst,
+MIPSF_SINGLE_FP32 __global__ __launch_bounds__(256) void ro_particles_kernel(const float* __restrict__ pst,
                                                            const float* __restrict__ state,
                                                            const float* __restrict__ rays_d_cam,
                                                            const float* __restrict__ target_d, NormCfg nc,
@@ -194,7 +194,7 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
 
 // RandomOptimizer.py:196-224, one workgroup.  Sums are accumulated in fp64 (any fp32 summation order of the
 // reference is within one rounding of them).
-__global__ __launch_bounds__(256) void ro_update_kernel(const float* __restrict__ mean_masked,
+MIPSF_SINGLE_FP32 __global__ __launch_bounds__(256) void ro_update_kernel(const float* __restrict__ mean_masked,
                                                         const float* __restrict__ pst7, float* __restrict__ state,
                                                         float sdf_weight, float rescale, uint32_t P) {
     __shared__ double sh[4];

@@ -79,6 +79,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 //   0 LDS reads feeding a chain of bf16 MFMAs      1 v_cvt_pk_bf16_f32      2 v_pk_fma_f32      3 v_pk_add_f32 with a crossed op_sel
 //   4 v_sin_f32      5 ds_bpermute_b32      6 MFMA + cvt_pk + pk_fma (the decoder's mix)      7 ds_read/ds_write_b128 + s_barrier
 //   8 global loads and stores      9 straight-line code twice the size of the instruction cache
+//   10 back-to-back MFMAs on register operands (the power the decoder kernels draw)
 template <int KIND>
 __global__ __launch_bounds__(512) void neighbour(unsigned iters, float* __restrict__ sink) {
     extern __shared__ bf8 tile[];
@@ -127,6 +128,18 @@ __global__ __launch_bounds__(512) void neighbour(unsigned iters, float* __restri
             tile[(threadIdx.x * 5u + 13u * i) % T] = x;
             __syncthreads();
         }
+        if (KIND == 10) {     // the matrix cores flat out: four independent accumulators, operands with busy bit patterns held in registers
+            bf8 x, y;
+            for (int j = 0; j < 8; ++j) x[j] = (short)(0x3f80 ^ ((threadIdx.x * 2654435761u) >> (j + 3))), y[j] = (short)(0x3f00 ^ ((threadIdx.x * 40503u) >> j));
+            f16v acc1 = acc, acc2 = acc, acc3 = acc;
+            for (unsigned q = 0; q < 64; ++q) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, x, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, x, acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, y, acc3, 0, 0, 0);
+            }
+            for (int j = 0; j < 16; ++j) acc[j] = (acc[j] + acc1[j] + acc2[j] + acc3[j]) * 1e-30f;
+        }
         if (KIND == 9) {      // 128 KB of straight-line code, run through over and over: twice the instruction cache the CUs share
 #define R4(x) x x x x
 #define R16(x) R4(R4(x))
@@ -148,7 +161,7 @@ static neighbour_fn neighbour_of(int kind) {
     switch (kind) {
         case 1: return neighbour<1>; case 2: return neighbour<2>; case 3: return neighbour<3>; case 4: return neighbour<4>;
         case 5: return neighbour<5>; case 6: return neighbour<6>; case 7: return neighbour<7>; case 8: return neighbour<8>;
-        case 9: return neighbour<9>;
+        case 9: return neighbour<9>; case 10: return neighbour<10>;
         default: return neighbour<0>;
     }
 }
@@ -158,13 +171,17 @@ int main(int argc, char** argv) {
     const double seconds = argc > 2 ? atof(argv[2]) : 10.0;
     const bool inproc = argc > 3 && !strncmp(argv[3], "inproc", 6);
     const int kind = argc > 3 && strchr(argv[3], ':') ? atoi(strchr(argv[3], ':') + 1) : 0;       // "inproc:6", "kind:6" (neighbour mode)
-    const neighbour_fn nb = neighbour_of(kind);
-    const unsigned nb_iters = kind == 7 ? 3000u : kind == 8 ? 4000u : kind == 9 ? 10u : 20000u;
+    // "inproc:6,7": two kinds launched alternately, each for ~150 us (a forward and a backward kernel taking turns)
+    const int kind2 = argc > 3 && strchr(argv[3], ',') ? atoi(strchr(argv[3], ',') + 1) : -1;
+    const neighbour_fn nb = neighbour_of(kind), nb2 = neighbour_of(kind2 < 0 ? kind : kind2);
+    const unsigned alt_iters = argc > 4 ? (unsigned)atoi(argv[4]) : 3000u;
+    const unsigned nb_iters = kind == 7 ? 3000u : kind == 8 ? 4000u : kind == 9 ? 10u : kind == 10 ? 100u : 20000u;
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     float* sink;
     CHECK(hipMalloc(&sink, 4096 + (sizeof(float) << 22)));
     CHECK(hipFuncSetAttribute((const void*)nb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CHECK(hipFuncSetAttribute((const void*)nb2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const auto t0 = std::chrono::steady_clock::now();
     auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     if (!strcmp(mode, "neighbour")) {
@@ -252,7 +269,12 @@ int main(int argc, char** argv) {
     unsigned launches = 0, differing = 0;
     unsigned long long values = 0, lanes = 0, comps = 0;
     while (elapsed() < seconds) {
-        if (inproc) hipLaunchKernelGGL(nb, dim3(prop.multiProcessorCount), dim3(512), 160 * 1024, side, nb_iters, sink);
+        if (inproc && kind2 < 0) hipLaunchKernelGGL(nb, dim3(prop.multiProcessorCount), dim3(512), 160 * 1024, side, nb_iters, sink);
+        if (inproc && kind2 >= 0)
+            for (int k = 0; k < 2; ++k) {
+                hipLaunchKernelGGL(nb, dim3(prop.multiProcessorCount), dim3(512), 160 * 1024, side, alt_iters, sink);
+                hipLaunchKernelGGL(nb2, dim3(prop.multiProcessorCount), dim3(512), 64 * 1024, side, alt_iters, sink);
+            }
         for (int k = 0; k < 16; ++k) {
             CHECK(hipMemsetAsync(d_out, 0, 32, 0));
             launch(d_xn);
@@ -264,7 +286,7 @@ int main(int argc, char** argv) {
         }
     }
     CHECK(hipDeviceSynchronize());
-    if (inproc) printf("[neighbour kind %d] ", kind);
+    if (inproc) printf("[neighbour kind %d%s%s] ", kind, kind2 >= 0 ? " alternating with " : "", kind2 >= 0 ? strchr(argv[3], ',') + 1 : "");
     printf("%s%s pid %d: %u of %u launches differ from the first launch (%llu values; lanes 0x%016llx, components 0x%llx) in %.1f s\n",
            mode, inproc ? " (neighbour kernels in this process)" : "", (int)getpid(), differing, launches, values, lanes, comps, elapsed());
     return 0;
