@@ -156,7 +156,7 @@ MIPSF_SINGLE_FP32 __global__ __launch_bounds__(256) void ro_particles_kernel(con
                   "s70", "s71", "s73", "s74", "s75", "s82", "s83", "s84");
 #undef RO_S
         }
-#elif MIPSF_RO_PACKED      // reproducer builds (tools/micro/ro_diag.sh): the products as hipcc packs them (v_pk_mul_f32)
+#elif MIPSF_RO_PACKED      // reproducer builds (tools/micro/ro_diag.sh; build with -DMIPSF_KEEP_PACKED_FP32 as well): the products as hipcc packs them
         const float w0 = ((aR[0] * c0 + aR[1] * c1) + aR[2] * c2) + t0;     // batch_points_trans
         const float w1 = ((aR[3] * c0 + aR[4] * c1) + aR[5] * c2) + t1;
         const float w2 = ((aR[6] * c0 + aR[7] * c1) + aR[8] * c2) + t2;

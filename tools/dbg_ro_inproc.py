@@ -1,7 +1,9 @@
 """Does the lanes-48..63 fault of the PACKED build of ro_particles_kernel need a second PROCESS, or only the decoder's
 persistent kernels on the same CUs?  One process, two streams: the recorded decoder calls of a mapping step replayed on the
 stream they were recorded on, the particle kernel launched beside them on another stream and compared launch by launch.
-    MIPSF_LIB=$PWD/tools/micro/libv_ropk1.so python tools/dbg_ro_inproc.py [seconds] [regex of the calls to run beside]"""
+    tools/micro/variant.sh ropk1 ro -DMIPSF_RO_PACKED=1 -DMIPSF_KEEP_PACKED_FP32      (the kernel as rounds 3-4 shipped it)
+    MIPSF_LIB=$PWD/tools/micro/libv_ropk1.so python tools/dbg_ro_inproc.py [seconds] [regex of the calls to run beside]
+    (PREC=f16x3|f32: the decoder arithmetic of the neighbour; QUICK=1: one alone/beside pair)"""
 import os
 import re
 import sys
