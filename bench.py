@@ -728,9 +728,8 @@ def multi_gpu_checks(cfg, model, dev, rank, world):
             pose = ro.optimize(replica, frame["depth"], init, None, n_iter=n_ro)
         torch.cuda.synchronize()
         return pose, (time.perf_counter() - t0) / 5 / n_ro * 1e3
-    # ONE comparison, reported as it came out (ranks that share a device -- the two-process test on one GPU, a debugging
-    # topology -- have shown rare last-bit differences between runs of the same kernels: DESIGN.md 4h; the line says which
-    # topology this was)
+    # ONE comparison, reported as it came out (round 3 retried it when ranks shared a device: the differences it saw there are
+    # the packed-fp32 hazard of DESIGN.md 4h, fixed in the kernels; the line says which topology this was)
     pose_one, ms_one = timed_ro(False)
     pose_split, ms_split = timed_ro(True)
     out["ranks_share_a_device"] = bool(world > 1 and torch.cuda.device_count() < world)

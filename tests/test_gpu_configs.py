@@ -345,8 +345,10 @@ def test_mapping_and_tracking_beside_a_second_process_on_the_same_gpu(dev):
     tracking iteration against the oracle at their normal gates, and (c) repeats a pose-only tracking iteration and a
     RandomOptimizer frame 200 times each: everything on that path is deterministic (no float atomics: fixed-order reductions,
     fp64 LDS accumulation rounded once), so every repetition must reproduce the first BIT FOR BIT -- a wavefront disturbed by
-    the neighbour process would show here (round 3 saw lanes 48..63 of a few wavefronts hold another pose under
-    exactly this sharing on one box; not reproduced since, this test keeps watching)."""
+    the neighbour process shows here.  It did: DESIGN.md 4h -- with the decoder kernels of the neighbour on the same CUs, a
+    packed fp32 add whose low result takes the high half of a source lost that operand in lanes 48..63 (28 of 200 RandomOptimizer
+    frames on the build of that day); the kernels that would hold such an instruction are now built without packed fp32
+    (MIPSF_SINGLE_FP32, tools/audit_packed.py) and this test is what watches the rest."""
     import os
     import subprocess
     import sys
