@@ -386,6 +386,41 @@ class UnchangedCallerLoop:
         return loss
 
 
+def unchanged_caller_device_split(loop, pre_rows, pre_owner, n=10):
+    """Whose kernels the unchanged caller's iteration runs: a torch.profiler pass over n iterations (indices pre-drawn), device
+    time and launches per iteration of the drop-in modules' kernels (mipsf::*) and of everything else -- the caller's own eager
+    torch ops and their autograd (the poses_all[indices] gathers' backward is one indexing_backward kernel each), torch.optim.Adam,
+    the uploads."""
+    from torch.autograd import DeviceType
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for k in range(n):
+            loop.iterate((pre_rows[k % 8], pre_owner[k % 8]))
+        torch.cuda.synchronize()
+    split = {"modules_kernels": [0.0, 0], "torch_kernels_of_the_caller_and_torch_optim": [0.0, 0], "copies_and_fills_by_the_runtime": [0.0, 0]}
+    top = []
+    for e in prof.key_averages():
+        if e.device_type != DeviceType.CUDA or not ("(" in e.key or e.key.startswith("Mem")):       # kernels and copies, not ranges
+            continue
+        us = getattr(e, "self_device_time_total", None)
+        us = e.self_cuda_time_total if us is None else us
+        if "mipsf::" in e.key:
+            k = "modules_kernels"
+        elif e.key.startswith("Memcpy") or e.key.startswith("Memset"):
+            k = "copies_and_fills_by_the_runtime"
+        else:
+            k = "torch_kernels_of_the_caller_and_torch_optim"
+            top.append((us / n * 1e-3, e.count / n, e.key))
+        split[k][0] += us
+        split[k][1] += e.count
+    out = {k: {"ms_per_step": round(v[0] / n * 1e-3, 4), "launches_per_step": round(v[1] / n, 1)} for k, v in split.items()}
+    out["largest_torch_kernels"] = [{"ms_per_step": round(a, 4), "launches_per_step": round(b, 1), "kernel": c[:90]}
+                                    for a, b, c in sorted(top, reverse=True)[:4]]
+    out["note"] = ("device time, not wall clock: the step is what these add up to plus the launch gaps of ~200 eager launches; the "
+                   "modules' share is what a caller-side change cannot touch, the rest is the reference's own torch code")
+    return out
+
+
 def unchanged_caller_rate(cfg, model, frames, poses, table, db, R, dev, steps):
     loop = UnchangedCallerLoop(cfg, model, frames, poses, table, db, R, dev)
     pre_rows, pre_owner = draw_index_sets(cfg, frames, db, R, 8)
@@ -413,6 +448,7 @@ def unchanged_caller_rate(cfg, model, frames, poses, table, db, R, dev, steps):
     out["breakdown_note"] = ("the backward section contains the autograd of the CALLER's own eager torch ray ops (poses_all[indices] gather -> "
                              "index_put with a sort, the quaternion chain: ~150 small launches) next to the modules' six kernels; the "
                              "line above it without them is what the drop-in modules themselves cost")
+    out["device_time_by_owner"] = unchanged_caller_device_split(loop, pre_rows, pre_owner)
     t0 = time.perf_counter()
     for _ in range(10):
         torch.rand(N_RAYS, N_SAMPLES)

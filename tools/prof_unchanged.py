@@ -45,3 +45,18 @@ for k in range(40):
 torch.cuda.synchronize()
 print("=========== inside the autograd Functions' backward (engine thread), 40 iterations")
 pstats.Stats(prof2).sort_stats("cumulative").print_stats(35)
+
+# torch.profiler over 20 iterations: the operators and kernels of the backward pass by name (CPU time on the engine thread,
+# device time), to see what the 1.1 ms of run_backward is made of
+if os.environ.get("TORCH_PROF", "1") == "1":
+    from torch.profiler import profile, ProfilerActivity
+    for cls in (scene_rep._QueryFn, scene_rep._RenderFn, scene_rep._PlaceFn):
+        pass
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for k in range(20):
+            loop.iterate((rows[k % 8], owner[k % 8]))
+        torch.cuda.synchronize()
+    print("=========== torch.profiler, 20 iterations, by CPU time")
+    print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=40, max_name_column_width=60))
+    print("=========== by device time")
+    print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=25, max_name_column_width=60))
