@@ -1105,7 +1105,8 @@ __device__ __forceinline__ void w16x_role_a(const W16Args& a, const W16X<A>& lx,
         W16_FENCE();
         W16_MARK(6);
         if (TWO_BARRIERS) w16x_barrier();      // this tile's XA / XB have been read: the next tile may overwrite them
-        W16_TRACE_SUM(6, w);
+        W16_MARK(7);
+        W16_TRACE_SUM(7, w);
     }
     float* rec = a.rec;
 #pragma unroll
@@ -1137,6 +1138,10 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X<A>& lx,
     typedef typename A::v8 v8;
     constexpr int P = A::P;
     constexpr bool TWO_BARRIERS = L::NBUF == 1;
+#ifndef W16_B_EARLY_X
+#define W16_B_EARLY_X 1      // experiments: 0 = both transposes between the second barrier and the first one (round 4's first form)
+#endif
+    constexpr bool EARLY_X = TWO_BARRIERS && W16_B_EARLY_X;
     const int j = lane & 31, h = lane >> 5;
     const uint32_t lane16 = 16u * (uint32_t)lane;
     f32x16 acc[5];
@@ -1150,21 +1155,23 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X<A>& lx,
     };
     const uint64_t feat_bytes = (uint64_t)a.M * N_GRID * 4;
     const srd_t feat_srd = make_srd(a.feat, feat_bytes > 0xffffffffull ? 0xffffffffu : (uint32_t)feat_bytes);
-    // what this wave transposes for everybody.  All four waves issue the same 4 + 16 loads (see w16x_role_a): sdf_emb row
-    // tile rt for rt < 2, the grid features for rt == 2, the rest against empty resources (zeros, no memory traffic)
-    f32x8 bGr[2];
-    const srd_t grid_srd = rt == 2 ? feat_srd : make_srd(a.feat, 0);
+    // what this wave transposes for everybody: sdf_emb row tile rt for rt < 2 (4 loads of 16 bytes), the grid features for
+    // rt == 2 (16 loads of 4 bytes), both into bY -- the branch is wave-uniform, and the wave with the e column tiles (rt == 3)
+    // loads nothing here
     auto load_mine = [&](uint32_t tile) {
-        load_tile_rows(make_srd(a.saved + (size_t)tile * ACT_TILE_FLOATS, rt < 2 ? ACT_TILE_FLOATS * 4 : 0), 1, rt & 1, lane16, bY);
-        const uint32_t s_raw = tile * 32u + (uint32_t)j;
-        const uint32_t s_c = s_raw < a.M ? s_raw : a.M - 1;
-        const uint32_t voff = LAYOUT == MIPSF_FEAT_AOS ? s_c * (uint32_t)(N_GRID * 4) + 4u * (uint32_t)h : (s_c * 2u + (uint32_t)h) * 4u;
-        const uint32_t lstride = LAYOUT == MIPSF_FEAT_AOS ? 8u : a.M * 8u;
+        if (rt < 2) {
+            load_tile_rows(make_srd(a.saved + (size_t)tile * ACT_TILE_FLOATS, ACT_TILE_FLOATS * 4), 1, rt & 1, lane16, bY);
+        } else if (rt == 2) {
+            const uint32_t s_raw = tile * 32u + (uint32_t)j;
+            const uint32_t s_c = s_raw < a.M ? s_raw : a.M - 1;
+            const uint32_t voff = LAYOUT == MIPSF_FEAT_AOS ? s_c * (uint32_t)(N_GRID * 4) + 4u * (uint32_t)h : (s_c * 2u + (uint32_t)h) * 4u;
+            const uint32_t lstride = LAYOUT == MIPSF_FEAT_AOS ? 8u : a.M * 8u;
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                bGr[q][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(grid_srd, voff, (uint32_t)(8 * q + u) * lstride, 0));
+                for (int u = 0; u < 8; ++u)
+                    bY[q][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(feat_srd, voff, (uint32_t)(8 * q + u) * lstride, 0));
+        }
     };
     // lean gradient record: dG3[rt] = relu'(H3[rt]) (Ws2^T dlogits)[rt] is recomputed from the sample's 8 small-row values and
     // its mask bits (loaded one tile ahead like everything else); the record's dG3 pieces are then read through an empty resource
@@ -1192,42 +1199,9 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X<A>& lx,
     }
     w16x_barrier();
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma clang loop unroll(disable)
-    for (; it < a.n_tiles; it += gridDim.x, par ^= (L::NBUF == 2 ? 1u : 0u)) {
-        const uint32_t nt = it + gridDim.x < a.n_tiles ? w16_tile(a, it + gridDim.x) : w16_tile(a, it);
-        const v8* xe = lx.xe + par * L::XE;
-        v8* xb = lx.xb + par * L::XB;
-        v8 X3[P][2], X1[P][2];
-        W16_TRACE_DECL;
-        W16_MARK(0);
-        // ---- this wave's column tile(s) -> XB
-        if (rt < 3) {
-            if (rt == 2) bY[0] = bGr[0] * w16_grid_shift<A>(), bY[1] = bGr[1] * w16_grid_shift<A>();
-            v8 Y[P][2];
-            transpose_block<A, false>(bY, I, Y, dummy);
-            w16x_put<A>(xb + rt * L::CT, lane, Y);
-        } else {
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {           // e column tile blk = k-steps 2 blk, 2 blk + 1, plane by plane
-                v8 Y[P][2];
-#pragma unroll
-                for (int pb = 0; pb < P; ++pb) {
-#ifdef W16_DBG_NO_COMPUTE
-                    Y[pb][0] = I[0], Y[pb][1] = I[1];
-                    continue;
-#endif
-                    f32x16 T = mfma16(xe[((2 * blk) * P + pb) * 64 + lane], I[0], zero);
-                    T = mfma16(xe[((2 * blk + 1) * P + pb) * 64 + lane], I[1], T);
-                    pack_T<A>(T, Y[pb]);
-                }
-                w16x_put<A>(xb + (3 + blk) * L::CT, lane, Y);
-            }
-        }
-        W16_FENCE();
-        load_mine(nt);
-        W16_FENCE();
-        W16_MARK(1);
-        // ---- X3 = dG3[rt], X1 = dG1[rt]
+    v8 X3[P][2], X1[P][2];
+    // X3 = dG3[rt], X1 = dG1[rt] of the tile whose records are in bSm / bMk / bG3 / bG1, then the loads of tile `nt` into them
+    auto make_x = [&](uint32_t nt, bool with_loads) {
         if (lean) {
             float up, down;
             w16x_updown(bSm, up, down);
@@ -1253,9 +1227,10 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X<A>& lx,
         }
         transpose_block<A, true>(bG3, I, X3, bsum0);
         W16_FENCE();
-        W16_MARK(2);
-        load_lean(nt);
-        load_tile_rows(g3_srd(nt), 2, rt, lane16, bG3);
+        if (with_loads) {
+            load_lean(nt);
+            load_tile_rows(g3_srd(nt), 2, rt, lane16, bG3);
+        }
         W16_FENCE();
         if (A::SCALED) {
             float rs;
@@ -1265,8 +1240,58 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X<A>& lx,
         }
         transpose_block<A, true>(bG1, I, X1, bsum1);
         W16_FENCE();
-        load_tile_rows(act_srd(a.dact, nt), 0, rt, lane16, bG1);
+        if (with_loads) load_tile_rows(act_srd(a.dact, nt), 0, rt, lane16, bG1);
         W16_FENCE();
+    };
+    auto load_x = [&](uint32_t nt) {       // the records make_x reads, of tile nt
+        load_lean(nt);
+        load_tile_rows(g3_srd(nt), 2, rt, lane16, bG3);
+        load_tile_rows(act_srd(a.dact, nt), 0, rt, lane16, bG1);
+    };
+    // With ONE set of exchange buffers (P = 3: two sets do not fit the CU's LDS) a tile has two barriers, and everything a wave
+    // does between the second one and the first one of the next tile is on the workgroup's critical path (the role-a waves wait
+    // at the first barrier with their products still to do).  The two transposes of this role are private to the wave, so there
+    // they are done for the NEXT tile right behind this tile's products -- beside the role-a waves' products -- and only the
+    // column tile everybody waits for is left between the barriers (phase trace, tools/replay.py w16trace: the role-a waves
+    // waited 6 350 of their 15 960 cycles per tile at the first barrier).
+    if (EARLY_X && it < a.n_tiles) make_x(0u, false);
+#pragma clang loop unroll(disable)
+    for (; it < a.n_tiles; it += gridDim.x, par ^= (L::NBUF == 2 ? 1u : 0u)) {
+        const uint32_t nt = it + gridDim.x < a.n_tiles ? w16_tile(a, it + gridDim.x) : w16_tile(a, it);
+        const v8* xe = lx.xe + par * L::XE;
+        v8* xb = lx.xb + par * L::XB;
+        W16_TRACE_DECL;
+        W16_MARK(0);
+        // ---- this wave's column tile(s) -> XB
+        if (rt < 3) {
+            if (rt == 2) bY[0] = bY[0] * w16_grid_shift<A>(), bY[1] = bY[1] * w16_grid_shift<A>();
+            v8 Y[P][2];
+            transpose_block<A, false>(bY, I, Y, dummy);
+            w16x_put<A>(xb + rt * L::CT, lane, Y);
+        } else {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {           // e column tile blk = k-steps 2 blk, 2 blk + 1, plane by plane
+                v8 Y[P][2];
+#pragma unroll
+                for (int pb = 0; pb < P; ++pb) {
+#ifdef W16_DBG_NO_COMPUTE
+                    Y[pb][0] = I[0], Y[pb][1] = I[1];
+                    continue;
+#endif
+                    f32x16 T = mfma16(xe[((2 * blk) * P + pb) * 64 + lane], I[0], zero);
+                    T = mfma16(xe[((2 * blk + 1) * P + pb) * 64 + lane], I[1], T);
+                    pack_T<A>(T, Y[pb]);
+                }
+                w16x_put<A>(xb + (3 + blk) * L::CT, lane, Y);
+            }
+        }
+        W16_FENCE();
+        load_mine(nt);
+        W16_FENCE();
+        W16_MARK(1);
+        if (!EARLY_X) make_x(nt, true);       // ---- X3 = dG3[rt], X1 = dG1[rt]
+        else load_x(nt);                      // (the column tile's temporaries are gone: the records of the next tile's X3, X1)
+        W16_MARK(2);
         W16_MARK(3);
         w16x_barrier();
         W16_MARK(4);
@@ -1282,9 +1307,11 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X<A>& lx,
         }
         W16_FENCE();
         W16_MARK(5);
+        if (EARLY_X && it + gridDim.x < a.n_tiles) make_x(0u, false);      // the next tile's X3, X1
         W16_MARK(6);
         if (TWO_BARRIERS) w16x_barrier();
-        W16_TRACE_SUM(6, 4 + rt);
+        W16_MARK(7);
+        W16_TRACE_SUM(7, 4 + rt);
     }
     float* rec = a.rec;
 #pragma unroll

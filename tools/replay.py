@@ -59,17 +59,18 @@ def report_wgrad_trace(lname, h):
     buf = np.zeros(2048 * 16, dtype=np.uint64)
     fn(buf.ctypes.data_as(C.c_void_p), 1)
     t = buf.reshape(2048, 16).astype(np.float64)
-    names = {"A": ["H1[w] -> XA", "e(next)[w] -> XE", "X = dH2[w]^T", "barrier", "4 x mac", "small rows + next loads"],
-             "B": ["column tile -> XB", "X3 = dG3^T", "X1 = dG1^T", "barrier", "5 x mac", "-"]}
+    names = {"A": ["H1[w] -> XA", "e(next)[w] -> XE", "X = dH2[w]^T", "barrier", "4 x mac", "small rows + next loads", "second barrier"],
+             "B": ["column tile -> XB", "X3 = dG3^T (or: the next records' loads)", "X1 = dG1^T", "barrier", "5 x mac", "next tile's X3, X1 (early form)",
+                   "second barrier"]}
     for role, sel in (("A", lambda w: w % 8 < 4), ("B", lambda w: w % 8 >= 4)):
         rows = np.array([w for w in range(2048) if sel(w) and t[w, 15] > 0])
         if rows.size == 0:
             continue
-        per = t[rows, :6].sum(0) / t[rows, 15].sum()
+        per = t[rows, :7].sum(0) / t[rows, 15].sum()
         print(f"  [{lname}] role {role}: {per.sum():.0f} cycles per tile: " + ", ".join(f"{n} {c:.0f}" for n, c in zip(names[role], per)))
         for k in range(4):
             r2 = rows[rows % 4 == k]
-            p2 = t[r2, :6].sum(0) / t[r2, 15].sum()
+            p2 = t[r2, :7].sum(0) / t[r2, 15].sum()
             print(f"      wave {k + (0 if role == 'A' else 4)}: " + " ".join(f"{c:6.0f}" for c in p2))
 
 
