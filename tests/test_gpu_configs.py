@@ -410,6 +410,55 @@ def test_mapping_and_tracking_beside_a_second_process_on_the_same_gpu(dev):
             other.kill()
 
 
+def test_deterministic_kernels_beside_the_decoder_kernels_on_another_stream(dev):
+    """DESIGN.md 4h, the setting in which the packed-fp32 hazard showed best (3 % of the launches of the build of that day): the
+    decoder's forward and backward kernels of a mapping step taking turns on one stream, the RandomOptimizer's particle kernel
+    and the fused ray-construction / sample-placement kernel launched over and over on another one.  Every launch must reproduce
+    the first bit for bit."""
+    import time
+    cfg = synth.config_headline()
+    m, _ = build(cfg, dev, seed=11)
+    m.train()
+    M = 4096 * 64
+    g = torch.Generator().manual_seed(2)
+    xn = torch.rand(M, 3, generator=g).to(dev)
+    ws = m.decoder.ordered_parameters()
+    from mipsfusion_amd._lib import FEAT_LEVEL_MAJOR
+    feat = ops.hashgrid_fwd(xn, m.embed_fn.params.detach(), m.embed_fn.meta, FEAT_LEVEL_MAJOR)
+    dout = (torch.randn(M, 10, generator=g) * 1e-3).to(dev)
+    pk = ops.decoder_pack16(ws, precision=m.decoder_precision)
+
+    def decoder_round():                                     # forward (masks only) then the backward chain, as in a tracking step
+        out, saved = ops.decoder_fwd(None, feat, FEAT_LEVEL_MAJOR, xn, None, M, "masks", precision=m.decoder_precision, packed16=pk)
+        ops.decoder_bwd(None, feat, FEAT_LEVEL_MAJOR, xn, None, out, dout, saved, None, M, precision=m.decoder_precision, packed16=pk)
+    decoder_round()
+    P, n = 2000, 384
+    pst = (torch.rand(P, 6, generator=g) * 2 - 1).to(dev)
+    state = torch.zeros(ops.RO_STATE_FLOATS, device=dev)
+    state[:12] = torch.tensor([0.962, -0.059, 0.266, 0.011, 0.984, 0.178, -0.272, -0.169, 0.947, 1.168, 3.796, 0.946])
+    state[12:18] = 0.02
+    dirs = torch.stack([torch.rand(n, generator=g) - 0.5, 0.8 * (torch.rand(n, generator=g) - 0.5), torch.ones(n)], 1).contiguous().to(dev)
+    depth = (0.8 + 2.2 * torch.rand(n, generator=g)).to(dev)
+    rc = m._rc(1, 0)
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        ref, ref7 = ops.ro_particles(pst, state, dirs, depth, rc, point_major=True)
+    torch.cuda.synchronize()
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    launches, t0 = 0, time.time()
+    while time.time() - t0 < 6.0:
+        for _ in range(4):
+            decoder_round()
+        with torch.cuda.stream(side):
+            for _ in range(32):
+                a, b = ops.ro_particles(pst, state, dirs, depth, rc, point_major=True)
+                bad += (a != ref).any() | (b != ref7).any()
+                launches += 1
+        torch.cuda.synchronize()
+    print(f"\n  {int(bad)} of {launches} particle-kernel launches beside the decoder kernels differ from the first")
+    assert launches > 2000 and int(bad) == 0
+
+
 # ------------------------------------------------------------------------ ray-data-parallel training == the single-process step
 RDP_STEPS, RDP_N, RDP_S = 5, 4096, 64
 
