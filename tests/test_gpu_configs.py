@@ -337,6 +337,33 @@ def test_config4_global_ba_single_rank_vs_oracle(dev):
     assert err < 2e-5 + 1e-2 * moved
 
 
+def _pose_only_tracking_iteration(dev, seed=9):
+    """-> (cfg, model, frame, fn): fn() runs one pose-only tracking iteration (frozen map, fixed rays and jitter) and returns its
+    pose gradients and depth map -- deterministic by construction (no float atomics anywhere on that path)."""
+    cfg = synth.config_headline()
+    m, _ = build(cfg, dev, seed=seed)
+    m.train()
+    for p in m.parameters():
+        p.requires_grad_(False)                                      # tracking: the map is frozen (mipsfusion.py:226-230)
+    f = synth.make_frame(cfg, seed=seed)
+    H, W = f["depth"].shape
+    g = torch.Generator().manual_seed(3)
+    idx = torch.randperm(H * W, generator=g)[:cfg["tracking"]["sample"]]
+    r, c = torch.div(idx, W, rounding_mode="floor"), torch.remainder(idx, W)
+    d_cam, rgb, d = f["direction"][r, c].to(dev), f["rgb"][r, c].contiguous().to(dev), f["depth"][r, c][:, None].contiguous().to(dev)
+    noise = torch.rand(idx.numel(), 64, generator=g).to(dev)
+    q0, t0 = matrix_to_quaternion(f["c2w"][None, :3, :3]).to(dev), f["c2w"][None, :3, 3].clone().to(dev)
+    owner = torch.zeros(idx.numel(), dtype=torch.int64, device=dev)
+
+    def tracking_iteration():
+        rot, trans = torch.nn.Parameter(q0.clone()), torch.nn.Parameter(t0.clone())
+        ro, rd = ops.pose_rays(rot, trans, None, owner, d_cam)
+        ret = m.forward(ro, rd, rgb, d, EMD_w=0.0, noise=noise)
+        path_cpu.total_loss(ret, cfg["training"]).backward()
+        return torch.cat([rot.grad.reshape(-1), trans.grad.reshape(-1), ret["depth"].detach().reshape(-1)])
+    return cfg, m, f, tracking_iteration
+
+
 # ------------------------------------------------------------------------ the reference's process topology: two processes, one GPU
 def test_mapping_and_tracking_beside_a_second_process_on_the_same_gpu(dev):
     """The reference runs TWO processes on one GPU: the active map's tracking + mapping and the InactiveMap process's local BA
@@ -362,27 +389,7 @@ def test_mapping_and_tracking_beside_a_second_process_on_the_same_gpu(dev):
         test_config2_full_iteration_vs_oracle(dev)                       # (a)
         test_config5_scannet_tracking_iteration_vs_oracle(dev)           # (b)
         # (c) run-to-run identity under sharing
-        cfg = synth.config_headline()
-        m, _ = build(cfg, dev, seed=9)
-        m.train()
-        for p in m.parameters():
-            p.requires_grad_(False)                                      # tracking: the map is frozen (mipsfusion.py:226-230)
-        f = synth.make_frame(cfg, seed=9)
-        H, W = f["depth"].shape
-        g = torch.Generator().manual_seed(3)
-        idx = torch.randperm(H * W, generator=g)[:cfg["tracking"]["sample"]]
-        r, c = torch.div(idx, W, rounding_mode="floor"), torch.remainder(idx, W)
-        d_cam, rgb, d = f["direction"][r, c].to(dev), f["rgb"][r, c].contiguous().to(dev), f["depth"][r, c][:, None].contiguous().to(dev)
-        noise = torch.rand(idx.numel(), 64, generator=g).to(dev)
-        q0, t0 = matrix_to_quaternion(f["c2w"][None, :3, :3]).to(dev), f["c2w"][None, :3, 3].clone().to(dev)
-        owner = torch.zeros(idx.numel(), dtype=torch.int64, device=dev)
-
-        def tracking_iteration():
-            rot, trans = torch.nn.Parameter(q0.clone()), torch.nn.Parameter(t0.clone())
-            ro, rd = ops.pose_rays(rot, trans, None, owner, d_cam)
-            ret = m.forward(ro, rd, rgb, d, EMD_w=0.0, noise=noise)
-            path_cpu.total_loss(ret, cfg["training"]).backward()
-            return torch.cat([rot.grad.reshape(-1), trans.grad.reshape(-1), ret["depth"].detach().reshape(-1)])
+        cfg, m, f, tracking_iteration = _pose_only_tracking_iteration(dev)
         first = tracking_iteration()
         n_diff = sum(0 if torch.equal(tracking_iteration(), first) else 1 for _ in range(200))
         print(f"\n  beside a second process: {n_diff} of 200 tracking iterations differ from the first")
@@ -412,9 +419,8 @@ def test_mapping_and_tracking_beside_a_second_process_on_the_same_gpu(dev):
 
 def test_deterministic_kernels_beside_the_decoder_kernels_on_another_stream(dev):
     """DESIGN.md 4h, the setting in which the packed-fp32 hazard showed best (3 % of the launches of the build of that day): the
-    decoder's forward and backward kernels of a mapping step taking turns on one stream, the RandomOptimizer's particle kernel
-    and the fused ray-construction / sample-placement kernel launched over and over on another one.  Every launch must reproduce
-    the first bit for bit."""
+    decoder's forward and backward kernels taking turns on one stream, the RandomOptimizer's particle kernel -- and then whole
+    pose-only tracking iterations -- launched over and over on another one.  Every launch must reproduce the first bit for bit."""
     import time
     cfg = synth.config_headline()
     m, _ = build(cfg, dev, seed=11)
@@ -457,6 +463,22 @@ def test_deterministic_kernels_beside_the_decoder_kernels_on_another_stream(dev)
         torch.cuda.synchronize()
     print(f"\n  {int(bad)} of {launches} particle-kernel launches beside the decoder kernels differ from the first")
     assert launches > 2000 and int(bad) == 0
+    # the tracking iteration's kernels (pose rays, placement, render forward / backward, their pose gradients) the same way
+    _cfg, _m, _f, tracking_iteration = _pose_only_tracking_iteration(dev)
+    with torch.cuda.stream(side):
+        first = tracking_iteration()
+    torch.cuda.synchronize()
+    n_diff, n_it, t0 = 0, 0, time.time()
+    while time.time() - t0 < 6.0:
+        for _ in range(4):
+            decoder_round()
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                n_diff += 0 if torch.equal(tracking_iteration(), first) else 1
+                n_it += 1
+        torch.cuda.synchronize()
+    print(f"  {n_diff} of {n_it} tracking iterations beside the decoder kernels differ from the first")
+    assert n_it > 100 and n_diff == 0
 
 
 # ------------------------------------------------------------------------ ray-data-parallel training == the single-process step
