@@ -1289,12 +1289,18 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X<A>& lx,
         load_mine(nt);
         W16_FENCE();
         W16_MARK(1);
+#ifndef W16_B_LOADS_LATE
+#define W16_B_LOADS_LATE 1           // experiments: 0 = the next records' loads in front of the first barrier
+#endif
         if (!EARLY_X) make_x(nt, true);       // ---- X3 = dG3[rt], X1 = dG1[rt]
-        else load_x(nt);                      // (the column tile's temporaries are gone: the records of the next tile's X3, X1)
+        else if (!W16_B_LOADS_LATE) load_x(nt);
         W16_MARK(2);
         W16_MARK(3);
         w16x_barrier();
         W16_MARK(4);
+        // (the column tile's temporaries are gone, and issuing these loads is not in the other waves' way any more: the
+        // records of the next tile's X3, X1; the products below cover their latency)
+        if (EARLY_X && W16_B_LOADS_LATE) load_x(nt);
         if constexpr (P == 3) {
             w16x_mac2<A>(X3, xb, acc[0], X3, xb + L::CT, acc[1], lane);
             w16x_mac2<A>(X3, xb + 2 * L::CT, acc[2], X1, xb + 3 * L::CT, acc[3], lane);
