@@ -481,6 +481,34 @@ def test_deterministic_kernels_beside_the_decoder_kernels_on_another_stream(dev)
     assert n_it > 100 and n_diff == 0
 
 
+def test_particle_kernel_beside_back_to_back_mfmas(dev, tmp_path):
+    """The strongest known trigger of the packed-fp32 hazard: tools/micro/pk_lanes.hip launches a kernel whose
+    waves issue bf16 MFMAs back to back on a second stream and, beside it, (a) its own victim kernel with hipcc's crossed packed
+    add -- reported, not asserted: ~6 % of the launches come out wrong on the boxes seen so far -- and (b) the LIBRARY's particle
+    kernel on the same inputs, which must reproduce its first launch every time."""
+    import os
+    import re
+    import shutil
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not shutil.which(hipcc):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "pk_lanes")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-w", "-I" + os.path.join(root, "include"), "-o", exe,
+                    os.path.join(root, "tools", "micro", "pk_lanes.hip"), "-ldl"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    from mipsfusion_amd import _lib
+    counts = {}
+    for mode in ("asm", "lib:" + _lib.LIB_PATH):
+        out = subprocess.run([exe, mode, "5", "inproc:10"], check=True, capture_output=True, text=True, timeout=120).stdout
+        m = re.search(r"(\d+) of (\d+) launches differ", out)
+        assert m, out
+        counts[mode[:3]] = (int(m.group(1)), int(m.group(2)))
+    print(f"\n  beside back-to-back bf16 MFMAs: crossed packed add {counts['asm'][0]} of {counts['asm'][1]} launches wrong; "
+          f"the library's particle kernel {counts['lib'][0]} of {counts['lib'][1]}")
+    assert counts["lib"][1] > 5000 and counts["lib"][0] == 0
+
+
 # ------------------------------------------------------------------------ ray-data-parallel training == the single-process step
 RDP_STEPS, RDP_N, RDP_S = 5, 4096, 64
 
