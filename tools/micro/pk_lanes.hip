@@ -144,6 +144,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 //   4 v_sin_f32      5 ds_bpermute_b32      6 MFMA + cvt_pk + pk_fma (the decoder's mix)      7 ds_read/ds_write_b128 + s_barrier
 //   8 global loads and stores      9 straight-line code twice the size of the instruction cache
 //   10 back-to-back MFMAs on register operands (the power the decoder kernels draw)      11 the same on ~250 VGPRs per wave      12 the same with fp32-input MFMAs
+//   13 / 14 / 15 the same with f16 32x32x16 / bf16 16x16x32 / i8 32x32x32
 template <int KIND>
 __global__ __launch_bounds__(512) void neighbour(unsigned iters, float* __restrict__ sink) {
     extern __shared__ bf8 tile[];
@@ -204,6 +205,44 @@ __global__ __launch_bounds__(512) void neighbour(unsigned iters, float* __restri
             }
             for (int j = 0; j < 16; ++j) acc[j] = (acc[j] + acc1[j] + acc2[j] + acc3[j]) * 1e-30f;
         }
+        if (KIND == 13 || KIND == 14 || KIND == 15) {     // like 10 with other 16-bit / 8-bit matrix instructions: 13 f16 32x32x16, 14 bf16 16x16x32,
+            typedef _Float16 hf8 __attribute__((ext_vector_type(8)));       // 15 i8 32x32x32
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            typedef int i4v __attribute__((ext_vector_type(4)));
+            typedef int i16v __attribute__((ext_vector_type(16)));
+            bf8 x, y;
+            for (int j = 0; j < 8; ++j) x[j] = (short)(0x3c00 ^ ((threadIdx.x * 2654435761u) >> (j + 3)) & 0x3ff), y[j] = (short)(0x3800 ^ ((threadIdx.x * 40503u) >> j) & 0x3ff);
+            if (KIND == 13) {
+                const hf8 hx = __builtin_bit_cast(hf8, x), hy = __builtin_bit_cast(hf8, y);
+                f16v a1 = acc, a2 = acc, a3 = acc;
+                for (unsigned q = 0; q < 64; ++q) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hx, hy, acc, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hy, hx, a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hx, hx, a2, 0, 0, 0);
+                    a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hy, hy, a3, 0, 0, 0);
+                }
+                for (int j = 0; j < 16; ++j) acc[j] = (acc[j] + a1[j] + a2[j] + a3[j]) * 1e-30f;
+            } else if (KIND == 14) {
+                f4v c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+                for (unsigned q = 0; q < 128; ++q) {
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y, x, c1, 0, 0, 0);
+                    c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, x, c2, 0, 0, 0);
+                    c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y, y, c3, 0, 0, 0);
+                }
+                for (int j = 0; j < 4; ++j) acc[j] = (c0[j] + c1[j] + c2[j] + c3[j]) * 1e-30f;
+            } else {
+                const i4v ix = __builtin_bit_cast(i4v, x), iy = __builtin_bit_cast(i4v, y);
+                i16v d0 = {}, d1 = {}, d2 = {}, d3 = {};
+                for (unsigned q = 0; q < 64; ++q) {
+                    d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(ix, iy, d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(iy, ix, d1, 0, 0, 0);
+                    d2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(ix, ix, d2, 0, 0, 0);
+                    d3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(iy, iy, d3, 0, 0, 0);
+                }
+                for (int j = 0; j < 16; ++j) acc[j] = (float)(d0[j] + d1[j] + d2[j] + d3[j]) * 1e-30f;
+            }
+        }
         if (KIND == 12) {     // like 10 on the fp32-input matrix instruction (v_mfma_f32_32x32x2_f32: the round-1 decoder kernels)
             const float xa = 1.0f + threadIdx.x * 1e-3f, xb = 0.5f - threadIdx.x * 1e-4f;
             f16v acc1 = acc, acc2 = acc, acc3 = acc;
@@ -251,6 +290,7 @@ static neighbour_fn neighbour_of(int kind) {
         case 1: return neighbour<1>; case 2: return neighbour<2>; case 3: return neighbour<3>; case 4: return neighbour<4>;
         case 5: return neighbour<5>; case 6: return neighbour<6>; case 7: return neighbour<7>; case 8: return neighbour<8>;
         case 9: return neighbour<9>; case 10: return neighbour<10>; case 11: return neighbour<11>; case 12: return neighbour<12>;
+        case 13: return neighbour<13>; case 14: return neighbour<14>; case 15: return neighbour<15>;
         default: return neighbour<0>;
     }
 }
@@ -264,7 +304,7 @@ int main(int argc, char** argv) {
     const int kind2 = argc > 3 && strchr(argv[3], ',') ? atoi(strchr(argv[3], ',') + 1) : -1;
     const neighbour_fn nb = neighbour_of(kind), nb2 = neighbour_of(kind2 < 0 ? kind : kind2);
     const unsigned alt_iters = argc > 4 ? (unsigned)atoi(argv[4]) : 3000u;
-    const unsigned nb_iters = kind == 7 ? 3000u : kind == 8 ? 4000u : kind == 9 ? 10u : kind == 10 ? 100u : kind == 11 ? 60u : kind == 12 ? 50u : 20000u;
+    const unsigned nb_iters = kind == 7 ? 3000u : kind == 8 ? 4000u : kind == 9 ? 10u : kind == 10 ? 100u : kind == 11 ? 60u : kind == 12 ? 50u : kind >= 13 ? 100u : 20000u;
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     float* sink;
