@@ -55,7 +55,23 @@ _spec = importlib.util.spec_from_file_location("mipsf_hostcpu", os.path.join(os.
                                                                            "mipsfusion_amd", "hostcpu.py"))
 _hostcpu = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(_hostcpu)
-HOST_CPUS = None if os.environ.get("MIPSF_NO_CONFINE") else _hostcpu.confine_to_numa_node(32, int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+
+
+def _only_launches_ranks(argv):
+    """True for `python bench.py --gpus N` (N > 1) without a launcher: this process only starts the ranks (launch_ranks) and
+    must leave its affinity mask alone -- the children inherit it and each picks its OWN NUMA node from the full mask."""
+    if "WORLD_SIZE" in os.environ:
+        return False
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return argv[i + 1].isdigit() and int(argv[i + 1]) > 1
+        if a.startswith("--gpus="):
+            return a[7:].isdigit() and int(a[7:]) > 1
+    return False
+
+
+HOST_CPUS = None if (os.environ.get("MIPSF_NO_CONFINE") or _only_launches_ranks(sys.argv[1:])) else _hostcpu.confine_to_numa_node(
+    32, int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
 
 # OpenMP sizes its pools by the machine's core count (256 on the GPU hosts) although the cgroup grants 16: every host
 # thread that touches a torch CPU op would oversubscribe the quota.  Must be set before torch is imported.
@@ -144,14 +160,9 @@ DECODER_FLOP_PER_SAMPLE = 72370.0
 STREAM_CEILINGS_TBS = {"read": 6.3, "read_nt": 7.0, "write": 6.0, "copy": 5.6, "spec": 8.0}
 
 
-DTYPE_OF = {
-    "bf16x6": "f32 (parameters, activations, gradients, accumulators); the decoder's matrix products -- forward, "
-              "activation-gradient chain, weight gradients -- on the bf16 matrix cores with every fp32 operand carried "
-              "EXACTLY as three bf16 pieces (24 significant bits) and six MFMAs per product, fp32 accumulate: dropped "
-              "partial products < 2^-23 |a||w|, below the rounding of the fp32 accumulation (fp32-class against fp64 truth, "
-              "tests/test_gpu_parity.py::test_decoder_true_error_of_every_arithmetic_against_fp64)",
-    "f16x3": "f32 (parameters, activations, gradients, accumulators); the decoder's matrix products: f16 MFMA on "
-             "hi/lo split operands = 22-23-bit operands (forward, activation-gradient chain, weight gradients)",
+DTYPE_OF = {        # <= 120 characters (the long description of each arithmetic: DESIGN.md 2)
+    "bf16x6": "f32; decoder products as 3 x bf16 pieces of each fp32 operand, 6 bf16 MFMAs per product, fp32 accumulate",
+    "f16x3": "f32; decoder products as f16 hi/lo halves (22-23 operand bits), 3 f16 MFMAs per product, fp32 accumulate",
     "f32": "f32 everywhere (fp32-input MFMA = exact fp32 products)",
 }
 _T0 = time.time()
@@ -984,8 +995,8 @@ def kernel_table(prof, M, precision, live_share, pair_share, with_traffic=True):
             share = shares[liveness] if shares[liveness] is not None else 1.0
             work = M * (share * per_live + (1.0 - share) * per_dead)
             work_full = M * per_live
-            if bound == "mfma" and mult and mult > 1:           # issued products on the 16-bit pipe
-                work, work_full = work * mult, work_full * mult
+            # `achieved` counts ALGORITHMIC FLOPs (one fp32-exact product = 2 FLOP, however many 16-bit MFMA
+            # products carry it); the issued figure (x mult) sits next to it as `frac_issued`
             if len(cost[name]) > 7:
                 hbm_bytes = M * (share * cost[name][7] + (1.0 - share) * cost[name][8])
                 hbm_view = {"algorithmic_bytes_per_launch": round(hbm_bytes, 1), "achieved_GBps": round(hbm_bytes / (ms * 1e-3) / 1e9, 2),
@@ -1004,9 +1015,14 @@ def kernel_table(prof, M, precision, live_share, pair_share, with_traffic=True):
                          "frac": round(achieved / peak, 4), "avg_ms": round(ms, 4), "dtype": dtype,
                          "launches": n_launch, "work_per_launch": round(work, 1),
                          "traffic": traffic.get(name), "traffic_uncorrected": traffic_raw.get(name)}
+        if bound == "mfma" and mult and mult > 1:
+            kernels[name]["frac_issued"] = round(achieved * mult / peak, 4)
+            kernels[name]["frac_of_fp32_mfma_peak"] = round(achieved / MFMA_F32_PEAK_TFLOPS, 4)
+            kernels[name]["products_issued_per_algorithmic_product"] = mult
+            kernels[name]["achieved_is"] = (f"algorithmic FLOP/s of the units processed against the dense 16-bit peak; every fp32-exact "
+                                            f"product is issued as {mult} 16-bit MFMA products (frac_issued)")
         if hbm_view is not None:
             kernels[name]["hbm_view"] = hbm_view
-            kernels[name]["achieved_is"] = f"issued matrix FLOP/s: {mult} bf16 MFMA products per fp32-exact product"
         if design:
             kernels[name]["design_bytes_per_launch"] = round(M * design, 1)
             kernels[name]["design_note"] = "bytes the design moves on top of the algorithmic ones (the Jacobian kept for the backward), not priced"
@@ -1029,6 +1045,104 @@ def kernel_table(prof, M, precision, live_share, pair_share, with_traffic=True):
                                       "reads 16 B per lane); not collected in this run")
         roofline["device_stream_ceilings_TBps"] = STREAM_CEILINGS_TBS
     return kernels, roofline
+
+
+LINE_LIMIT = 6000            # the driver keeps an 8 000-character stdout tail: the line it parses has to fit with room to spare
+REQUIRED_LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                      "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(out):
+    """The ONE line the driver parses, built from the full result `out`: the contract fields, `roofline` (dominant kernel,
+    algorithmic AND issued fractions), `cpu_baseline`, the frame metric, the unchanged caller's step and one row of
+    (avg_ms, frac) per kernel.  Everything else -- variants, per-kernel detail, sequences, inference -- goes to
+    bench_detail.json beside this script and to stderr.  Always shorter than LINE_LIMIT (tests/test_host_cpu.py)."""
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype", "data"))
+    line["vs_baseline"] = out.get("vs_baseline")                  # null is the contract's value when nothing is published
+    cfg = out.get("config") or {}
+    line["config"] = _pick(cfg, ("workload", "rays", "samples_per_ray", "hash_size", "parallelism"))
+    line["launch"] = out.get("launch")
+    line["eager_ms_per_step"] = out.get("eager_ms_per_step")
+    if out.get("step_ms_stats"):
+        line["step_ms_stats"] = _pick(out["step_ms_stats"], ("steps", "min", "median", "p95", "max"))
+    roof = out.get("roofline")
+    if roof:
+        r = _pick(roof, ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_ms", "launches", "work_per_launch", "traffic",
+                         "frac_issued", "frac_of_fp32_mfma_peak", "products_issued_per_algorithmic_product", "units",
+                         "frac_full_batch"))
+        r["traffic"] = roof.get("traffic")                         # null when no PMC pass is on file
+        if roof.get("hbm_view"):
+            r["hbm_view_frac_of_8_TBps"] = roof["hbm_view"].get("frac_of_8_TBps")
+        r["traffic_source"] = "profiles/pmc_latest.json (rocprofv3 --pmc passes of this command, per launch; not collected in this run)"
+        line["roofline"] = r
+    else:
+        line["roofline"] = None
+    cb = out.get("cpu_baseline")
+    if cb:
+        c = _pick(cb, ("value", "unit", "cores", "kind", "s_per_iter", "gpu_vs_oracle_same_batch"))
+        c["value"] = round(float(cb["value"]), 1)
+        c["sample"] = str(cb.get("sample", ""))[:200]
+        line["cpu_baseline"] = c
+    else:
+        line["cpu_baseline"] = None
+    kern = out.get("kernels") or {}
+    line["kernels_avg_ms_frac"] = {k: [v.get("avg_ms"), v.get("frac")] for k, v in kern.items()}
+    if out.get("forward_only"):
+        line["forward_only"] = _pick(out["forward_only"], ("value", "ms"))
+    frame = out.get("frame") or {}
+    if frame:
+        f = _pick(frame, ("tracking_plus_mapping_ms_per_frame", "ms_per_frame_device_sampling", "ms_per_frame_from_iteration_times",
+                          "ro_iter_ms", "go_iter_ms", "ba_iter_ms", "decoder_arithmetic"))
+        c3 = frame.get("config3_multi_submap")
+        if c3:
+            f["config3_multi_submap"] = _pick(c3, ("frames", "ms_per_frame_mean", "ate_rmse_m"))
+        line["frame"] = f
+    var = out.get("variants") or {}
+    if var:
+        line["variants_ms_per_step"] = {k: v.get("ms_per_step") for k, v in var.items() if isinstance(v, dict)}
+        uc = var.get("unchanged_caller") or {}
+        if uc.get("ms_per_step"):
+            line["unchanged_caller_ms_per_step"] = uc["ms_per_step"]
+            line["unchanged_caller_over_headline"] = round(uc["ms_per_step"] / out["ms_per_step"], 2)
+    if out.get("gradient_sparsity"):
+        line["gradient_sparsity"] = _pick(out["gradient_sparsity"], ("live_32_sample_tiles", "live_sample_level_pairs"))
+    mg = out.get("multi_gpu")
+    if mg:
+        line["multi_gpu"] = _pick(mg, ("ms_per_step_of_each_rank", "pose_all_gather_ms", "pose_grad_all_reduce_ms",
+                                       "prediction_table_all_reduce_ms", "backend", "global_ba_iter_ms"))
+        if mg.get("ranks"):
+            line["multi_gpu"]["ranks"] = _pick(mg["ranks"], ("world_size", "backend", "distinct_devices"))
+    line["scaling_curve"] = str(out.get("scaling_curve", ""))[:160]
+    line["detail"] = "bench_detail.json (full result: variants, per-kernel rows, sequences, inference); also on stderr"
+    text = json.dumps(line, separators=(",", ":"))
+    # never over the limit: drop the optional blocks, least important first
+    for k in ("gradient_sparsity", "step_ms_stats", "variants_ms_per_step", "kernels_avg_ms_frac", "multi_gpu", "forward_only", "frame"):
+        if len(text) < LINE_LIMIT:
+            break
+        line.pop(k, None)
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < LINE_LIMIT, len(text)
+    return text
+
+
+def emit(out):
+    """full result -> bench_detail.json + stderr; the compact line -> stdout (last line)."""
+    detail = json.dumps(out)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(detail + "\n")
+            except OSError as e:
+                log(f"bench_detail.json not written in {d}: {e}")
+    sys.stderr.write("[bench detail] " + detail + "\n")
+    sys.stderr.flush()
+    print(compact_line(out), flush=True)
 
 
 def launch_ranks(n):
@@ -1250,8 +1364,7 @@ def main():
     fwd_rate, fwd_ms = forward_only_rate(model, loop, dev)
     log(f"forward-only {fwd_ms:.3f} ms")
     out = {
-        "metric": "rays*samples/s, full optimisation iteration (sample placement -> hash grid -> decoder -> SDF "
-                  "render -> losses -> backward -> pose+map Adam), 4096 rays x 64 samples, 640x480 RGB-D",
+        "metric": "rays*samples/s per GPU, full optimisation iteration (fwd + bwd + pose+map Adam), 4096 rays x 64 samples, 640x480 RGB-D",
         "value": round(value, 1), "unit": "rays*samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
         "launch": "hipGraph replay of pose_accum_step iterations" if use_graph else "eager",
@@ -1262,9 +1375,8 @@ def main():
         "vs_baseline": None,
         "dtype": DTYPE_OF[headline_precision],
         "data": "synthetic",
-        "config": {"workload": "BASELINE config 2: FastCaMo-synth apartment_2 bound, 1 active submap per GPU, "
-                               "4096 rays x 64 samples (43 uniform + 21 depth-guided), hash grid 2^19 x 16 levels x 2, "
-                               "620x460 synthetic RGB-D (640x480 cropped by 10)",
+        "config": {"workload": "BASELINE config 2: FastCaMo-synth apartment_2, 1 active submap per GPU, 4096 rays x 64 samples, "
+                               "hash grid 2^19 x 16 x 2, 620x460 synthetic RGB-D",
                    "rays": N_RAYS, "samples_per_ray": N_SAMPLES, "hash_size": cfg["grid"]["hash_size"],
                    "parallelism": f"submap-per-gpu x{world}" if world > 1 else "single gpu",
                    "ray_build": "torch eager ops" if args.torch_pose else "row gather + pose rays + sample placement in one kernel",
@@ -1306,7 +1418,7 @@ def main():
                             "ranks sharing one GPU (tests/test_gpu_configs.py)") if world == 1 else "this line is one point of it"
     if world == 1 and args.cpu_rays > 0:
         out["cpu_baseline"] = cpu_baseline(cfg, loop, args.cpu_rays, args.cpu_iters, args.cpu_warmup)
-    print(json.dumps(out), flush=True)
+    emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

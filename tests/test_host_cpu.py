@@ -477,3 +477,68 @@ def test_no_kernel_holds_a_packed_fp32_operation_that_crosses_halves():
     crossed = [(u, k, c) for u, k, _n, c, _l in audit_packed.audit_all() if c]
     assert not crossed, crossed
     assert any(c for _u, _k, _n, c, _l in audit_packed.audit_all(("-DMIPSF_KEEP_PACKED_FP32",), units=("ro",)))     # the audit is not blind
+
+
+def _load_bench_module():
+    """bench.py as a module, without its NUMA confinement (import-time side effect of the script)"""
+    import importlib.util
+    os.environ["MIPSF_NO_CONFINE"] = "1"
+    spec = importlib.util.spec_from_file_location("mipsf_bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("record", ["r04_f_bench.json", "r03_k_bench.json"])
+def test_bench_line_is_compact_and_carries_the_contract(record):
+    """The driver keeps an 8 000-character stdout tail: round 4's 23 KB line could not be parsed.  The line bench.py prints
+    is built by `compact_line` from the full result; here from RECORDED full results (the largest one on file and an
+    older layout), plus a worst case with every optional block inflated."""
+    import json
+    bench = _load_bench_module()
+    out = json.load(open(os.path.join(ROOT, "profiles", record)))
+    text = bench.compact_line(out)
+    assert len(text) < bench.LINE_LIMIT <= 6000 and "\n" not in text
+    line = json.loads(text)
+    for k in bench.REQUIRED_LINE_KEYS:
+        assert k in line, k
+    assert line["value"] == out["value"] and line["ms_per_step"] == out["ms_per_step"]
+    assert len(line["dtype"]) <= max(120, len(out["dtype"])) and "workload" in line["config"]
+    assert "model" not in line["config"]
+    roof = line["roofline"]
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_ms", "traffic"):
+        assert k in roof, k
+    cb = line["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    if "frame" in out:
+        assert line["frame"]["tracking_plus_mapping_ms_per_frame"] == out["frame"]["tracking_plus_mapping_ms_per_frame"]
+    if (out.get("variants") or {}).get("unchanged_caller"):
+        assert line["unchanged_caller_ms_per_step"] == out["variants"]["unchanged_caller"]["ms_per_step"]
+    # worst case: hundreds of kernels and variants -> optional blocks are dropped, the contract stays
+    fat = dict(out)
+    fat["kernels"] = {f"kernel_with_a_long_name_{i}": {"avg_ms": 0.123456, "frac": 0.5} for i in range(400)}
+    fat["variants"] = {f"variant_{i}": {"ms_per_step": 1.0} for i in range(300)}
+    text = bench.compact_line(fat)
+    assert len(text) < bench.LINE_LIMIT
+    line = json.loads(text)
+    for k in bench.REQUIRED_LINE_KEYS:
+        assert k in line, k
+
+
+def test_bench_launcher_process_keeps_its_affinity_mask():
+    """`python bench.py --gpus N` only starts the ranks: confining THAT process would hand every child a one-node mask
+    (each rank then gets 32/N CPUs of the same node instead of a node of its own)."""
+    bench = _load_bench_module()
+    env = os.environ.pop("WORLD_SIZE", None)
+    try:
+        assert bench._only_launches_ranks(["--gpus", "8", "--steps", "5"])
+        assert bench._only_launches_ranks(["--steps", "5", "--gpus=2"])
+        assert not bench._only_launches_ranks(["--gpus", "1"])
+        assert not bench._only_launches_ranks(["--steps", "5"])
+        os.environ["WORLD_SIZE"] = "8"
+        assert not bench._only_launches_ranks(["--gpus", "8"])
+    finally:
+        os.environ.pop("WORLD_SIZE", None)
+        if env is not None:
+            os.environ["WORLD_SIZE"] = env
