@@ -10,8 +10,11 @@ for f in sorted(glob.glob(os.path.join(src, "pass*_summary.txt"))):
             continue
         k = m.group(1)
         for kv in m.group(4).split():
-            c, v = kv.split("=")
-            vals.setdefault(k, {})[c] = float(v)
+            c, _, v = kv.partition("=")
+            try:
+                vals.setdefault(k, {})[c] = float(v)
+            except ValueError:
+                vals.setdefault(k, {})[c] = v
 # map rocprof kernel names -> bench kernel groups (a group = one C-ABI call)
 groups = {"hashgrid_fwd": ["hashgrid_fwd_kernel"],
           "hashgrid_bwd": ["scatter_zero_kernel", "scatter_route_kernel", "scatter_scan_kernel", "hashgrid_scatter_kernel",

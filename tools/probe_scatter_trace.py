@@ -25,9 +25,9 @@ cap = {}
 orig = ops.hashgrid_bwd
 
 
-def grab(x, params, dout, dparams, meta, layout=ops.FEAT_AOS, dx=None, routed=None):
+def grab(x, params, dout, dparams, meta, layout=ops.FEAT_AOS, dx=None, routed=None, dparams_zero=False):
     cap.update(x=x.clone(), dout=dout.clone(), meta=meta, layout=layout, params=params)
-    return orig(x, params, dout, dparams, meta, layout, dx, routed)
+    return orig(x, params, dout, dparams, meta, layout, dx, routed, dparams_zero)
 
 
 ops.hashgrid_bwd = grab
