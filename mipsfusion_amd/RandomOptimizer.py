@@ -17,7 +17,7 @@ from .helper_functions.geometry_helper import quaternion_to_matrix
 from .helper_functions.sampling_helper import sample_pixels_uniformly
 
 
-# sample order of a round: point-major (hash-grid lookups 144 -> 77 us per round; see mipsf_ro_particles_pm)
+# sample order of a round: point-major (hash-grid lookups 144 -> 77 us per round; see mipsf_ro_particles(point_major))
 _POINT_MAJOR = True
 
 

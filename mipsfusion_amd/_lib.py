@@ -42,6 +42,49 @@ class RenderCfg(C.Structure):
                 ("depth_trunc", C.c_float), ("rgb_missing_nonzero", C.c_int), ("emd_w", C.c_float)]
 
 
+def _args(name, fields):
+    """ctypes mirror of an argument block of include/mipsf.h (struct_size first; `new()` returns a zeroed, sized block)."""
+    cls = type(name, (C.Structure,), {"_fields_": [("struct_size", C.c_uint32)] + fields})
+
+    def new(**kw):
+        a = cls()
+        a.struct_size = C.sizeof(cls)
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return a
+    cls.new = staticmethod(new)
+    return cls
+
+
+_VP, _CU, _CI = C.c_void_p, C.c_uint32, C.c_int
+HashgridBwdArgs = _args("HashgridBwdArgs", [("M", _CU), ("x", _VP), ("params", _VP), ("dout", _VP), ("dparams", _VP), ("dx", _VP),
+                                            ("scratch", _VP), ("counters", _VP), ("meta", C.POINTER(GridMeta)),
+                                            ("feat_layout", _CI), ("flags", _CU)])
+DecoderFwd16Args = _args("DecoderFwd16Args", [("M", _CU), ("packed16", _VP), ("feat", _VP), ("x", _VP), ("out", _VP), ("saved", _VP),
+                                              ("tile_live_clear", _VP), ("feat_layout", _CI), ("precision", _CI),
+                                              ("sdf_only", _CI), ("lean_record", _CI)])
+DecoderChain16Args = _args("DecoderChain16Args", [("M", _CU), ("packed16", _VP), ("x", _VP), ("out", _VP), ("dout", _VP),
+                                                  ("saved", _VP), ("dfeat", _VP), ("dx", _VP), ("dact", _VP), ("tile_live", _VP),
+                                                  ("feat_layout", _CI), ("flags", _CI)])
+DecoderWgrad16Args = _args("DecoderWgrad16Args", [("M", _CU), ("packed16", _VP), ("feat", _VP), ("x", _VP), ("saved", _VP),
+                                                  ("dact", _VP), ("tile_live", _VP), ("grads", C.POINTER(DecoderGrads)),
+                                                  ("partial", _VP), ("feat_layout", _CI), ("arithmetic", _CI), ("flags", _CU)])
+RenderFwdArgs = _args("RenderFwdArgs", [("N", _CU), ("S", _CU), ("raw", _VP), ("z_vals", _VP), ("target_rgb", _VP), ("target_d", _VP),
+                                        ("counts", _VP), ("cfg", C.POINTER(RenderCfg)), ("rgb", _VP), ("depth", _VP),
+                                        ("depth_var", _VP), ("disp", _VP), ("acc", _VP), ("weights", _VP), ("losses", _VP),
+                                        ("partial", _VP), ("loss_weights", _VP), ("loss_total", _VP), ("ticket", _VP),
+                                        ("sums", _VP)])
+RenderBwdArgs = _args("RenderBwdArgs", [("N", _CU), ("S", _CU), ("N_norm", _CU), ("raw", _VP), ("z_vals", _VP), ("target_rgb", _VP),
+                                        ("target_d", _VP), ("counts", _VP), ("losses", _VP), ("cfg", C.POINTER(RenderCfg)),
+                                        ("g_losses", _VP), ("g_total", _VP), ("loss_weights", _VP), ("g_rgb", _VP),
+                                        ("g_depth", _VP), ("draw", _VP)])
+
+# mipsf_buffer_size(which, n, a, b, meta): MIPSF_SIZE_* of include/mipsf.h
+(SIZE_HASHGRID_BWD_SCRATCH, SIZE_HASHGRID_COUNTER_WORDS, SIZE_DECODER_PACKED, SIZE_DECODER_SAVED, SIZE_DECODER_DACT,
+ SIZE_DECODER_WGRAD_PARTIAL, SIZE_DECODER_PACKED16, SIZE_DECODER_TILE_WORDS, SIZE_RENDER_PARTIAL, SIZE_PLACE_POSE_SCRATCH,
+ SIZE_POSE_RAYS_SCRATCH) = range(1, 12)
+
+
 ADAM_MAX_TENSORS = 16
 
 
@@ -74,89 +117,59 @@ SIGNATURES = {
     "mipsf_last_error": (C.c_char_p, []),
     "mipsf_abi_version": (_I, []),
     "mipsf_device_cu_count": (_I, []),
+    "mipsf_buffer_size": (_U64, [_I, _U32, _U32, _U32, C.POINTER(GridMeta)]),
     "mipsf_hashgrid_meta_init": (_I, [C.POINTER(GridMeta), _U32, _U32, _U32, _U32, _D]),
-    "mipsf_hashgrid_fwd": (_I, [_P, _P, _P, _U32, C.POINTER(GridMeta), _I, _P]),
-    "mipsf_hashgrid_fwd_jac": (_I, [_P, _P, _P, _P, _U32, C.POINTER(GridMeta), _I, _P]),
-    "mipsf_hashgrid_dx_from_jac": (_I, [_P, _P, _P, _U32, C.POINTER(GridMeta), _I, _P]),
-    "mipsf_hashgrid_dx_from_jac_tiles": (_I, [_P, _P, _P, _P, _U32, C.POINTER(GridMeta), _I, _P]),
-    "mipsf_hashgrid_bwd_scratch_floats": (_U64, [C.POINTER(GridMeta), _U32, _I]),
-    "mipsf_hashgrid_bwd": (_I, [_P, _P, _P, _P, _P, _P, _U32, C.POINTER(GridMeta), _I, _P]),
-    "mipsf_hashgrid_counter_words": (_U64, [C.POINTER(GridMeta)]),
-    "mipsf_hashgrid_bwd_keep": (_I, [_P, _P, _P, _P, _P, _P, _P, _U32, C.POINTER(GridMeta), _I, _P]),
-    "mipsf_hashgrid_bwd_keep_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, _U32, C.POINTER(GridMeta), _I, _U32, _P]),
+    "mipsf_hashgrid_fwd": (_I, [_P, _P, _P, _P, _U32, C.POINTER(GridMeta), _I, _P]),
+    "mipsf_hashgrid_dx_from_jac": (_I, [_P, _P, _P, _P, _U32, C.POINTER(GridMeta), _I, _P]),
+    "mipsf_hashgrid_bwd": (_I, [C.POINTER(HashgridBwdArgs), _P]),
     "mipsf_hashgrid_route": (_I, [_P, _P, _U32, C.POINTER(GridMeta), _P]),
-    "mipsf_hashgrid_bwd_routed": (_I, [_P, _P, _P, _P, _P, _P, _U32, C.POINTER(GridMeta), _I, _P]),
     "mipsf_hashgrid_indices": (_I, [_P, _P, _U32, C.POINTER(GridMeta), _P]),
     "mipsf_freq_fwd": (_I, [_P, _P, _U32, _U32, _U32, _P]),
     "mipsf_freq_bwd": (_I, [_P, _P, _P, _U32, _U32, _U32, _P]),
-    "mipsf_decoder_packed_floats": (_U32, []),
-    "mipsf_decoder_saved_floats": (_U64, [_U32]),
-    "mipsf_decoder_dact_floats": (_U64, [_U32]),
-    "mipsf_decoder_wgrad_partial_floats": (_U64, []),
     "mipsf_decoder_pack": (_I, [C.POINTER(DecoderWeights), _P, _P]),
     "mipsf_decoder_pack_host": (_I, [C.POINTER(DecoderWeights), _P]),
     "mipsf_decoder_fwd": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _U32, _P]),
     "mipsf_decoder_fwd_sdf": (_I, [_P, _P, _I, _P, _P, _I, _P, _U32, _P]),
-    "mipsf_decoder_packed16_floats": (_U32, []),
-    "mipsf_decoder_pack16": (_I, [C.POINTER(DecoderWeights), _P, _P]),
-    "mipsf_decoder_packed16_floats_ex": (_U32, [_I]),
-    "mipsf_decoder_pack16_ex": (_I, [C.POINTER(DecoderWeights), _P, _I, _P]),
-    "mipsf_decoder_fwd16": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _U32, _P]),
-    "mipsf_decoder_fwd16_ex": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _U32, _P]),
-    "mipsf_decoder_bwd_chain16": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _U32, _P]),
-    "mipsf_decoder_bwd_chain16_ex": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _U32, _P]),
-    "mipsf_decoder_fwd16_ex2": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _U32, _P]),
-    "mipsf_decoder_bwd_chain16_ex2": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _U32, _P]),
-    "mipsf_decoder_tile_words": (C.c_uint64, [_U32]),
     "mipsf_decoder_bwd": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.POINTER(DecoderGrads), _P, _P,
                                _U32, _P]),
     "mipsf_decoder_bwd_chain": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _U32, _P]),
-    "mipsf_decoder_wgrad": (_I, [_P, _I, _P, _P, _I, _P, _P, C.POINTER(DecoderGrads), _P, _U32, _P]),
-    "mipsf_decoder_wgrad_ex": (_I, [_P, _I, _P, _P, _I, _P, _P, C.POINTER(DecoderGrads), _P, _I, _U32, _P]),
-    "mipsf_decoder_wgrad16": (_I, [_P, _I, _P, _P, _P, C.POINTER(DecoderGrads), _P, _I, _U32, _P]),
-    "mipsf_decoder_wgrad16_ex": (_I, [_P, _P, _I, _P, _P, _P, C.POINTER(DecoderGrads), _P, _I, _U32, _P]),
-    "mipsf_decoder_wgrad16_tiles": (_I, [_P, _P, _I, _P, _P, _P, _P, C.POINTER(DecoderGrads), _P, _I, _U32, _P]),
-    "mipsf_decoder_wgrad16_tiles_ex": (_I, [_P, _P, _I, _P, _P, _P, _P, C.POINTER(DecoderGrads), _P, _I, _U32, _U32, _P]),
+    "mipsf_decoder_wgrad": (_I, [_P, _I, _P, _P, _I, _P, _P, C.POINTER(DecoderGrads), _P, _I, _U32, _P]),
+    "mipsf_decoder_pack16": (_I, [C.POINTER(DecoderWeights), _P, _I, _P]),
+    "mipsf_decoder_fwd16": (_I, [C.POINTER(DecoderFwd16Args), _P]),
+    "mipsf_decoder_bwd_chain16": (_I, [C.POINTER(DecoderChain16Args), _P]),
+    "mipsf_decoder_wgrad16": (_I, [C.POINTER(DecoderWgrad16Args), _P]),
     "mipsf_sample_rays": (_I, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _U32, _P]),
     "mipsf_normalise_points": (_I, [_P, C.POINTER(RenderCfg), _P, _U32, _P]),
-    "mipsf_render_fwd": (_I, [_P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _U32, _U32,
-                              _P]),
-    "mipsf_render_bwd": (_I, [_P, _P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _U32, _U32, _P]),
-    "mipsf_render_fwd_ex": (_I, [_P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U32,
-                                 _U32, _P]),
-    "mipsf_render_fwd_ex2": (_I, [_P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                  _U32, _U32, _P]),
-    "mipsf_render_bwd_ex": (_I, [_P, _P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _P, _P, _U32, _U32, _P]),
-    "mipsf_render_bwd_ex2": (_I, [_P, _P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _P, _P, _U32, _U32, _U32, _P]),
-    "mipsf_render_partial_floats": (_U64, [_U32]),
-    "mipsf_render_fwd_sums": (_I, [_P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _U32, _U32, _P]),
+    "mipsf_render_fwd": (_I, [C.POINTER(RenderFwdArgs), _P]),
     "mipsf_loss_finalize_sums": (_I, [_P, C.POINTER(RenderCfg), _U32, _U32, _P, _P, _P, _P]),
-    "mipsf_rays_bwd": (_I, [_P, _P, C.POINTER(RenderCfg), _P, _P, _U32, _U32, _P]),
-    "mipsf_normalise_bwd": (_I, [_P, C.POINTER(RenderCfg), _P, _U32, _P]),
-    "mipsf_pose_rays_fwd": (_I, [_P, _P, _P, _U32, _U32, _P, _P, _P, _P, _U32, _P]),
-    "mipsf_pose_rays_bwd": (_I, [_P, _P, _P, _U32, _U32, _P, _P, _P, _P, _P, _U32, _P]),
-    "mipsf_gather_pose_rays_fwd": (_I, [_P, C.c_uint64, _P, _P, _P, _P, _U32, _U32, _P, _P, _P, _P, _P, _P, _U32, _P]),
-    "mipsf_pose_rays_bwd_ex": (_I, [_P, _P, _P, _U32, _U32, _P, _P, _P, _P, _P, _U32, _I, _P]),
-    "mipsf_pose_rays_scratch_floats": (_U64, [_U32, _U32, _U32]),
+    "mipsf_render_bwd": (_I, [C.POINTER(RenderBwdArgs), _P]),
     "mipsf_gather_pose_place_fwd": (_I, [_P, _U64, _P, _P, _P, _P, _U32, _U32, _P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P,
                                          _P, _P, _P, _P, _U32, _P]),
-    "mipsf_place_pose_scratch_floats": (_U64, [_U32, _U32, _U32]),
     "mipsf_place_pose_bwd": (_I, [_P, _P, C.POINTER(RenderCfg), _P, _U32, _U32, _P, _P, _P, _P, _P, _U32, _U32, _I, _P]),
-    "mipsf_adam_step": (_I, [_P, _P, _P, _P, _U64, _F, _F, _F, _F, _F, _U32, _I, _P]),
-    "mipsf_adam_advance": (_I, [_P, _P, _F, _F, _F, _P]),
+    "mipsf_rays_bwd": (_I, [_P, _P, C.POINTER(RenderCfg), _P, _P, _U32, _U32, _P]),
+    "mipsf_normalise_bwd": (_I, [_P, C.POINTER(RenderCfg), _P, _U32, _P]),
+    "mipsf_pose_rays_fwd": (_I, [_P, _U64, _P, _P, _P, _P, _U32, _U32, _P, _P, _P, _P, _P, _P, _U32, _P]),
+    "mipsf_pose_rays_bwd": (_I, [_P, _P, _P, _U32, _U32, _P, _P, _P, _P, _P, _U32, _I, _P]),
+    "mipsf_adam_step": (_I, [_P, _P, _P, _P, _U64, _F, _F, _F, _F, _F, _U32, _P, _I, _P]),
     "mipsf_adam_advance_n": (_I, [_P, _P, _P, _P, _P, _U32, _P]),
-    "mipsf_adam_step_ex": (_I, [_P, _P, _P, _P, _U64, _F, _F, _F, _F, _F, _U32, _P, _I, _P]),
-    "mipsf_adam_step_multi_ex": (_I, [C.POINTER(AdamTensors), _F, _F, _F, _F, _F, _U32, _P, _I, _P]),
-    "mipsf_adam_step_multi": (_I, [C.POINTER(AdamTensors), _F, _F, _F, _F, _F, _U32, _I, _P]),
+    "mipsf_adam_step_multi": (_I, [C.POINTER(AdamTensors), _F, _F, _F, _F, _F, _U32, _P, _I, _P]),
     "mipsf_adam_step_small": (_I, [C.POINTER(AdamSmall), _I, _P]),
     "mipsf_adam_step_all": (_I, [C.POINTER(AdamSmall), _I, _P, _P]),
     "mipsf_ro_fitness": (_I, [_P, _U32, _P, _F, _P, _U32, _U32, _P]),
     "mipsf_ro_fitness_sdf": (_I, [_P, _P, _F, _P, _U32, _U32, _I, _P]),
-    "mipsf_ro_particles": (_I, [_P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _U32, _U32, _P]),
-    "mipsf_ro_particles_pm": (_I, [_P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _U32, _U32, _P]),
+    "mipsf_ro_particles": (_I, [_P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P, _U32, _U32, _I, _P]),
     "mipsf_ro_update": (_I, [_P, _P, _P, _F, _F, _U32, _P]),
     "mipsf_gather_rays": (_I, [_P, _U64, _P, _U32, _P, _P, _P, _P, _P]),
 }
+
+
+def buffer_size(which: int, n: int = 0, a: int = 0, b: int = 0, meta=None) -> int:
+    """mipsf_buffer_size: elements of a scratch / record buffer (SIZE_* above)."""
+    v = lib().mipsf_buffer_size(which, n, a, b, C.byref(meta) if meta is not None else None)
+    if v == 0xFFFFFFFFFFFFFFFF:
+        raise RuntimeError((lib().mipsf_last_error() or b"mipsf_buffer_size: bad query").decode())
+    return int(v)
+
 
 _lib: Optional[C.CDLL] = None
 
@@ -174,7 +187,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.mipsf_abi_version() != 1:
+        if handle.mipsf_abi_version() != 2:
             raise RuntimeError("libmipsf_hip.so ABI version mismatch")
         _lib = handle
     return _lib

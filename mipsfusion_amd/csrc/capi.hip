@@ -39,6 +39,29 @@ const char* mipsf_last_error(void) { return mipsf::g_err; }
 
 int mipsf_abi_version(void) { return MIPSF_ABI_VERSION; }
 
+uint64_t mipsf_buffer_size(int which, uint32_t n, uint32_t a, uint32_t b, const mipsf_grid_meta* meta) {
+    switch (which) {
+        case MIPSF_SIZE_HASHGRID_BWD_SCRATCH:
+        case MIPSF_SIZE_HASHGRID_COUNTER_WORDS: {
+            if (!meta) { mipsf::set_error("mipsf_buffer_size: buffer %d needs the grid's level table", which); return ~0ull; }
+            const uint64_t v = which == MIPSF_SIZE_HASHGRID_BWD_SCRATCH ? mipsf::hashgrid_bwd_scratch_floats(meta, n, (int)a)
+                                                                        : mipsf::hashgrid_counter_words(meta);
+            if (v == 0) { mipsf::set_error("mipsf_buffer_size: bad level table"); return ~0ull; }
+            return v;
+        }
+        case MIPSF_SIZE_DECODER_PACKED: return mipsf::decoder_packed_floats();
+        case MIPSF_SIZE_DECODER_SAVED: return mipsf::decoder_saved_floats(n);
+        case MIPSF_SIZE_DECODER_DACT: return mipsf::decoder_dact_floats(n);
+        case MIPSF_SIZE_DECODER_WGRAD_PARTIAL: return mipsf::decoder_wgrad_partial_floats();
+        case MIPSF_SIZE_DECODER_PACKED16: return mipsf::decoder_packed16_floats((int)a);
+        case MIPSF_SIZE_DECODER_TILE_WORDS: return mipsf::decoder_tile_words(n);
+        case MIPSF_SIZE_RENDER_PARTIAL: return mipsf::render_partial_floats(n);
+        case MIPSF_SIZE_PLACE_POSE_SCRATCH: return mipsf::place_pose_scratch_floats(a, b, n);
+        case MIPSF_SIZE_POSE_RAYS_SCRATCH: return mipsf::pose_rays_scratch_floats(a, b, n);
+        default: mipsf::set_error("mipsf_buffer_size: unknown buffer %d", which); return ~0ull;
+    }
+}
+
 int mipsf_device_cu_count(void) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) {

@@ -25,6 +25,19 @@ inline int device_slot() {
 // CU count of the calling thread's current device (cached per device); <= 0 on error
 int device_cus();
 
+// buffer sizes behind mipsf_buffer_size (capi.hip); each is defined next to the kernels that use the buffer
+uint64_t hashgrid_bwd_scratch_floats(const mipsf_grid_meta* meta, uint32_t M, int need_dx);
+uint64_t hashgrid_counter_words(const mipsf_grid_meta* meta);
+uint64_t decoder_packed_floats();
+uint64_t decoder_saved_floats(uint32_t M);
+uint64_t decoder_dact_floats(uint32_t M);
+uint64_t decoder_wgrad_partial_floats();
+uint64_t decoder_packed16_floats(int precision);
+uint64_t decoder_tile_words(uint32_t M);
+uint64_t render_partial_floats(uint32_t N);
+uint64_t place_pose_scratch_floats(uint32_t F, uint32_t K, uint32_t N);
+uint64_t pose_rays_scratch_floats(uint32_t F, uint32_t K, uint32_t N);
+
 #define MIPSF_REQUIRE(cond, ...)                 \
     do {                                         \
         if (!(cond)) {                           \

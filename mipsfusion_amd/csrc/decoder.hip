@@ -959,17 +959,18 @@ int wgrad_reduce_launch(const float* partial, uint32_t nrec, const mipsf_decoder
 static inline uint64_t n_wave_tiles(uint32_t M) { return ((uint64_t)M + 31) / 32; }
 static inline uint64_t n_block_tiles(uint32_t M) { return ((uint64_t)M + 127) / 128; }
 
+// buffer sizes (mipsf_buffer_size, capi.hip)
+uint64_t decoder_packed_floats() { return (uint64_t)PACKED_FLOATS; }
+// saved / dact are addressed per 128-sample block tile by the weight-gradient kernel -> round up to 4 wave tiles
+uint64_t decoder_saved_floats(uint32_t M) { return n_block_tiles(M) * 4 * (ACT_TILE_FLOATS + MASK_TILE_WORDS); }
+uint64_t decoder_dact_floats(uint32_t M) { return n_block_tiles(M) * 4 * ACT_TILE_FLOATS + n_block_tiles(M) * 128 * 8; }
+uint64_t decoder_wgrad_partial_floats() { return (uint64_t)WG_MAX_BLOCKS * G_STRIDE; }
+
 }  // namespace mipsf
 
 using namespace mipsf;
 
 extern "C" {
-
-uint32_t mipsf_decoder_packed_floats(void) { return (uint32_t)PACKED_FLOATS; }
-// saved / dact are addressed per 128-sample block tile by the weight-gradient kernel -> round up to 4 wave tiles
-uint64_t mipsf_decoder_saved_floats(uint32_t M) { return n_block_tiles(M) * 4 * (ACT_TILE_FLOATS + MASK_TILE_WORDS); }
-uint64_t mipsf_decoder_dact_floats(uint32_t M) { return n_block_tiles(M) * 4 * ACT_TILE_FLOATS + n_block_tiles(M) * 128 * 8; }
-uint64_t mipsf_decoder_wgrad_partial_floats(void) { return (uint64_t)WG_MAX_BLOCKS * G_STRIDE; }
 
 int mipsf_decoder_pack(const mipsf_decoder_weights* w, float* packed, void* stream) {
     MIPSF_REQUIRE(w && packed, "null pointer");
@@ -1068,12 +1069,7 @@ static int decoder_wgrad_launch(const float* feat, int feat_layout, const float*
                                bool bf16x3, uint32_t M, void* stream);
 int mipsf_decoder_wgrad(const float* feat, int feat_layout, const float* x, const float* embed_pos, int pe_mode,
                         const float* saved, const float* dact, const mipsf_decoder_grads* grads, float* partial,
-                        uint32_t M, void* stream) {
-    return decoder_wgrad_launch(feat, feat_layout, x, embed_pos, pe_mode, saved, dact, grads, partial, false, M, stream);
-}
-int mipsf_decoder_wgrad_ex(const float* feat, int feat_layout, const float* x, const float* embed_pos, int pe_mode,
-                           const float* saved, const float* dact, const mipsf_decoder_grads* grads, float* partial,
-                           int precision, uint32_t M, void* stream) {
+                        int precision, uint32_t M, void* stream) {
     MIPSF_REQUIRE(precision == MIPSF_PREC_F32 || precision == MIPSF_PREC_BF16X3, "precision must be f32 or bf16x3");
     return decoder_wgrad_launch(feat, feat_layout, x, embed_pos, pe_mode, saved, dact, grads, partial,
                                 precision == MIPSF_PREC_BF16X3, M, stream);
@@ -1129,7 +1125,7 @@ int mipsf_decoder_bwd(const float* packed, const float* feat, int feat_layout, c
     if (int e = mipsf_decoder_bwd_chain(packed, feat_layout, x, pe_mode, out, dout, saved, dfeat, dx, dembed_pos, dact,
                                         M, stream))
         return e;
-    return mipsf_decoder_wgrad(feat, feat_layout, x, embed_pos, pe_mode, saved, dact, grads, partial, M, stream);
+    return mipsf_decoder_wgrad(feat, feat_layout, x, embed_pos, pe_mode, saved, dact, grads, partial, MIPSF_PREC_F32, M, stream);
 }
 
 }  // extern "C"

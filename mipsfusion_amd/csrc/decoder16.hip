@@ -778,7 +778,7 @@ MIPSF_SINGLE_FP32 __global__ __launch_bounds__(F16_LDS_BLOCK, 1) void decoder16_
 // like the forward: every gradient tile is an accumulator image whose registers are the next product's B operand after
 // a float -> (hi, lo) conversion; the two narrow products (Ws2^T dlogits, Wrgb^T drgb: K = 5 and 3) ride on the matrix
 // pipe as one k-step each instead of ~420 fmas and 160 table reads per tile.  Operand images come from L2.
-// LIVE-TILE BUFFER (mipsf_decoder_bwd_chain16_ex -> mipsf_decoder_wgrad16_tiles), in words:
+// LIVE-TILE BUFFER (mipsf_decoder_bwd_chain16 -> mipsf_decoder_wgrad16), in words:
 //     [64 q]        hand-out counter of queue q = blockIdx.x & 7 (persistent kernel: tiles are dealt dynamically)
 //     [64 q + 32]   number of live tiles in list q
 //     [512 + q cap] list q: the tiles with a non-zero gradient, cap = tl_cap(n_tiles)
@@ -1205,6 +1205,12 @@ static uint32_t persist_min_tiles_per_cu() {
     return (uint32_t)v;
 }
 
+namespace mipsf {
+uint64_t decoder_packed16_floats(int precision) {
+    return precision == MIPSF_PREC_BF16X6 ? (uint64_t)PACKED16X_FLOATS : (uint64_t)PACKED16_FLOATS;
+}
+}  // namespace mipsf
+
 extern "C" {
 
 #ifdef D16_TRACE
@@ -1217,19 +1223,10 @@ int mipsf_d16_trace_read(unsigned long long* host, int clear) {
     return 0;
 }
 #endif
-uint32_t mipsf_decoder_packed16_floats(void) { return (uint32_t)PACKED16_FLOATS; }
-uint32_t mipsf_decoder_packed16_floats_ex(int precision) {
-    return precision == MIPSF_PREC_BF16X6 ? (uint32_t)PACKED16X_FLOATS : (uint32_t)PACKED16_FLOATS;
-}
-
-int mipsf_decoder_pack16(const mipsf_decoder_weights* w, float* packed16, void* stream) {
-    return mipsf_decoder_pack16_ex(w, packed16, MIPSF_PREC_F16X3, stream);
-}
-
 // precision MIPSF_PREC_F16X3 / MIPSF_PREC_F16: the f16 hi / lo images (one buffer serves both modes);
-// MIPSF_PREC_BF16X6: the three bf16 planes (mipsf_decoder_packed16_floats_ex(MIPSF_PREC_BF16X6) floats) -- a buffer packed for
+// MIPSF_PREC_BF16X6: the three bf16 planes (MIPSF_SIZE_DECODER_PACKED16 floats for that precision) -- a buffer packed for
 // one family must not be handed to the kernels of the other
-int mipsf_decoder_pack16_ex(const mipsf_decoder_weights* w, float* packed16, int precision, void* stream) {
+int mipsf_decoder_pack16(const mipsf_decoder_weights* w, float* packed16, int precision, void* stream) {
     MIPSF_REQUIRE(w && packed16, "null pointer");
     MIPSF_REQUIRE(precision == MIPSF_PREC_F16X3 || precision == MIPSF_PREC_F16 || precision == MIPSF_PREC_BF16X6,
                   "precision must be f16x3, f16 or bf16x6");
@@ -1244,22 +1241,16 @@ int mipsf_decoder_pack16_ex(const mipsf_decoder_weights* w, float* packed16, int
     return check_launch("decoder_pack16");
 }
 
-int mipsf_decoder_fwd16(const float* packed16, const float* feat, int feat_layout, const float* x, float* out,
-                        float* saved, int sdf_only, int precision, uint32_t M, void* stream) {
-    return mipsf_decoder_fwd16_ex(packed16, feat, feat_layout, x, out, saved, sdf_only, precision, 0, M, stream);
-}
-
-int mipsf_decoder_fwd16_ex(const float* packed16, const float* feat, int feat_layout, const float* x, float* out,
-                           float* saved, int sdf_only, int precision, int lean_record, uint32_t M, void* stream) {
-    return mipsf_decoder_fwd16_ex2(packed16, feat, feat_layout, x, out, saved, sdf_only, precision, lean_record, nullptr, M, stream);
-}
-
 // tile_live_clear (optional): the live-tile buffer the backward chain of THIS forward will fill
-// (mipsf_decoder_bwd_chain16_ex2 with header_is_clear = 1): its counters are cleared by this launch.
-int mipsf_decoder_fwd16_ex2(const float* packed16, const float* feat, int feat_layout, const float* x, float* out,
-                            float* saved, int sdf_only, int precision, int lean_record, uint32_t* tile_live_clear,
-                            uint32_t M, void* stream) {
-    uint32_t* clear_hdr = tile_live_clear;
+// (mipsf_decoder_bwd_chain16 with MIPSF_CHAIN_HEADER_CLEAR): its counters are cleared by this launch.
+int mipsf_decoder_fwd16(const mipsf_decoder_fwd16_args* a, void* stream) {
+    MIPSF_REQUIRE(a != nullptr, "null argument block");
+    MIPSF_REQUIRE(a->struct_size == sizeof(mipsf_decoder_fwd16_args), "mipsf_decoder_fwd16_args: struct_size %u, this library expects %u",
+                  a->struct_size, (unsigned)sizeof(mipsf_decoder_fwd16_args));
+    const float* packed16 = a->packed16; const float* feat = a->feat; const int feat_layout = a->feat_layout; const float* x = a->x;
+    float* out = a->out; float* saved = a->saved; const int sdf_only = a->sdf_only, precision = a->precision, lean_record = a->lean_record;
+    const uint32_t M = a->M;
+    uint32_t* clear_hdr = a->tile_live_clear;
     if (M == 0) return 0;
     MIPSF_REQUIRE(packed16 && feat && x && out, "null pointer");
     MIPSF_REQUIRE(!lean_record || (saved && (precision == MIPSF_PREC_F16X3 || precision == MIPSF_PREC_BF16X6)),
@@ -1322,25 +1313,18 @@ int mipsf_decoder_fwd16_ex2(const float* packed16, const float* feat, int feat_l
 }
 
 
-int mipsf_decoder_bwd_chain16(const float* packed16, int feat_layout, const float* x, const float* out, const float* dout,
-                              const float* saved, float* dfeat, float* dx, float* dact, uint32_t M, void* stream) {
-    return mipsf_decoder_bwd_chain16_ex(packed16, feat_layout, x, out, dout, saved, dfeat, dx, dact, nullptr, M, stream);
-}
-
-// tile_live (optional, mipsf_decoder_tile_words(M) words): receives the lists of the 32-sample tiles whose incoming
+// tile_live (optional, MIPSF_SIZE_DECODER_TILE_WORDS words): receives the lists of the 32-sample tiles whose incoming
 // gradient is not zero throughout (layout above); the other tiles get d(features) = d(x) = 0 and NO entry in `dact` --
-// hand the same buffer to mipsf_decoder_wgrad16_tiles.
-int mipsf_decoder_bwd_chain16_ex(const float* packed16, int feat_layout, const float* x, const float* out,
-                                 const float* dout, const float* saved, float* dfeat, float* dx, float* dact,
-                                 uint32_t* tile_live, uint32_t M, void* stream) {
-    return mipsf_decoder_bwd_chain16_ex2(packed16, feat_layout, x, out, dout, saved, dfeat, dx, dact, tile_live, 0, M, stream);
-}
-
-// flags: MIPSF_CHAIN_HEADER_CLEAR = the counters of tile_live were cleared by the forward (mipsf_decoder_fwd16_ex2) and not
+// hand the same buffer to mipsf_decoder_wgrad16.
+// flags: MIPSF_CHAIN_HEADER_CLEAR = the counters of tile_live were cleared by the forward (tile_live_clear) and not
 // used since; MIPSF_CHAIN_LEAN_DACT = the lean gradient record (see decoder16_bwd_tile)
-int mipsf_decoder_bwd_chain16_ex2(const float* packed16, int feat_layout, const float* x, const float* out,
-                                  const float* dout, const float* saved, float* dfeat, float* dx, float* dact,
-                                  uint32_t* tile_live, int flags, uint32_t M, void* stream) {
+int mipsf_decoder_bwd_chain16(const mipsf_decoder_chain16_args* a, void* stream) {
+    MIPSF_REQUIRE(a != nullptr, "null argument block");
+    MIPSF_REQUIRE(a->struct_size == sizeof(mipsf_decoder_chain16_args), "mipsf_decoder_chain16_args: struct_size %u, this library expects %u",
+                  a->struct_size, (unsigned)sizeof(mipsf_decoder_chain16_args));
+    const float* packed16 = a->packed16; const int feat_layout = a->feat_layout; const float* x = a->x; const float* out = a->out;
+    const float* dout = a->dout; const float* saved = a->saved; float* dfeat = a->dfeat; float* dx = a->dx; float* dact = a->dact;
+    uint32_t* tile_live = a->tile_live; const int flags = a->flags; const uint32_t M = a->M;
     if (M == 0) return 0;
     MIPSF_REQUIRE((flags & ~(MIPSF_CHAIN_HEADER_CLEAR | MIPSF_CHAIN_LEAN_DACT | MIPSF_CHAIN_BF16X6)) == 0, "unknown flags 0x%x", flags);
     const bool bf = (flags & MIPSF_CHAIN_BF16X6) != 0;

@@ -415,13 +415,6 @@ static AdamK make_adam(float lr, float beta1, float beta2, float eps, float weig
     return k;
 }
 
-int mipsf_adam_advance(int32_t* step_dev, float* hyper_dev, float lr, float beta1, float beta2, void* stream) {
-    MIPSF_REQUIRE(step_dev && hyper_dev, "null pointer");
-    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev, hyper_dev, lr, beta1,
-                       beta2);
-    return check_launch("adam_advance");
-}
-
 int mipsf_adam_advance_n(int32_t* const* step_dev, float* const* hyper_dev, const float* lr, const float* beta1,
                          const float* beta2, uint32_t n_groups, void* stream) {
     if (n_groups == 0) return 0;
@@ -438,14 +431,8 @@ int mipsf_adam_advance_n(int32_t* const* step_dev, float* const* hyper_dev, cons
 }
 
 int mipsf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1,
-                    float beta2, float eps, float weight_decay, uint32_t step, int zero_grad, void* stream) {
-    return mipsf_adam_step_ex(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, nullptr,
-                              zero_grad, stream);
-}
-
-int mipsf_adam_step_ex(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1,
-                       float beta2, float eps, float weight_decay, uint32_t step, const float* hyper_dev,
-                       int zero_grad, void* stream) {
+                    float beta2, float eps, float weight_decay, uint32_t step, const float* hyper_dev,
+                    int zero_grad, void* stream) {
     if (n == 0) return 0;
     MIPSF_REQUIRE(param && grad && exp_avg && exp_avg_sq, "null pointer");
     MIPSF_REQUIRE(step >= 1 || hyper_dev, "step must be >= 1 (or hyper_dev given)");
@@ -464,12 +451,7 @@ int mipsf_adam_step_ex(float* param, float* grad, float* exp_avg, float* exp_avg
 }
 
 int mipsf_adam_step_multi(const mipsf_adam_tensors* t, float lr, float beta1, float beta2, float eps,
-                          float weight_decay, uint32_t step, int zero_grad, void* stream) {
-    return mipsf_adam_step_multi_ex(t, lr, beta1, beta2, eps, weight_decay, step, nullptr, zero_grad, stream);
-}
-
-int mipsf_adam_step_multi_ex(const mipsf_adam_tensors* t, float lr, float beta1, float beta2, float eps,
-                             float weight_decay, uint32_t step, const float* hyper_dev, int zero_grad, void* stream) {
+                          float weight_decay, uint32_t step, const float* hyper_dev, int zero_grad, void* stream) {
     MIPSF_REQUIRE(t != nullptr, "null tensor table");
     if (t->count == 0) return 0;
     MIPSF_REQUIRE(t->count <= MIPSF_ADAM_MAX_TENSORS, "too many tensors (%u)", t->count);

@@ -11,7 +11,7 @@
 // XCD k serves levels {k+8, k} one after the other (fine level first), which keeps each L2 filled with
 // one level's table instead of thrashing all 34 MiB through every L2.  The mapping only affects speed.
 #include "common.h"
-#include "decoder_layout.h"      // layout of the backward chain's live-tile lists (mipsf_hashgrid_dx_from_jac_tiles)
+#include "decoder_layout.h"      // layout of the backward chain's live-tile lists (mipsf_hashgrid_dx_from_jac)
 
 namespace mipsf {
 
@@ -404,6 +404,21 @@ __device__ __forceinline__ bool route_groups_hashed_pow2(const Cell& cell, uint3
 // -- samples behind the truncation band carry no loss term and no rendering weight (45-56 % of the samples, on every
 // level, tools/micro/dout_zero_probe.py) -- so routing and accumulation handle half the records.  Exact: the skipped
 // contributions are +-0.
+#ifndef MIPSF_RT_LEVELS
+#define MIPSF_RT_LEVELS 1
+#endif
+// levels routed by ONE workgroup.  Which samples are live, their compaction and their coordinates do not depend on the
+// level, so a workgroup could route its 2048 samples for level g, g + G, g + 2G, ... (G = ceil(n_levels / RT_LEVELS) level
+// groups) and pay the liveness round trip, the scan with its three barriers and the x gather once.  MEASURED (round 5, whole
+// scatter on the headline step, tools/replay.py): 1 level 108.6 us, 2: 116.3, 4: 116.4, 8: 136.8 -- the liveness loads are
+// bound by their bytes, not by one latency (4 levels: 13 700 cycles instead of 4 500), per level 18 800 cycles instead of
+// 19 900, and a quarter of the workgroups balance worse.  Kept as a switch.  Also measured and dropped: liveness from one bit
+// per sample written by the backward chain (32 KB, warm in L2) instead of from the d feat planes -- 115 us either way: the
+// phase's latency is covered by the other workgroups of the CU.  With several levels a sample counts as live when its
+// feature gradient is non-zero on ANY of them (a record for a pair with a zero gradient adds +-0: exact).
+constexpr uint32_t RT_LEVELS = MIPSF_RT_LEVELS;
+__host__ __device__ inline uint32_t route_groups(uint32_t n_levels) { return (n_levels + RT_LEVELS - 1) / RT_LEVELS; }
+
 template <int LAYOUT>
 __global__ __launch_bounds__(RT_BLOCK) void scatter_route_kernel(const float* __restrict__ x,
                                                                 const float* __restrict__ dout, uint32_t M, GridLevels g,
@@ -420,54 +435,63 @@ __global__ __launch_bounds__(RT_BLOCK) void scatter_route_kernel(const float* __
 #ifndef MIPSF_SC_STAGE_CAP
 #define MIPSF_SC_STAGE_CAP (10 * RT_BLOCK)
 #endif
-    // Records beyond the staging capacity go straight to their bins (lane-per-record stores).  A workgroup's 4096 samples
-    // make <= 4 records each on most levels; with the dead half of a mapping batch skipped that is ~8000 records, and
-    // 10240 words keep the kernel's LDS at 62 KB = two workgroups per CU, whose barrier- and round-trip-separated phases
-    // then overlap (16384 words, one workgroup per CU: +4 us on the headline step; 8192: -1 us but overflows there)
+    // Records beyond the staging capacity go straight to their bins (lane-per-record stores).  A workgroup's 2048 samples
+    // make <= 4 records each on most levels; with the dead half of a mapping batch skipped that is ~4000 records, and
+    // 5120 words keep the kernel's LDS small enough for several workgroups per CU, whose barrier- and round-trip-separated
+    // phases then overlap
     constexpr uint32_t STAGE_CAP = MIPSF_SC_STAGE_CAP;
     __shared__ uint32_t lstart[SC_MAX_NS];
     __shared__ uint32_t stage[MIPSF_SC_STAGE ? STAGE_CAP : 1];
-    const uint32_t level = blockIdx.x % plan.n_levels;
-    const uint32_t chunk = blockIdx.x / plan.n_levels;
-    const uint32_t size = g.offsets[level + 1] - g.offsets[level];
-    const uint32_t res = g.res[level];
-    const float scale = g.scale[level];
-    const uint32_t ns = plan.n_slices[level], bin0 = plan.bin0[level];
-    const uint32_t shift = plan.slice_shift[level];
-    const int mode = level_mode(res, size);
+    const uint32_t n_groups = route_groups(plan.n_levels);
+    const uint32_t group = blockIdx.x % n_groups;
+    const uint32_t chunk = blockIdx.x / n_groups;
 #ifndef MIPSF_SC_AGG_MAX
 #define MIPSF_SC_AGG_MAX 1   // measured on the mapping workload: 65 us (<= 1 bin), 67 (<= 2), 88 (<= 8)
 #endif
 #ifndef MIPSF_SC_ROUTE_FAST
 #define MIPSF_SC_ROUTE_FAST 1   // experiments: 0 = the general grouping for every sample
 #endif
-    const bool aggregate = ns <= MIPSF_SC_AGG_MAX;
 #ifdef MIPSF_RT_TRACE
     unsigned long long tr_t[10];
+    unsigned long long tr_acc[9] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
 #define RT_MARK(k) do { __builtin_amdgcn_sched_barrier(0); tr_t[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define RT_MARK(k) do { } while (0)
 #endif
     RT_MARK(0);
-    for (uint32_t q = threadIdx.x; q < ns; q += RT_BLOCK) cnt[q] = 0u;
-    __syncthreads();
     const uint32_t s0 = chunk * (RT_BLOCK * SC_ROUTE_UNR);
     // COMPACTION.  The dead samples (zero gradient) are the tails of the rays, i.e. every wave of 64 consecutive samples
     // has some: skipping them lane by lane leaves the grouping and ranking below as expensive as before.  The workgroup's
-    // live samples are first packed (order kept) into `live_list`; round u then works on entries u * 1024 + thread, and
+    // live samples are first packed (order kept) into `live_list`; round u then works on entries u * RT_BLOCK + thread, and
     // a batch that is half dead takes two rounds of full waves instead of four of half-empty ones.
     __shared__ uint32_t live_list[RT_BLOCK * SC_ROUTE_UNR];
     __shared__ uint32_t wave_base[(RT_BLOCK / 64) * SC_ROUTE_UNR + 1];
     {
         const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
         unsigned long long alive[SC_ROUTE_UNR];
+        // every liveness load of the workgroup's levels is in flight before the first is looked at: one round trip
+        float2 gy[SC_ROUTE_UNR][RT_LEVELS];
+        if (dout != nullptr) {
+#pragma unroll
+            for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u) {
+                const uint32_t i = s0 + u * RT_BLOCK + threadIdx.x;
+#pragma unroll
+                for (uint32_t k = 0; k < RT_LEVELS; ++k) {
+                    const uint32_t level = group + k * n_groups;
+                    gy[u][k] = (i < M && level < plan.n_levels)
+                                   ? *reinterpret_cast<const float2*>(dout + feat_index<LAYOUT>(i, level, M, plan.n_levels))
+                                   : make_float2(0.f, 0.f);
+                }
+            }
+        }
 #pragma unroll
         for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u) {
             const uint32_t i = s0 + u * RT_BLOCK + threadIdx.x;
             bool live = i < M;
             if (live && dout != nullptr) {
-                const float2 gy = *reinterpret_cast<const float2*>(dout + feat_index<LAYOUT>(i, level, M, plan.n_levels));
-                live = !(gy.x == 0.0f && gy.y == 0.0f);           // (NaN gradients stay live)
+                live = false;
+#pragma unroll
+                for (uint32_t k = 0; k < RT_LEVELS; ++k) live = live || !(gy[u][k].x == 0.0f && gy[u][k].y == 0.0f);   // (NaN gradients stay live)
             }
             alive[u] = __ballot(live);
             if (lane == 0) wave_base[1 + u * (RT_BLOCK / 64) + wave] = (uint32_t)__popcll(alive[u]);
@@ -495,44 +519,80 @@ __global__ __launch_bounds__(RT_BLOCK) void scatter_route_kernel(const float* __
     }
     RT_MARK(2);
     const uint32_t n_live = wave_base[(RT_BLOCK / 64) * SC_ROUTE_UNR];
+    // the samples this thread routes (round u: entry u * RT_BLOCK + thread of the list) and their coordinates: loaded once,
+    // located on every level of the group
+    uint32_t mine[SC_ROUTE_UNR];
+    float xr[SC_ROUTE_UNR][3];
+#pragma unroll
+    for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u) {
+        const uint32_t c = u * RT_BLOCK + threadIdx.x;
+        const uint32_t i = c < n_live ? live_list[c] : 0u;
+        mine[u] = i;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) xr[u][d] = x[3 * (size_t)i + d];
+    }
+    const bool masked = M <= SC_MASKED_MAX_M;
+    uint32_t* rec = ws + plan.w_records;
+#ifdef MIPSF_RT_TRACE
+    tr_acc[0] = tr_t[1] - tr_t[0], tr_acc[1] = tr_t[2] - tr_t[1];
+    uint32_t tr_levels = 0;
+#endif
+    for (uint32_t k = 0; k < RT_LEVELS; ++k) {
+    const uint32_t level = group + k * n_groups;
+    if (level >= plan.n_levels) break;
+    RT_MARK(2);
+    const uint32_t size = g.offsets[level + 1] - g.offsets[level];
+    const uint32_t res = g.res[level];
+    const float scale = g.scale[level];
+    const uint32_t ns = plan.n_slices[level], bin0 = plan.bin0[level];
+    const uint32_t shift = plan.slice_shift[level];
+    const int mode = level_mode(res, size);
+    const bool aggregate = ns <= MIPSF_SC_AGG_MAX;
+    if (k != 0u) __syncthreads();                // (the previous level's write-out has read cnt / lstart / base / stage)
+    for (uint32_t q = threadIdx.x; q < ns; q += RT_BLOCK) cnt[q] = 0u;
+    __syncthreads();
     // across the barrier, per sample: 8 slots of (slice < 512, rank < 4096) as 16-bit halves, masks as bytes
     uint32_t sp[SC_ROUTE_UNR][4], rp[SC_ROUTE_UNR][4], mp[SC_ROUTE_UNR][2];
-    uint32_t mine[SC_ROUTE_UNR];                     // the sample this thread handles in round u
 #pragma unroll
     for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u) {
         const uint32_t c = u * RT_BLOCK + threadIdx.x;
         const bool live = c < n_live;
-        const uint32_t i = live ? live_list[c] : 0u;
-        mine[u] = i;
         uint32_t s[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, m[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
         bool general = false;
         if (!__any(live)) {                          // (whole wave past the end of the list)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) sp[u][k] = 0u, rp[u][k] = 0u;
+            for (int q = 0; q < 4; ++q) sp[u][q] = 0u, rp[u][q] = 0u;
             mp[u][0] = 0u, mp[u][1] = 0u;
             continue;
         }
+        Cell cell;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {               // (locate(), from the registers)
+            const float pos = fmaf(scale, xr[u][d], 0.5f);
+            const float fl = floorf(pos);
+            cell.c[d] = (uint32_t)(int)fl;
+            cell.f[d] = pos - fl;
+        }
         if (live) {
-            const Cell cell = locate(x, i, scale);
             if (MIPSF_SC_ROUTE_FAST && mode == 0) general = !route_groups_dense(cell, res, size, shift, s, m);
             else if (MIPSF_SC_ROUTE_FAST && mode == 1) general = !route_groups_hashed_pow2(cell, size, shift, s, m);
             else general = true;
         }
         if (__any(general)) {                       // (wave-uniform: the ranking below needs whole waves)
-            if (general) route_groups_general(mode, locate(x, i, scale), res, size, shift, s, m);
+            if (general) route_groups_general(mode, cell, res, size, shift, s, m);
         }
         const bool wide = __any((m[4] | m[5] | m[6] | m[7]) != 0u) != 0;
         uint32_t r[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = ranked_add(cnt, s[k], m[k] != 0u, aggregate);
+        for (int q = 0; q < 4; ++q) r[q] = ranked_add(cnt, s[q], m[q] != 0u, aggregate);
         if (wide) {
 #pragma unroll
-            for (int k = 4; k < 8; ++k) r[k] = ranked_add(cnt, s[k], m[k] != 0u, aggregate);
+            for (int q = 4; q < 8; ++q) r[q] = ranked_add(cnt, s[q], m[q] != 0u, aggregate);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            sp[u][k] = s[2 * k] | (s[2 * k + 1] << 16);
-            rp[u][k] = r[2 * k] | (r[2 * k + 1] << 16);
+        for (int q = 0; q < 4; ++q) {
+            sp[u][q] = s[2 * q] | (s[2 * q + 1] << 16);
+            rp[u][q] = r[2 * q] | (r[2 * q + 1] << 16);
         }
         mp[u][0] = m[0] | (m[1] << 8) | (m[2] << 16) | (m[3] << 24);
         mp[u][1] = m[4] | (m[5] << 8) | (m[6] << 16) | (m[7] << 24);
@@ -546,10 +606,10 @@ __global__ __launch_bounds__(RT_BLOCK) void scatter_route_kernel(const float* __
         constexpr uint32_t PER = SC_MAX_NS / 64;
         uint32_t c[PER], sum = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < PER; ++k) {
-            const uint32_t q = threadIdx.x * PER + k;
-            c[k] = q < ns ? cnt[q] : 0u;
-            sum += c[k];
+        for (uint32_t q2 = 0; q2 < PER; ++q2) {
+            const uint32_t q = threadIdx.x * PER + q2;
+            c[q2] = q < ns ? cnt[q] : 0u;
+            sum += c[q2];
         }
         uint32_t incl = sum;
 #pragma unroll
@@ -559,10 +619,10 @@ __global__ __launch_bounds__(RT_BLOCK) void scatter_route_kernel(const float* __
         }
         uint32_t run = incl - sum;
 #pragma unroll
-        for (uint32_t k = 0; k < PER; ++k) {
-            const uint32_t q = threadIdx.x * PER + k;
+        for (uint32_t q2 = 0; q2 < PER; ++q2) {
+            const uint32_t q = threadIdx.x * PER + q2;
             if (q < ns) lstart[q] = run;
-            run += c[k];
+            run += c[q2];
         }
     }
     RT_MARK(5);
@@ -570,18 +630,16 @@ __global__ __launch_bounds__(RT_BLOCK) void scatter_route_kernel(const float* __
     RT_MARK(6);
     // record = sample index | (the corners of the sample's cell that fall into this slice) << 24: the accumulate kernel
     // then hashes those corners only (on a hashed level 2 of 8: the pair along x) instead of all 8 plus 8 membership tests
-    const bool masked = M <= SC_MASKED_MAX_M;
-    uint32_t* rec = ws + plan.w_records;
 #pragma unroll
     for (uint32_t u = 0; u < SC_ROUTE_UNR; ++u) {
         const uint32_t i = mine[u];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (k == 4 && !__any(mp[u][1] != 0u)) break;
-            const uint32_t m = (mp[u][k >> 2] >> (8 * (k & 3))) & 0xffu;
+        for (int q = 0; q < 8; ++q) {
+            if (q == 4 && !__any(mp[u][1] != 0u)) break;
+            const uint32_t m = (mp[u][q >> 2] >> (8 * (q & 3))) & 0xffu;
             if (m) {
-                const uint32_t sl = (sp[u][k >> 1] >> (16 * (k & 1))) & 0xffffu;
-                const uint32_t rk = (rp[u][k >> 1] >> (16 * (k & 1))) & 0xffffu;
+                const uint32_t sl = (sp[u][q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                const uint32_t rk = (rp[u][q >> 1] >> (16 * (q & 1))) & 0xffffu;
                 if (MIPSF_SC_STAGE) {
                     const uint32_t p = lstart[sl] + rk;
                     if (p < STAGE_CAP) {
@@ -606,10 +664,15 @@ __global__ __launch_bounds__(RT_BLOCK) void scatter_route_kernel(const float* __
     }
 #ifdef MIPSF_RT_TRACE
     RT_MARK(9);
+    for (int q = 2; q < 9; ++q) tr_acc[q] += tr_t[q + 1] - tr_t[q];
+    ++tr_levels;
+#endif
+    }
+#ifdef MIPSF_RT_TRACE
     if ((threadIdx.x & 63u) == 0u) {
         unsigned long long* tr = reinterpret_cast<unsigned long long*>(ws + plan.w_end + 64) + (size_t)(blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6)) * 10;
-        for (int k = 0; k < 9; ++k) tr[k] = tr_t[k + 1] - tr_t[k];
-        tr[9] = (unsigned long long)level;
+        for (int q = 0; q < 9; ++q) tr[q] = tr_acc[q];
+        tr[9] = (unsigned long long)(group | (tr_levels << 8));
     }
 #endif
 }
@@ -1147,24 +1210,13 @@ static int hashgrid_fwd_impl(const float* x, const float* params, float* out, fl
     return check_launch("hashgrid_fwd");
 }
 
-int mipsf_hashgrid_fwd(const float* x, const float* params, float* out, uint32_t M,
+int mipsf_hashgrid_fwd(const float* x, const float* params, float* out, float* jac, uint32_t M,
                        const mipsf_grid_meta* meta, int layout, void* stream) {
-    return hashgrid_fwd_impl(x, params, out, nullptr, M, meta, layout, stream);
-}
-
-int mipsf_hashgrid_fwd_jac(const float* x, const float* params, float* out, float* jac, uint32_t M,
-                           const mipsf_grid_meta* meta, int layout, void* stream) {
-    MIPSF_REQUIRE(jac != nullptr || M == 0, "jac is null");
     return hashgrid_fwd_impl(x, params, out, jac, M, meta, layout, stream);
 }
 
-int mipsf_hashgrid_dx_from_jac(const float* jac, const float* dout, float* dx, uint32_t M,
+int mipsf_hashgrid_dx_from_jac(const float* jac, const float* dout, float* dx, const uint32_t* tile_live, uint32_t M,
                                const mipsf_grid_meta* meta, int layout, void* stream) {
-    return mipsf_hashgrid_dx_from_jac_tiles(jac, dout, dx, nullptr, M, meta, layout, stream);
-}
-
-int mipsf_hashgrid_dx_from_jac_tiles(const float* jac, const float* dout, float* dx, const uint32_t* tile_live, uint32_t M,
-                                     const mipsf_grid_meta* meta, int layout, void* stream) {
     GridLevels g;
     if (int rc = to_levels(meta, g)) return rc;
     if (M == 0) return 0;
@@ -1178,7 +1230,9 @@ int mipsf_hashgrid_dx_from_jac_tiles(const float* jac, const float* dout, float*
     return check_launch("hashgrid_dx_from_jac");
 }
 
-uint64_t mipsf_hashgrid_bwd_scratch_floats(const mipsf_grid_meta* meta, uint32_t M, int need_dx) {
+}  // extern "C"
+namespace mipsf {
+uint64_t hashgrid_bwd_scratch_floats(const mipsf_grid_meta* meta, uint32_t M, int need_dx) {
     GridLevels g;
     if (to_levels(meta, g)) return 0;
     const ScatterPlan p = make_plan(g, M);
@@ -1186,10 +1240,17 @@ uint64_t mipsf_hashgrid_bwd_scratch_floats(const mipsf_grid_meta* meta, uint32_t
     return p.w_end + 64 + 8ull * p.max_items + 64;
 #endif
 #ifdef MIPSF_RT_TRACE
-    return p.w_end + 64 + 20ull * (RT_BLOCK / 64) * (g.n_levels * ((M + RT_BLOCK * SC_ROUTE_UNR - 1) / (RT_BLOCK * SC_ROUTE_UNR))) + 64;
+    return p.w_end + 64 + 20ull * (RT_BLOCK / 64) * (route_groups(g.n_levels) * ((M + RT_BLOCK * SC_ROUTE_UNR - 1) / (RT_BLOCK * SC_ROUTE_UNR))) + 64;
 #endif
     return p.w_end + (need_dx ? (uint64_t)g.n_levels * M * 3 : 0) + 64;
 }
+uint64_t hashgrid_counter_words(const mipsf_grid_meta* meta) {
+    GridLevels g;
+    if (to_levels(meta, g)) return 0;
+    return make_plan(g, 1).w_items;              // {counts | head, tickets | first | parts}: independent of the batch size
+}
+}  // namespace mipsf
+extern "C" {
 
 #ifdef MIPSF_SC_TRACE
 // word offset of the trace rows, their capacity and the first bin of every level (diagnosis builds only)
@@ -1205,12 +1266,13 @@ uint64_t mipsf_hashgrid_trace_words(const mipsf_grid_meta* meta, uint32_t M, uin
 
 
 #ifdef MIPSF_RT_TRACE
-// word offset of the routing kernel's trace rows (10 x 8 bytes per wave: 9 phase durations in cycles + the level) and their number
+// word offset of the routing kernel's trace rows (10 x 8 bytes per wave: 9 phase durations in cycles, the per-level phases summed
+// over the workgroup's levels, + level group | levels << 8) and their number
 uint64_t mipsf_hashgrid_rt_trace_words(const mipsf_grid_meta* meta, uint32_t M, uint32_t* n_rows) {
     GridLevels g;
     if (to_levels(meta, g)) return 0;
     const ScatterPlan p = make_plan(g, M);
-    *n_rows = (RT_BLOCK / 64) * g.n_levels * ((M + RT_BLOCK * SC_ROUTE_UNR - 1) / (RT_BLOCK * SC_ROUTE_UNR));
+    *n_rows = (RT_BLOCK / 64) * route_groups(g.n_levels) * ((M + RT_BLOCK * SC_ROUTE_UNR - 1) / (RT_BLOCK * SC_ROUTE_UNR));
     return p.w_end + 64;
 }
 #endif
@@ -1232,7 +1294,7 @@ static int launch_route(const float* x, const float* dout, int layout, uint32_t*
         const uint32_t nz = plan.w_nitems + 4;   // bin counts, queue head, tickets
         hipLaunchKernelGGL(scatter_zero_kernel, dim3((nz + 255) / 256), dim3(256), 0, s, cw, nz);
     }
-    const uint32_t rb = g.n_levels * ((M + RT_BLOCK * SC_ROUTE_UNR - 1) / (RT_BLOCK * SC_ROUTE_UNR));
+    const uint32_t rb = route_groups(g.n_levels) * ((M + RT_BLOCK * SC_ROUTE_UNR - 1) / (RT_BLOCK * SC_ROUTE_UNR));
     if (layout == MIPSF_FEAT_AOS)
         hipLaunchKernelGGL(scatter_route_kernel<MIPSF_FEAT_AOS>, dim3(rb), dim3(RT_BLOCK), 0, s, x, dout, M, g, plan, ws, cw);
     else
@@ -1241,7 +1303,7 @@ static int launch_route(const float* x, const float* dout, int layout, uint32_t*
 }
 
 // The routing half of the parameter-gradient scatter depends on the sample positions only: a caller may run it as soon
-// as x exists (e.g. on a second stream next to the forward pass) and hand the scratch buffer to mipsf_hashgrid_bwd_routed.
+// as x exists (e.g. on a second stream next to the forward pass) and hand the scratch buffer to mipsf_hashgrid_bwd with MIPSF_HG_ROUTED.
 int mipsf_hashgrid_route(const float* x, float* scratch, uint32_t M, const mipsf_grid_meta* meta, void* stream) {
     GridLevels g;
     if (int rc = to_levels(meta, g)) return rc;
@@ -1251,12 +1313,6 @@ int mipsf_hashgrid_route(const float* x, float* scratch, uint32_t M, const mipsf
     if (int rc = check_plan(plan, g, M)) return rc;
     uint32_t* ws = reinterpret_cast<uint32_t*>(scratch);
     return launch_route(x, nullptr, MIPSF_FEAT_AOS, ws, ws, true, M, g, plan, (hipStream_t)stream);
-}
-
-uint64_t mipsf_hashgrid_counter_words(const mipsf_grid_meta* meta) {
-    GridLevels g;
-    if (to_levels(meta, g)) return 0;
-    return make_plan(g, 1).w_items;              // {counts | head, tickets | first | parts}: independent of the batch size
 }
 
 static int hashgrid_bwd_impl(const float* x, const float* params, const float* dout, float* dparams, float* dx,
@@ -1324,33 +1380,17 @@ static int hashgrid_bwd_impl(const float* x, const float* params, const float* d
     return 0;
 }
 
-int mipsf_hashgrid_bwd(const float* x, const float* params, const float* dout, float* dparams, float* dx,
-                       float* scratch, uint32_t M, const mipsf_grid_meta* meta, int layout, void* stream) {
-    return hashgrid_bwd_impl(x, params, dout, dparams, dx, scratch, nullptr, M, meta, layout, false, stream);
-}
-
-int mipsf_hashgrid_bwd_keep(const float* x, const float* params, const float* dout, float* dparams, float* dx,
-                            float* scratch, uint32_t* counters, uint32_t M, const mipsf_grid_meta* meta, int layout,
-                            void* stream) {
-    MIPSF_REQUIRE(counters, "null counter block");
-    return hashgrid_bwd_impl(x, params, dout, dparams, dx, scratch, counters, M, meta, layout, false, stream);
-}
-
-// the same with flags: MIPSF_HG_DPARAMS_ZERO = the caller vouches that dparams is all zero on entry (a gradient buffer the
+// ONE entry point for the family (round 5): every option is a field of the argument block (include/mipsf.h); unset fields
+// are zero / NULL.  MIPSF_HG_DPARAMS_ZERO = the caller vouches that dparams is all zero on entry (a gradient buffer the
 // optimiser cleared, a fresh torch.zeros): the table slices are stored instead of read-modify-written -- 36 MB less to read
 // on the headline table, and a work item of the accumulate kernel no longer waits for its slice's old values
-int mipsf_hashgrid_bwd_keep_ex(const float* x, const float* params, const float* dout, float* dparams, float* dx,
-                               float* scratch, uint32_t* counters, uint32_t M, const mipsf_grid_meta* meta, int layout,
-                               uint32_t flags, void* stream) {
-    MIPSF_REQUIRE(counters, "null counter block");
-    MIPSF_REQUIRE((flags & ~(uint32_t)MIPSF_HG_DPARAMS_ZERO) == 0u, "unknown flags 0x%x", flags);
-    return hashgrid_bwd_impl(x, params, dout, dparams, dx, scratch, counters, M, meta, layout, false, stream,
-                             (flags & MIPSF_HG_DPARAMS_ZERO) != 0u);
-}
-
-int mipsf_hashgrid_bwd_routed(const float* x, const float* params, const float* dout, float* dparams, float* dx,
-                              float* scratch, uint32_t M, const mipsf_grid_meta* meta, int layout, void* stream) {
-    return hashgrid_bwd_impl(x, params, dout, dparams, dx, scratch, nullptr, M, meta, layout, true, stream);
+int mipsf_hashgrid_bwd(const mipsf_hashgrid_bwd_args* a, void* stream) {
+    MIPSF_REQUIRE(a != nullptr, "null argument block");
+    MIPSF_REQUIRE(a->struct_size == sizeof(mipsf_hashgrid_bwd_args), "mipsf_hashgrid_bwd_args: struct_size %u, this library expects %u",
+                  a->struct_size, (unsigned)sizeof(mipsf_hashgrid_bwd_args));
+    MIPSF_REQUIRE((a->flags & ~(uint32_t)(MIPSF_HG_DPARAMS_ZERO | MIPSF_HG_ROUTED)) == 0u, "unknown flags 0x%x", a->flags);
+    return hashgrid_bwd_impl(a->x, a->params, a->dout, a->dparams, a->dx, a->scratch, a->counters, a->M, a->meta, a->feat_layout,
+                             (a->flags & MIPSF_HG_ROUTED) != 0u, stream, (a->flags & MIPSF_HG_DPARAMS_ZERO) != 0u);
 }
 
 int mipsf_hashgrid_indices(const float* x, uint32_t* idx, uint32_t M, const mipsf_grid_meta* meta, void* stream) {

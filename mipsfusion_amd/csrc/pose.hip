@@ -148,9 +148,9 @@ using namespace mipsf;
 
 extern "C" {
 
-int mipsf_pose_rays_fwd(const float* fixed_poses, const float* rot, const float* trans, uint32_t F, uint32_t K,
-                        const int64_t* owner, const float* d_cam, float* rays_o, float* rays_d, uint32_t N,
-                        void* stream) {
+static int pose_rays_fwd_plain(const float* fixed_poses, const float* rot, const float* trans, uint32_t F, uint32_t K,
+                               const int64_t* owner, const float* d_cam, float* rays_o, float* rays_d, uint32_t N,
+                               void* stream) {
     if (N == 0) return 0;
     MIPSF_REQUIRE(owner && d_cam && rays_o && rays_d, "null pointer");
     MIPSF_REQUIRE((F == 0 || fixed_poses) && (K == 0 || (rot && trans)), "null pose pointer");
@@ -160,10 +160,12 @@ int mipsf_pose_rays_fwd(const float* fixed_poses, const float* rot, const float*
     return check_launch("pose_rays_fwd");
 }
 
-int mipsf_gather_pose_rays_fwd(const float* db, uint64_t n_rows, const int64_t* idx, const float* fixed_poses,
-                               const float* rot, const float* trans, uint32_t F, uint32_t K, const int64_t* owner,
-                               float* d_cam, float* rgb, float* depth, float* rays_o, float* rays_d, uint32_t N,
-                               void* stream) {
+// db != NULL: the rows idx[N] of the ray table are gathered first (d_cam, rgb, depth are written); db NULL: d_cam is an input
+int mipsf_pose_rays_fwd(const float* db, uint64_t n_rows, const int64_t* idx, const float* fixed_poses,
+                        const float* rot, const float* trans, uint32_t F, uint32_t K, const int64_t* owner,
+                        float* d_cam, float* rgb, float* depth, float* rays_o, float* rays_d, uint32_t N,
+                        void* stream) {
+    if (db == nullptr) return pose_rays_fwd_plain(fixed_poses, rot, trans, F, K, owner, d_cam, rays_o, rays_d, N, stream);
     if (N == 0) return 0;
     MIPSF_REQUIRE(db && idx && owner && d_cam && rgb && depth && rays_o && rays_d, "null pointer");
     MIPSF_REQUIRE((F == 0 || fixed_poses) && (K == 0 || (rot && trans)), "null pose pointer");
@@ -174,19 +176,17 @@ int mipsf_gather_pose_rays_fwd(const float* db, uint64_t n_rows, const int64_t* 
     return check_launch("gather_pose_rays_fwd");
 }
 
-uint64_t mipsf_pose_rays_scratch_floats(uint32_t F, uint32_t K, uint32_t N) {
+}  // extern "C"
+namespace mipsf {
+uint64_t pose_rays_scratch_floats(uint32_t F, uint32_t K, uint32_t N) {
     return 1ull + 12ull * (F + K) * ((N + PR_BLOCK - 1) / PR_BLOCK);
 }
+}  // namespace mipsf
+extern "C" {
 
 int mipsf_pose_rays_bwd(const float* g_rays_o, const float* g_rays_d, const float* rot, uint32_t F, uint32_t K,
                         const int64_t* owner, const float* d_cam, float* d_rot, float* d_trans, float* scratch,
-                        uint32_t N, void* stream) {
-    return mipsf_pose_rays_bwd_ex(g_rays_o, g_rays_d, rot, F, K, owner, d_cam, d_rot, d_trans, scratch, N, 0, stream);
-}
-
-int mipsf_pose_rays_bwd_ex(const float* g_rays_o, const float* g_rays_d, const float* rot, uint32_t F, uint32_t K,
-                           const int64_t* owner, const float* d_cam, float* d_rot, float* d_trans, float* scratch,
-                           uint32_t N, int accumulate, void* stream) {
+                        uint32_t N, int accumulate, void* stream) {
     MIPSF_REQUIRE(K >= 1, "no optimisable pose");
     MIPSF_REQUIRE(rot && owner && d_cam && d_rot && d_trans && scratch, "null pointer");
     MIPSF_REQUIRE(F + K <= PR_MAX_POSES, "number of poses %u above %d", F + K, PR_MAX_POSES);

@@ -199,7 +199,7 @@ struct LossFinalize {           // FUSED: the last workgroup of render_fwd_kerne
     const float* loss_weights;
     float* loss_total;
     double* sums_out;           // != null: the nine sums of THIS batch are left here and the losses are NOT finished (a share of
-};                              // a ray-data-parallel batch: mipsf_render_fwd_sums; the sums of all shares go to mipsf_loss_finalize_sums)
+};                              // a ray-data-parallel batch: mipsf_render_fwd (sums); the sums of all shares go to mipsf_loss_finalize_sums)
 
 MIPSF_SINGLE_FP32 __device__ void finalize_losses(const double (&t)[9], float emd_w, uint32_t N, uint32_t S, float* __restrict__ losses,
                                 const float* __restrict__ loss_weights, float* __restrict__ loss_total);
@@ -759,9 +759,18 @@ int mipsf_gather_pose_place_fwd(const float* db, uint64_t n_rows, const int64_t*
     return check_launch("gather_pose_place");
 }
 
-uint64_t mipsf_place_pose_scratch_floats(uint32_t F, uint32_t K, uint32_t N) {
+}  // extern "C"
+namespace mipsf {
+uint64_t place_pose_scratch_floats(uint32_t F, uint32_t K, uint32_t N) {
     return 1ull + 12ull * (F + K) * ((N + PPB - 1) / PPB);
 }
+uint64_t render_partial_floats(uint32_t N) {
+    // per-ray rows of the two-launch form (8 floats per ray) or one row of nine doubles per 16-ray workgroup of the fused form
+    const uint64_t rows = 8ull * N, fused = 18ull * (((uint64_t)N + 15) / 16);
+    return rows > fused ? rows : fused;
+}
+}  // namespace mipsf
+extern "C" {
 
 int mipsf_place_pose_bwd(const float* dxn, const float* z_vals, const mipsf_render_cfg* cfg, const float* rot, uint32_t F,
                          uint32_t K, const int64_t* owner, const float* d_cam, float* d_rot, float* d_trans, float* scratch,
@@ -777,27 +786,29 @@ int mipsf_place_pose_bwd(const float* dxn, const float* z_vals, const mipsf_rend
     return check_launch("place_pose_bwd");
 }
 
-int mipsf_render_fwd(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
-                     const uint32_t* counts, const mipsf_render_cfg* cfg, float* rgb, float* depth,
-                     float* depth_var, float* disp, float* acc, float* weights, float* losses, float* partial,
-                     uint32_t N, uint32_t S, void* stream) {
-    return mipsf_render_fwd_ex(raw, z_vals, target_rgb, target_d, counts, cfg, rgb, depth, depth_var, disp, acc, weights,
-                               losses, partial, nullptr, nullptr, N, S, stream);
-}
+static int render_fwd_sums(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
+                           const uint32_t* counts, const mipsf_render_cfg* cfg, float* rgb, float* depth, float* depth_var,
+                           float* disp, float* acc, float* weights, float* partial, double* sums, uint32_t* ticket, uint32_t N,
+                           uint32_t S, void* stream);
 
-int mipsf_render_fwd_ex(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
-                        const uint32_t* counts, const mipsf_render_cfg* cfg, float* rgb, float* depth,
-                        float* depth_var, float* disp, float* acc, float* weights, float* losses, float* partial,
-                        const float* loss_weights, float* loss_total, uint32_t N, uint32_t S, void* stream) {
-    return mipsf_render_fwd_ex2(raw, z_vals, target_rgb, target_d, counts, cfg, rgb, depth, depth_var, disp, acc, weights,
-                                losses, partial, loss_weights, loss_total, nullptr, N, S, stream);
-}
-
-int mipsf_render_fwd_ex2(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
-                         const uint32_t* counts, const mipsf_render_cfg* cfg, float* rgb, float* depth,
-                         float* depth_var, float* disp, float* acc, float* weights, float* losses, float* partial,
-                         const float* loss_weights, float* loss_total, uint32_t* ticket, uint32_t N, uint32_t S,
-                         void* stream) {
+// ONE entry point for the forward (round 5; include/mipsf.h): evaluation, training in two launches, training in one launch
+// (ticket), the training objective formed in the same launch (loss_weights / loss_total), a share of a ray-data-parallel
+// batch (sums).
+int mipsf_render_fwd(const mipsf_render_fwd_args* a, void* stream) {
+    MIPSF_REQUIRE(a != nullptr, "null argument block");
+    MIPSF_REQUIRE(a->struct_size == sizeof(mipsf_render_fwd_args), "mipsf_render_fwd_args: struct_size %u, this library expects %u",
+                  a->struct_size, (unsigned)sizeof(mipsf_render_fwd_args));
+    const float* raw = a->raw; const float* z_vals = a->z_vals; const float* target_rgb = a->target_rgb; const float* target_d = a->target_d;
+    const uint32_t* counts = a->counts; const mipsf_render_cfg* cfg = a->cfg; float* rgb = a->rgb; float* depth = a->depth;
+    float* depth_var = a->depth_var; float* disp = a->disp; float* acc = a->acc; float* weights = a->weights; float* losses = a->losses;
+    float* partial = a->partial; const float* loss_weights = a->loss_weights; float* loss_total = a->loss_total;
+    uint32_t* ticket = a->ticket; const uint32_t N = a->N, S = a->S;
+    if (a->sums != nullptr) {
+        MIPSF_REQUIRE(losses == nullptr && loss_weights == nullptr && loss_total == nullptr,
+                      "sums: the losses of a share are finished by mipsf_loss_finalize_sums, not here");
+        return render_fwd_sums(raw, z_vals, target_rgb, target_d, counts, cfg, rgb, depth, depth_var, disp, acc, weights, partial,
+                               a->sums, ticket, N, S, stream);
+    }
     MIPSF_REQUIRE((loss_weights == nullptr) == (loss_total == nullptr), "loss_weights and loss_total come together");
     MIPSF_REQUIRE(loss_total == nullptr || losses != nullptr, "loss_total needs the training mode (losses)");
     if (N == 0) return 0;
@@ -827,19 +838,13 @@ int mipsf_render_fwd_ex2(const float* raw, const float* z_vals, const float* tar
     return check_launch("render_fwd");
 }
 
-uint64_t mipsf_render_partial_floats(uint32_t N) {
-    // per-ray rows of the two-launch form (8 floats per ray) or one row of nine doubles per 16-ray workgroup of the fused form
-    const uint64_t rows = 8ull * N, fused = 18ull * (((uint64_t)N + 15) / 16);
-    return rows > fused ? rows : fused;
-}
-
 // A SHARE of a batch (ray-data-parallel training): the per-ray maps of this share and the nine fp64 sums its losses are made
 // of -- {rgb_sq, depth_sq(valid), fs_sq, sdf_sq, fs_emd, sdf_emd, n_valid, n_front, n_band} -- in sums[9] (device).  The
 // caller adds the shares' sums (an all-reduce of 72 bytes) and finishes the losses with mipsf_loss_finalize_sums.
-int mipsf_render_fwd_sums(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
-                          const uint32_t* counts, const mipsf_render_cfg* cfg, float* rgb, float* depth, float* depth_var,
-                          float* disp, float* acc, float* weights, float* partial, double* sums, uint32_t* ticket, uint32_t N,
-                          uint32_t S, void* stream) {
+static int render_fwd_sums(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
+                           const uint32_t* counts, const mipsf_render_cfg* cfg, float* rgb, float* depth, float* depth_var,
+                           float* disp, float* acc, float* weights, float* partial, double* sums, uint32_t* ticket, uint32_t N,
+                           uint32_t S, void* stream) {
     MIPSF_REQUIRE(cfg && raw && z_vals && rgb && depth && target_rgb && target_d && counts && partial && sums && ticket, "null pointer");
     MIPSF_REQUIRE(S >= 1 && S <= MAX_S, "samples per ray %u outside [1,%d]", S, MAX_S);
     hipStream_t s = (hipStream_t)stream;
@@ -854,7 +859,7 @@ int mipsf_render_fwd_sums(const float* raw, const float* z_vals, const float* ta
     return check_launch("render_fwd_sums");
 }
 
-// losses[8] (and loss_total, as in mipsf_render_fwd_ex) of a batch of N_total rays from its nine sums
+// losses[8] (and loss_total, as in mipsf_render_fwd) of a batch of N_total rays from its nine sums
 int mipsf_loss_finalize_sums(const double* sums, const mipsf_render_cfg* cfg, uint32_t N_total, uint32_t S, float* losses,
                              const float* loss_weights, float* loss_total, void* stream) {
     MIPSF_REQUIRE(sums && cfg && losses, "null pointer");
@@ -864,27 +869,14 @@ int mipsf_loss_finalize_sums(const double* sums, const mipsf_render_cfg* cfg, ui
     return check_launch("loss_finalize_sums");
 }
 
-int mipsf_render_bwd(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
-                     const uint32_t* counts, const float* losses, const mipsf_render_cfg* cfg,
-                     const float* g_losses, const float* g_rgb, const float* g_depth, float* draw, uint32_t N,
-                     uint32_t S, void* stream) {
-    return mipsf_render_bwd_ex(raw, z_vals, target_rgb, target_d, counts, losses, cfg, g_losses, nullptr, nullptr, g_rgb,
-                               g_depth, draw, N, S, stream);
-}
-
-int mipsf_render_bwd_ex(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
-                        const uint32_t* counts, const float* losses, const mipsf_render_cfg* cfg,
-                        const float* g_losses, const float* g_total, const float* loss_weights, const float* g_rgb,
-                        const float* g_depth, float* draw, uint32_t N, uint32_t S, void* stream) {
-    return mipsf_render_bwd_ex2(raw, z_vals, target_rgb, target_d, counts, losses, cfg, g_losses, g_total, loss_weights, g_rgb,
-                                g_depth, draw, N, N, S, stream);
-}
-
-int mipsf_render_bwd_ex2(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
-                         const uint32_t* counts, const float* losses, const mipsf_render_cfg* cfg,
-                         const float* g_losses, const float* g_total, const float* loss_weights, const float* g_rgb,
-                         const float* g_depth, float* draw, uint32_t N, uint32_t N_norm, uint32_t S, void* stream) {
-    (void)counts;
+int mipsf_render_bwd(const mipsf_render_bwd_args* a, void* stream) {
+    MIPSF_REQUIRE(a != nullptr, "null argument block");
+    MIPSF_REQUIRE(a->struct_size == sizeof(mipsf_render_bwd_args), "mipsf_render_bwd_args: struct_size %u, this library expects %u",
+                  a->struct_size, (unsigned)sizeof(mipsf_render_bwd_args));
+    const float* raw = a->raw; const float* z_vals = a->z_vals; const float* target_rgb = a->target_rgb; const float* target_d = a->target_d;
+    const float* losses = a->losses; const mipsf_render_cfg* cfg = a->cfg; const float* g_losses = a->g_losses;
+    const float* g_total = a->g_total; const float* loss_weights = a->loss_weights; const float* g_rgb = a->g_rgb;
+    const float* g_depth = a->g_depth; float* draw = a->draw; const uint32_t N = a->N, S = a->S, N_norm = a->N_norm ? a->N_norm : a->N;
     if (N == 0) return 0;
     MIPSF_REQUIRE(N_norm >= N, "N_norm = %u: the normalising ray count cannot be below this launch's %u rays", N_norm, N);
     MIPSF_REQUIRE(cfg && raw && z_vals && draw, "null pointer");

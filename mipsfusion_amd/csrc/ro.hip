@@ -263,22 +263,13 @@ using namespace mipsf;
 extern "C" {
 
 int mipsf_ro_particles(const float* pst, const float* state, const float* rays_d_cam, const float* target_d,
-                       const mipsf_render_cfg* cfg, float* xn, float* pst7, uint32_t P, uint32_t n, void* stream) {
+                       const mipsf_render_cfg* cfg, float* xn, float* pst7, uint32_t P, uint32_t n, int point_major,
+                       void* stream) {
     if (P == 0 || n == 0) return 0;
     MIPSF_REQUIRE(pst && state && rays_d_cam && target_d && cfg && xn && pst7, "null pointer");
     const uint32_t threads = P * MIPSF_WAVE;
     hipLaunchKernelGGL(ro_particles_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, pst, state,
-                       rays_d_cam, target_d, make_norm(*cfg), xn, pst7, P, n, 0);
-    return check_launch("ro_particles");
-}
-
-int mipsf_ro_particles_pm(const float* pst, const float* state, const float* rays_d_cam, const float* target_d,
-                          const mipsf_render_cfg* cfg, float* xn, float* pst7, uint32_t P, uint32_t n, void* stream) {
-    if (P == 0 || n == 0) return 0;
-    MIPSF_REQUIRE(pst && state && rays_d_cam && target_d && cfg && xn && pst7, "null pointer");
-    const uint32_t threads = P * MIPSF_WAVE;
-    hipLaunchKernelGGL(ro_particles_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, pst, state,
-                       rays_d_cam, target_d, make_norm(*cfg), xn, pst7, P, n, 1);
+                       rays_d_cam, target_d, make_norm(*cfg), xn, pst7, P, n, point_major ? 1 : 0);
     return check_launch("ro_particles");
 }
 

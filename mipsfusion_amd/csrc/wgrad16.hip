@@ -452,7 +452,7 @@ __device__ __forceinline__ void w16_role_a(const W16Args& a, const typename A::v
     }
 }
 
-// Role A of the LEAN record (mipsf_decoder_fwd16_ex: H1 is not stored).  H1 is RECOMPUTED, directly in the layout the product
+// Role A of the LEAN record (mipsf_decoder_fwd16: H1 is not stored).  H1 is RECOMPUTED, directly in the layout the product
 // wants: the forward evaluates H1^T = W1 e^T with the weight image as A operand; with the operands swapped the same
 // instruction yields H1 = e W1^T -- lane = feature, registers = 16 samples -- from the SAME image (an A-operand image of
 // W1's rows is a B-operand image of W1^T's columns) and the same e operands, products in the same order: the forward's H1,
@@ -1348,7 +1348,7 @@ __global__ __launch_bounds__(W16_BLOCK, 2) void decoder_wgrad16_kernel(const flo
                                                                        uint32_t n_tiles_all,
                                                                        const uint32_t* __restrict__ live, uint32_t lean_dact) {
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // live: the chain kernel's live-tile buffer (mipsf_decoder_bwd_chain16_ex): eight lists, visited one after the other
+    // live: the chain kernel's live-tile buffer (mipsf_decoder_bwd_chain16): eight lists, visited one after the other
     uint32_t n_tiles = n_tiles_all, live_start[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (live) {
         n_tiles = 0;
@@ -1437,35 +1437,18 @@ extern "C" int mipsf_w16_trace_read(unsigned long long* host, int clear) {
     return 0;
 }
 #endif
-extern "C" uint64_t mipsf_decoder_tile_words(uint32_t M) {
-    return TL_HEADER + 8ull * tl_cap((uint32_t)(((uint64_t)M + 31) / 32));
-}
+namespace mipsf {
+uint64_t decoder_tile_words(uint32_t M) { return TL_HEADER + 8ull * tl_cap((uint32_t)(((uint64_t)M + 31) / 32)); }
+}  // namespace mipsf
 
-extern "C" int mipsf_decoder_wgrad16(const float* feat, int feat_layout, const float* x, const float* saved,
-                                     const float* dact, const mipsf_decoder_grads* grads, float* partial, int arithmetic,
-                                     uint32_t M, void* stream) {
-    return mipsf_decoder_wgrad16_ex(nullptr, feat, feat_layout, x, saved, dact, grads, partial, arithmetic, M, stream);
-}
-
-extern "C" int mipsf_decoder_wgrad16_ex(const float* packed16, const float* feat, int feat_layout, const float* x,
-                                        const float* saved, const float* dact, const mipsf_decoder_grads* grads,
-                                        float* partial, int arithmetic, uint32_t M, void* stream) {
-    return mipsf_decoder_wgrad16_tiles(packed16, feat, feat_layout, x, saved, dact, nullptr, grads, partial, arithmetic, M,
-                                       stream);
-}
-
-extern "C" int mipsf_decoder_wgrad16_tiles(const float* packed16, const float* feat, int feat_layout, const float* x,
-                                           const float* saved, const float* dact, const uint32_t* tile_live,
-                                           const mipsf_decoder_grads* grads, float* partial, int arithmetic, uint32_t M,
-                                           void* stream) {
-    return mipsf_decoder_wgrad16_tiles_ex(packed16, feat, feat_layout, x, saved, dact, tile_live, grads, partial, arithmetic, 0u,
-                                          M, stream);
-}
-
-extern "C" int mipsf_decoder_wgrad16_tiles_ex(const float* packed16, const float* feat, int feat_layout, const float* x,
-                                              const float* saved, const float* dact, const uint32_t* tile_live,
-                                              const mipsf_decoder_grads* grads, float* partial, int arithmetic,
-                                              uint32_t flags, uint32_t M, void* stream) {
+extern "C" int mipsf_decoder_wgrad16(const mipsf_decoder_wgrad16_args* a, void* stream) {
+    MIPSF_REQUIRE(a != nullptr, "null argument block");
+    MIPSF_REQUIRE(a->struct_size == sizeof(mipsf_decoder_wgrad16_args), "mipsf_decoder_wgrad16_args: struct_size %u, this library expects %u",
+                  a->struct_size, (unsigned)sizeof(mipsf_decoder_wgrad16_args));
+    const float* packed16 = a->packed16; const float* feat = a->feat; const int feat_layout = a->feat_layout; const float* x = a->x;
+    const float* saved = a->saved; const float* dact = a->dact; const uint32_t* tile_live = a->tile_live;
+    const mipsf_decoder_grads* grads = a->grads; float* partial = a->partial; const int arithmetic = a->arithmetic;
+    const uint32_t flags = a->flags, M = a->M;
     if (M == 0) return 0;
     MIPSF_REQUIRE((flags & ~(uint32_t)MIPSF_WGRAD_LEAN_DACT) == 0u, "unknown flags 0x%x", flags);
     const uint32_t lean_dact = (flags & MIPSF_WGRAD_LEAN_DACT) ? 1u : 0u;

@@ -67,11 +67,11 @@ def hashgrid_fwd(x: torch.Tensor, params: torch.Tensor, meta, layout=FEAT_AOS, w
     if with_jac:
         jac = torch.empty((meta.n_levels, 3, M, 2), dtype=torch.float32, device=x.device)
         with _timed("hashgrid_fwd"):
-            check(lib().mipsf_hashgrid_fwd_jac(dptr(x), dptr(params), dptr(out), dptr(jac), M, C.byref(meta), layout,
-                                               stream_ptr()), "hashgrid_fwd_jac")
+            check(lib().mipsf_hashgrid_fwd(dptr(x), dptr(params), dptr(out), dptr(jac), M, C.byref(meta), layout,
+                                           stream_ptr()), "hashgrid_fwd (with the Jacobian)")
         return out, jac
     with _timed("hashgrid_fwd"):
-        check(lib().mipsf_hashgrid_fwd(dptr(x), dptr(params), dptr(out), M, C.byref(meta), layout, stream_ptr()),
+        check(lib().mipsf_hashgrid_fwd(dptr(x), dptr(params), dptr(out), None, M, C.byref(meta), layout, stream_ptr()),
               "hashgrid_fwd")
     return out
 
@@ -83,8 +83,8 @@ def hashgrid_dx_from_jac(jac, dout, dx, meta, layout=FEAT_AOS, tiles=None):
     gradient added into `dout` afterwards (a feature regulariser, say) makes them stale -- leave `tiles` out then."""
     M = dx.shape[0]
     with _timed("hashgrid_dx"):
-        check(lib().mipsf_hashgrid_dx_from_jac_tiles(dptr(jac), dptr(dout), dptr(dx), dptr(tiles, torch.int32), M,
-                                                     C.byref(meta), layout, stream_ptr()), "hashgrid_dx_from_jac")
+        check(lib().mipsf_hashgrid_dx_from_jac(dptr(jac), dptr(dout), dptr(dx), dptr(tiles, torch.int32), M,
+                                               C.byref(meta), layout, stream_ptr()), "hashgrid_dx_from_jac")
 
 
 _SIDE_STREAMS = {}
@@ -130,7 +130,7 @@ def hashgrid_route_ahead(x, meta):
     the CALLER must make the current stream wait for `event` (or the side stream) before the scratch buffer's memory can
     be reused -- ``hashgrid_bwd`` does.  Works under hipGraph capture (a fork / join of the captured stream)."""
     M = x.shape[0]
-    n = lib().mipsf_hashgrid_bwd_scratch_floats(C.byref(meta), M, 0)
+    n = _lib.buffer_size(_lib.SIZE_HASHGRID_BWD_SCRATCH, M, 0, 0, meta)
     scratch = torch.empty(n, dtype=torch.float32, device=x.device)       # owned by the CURRENT stream's allocator pool
     main, side = torch.cuda.current_stream(x.device), side_stream(x.device)
     side.wait_stream(main)
@@ -162,11 +162,11 @@ _lib.KEPT_BLOCK_CACHES.append(_SCATTER_COUNTERS)
 
 def _scatter_counters(device, meta):
     """The routed scatter's counter block (bin counts, queue head, tickets): zero once, left ready by every call
-    (mipsf_hashgrid_bwd_keep), so one zero-initialised block per (device, stream, size) is kept -- calls on one stream are
+    (mipsf_hashgrid_bwd), so one zero-initialised block per (device, stream, size) is kept -- calls on one stream are
     ordered -- and no call launches a clearing kernel.  One stream per block: a graph captured on stream A must not be
     replayed concurrently on two streams (both replays would count in the same block); a failed call empties the cache
     (_lib.check)."""
-    n = int(lib().mipsf_hashgrid_counter_words(C.byref(meta)))
+    n = _lib.buffer_size(_lib.SIZE_HASHGRID_COUNTER_WORDS, meta=meta)
     key = (device.index, stream_ptr(), n)
     buf = _SCATTER_COUNTERS.get(key)
     if buf is None:
@@ -177,6 +177,7 @@ def _scatter_counters(device, meta):
 # the chain kernel leaves out the half of its gradient record that the weight-gradient kernel can recompute (experiments: 0)
 LEAN_DACT = not bool(os.environ.get("MIPSF_FULL_DACT"))
 HG_DPARAMS_ZERO = 1     # include/mipsf.h MIPSF_HG_DPARAMS_ZERO
+HG_ROUTED = 2           # MIPSF_HG_ROUTED
 _HG_IGNORE_ZERO_HINT = bool(os.environ.get("MIPSF_HG_IGNORE_ZERO_HINT"))     # experiments: always read-modify-write
 
 
@@ -189,20 +190,22 @@ def hashgrid_bwd(x, params, dout, dparams, meta, layout=FEAT_AOS, dx: Optional[t
     if PROFILE is not None:
         global _LAST_SCATTER_DOUT
         _LAST_SCATTER_DOUT = dout
+    a = _lib.HashgridBwdArgs.new(M=M, x=dptr(x), params=dptr(params), dout=dptr(dout), dparams=dptr(dparams),
+                                 meta=C.pointer(meta), feat_layout=layout)
     if routed is not None and dx is None and dparams is not None:
         scratch, ev = routed
         torch.cuda.current_stream(x.device).wait_event(ev)
+        a.scratch, a.flags = dptr(scratch), HG_ROUTED
         with _timed("hashgrid_bwd"):
-            check(lib().mipsf_hashgrid_bwd_routed(dptr(x), dptr(params), dptr(dout), dptr(dparams), None, dptr(scratch),
-                                                  M, C.byref(meta), layout, stream_ptr()), "hashgrid_bwd_routed")
+            check(lib().mipsf_hashgrid_bwd(C.byref(a), stream_ptr()), "hashgrid_bwd (routed)")
         return
-    n = lib().mipsf_hashgrid_bwd_scratch_floats(C.byref(meta), M, 1 if dx is not None else 0)
+    n = _lib.buffer_size(_lib.SIZE_HASHGRID_BWD_SCRATCH, M, 1 if dx is not None else 0, 0, meta)
     scratch = torch.empty(n, dtype=torch.float32, device=x.device)
     counters = _scatter_counters(x.device, meta)
+    a.dx, a.scratch, a.counters = dptr(dx), dptr(scratch), dptr(counters, torch.int32)
+    a.flags = HG_DPARAMS_ZERO if (dparams_zero and not _HG_IGNORE_ZERO_HINT) else 0
     with _timed("hashgrid_bwd"):
-        check(lib().mipsf_hashgrid_bwd_keep_ex(dptr(x), dptr(params), dptr(dout), dptr(dparams), dptr(dx), dptr(scratch),
-                                               dptr(counters, torch.int32), M, C.byref(meta), layout,
-                                               HG_DPARAMS_ZERO if (dparams_zero and not _HG_IGNORE_ZERO_HINT) else 0, stream_ptr()), "hashgrid_bwd")
+        check(lib().mipsf_hashgrid_bwd(C.byref(a), stream_ptr()), "hashgrid_bwd")
 
 
 def hashgrid_indices(x, meta) -> torch.Tensor:
@@ -276,7 +279,7 @@ def decoder_pack(weights, packed: Optional[torch.Tensor] = None) -> torch.Tensor
     """weights: the 10 nn.Linear tensors in DECODER_PARAM_ORDER -> MFMA operand images."""
     dev = weights[0].device
     if packed is None:
-        packed = torch.empty(lib().mipsf_decoder_packed_floats(), dtype=torch.float32, device=dev)
+        packed = torch.empty(_lib.buffer_size(_lib.SIZE_DECODER_PACKED), dtype=torch.float32, device=dev)
     ws = [w.detach() for w in weights]
     st = _decoder_struct(ws, _lib.DecoderWeights)
     with _timed("decoder_pack"):
@@ -290,14 +293,14 @@ def decoder_pack16(weights, packed16: Optional[torch.Tensor] = None, precision: 
     "bf16x6": the three bf16 pieces of every weight (another, larger buffer: it is for the bf16x6 kernels only)."""
     dev = weights[0].device
     fam = _PACK16_FAMILY[precision]
-    n = lib().mipsf_decoder_packed16_floats_ex(_lib.PREC[fam])
+    n = _lib.buffer_size(_lib.SIZE_DECODER_PACKED16, 0, _lib.PREC[fam])
     if packed16 is None:
         packed16 = torch.empty(n, dtype=torch.float32, device=dev)
     elif packed16.numel() != n:
         raise RuntimeError(f"packed16 has {packed16.numel()} floats, precision {precision!r} needs {n}")
     st = _decoder_struct([w.detach() for w in weights], _lib.DecoderWeights)
     with _timed("decoder_pack"):
-        check(lib().mipsf_decoder_pack16_ex(C.byref(st), dptr(packed16), _lib.PREC[fam], stream_ptr()), "decoder_pack16")
+        check(lib().mipsf_decoder_pack16(C.byref(st), dptr(packed16), _lib.PREC[fam], stream_ptr()), "decoder_pack16")
     packed16.mipsf_family = fam
     return packed16
 
@@ -326,7 +329,7 @@ def decoder_fwd(packed, feat, layout, x, embed_pos, M, save, precision: str = "f
     out = torch.empty((M, 10), dtype=torch.float32, device=x.device)
     saved = None
     if save:
-        saved = torch.empty(lib().mipsf_decoder_saved_floats(M), dtype=torch.float32, device=x.device)
+        saved = torch.empty(_lib.buffer_size(_lib.SIZE_DECODER_SAVED, M), dtype=torch.float32, device=x.device)
     if precision != "f32":
         if embed_pos is not None or packed16 is None:
             raise RuntimeError("the f16 decoder modes take packed16 and compute the positional encoding in-kernel")
@@ -337,11 +340,12 @@ def decoder_fwd(packed, feat, layout, x, embed_pos, M, save, precision: str = "f
         # their counters (a memset in front of the chain kernel was a launch of its own)
         tile_live = None
         if save and SKIP_ZERO_TILES:
-            tile_live = torch.empty(lib().mipsf_decoder_tile_words(M), dtype=torch.int32, device=x.device)
+            tile_live = torch.empty(_lib.buffer_size(_lib.SIZE_DECODER_TILE_WORDS, M), dtype=torch.int32, device=x.device)
+        a = _lib.DecoderFwd16Args.new(M=M, packed16=dptr(packed16), feat=dptr(feat), x=dptr(x), out=dptr(out), saved=dptr(saved),
+                                      tile_live_clear=dptr(tile_live, torch.int32), feat_layout=layout,
+                                      precision=_lib.PREC[precision], lean_record=(2 if masks_only else 1) if lean else 0)
         with _timed("decoder_fwd"):
-            check(lib().mipsf_decoder_fwd16_ex2(dptr(packed16), dptr(feat), layout, dptr(x), dptr(out), dptr(saved), 0,
-                                                _lib.PREC[precision], (2 if masks_only else 1) if lean else 0, dptr(tile_live, torch.int32), M,
-                                                stream_ptr()), "decoder_fwd16")
+            check(lib().mipsf_decoder_fwd16(C.byref(a), stream_ptr()), "decoder_fwd16")
         if lean:
             saved.mipsf_lean_record = True          # decoder_bwd refuses to read H1 from such a record
         if masks_only:
@@ -390,7 +394,7 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
     dx = torch.empty((M, 3), dtype=torch.float32, device=dev)
     dpe = torch.empty((M, 48), dtype=torch.float32, device=dev) if embed_pos is not None else None
     # (a frozen decoder behind the f16x3 chain: the pre-activation gradients are for the weight-gradient kernel only)
-    dact = None if (grads is None and precision in SPLIT_PRECISIONS) else torch.empty(lib().mipsf_decoder_dact_floats(M), dtype=torch.float32, device=dev)
+    dact = None if (grads is None and precision in SPLIT_PRECISIONS) else torch.empty(_lib.buffer_size(_lib.SIZE_DECODER_DACT, M), dtype=torch.float32, device=dev)
     pe_mode = 0 if embed_pos is None else 1
     tile_live = None
     lean_dact = False
@@ -410,19 +414,20 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
                 tile_live, hdr_clear = pre[0], hdr_clear | 1
                 pre[1] = False                      # (a second backward through the same record clears them itself)
             else:
-                tile_live = torch.empty(lib().mipsf_decoder_tile_words(M), dtype=torch.int32, device=dev)
+                tile_live = torch.empty(_lib.buffer_size(_lib.SIZE_DECODER_TILE_WORDS, M), dtype=torch.int32, device=dev)
             _LAST_TILE_LIVE = (tile_live, M)
+        a = _lib.DecoderChain16Args.new(M=M, packed16=dptr(packed16), x=dptr(x), out=dptr(out), dout=dptr(dout), saved=dptr(saved),
+                                        dfeat=dptr(dfeat), dx=dptr(dx), dact=dptr(dact), tile_live=dptr(tile_live, torch.int32),
+                                        feat_layout=layout, flags=hdr_clear | (2 if lean_dact else 0))
         with _timed("decoder_bwd_chain"):
-            check(lib().mipsf_decoder_bwd_chain16_ex2(dptr(packed16), layout, dptr(x), dptr(out), dptr(dout), dptr(saved),
-                                                      dptr(dfeat), dptr(dx), dptr(dact), dptr(tile_live, torch.int32),
-                                                      hdr_clear | (2 if lean_dact else 0), M, stream_ptr()), "decoder_bwd_chain16")
+            check(lib().mipsf_decoder_bwd_chain16(C.byref(a), stream_ptr()), "decoder_bwd_chain16")
     else:
         with _timed("decoder_bwd_chain"):
             check(lib().mipsf_decoder_bwd_chain(dptr(packed), layout, dptr(x), pe_mode, dptr(out), dptr(dout),
                                                 dptr(saved), dptr(dfeat), dptr(dx), dptr(dpe), dptr(dact), M,
                                                 stream_ptr()), "decoder_bwd_chain")
     if grads is not None:
-        partial = torch.empty(lib().mipsf_decoder_wgrad_partial_floats(), dtype=torch.float32, device=dev)
+        partial = torch.empty(_lib.buffer_size(_lib.SIZE_DECODER_WGRAD_PARTIAL), dtype=torch.float32, device=dev)
         st = _decoder_struct(grads, _lib.DecoderGrads)
         if wgrad_precision.startswith("stream_"):
             # streaming kernel (csrc/wgrad16.hip): "stream_f16x3" (default of the f16x3 decoder), "stream_bf16x6", "stream_bf16x3"
@@ -433,19 +438,19 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
                 raise RuntimeError("recompute_h1 needs wgrad_precision 'stream_f16x3' / 'stream_bf16x6' and packed16")
             if recompute_h1:
                 _check_family(packed16, wgrad_precision[len("stream_"):])
+            a = _lib.DecoderWgrad16Args.new(M=M, packed16=dptr(packed16) if recompute_h1 else None, feat=dptr(feat), x=dptr(x),
+                                            saved=dptr(saved), dact=dptr(dact), tile_live=dptr(tile_live, torch.int32),
+                                            grads=C.pointer(st), partial=dptr(partial), feat_layout=layout, arithmetic=arith,
+                                            flags=1 if lean_dact else 0)
             with _timed("decoder_wgrad"):
-                check(lib().mipsf_decoder_wgrad16_tiles_ex(dptr(packed16) if recompute_h1 else None, dptr(feat), layout,
-                                                           dptr(x), dptr(saved), dptr(dact),
-                                                           dptr(tile_live, torch.int32), C.byref(st), dptr(partial), arith,
-                                                           1 if lean_dact else 0, M, stream_ptr()),
-                      "decoder_wgrad16")
+                check(lib().mipsf_decoder_wgrad16(C.byref(a), stream_ptr()), "decoder_wgrad16")
             return (dfeat, dx, dpe, tile_live) if return_tiles else (dfeat, dx, dpe)
         if recompute_h1:
             raise RuntimeError("recompute_h1 needs wgrad_precision 'stream_f16x3'")
         with _timed("decoder_wgrad"):
             wprec = _lib.PREC[wgrad_precision]
-            check(lib().mipsf_decoder_wgrad_ex(dptr(feat), layout, dptr(x), dptr(embed_pos), pe_mode, dptr(saved),
-                                               dptr(dact), C.byref(st), dptr(partial), wprec, M, stream_ptr()),
+            check(lib().mipsf_decoder_wgrad(dptr(feat), layout, dptr(x), dptr(embed_pos), pe_mode, dptr(saved),
+                                            dptr(dact), C.byref(st), dptr(partial), wprec, M, stream_ptr()),
                   "decoder_wgrad")
     return (dfeat, dx, dpe, tile_live) if return_tiles else (dfeat, dx, dpe)
 
@@ -459,8 +464,9 @@ def decoder_fwd_sdf(packed, feat, layout, x, embed_pos, M, precision: str = "f32
             raise RuntimeError("the f16 decoder modes take packed16 and compute the positional encoding in-kernel")
         _check_family(packed16, precision)
         with _timed("decoder_fwd"):
-            check(lib().mipsf_decoder_fwd16(dptr(packed16), dptr(feat), layout, dptr(x), dptr(sdf), None, 1,
-                                            _lib.PREC[precision], M, stream_ptr()), "decoder_fwd16")
+            a = _lib.DecoderFwd16Args.new(M=M, packed16=dptr(packed16), feat=dptr(feat), x=dptr(x), out=dptr(sdf), feat_layout=layout,
+                                          precision=_lib.PREC[precision], sdf_only=1)
+            check(lib().mipsf_decoder_fwd16(C.byref(a), stream_ptr()), "decoder_fwd16")
         return sdf
     pe_mode = 0 if embed_pos is None else 1
     with _timed("decoder_fwd"):
@@ -539,6 +545,13 @@ def sample_rays(rays_o, rays_d, target_d, noise, tables, rc, N, S):
     return z_vals, xn, counts
 
 
+def _render_fwd_args(raw, z_vals, target_rgb, target_d, counts, rc, rgb, depth, var, disp, acc, weights, N, S):
+    return _lib.RenderFwdArgs.new(N=N, S=S, raw=dptr(raw), z_vals=dptr(z_vals), target_rgb=dptr(target_rgb), target_d=dptr(target_d),
+                                  counts=dptr(counts, torch.int32) if counts is not None else None, cfg=C.pointer(rc),
+                                  rgb=dptr(rgb), depth=dptr(depth), depth_var=dptr(var), disp=dptr(disp), acc=dptr(acc),
+                                  weights=dptr(weights))
+
+
 def render_fwd(raw, z_vals, target_rgb, target_d, counts, rc, N, S, train: bool, want_weights=False, loss_weights=None,
                share_of=None):
     """loss_weights (train only): device tensor of the 4 loss weights -> an 8th return value, the objective
@@ -552,16 +565,15 @@ def render_fwd(raw, z_vals, target_rgb, target_d, counts, rc, N, S, train: bool,
     rgb, depth, var, disp, acc = f(N, 3), f(N), f(N), f(N), f(N)
     weights = f(N, S) if want_weights else None
     losses = f(8) if train else None
-    partial = f(int(lib().mipsf_render_partial_floats(N))) if train else None
+    partial = f(_lib.buffer_size(_lib.SIZE_RENDER_PARTIAL, N)) if train else None
     total = f(1) if (train and loss_weights is not None) else None
     ticket = _zeroed_words(dev, 1, "render_fwd") if train else None    # the last workgroup finishes the losses: one launch
     if train and share_of is not None:
         sums = torch.zeros(10, dtype=torch.float64, device=dev)
+        a = _render_fwd_args(raw, z_vals, target_rgb, target_d, counts, rc, rgb, depth, var, disp, acc, weights, N, S)
+        a.partial, a.sums, a.ticket = dptr(partial), dptr(sums, torch.float64), dptr(ticket, torch.int32)
         with _timed("render_fwd"):
-            check(lib().mipsf_render_fwd_sums(dptr(raw), dptr(z_vals), dptr(target_rgb), dptr(target_d),
-                                              dptr(counts, torch.int32), C.byref(rc), dptr(rgb), dptr(depth), dptr(var),
-                                              dptr(disp), dptr(acc), dptr(weights), dptr(partial), dptr(sums, torch.float64),
-                                              dptr(ticket, torch.int32), N, S, stream_ptr()), "render_fwd_sums")
+            check(lib().mipsf_render_fwd(C.byref(a), stream_ptr()), "render_fwd (sums of a share)")
         sums[9] = float(N)
         sums = share_of(sums)
         n_total = int(round(float(sums[9])))            # (one small read-back per step: the collective synchronises anyway)
@@ -571,12 +583,11 @@ def render_fwd(raw, z_vals, target_rgb, target_d, counts, rc, N, S, train: bool,
         if loss_weights is not None:
             return rgb, depth, var, disp, acc, weights, losses, total, n_total
         return rgb, depth, var, disp, acc, weights, losses, None, n_total
+    a = _render_fwd_args(raw, z_vals, target_rgb, target_d, counts, rc, rgb, depth, var, disp, acc, weights, N, S)
+    a.losses, a.partial, a.ticket = dptr(losses), dptr(partial), dptr(ticket, torch.int32)
+    a.loss_weights, a.loss_total = (dptr(loss_weights) if total is not None else None), dptr(total)
     with _timed("render_fwd"):
-        check(lib().mipsf_render_fwd_ex2(dptr(raw), dptr(z_vals), dptr(target_rgb), dptr(target_d),
-                                         dptr(counts, torch.int32) if counts is not None else None, C.byref(rc), dptr(rgb),
-                                         dptr(depth), dptr(var), dptr(disp), dptr(acc), dptr(weights), dptr(losses),
-                                         dptr(partial), dptr(loss_weights) if total is not None else None, dptr(total),
-                                         dptr(ticket, torch.int32), N, S, stream_ptr()), "render_fwd")
+        check(lib().mipsf_render_fwd(C.byref(a), stream_ptr()), "render_fwd")
     if loss_weights is not None and train:
         return rgb, depth, var, disp, acc, weights, losses, total
     return rgb, depth, var, disp, acc, weights, losses
@@ -587,12 +598,14 @@ def render_bwd(raw, z_vals, target_rgb, target_d, counts, losses, rc, g_losses, 
     """g_total / loss_weights: gradient of render_fwd's objective and its weights (the kernel forms g_total * w itself).
     n_norm: the ray count the losses were normalised by when these N rays are a share of a larger batch (render_fwd(share_of=))."""
     draw = torch.empty_like(raw)
+    a = _lib.RenderBwdArgs.new(N=N, S=S, N_norm=0 if n_norm is None else int(n_norm), raw=dptr(raw), z_vals=dptr(z_vals),
+                               target_rgb=dptr(target_rgb), target_d=dptr(target_d),
+                               counts=dptr(counts, torch.int32) if counts is not None else None, losses=dptr(losses),
+                               cfg=C.pointer(rc), g_losses=dptr(g_losses), g_total=dptr(g_total),
+                               loss_weights=dptr(loss_weights) if g_total is not None else None, g_rgb=dptr(g_rgb),
+                               g_depth=dptr(g_depth), draw=dptr(draw))
     with _timed("render_bwd"):
-        check(lib().mipsf_render_bwd_ex2(dptr(raw), dptr(z_vals), dptr(target_rgb), dptr(target_d),
-                                         dptr(counts, torch.int32) if counts is not None else None, dptr(losses),
-                                         C.byref(rc), dptr(g_losses), dptr(g_total),
-                                         dptr(loss_weights) if g_total is not None else None, dptr(g_rgb), dptr(g_depth),
-                                         dptr(draw), N, N if n_norm is None else int(n_norm), S, stream_ptr()), "render_bwd")
+        check(lib().mipsf_render_bwd(C.byref(a), stream_ptr()), "render_bwd")
     return draw
 
 
@@ -614,7 +627,7 @@ def _pose_scratch(device, F, K, N):
     """Scratch of mipsf_pose_rays_bwd: its first word is a ticket that must be zero on entry and is left zero by the
     kernel, so one zero-initialised buffer per (device, stream, size) is kept and reused (calls on one stream are
     ordered; no per-call memset launch)."""
-    n = int(lib().mipsf_pose_rays_scratch_floats(F, K, N))
+    n = _lib.buffer_size(_lib.SIZE_POSE_RAYS_SCRATCH, N, F, K)
     key = (device.index, stream_ptr(), n)
     buf = _POSE_SCRATCH.get(key)
     if buf is None:
@@ -650,13 +663,14 @@ class PoseRaysFn(torch.autograd.Function):
         rays_d = torch.empty((N, 3), dtype=torch.float32, device=dev)
         with _timed("pose_rays_fwd"):
             if table is not None:
-                check(lib().mipsf_gather_pose_rays_fwd(dptr(flat), flat.shape[0], dptr(rows, torch.int64), dptr(fixed),
-                                                       dptr(rot), dptr(trans), F, K, dptr(owner, torch.int64), dptr(d_cam),
-                                                       dptr(rgb), dptr(depth), dptr(rays_o), dptr(rays_d), N, stream_ptr()),
-                      "gather_pose_rays_fwd")
+                check(lib().mipsf_pose_rays_fwd(dptr(flat), flat.shape[0], dptr(rows, torch.int64), dptr(fixed),
+                                                dptr(rot), dptr(trans), F, K, dptr(owner, torch.int64), dptr(d_cam),
+                                                dptr(rgb), dptr(depth), dptr(rays_o), dptr(rays_d), N, stream_ptr()),
+                      "pose_rays_fwd (rows of the ray table)")
             else:
-                check(lib().mipsf_pose_rays_fwd(dptr(fixed), dptr(rot), dptr(trans), F, K, dptr(owner, torch.int64),
-                                                dptr(d_cam), dptr(rays_o), dptr(rays_d), N, stream_ptr()), "pose_rays_fwd")
+                check(lib().mipsf_pose_rays_fwd(None, 0, None, dptr(fixed), dptr(rot), dptr(trans), F, K,
+                                                dptr(owner, torch.int64), dptr(d_cam), None, None, dptr(rays_o), dptr(rays_d), N,
+                                                stream_ptr()), "pose_rays_fwd")
         ctx.F, ctx.K, ctx.N = F, K, N
         ctx.save_for_backward(rot, owner, d_cam)
         ctx.set_materialize_grads(False)
@@ -685,9 +699,9 @@ class PoseRaysFn(torch.autograd.Function):
             d_rot = torch.empty((ctx.K, 4), dtype=torch.float32, device=rot.device)
             d_trans = torch.empty((ctx.K, 3), dtype=torch.float32, device=rot.device)
         with _timed("pose_rays_bwd"):
-            check(lib().mipsf_pose_rays_bwd_ex(dptr(g_o), dptr(g_d), dptr(rot), ctx.F, ctx.K, dptr(owner, torch.int64),
-                                               dptr(d_cam), dptr(d_rot), dptr(d_trans), dptr(scratch), ctx.N,
-                                               1 if direct else 0, stream_ptr()), "pose_rays_bwd")
+            check(lib().mipsf_pose_rays_bwd(dptr(g_o), dptr(g_d), dptr(rot), ctx.F, ctx.K, dptr(owner, torch.int64),
+                                            dptr(d_cam), dptr(d_rot), dptr(d_trans), dptr(scratch), ctx.N,
+                                            1 if direct else 0, stream_ptr()), "pose_rays_bwd")
         if direct:
             return None, None, None, None, None, None, None, None
         return d_rot, d_trans, None, None, None, None, None, None
@@ -743,7 +757,7 @@ class GatherPosePlaceFn(torch.autograd.Function):
         if dxn is None:
             return (None,) * 11
         rot, owner, d_cam, z_vals = ctx.saved_tensors
-        n = int(lib().mipsf_place_pose_scratch_floats(ctx.F, ctx.K, ctx.N))
+        n = _lib.buffer_size(_lib.SIZE_PLACE_POSE_SCRATCH, ctx.N, ctx.F, ctx.K)
         key = (rot.device.index, stream_ptr(), "place", n)
         scratch = _POSE_SCRATCH.get(key)
         if scratch is None:
@@ -770,8 +784,7 @@ class GatherPosePlaceFn(torch.autograd.Function):
 
 # ----------------------------------------------------------------------------------- Adam
 def adam_advance(step_dev, hyper_dev, lr, beta1, beta2):
-    check(lib().mipsf_adam_advance(dptr(step_dev, torch.int32), dptr(hyper_dev), lr, beta1, beta2, stream_ptr()),
-          "adam_advance")
+    adam_advance_n([(step_dev, hyper_dev, lr, beta1, beta2)])
 
 
 def adam_advance_n(groups):
@@ -788,9 +801,9 @@ def adam_advance_n(groups):
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, zero_grad=False,
               hyper_dev=None):
     with _timed("adam_step" if param.numel() > (1 << 20) else "adam_step_small"):
-        check(lib().mipsf_adam_step_ex(dptr(param), dptr(grad), dptr(exp_avg), dptr(exp_avg_sq), param.numel(), lr,
-                                       beta1, beta2, eps, weight_decay, step, dptr(hyper_dev),
-                                       1 if zero_grad else 0, stream_ptr()), "adam_step")
+        check(lib().mipsf_adam_step(dptr(param), dptr(grad), dptr(exp_avg), dptr(exp_avg_sq), param.numel(), lr,
+                                    beta1, beta2, eps, weight_decay, step, dptr(hyper_dev),
+                                    1 if zero_grad else 0, stream_ptr()), "adam_step")
 
 
 def adam_step_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, weight_decay, step, zero_grad=False,
@@ -804,8 +817,8 @@ def adam_step_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps,
             t.param[j], t.grad[j], t.exp_avg[j], t.exp_avg_sq[j] = dptr(p), dptr(g), dptr(m), dptr(v)
             t.numel[j] = p.numel()
         with _timed("adam_step_small"):
-            check(lib().mipsf_adam_step_multi_ex(C.byref(t), lr, beta1, beta2, eps, weight_decay, step,
-                                                 dptr(hyper_dev), 1 if zero_grad else 0, stream_ptr()),
+            check(lib().mipsf_adam_step_multi(C.byref(t), lr, beta1, beta2, eps, weight_decay, step,
+                                              dptr(hyper_dev), 1 if zero_grad else 0, stream_ptr()),
                   "adam_step_multi")
 
 
@@ -871,10 +884,9 @@ def ro_particles(pst, state, rays_d_cam, target_d, rc, point_major: bool = False
     P, n = pst.shape[0], rays_d_cam.shape[0]
     xn = torch.empty((P * n, 3), dtype=torch.float32, device=pst.device)
     pst7 = torch.empty((P, 7), dtype=torch.float32, device=pst.device)
-    fn = lib().mipsf_ro_particles_pm if point_major else lib().mipsf_ro_particles
     with _timed("ro_particles"):
-        check(fn(dptr(pst), dptr(state), dptr(rays_d_cam), dptr(target_d), C.byref(rc), dptr(xn), dptr(pst7), P, n,
-                 stream_ptr()), "ro_particles")
+        check(lib().mipsf_ro_particles(dptr(pst), dptr(state), dptr(rays_d_cam), dptr(target_d), C.byref(rc), dptr(xn),
+                                       dptr(pst7), P, n, 1 if point_major else 0, stream_ptr()), "ro_particles")
     return xn, pst7
 
 

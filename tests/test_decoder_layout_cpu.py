@@ -81,7 +81,7 @@ TOTAL = layout_offsets()
 
 def pack_host(w):
     lib = _lib.lib()
-    assert lib.mipsf_decoder_packed_floats() == TOTAL
+    assert _lib.buffer_size(_lib.SIZE_DECODER_PACKED) == TOTAL
     keep = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in w.items()}
     st = _lib.DecoderWeights()
     for field, key in (("w_pts0", "pts_linear.0.weight"), ("b_pts0", "pts_linear.0.bias"),
@@ -391,7 +391,7 @@ class _SinAt(torch.autograd.Function):
 
 
 def test_packed_size_matches_library():
-    assert _lib.lib().mipsf_decoder_packed_floats() == TOTAL
+    assert _lib.buffer_size(_lib.SIZE_DECODER_PACKED) == TOTAL
 
 
 def test_chain_forward_backward_and_wgrad_match_oracle(problem):

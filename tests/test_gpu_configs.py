@@ -675,9 +675,13 @@ def test_two_process_run_exercises_every_sharding(dev):
     res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    assert len(line) < 6000                      # the line the driver parses (bench.compact_line); the full result is beside it
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
-    mg = out["multi_gpu"]
+    assert out["multi_gpu"]["ranks"]["world_size"] == 2 and len(out["multi_gpu"]["ms_per_step_of_each_rank"]) == 2
+    detail = json.load(open(os.path.join(root, "bench_detail.json")))
+    assert detail["value"] == out["value"]
+    mg = detail["multi_gpu"]
     assert mg["ranks"]["world_size"] == 2 and mg["ranks"]["backend"] == "gloo" and len(mg["ranks"]["device_of_rank"]) == 2
     print("\ntwo ranks on one GPU (gloo):", json.dumps(mg))
     assert mg["ro_split_pose_equals_unsplit"] is True

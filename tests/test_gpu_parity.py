@@ -194,7 +194,7 @@ def test_scatter_counter_block_survives_many_alternating_calls(dev):
         dy[:, torch.rand(M, device=dev) < 0.5] = 0.0
         batches.append((x, dy))
     counters = ops._scatter_counters(dev, meta)
-    n_bins_plus = int(_lib.lib().mipsf_hashgrid_counter_words(meta)) - 8
+    n_bins_plus = _lib.buffer_size(_lib.SIZE_HASHGRID_COUNTER_WORDS, meta=meta) - 8
     n_bins = n_bins_plus // 3
     want = []
     for x, dy in batches:
@@ -668,8 +668,8 @@ def test_fused_adam_whole_step_in_one_launch(dev):
 
 
 def test_render_losses_finished_in_the_render_launch(dev):
-    """mipsf_render_fwd_ex2 (the last workgroup of the render kernel finishes the losses, one launch) against the
-    two-launch form mipsf_render_fwd_ex: every output and all eight loss entries, at ray counts that leave the last
+    """mipsf_render_fwd with a ticket (the last workgroup of the render kernel finishes the losses, one launch) against the
+    two-launch form mipsf_render_fwd: every output and all eight loss entries, at ray counts that leave the last
     16-ray workgroup partly empty and that need one / several workgroups; the ticket is left at zero and repeated calls
     agree bit for bit."""
     import ctypes as C
@@ -691,10 +691,12 @@ def test_render_losses_finished_in_the_render_launch(dev):
             f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)      # noqa: E731
             outs = [f(N, 3), f(N), f(N), f(N), f(N)]
             losses, partial, total = f(8), f(N * 8), f(1)
-            rcode = lib().mipsf_render_fwd_ex2(dptr(raw), dptr(z), dptr(t_rgb), dptr(t_d), dptr(counts, torch.int32), C.byref(rc),
-                                               *[dptr(o) for o in outs], None, dptr(losses), dptr(partial), dptr(lw), dptr(total),
-                                               dptr(ticket, torch.int32) if ticket is not None else None, N, S, stream_ptr())
-            assert rcode == 0
+            a = _lib.RenderFwdArgs.new(N=N, S=S, raw=dptr(raw), z_vals=dptr(z), target_rgb=dptr(t_rgb), target_d=dptr(t_d),
+                                       counts=dptr(counts, torch.int32), cfg=C.pointer(rc), rgb=dptr(outs[0]), depth=dptr(outs[1]),
+                                       depth_var=dptr(outs[2]), disp=dptr(outs[3]), acc=dptr(outs[4]), losses=dptr(losses),
+                                       partial=dptr(partial), loss_weights=dptr(lw), loss_total=dptr(total),
+                                       ticket=dptr(ticket, torch.int32) if ticket is not None else None)
+            assert lib().mipsf_render_fwd(C.byref(a), stream_ptr()) == 0
             return outs, losses, total
         ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         o2, l2, t2 = run(None)
@@ -899,11 +901,11 @@ def test_pose_rays_bwd_ticket_reduction_under_load(dev):
     owner = torch.arange(N, device=dev) // 64 % P
     d_cam = torch.randn(N, 3, device=dev)
     sets = [(torch.randn(N, 3, device=dev), torch.randn(N, 3, device=dev)) for _ in range(2)]
-    scratch = torch.zeros(int(lib().mipsf_pose_rays_scratch_floats(F, K, N)), device=dev)
+    scratch = torch.zeros(_lib.buffer_size(_lib.SIZE_POSE_RAYS_SCRATCH, N, F, K), device=dev)
 
     def call(k, out_rot, out_trans):
         go, gd = sets[k]
-        rc = lib().mipsf_pose_rays_bwd_ex(dptr(go), dptr(gd), dptr(rot), F, K, dptr(owner, torch.int64), dptr(d_cam),
+        rc = lib().mipsf_pose_rays_bwd(dptr(go), dptr(gd), dptr(rot), F, K, dptr(owner, torch.int64), dptr(d_cam),
                                           dptr(out_rot), dptr(out_trans), dptr(scratch), N, 0, stream_ptr())
         assert rc == 0
     want = []
@@ -1405,7 +1407,7 @@ def test_autograd_grad_and_partial_backward_with_trainable_params(dev):
 
 def test_route_ahead_on_second_stream_gives_identical_gradients(dev, monkeypatch):
     """JointEncoding.route_ahead (opt-in): the routing half of the hash grid's backward runs on a second stream next to
-    the forward (mipsf_hashgrid_route + mipsf_hashgrid_bwd_routed instead of mipsf_hashgrid_bwd).  Same kernels on the
+    the forward (mipsf_hashgrid_route + mipsf_hashgrid_bwd with MIPSF_HG_ROUTED instead of mipsf_hashgrid_bwd).  Same kernels on the
     same data: every gradient must equal the single-stream path's (to the run-to-run noise of the scatter's atomics),
     eagerly and inside a captured graph."""
     from mipsfusion_amd.model import scene_rep
@@ -1574,7 +1576,7 @@ def test_decoder_f16x3_forward_matches_fp32_kernel_and_oracle(dev, M, layout):
 @pytest.mark.parametrize("M", [64, 4096 + 17, 70000])
 @pytest.mark.parametrize("layout", ["aos", "level_major"])
 def test_decoder_backward_short_cuts_zero_gradient_tiles_exactly(dev, M, layout):
-    """ops.decoder_bwd with the zero-tile flags (mipsf_decoder_bwd_chain16_ex + mipsf_decoder_wgrad16_tiles) against the
+    """ops.decoder_bwd with the zero-tile flags (mipsf_decoder_bwd_chain16 + mipsf_decoder_wgrad16) against the
     same call with every tile processed: the incoming gradient is zero on the tail of every 64-sample ray (as behind the
     truncation band, scene_rep.py:58-78), on some whole rays and on scattered single samples.  d(features) and d(x) must
     be EQUAL (the skipped tiles are zeros either way, the others go through the same arithmetic); the parameter gradients

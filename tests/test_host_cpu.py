@@ -23,7 +23,8 @@ def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "mipsf.h")).read()
     declared = set(re.findall(r"\b(mipsf_[a-z0-9_]+)\s*\(", header))
     declared -= {"mipsf_grid_meta", "mipsf_decoder_weights", "mipsf_decoder_grads", "mipsf_render_cfg"}
-    assert len(declared) >= 25
+    assert 25 <= len(declared) <= 45, "one argument block per kernel family, not a suffix per option (review of round 4)"
+    assert not [n for n in declared if re.search(r"_ex\d*$|_v$|_keep$|_tiles$", n)]
     handle = C.CDLL(_lib.LIB_PATH)
     for name in sorted(declared):
         assert hasattr(handle, name), f"{name} declared in mipsf.h but not exported"
@@ -32,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_channel():
     lib = _lib.lib()
-    assert lib.mipsf_abi_version() == 1
+    assert lib.mipsf_abi_version() == 2
     m = _lib.GridMeta()
     rc = lib.mipsf_hashgrid_meta_init(C.byref(m), 16, 4, 19, 16, 1.2)
     assert rc != 0 and b"n_features" in lib.mipsf_last_error()
@@ -45,9 +46,22 @@ def test_size_queries_and_failed_calls_reset_the_kept_blocks():
     doubles per 16-ray workgroup: the larger for N < 3 -- a caller with exact allocations used to be overrun), the bf16x6 operand
     buffer is the f16 one plus its plane-2 extension; a failed call empties every cache of caller-kept counter blocks."""
     lib = _lib.lib()
-    assert [int(lib.mipsf_render_partial_floats(n)) for n in (1, 2, 3, 16, 17, 4096)] == [18, 18, 24, 128, 136, 32768]
-    f16, bf = lib.mipsf_decoder_packed16_floats_ex(_lib.PREC["f16x3"]), lib.mipsf_decoder_packed16_floats_ex(_lib.PREC["bf16x6"])
-    assert f16 == lib.mipsf_decoder_packed16_floats() == lib.mipsf_decoder_packed16_floats_ex(_lib.PREC["f16"]) and bf > f16
+    assert [_lib.buffer_size(_lib.SIZE_RENDER_PARTIAL, n) for n in (1, 2, 3, 16, 17, 4096)] == [18, 18, 24, 128, 136, 32768]
+    f16, bf = (_lib.buffer_size(_lib.SIZE_DECODER_PACKED16, 0, _lib.PREC[k]) for k in ("f16x3", "bf16x6"))
+    assert f16 == _lib.buffer_size(_lib.SIZE_DECODER_PACKED16, 0, _lib.PREC["f16"]) and bf > f16
+    with pytest.raises(RuntimeError, match="unknown buffer"):
+        _lib.buffer_size(99)
+    # an argument block of another size (a caller built against another header) is refused before anything is launched
+    a = _lib.HashgridBwdArgs.new()
+    a.struct_size += 8
+    assert lib.mipsf_hashgrid_bwd(C.byref(a), None) != 0 and b"struct_size" in lib.mipsf_last_error()
+    for cls, fn in ((_lib.DecoderFwd16Args, lib.mipsf_decoder_fwd16), (_lib.DecoderChain16Args, lib.mipsf_decoder_bwd_chain16),
+                    (_lib.DecoderWgrad16Args, lib.mipsf_decoder_wgrad16), (_lib.RenderFwdArgs, lib.mipsf_render_fwd),
+                    (_lib.RenderBwdArgs, lib.mipsf_render_bwd)):
+        blk = cls.new()
+        blk.struct_size -= 4
+        assert fn(C.byref(blk), None) != 0 and b"struct_size" in lib.mipsf_last_error()
+        assert fn(None, None) != 0
     from mipsfusion_amd import ops
     ops._ZEROED[("probe",)] = object()
     with pytest.raises(RuntimeError):

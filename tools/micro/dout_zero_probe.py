@@ -20,9 +20,9 @@ cap = {}
 orig = ops.hashgrid_bwd
 
 
-def grab(x, params, dout, dparams, meta, layout=ops.FEAT_AOS, dx=None, routed=None):
+def grab(x, params, dout, dparams, meta, layout=ops.FEAT_AOS, *args, **kw):
     cap.update(dout=dout.clone(), layout=layout, M=x.shape[0], L=meta.n_levels)
-    return orig(x, params, dout, dparams, meta, layout, dx, routed)
+    return orig(x, params, dout, dparams, meta, layout, *args, **kw)
 
 
 ops.hashgrid_bwd = grab

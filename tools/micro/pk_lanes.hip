@@ -16,7 +16,7 @@
 //                                          (fma: third) source; the verbatim add 32 idle cycles behind its producers
 //   ./pk_lanes packed 20 inproc[:kind]   # neighbour kernels on a second stream of THIS process instead of a second process
 //   ./pk_lanes neighbour 60 kind:6       # (kinds: see neighbour<KIND>)
-//   ./pk_lanes lib:<path to a libmipsf_hip build> 20     # the library's own mipsf_ro_particles_pm on the same inputs
+//   ./pk_lanes lib:<path to a libmipsf_hip build> 20     # the library's own mipsf_ro_particles (point-major) on the same inputs
 //                                          (tools/micro/libv_ropk1.so = the packed build, mipsfusion_amd/libmipsf_hip.so = the product)
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -327,13 +327,13 @@ int main(int argc, char** argv) {
                       !strcmp(mode, "asmfma") ? 5 : !strcmp(mode, "asmmov") ? 6 : !strcmp(mode, "asmadd0") ? 7 : !strcmp(mode, "asmmul1") ? 8 :
                       !strcmp(mode, "asmfma1") ? 9 : !strcmp(mode, "asmfma2") ? 10 : !strcmp(mode, "asmnop") ? 11 : 0;
     typedef int (*ro_fn)(const float*, const float*, const float*, const float*, const mipsf_render_cfg*, float*, float*, uint32_t,
-                         uint32_t, void*);
+                         uint32_t, int, void*);
     ro_fn ro = nullptr;
     if (!strncmp(mode, "lib:", 4)) {
         void* h = dlopen(mode + 4, RTLD_NOW);
         if (!h) { fprintf(stderr, "%s\n", dlerror()); return 2; }
-        ro = (ro_fn)dlsym(h, "mipsf_ro_particles_pm");
-        if (!ro) { fprintf(stderr, "no mipsf_ro_particles_pm in %s\n", mode + 4); return 2; }
+        ro = (ro_fn)dlsym(h, "mipsf_ro_particles");
+        if (!ro) { fprintf(stderr, "no mipsf_ro_particles in %s\n", mode + 4); return 2; }
     }
     const unsigned P = 2000, n = 384;
     std::vector<float> pose(12 * P), dirs(3 * n), depth(n);
@@ -383,7 +383,7 @@ int main(int argc, char** argv) {
     CHECK(hipMemcpy(d_state, state.data(), state.size() * 4, hipMemcpyHostToDevice));
     auto launch = [&](float* dst) {
         if (ro) {
-            if (ro(d_pst, d_state, d_dirs, d_depth, &rc, dst, d_pst7, P, n, (void*)vs) != 0) { fprintf(stderr, "mipsf_ro_particles_pm failed\n"); exit(2); }
+            if (ro(d_pst, d_state, d_dirs, d_depth, &rc, dst, d_pst7, P, n, 1, (void*)vs) != 0) { fprintf(stderr, "mipsf_ro_particles failed\n"); exit(2); }
             return;
         }
         if (vmode == 1) hipLaunchKernelGGL(particles<1>, dim3(P / 4), dim3(256), 0, vs, d_pose, d_dirs, d_depth, nc, dst, P, n);

@@ -27,7 +27,7 @@ tt = torch.linspace(0.0, 0.35, S, device=dev).view(1, S, 1)
 x = (o + d * tt).clamp(0.001, 0.999).reshape(-1, 3).contiguous()
 M = x.shape[0]
 lib = _lib.lib()
-n = lib.mipsf_hashgrid_bwd_scratch_floats(C.byref(meta), M, 0)
+n = _lib.buffer_size(_lib.SIZE_HASHGRID_BWD_SCRATCH, M, 0, 0, meta)
 scratch = torch.zeros(n, dtype=torch.float32, device=dev)
 for _ in range(5):
     ops.check(lib.mipsf_hashgrid_route(ops.dptr(x), ops.dptr(scratch), M, C.byref(meta), ops.stream_ptr()), "route")

@@ -25,9 +25,9 @@ cap = {}
 orig = ops.hashgrid_bwd
 
 
-def grab(x, params, dout, dparams, meta, layout=ops.FEAT_AOS, dx=None, routed=None, dparams_zero=False):
+def grab(x, params, dout, dparams, meta, layout=ops.FEAT_AOS, *args, **kw):
     cap.update(x=x.clone(), dout=dout.clone(), meta=meta, layout=layout, params=params)
-    return orig(x, params, dout, dparams, meta, layout, dx, routed, dparams_zero)
+    return orig(x, params, dout, dparams, meta, layout, *args, **kw)
 
 
 ops.hashgrid_bwd = grab
@@ -41,21 +41,20 @@ lib.mipsf_hashgrid_rt_trace_words.restype = C.c_uint64
 lib.mipsf_hashgrid_rt_trace_words.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
 n_rows = C.c_uint32()
 off = lib.mipsf_hashgrid_rt_trace_words(C.byref(meta), M, C.byref(n_rows))
-n = lib.mipsf_hashgrid_bwd_scratch_floats(C.byref(meta), M, 0)
+n = _lib.buffer_size(_lib.SIZE_HASHGRID_BWD_SCRATCH, M, 0, 0, meta)
 scratch = torch.zeros(n, dtype=torch.float32, device=dev)
 dparams = torch.zeros_like(params)
+ARGS = _lib.HashgridBwdArgs.new(M=M, x=ops.dptr(x), params=ops.dptr(params), dout=ops.dptr(dout), dparams=ops.dptr(dparams),
+                                scratch=ops.dptr(scratch), meta=C.pointer(meta), feat_layout=layout)
 for rep in range(3):
-    ops.check(lib.mipsf_hashgrid_bwd(ops.dptr(x), ops.dptr(params), ops.dptr(dout), ops.dptr(dparams), None,
-                                     ops.dptr(scratch), M, C.byref(meta), layout, ops.stream_ptr()), "bwd")
+    ops.check(lib.mipsf_hashgrid_bwd(C.byref(ARGS), ops.stream_ptr()), "bwd")
 torch.cuda.synchronize()
 rows = scratch[off:off + 20 * n_rows.value].view(torch.int64).cpu().numpy().reshape(-1, 10)
 names = ["liveness loads + ballots", "scan + compaction (3 barriers)", "x gather, locate, group, rank", "barrier",
          "bin atomics issued + prefix", "barrier (atomics return)", "records -> stage", "barrier", "write-out"]
-lvl = rows[:, 9]
-L = int(lvl.max()) + 1
-print(f"{rows.shape[0]} waves; cycles per phase (mean over the waves of a level class)")
-for label, sel in (("dense levels", lvl < 9), ("hashed levels", lvl >= 9), ("all", lvl >= 0)):
-    r = rows[sel, :9].astype(np.float64)
-    tot = r.sum(1).mean()
-    print(f"  {label:14s} total {tot:7.0f}: " + ", ".join(f"{nm} {v:.0f}" for nm, v in zip(names, r.mean(0))))
-print("  per level totals: " + " ".join(f"{l}:{rows[lvl == l, :9].sum(1).mean():.0f}" for l in range(L)))
+grp, nlv = rows[:, 9] & 0xff, np.maximum(rows[:, 9] >> 8, 1)
+print(f"{rows.shape[0]} waves, {int(nlv.max())} levels per workgroup; cycles per phase (mean over all waves; the first two phases are paid "
+      f"once per workgroup, the others are sums over its levels)")
+r = rows[:, :9].astype(np.float64)
+print(f"  total {r.sum(1).mean():7.0f} per workgroup-wave = {(r.sum(1) / nlv).mean():7.0f} per level: " + ", ".join(f"{nm} {v:.0f}" for nm, v in zip(names, r.mean(0))))
+print("  per level group: " + " ".join(f"{g_}:{rows[grp == g_, :9].sum(1).mean():.0f}" for g_ in sorted(set(grp.tolist()))))

@@ -25,9 +25,9 @@ cap = {}
 orig = ops.hashgrid_bwd
 
 
-def grab(x, params, dout, dparams, meta, layout=ops.FEAT_AOS, dx=None, routed=None, dparams_zero=False):
+def grab(x, params, dout, dparams, meta, layout=ops.FEAT_AOS, *args, **kw):
     cap.update(x=x.clone(), dout=dout.clone(), meta=meta, layout=layout, params=params)
-    return orig(x, params, dout, dparams, meta, layout, dx, routed, dparams_zero)
+    return orig(x, params, dout, dparams, meta, layout, *args, **kw)
 
 
 ops.hashgrid_bwd = grab
@@ -42,20 +42,20 @@ lib.mipsf_hashgrid_trace_words.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c
 n_rows = C.c_uint32()
 bin0 = (C.c_uint32 * 33)()
 off = lib.mipsf_hashgrid_trace_words(C.byref(meta), M, C.byref(n_rows), bin0)
-n = lib.mipsf_hashgrid_bwd_scratch_floats(C.byref(meta), M, 0)
+n = _lib.buffer_size(_lib.SIZE_HASHGRID_BWD_SCRATCH, M, 0, 0, meta)
 scratch = torch.zeros(n, dtype=torch.float32, device=dev)
 dparams = torch.zeros_like(params)
+ARGS = _lib.HashgridBwdArgs.new(M=M, x=ops.dptr(x), params=ops.dptr(params), dout=ops.dptr(dout), dparams=ops.dptr(dparams),
+                                scratch=ops.dptr(scratch), meta=C.pointer(meta), feat_layout=layout)
 L = meta.n_levels
 for rep in range(3):
     scratch[off - 1:off + 8 * n_rows.value].zero_()
-    ops.check(lib.mipsf_hashgrid_bwd(ops.dptr(x), ops.dptr(params), ops.dptr(dout), ops.dptr(dparams), None,
-                                     ops.dptr(scratch), M, C.byref(meta), layout, ops.stream_ptr()), "bwd")
+    ops.check(lib.mipsf_hashgrid_bwd(C.byref(ARGS), ops.stream_ptr()), "bwd")
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for rep in range(20):
-    lib.mipsf_hashgrid_bwd(ops.dptr(x), ops.dptr(params), ops.dptr(dout), ops.dptr(dparams), None,
-                           ops.dptr(scratch), M, C.byref(meta), layout, ops.stream_ptr())
+    lib.mipsf_hashgrid_bwd(C.byref(ARGS), ops.stream_ptr())
 e1.record()
 torch.cuda.synchronize()
 print(f"whole scatter (clear + route + accumulate + fold, with trace stores): {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per call")
