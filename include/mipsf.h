@@ -411,6 +411,15 @@ int mipsf_pose_rays_fwd(const float* db, uint64_t n_rows, const int64_t* idx, co
                         const float* rot, const float* trans, uint32_t F, uint32_t K, const int64_t* owner,
                         float* d_cam, float* rgb, float* depth, float* rays_o, float* rays_d, uint32_t N,
                         void* stream);
+/* One pose handed from one stage of a frame to the next on the device: the reference passes a 4x4 between its stages
+ * (mipsfusion.py:479-501, 556-575), i.e. every stage starts from matrix_to_quaternion of the previous stage's matrix, a
+ * unit quaternion.  src: MIPSF_POSE_MATRIX = 12 floats [3x3 rotation row-major | translation] (words 0..11 of the
+ * RandomOptimizer's state), MIPSF_POSE_QUATERNION = 7 floats [w x y z | t] (a stage's pose Parameters; must not alias the
+ * destination) -> rot[4] (w >= 0), trans[3].  geometry_helper.qt_to_transform_matrix / matrix_to_quaternion
+ * (geometry_helper.py:11-33) operation by operation in IEEE fp32.  No host round trip. */
+#define MIPSF_POSE_MATRIX 0
+#define MIPSF_POSE_QUATERNION 1
+int mipsf_pose_handover(const float* src, int src_kind, float* rot, float* trans, void* stream);
 /* d_rot [K,4], d_trans [K,3] are written, or ADDED to when accumulate != 0 (the parameters' own .grad buffers: no separate
  * accumulation pass).  scratch: MIPSF_SIZE_POSE_RAYS_SCRATCH floats whose FIRST word must be zero on entry (clear it once
  * after allocating) and is zero again on return -- it is the ticket that lets the last workgroup finish the reduction and

@@ -148,11 +148,10 @@ class RandomOptimizer:
                                           for o in range(5)]).to(dev)
 
     @torch.no_grad()
-    def optimize_graphed(self, depth_flat_dev, initial_pose_cpu, waiting=None):
-        """depth_flat_dev: the frame's depth as a flat DEVICE tensor [H*W] (the lattice is gathered on the device);
-        initial_pose_cpu: [4,4] CPU tensor -> tracked pose [4,4] on the CPU.  Same arithmetic as ``optimize``.
-        waiting: optional ``f(fn)`` that runs the blocking read-back ``fn`` (mipsfusion_amd.sequence: lets the sample
-        producer threads use the host while this thread waits for the GPU)."""
+    def enqueue_graphed(self, depth_flat_dev, initial_pose_cpu):
+        """The frame's rounds, enqueued and NOT waited for: the tracked pose is left in words 0..11 of the device search
+        state (``tracked_pose_dev``: 3x3 rotation row-major | translation) for a consumer on the same stream --
+        ``ops.pose_handover`` hands it to the tracking iterations' pose Parameters without a host round trip."""
         h = self._g_state_host
         h.zero_()
         h[0:9] = initial_pose_cpu[:3, :3].reshape(9)
@@ -161,6 +160,17 @@ class RandomOptimizer:
         self._g_state.copy_(h, non_blocking=True)
         torch.index_select(depth_flat_dev, 0, self._lattice_flat.reshape(-1), out=self._g_td5.view(-1))
         self._graph.replay()
+
+    @property
+    def tracked_pose_dev(self):
+        return self._g_state
+
+    def optimize_graphed(self, depth_flat_dev, initial_pose_cpu, waiting=None):
+        """depth_flat_dev: the frame's depth as a flat DEVICE tensor [H*W] (the lattice is gathered on the device);
+        initial_pose_cpu: [4,4] CPU tensor -> tracked pose [4,4] on the CPU.  Same arithmetic as ``optimize``.
+        waiting: optional ``f(fn)`` that runs the blocking read-back ``fn`` (mipsfusion_amd.sequence: lets the sample
+        producer threads use the host while this thread waits for the GPU)."""
+        self.enqueue_graphed(depth_flat_dev, initial_pose_cpu)
         self._g_out_host.copy_(self._g_state, non_blocking=True)
         if waiting is None:
             torch.cuda.current_stream().synchronize()

@@ -149,6 +149,7 @@ SIGNATURES = {
     "mipsf_rays_bwd": (_I, [_P, _P, C.POINTER(RenderCfg), _P, _P, _U32, _U32, _P]),
     "mipsf_normalise_bwd": (_I, [_P, C.POINTER(RenderCfg), _P, _U32, _P]),
     "mipsf_pose_rays_fwd": (_I, [_P, _U64, _P, _P, _P, _P, _U32, _U32, _P, _P, _P, _P, _P, _P, _U32, _P]),
+    "mipsf_pose_handover": (_I, [_P, _I, _P, _P, _P]),
     "mipsf_pose_rays_bwd": (_I, [_P, _P, _P, _U32, _U32, _P, _P, _P, _P, _P, _U32, _I, _P]),
     "mipsf_adam_step": (_I, [_P, _P, _P, _P, _U64, _F, _F, _F, _F, _F, _U32, _P, _I, _P]),
     "mipsf_adam_advance_n": (_I, [_P, _P, _P, _P, _P, _U32, _P]),

@@ -137,6 +137,52 @@ MIPSF_SINGLE_FP32 __global__ __launch_bounds__(PR_BLOCK) void pose_rays_bwd_kern
     pose_block_finish<PR_BLOCK>(sacc, &is_last, P, F, K, part, ticket, rot, d_rot, d_trans, accumulate != 0);
 }
 
+// One pose handed from one stage of a frame to the next ON THE DEVICE.  The reference passes a 4x4 between its stages
+// (mipsfusion.py:479-501: RandomOptimizer -> tracking iterations; :556-575 -> local BA), i.e. every stage starts from
+// matrix_to_quaternion of the previous stage's matrix -- a UNIT quaternion, also when the previous stage's Adam steps left
+// its own quaternion slightly off the sphere.  Same here, without the host round trip:
+//   src_kind 0: src = [3x3 rotation row-major | translation] (words 0..11 of the RandomOptimizer's device state)
+//   src_kind 1: src = [w x y z | tx ty tz] (a stage's pose Parameters): qt_to_transform_matrix first (geometry_helper.py:11-17)
+// then geometry_helper.matrix_to_quaternion (:20-33), operation by operation in IEEE fp32 (no contraction: the file is built
+// with -ffp-contract=off; square roots and divisions through fp64, whose rounded result is the correctly rounded fp32 one:
+// 53 >= 2 * 24 + 2 bits), so the result equals the frame loop's host helpers (sequence._qt_to_matrix_np,
+// _matrix_to_quaternion_np) bit for bit; torch's own CPU kernels differ from IEEE in the last bit on some hosts.
+__global__ void pose_handover_kernel(const float* __restrict__ src, int src_kind, float* __restrict__ rot, float* __restrict__ trans) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float a, b, c, d, e, f, g, h, i, tx, ty, tz;
+    if (src_kind == 0) {
+        a = src[0], b = src[1], c = src[2], d = src[3], e = src[4], f = src[5], g = src[6], h = src[7], i = src[8];
+        tx = src[9], ty = src[10], tz = src[11];
+    } else {
+        const float w = src[0], x = src[1], y = src[2], z = src[3];
+        const float k = (float)(2.0 / (double)(((w * w + x * x) + y * y) + z * z));
+        a = 1.0f - k * (y * y + z * z), b = k * (x * y - z * w), c = k * (x * z + y * w);
+        d = k * (x * y + z * w), e = 1.0f - k * (x * x + z * z), f = k * (y * z - x * w);
+        g = k * (x * z - y * w), h = k * (y * z + x * w), i = 1.0f - k * (x * x + y * y);
+        tx = src[4], ty = src[5], tz = src[6];
+    }
+    const float m2[4] = {((1.0f + a) + e) + i, ((1.0f + a) - e) - i, ((1.0f - a) + e) - i, ((1.0f - a) - e) + i};
+    float mag[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mag[k] = m2[k] > 0.0f ? (float)sqrt((double)m2[k]) : 0.0f;
+    int best = 0;                                    // (argmax: the first of equal maxima, as torch / numpy)
+#pragma unroll
+    for (int k = 1; k < 4; ++k) best = mag[k] > mag[best] ? k : best;
+    float t[4];
+    if (best == 0) t[0] = mag[0] * mag[0], t[1] = h - f, t[2] = c - g, t[3] = d - b;
+    else if (best == 1) t[0] = h - f, t[1] = mag[1] * mag[1], t[2] = d + b, t[3] = c + g;
+    else if (best == 2) t[0] = c - g, t[1] = d + b, t[2] = mag[2] * mag[2], t[3] = f + h;
+    else t[0] = d - b, t[1] = g + c, t[2] = h + f, t[3] = mag[3] * mag[3];
+    const float den = 2.0f * fmaxf(mag[best], 0.1f);
+    float q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = (float)((double)t[k] / (double)den);
+    const bool neg = q[0] < 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rot[k] = neg ? -q[k] : q[k];
+    trans[0] = tx, trans[1] = ty, trans[2] = tz;
+}
+
 __global__ void pose_zero_kernel(float* __restrict__ p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.f;
@@ -183,6 +229,14 @@ uint64_t pose_rays_scratch_floats(uint32_t F, uint32_t K, uint32_t N) {
 }
 }  // namespace mipsf
 extern "C" {
+
+int mipsf_pose_handover(const float* src, int src_kind, float* rot, float* trans, void* stream) {
+    MIPSF_REQUIRE(src && rot && trans, "null pointer");
+    MIPSF_REQUIRE(src_kind == MIPSF_POSE_MATRIX || src_kind == MIPSF_POSE_QUATERNION, "src_kind %d", src_kind);
+    MIPSF_REQUIRE(src_kind == MIPSF_POSE_MATRIX || (src != rot && src + 4 != trans), "a quaternion source must not be the destination");
+    hipLaunchKernelGGL(pose_handover_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, src, src_kind, rot, trans);
+    return check_launch("pose_handover");
+}
 
 int mipsf_pose_rays_bwd(const float* g_rays_o, const float* g_rays_d, const float* rot, uint32_t F, uint32_t K,
                         const int64_t* owner, const float* d_cam, float* d_rot, float* d_trans, float* scratch,

@@ -635,6 +635,14 @@ def _pose_scratch(device, F, K, N):
     return buf
 
 
+def pose_handover(src, rot_out, trans_out, quaternion: bool = False):
+    """One pose from stage to stage on the device.  src: 12 floats [3x3 row-major | t] (the RandomOptimizer's state), or with
+    quaternion=True 7 floats [w x y z | t] -> rot_out[4] (unit quaternion, w >= 0), trans_out[3] (views of the next stage's
+    pose Parameters): qt_to_transform_matrix / matrix_to_quaternion as the reference applies them between its stages, in IEEE
+    fp32 -- bit-identical to the frame loop's host helpers; no host round trip."""
+    check(lib().mipsf_pose_handover(dptr(src), 1 if quaternion else 0, dptr(rot_out), dptr(trans_out), stream_ptr()), "pose_handover")
+
+
 class PoseRaysFn(torch.autograd.Function):
     """(rot [K,4], trans [K,3]) -> rays_o, rays_d [N,3]; fused replacement of
     ``qt_to_transform_matrix`` + ``poses_all[owner]`` gather + ``sum(d_cam * R, -1)`` (mipsfusion.py:320-322)."""

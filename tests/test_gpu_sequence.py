@@ -235,3 +235,92 @@ def test_graphed_two_room_sequence_tracks_through_both_switches():
     new_k, back_k = sorted(schedule)
     assert out["submap_keyframe_slots"][1] == list(range(new_k // 15, back_k // 15))
     assert out["ate_rmse_m"] < 0.05 and out["ate_max_m"] < 0.15
+
+
+def test_pose_from_matrix_equals_the_host_helpers_bit_for_bit():
+    """mipsf_pose_handover (the device hand-over of the RandomOptimizer's pose to the tracking Parameters) against the
+    frame loop's host helper (sequence._matrix_to_quaternion_np: geometry_helper.matrix_to_quaternion in IEEE fp32 scalars):
+    every branch of the largest-magnitude selection, rotations near the branch boundaries and a slightly non-orthonormal
+    matrix -- the same bits; and against torch's own CPU kernels to the last bit but one (their vectorised sqrt / divide
+    differ from IEEE in the last bit on some hosts: 2 of these 400 cases in the build container, 122 on a GPU host)."""
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the gpu-marked tests must run on the MI355X box")
+    from mipsfusion_amd import ops, sequence
+    from mipsfusion_amd.helper_functions.geometry_helper import matrix_to_quaternion, quaternion_to_matrix
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(400, 4, generator=g)
+    q[:40] = torch.eye(4).repeat(10, 1) + 1e-3 * torch.randn(40, 4, generator=g)        # each branch dominant
+    q[40:80] = torch.tensor([0.5, 0.5, 0.5, 0.5]) + 1e-6 * torch.randn(40, 4, generator=g)   # at the branch boundaries
+    R = quaternion_to_matrix(q)
+    R[80:120] += 1e-4 * torch.randn(40, 3, 3, generator=g)                                 # not quite orthonormal
+    t = torch.randn(400, 3, generator=g)
+    ref = matrix_to_quaternion(R)
+    rot, trans = torch.empty(4, device=dev), torch.empty(3, device=dev)
+    for k in range(R.shape[0]):
+        src = torch.cat([R[k].reshape(9), t[k]]).to(dev)
+        ops.pose_handover(src, rot, trans)
+        want = sequence._matrix_to_quaternion_np(R[k].numpy())
+        if 40 <= k < 80:     # four equal magnitudes: which branch wins is decided in the last bit of a square root -- same rotation
+            assert abs(float((rot.cpu() * torch.from_numpy(want)).sum())) > 1.0 - 1e-6
+        else:
+            assert np.array_equal(rot.cpu().numpy(), want), (k, rot.cpu().view(torch.int32), torch.from_numpy(want).view(torch.int32))
+        assert torch.equal(trans.cpu(), t[k])
+        # (near a branch boundary torch may pick the neighbouring branch after its last-bit differences: same rotation)
+        r = rot.cpu()
+        assert float((r - ref[k]).abs().max()) <= 2.5e-7 or abs(float((r * ref[k]).sum())) > 1.0 - 1e-6
+        # the quaternion form (a stage's pose Parameters, off the unit sphere after Adam steps) = the host's two helpers in a row
+        qt = torch.cat([q[k] * (1.0 + 0.01 * float(t[k, 0])), t[k]])
+        ops.pose_handover(qt.to(dev), rot, trans, quaternion=True)
+        want_q = sequence._matrix_to_quaternion_np(sequence._qt_to_matrix_np(qt.numpy())[:3, :3])
+        if not 40 <= k < 80:
+            assert np.array_equal(rot.cpu().numpy(), want_q), (k, rot.cpu(), want_q)
+        assert abs(float(rot.cpu().norm()) - 1.0) < 1e-6 and torch.equal(trans.cpu(), t[k])
+
+
+@pytest.mark.parametrize("sampler", ["device", "reference"])
+def test_device_pose_handover_tracks_exactly_what_the_host_handover_tracks(sampler):
+    """GraphedSequence.run with the pose handed from the RandomOptimizer to the tracking iterations on the device (ONE
+    read-back per frame) against round 4's loop (a synchronising read-back and host 4x4 algebra after every stage), on the
+    SAME map (the second run takes over the first one's parameters after the first-frame initialisation, whose table
+    scatter is not reproducible to the bit) and without BA rounds (same reason): tracking is bit-reproducible
+    (DESIGN 4h), so every estimated pose must be equal bit for bit.  The BA hand-over (quaternion -> 4x4 -> quaternion) is
+    covered kernel against host helper above and by the full sequences' trajectory error."""
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the gpu-marked tests must run on the MI355X box")
+    from mipsfusion_amd import sequence
+    from mipsfusion_amd.graph import work_stream
+    dev = torch.device("cuda:0")
+    prev = torch.cuda.current_stream(dev)
+    poses, snap = {}, {}
+    try:
+        for handover in (False, True):
+            cfg = _small_two_room_cfg()
+            cfg["mapping"]["map_every"] = 1000
+            random.seed(0), np.random.seed(0), torch.manual_seed(0)
+            torch.cuda.manual_seed_all(0)
+            gt, frames, _ = synth.two_room_sequence(cfg, 14, kf_every=5)
+            seq = sequence.GraphedSequence(cfg, dev, frames, kf_every=5, sampler=sampler, stream=work_stream(dev),
+                                           device_handover=handover)
+            assert seq.device_handover is handover
+            first = seq.first_frame
+
+            def first_frame(gt0, seq=seq, first=first):
+                pose = first(gt0)
+                if "params" not in snap:
+                    snap["params"], snap["pose"] = [p.detach().clone() for p in seq.model.parameters()], pose
+                else:
+                    with torch.no_grad():
+                        for p, q in zip(seq.model.parameters(), snap["params"]):
+                            p.copy_(q)
+                return snap["pose"]
+            seq.first_frame = first_frame
+            random.seed(1), np.random.seed(1), torch.manual_seed(1)
+            torch.cuda.manual_seed_all(1)
+            res = seq.run(gt)
+            poses[handover] = torch.stack([p.float() for p in res["est"]])
+            assert len(res["frame_ms"]) == 13 and len(res["go_ms"]) == 13 and not any(res["ba_ms"])
+    finally:
+        torch.cuda.set_stream(prev)
+    assert torch.isfinite(poses[True]).all()
+    assert torch.equal(poses[True], poses[False]), [round(float((a - b).abs().max()), 9) for a, b in zip(poses[True], poses[False])]
