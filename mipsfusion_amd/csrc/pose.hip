@@ -147,7 +147,7 @@ MIPSF_SINGLE_FP32 __global__ __launch_bounds__(PR_BLOCK) void pose_rays_bwd_kern
 // with -ffp-contract=off; square roots and divisions through fp64, whose rounded result is the correctly rounded fp32 one:
 // 53 >= 2 * 24 + 2 bits), so the result equals the frame loop's host helpers (sequence._qt_to_matrix_np,
 // _matrix_to_quaternion_np) bit for bit; torch's own CPU kernels differ from IEEE in the last bit on some hosts.
-__global__ void pose_handover_kernel(const float* __restrict__ src, int src_kind, float* __restrict__ rot, float* __restrict__ trans) {
+MIPSF_SINGLE_FP32 __global__ void pose_handover_kernel(const float* __restrict__ src, int src_kind, float* __restrict__ rot, float* __restrict__ trans) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float a, b, c, d, e, f, g, h, i, tx, ty, tz;
     if (src_kind == 0) {
