@@ -228,6 +228,9 @@ typedef struct mipsf_decoder_fwd16_args {
     int precision;
     int sdf_only;
     int lean_record;
+    uint32_t packed16_floats;       /* 0 = unchecked; else the size of the packed16 buffer: refused unless it is
+                                       MIPSF_SIZE_DECODER_PACKED16 of `precision`'s family (an f16 buffer handed to the
+                                       bf16x6 kernels would be read past its end) */
 } mipsf_decoder_fwd16_args;
 int mipsf_decoder_fwd16(const mipsf_decoder_fwd16_args* args_host, void* stream);
 /* Activation-gradient chain: d(out) -> dfeat, dx, dact (autograd of MLP_reg.forward with respect to its inputs); leaves the
@@ -262,6 +265,7 @@ typedef struct mipsf_decoder_chain16_args {
     uint32_t* tile_live;            /* nullable */
     int feat_layout;
     int flags;
+    uint32_t packed16_floats;       /* 0 = unchecked (see mipsf_decoder_fwd16_args) */
 } mipsf_decoder_chain16_args;
 int mipsf_decoder_bwd_chain16(const mipsf_decoder_chain16_args* args_host, void* stream);
 /* Weight gradients from the records by the STREAMING kernel of csrc/wgrad16.hip: the 16-bit matrix cores transpose the
@@ -287,6 +291,7 @@ typedef struct mipsf_decoder_wgrad16_args {
     int feat_layout;
     int arithmetic;
     uint32_t flags;
+    uint32_t packed16_floats;       /* 0 = unchecked (see mipsf_decoder_fwd16_args) */
 } mipsf_decoder_wgrad16_args;
 int mipsf_decoder_wgrad16(const mipsf_decoder_wgrad16_args* args_host, void* stream);
 

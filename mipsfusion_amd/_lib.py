@@ -62,13 +62,14 @@ HashgridBwdArgs = _args("HashgridBwdArgs", [("M", _CU), ("x", _VP), ("params", _
                                             ("feat_layout", _CI), ("flags", _CU)])
 DecoderFwd16Args = _args("DecoderFwd16Args", [("M", _CU), ("packed16", _VP), ("feat", _VP), ("x", _VP), ("out", _VP), ("saved", _VP),
                                               ("tile_live_clear", _VP), ("feat_layout", _CI), ("precision", _CI),
-                                              ("sdf_only", _CI), ("lean_record", _CI)])
+                                              ("sdf_only", _CI), ("lean_record", _CI), ("packed16_floats", _CU)])
 DecoderChain16Args = _args("DecoderChain16Args", [("M", _CU), ("packed16", _VP), ("x", _VP), ("out", _VP), ("dout", _VP),
                                                   ("saved", _VP), ("dfeat", _VP), ("dx", _VP), ("dact", _VP), ("tile_live", _VP),
-                                                  ("feat_layout", _CI), ("flags", _CI)])
+                                                  ("feat_layout", _CI), ("flags", _CI), ("packed16_floats", _CU)])
 DecoderWgrad16Args = _args("DecoderWgrad16Args", [("M", _CU), ("packed16", _VP), ("feat", _VP), ("x", _VP), ("saved", _VP),
                                                   ("dact", _VP), ("tile_live", _VP), ("grads", C.POINTER(DecoderGrads)),
-                                                  ("partial", _VP), ("feat_layout", _CI), ("arithmetic", _CI), ("flags", _CU)])
+                                                  ("partial", _VP), ("feat_layout", _CI), ("arithmetic", _CI), ("flags", _CU),
+                                                  ("packed16_floats", _CU)])
 RenderFwdArgs = _args("RenderFwdArgs", [("N", _CU), ("S", _CU), ("raw", _VP), ("z_vals", _VP), ("target_rgb", _VP), ("target_d", _VP),
                                         ("counts", _VP), ("cfg", C.POINTER(RenderCfg)), ("rgb", _VP), ("depth", _VP),
                                         ("depth_var", _VP), ("disp", _VP), ("acc", _VP), ("weights", _VP), ("losses", _VP),

@@ -1251,6 +1251,9 @@ int mipsf_decoder_fwd16(const mipsf_decoder_fwd16_args* a, void* stream) {
     float* out = a->out; float* saved = a->saved; const int sdf_only = a->sdf_only, precision = a->precision, lean_record = a->lean_record;
     const uint32_t M = a->M;
     uint32_t* clear_hdr = a->tile_live_clear;
+    MIPSF_REQUIRE(a->packed16_floats == 0u || a->packed16_floats == decoder_packed16_floats(precision),
+                  "packed16 holds %u floats, precision %d needs %u: packed for the other family?", a->packed16_floats, precision,
+                  (unsigned)decoder_packed16_floats(precision));
     if (M == 0) return 0;
     MIPSF_REQUIRE(packed16 && feat && x && out, "null pointer");
     MIPSF_REQUIRE(!lean_record || (saved && (precision == MIPSF_PREC_F16X3 || precision == MIPSF_PREC_BF16X6)),
@@ -1325,6 +1328,12 @@ int mipsf_decoder_bwd_chain16(const mipsf_decoder_chain16_args* a, void* stream)
     const float* packed16 = a->packed16; const int feat_layout = a->feat_layout; const float* x = a->x; const float* out = a->out;
     const float* dout = a->dout; const float* saved = a->saved; float* dfeat = a->dfeat; float* dx = a->dx; float* dact = a->dact;
     uint32_t* tile_live = a->tile_live; const int flags = a->flags; const uint32_t M = a->M;
+    {
+        const int fam = (flags & MIPSF_CHAIN_BF16X6) ? MIPSF_PREC_BF16X6 : MIPSF_PREC_F16X3;
+        MIPSF_REQUIRE(a->packed16_floats == 0u || a->packed16_floats == decoder_packed16_floats(fam),
+                      "packed16 holds %u floats, this chain needs %u: packed for the other family?", a->packed16_floats,
+                      (unsigned)decoder_packed16_floats(fam));
+    }
     if (M == 0) return 0;
     MIPSF_REQUIRE((flags & ~(MIPSF_CHAIN_HEADER_CLEAR | MIPSF_CHAIN_LEAN_DACT | MIPSF_CHAIN_BF16X6)) == 0, "unknown flags 0x%x", flags);
     const bool bf = (flags & MIPSF_CHAIN_BF16X6) != 0;

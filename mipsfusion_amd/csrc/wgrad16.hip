@@ -1449,6 +1449,9 @@ extern "C" int mipsf_decoder_wgrad16(const mipsf_decoder_wgrad16_args* a, void* 
     const float* saved = a->saved; const float* dact = a->dact; const uint32_t* tile_live = a->tile_live;
     const mipsf_decoder_grads* grads = a->grads; float* partial = a->partial; const int arithmetic = a->arithmetic;
     const uint32_t flags = a->flags, M = a->M;
+    MIPSF_REQUIRE(packed16 == nullptr || a->packed16_floats == 0u || a->packed16_floats == decoder_packed16_floats(arithmetic),
+                  "packed16 holds %u floats, arithmetic %d needs %u: packed for the other family?", a->packed16_floats, arithmetic,
+                  (unsigned)decoder_packed16_floats(arithmetic));
     if (M == 0) return 0;
     MIPSF_REQUIRE((flags & ~(uint32_t)MIPSF_WGRAD_LEAN_DACT) == 0u, "unknown flags 0x%x", flags);
     const uint32_t lean_dact = (flags & MIPSF_WGRAD_LEAN_DACT) ? 1u : 0u;

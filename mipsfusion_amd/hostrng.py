@@ -13,6 +13,7 @@ afterwards); if this build of torch should differ, or the library is missing, th
 Not thread-safe against other users of the default generator while a session is open (neither is the generator's stream
 order, which is the point of running it on one thread)."""
 import contextlib
+import threading
 import ctypes as C
 import os
 import random
@@ -152,14 +153,22 @@ def available(threads: int = 4) -> bool:
     return _ok
 
 
+# One session at a time, process wide: a session takes the default generator's state out of torch, draws, and puts it
+# back -- a second thread doing the same in between (the frame loop's sample producer, a caller's own worker) would have
+# its draws overwritten or duplicated.  (Re-entrant only so that a mistaken nested session cannot deadlock its own thread; a
+# nested session's draws are lost when the outer one puts ITS state back -- draw through the session you hold.)
+_SESSION_LOCK = threading.RLock()
+
+
 @contextlib.contextmanager
 def session(threads: int = 4):
-    s = _Session(available(threads), threads)
-    s.take()
-    try:
-        yield s
-    finally:
-        s.give()
+    with _SESSION_LOCK:
+        s = _Session(available(threads), threads)
+        s.take()
+        try:
+            yield s
+        finally:
+            s.give()
 
 
 # ---------------------------------------------------------------------------------------------- scores + top-k

@@ -59,6 +59,8 @@ class _NormaliseFn(torch.autograd.Function):
 
 # below this many samples the routing kernels take a few microseconds and a second stream only adds launch work
 _ROUTE_AHEAD_MIN_M = 65536
+# forward-only queries of 2^24 samples or more are cut into launches of 2^23 (see JointEncoding._query)
+_MAX_QUERY, _QUERY_CHUNK = 1 << 24, 1 << 23
 
 
 class _QueryFn(torch.autograd.Function):
@@ -309,6 +311,11 @@ class JointEncoding(nn.Module):
         return self._tables[key]
 
     def _query(self, x32):
+        # the 16-bit decoder kernels address a call's samples through 4 GB buffer resources: at most 2^24 - 1 samples per
+        # launch.  Forward-only consumers (a 256^3 mesher grid in one call, Mesher.py:342-630) are cut into launches of 2^23
+        M = x32.shape[0]
+        if M >= _MAX_QUERY and not (torch.is_grad_enabled() and (x32.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            return torch.cat([self._query(x32[i:i + _QUERY_CHUNK]) for i in range(0, M, _QUERY_CHUNK)], 0)
         return _QueryFn.apply(x32, self, self.embed_fn.params, *self.decoder.ordered_parameters())
 
     def __getstate__(self):
@@ -349,13 +356,16 @@ class JointEncoding(nn.Module):
         if not flat.is_cuda:
             raise RuntimeError("JointEncoding runs on the GPU only (no CPU fallback)")
         xn = ops._f32c(flat)
-        feat = ops.hashgrid_fwd(xn, self.embed_fn.params.detach(), self.embed_fn.meta, FEAT_LEVEL_MAJOR)
         prec = self.decoder_precision
         ws = self.decoder.ordered_parameters()
         packed = ops.decoder_pack(ws) if prec == "f32" else None
         packed16 = ops.decoder_pack16(ws, precision=prec) if prec != "f32" else None
-        return ops.decoder_fwd_sdf(packed, feat, FEAT_LEVEL_MAJOR, xn, None, xn.shape[0], precision=prec,
-                                   packed16=packed16)[:, None]
+        out = []
+        for i in range(0, max(1, xn.shape[0]), _QUERY_CHUNK if xn.shape[0] >= _MAX_QUERY else max(1, xn.shape[0])):
+            xc = xn[i:i + _QUERY_CHUNK] if xn.shape[0] >= _MAX_QUERY else xn
+            feat = ops.hashgrid_fwd(xc, self.embed_fn.params.detach(), self.embed_fn.meta, FEAT_LEVEL_MAJOR)
+            out.append(ops.decoder_fwd_sdf(packed, feat, FEAT_LEVEL_MAJOR, xc, None, xc.shape[0], precision=prec, packed16=packed16))
+        return (out[0] if len(out) == 1 else torch.cat(out, 0))[:, None]
 
     def query_color(self, query_points):
         return torch.sigmoid(self.query_color_sdf(query_points)[..., :3])
@@ -417,16 +427,21 @@ class JointEncoding(nn.Module):
         routine otherwise; 0.12 ms instead of 0.5-1.6 ms for 262 144 values) straight into one of four pinned buffers and goes
         up as an asynchronous copy -- the caller's thread does not wait for a pageable-memory staging copy."""
         from .. import hostrng
-        key = (N, S, str(device))
-        ring = self._jitter_ring.get(key)
-        if ring is None:
-            ring = self._jitter_ring[key] = {"bufs": [torch.empty(N, S, dtype=torch.float32).pin_memory() for _ in range(4)],
-                                             "events": [None] * 4, "i": 0}
+        if torch.cuda.is_current_stream_capturing():     # (a captured loop passes its jitter in: this draw would be baked into the graph)
+            raise RuntimeError("JointEncoding drew its sample jitter on the host while a hipGraph was being captured: pass "
+                               "`noise` (a static device tensor refilled before every replay) to forward / render_rays")
+        n = N * S
+        ring = self._jitter_ring.get(str(device))
+        if ring is None or ring["cap"] < n:
+            # ONE ring of four pinned buffers per device, sized for the largest batch seen so far and sliced per call (a
+            # ring per (N, S) pinned 4 x N x S x 4 bytes for every distinct batch size a caller ever used)
+            ring = self._jitter_ring[str(device)] = {"bufs": [torch.empty(n, dtype=torch.float32).pin_memory() for _ in range(4)],
+                                                     "events": [None] * 4, "i": 0, "cap": n}
         i = ring["i"]
         ring["i"] = (i + 1) % 4
         if ring["events"][i] is not None:
             ring["events"][i].synchronize()          # the upload that last read this buffer (four draws ago) is done
-        buf = ring["bufs"][i]
+        buf = ring["bufs"][i][:n].view(N, S)
         with hostrng.session() as sess:
             sess.rand_(buf)
         out = buf.to(device, non_blocking=True)

@@ -310,9 +310,15 @@ SPLIT_PRECISIONS = ("f16x3", "bf16x6")        # decoder arithmetics that keep ac
 
 
 def _check_family(packed16, precision):
+    """An operand buffer packed for one family must not reach the other's kernels (they would read an f16 buffer past its end,
+    or take bf16 planes for f16 halves).  The buffers differ in SIZE, which survives views, clones and .to() -- the python
+    attribute is only the better message; the library checks the size again (packed16_floats of its argument blocks)."""
     fam = getattr(packed16, "mipsf_family", None)
     if fam is not None and fam != _PACK16_FAMILY[precision]:
         raise RuntimeError(f"packed16 was packed for {fam!r}, the call asks for {precision!r}")
+    n = _lib.buffer_size(_lib.SIZE_DECODER_PACKED16, 0, _lib.PREC[_PACK16_FAMILY[precision]])
+    if packed16.numel() != n:
+        raise RuntimeError(f"packed16 holds {packed16.numel()} floats, precision {precision!r} needs {n}: packed for the other family?")
 
 
 def decoder_fwd(packed, feat, layout, x, embed_pos, M, save, precision: str = "f32", packed16=None):
@@ -343,7 +349,8 @@ def decoder_fwd(packed, feat, layout, x, embed_pos, M, save, precision: str = "f
             tile_live = torch.empty(_lib.buffer_size(_lib.SIZE_DECODER_TILE_WORDS, M), dtype=torch.int32, device=x.device)
         a = _lib.DecoderFwd16Args.new(M=M, packed16=dptr(packed16), feat=dptr(feat), x=dptr(x), out=dptr(out), saved=dptr(saved),
                                       tile_live_clear=dptr(tile_live, torch.int32), feat_layout=layout,
-                                      precision=_lib.PREC[precision], lean_record=(2 if masks_only else 1) if lean else 0)
+                                      precision=_lib.PREC[precision], lean_record=(2 if masks_only else 1) if lean else 0,
+                                      packed16_floats=packed16.numel())
         with _timed("decoder_fwd"):
             check(lib().mipsf_decoder_fwd16(C.byref(a), stream_ptr()), "decoder_fwd16")
         if lean:
@@ -418,7 +425,7 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
             _LAST_TILE_LIVE = (tile_live, M)
         a = _lib.DecoderChain16Args.new(M=M, packed16=dptr(packed16), x=dptr(x), out=dptr(out), dout=dptr(dout), saved=dptr(saved),
                                         dfeat=dptr(dfeat), dx=dptr(dx), dact=dptr(dact), tile_live=dptr(tile_live, torch.int32),
-                                        feat_layout=layout, flags=hdr_clear | (2 if lean_dact else 0))
+                                        feat_layout=layout, flags=hdr_clear | (2 if lean_dact else 0), packed16_floats=packed16.numel())
         with _timed("decoder_bwd_chain"):
             check(lib().mipsf_decoder_bwd_chain16(C.byref(a), stream_ptr()), "decoder_bwd_chain16")
     else:
@@ -441,7 +448,7 @@ def decoder_bwd(packed, feat, layout, x, embed_pos, out, dout, saved, grads, M, 
             a = _lib.DecoderWgrad16Args.new(M=M, packed16=dptr(packed16) if recompute_h1 else None, feat=dptr(feat), x=dptr(x),
                                             saved=dptr(saved), dact=dptr(dact), tile_live=dptr(tile_live, torch.int32),
                                             grads=C.pointer(st), partial=dptr(partial), feat_layout=layout, arithmetic=arith,
-                                            flags=1 if lean_dact else 0)
+                                            flags=1 if lean_dact else 0, packed16_floats=packed16.numel() if recompute_h1 else 0)
             with _timed("decoder_wgrad"):
                 check(lib().mipsf_decoder_wgrad16(C.byref(a), stream_ptr()), "decoder_wgrad16")
             return (dfeat, dx, dpe, tile_live) if return_tiles else (dfeat, dx, dpe)
@@ -465,7 +472,7 @@ def decoder_fwd_sdf(packed, feat, layout, x, embed_pos, M, precision: str = "f32
         _check_family(packed16, precision)
         with _timed("decoder_fwd"):
             a = _lib.DecoderFwd16Args.new(M=M, packed16=dptr(packed16), feat=dptr(feat), x=dptr(x), out=dptr(sdf), feat_layout=layout,
-                                          precision=_lib.PREC[precision], sdf_only=1)
+                                          precision=_lib.PREC[precision], sdf_only=1, packed16_floats=packed16.numel())
             check(lib().mipsf_decoder_fwd16(C.byref(a), stream_ptr()), "decoder_fwd16")
         return sdf
     pe_mode = 0 if embed_pos is None else 1

@@ -113,7 +113,8 @@ class RayDataParallelStep:
             loss = objective(model.forward(*rays)); loss.backward()
             rdp.step(pose=(it + 1) % pose_accum_step == 0)
 
-    The constructor sets ``model.ray_share_reduce``: the model's training forward then returns the losses of the WHOLE batch
+    The constructor sets ``model.ray_share_reduce`` (``close()`` / leaving the ``with`` block clears it; while it is set every
+    training forward is a COLLECTIVE call): the model's training forward then returns the losses of the WHOLE batch
     (one 80-byte all-reduce inside forward), so ``loss.backward()`` leaves every rank with its rays' part of the batch's
     gradient.  ``step`` SUMS the gradients over the ranks (grid: reduce-scatter into this rank's slice; decoder and poses:
     all-reduce), runs the optimisers, and hands every rank the updated table (all-gather).  All ranks end every step with
@@ -121,6 +122,13 @@ class RayDataParallelStep:
 
     def __init__(self, model, make_grid_opt, make_decoder_opt, pose_params: Sequence[torch.nn.Parameter] = (),
                  make_pose_opt: Optional[Callable[[List[torch.nn.Parameter]], torch.optim.Optimizer]] = None, group=None):
+        # `step` SUMS gradients over the ranks, which is the batch's gradient only when the model's forward finishes the
+        # WHOLE batch's losses through this hook; a model without it would silently step along world x the gradient of the
+        # mean objective
+        if not hasattr(model, "ray_share_reduce"):
+            raise TypeError("RayDataParallelStep needs a model whose training forward sums its loss terms over the ranks "
+                            "through `model.ray_share_reduce` (mipsfusion_amd.model.JointEncoding does): the gradients of the "
+                            "shares are SUMMED, not averaged")
         self.group = group
         self.rank, self.world = rank_world(group)
         self.model = model
@@ -130,8 +138,21 @@ class RayDataParallelStep:
         self.pose_params = list(pose_params)
         self.pose_opt = make_pose_opt(self.pose_params) if (self.pose_params and make_pose_opt) else None
         self._dec_flat = None
-        if hasattr(model, "ray_share_reduce"):
-            model.ray_share_reduce = self.reduce_share
+        model.ray_share_reduce = self.reduce_share
+
+    def close(self):
+        """Take the hook off the model again: from here on its training forward is an ordinary single-process forward (with the
+        hook set EVERY training forward issues a collective -- a forward on a subset of the ranks, rank-0 evaluation in
+        train() mode say, would wait for the others forever).  Also the exit of ``with RayDataParallelStep(...) as rdp``."""
+        if getattr(self.model, "ray_share_reduce", None) == self.reduce_share:
+            self.model.ray_share_reduce = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def reduce_share(self, t: torch.Tensor) -> torch.Tensor:
         """sum of a small fp64 vector over the ranks (the nine loss sums + the ray count of every share)"""

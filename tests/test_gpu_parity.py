@@ -1892,3 +1892,40 @@ def test_random_optimizer_graph_capture_equals_eager_rounds(dev):
             graphed = ro.optimize_graphed(depth.to(dev).reshape(-1), start.clone())
             assert torch.equal(eager, graphed), f"frame {trial}: captured rounds differ from eager rounds"
     torch.cuda.synchronize()
+
+
+def test_operand_buffers_of_the_other_family_are_refused_and_huge_queries_are_cut(dev, monkeypatch):
+    """(1) A packed16 buffer of the f16 family must not reach the bf16x6 kernels (they would read it past its end) nor the
+    other way round: the buffers differ in size, which -- unlike a python attribute -- survives clone() / views; ops refuses,
+    and the library refuses again (packed16_floats of its argument blocks).  (2) bf16x6 takes at most 2^24 - 1 samples per
+    launch: forward-only queries beyond that (a 256^3 mesher grid) are cut into several launches -- same values (exercised
+    here with the limits lowered)."""
+    import ctypes as C
+    from mipsfusion_amd._lib import dptr, lib, stream_ptr
+    from mipsfusion_amd.model import scene_rep
+    torch.manual_seed(11)
+    dec = MLP_reg({}, input_ch=32, input_ch_pos=48).to(dev)
+    ws = dec.ordered_parameters()
+    M = 100
+    x = torch.rand(M, 3, device=dev)
+    feat = torch.randn(16, M, 2, device=dev) * 0.1
+    p_f16, p_bf = ops.decoder_pack16(ws, precision="f16x3"), ops.decoder_pack16(ws, precision="bf16x6")
+    for buf, prec in ((p_f16.clone(), "bf16x6"), (p_bf.clone(), "f16x3"), (p_bf[: p_f16.numel() + 8].clone(), "bf16x6")):
+        with pytest.raises(RuntimeError, match="packed for the other family|holds"):
+            ops.decoder_fwd(None, feat, _lib.FEAT_LEVEL_MAJOR, x, None, M, save=False, precision=prec, packed16=buf)
+    out = torch.empty(M, 10, device=dev)
+    a = _lib.DecoderFwd16Args.new(M=M, packed16=dptr(p_f16), feat=dptr(feat), x=dptr(x), out=dptr(out),
+                                  feat_layout=_lib.FEAT_LEVEL_MAJOR, precision=_lib.PREC["bf16x6"], packed16_floats=p_f16.numel())
+    assert lib().mipsf_decoder_fwd16(C.byref(a), stream_ptr()) != 0 and b"other family" in lib().mipsf_last_error()
+    a.packed16, a.packed16_floats = dptr(p_bf), p_bf.numel()
+    assert lib().mipsf_decoder_fwd16(C.byref(a), stream_ptr()) == 0
+    # (2)
+    g = load_golden("scene_cfg1.npz")
+    m = make_scene(g, cfg_for("scene_cfg1.npz"), dev).eval()
+    pts = torch.rand(1000, 3, device=dev)
+    with torch.no_grad():
+        whole, sdf_whole = m.query_color_sdf(pts), m.query_sdf(pts)
+        monkeypatch.setattr(scene_rep, "_MAX_QUERY", 256)
+        monkeypatch.setattr(scene_rep, "_QUERY_CHUNK", 192)
+        cut, sdf_cut = m.query_color_sdf(pts), m.query_sdf(pts)
+    assert torch.equal(whole, cut) and torch.equal(sdf_whole, sdf_cut) and cut.shape == (1000, 10) and sdf_cut.shape == (1000, 1)

@@ -556,3 +556,47 @@ def test_bench_launcher_process_keeps_its_affinity_mask():
         os.environ.pop("WORLD_SIZE", None)
         if env is not None:
             os.environ["WORLD_SIZE"] = env
+
+
+def test_host_rng_sessions_exclude_each_other_and_ray_dp_refuses_a_model_without_the_hook():
+    """(1) hostrng.session takes the default CPU generator's state out of torch and puts it back: two threads doing that at
+    once would overwrite each other's draws (the frame loop has a sample-producer thread).  One process-wide lock:
+    draws made by two threads through sessions are, as a set, exactly the draws one thread makes in a row.  (2)
+    RayDataParallelStep sums gradients over the ranks, which is only right for a model that finishes the whole batch's losses
+    through `ray_share_reduce`: a model without the hook is refused, and close() takes the hook off again."""
+    import threading
+    import types
+    from mipsfusion_amd import hostrng
+    from mipsfusion_amd.ray_dp import RayDataParallelStep
+    n, rounds = 4096, 40
+    torch.manual_seed(123)
+    want = torch.rand(2 * rounds, n)
+    torch.manual_seed(123)
+    got = [[], []]
+
+    def worker(j):
+        for _ in range(rounds):
+            buf = torch.empty(n)
+            with hostrng.session() as sess:
+                sess.rand_(buf)
+            got[j].append(buf)
+    ts = [threading.Thread(target=worker, args=(j,)) for j in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    rows = {tuple(r[:8].tolist()) for r in want}
+    seen = [tuple(b[:8].tolist()) for g in got for b in g]
+    assert len(set(seen)) == 2 * rounds and set(seen) == rows, "two sessions interleaved: draws were lost or made twice"
+    with pytest.raises(TypeError, match="ray_share_reduce"):
+        RayDataParallelStep(types.SimpleNamespace(), None, None)
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.embed_fn = types.SimpleNamespace(params=torch.nn.Parameter(torch.zeros(64)))
+            self.decoder = torch.nn.Linear(2, 2)
+            self.ray_share_reduce = None
+    m = Tiny()
+    mk = lambda ps: torch.optim.Adam([ps] if isinstance(ps, torch.Tensor) else ps)      # noqa: E731
+    with RayDataParallelStep(m, mk, mk) as rdp:
+        assert m.ray_share_reduce == rdp.reduce_share
+    assert m.ray_share_reduce is None

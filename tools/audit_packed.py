@@ -7,6 +7,7 @@ import collections
 import concurrent.futures
 import os
 import re
+import shlex
 import subprocess
 import sys
 import tempfile
@@ -18,6 +19,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mu
 
 
 def unit_isa(unit, out_dir, extra=()):
+    """ISA of one unit under the product's flags + `extra` + whatever $EXTRA holds (the variable the Makefile appends to its
+    own flags: `make EXTRA=-DFOO` and `EXTRA=-DFOO python tools/audit_packed.py` see the same build)"""
+    extra = tuple(extra) + tuple(shlex.split(os.environ.get("EXTRA", "")))
     out = os.path.join(out_dir, unit + ".s")
     subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *extra, "-S", "--cuda-device-only", "-o", out, os.path.join(SRC, unit + ".hip")],
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
