@@ -735,6 +735,9 @@ __device__ __forceinline__ void scatter_item(const float* __restrict__ x, const 
     float sum[8][2];
     bool open = false;
     auto flush = [&]() {
+#ifdef MIPSF_SC_ABL_DENSE_NOATOM      // ablation: a dense item without its LDS atomics (wrong results)
+        if (mode == 0) { asm volatile("" :: "v"(sum[0][0]), "v"(sum[7][1])); return; }
+#endif
         Cell cell;
         cell.c[0] = cc[0], cell.c[1] = cc[1], cell.c[2] = cc[2];
         uint32_t idx[8];
@@ -791,8 +794,15 @@ __device__ __forceinline__ void scatter_item(const float* __restrict__ x, const 
 #pragma unroll
             for (int u = 0; u < UD; ++u) {
                 const uint32_t ii = masked ? (si[u] & 0xffffffu) : si[u];
+#ifdef MIPSF_SC_ABL_NOGATHER     // ablation: what a hashed item costs WITHOUT its two per-record gathers (wrong results)
+                px[u][0] = (float)(ii & 1023u) * (1.0f / 1024.0f), px[u][1] = (float)((ii >> 10) & 1023u) * (1.0f / 1024.0f);
+                px[u][2] = (float)((ii >> 5) & 1023u) * (1.0f / 1024.0f);
+                pg[u] = make_float2(1e-3f, 2e-3f);
+#else
+                // (non-temporal loads for these two gathers: 109 -> 150 us)
                 px[u][0] = x[3 * (size_t)ii], px[u][1] = x[3 * (size_t)ii + 1], px[u][2] = x[3 * (size_t)ii + 2];
                 pg[u] = *reinterpret_cast<const float2*>(dout + feat_index<LAYOUT>(ii, level, M, g.n_levels));
+#endif
             }
 #pragma unroll
             for (int u = 0; u < UD; ++u) {
@@ -870,8 +880,14 @@ __device__ __forceinline__ void scatter_item(const float* __restrict__ x, const 
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const uint32_t ii = si[u];
+#ifdef MIPSF_SC_ABL_DENSE_NOGATHER    // ablation: a dense item without its x / d feat loads (wrong results)
+            px[u][0] = (float)(ii & 4095u) * (1.0f / 4096.0f), px[u][1] = (float)((ii >> 6) & 4095u) * (1.0f / 4096.0f);
+            px[u][2] = (float)((ii >> 12) & 63u) * (1.0f / 64.0f);
+            pg[u] = make_float2(1e-3f, 2e-3f);
+#else
             px[u][0] = x[3 * (size_t)ii], px[u][1] = x[3 * (size_t)ii + 1], px[u][2] = x[3 * (size_t)ii + 2];
             pg[u] = *reinterpret_cast<const float2*>(dout + feat_index<LAYOUT>(ii, level, M, g.n_levels));
+#endif
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -886,7 +902,9 @@ __device__ __forceinline__ void scatter_item(const float* __restrict__ x, const 
             }
             const bool same = open && cell.c[0] == cc[0] && cell.c[1] == cc[1] && cell.c[2] == cc[2];
             if (!same) {
+#ifndef MIPSF_SC_ABL_DENSE_NOMID      // ablation: the flushes at a cell boundary inside a thread's records dropped (wrong results)
                 if (open) flush();
+#endif
                 cc[0] = cell.c[0], cc[1] = cell.c[1], cc[2] = cell.c[2];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) sum[c][0] = 0.0f, sum[c][1] = 0.0f;
@@ -902,6 +920,9 @@ __device__ __forceinline__ void scatter_item(const float* __restrict__ x, const 
                 sum[c][1] = sum[c][1] + wgt * gy.y;
             }
         }
+        // The run still open at the end of the thread's records.  (Adding up the open runs of neighbouring lanes that end in
+        // the same cell first -- a segmented sum through the wave, so that only one lane of a stretch goes to LDS -- was measured
+        // twice in round 5, with ds_bpermute and with DPP row shifts: no change)
         if (open) flush();
         open = false;
     }
