@@ -358,6 +358,10 @@ typedef struct mipsf_render_fwd_args {
     float* loss_total;              /* nullable */
     uint32_t* ticket;               /* nullable */
     double* sums;                   /* nullable */
+    float* draw;                    /* nullable; [N,S,10]: ALSO the backward of the objective, in the same launch -- d loss_total /
+                                     * d raw for an objective gradient of exactly 1 (what mipsf_render_bwd writes for g_total = {1},
+                                     * no other gradient; bit for bit).  Needs ticket, loss_weights, loss_total and S <= 128.  A block
+                                     * whose struct_size ends before this field is accepted (draw = NULL) */
 } mipsf_render_fwd_args;
 int mipsf_render_fwd(const mipsf_render_fwd_args* args_host, void* stream);
 int mipsf_loss_finalize_sums(const double* sums, const mipsf_render_cfg* cfg_host, uint32_t N_total, uint32_t S,
@@ -384,7 +388,11 @@ typedef struct mipsf_render_bwd_args {
     const float* g_rgb;             /* nullable */
     const float* g_depth;           /* nullable */
     float* draw;
+    uint32_t flags;                 /* MIPSF_RENDER_BWD_*; a block whose struct_size ends before this field is accepted (0) */
 } mipsf_render_bwd_args;
+/* draw already holds mipsf_render_fwd's `draw` (the gradient for g_total = {1}): the kernel returns at once when g_total[0] is
+ * exactly 1 and rewrites draw otherwise.  g_total must be the only gradient given */
+#define MIPSF_RENDER_BWD_KEEP_IF_UNIT 1u
 int mipsf_render_bwd(const mipsf_render_bwd_args* args_host, void* stream);
 /* Row gather of the ray table + ray construction from the pose parameters + sample placement in one launch
  * (mipsf_pose_rays_fwd with a ray table + mipsf_sample_rays: keyframeSet.py:264-290, mipsfusion.py:320-322,

@@ -74,11 +74,12 @@ RenderFwdArgs = _args("RenderFwdArgs", [("N", _CU), ("S", _CU), ("raw", _VP), ("
                                         ("counts", _VP), ("cfg", C.POINTER(RenderCfg)), ("rgb", _VP), ("depth", _VP),
                                         ("depth_var", _VP), ("disp", _VP), ("acc", _VP), ("weights", _VP), ("losses", _VP),
                                         ("partial", _VP), ("loss_weights", _VP), ("loss_total", _VP), ("ticket", _VP),
-                                        ("sums", _VP)])
+                                        ("sums", _VP), ("draw", _VP)])
 RenderBwdArgs = _args("RenderBwdArgs", [("N", _CU), ("S", _CU), ("N_norm", _CU), ("raw", _VP), ("z_vals", _VP), ("target_rgb", _VP),
                                         ("target_d", _VP), ("counts", _VP), ("losses", _VP), ("cfg", C.POINTER(RenderCfg)),
                                         ("g_losses", _VP), ("g_total", _VP), ("loss_weights", _VP), ("g_rgb", _VP),
-                                        ("g_depth", _VP), ("draw", _VP)])
+                                        ("g_depth", _VP), ("draw", _VP), ("flags", _CU)])
+RENDER_BWD_KEEP_IF_UNIT = 1
 
 # mipsf_buffer_size(which, n, a, b, meta): MIPSF_SIZE_* of include/mipsf.h
 (SIZE_HASHGRID_BWD_SCRATCH, SIZE_HASHGRID_COUNTER_WORDS, SIZE_DECODER_PACKED, SIZE_DECODER_SAVED, SIZE_DECODER_DACT,

@@ -6,6 +6,8 @@
 // Reference: model/scene_rep.py:58-103 (sdf2weights, raw2outputs), :156-179 (placement), :211-236 (losses);
 // helper_functions/utils.py:21-49, 71-111 (get_masks, get_sdf_loss).
 #include "pose_dev.h"
+#include <cstring>
+#include <cstddef>
 
 namespace mipsf {
 
@@ -307,28 +309,12 @@ __device__ __forceinline__ void render_fwd_ray(
     }
 }
 
-// partial[n*8 + {0..5}] = {rgb_sq, depth_sq(valid), fs_sq, sdf_sq, fs_emd, sdf_emd}; [6] = valid flag
-// FUSED (training, fin.ticket given): ONE launch.  Every workgroup adds its four rays' rows (and their front / band
-// counts) in fp64, writes the 9 sums through as ITS row of `partial` ([workgroups][9] doubles), waits for the stores'
-// acknowledgement (s_waitcnt vmcnt(0)) and takes a device-scope ticket; the LAST workgroup adds all rows in a fixed order
-// (so the result does not depend on which workgroup is last), finishes the losses and leaves the ticket at zero.  The same
-// hand-off as pose_rays_bwd_kernel (csrc/pose.hip: sc1 stores + vmcnt(0) + ticket, sc1 loads on the reading side).
-// 16 rays per workgroup in this form: the tickets are same-address device atomics (~90 per microsecond): the 1024 workgroups
-// of the 4-ray form spent 12 us on them (30 us instead of the 21 us of the two launches), 256 workgroups spend 3.
-template <bool TRAIN, bool FUSED, int RPB>
-__global__ __launch_bounds__(RPB * MIPSF_WAVE) void render_fwd_kernel(
-    const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ target_rgb,
-    const float* __restrict__ target_d, RenderCfg rc, float* __restrict__ rgb_out, float* __restrict__ depth_out,
-    float* __restrict__ var_out, float* __restrict__ disp_out, float* __restrict__ acc_out,
-    float* __restrict__ weights_out, float* __restrict__ partial, uint32_t N, uint32_t S, LossFinalize fin) {
-    __shared__ float ssdf[RPB][MAX_S];
-    const uint32_t w = threadIdx.x / MIPSF_WAVE, lane = threadIdx.x & (MIPSF_WAVE - 1);
-    const uint32_t n = blockIdx.x * RPB + w;
-    float row[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (n < N)
-        render_fwd_ray<TRAIN, FUSED>(raw, z_vals, target_rgb, target_d, rc, rgb_out, depth_out, var_out, disp_out, acc_out,
-                                     weights_out, partial, N, S, ssdf[w], n, lane, row);
-    if (!FUSED) return;
+// The hand-off of the one-launch training forward (see render_fwd_kernel): this workgroup's rays' loss rows (`row`, wave-uniform
+// per ray) and their front / band counts are added in fp64 and written through as ITS row of `partial`; the last workgroup through
+// the ticket adds all rows in a fixed order and finishes the losses.  Called by every thread of the workgroup.
+template <int RPB>
+__device__ __forceinline__ void render_fused_tail(const float (&row)[7], uint32_t n, uint32_t w, uint32_t lane, uint32_t N, uint32_t S,
+                                                  const RenderCfg& rc, float* __restrict__ partial, const LossFinalize& fin) {
     __shared__ bool is_last;
     __shared__ double red[RPB][9];
     if (lane == 0) {
@@ -392,6 +378,308 @@ __global__ __launch_bounds__(RPB * MIPSF_WAVE) void render_fwd_kernel(
         }
         __hip_atomic_store(fin.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// partial[n*8 + {0..5}] = {rgb_sq, depth_sq(valid), fs_sq, sdf_sq, fs_emd, sdf_emd}; [6] = valid flag
+// FUSED (training, fin.ticket given): ONE launch.  Every workgroup adds its four rays' rows (and their front / band
+// counts) in fp64, writes the 9 sums through as ITS row of `partial` ([workgroups][9] doubles), waits for the stores'
+// acknowledgement (s_waitcnt vmcnt(0)) and takes a device-scope ticket; the LAST workgroup adds all rows in a fixed order
+// (so the result does not depend on which workgroup is last), finishes the losses and leaves the ticket at zero.  The same
+// hand-off as pose_rays_bwd_kernel (csrc/pose.hip: sc1 stores + vmcnt(0) + ticket, sc1 loads on the reading side).
+// 16 rays per workgroup in this form: the tickets are same-address device atomics (~90 per microsecond): the 1024 workgroups
+// of the 4-ray form spent 12 us on them (30 us instead of the 21 us of the two launches), 256 workgroups spend 3.
+template <bool TRAIN, bool FUSED, int RPB>
+MIPSF_SINGLE_FP32 __global__ __launch_bounds__(RPB * MIPSF_WAVE) void render_fwd_kernel(
+    const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ target_rgb,
+    const float* __restrict__ target_d, RenderCfg rc, float* __restrict__ rgb_out, float* __restrict__ depth_out,
+    float* __restrict__ var_out, float* __restrict__ disp_out, float* __restrict__ acc_out,
+    float* __restrict__ weights_out, float* __restrict__ partial, uint32_t N, uint32_t S, LossFinalize fin) {
+    __shared__ float ssdf[RPB][MAX_S];
+    const uint32_t w = threadIdx.x / MIPSF_WAVE, lane = threadIdx.x & (MIPSF_WAVE - 1);
+    const uint32_t n = blockIdx.x * RPB + w;
+    float row[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (n < N)
+        render_fwd_ray<TRAIN, FUSED>(raw, z_vals, target_rgb, target_d, rc, rgb_out, depth_out, var_out, disp_out, acc_out,
+                                     weights_out, partial, N, S, ssdf[w], n, lane, row);
+    if (!FUSED) return;
+    render_fused_tail<RPB>(row, n, w, lane, N, S, rc, partial, fin);
+}
+
+// ------------------------------------------------------------ training forward (+ the backward of the objective) in ONE pass
+// The one-launch training forward again, for S <= 128, with the ray's data read ONCE: its row of `raw` (S x 10 floats, contiguous)
+// is staged in LDS by coalesced loads -- render_fwd_ray / render_bwd_kernel read it component by component, 40 bytes from lane
+// to lane, in every one of their passes, and fetch z[first crossing] from memory behind the ballot -- its depths sit in registers
+// (two samples per lane), every sigmoid is evaluated once.  Same expressions in the same order: the same bits as
+// render_fwd_kernel<true, true, 16>.
+// DRAW: d objective / d raw for an objective gradient of exactly 1 (g_total = 1, no other gradient: what `loss.backward()` on
+// render_fwd's loss_total means) is written as well -- render_bwd_kernel's expressions, bit for bit.  What that kernel takes
+// from the finished losses (fs_weight, sdf_weight, n_valid) depends on the sample depths and the target depths only: every
+// workgroup adds the per-ray counts of ALL rays itself (integers: exact in any order; 48 KB from L2, under the staging loads).
+constexpr int RT_RPB = 16;          // rays per workgroup (the ticket traffic: see render_fwd_kernel)
+constexpr uint32_t RT_MAX_S = 2 * MIPSF_WAVE;          // RT_KMAX = samples per lane: 1 or 2
+// sum of an integer over the wave's lanes (DPP: vector pipe, no LDS traffic; integers add exactly in any order)
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);      // row_shr:1, 2, 4, 8: lane 15 of a row holds the row's sum
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, true);      // row_bcast:15 into rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, true);      // row_bcast:31 into rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
+template <bool DRAW, int RT_KMAX>
+MIPSF_SINGLE_FP32 __global__ __launch_bounds__(RT_RPB * MIPSF_WAVE) void render_train_kernel(
+    const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ target_rgb,
+    const float* __restrict__ target_d, RenderCfg rc, float* __restrict__ rgb_out, float* __restrict__ depth_out,
+    float* __restrict__ var_out, float* __restrict__ disp_out, float* __restrict__ acc_out,
+    float* __restrict__ weights_out, float* __restrict__ partial, uint32_t N, uint32_t S, LossFinalize fin,
+    float* __restrict__ draw) {
+    extern __shared__ float rt_rows[];                  // [RT_RPB][S * 10]
+    __shared__ uint32_t cred[RT_RPB][3];
+    constexpr uint32_t T = RT_RPB * MIPSF_WAVE;
+    const uint32_t w = threadIdx.x / MIPSF_WAVE, lane = threadIdx.x & (MIPSF_WAVE - 1);
+    const uint32_t n = blockIdx.x * RT_RPB + w;
+    const bool live = n < N;
+    const uint32_t row_words = S * 10u;
+    float* sraw = rt_rows + (size_t)w * row_words;
+    const uint32_t nn = live ? n : N - 1;
+    const float* rraw = raw + (size_t)nn * row_words;
+    const float* rz = z_vals + (size_t)nn * S;
+
+    // ---- every load of the ray in flight at once (the counts of all rays first: they are reduced while the row arrives)
+    uint32_t cf = 0, cb = 0, cv = 0;
+    if (DRAW) {
+        for (uint32_t m0 = threadIdx.x; m0 < N; m0 += 4 * T) {
+            uint2 c[4];
+            float dd[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t m = m0 + (uint32_t)u * T;
+                const uint32_t mm = m < N ? m : N - 1;
+                c[u] = reinterpret_cast<const uint2*>(fin.counts)[mm];
+                dd[u] = target_d[mm];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (m0 + (uint32_t)u * T >= N) break;
+                cf += c[u].x, cb += c[u].y;
+                cv += ((dd[u] > 0.f) && (dd[u] < rc.depth_trunc)) ? 1u : 0u;
+            }
+        }
+    }
+    float stage[RT_KMAX * 10];
+#pragma unroll
+    for (int q = 0; q < RT_KMAX * 10; ++q) {
+        const uint32_t i = lane + (uint32_t)q * MIPSF_WAVE;
+        stage[q] = i < row_words ? rraw[i] : 0.0f;
+    }
+    float zz[RT_KMAX];
+    bool in[RT_KMAX];
+#pragma unroll
+    for (int j = 0; j < RT_KMAX; ++j) {
+        const uint32_t k = lane + (uint32_t)j * MIPSF_WAVE;
+        in[j] = k < S;
+        zz[j] = in[j] ? rz[k] : 0.0f;
+    }
+    const float d = target_d[nn];
+    const float t_r = target_rgb[3 * nn], t_g = target_rgb[3 * nn + 1], t_b = target_rgb[3 * nn + 2];
+    if (DRAW) {
+        cf = wave_sum_u32(cf), cb = wave_sum_u32(cb), cv = wave_sum_u32(cv);
+        if (lane == 0) cred[w][0] = cf, cred[w][1] = cb, cred[w][2] = cv;
+    }
+#pragma unroll
+    for (int q = 0; q < RT_KMAX * 10; ++q) {
+        const uint32_t i = lane + (uint32_t)q * MIPSF_WAVE;
+        if (i < row_words) sraw[i] = stage[q];
+    }
+    uint32_t n_front = 0, n_band = 0, n_valid = 0;        // of the whole batch (< 2^32: M = N S is a 32-bit count)
+    if (DRAW) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < RT_RPB; ++q) n_front += cred[q][0], n_band += cred[q][1], n_valid += cred[q][2];
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    float row[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        float sv[RT_KMAX], u_[RT_KMAX], sg[RT_KMAX], c0[RT_KMAX], c1[RT_KMAX], c2[RT_KMAX];
+        bool keep[RT_KMAX];
+        // first k in [0, S - 1) with s[k] * s[k + 1] < 0, else 0 (first_crossing)
+        uint32_t kc = 0;
+        bool found = false;
+#pragma unroll
+        for (int j = 0; j < RT_KMAX; ++j) {
+            const uint32_t k = lane + (uint32_t)j * MIPSF_WAVE;
+            sv[j] = in[j] ? sraw[k * 10 + 3] : 0.0f;
+            const float nxt = (k + 1 < S) ? sraw[(k + 1) * 10 + 3] : 0.0f;
+            const bool hit = (k + 1 < S) && (sv[j] * nxt < 0.0f);
+            const unsigned long long m = __ballot(hit);
+            if (!found && m != 0ull) kc = (uint32_t)j * MIPSF_WAVE + (uint32_t)(__ffsll((long long)m) - 1), found = true;
+        }
+        float zsel = zz[0];
+#pragma unroll
+        for (int j = 1; j < RT_KMAX; ++j) zsel = (kc / MIPSF_WAVE == (uint32_t)j) ? zz[j] : zsel;
+        const float z_min = __shfl(zsel, (int)(kc & (MIPSF_WAVE - 1)), 64);
+        const float z_cut = z_min + rc.band;
+
+        float usum = 0.f;
+#pragma unroll
+        for (int j = 0; j < RT_KMAX; ++j) {
+            if (!in[j]) continue;
+            const float q = sv[j] / rc.trunc;
+            sg[j] = sigmoidf_(q);
+            u_[j] = sg[j] * sigmoidf_(-q);
+            keep[j] = zz[j] < z_cut;
+            usum += keep[j] ? u_[j] : 0.f;
+        }
+        usum = wave_sum(usum);
+        const float inv = 1.0f / (usum + 1e-8f);
+
+        float a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f, a_w = 0.f;
+#pragma unroll
+        for (int j = 0; j < RT_KMAX; ++j) {
+            if (!in[j]) continue;
+            const uint32_t k = lane + (uint32_t)j * MIPSF_WAVE;
+            const float u = keep[j] ? u_[j] : 0.f;
+            const float wn = u * inv;
+            if (weights_out) weights_out[(size_t)n * S + k] = wn;
+            c0[j] = sigmoidf_(sraw[k * 10 + 0]), c1[j] = sigmoidf_(sraw[k * 10 + 1]), c2[j] = sigmoidf_(sraw[k * 10 + 2]);
+            a_r += wn * c0[j];
+            a_g += wn * c1[j];
+            a_b += wn * c2[j];
+            a_d += wn * zz[j];
+            a_w += wn;
+        }
+        a_r = wave_sum(a_r), a_g = wave_sum(a_g), a_b = wave_sum(a_b), a_d = wave_sum(a_d), a_w = wave_sum(a_w);
+        float a_v = 0.f;
+#pragma unroll
+        for (int j = 0; j < RT_KMAX; ++j) {
+            if (!in[j]) continue;
+            const float u = keep[j] ? u_[j] : 0.f;
+            const float t = zz[j] - a_d;
+            a_v += (u * inv) * (t * t);
+        }
+        a_v = wave_sum(a_v);
+        if (lane == 0) {
+            rgb_out[3 * n] = a_r, rgb_out[3 * n + 1] = a_g, rgb_out[3 * n + 2] = a_b;
+            depth_out[n] = a_d;
+            if (var_out) var_out[n] = a_v;
+            if (disp_out) disp_out[n] = 1.0f / fmaxf(1e-10f, a_d / a_w);
+            if (acc_out) acc_out[n] = a_w;
+        }
+
+        // ---- the losses' per-ray sums (render_fwd_ray)
+        const bool valid = (d > 0.f) && (d < rc.depth_trunc);
+        const float cw = (valid || rc.rgb_missing_nonzero) ? 1.f : 0.f;
+        float p_fs = 0.f, p_sd = 0.f, p_fe = 0.f, p_se = 0.f;
+        const float TT = rc.trunc_total;
+        const bool has_depth = d > 0.f;
+#pragma unroll
+        for (int j = 0; j < RT_KMAX; ++j) {
+            if (!in[j]) continue;
+            const uint32_t k = lane + (uint32_t)j * MIPSF_WAVE;
+            const float z = zz[j], s = sv[j];
+            const bool front = z < d - TT;
+            const bool back = z > d + TT;
+            const float fm = front ? 1.f : 0.f;
+            const float bm = (!front && !back && has_depth) ? 1.f : 0.f;
+            const float ef = s * fm - fm;
+            p_fs += ef * ef;
+            const float es = (z + s * TT) * bm - d * bm;
+            p_sd += es * es;
+            if (rc.emd_w > 0.f) {
+                const float gt = (((d - z) + TT) / (2.f * TT)) * 4.f;
+                float fe = 0.f, se = 0.f;
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    const float p = sraw[k * 10 + 5 + c];
+                    fe += p * (float)(4 - c) * fm;
+                    se += fabsf(gt - (float)c) * bm * p;
+                }
+                p_fe += fe;
+                p_se += se;
+            }
+        }
+        p_fs = wave_sum(p_fs), p_sd = wave_sum(p_sd), p_fe = wave_sum(p_fe), p_se = wave_sum(p_se);
+        const float e0 = a_r * cw - t_r * cw;
+        const float e1 = a_g * cw - t_g * cw;
+        const float e2 = a_b * cw - t_b * cw;
+        const float ed = a_d - d;
+        row[0] = e0 * e0 + e1 * e1 + e2 * e2, row[1] = valid ? ed * ed : 0.f, row[2] = p_fs, row[3] = p_sd, row[4] = p_fe, row[5] = p_se;
+        row[6] = valid ? 1.f : 0.f;
+
+        if (DRAW) {
+            // ---- render_bwd_kernel with g_losses = g_rgb = g_depth = null, g_total = 1, N_norm = N
+            float gl[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gl[k] = 0.f + 1.0f * fin.loss_weights[k];
+            const float gR = gl[0], gD = gl[1], gS = gl[2], gF = gl[3];
+            const float nf = (float)n_front, nb = (float)n_band;
+            const float total = nf + nb;
+            const float fs_w = 1.0f - nf / total, sdf_w = 1.0f - nb / total;      // finalize_losses
+            const float NS = (float)N * (float)S;
+            float G_r = 0.f, G_g = 0.f, G_b = 0.f, G_d = 0.f;
+            const float k_rgb = gR * 2.f * cw * cw / (3.f * (float)N);
+            G_r += k_rgb * (a_r - t_r);
+            G_g += k_rgb * (a_g - t_g);
+            G_b += k_rgb * (a_b - t_b);
+            if (valid) G_d += gD * 2.f * (a_d - d) / (float)n_valid;
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < RT_KMAX; ++j) {
+                if (!in[j]) continue;
+                const float wn = (keep[j] ? u_[j] : 0.f) * inv;
+                const float Gk = G_r * c0[j] + G_g * c1[j] + G_b * c2[j] + G_d * zz[j];
+                dot += Gk * wn;
+            }
+            dot = wave_sum(dot);
+#pragma unroll
+            for (int j = 0; j < RT_KMAX; ++j) {
+                if (!in[j]) continue;
+                const uint32_t k = lane + (uint32_t)j * MIPSF_WAVE;
+                const float z = zz[j], s = sv[j];
+                const float a = u_[j];
+                const float wn = (keep[j] ? a : 0.f) * inv;
+                const float Gk = G_r * c0[j] + G_g * c1[j] + G_b * c2[j] + G_d * z;
+                float ds = keep[j] ? (Gk - dot) * inv * (a * (1.f - 2.f * sg[j]) / rc.trunc) : 0.f;
+                float dp[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+                const bool front = z < d - TT;
+                const bool back = z > d + TT;
+                const float fm = front ? 1.f : 0.f;
+                const float bm = (!front && !back && has_depth) ? 1.f : 0.f;
+                ds += gF * fs_w * (2.f / NS) * fm * (s * fm - fm);
+                ds += gS * sdf_w * (2.f / NS) * (bm * TT) * ((z + s * TT) * bm - d * bm);
+                if (rc.emd_w > 0.f) {
+                    const float gt = (((d - z) + TT) / (2.f * TT)) * 4.f;
+                    const float kf = gF * rc.emd_w / (250.f * NS), ks = gS * rc.emd_w / (5000.f * NS);
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) dp[c] = kf * fm * (float)(4 - c) + ks * bm * fabsf(gt - (float)c);
+                }
+                float* o = sraw + k * 10;          // this sample's own words: nobody else reads them any more
+                o[0] = G_r * wn * c0[j] * (1.f - c0[j]);
+                o[1] = G_g * wn * c1[j] * (1.f - c1[j]);
+                o[2] = G_b * wn * c2[j] * (1.f - c2[j]);
+                o[3] = ds;
+                o[4] = 0.f;
+#pragma unroll
+                for (int c = 0; c < 5; ++c) o[5 + c] = dp[c];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float* rdr = draw + (size_t)n * row_words;
+#pragma unroll
+            for (int q = 0; q < RT_KMAX * 10; ++q) {
+                const uint32_t i = lane + (uint32_t)q * MIPSF_WAVE;
+                if (i < row_words) rdr[i] = sraw[i];
+            }
+        }
+    }
+    render_fused_tail<RT_RPB>(row, n, w, lane, N, S, rc, partial, fin);
 }
 
 // losses[8] = {rgb_loss, depth_loss, sdf_loss, fs_loss, psnr, fs_weight, sdf_weight, n_valid}
@@ -495,7 +783,9 @@ MIPSF_SINGLE_FP32 __global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void
     const float* __restrict__ target_d, const float* __restrict__ losses, RenderCfg rc, int train,
     const float* __restrict__ g_losses, const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
     float* __restrict__ draw, uint32_t N, uint32_t S, const float* __restrict__ g_total,
-    const float* __restrict__ loss_weights, uint32_t N_norm) {
+    const float* __restrict__ loss_weights, uint32_t N_norm, int keep_if_unit) {
+    // draw already holds the gradient for an objective gradient of exactly 1 (render_train_kernel<true, .>): nothing to do then
+    if (keep_if_unit && g_total[0] == 1.0f) return;
     __shared__ float ssdf[RAYS_PER_BLOCK][MAX_S];
     const uint32_t w = threadIdx.x / MIPSF_WAVE, lane = threadIdx.x & (MIPSF_WAVE - 1);
     const uint32_t n = blockIdx.x * RAYS_PER_BLOCK + w;
@@ -786,6 +1076,34 @@ int mipsf_place_pose_bwd(const float* dxn, const float* z_vals, const mipsf_rend
     return check_launch("place_pose_bwd");
 }
 
+// render_train_kernel (S <= RT_MAX_S): RT_RPB x S x 40 bytes of dynamic LDS, above 64 KB from S = 103
+static int launch_render_train(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
+                               const RenderCfg& rc, float* rgb, float* depth, float* depth_var, float* disp, float* acc,
+                               float* weights, float* partial, uint32_t N, uint32_t S, const LossFinalize& fin, float* draw,
+                               hipStream_t s) {
+    const uint32_t lds = (uint32_t)RT_RPB * S * 40u;
+    const int two = S > MIPSF_WAVE ? 1 : 0;       // samples per lane - 1
+    const void* fn[2][2] = {{(const void*)render_train_kernel<false, 1>, (const void*)render_train_kernel<false, 2>},
+                            {(const void*)render_train_kernel<true, 1>, (const void*)render_train_kernel<true, 2>}};
+    static uint32_t attr_dev[MAX_DEVICES][2] = {};
+    uint32_t& attr = attr_dev[device_slot()][draw ? 1 : 0];
+    if (lds > 48u * 1024u && lds > attr) {        // (only the two-samples-per-lane kernels get there)
+        if (hipFuncSetAttribute(fn[draw ? 1 : 0][1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("cannot raise dynamic LDS to %u bytes", lds);
+            return 4;
+        }
+        attr = lds;
+    }
+    const dim3 grid((N + RT_RPB - 1) / RT_RPB), block(RT_RPB * MIPSF_WAVE);
+#define RT_LAUNCH(D, K)                                                                                                         \
+    hipLaunchKernelGGL((render_train_kernel<D, K>), grid, block, lds, s, raw, z_vals, target_rgb, target_d, rc, rgb, depth, depth_var, \
+                       disp, acc, weights, partial, N, S, fin, draw)
+    if (draw) { if (two) RT_LAUNCH(true, 2); else RT_LAUNCH(true, 1); }
+    else { if (two) RT_LAUNCH(false, 2); else RT_LAUNCH(false, 1); }
+#undef RT_LAUNCH
+    return 0;
+}
+
 static int render_fwd_sums(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
                            const uint32_t* counts, const mipsf_render_cfg* cfg, float* rgb, float* depth, float* depth_var,
                            float* disp, float* acc, float* weights, float* partial, double* sums, uint32_t* ticket, uint32_t N,
@@ -794,17 +1112,22 @@ static int render_fwd_sums(const float* raw, const float* z_vals, const float* t
 // ONE entry point for the forward (round 5; include/mipsf.h): evaluation, training in two launches, training in one launch
 // (ticket), the training objective formed in the same launch (loss_weights / loss_total), a share of a ray-data-parallel
 // batch (sums).
-int mipsf_render_fwd(const mipsf_render_fwd_args* a, void* stream) {
-    MIPSF_REQUIRE(a != nullptr, "null argument block");
-    MIPSF_REQUIRE(a->struct_size == sizeof(mipsf_render_fwd_args), "mipsf_render_fwd_args: struct_size %u, this library expects %u",
-                  a->struct_size, (unsigned)sizeof(mipsf_render_fwd_args));
+int mipsf_render_fwd(const mipsf_render_fwd_args* a_in, void* stream) {
+    MIPSF_REQUIRE(a_in != nullptr, "null argument block");
+    // (a block that ends before `draw` -- the first form of this ABI version -- is accepted: the field reads as null)
+    MIPSF_REQUIRE(a_in->struct_size == sizeof(mipsf_render_fwd_args) || a_in->struct_size == offsetof(mipsf_render_fwd_args, draw),
+                  "mipsf_render_fwd_args: struct_size %u, this library expects %u", a_in->struct_size,
+                  (unsigned)sizeof(mipsf_render_fwd_args));
+    mipsf_render_fwd_args a_copy = {};
+    memcpy(&a_copy, a_in, a_in->struct_size);
+    const mipsf_render_fwd_args* a = &a_copy;
     const float* raw = a->raw; const float* z_vals = a->z_vals; const float* target_rgb = a->target_rgb; const float* target_d = a->target_d;
     const uint32_t* counts = a->counts; const mipsf_render_cfg* cfg = a->cfg; float* rgb = a->rgb; float* depth = a->depth;
     float* depth_var = a->depth_var; float* disp = a->disp; float* acc = a->acc; float* weights = a->weights; float* losses = a->losses;
     float* partial = a->partial; const float* loss_weights = a->loss_weights; float* loss_total = a->loss_total;
     uint32_t* ticket = a->ticket; const uint32_t N = a->N, S = a->S;
     if (a->sums != nullptr) {
-        MIPSF_REQUIRE(losses == nullptr && loss_weights == nullptr && loss_total == nullptr,
+        MIPSF_REQUIRE(losses == nullptr && loss_weights == nullptr && loss_total == nullptr && a->draw == nullptr,
                       "sums: the losses of a share are finished by mipsf_loss_finalize_sums, not here");
         return render_fwd_sums(raw, z_vals, target_rgb, target_d, counts, cfg, rgb, depth, depth_var, disp, acc, weights, partial,
                                a->sums, ticket, N, S, stream);
@@ -820,6 +1143,14 @@ int mipsf_render_fwd(const mipsf_render_fwd_args* a, void* stream) {
     const LossFinalize fin = {counts, ticket, losses, loss_weights, loss_total, nullptr};
     if (losses) {
         MIPSF_REQUIRE(target_rgb && target_d && counts && partial, "training mode needs targets, counts, partial");
+        MIPSF_REQUIRE(a->draw == nullptr || (ticket && loss_total && S <= RT_MAX_S),
+                      "draw: the one-launch form with the objective (ticket, loss_weights, loss_total) and S <= %u", RT_MAX_S);
+        if (ticket && S <= RT_MAX_S) {      // one launch, the ray read once; with `draw` also the backward of the objective
+            if (int e = launch_render_train(raw, z_vals, target_rgb, target_d, rc, rgb, depth, depth_var, disp, acc, weights, partial,
+                                            N, S, fin, a->draw, s))
+                return e;
+            return check_launch("render_fwd");
+        }
         if (ticket) {       // one launch: the last workgroup finishes the losses
             constexpr int RPB = 16;
             hipLaunchKernelGGL((render_fwd_kernel<true, true, RPB>), dim3((N + RPB - 1) / RPB), dim3(RPB * MIPSF_WAVE), 0, s, raw,
@@ -853,6 +1184,12 @@ static int render_fwd_sums(const float* raw, const float* z_vals, const float* t
         return 0;
     }
     const LossFinalize fin = {counts, ticket, nullptr, nullptr, nullptr, sums};
+    if (S <= RT_MAX_S) {
+        if (int e = launch_render_train(raw, z_vals, target_rgb, target_d, to_render_cfg(*cfg), rgb, depth, depth_var, disp, acc, weights,
+                                        partial, N, S, fin, nullptr, s))
+            return e;
+        return check_launch("render_fwd_sums");
+    }
     constexpr int RPB = 16;
     hipLaunchKernelGGL((render_fwd_kernel<true, true, RPB>), dim3((N + RPB - 1) / RPB), dim3(RPB * MIPSF_WAVE), 0, s, raw, z_vals,
                        target_rgb, target_d, to_render_cfg(*cfg), rgb, depth, depth_var, disp, acc, weights, partial, N, S, fin);
@@ -869,10 +1206,14 @@ int mipsf_loss_finalize_sums(const double* sums, const mipsf_render_cfg* cfg, ui
     return check_launch("loss_finalize_sums");
 }
 
-int mipsf_render_bwd(const mipsf_render_bwd_args* a, void* stream) {
-    MIPSF_REQUIRE(a != nullptr, "null argument block");
-    MIPSF_REQUIRE(a->struct_size == sizeof(mipsf_render_bwd_args), "mipsf_render_bwd_args: struct_size %u, this library expects %u",
-                  a->struct_size, (unsigned)sizeof(mipsf_render_bwd_args));
+int mipsf_render_bwd(const mipsf_render_bwd_args* a_in, void* stream) {
+    MIPSF_REQUIRE(a_in != nullptr, "null argument block");
+    MIPSF_REQUIRE(a_in->struct_size == sizeof(mipsf_render_bwd_args) || a_in->struct_size == offsetof(mipsf_render_bwd_args, flags),
+                  "mipsf_render_bwd_args: struct_size %u, this library expects %u", a_in->struct_size,
+                  (unsigned)sizeof(mipsf_render_bwd_args));
+    mipsf_render_bwd_args a_copy = {};
+    memcpy(&a_copy, a_in, a_in->struct_size);
+    const mipsf_render_bwd_args* a = &a_copy;
     const float* raw = a->raw; const float* z_vals = a->z_vals; const float* target_rgb = a->target_rgb; const float* target_d = a->target_d;
     const float* losses = a->losses; const mipsf_render_cfg* cfg = a->cfg; const float* g_losses = a->g_losses;
     const float* g_total = a->g_total; const float* loss_weights = a->loss_weights; const float* g_rgb = a->g_rgb;
@@ -884,9 +1225,12 @@ int mipsf_render_bwd(const mipsf_render_bwd_args* a, void* stream) {
     MIPSF_REQUIRE(g_total == nullptr || loss_weights != nullptr, "g_total needs the loss weights");
     const int train = g_losses != nullptr || g_total != nullptr;
     MIPSF_REQUIRE(!train || (target_rgb && target_d && losses), "training backward needs targets and losses");
+    const int keep_if_unit = (a->flags & MIPSF_RENDER_BWD_KEEP_IF_UNIT) != 0;
+    MIPSF_REQUIRE(!keep_if_unit || (g_total && !g_losses && !g_rgb && !g_depth && N_norm == N),
+                  "KEEP_IF_UNIT: draw holds mipsf_render_fwd's gradient for g_total = 1 -- g_total must be the only gradient");
     hipLaunchKernelGGL(render_bwd_kernel, dim3((N + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK),
                        dim3(RAYS_PER_BLOCK * MIPSF_WAVE), 0, (hipStream_t)stream, raw, z_vals, target_rgb, target_d,
-                       losses, to_render_cfg(*cfg), train, g_losses, g_rgb, g_depth, draw, N, S, g_total, loss_weights, N_norm);
+                       losses, to_render_cfg(*cfg), train, g_losses, g_rgb, g_depth, draw, N, S, g_total, loss_weights, N_norm, keep_if_unit);
     return check_launch("render_bwd");
 }
 

@@ -76,8 +76,12 @@ def backward_from_one(loss, **kw):
     """``loss.backward()`` with the root gradient taken from a cached tensor of ones: autograd otherwise materialises
     ``ones_like(loss)`` with a fill kernel on every call (a 5 us launch in a 140 us tracking iteration; inside a captured
     graph it is replayed every time).  Same computation, same result."""
-    key = (loss.device, loss.dtype, tuple(loss.shape))
-    one = _ONES.get(key)
-    if one is None:
-        one = _ONES[key] = torch.ones_like(loss, requires_grad=False)
+    if loss.is_cuda and loss.dtype == torch.float32 and loss.dim() == 0:
+        from .. import ops
+        one = ops.unit_grad(loss.device)     # (the render backward recognises THIS tensor: its gradient is already written)
+    else:
+        key = (loss.device, loss.dtype, tuple(loss.shape))
+        one = _ONES.get(key)
+        if one is None:
+            one = _ONES[key] = torch.ones_like(loss, requires_grad=False)
     loss.backward(gradient=one, **kw)

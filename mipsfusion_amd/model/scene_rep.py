@@ -13,6 +13,7 @@ reach the grid, the decoder and -- through ``rays_o`` / ``rays_d`` -- the pose p
 import copy
 
 import numpy as np
+import os
 import torch
 import torch.nn as nn
 
@@ -177,18 +178,25 @@ class _QueryFn(torch.autograd.Function):
 
 class _RenderFn(torch.autograd.Function):
     """raw2outputs / sdf2weights (+ the four training losses): scene_rep.py:58-103, 211-236."""
+    fuse_backward = os.environ.get("MIPSF_RENDER_FUSE_BWD", "1") != "0"    # the objective's gradient in the forward launch
 
     @staticmethod
     def forward(ctx, raw, z_vals, target_rgb, target_d, counts, rc, N, S, train, loss_w=None, share_of=None):
         raw = ops._f32c(raw)
         total = None
         ctx.n_norm = None
+        ctx.draw, ctx.draw_stale = None, False
         if train and share_of is not None:   # a share of a ray-data-parallel batch: the losses of the WHOLE batch
             rgb, depth, var, disp, acc, _, losses, total, ctx.n_norm = ops.render_fwd(
                 raw, z_vals, target_rgb, target_d, counts, rc, N, S, train, loss_weights=loss_w, share_of=share_of)
         elif train and loss_w is not None:     # the weighted objective comes out of the loss kernel itself
-            rgb, depth, var, disp, acc, _, losses, total = ops.render_fwd(raw, z_vals, target_rgb, target_d, counts, rc, N,
-                                                                          S, train, loss_weights=loss_w)
+            if ctx.needs_input_grad[0] and S <= ops.RENDER_DRAW_MAX_S and _RenderFn.fuse_backward:
+                # ... and its gradient with it (for an objective gradient of exactly 1: `loss.backward()`)
+                rgb, depth, var, disp, acc, _, losses, total, ctx.draw = ops.render_fwd(
+                    raw, z_vals, target_rgb, target_d, counts, rc, N, S, train, loss_weights=loss_w, want_draw=True)
+            else:
+                rgb, depth, var, disp, acc, _, losses, total = ops.render_fwd(raw, z_vals, target_rgb, target_d, counts, rc, N,
+                                                                              S, train, loss_weights=loss_w)
         else:
             rgb, depth, var, disp, acc, _, losses = ops.render_fwd(raw, z_vals, target_rgb, target_d, counts, rc, N, S,
                                                                    train)
@@ -208,6 +216,14 @@ class _RenderFn(torch.autograd.Function):
         g_rgb = ops._f32c(g_rgb) if g_rgb is not None else None
         g_depth = ops._f32c(g_depth) if g_depth is not None else None
         g_total = ops._f32c(g_total).reshape(1) if (g_total is not None and loss_w is not None) else None
+        if ctx.draw is not None and not ctx.draw_stale and g_total is not None and g_losses is None and g_rgb is None and g_depth is None:
+            # the forward launch has written d objective / d raw for an objective gradient of exactly 1
+            if g_total.data_ptr() == ops.unit_grad(raw.device).data_ptr():
+                return ctx.draw, None, None, None, None, None, None, None, None, None, None     # ... and this IS that gradient
+            ctx.draw_stale = True         # the kernel decides on the device (g_total == 1: returns at once), so after this call
+            draw = ops.render_bwd(raw, z_vals, target_rgb, target_d, counts, losses, ctx.rc, None, None, None, ctx.N, ctx.S,
+                                  g_total=g_total, loss_weights=loss_w, keep_draw=ctx.draw)     # the buffer may hold either
+            return draw, None, None, None, None, None, None, None, None, None, None
         if ctx.train and g_losses is None and g_total is None:
             g_losses = torch.zeros(8, dtype=torch.float32, device=raw.device)
         draw = ops.render_bwd(raw, z_vals, target_rgb, target_d, counts, losses, ctx.rc,

@@ -559,14 +559,34 @@ def _render_fwd_args(raw, z_vals, target_rgb, target_d, counts, rc, rgb, depth, 
                                   weights=dptr(weights))
 
 
+RENDER_DRAW_MAX_S = 128     # mipsf_render_fwd's `draw`: two samples per lane
+
+_UNIT_GRAD = {}
+
+
+def unit_grad(device):
+    """THE root gradient of a plain ``loss.backward()``: one cached fp32 scalar 1.0 per device (helper_functions.utils.
+    backward_from_one passes it).  ``_RenderFn.backward`` recognises it by address -- the gradient of the objective is then known
+    to be exactly 1 on the host, and the gradient the forward launch has already written is returned without a launch."""
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    one = _UNIT_GRAD.get(dev)
+    if one is None:
+        one = _UNIT_GRAD[dev] = torch.ones((), dtype=torch.float32, device=dev)
+    return one
+
+
 def render_fwd(raw, z_vals, target_rgb, target_d, counts, rc, N, S, train: bool, want_weights=False, loss_weights=None,
-               share_of=None):
+               share_of=None, want_draw=False):
     """loss_weights (train only): device tensor of the 4 loss weights -> an 8th return value, the objective
     sum_k w_k * losses[k] formed inside the loss kernel (one float).
     share_of (train only): ``reduce(t)`` -- these N rays are ONE SHARE of a ray-data-parallel batch; ``reduce`` receives the
     share's ten fp64 numbers (the nine loss sums + its ray count) and must return their sums over all shares (an all-reduce
     of 80 bytes); the losses are those of the WHOLE batch, identical on every rank, and a 9th value is returned: the whole
-    batch's ray count (for render_bwd's n_norm)."""
+    batch's ray count (for render_bwd's n_norm).
+    want_draw (train with loss_weights, no share_of, S <= RENDER_DRAW_MAX_S): the same launch also writes d objective / d raw for
+    an objective gradient of exactly 1 -- one more return value, [N, S, 10] (render_bwd(keep_draw=) decides whether it stands)."""
     dev = raw.device
     f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)   # noqa: E731
     rgb, depth, var, disp, acc = f(N, 3), f(N), f(N), f(N), f(N)
@@ -593,24 +613,35 @@ def render_fwd(raw, z_vals, target_rgb, target_d, counts, rc, N, S, train: bool,
     a = _render_fwd_args(raw, z_vals, target_rgb, target_d, counts, rc, rgb, depth, var, disp, acc, weights, N, S)
     a.losses, a.partial, a.ticket = dptr(losses), dptr(partial), dptr(ticket, torch.int32)
     a.loss_weights, a.loss_total = (dptr(loss_weights) if total is not None else None), dptr(total)
+    draw = None
+    if want_draw:
+        if total is None or S > RENDER_DRAW_MAX_S:
+            raise ValueError(f"want_draw needs the training objective (loss_weights) and S <= {RENDER_DRAW_MAX_S}")
+        draw = torch.empty_like(raw)
+        a.draw = dptr(draw)
     with _timed("render_fwd"):
         check(lib().mipsf_render_fwd(C.byref(a), stream_ptr()), "render_fwd")
+    if want_draw:
+        return rgb, depth, var, disp, acc, weights, losses, total, draw
     if loss_weights is not None and train:
         return rgb, depth, var, disp, acc, weights, losses, total
     return rgb, depth, var, disp, acc, weights, losses
 
 
 def render_bwd(raw, z_vals, target_rgb, target_d, counts, losses, rc, g_losses, g_rgb, g_depth, N, S, g_total=None,
-               loss_weights=None, n_norm=None):
+               loss_weights=None, n_norm=None, keep_draw=None):
     """g_total / loss_weights: gradient of render_fwd's objective and its weights (the kernel forms g_total * w itself).
-    n_norm: the ray count the losses were normalised by when these N rays are a share of a larger batch (render_fwd(share_of=))."""
-    draw = torch.empty_like(raw)
+    n_norm: the ray count the losses were normalised by when these N rays are a share of a larger batch (render_fwd(share_of=)).
+    keep_draw: render_fwd(want_draw=True)'s gradient buffer -- it is returned; the kernel leaves it alone when g_total is exactly
+    1 (decided on the device) and rewrites it otherwise.  g_total must then be the only gradient."""
+    draw = torch.empty_like(raw) if keep_draw is None else keep_draw
     a = _lib.RenderBwdArgs.new(N=N, S=S, N_norm=0 if n_norm is None else int(n_norm), raw=dptr(raw), z_vals=dptr(z_vals),
                                target_rgb=dptr(target_rgb), target_d=dptr(target_d),
                                counts=dptr(counts, torch.int32) if counts is not None else None, losses=dptr(losses),
                                cfg=C.pointer(rc), g_losses=dptr(g_losses), g_total=dptr(g_total),
                                loss_weights=dptr(loss_weights) if g_total is not None else None, g_rgb=dptr(g_rgb),
-                               g_depth=dptr(g_depth), draw=dptr(draw))
+                               g_depth=dptr(g_depth), draw=dptr(draw),
+                               flags=_lib.RENDER_BWD_KEEP_IF_UNIT if keep_draw is not None else 0)
     with _timed("render_bwd"):
         check(lib().mipsf_render_bwd(C.byref(a), stream_ptr()), "render_bwd")
     return draw

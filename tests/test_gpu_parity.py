@@ -713,6 +713,95 @@ def test_render_losses_finished_in_the_render_launch(dev):
             l_prev = l1
 
 
+def test_render_backward_written_by_the_forward_launch(dev):
+    """mipsf_render_fwd with `draw` (S <= 128: the ray staged once, the objective's gradient written by the same launch) against
+    the separate kernels: per-ray outputs equal the two-launch forward's bit for bit, `draw` equals mipsf_render_bwd's for
+    g_total = 1 bit for bit (EMD on and off, rays without depth, partly empty workgroups, one and two samples per lane);
+    KEEP_IF_UNIT leaves the buffer alone for g_total = 1 and rewrites it -- bit-equal to the plain backward -- otherwise; through
+    autograd every way of calling backward gives the gradients of the unfused path."""
+    import ctypes as C
+    from mipsfusion_amd._lib import dptr, lib, stream_ptr
+    from mipsfusion_amd.helper_functions.utils import backward_from_one
+    from mipsfusion_amd.model.scene_rep import _RenderFn
+    torch.manual_seed(21)
+    cfg = synth.config_headline()
+    lw = torch.tensor([1.0, 0.1, 1000.0, 10.0], device=dev)
+    one, two = torch.ones(1, device=dev), torch.full((1,), 2.0, device=dev)
+    for S, N, emd in ((16, 17, 0.01), (64, 1000, 0.01), (64, 4096, 0.0), (75, 333, 0.01), (128, 50, 0.01), (100, 16, 0.0)):
+        rc = ops.make_render_cfg(cfg, cfg["mapping"]["bound"], cfg["mapping"]["localMLP_max_len"], S - S // 3, S // 3, emd)
+        raw = torch.randn(N, S, 10, device=dev)
+        raw[..., 3] = torch.linspace(1.0, -1.0, S, device=dev)[None] + 0.1 * torch.randn(N, S, device=dev)
+        raw[..., 5:] = torch.softmax(raw[..., 5:], -1)
+        raw[::5, :, 3] = raw[::5, :, 3].abs()                    # rays without a sign change
+        z = torch.sort(torch.rand(N, S, device=dev) * 4.0 + 0.1, dim=1).values
+        t_rgb, t_d = torch.rand(N, 3, device=dev), torch.rand(N, 1, device=dev) * 4.0
+        t_d[::7] = 0.0
+        counts = torch.randint(0, S, (N, 2), dtype=torch.int32, device=dev)
+        res = ops.render_fwd(raw, z, t_rgb, t_d, counts, rc, N, S, True, want_weights=True, loss_weights=lw, want_draw=True)
+        rgb, depth, var, disp, acc, weights, losses, total, draw = res
+        # the two-launch forward (the component-by-component kernel)
+        f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)      # noqa: E731
+        o2 = [f(N, 3), f(N), f(N), f(N), f(N), f(N, S)]
+        l2, partial, t2 = f(8), f(N * 8), f(1)
+        a = _lib.RenderFwdArgs.new(N=N, S=S, raw=dptr(raw), z_vals=dptr(z), target_rgb=dptr(t_rgb), target_d=dptr(t_d),
+                                   counts=dptr(counts, torch.int32), cfg=C.pointer(rc), rgb=dptr(o2[0]), depth=dptr(o2[1]),
+                                   depth_var=dptr(o2[2]), disp=dptr(o2[3]), acc=dptr(o2[4]), weights=dptr(o2[5]), losses=dptr(l2),
+                                   partial=dptr(partial), loss_weights=dptr(lw), loss_total=dptr(t2))
+        assert lib().mipsf_render_fwd(C.byref(a), stream_ptr()) == 0
+        for x, y in zip((rgb, depth, var, disp, acc, weights), o2):
+            assert torch.equal(x, y), (S, N)
+        np.testing.assert_allclose(losses.cpu().numpy(), l2.cpu().numpy(), rtol=3e-7, equal_nan=True)
+        np.testing.assert_allclose(total.cpu().numpy(), t2.cpu().numpy(), rtol=3e-7, equal_nan=True)
+        # the gradient
+        ref1 = ops.render_bwd(raw, z, t_rgb, t_d, counts, losses, rc, None, None, None, N, S, g_total=one, loss_weights=lw)
+        assert torch.equal(draw, ref1), (S, N, float((draw - ref1).abs().max()))
+        ref2 = ops.render_bwd(raw, z, t_rgb, t_d, counts, losses, rc, None, None, None, N, S, g_total=two, loss_weights=lw)
+        mark = torch.full_like(raw, 7.0)
+        kept = ops.render_bwd(raw, z, t_rgb, t_d, counts, losses, rc, None, None, None, N, S, g_total=one, loss_weights=lw,
+                              keep_draw=mark)
+        assert kept is mark and bool((mark == 7.0).all())
+        again = ops.render_bwd(raw, z, t_rgb, t_d, counts, losses, rc, None, None, None, N, S, g_total=two, loss_weights=lw,
+                               keep_draw=mark)
+        assert torch.equal(again, ref2)
+    with pytest.raises(ValueError):
+        ops.render_fwd(torch.randn(4, 129, 10, device=dev), torch.rand(4, 129, device=dev), torch.rand(4, 3, device=dev),
+                       torch.rand(4, 1, device=dev), torch.zeros(4, 2, dtype=torch.int32, device=dev), rc, 4, 129, True,
+                       loss_weights=lw, want_draw=True)
+
+    # ---- through autograd
+    S, N = 64, 500
+    rc = ops.make_render_cfg(cfg, cfg["mapping"]["bound"], cfg["mapping"]["localMLP_max_len"], 43, 21, 0.01)
+    raw0 = torch.randn(N, S, 10, device=dev)
+    raw0[..., 3] = torch.linspace(1.0, -1.0, S, device=dev)[None] + 0.1 * torch.randn(N, S, device=dev)
+    z = torch.sort(torch.rand(N, S, device=dev) * 4.0 + 0.1, dim=1).values
+    t_rgb, t_d = torch.rand(N, 3, device=dev), torch.rand(N, 1, device=dev) * 4.0
+    counts = torch.randint(0, S, (N, 2), dtype=torch.int32, device=dev)
+
+    def grads(fuse, how):
+        _RenderFn.fuse_backward = fuse
+        try:
+            raw = raw0.clone().requires_grad_(True)
+            res = _RenderFn.apply(raw, z, t_rgb, t_d, counts, rc, N, S, True, lw, None)
+            total, rgb = res[6], res[0]
+            if how == "unit":
+                backward_from_one(total)
+            elif how == "plain":
+                total.backward()
+            elif how == "scaled":
+                (total * 2.0).backward()
+            elif how == "with_rgb":
+                (total + rgb.sum()).backward()
+            elif how == "twice":
+                backward_from_one(total, retain_graph=True)
+                (total * 3.0).backward(retain_graph=True)
+                backward_from_one(total)
+            return raw.grad.clone()
+        finally:
+            _RenderFn.fuse_backward = True
+    for how in ("unit", "plain", "scaled", "with_rgb", "twice"):
+        assert torch.equal(grads(True, how), grads(False, how)), how
+
+
 def test_fused_adam_reset_equals_fresh_optimizer(dev):
     """FusedAdam.reset() (in place, also under capturable=True) must continue exactly like a newly built
     torch.optim.Adam -- the reference rebuilds its pose optimiser every frame (mipsfusion.py:472-475)."""
