@@ -484,13 +484,14 @@ class GraphedSequence:
         if decoder_precision is not None:
             self.model.decoder_precision = decoder_precision
         self.model.accumulate_param_grads_in_place = True
-        # the captured loops run ONE backward per map step and the optimiser kernel clears the gradients (map_accum_step 1,
-        # map_wait_step 0: what every shipped configuration of the reference uses, mipsfusion.py:330-335); gradient
-        # accumulation over several backward passes is not recorded by these graphs -- refuse instead of training wrongly
-        if mp.get("map_accum_step", 1) != 1 or mp.get("map_wait_step", 0) != 0:
-            raise ValueError("GraphedSequence records one backward pass per map step: mapping.map_accum_step must be 1 and "
-                             "mapping.map_wait_step 0 (use the eager loop for accumulated map gradients)")
-        self.model.grid_grad_is_zero_at_backward = True    # every map step is one backward + map_opt.step(zero_grad=True)
+        # map_accum_step 1, map_wait_step 0 is what every shipped configuration of the reference uses (mipsfusion.py:330-335):
+        # the captured loops run ONE backward per map step and the optimiser kernel clears the gradients (the shipped values);
+        # other values are honoured by the BA round's graph (_ba_step_fn: the conditions depend on the iteration number only,
+        # so they are recorded as they fall), and the scatter then ADDS into the table's gradient instead of storing slices
+        if mp.get("map_accum_step", 1) < 1 or mp.get("map_wait_step", 0) < 0:
+            raise ValueError("mapping.map_accum_step must be >= 1 and mapping.map_wait_step >= 0")
+        self.plain_map_steps = mp.get("map_accum_step", 1) == 1 and mp.get("map_wait_step", 0) == 0
+        self.model.grid_grad_is_zero_at_backward = self.plain_map_steps    # every map step is one backward + map_opt.step(zero_grad=True)
         # recover_initial_param() at a switch is a device-to-device copy (the reference's initial_dict sits where the model was built)
         self.model.initial_dict = {k: v.to(dev) for k, v in self.model.initial_dict.items()}
         self.host_rays = [frame_rays(f).pin_memory() for f in frames]        # what a capture thread hands over
@@ -629,11 +630,24 @@ class GraphedSequence:
 
         rows, owner, noise = packed(self.ba_rows, n), packed(self.ba_owner, n), packed(self.ba_noise, n)
 
+        accum, wait = mp.get("map_accum_step", 1), mp.get("map_wait_step", 0)
+
+        def zero_map_grads():
+            gs = [p.grad for p in self.model.parameters() if p.grad is not None]
+            if gs:
+                torch._foreach_zero_(gs)
+
         def step(k):
+            if k == 0 and not self.plain_map_steps:
+                zero_map_grads()                          # mipsfusion.py:285 (what an unfinished accumulation left behind)
             ret = self.model.forward_from_table(self.table, rows[k], self.ba_rot, self.ba_trans, self.fixed, owner[k], noise[k],
                                                 accumulate_in_place=True)
             backward_from_one(get_loss_from_ret(ret, tcfg))
-            self.map_opt.step(zero_grad=True)
+            if (k + 1) % accum == 0:                      # mipsfusion.py:330-335
+                if (k + 1) > wait:
+                    self.map_opt.step(zero_grad=True)
+                else:
+                    zero_map_grads()
             if (k + 1) % mp["pose_accum_step"] == 0:
                 self.ba_popt.step(zero_grad=True)
         return step
