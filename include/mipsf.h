@@ -406,12 +406,7 @@ int mipsf_gather_pose_place_fwd(const float* db, uint64_t n_rows, const int64_t*
                                 float* depth, float* z_vals, float* xn, uint32_t* counts, uint32_t N, void* stream);
 int mipsf_place_pose_bwd(const float* dxn, const float* z_vals, const mipsf_render_cfg* cfg_host, const float* rot, uint32_t F,
                          uint32_t K, const int64_t* owner, const float* d_cam, float* d_rot, float* d_trans, float* scratch,
-                         uint32_t N, uint32_t S, int accumulate, const float* jac, const float* dfeat, uint32_t n_levels,
-                         void* stream);
-/* jac / dfeat (nullable, together; level-major features only, n_levels <= 16): dxn then holds the DECODER's part of the gradient only (what
- * mipsf_decoder_bwd_chain16 wrote) and the hash grid's part -- mipsf_hashgrid_dx_from_jac's sum, in its order -- is formed from the
- * forward's Jacobian [L][3][N*S][2] and the chain's feature gradients [L][N*S][2] inside this launch: same pose gradients bit for
- * bit, mipsf_hashgrid_dx_from_jac is not called and dxn is not rewritten. */
+                         uint32_t N, uint32_t S, int accumulate, void* stream);
 /* dxn [N*S,3] -> d_rays_o [N,3], d_rays_d [N,3] (written) */
 int mipsf_rays_bwd(const float* dxn, const float* z_vals, const mipsf_render_cfg* cfg_host, float* d_rays_o,
                    float* d_rays_d, uint32_t N, uint32_t S, void* stream);

@@ -147,7 +147,7 @@ SIGNATURES = {
     "mipsf_render_bwd": (_I, [C.POINTER(RenderBwdArgs), _P]),
     "mipsf_gather_pose_place_fwd": (_I, [_P, _U64, _P, _P, _P, _P, _U32, _U32, _P, _P, _P, _P, _P, C.POINTER(RenderCfg), _P, _P,
                                          _P, _P, _P, _P, _U32, _P]),
-    "mipsf_place_pose_bwd": (_I, [_P, _P, C.POINTER(RenderCfg), _P, _U32, _U32, _P, _P, _P, _P, _P, _U32, _U32, _I, _P, _P, _U32, _P]),
+    "mipsf_place_pose_bwd": (_I, [_P, _P, C.POINTER(RenderCfg), _P, _U32, _U32, _P, _P, _P, _P, _P, _U32, _U32, _I, _P]),
     "mipsf_rays_bwd": (_I, [_P, _P, C.POINTER(RenderCfg), _P, _P, _U32, _U32, _P]),
     "mipsf_normalise_bwd": (_I, [_P, C.POINTER(RenderCfg), _P, _U32, _P]),
     "mipsf_pose_rays_fwd": (_I, [_P, _U64, _P, _P, _P, _P, _U32, _U32, _P, _P, _P, _P, _P, _P, _U32, _P]),

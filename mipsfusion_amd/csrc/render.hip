@@ -927,18 +927,12 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * MIPSF_WAVE) void rays_bwd_kernel(c
 
 // d(xn) -> pose gradients in ONE launch (rays_bwd_kernel + pose_rays_bwd_kernel: the per-ray {d o, d d} stay in
 // registers).  16 rays per workgroup: 256 tickets for 4096 rays (same-address device atomics retire at ~90 per us).
-// JAC: dxn holds the decoder's part of d loss / d xn only; the hash grid's part -- sum over levels of (d feat / d x)^T d feat,
-// hashgrid_dx_jac_kernel's expression in its order -- is formed here from the forward's Jacobian planes [L][3][M][2] and the
-// chain's feature gradients [L][M][2] and added on the fly: the [M, 3] gradient makes no round trip through memory and the step
-// has one launch less.  A sample whose feature gradients are all zero (the chain's dead tiles) reads no Jacobian.
 constexpr int PPB = 16;
-constexpr uint32_t PPB_MAX_L = 16;      // levels of the in-launch Jacobian product (its operands sit in registers)
-template <bool JAC>
 MIPSF_SINGLE_FP32 __global__ __launch_bounds__(PPB * MIPSF_WAVE) void place_pose_bwd_kernel(
     const float* __restrict__ dxn, const float* __restrict__ z_vals, NormCfg nc, const float* __restrict__ d_cam,
     const int64_t* __restrict__ owner, const float* __restrict__ rot, int F, int K, float* __restrict__ part,
     uint32_t* __restrict__ ticket, float* __restrict__ d_rot, float* __restrict__ d_trans, uint32_t N, uint32_t S,
-    int accumulate, const float2* __restrict__ jac, const float2* __restrict__ dfeat, uint32_t L) {
+    int accumulate) {
     __shared__ float sacc[PR_MAX_POSES * 12];
     __shared__ float wv[PPB][12];
     __shared__ int wp[PPB];
@@ -952,38 +946,7 @@ MIPSF_SINGLE_FP32 __global__ __launch_bounds__(PPB * MIPSF_WAVE) void place_pose
         float so[3] = {0.f, 0.f, 0.f}, sd[3] = {0.f, 0.f, 0.f};
         for (uint32_t k = lane; k < S; k += MIPSF_WAVE) {
             const float z = z_vals[(size_t)n * S + k];
-            const size_t i = (size_t)n * S + k;
-            float g[3] = {dxn[i * 3], dxn[i * 3 + 1], dxn[i * 3 + 2]};
-            if (JAC) {
-                const size_t M = (size_t)N * S;
-                // straight-line loads (levels past L re-read level L - 1 and are not used): all of a phase's loads in flight
-                float2 gy[PPB_MAX_L];
-                uint32_t nz = 0;
-#pragma unroll
-                for (uint32_t l = 0; l < PPB_MAX_L; ++l) gy[l] = dfeat[(size_t)(l < L ? l : L - 1) * M + i];
-#pragma unroll
-                for (uint32_t l = 0; l < PPB_MAX_L; ++l) nz |= (__float_as_uint(gy[l].x) | __float_as_uint(gy[l].y)) << 1;    // (+-0 is zero)
-                if (nz != 0u) {
-                    float a[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-                    for (uint32_t h = 0; h < PPB_MAX_L; h += 8) {
-                        float2 jv[8][3];
-#pragma unroll
-                        for (uint32_t q = 0; q < 8; ++q)
-#pragma unroll
-                            for (int d = 0; d < 3; ++d) jv[q][d] = jac[((size_t)(h + q < L ? h + q : L - 1) * 3 + d) * M + i];
-#pragma unroll
-                        for (uint32_t q = 0; q < 8; ++q) {
-                            if (h + q < L) {
-#pragma unroll
-                                for (int d = 0; d < 3; ++d) a[d] += jv[q][d].x * gy[h + q].x + jv[q][d].y * gy[h + q].y;
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) g[d] += a[d];
-                }
-            }
+            const float* g = dxn + ((size_t)n * S + k) * 3;
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 const float gp = (float)(((double)g[d] / nc.norm_factor) / nc.div[d]);
@@ -1101,24 +1064,15 @@ extern "C" {
 
 int mipsf_place_pose_bwd(const float* dxn, const float* z_vals, const mipsf_render_cfg* cfg, const float* rot, uint32_t F,
                          uint32_t K, const int64_t* owner, const float* d_cam, float* d_rot, float* d_trans, float* scratch,
-                         uint32_t N, uint32_t S, int accumulate, const float* jac, const float* dfeat, uint32_t n_levels,
-                         void* stream) {
+                         uint32_t N, uint32_t S, int accumulate, void* stream) {
     MIPSF_REQUIRE(K >= 1, "no optimisable pose");
     MIPSF_REQUIRE(cfg && dxn && z_vals && rot && owner && d_cam && d_rot && d_trans && scratch, "null pointer");
     MIPSF_REQUIRE(F + K <= (uint32_t)PR_MAX_POSES, "number of poses %u above %d", F + K, PR_MAX_POSES);
     if (N == 0) return 0;
     // scratch[0] = ticket (zero on entry, zero again on return), then one row of partials per workgroup
-    MIPSF_REQUIRE((jac == nullptr) == (dfeat == nullptr), "jac and dfeat come together");
-    MIPSF_REQUIRE(jac == nullptr || (n_levels >= 1 && n_levels <= PPB_MAX_L), "jac: n_levels %u outside [1,%u]", n_levels, PPB_MAX_L);
-    if (jac)
-        hipLaunchKernelGGL(place_pose_bwd_kernel<true>, dim3((N + PPB - 1) / PPB), dim3(PPB * MIPSF_WAVE), 0, (hipStream_t)stream,
-                           dxn, z_vals, make_norm(*cfg), d_cam, owner, rot, (int)F, (int)K, scratch + 1,
-                           reinterpret_cast<uint32_t*>(scratch), d_rot, d_trans, N, S, accumulate,
-                           reinterpret_cast<const float2*>(jac), reinterpret_cast<const float2*>(dfeat), n_levels);
-    else
-        hipLaunchKernelGGL(place_pose_bwd_kernel<false>, dim3((N + PPB - 1) / PPB), dim3(PPB * MIPSF_WAVE), 0, (hipStream_t)stream,
-                           dxn, z_vals, make_norm(*cfg), d_cam, owner, rot, (int)F, (int)K, scratch + 1,
-                           reinterpret_cast<uint32_t*>(scratch), d_rot, d_trans, N, S, accumulate, nullptr, nullptr, 0u);
+    hipLaunchKernelGGL(place_pose_bwd_kernel, dim3((N + PPB - 1) / PPB), dim3(PPB * MIPSF_WAVE), 0, (hipStream_t)stream, dxn,
+                       z_vals, make_norm(*cfg), d_cam, owner, rot, (int)F, (int)K, scratch + 1,
+                       reinterpret_cast<uint32_t*>(scratch), d_rot, d_trans, N, S, accumulate);
     return check_launch("place_pose_bwd");
 }
 

@@ -124,10 +124,6 @@ class _QueryFn(torch.autograd.Function):
             torch.cuda.current_stream(xn.device).wait_event(routed[1])
         ctx.routed = routed
         ctx.owner, ctx.M, ctx.meta, ctx.has_jac = owner, M, meta, jac is not None
-        # forward_from_table: the points come from the placement kernel and go nowhere else -- its backward completes their
-        # gradient with the grid's part itself (ops.defer_dx)
-        ctx.defer_dx = bool(owner._dx_sink_next and jac is not None and meta.n_levels <= ops.DEFER_DX_MAX_LEVELS and M >= ops.DEFER_DX_MIN_M)
-        owner._dx_sink_next = False
         ctx.save_for_backward(xn, feat, out, saved, packed, grid_params, *weights, *([jac] if jac is not None else []))
         return out
 
@@ -172,9 +168,7 @@ class _QueryFn(torch.autograd.Function):
             ops.hashgrid_bwd(xn, grid_params.detach(), dfeat, dparams, ctx.meta, FEAT_LEVEL_MAJOR, None, routed=ctx.routed,
                              dparams_zero=(not direct) or fresh_grad or ctx.owner.grid_grad_is_zero_at_backward)
             ctx.routed = None
-        if need_x and ctx.defer_dx:
-            ops.defer_dx(dx, jac, dfeat, ctx.meta.n_levels)
-        elif need_x:
+        if need_x:
             ops.hashgrid_dx_from_jac(jac, dfeat, dx, ctx.meta, FEAT_LEVEL_MAJOR, tiles=tiles)   # (dfeat is untouched since the chain wrote it)
         w_out = [None] * len(weights)
         if need_w and not direct:
@@ -275,10 +269,6 @@ class JointEncoding(nn.Module):
         # beside the persistent decoder forward, take 211 us instead of 70 and slow that kernel from 99 to 137 us -- the
         # step gets 40 us LONGER (0.88 -> 0.92 ms).  It pays only where the forward leaves CUs idle.
         self.route_ahead = False
-        # forward_from_table: the hash grid's part of the points' gradient is formed inside the placement's backward launch
-        # (mipsf_place_pose_bwd with the Jacobian) instead of a launch of its own + a round trip of the [M, 3] gradient
-        self.defer_grid_dx = os.environ.get("MIPSF_DEFER_GRID_DX", "1") != "0"
-        self._dx_sink_next = False
         # ray-data-parallel training (mipsfusion_amd/ray_dp.py sets it): the rays handed to forward() are ONE SHARE of the
         # iteration's batch; the callable sums a small fp64 vector over the ranks, the losses (and their gradients) are then
         # those of the WHOLE batch -- fs_weight / sdf_weight from the batch's counts (helper_functions/utils.py:43-47), the
@@ -366,7 +356,6 @@ class JointEncoding(nn.Module):
         new.wgrad_precision = self.wgrad_precision
         new.lean_record = self.lean_record
         new.route_ahead = self.route_ahead
-        new.defer_grid_dx = self.defer_grid_dx
         new._frozen_pack = None
         new.train(self.training)
         return new
@@ -518,9 +507,7 @@ class JointEncoding(nn.Module):
         trgb, td, z_vals, xn, counts = ops.GatherPosePlaceFn.apply(rot, trans, fixed_poses, owner, table, rows,
                                                                    ops._f32c(noise) if rc.perturb else None, tables, rc, S,
                                                                    accumulate_in_place)
-        self._dx_sink_next = self.defer_grid_dx        # (consumed by the _QueryFn.forward this call reaches next)
         raw = self._query(xn)
-        self._dx_sink_next = False
         res = _RenderFn.apply(raw, z_vals, trgb, td, counts, rc, N, S, True, self._objective_weights(raw.device),
                               self.ray_share_reduce)
         rgb, depth, losses = res[0], res[1], res[5]

@@ -767,23 +767,6 @@ def gather_pose_rays(table, rows, rot, trans, fixed_poses, owner, accumulate_in_
     return PoseRaysFn.apply(rot, trans, fixed_poses, owner, None, accumulate_in_place, table, rows.to(torch.int64).contiguous())
 
 
-# The hash grid's part of d loss / d xn, handed from _QueryFn.backward to the placement's backward WITHOUT being formed: the
-# gradient tensor that travels through autograd holds the decoder's part only, and this table says -- by its address -- which
-# Jacobian and feature gradients complete it (mipsf_place_pose_bwd forms the product inside its launch).  Only used where the
-# points have ONE producer and ONE consumer that both know about it (JointEncoding.forward_from_table).
-DEFERRED_DX = {}
-DEFER_DX_MAX_LEVELS = 16
-# measured (tools/replay.py, one box): 262 144 samples 16.8 + 14.8 -> 28.6 us; a tracking iteration's 75 000 samples are two
-# launch-bound kernels either way and the ray-shaped kernel (one wave per ray, 63 workgroups) is no faster than they are
-DEFER_DX_MIN_M = 1 << 17
-
-
-def defer_dx(dx, jac, dfeat, n_levels):
-    if len(DEFERRED_DX) > 8:        # (backwards whose placement half never ran)
-        DEFERRED_DX.clear()
-    DEFERRED_DX[dx.data_ptr()] = (jac, dfeat, n_levels, dx)
-
-
 class GatherPosePlaceFn(torch.autograd.Function):
     """Row gather of the ray table + rays from the pose Parameters + sample placement (``gather_pose_rays`` followed by
     ``JointEncoding``'s placement: keyframeSet.py:264-290, mipsfusion.py:320-322, scene_rep.py:156-179) as ONE launch
@@ -836,15 +819,10 @@ class GatherPosePlaceFn(torch.autograd.Function):
         else:
             d_rot = torch.empty((ctx.K, 4), dtype=torch.float32, device=rot.device)
             d_trans = torch.empty((ctx.K, 3), dtype=torch.float32, device=rot.device)
-        jac, dfeat, n_levels, _keep = DEFERRED_DX.pop(dxn.data_ptr(), (None, None, 0, None))
-        dxn = _f32c(dxn)
-        if jac is not None and _keep.data_ptr() != dxn.data_ptr():
-            raise RuntimeError("deferred grid gradient: the gradient of the points was copied on its way")
         with _timed("rays_bwd"):
-            check(lib().mipsf_place_pose_bwd(dptr(dxn), dptr(z_vals), C.byref(ctx.rc), dptr(rot), ctx.F, ctx.K,
+            check(lib().mipsf_place_pose_bwd(dptr(_f32c(dxn)), dptr(z_vals), C.byref(ctx.rc), dptr(rot), ctx.F, ctx.K,
                                              dptr(owner, torch.int64), dptr(d_cam), dptr(d_rot), dptr(d_trans), dptr(scratch),
-                                             ctx.N, ctx.S, 1 if direct else 0, dptr(jac), dptr(dfeat), n_levels, stream_ptr()),
-                  "place_pose_bwd")
+                                             ctx.N, ctx.S, 1 if direct else 0, stream_ptr()), "place_pose_bwd")
         if direct:
             return (None,) * 11
         return (d_rot, d_trans) + (None,) * 9

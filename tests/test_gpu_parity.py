@@ -966,73 +966,6 @@ def test_forward_from_table_equals_gather_then_forward(dev):
     assert_close(trans.grad, 2 * gtb, 2e-5, "d translation accumulated in place twice")
 
 
-def test_grid_part_of_the_point_gradient_formed_inside_the_placement_backward(dev):
-    """forward_from_table with JointEncoding.defer_grid_dx (the hash grid's part of d loss / d xn is formed from the Jacobian
-    inside mipsf_place_pose_bwd; mipsf_hashgrid_dx_from_jac is not launched) against the same call without it: pose gradients bit
-    for bit -- map trained a little so that dead tiles exist, S = 64 and 75, frozen and trainable map, in-place accumulation --
-    and nothing else moves."""
-    from mipsfusion_amd.helper_functions.utils import backward_from_one, get_loss_from_ret
-    torch.manual_seed(8)
-    for n_d, n_r in ((43, 21), (50, 25)):
-        cfg = synth.config_headline()
-        cfg["grid"]["hash_size"] = 15
-        cfg["training"]["n_samples_d"], cfg["training"]["n_range_d"] = n_d, n_r
-        bb = torch.from_numpy(np.array(cfg["mapping"]["bound"]))
-        nf = torch.from_numpy(np.array(cfg["mapping"]["localMLP_max_len"]))
-        m = JointEncoding(cfg, bb, nf).to(dev).train()
-        frame = synth.make_frame(cfg, seed=6)
-        table = torch.cat([frame["direction"], frame["rgb"], frame["depth"][..., None]], -1).reshape(-1, 7)[:60000].contiguous().to(dev)
-        S, F, K = n_d + n_r, 1, 3
-        c2w = synth.default_pose(cfg)
-        fixed = c2w[None].to(dev)
-        rot0 = gh_quat(c2w[:3, :3])[None].repeat(K, 1).to(dev) + 0.01 * torch.randn(K, 4, device=dev)
-        trans0 = c2w[None, :3, 3].repeat(K, 1).to(dev) + 0.02 * torch.randn(K, 3, device=dev)
-        opt = torch.optim.Adam(m.parameters(), lr=5e-3)
-        N = 777
-        rows = torch.randint(0, 60000, (N,), device=dev)
-        owner = torch.randint(0, F + K, (N,), device=dev)
-        noise = torch.rand(N, S, device=dev)
-        for _ in range(30):                         # a little training: free space gets zero-gradient tiles
-            opt.zero_grad(set_to_none=True)
-            get_loss_from_ret(m.forward_from_table(table, rows, rot0, trans0, fixed, owner, noise), cfg["training"]).backward()
-            opt.step()
-        launches = {"dx": 0}
-        orig, min_m = ops.hashgrid_dx_from_jac, ops.DEFER_DX_MIN_M
-        ops.DEFER_DX_MIN_M = 0                       # (the product defers from 2^17 samples on)
-
-        def counted(*a, **k):
-            launches["dx"] += 1
-            return orig(*a, **k)
-        ops.hashgrid_dx_from_jac = counted
-        try:
-            for frozen in (False, True):
-                for p_ in m.parameters():
-                    p_.requires_grad_(not frozen)
-                res = {}
-                for defer in (False, True):
-                    m.defer_grid_dx = defer
-                    launches["dx"] = 0
-                    rot, trans = rot0.clone().requires_grad_(True), trans0.clone().requires_grad_(True)
-                    m.zero_grad(set_to_none=True)
-                    for rep in range(2):
-                        loss = get_loss_from_ret(m.forward_from_table(table, rows, rot, trans, fixed, owner, noise,
-                                                                      accumulate_in_place=True), cfg["training"])
-                        backward_from_one(loss)
-                    assert launches["dx"] == (0 if defer else 2)
-                    res[defer] = (loss.detach().clone(), rot.grad.clone(), trans.grad.clone(),
-                                  None if frozen else m.embed_fn.params.grad.clone())
-                assert torch.equal(res[True][0], res[False][0])
-                assert float(res[False][1].abs().max()) > 0
-                assert torch.equal(res[True][1], res[False][1]), (S, frozen, float((res[True][1] - res[False][1]).abs().max()))
-                assert torch.equal(res[True][2], res[False][2]), (S, frozen)
-                if not frozen:
-                    assert_close(res[True][3], res[False][3], 1e-6, "grid gradient")
-        finally:
-            ops.hashgrid_dx_from_jac, ops.DEFER_DX_MIN_M = orig, min_m
-            m.defer_grid_dx = True
-        assert not ops.DEFERRED_DX
-
-
 def gh_quat(R):
     from mipsfusion_amd.helper_functions.geometry_helper import matrix_to_quaternion
     return matrix_to_quaternion(R[None])[0]
