@@ -120,6 +120,19 @@ __device__ __forceinline__ void pack_T(const f32x16& T, typename A::v8 (&op)[2])
 // For the accumulator images (pieces g = 2q + (u >> 2), element u & 3) that is column = feature - 32 * row tile.
 // NQ = 1: only vals[0] is non-zero (the small rows), placed at columns 16 q0 + ...   SUM: rowsum += this lane's 16
 // samples of the block (bias gradients; plane by plane, each plane's sum is exact to fp32 rounding).  vals is consumed.
+#ifdef W16_ABL_FREE_CUT     // ablation (wrong results): the 16-bit planes of a block cost nothing -- what a record that arrives as
+// ready operand planes would save, as an upper bound (the recomputed blocks' cuts are free here as well)
+template <typename A>
+__device__ __forceinline__ typename A::v8 abl_plane(const f32x8& r, int p) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const int o = (2 * p) & 4;
+    const u4 w = {__float_as_uint(r[o]), __float_as_uint(r[o + 1]), __float_as_uint(r[o + 2]), __float_as_uint(r[o + 3])};
+    return __builtin_bit_cast(typename A::v8, w);
+}
+#define W16_PLANE(A, LASTP, V, P) abl_plane<A>(V, P)
+#else
+#define W16_PLANE(A, LASTP, V, P) ((LASTP) ? next_plane<A, true>(V) : next_plane<A, false>(V))
+#endif
 template <typename A, bool SUM, int NQ = 2>
 __device__ __forceinline__ void transpose_block(f32x8 (&vals)[2], const typename A::v8 (&I)[2],
                                                 typename A::v8 (&ops)[A::P][2], float& rowsum, int q0 = 0) {
@@ -132,8 +145,8 @@ __device__ __forceinline__ void transpose_block(f32x8 (&vals)[2], const typename
     float s = 0.f;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        f32x16 T = mfma16(p == P - 1 ? next_plane<A, true>(vals[0]) : next_plane<A, false>(vals[0]), I[q0], zero);
-        if (NQ == 2) T = mfma16(p == P - 1 ? next_plane<A, true>(vals[1]) : next_plane<A, false>(vals[1]), I[1], T);
+        f32x16 T = mfma16(W16_PLANE(A, p == P - 1, vals[0], p), I[q0], zero);
+        if (NQ == 2) T = mfma16(W16_PLANE(A, p == P - 1, vals[1], p), I[1], T);
         pack_T<A>(T, ops[p]);
         if (SUM) {
             float sp = 0.f;
@@ -160,8 +173,8 @@ __device__ __forceinline__ void transpose_mac(f32x8 (&vals)[2], const typename A
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int pb = 0; pb < P; ++pb) {
-        f32x16 T = mfma16(pb == P - 1 ? next_plane<A, true>(vals[0]) : next_plane<A, false>(vals[0]), I[0], zero);
-        T = mfma16(pb == P - 1 ? next_plane<A, true>(vals[1]) : next_plane<A, false>(vals[1]), I[1], T);
+        f32x16 T = mfma16(W16_PLANE(A, pb == P - 1, vals[0], pb), I[0], zero);
+        T = mfma16(W16_PLANE(A, pb == P - 1, vals[1], pb), I[1], T);
         typename A::v8 Y[2];
         pack_T<A>(T, Y);
         if (pb + 1 < P) W16_PIN4(vals[0], vals[1], Y[0], Y[1]);
@@ -192,6 +205,13 @@ __device__ __forceinline__ void load_tile_rows(srd_t rec, int mat, int rt, uint3
         vals[g >> 1][4 * (g & 1) + 0] = v.x, vals[g >> 1][4 * (g & 1) + 1] = v.y;
         vals[g >> 1][4 * (g & 1) + 2] = v.z, vals[g >> 1][4 * (g & 1) + 3] = v.w;
     }
+#ifdef W16_ABL_MORE_BYTES   // ablation: two more 16-byte pieces per lane (a record of three bf16 planes is 96 bytes where fp32 is 64)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const float4 v = buf_load16_aux<W16_LOAD_AUX>(rec, lane16, (uint32_t)(mat * 16 + ((rt + 1) & 3) * 4 + g) * 1024u);
+        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+    }
+#endif
 }
 
 __device__ __forceinline__ void zero_tile(f32x16& a) {
