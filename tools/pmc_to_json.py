@@ -23,7 +23,7 @@ groups = {"hashgrid_fwd": ["hashgrid_fwd_kernel"],
           "decoder_fwd": ["decoder_fwd_kernel", "decoder_fwd_lds_kernel", "decoder16_fwd_kernel", "decoder16_fwd_lds_kernel"],
           "decoder_bwd_chain": ["decoder_bwd_lds_kernel", "decoder16_bwd_kernel", "decoder16_bwd_lds_kernel"],
           "decoder_wgrad": ["decoder_wgrad_kernel", "decoder_wgrad16_kernel", "decoder_wgrad_reduce_kernel"],
-          "adam_step": ["adam_kernel", "adam_all_kernel"], "sample_rays": ["sample_rays_kernel"], "render_fwd": ["render_fwd_kernel", "loss_finalize_kernel"],
+          "adam_step": ["adam_kernel", "adam_all_kernel"], "sample_rays": ["sample_rays_kernel"], "render_fwd": ["render_fwd_kernel", "render_train_kernel", "loss_finalize_kernel"],
           "render_bwd": ["render_bwd_kernel"], "rays_bwd": ["rays_bwd_kernel"]}
 # FETCH_SIZE on gfx950 reports HALF the bytes of a 16-byte-per-lane streaming read (MI355X_MICROARCH.md, HBM section;
 # calibrated here by adam_kernel: 72 MB reported for 144 MB of p/g/m/v reads).  Kernels whose reads are such streams get
