@@ -763,6 +763,26 @@ def test_render_backward_written_by_the_forward_launch(dev):
         again = ops.render_bwd(raw, z, t_rgb, t_d, counts, losses, rc, None, None, None, N, S, g_total=two, loss_weights=lw,
                                keep_draw=mark)
         assert torch.equal(again, ref2)
+    # edges: one and two samples per ray, one ray, and a batch without a single valid depth (depth_loss = 0 / 0, fs / sdf weights
+    # from zero counts: NaN where the separate kernels have NaN, bit for bit)
+    same = lambda a_, b_: torch.equal(a_.view(torch.int32), b_.view(torch.int32))      # noqa: E731
+    for S, N, no_depth in ((1, 5, False), (2, 1, False), (64, 33, True), (75, 16, True)):
+        rc = ops.make_render_cfg(cfg, cfg["mapping"]["bound"], cfg["mapping"]["localMLP_max_len"], S, 0, 0.01)
+        raw = torch.randn(N, S, 10, device=dev)
+        z = torch.sort(torch.rand(N, S, device=dev) * 4.0 + 0.1, dim=1).values
+        t_rgb = torch.rand(N, 3, device=dev)
+        t_d = torch.zeros(N, 1, device=dev) if no_depth else torch.rand(N, 1, device=dev) * 4.0
+        counts = torch.zeros(N, 2, dtype=torch.int32, device=dev) if no_depth else torch.randint(0, S + 1, (N, 2), dtype=torch.int32, device=dev)
+        res = ops.render_fwd(raw, z, t_rgb, t_d, counts, rc, N, S, True, loss_weights=lw, want_draw=True)
+        losses, draw = res[6], res[8]
+        ref = ops.render_bwd(raw, z, t_rgb, t_d, counts, losses, rc, None, None, None, N, S, g_total=one, loss_weights=lw)
+        assert same(draw, ref), (S, N, no_depth)
+        if no_depth:
+            assert bool(torch.isnan(losses[1]))
+        nan = torch.full((1,), float("nan"), device=dev)
+        again = ops.render_bwd(raw, z, t_rgb, t_d, counts, losses, rc, None, None, None, N, S, g_total=nan, loss_weights=lw,
+                               keep_draw=draw.clone())
+        assert same(again, ops.render_bwd(raw, z, t_rgb, t_d, counts, losses, rc, None, None, None, N, S, g_total=nan, loss_weights=lw))
     with pytest.raises(ValueError):
         ops.render_fwd(torch.randn(4, 129, 10, device=dev), torch.rand(4, 129, device=dev), torch.rand(4, 3, device=dev),
                        torch.rand(4, 1, device=dev), torch.zeros(4, 2, dtype=torch.int32, device=dev), rc, 4, 129, True,
