@@ -182,7 +182,7 @@ def test_graphed_sequence_switches_submaps_and_captures_without_training():
             assert torch.equal(x, y), "capturing the graphs of the sequence changed the map optimiser's moments"
         assert float(seq.ba_rot.detach()[:, 0].min()) == 1.0 and float(seq.ba_trans.detach().abs().max()) == 0.0
         # ---- ("new",)
-        seq.cur.copy_(seq.host_rays[10])
+        seq._upload_frame(10)
         seq.n_kf = 2                                    # slots 0, 1 are taken when frame 10 arrives (kf_every 5)
         seq.submaps[0]["kfs"] = [0, 1]
         seq._switch_new(gt[10].float())
@@ -198,7 +198,7 @@ def test_graphed_sequence_switches_submaps_and_captures_without_training():
         big = max(range(len(a)), key=lambda i: a[i].numel())                 # the hash grid
         assert not torch.equal(a[big], b[big]), "the new sub-map still holds the old parameters"
         # ---- ("back", 0)
-        seq.cur.copy_(seq.host_rays[25])
+        seq._upload_frame(25)
         pose = seq._switch_back(0, gt[25].float(), lambda f: f())
         torch.cuda.synchronize()
         for x, y in zip(b, seq.submaps[1]["state"]):
