@@ -14,7 +14,7 @@ dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
 cfg = synth.config_headline()
 model, frames, poses = bench.build_submap(cfg, dev, seed=0)
-M = 262144
+M = int(os.environ.get("MIPSF_PROBE_M", "262144"))
 PREC = os.environ.get("MIPSF_PROBE_PREC", "bf16x6")
 packed16 = ops.decoder_pack16(model.decoder.ordered_parameters(), precision=PREC)
 x = torch.rand(M, 3, device=dev)
@@ -25,7 +25,7 @@ from mipsfusion_amd import _lib
 PHASES = ["e (sin)", "layer 1", "relu 1 + masks", "layer 2 (+H1 stores)", "unscale 2 + grid loads", "rgb head", "rgb_emb stores",
           "layer 3 (+H2 stores)", "relu 3 + H3 stores + masks", "sdf head", "softmax + out"]
 tracer = getattr(C.CDLL(_lib.LIB_PATH), "mipsf_d16_trace_read", None) if os.environ.get("MIPSF_LIB") else None
-for save in (False, "lean"):
+for save in (False, "lean", "masks"):
     fn = lambda: ops.decoder_fwd(None, feat, FEAT_LEVEL_MAJOR, x, None, M, save=save, precision=PREC, packed16=packed16)   # noqa: E731
     for _ in range(3):
         fn()
