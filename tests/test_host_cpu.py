@@ -62,6 +62,13 @@ def test_size_queries_and_failed_calls_reset_the_kept_blocks():
         blk.struct_size -= 4
         assert fn(C.byref(blk), None) != 0 and b"struct_size" in lib.mipsf_last_error()
         assert fn(None, None) != 0
+    # ... but the two render blocks are also taken in their first form (struct_size up to the field before `draw` / `flags`, added
+    # later in this ABI version): an empty batch is accepted without touching a device
+    for cls, fn, field in ((_lib.RenderFwdArgs, lib.mipsf_render_fwd, "draw"), (_lib.RenderBwdArgs, lib.mipsf_render_bwd, "flags")):
+        blk = cls.new()
+        assert fn(C.byref(blk), None) == 0
+        blk.struct_size = getattr(cls, field).offset
+        assert fn(C.byref(blk), None) == 0, lib.mipsf_last_error()
     from mipsfusion_amd import ops
     ops._ZEROED[("probe",)] = object()
     with pytest.raises(RuntimeError):
