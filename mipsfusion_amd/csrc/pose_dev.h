@@ -70,6 +70,9 @@ template <int T>
 __device__ __forceinline__ void pose_block_finish(float* sacc, bool* is_last, int P, int F, int K, float* __restrict__ part,
                                                   uint32_t* __restrict__ ticket, const float* __restrict__ rot,
                                                   float* __restrict__ d_rot, float* __restrict__ d_trans, bool accumulate) {
+#ifdef RT_ABL_NO_TAIL
+    return;
+#endif
     __syncthreads();
     for (int q = threadIdx.x; q < P * 12; q += T)
         __hip_atomic_store(&part[(size_t)blockIdx.x * (P * 12) + q], sacc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

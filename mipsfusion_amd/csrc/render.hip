@@ -315,6 +315,9 @@ __device__ __forceinline__ void render_fwd_ray(
 template <int RPB>
 __device__ __forceinline__ void render_fused_tail(const float (&row)[7], uint32_t n, uint32_t w, uint32_t lane, uint32_t N, uint32_t S,
                                                   const RenderCfg& rc, float* __restrict__ partial, const LossFinalize& fin) {
+#ifdef RT_ABL_NO_TAIL      // ablation (no losses): what the hand-off costs
+    return;
+#endif
     __shared__ bool is_last;
     __shared__ double red[RPB][9];
     if (lane == 0) {
