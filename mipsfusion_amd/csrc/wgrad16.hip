@@ -1353,8 +1353,626 @@ __device__ __forceinline__ void w16x_role_b(const W16Args& a, const W16X<A>& lx,
     if (h == 0) rec[G_B_SDF0 + 32 * rt + j] = b3, rec[G_B_PTS0 + 32 * rt + j] = b1;
 }
 
+
+// ============================================================ the TRANSPOSE-READ form (round 6): the exchange form without
+// matrix-core transposes.  What round 2 gave to the matrix pipe -- T = X I, 2 MFMAs + 16 converts back to 16 bits per plane of
+// a 32 x 32 block: 162 of the exchange form's 830 MFMAs per tile -- is what gfx950's LDS does on the way out:
+// ds_read_b64_tr_b16 hands lane i of a 16-lane group element (i & 3) of the four 8-byte chunks that lanes 4 k + (i >> 2) of
+// the group address, k = 0..3 (tools/micro/tr_probe.hip checks the mapping on the device).  A block is cut into its 16-bit
+// planes in the records' LOAD layout (lane = sample, 16 features per lane as four chunks of four consecutive features), every
+// plane is written to LDS as it is cut (2 x ds_write_b128 per lane) and read back as the MFMA operand: lane = feature, 8
+// consecutive samples per lane = two transpose reads of 4 samples each.
+//   plane of a block (2 KB): row = sample (64 B), four 16-byte slots; the lane (j, h) of the load layout owns slots
+//       (2 q + h) ^ sw(j), q = 0, 1 (features 16 q + 4 h + {0..3} and 16 q + 8 + 4 h + {0..3}: the two chunks of a slot),
+//       sw(j) = bit 1 of j | (bit 2 ^ bit 3 of j) << 1:  the 8 lanes of a ds_write_b128 group hit 8 different bank quads, the
+//       32 lanes of a transpose read cover 4 whole rows (32-wide operand) or complementary halves of 8 rows (16-wide operand)
+//       = all 64 banks once.
+// The small-row products (d w_sdf2: 5 rows, d w_rgb0: 3 rows; 96 MFMAs of 32 x 32 x 16 + 60 transposing ones per tile in the
+// exchange form, for 0.7 % of the arithmetic) run on v_mfma_f32_16x16x32: its k = 32 is the whole tile's samples, 16 output
+// rows hold the 8 small rows, and a product is one instruction of half the cycles per 16 columns.
+// Bias gradients: d b_pts0 and the small rows' are columns of products that exist anyway (the e operand carries constant
+// ones against the layer-1 bias pieces: column 18 of its second column tile); d b_pts2 / d b_sdf0 are per-lane sums in the
+// load layout, reduced across lanes once per launch.
+// Per tile: 4 x (24 + 48 + 24 half-size [+ 6]) + 4 x (60 [+ 6] [+ 12]) = 684 MFMA instructions (830), 612 in 32 x 32 units.
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define W16_LDS(T, addr) ((__attribute__((address_space(3))) T*)(addr))
+
+__device__ __forceinline__ f32x4 mfma16s(bf8 a, bf8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16s(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ uint32_t w16t_lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+// two transpose reads = one 8-element operand (whole-vector bit casts only: an element-wise __builtin_bit_cast of the
+// result's elements compiled to element 0 four times, tools/micro/tr_probe.hip)
+template <typename A>
+__device__ __forceinline__ typename A::v8 w16t_tr2(uint32_t a0, uint32_t a1) {
+    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(W16_LDS(s4v, a0));
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(W16_LDS(s4v, a1));
+    return __builtin_bit_cast(typename A::v8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+template <typename A>
+__device__ __forceinline__ void w16t_st(uint32_t addr, const typename A::v8& v) { *W16_LDS(typename A::v8, addr) = v; }
+template <typename A>
+__device__ __forceinline__ typename A::v8 w16t_ld(uint32_t addr) { return *W16_LDS(typename A::v8, addr); }
+
+constexpr uint32_t W16T_PLANE = 2048;       // bytes of one 16-bit plane of a 32 x 32 block
+
+// this lane's byte offsets inside a plane
+struct W16TAddr {
+    uint32_t wr0, wr1;      // its two slots (q = 0, 1)
+    uint32_t rd0, rd1;      // 32-wide operand (v_mfma_32x32x16: lane = feature l & 31, half l >> 5): the two transpose reads of
+                            //   k-step 0; k-step 1 at + 1024
+    uint32_t rsa, rsb;      // 16-wide operand (v_mfma_16x16x32: lane = feature 16 cg + (l & 15), k group l >> 4): read r of
+                            //   column group cg at (cg ^ r ? rsb : rsa) + 512 r
+    uint32_t ry;            // 16-wide operand out of READY 32-wide operand planes ([k-step m][64 lanes] x 16 B): column group cg of
+                            //   plane entry e0 (its k-step 0) at (e0 * 64 + 16 cg) * 16 + ry
+};
+__device__ __forceinline__ W16TAddr w16t_addr(int lane) {
+    W16TAddr ad;
+    const uint32_t j = lane & 31, h = lane >> 5;
+    const uint32_t sw = ((j >> 1) & 1u) | ((((j >> 2) ^ (j >> 3)) & 1u) << 1);
+    ad.wr0 = j * 64u + ((h ^ sw) * 16u);
+    ad.wr1 = j * 64u + (((2u + h) ^ sw) * 16u);
+    const uint32_t g = lane >> 4, ii = lane & 15, hh = ii & 1u, aa = (ii >> 1) & 1u, s1 = (ii >> 3) & 1u;
+    // Which sample is element u of an operand: the READY planes (H1 out of its product, the e column tiles out of pack_T) hold the
+    // accumulator rows of a 32 x 32 tile, k-step m, half kg, element u = sample 16 m + 8 (u >> 2) + 4 kg + (u & 3); the transpose
+    // reads follow that order (read r = u >> 2 fetches rows 8 r + 4 kg + {0..3}), a product pairs the same samples on both sides.
+    {   // 32-wide: q = g & 1, kg = g >> 1; row 16 m + 8 r + 4 kg + (ii >> 2), slot 2 (q ^ r ^ kg) + (hh ^ s1)
+        const uint32_t q = g & 1u, kg = g >> 1;
+        const uint32_t row0 = 4u * kg + (ii >> 2), lo = (hh ^ s1) * 16u + 8u * aa;
+        ad.rd0 = row0 * 64u + 32u * (q ^ kg) + lo;
+        ad.rd1 = (row0 + 8u) * 64u + 32u * (q ^ 1u ^ kg) + lo;
+    }
+    {   // 16-wide: group g = k-step g >> 1, half g & 1 of the same order: row 16 (g >> 1) + 8 r + 4 (g & 1) + (ii >> 2),
+        // slot 2 (cg ^ r ^ (g & 1)) + (hh ^ s1)
+        const uint32_t base = (16u * (g >> 1) + 4u * (g & 1u) + (ii >> 2)) * 64u + (hh ^ s1) * 16u + 8u * aa;
+        ad.rsa = base + 32u * (g & 1u);
+        ad.rsb = base + 32u * (1u - (g & 1u));
+    }
+    ad.ry = (((g >> 1) * 64u) + (g & 1u) * 32u + ii) * 16u;
+    return ad;
+}
+
+// plane by plane: cut, write, read back transposed -- X[p][m] = the 32-wide operand (A or B alike) of k-step m.  One plane of
+// scratch per wave: the LDS executes a wave's instructions in order, the next plane's writes cannot pass this plane's reads.
+template <typename A>
+__device__ __forceinline__ void w16t_x32(f32x8 (&vals)[2], uint32_t scr, const W16TAddr& ad, typename A::v8 (&X)[A::P][2]) {
+    constexpr int P = A::P;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        w16t_st<A>(scr + ad.wr0, W16_PLANE(A, p == P - 1, vals[0], p));
+        w16t_st<A>(scr + ad.wr1, W16_PLANE(A, p == P - 1, vals[1], p));
+        X[p][0] = w16t_tr2<A>(scr + ad.rd0, scr + ad.rd1);
+        X[p][1] = w16t_tr2<A>(scr + ad.rd0 + 1024u, scr + ad.rd1 + 1024u);
+    }
+}
+// a block as a column tile for everybody: its planes in load layout at `tile` (P planes)
+template <typename A>
+__device__ __forceinline__ void w16t_put_block(f32x8 (&vals)[2], uint32_t tile, const W16TAddr& ad) {
+    constexpr int P = A::P;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        w16t_st<A>(tile + p * W16T_PLANE + ad.wr0, W16_PLANE(A, p == P - 1, vals[0], p));
+        w16t_st<A>(tile + p * W16T_PLANE + ad.wr1, W16_PLANE(A, p == P - 1, vals[1], p));
+    }
+}
+// where a product's right-hand operand (plane pb, k-step m) comes from: ready planes, or load-layout planes read transposed
+template <typename A>
+struct W16YReady {
+    uint32_t base;      // tile + 16 lane
+    __device__ __forceinline__ typename A::v8 operator()(int pb, int m) const { return w16t_ld<A>(base + (uint32_t)(2 * pb + m) * 1024u); }
+};
+template <typename A>
+struct W16YTr {
+    uint32_t b0, b1;    // tile + rd0, tile + rd1
+    __device__ __forceinline__ typename A::v8 operator()(int pb, int m) const {
+        const uint32_t o = (uint32_t)pb * W16T_PLANE + (uint32_t)m * 1024u;
+        return w16t_tr2<A>(b0 + o, b1 + o);
+    }
+};
+// acc_a += Xa^T Ya, acc_b += Xb^T Yb, the two chains' MFMAs in turn (w16x_mac2)
+template <typename A, typename YA, typename YB>
+__device__ __forceinline__ void w16t_mac2(const typename A::v8 (&Xa)[A::P][2], const YA& ya, f32x16& acc_a,
+                                          const typename A::v8 (&Xb)[A::P][2], const YB& yb, f32x16& acc_b) {
+    constexpr int P = A::P;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int pb = 0; pb < P; ++pb) {
+            const typename A::v8 Ya = ya(pb, m), Yb = yb(pb, m);
+#pragma unroll
+            for (int pa = 0; pa + pb < P; ++pa) {
+                acc_a = mfma16(Xa[pa][m], Ya, acc_a);
+                acc_b = mfma16(Xb[pa][m], Yb, acc_b);
+            }
+        }
+}
+template <typename A, typename YA>
+__device__ __forceinline__ void w16t_mac(const typename A::v8 (&Xa)[A::P][2], const YA& ya, f32x16& acc_a) {
+    constexpr int P = A::P;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int pb = 0; pb < P; ++pb) {
+            const typename A::v8 Ya = ya(pb, m);
+#pragma unroll
+            for (int pa = 0; pa + pb < P; ++pa) acc_a = mfma16(Xa[pa][m], Ya, acc_a);
+        }
+}
+// the small rows times a private block (its planes through the wave's scratch): acc[cg] += S^T Y[:, 16 cg ..]
+template <typename A>
+__device__ __forceinline__ void w16t_small_block(f32x8 (&vals)[2], uint32_t scr, const W16TAddr& ad, const typename A::v8 (&S)[A::P],
+                                                 f32x4 (&acc)[2]) {
+    constexpr int P = A::P;
+#pragma unroll
+    for (int pb = 0; pb < P; ++pb) {
+        w16t_st<A>(scr + ad.wr0, W16_PLANE(A, pb == P - 1, vals[0], pb));
+        w16t_st<A>(scr + ad.wr1, W16_PLANE(A, pb == P - 1, vals[1], pb));
+        const typename A::v8 Y0 = w16t_tr2<A>(scr + ad.rsa, scr + ad.rsb + 512u);       // cg 0: r = 0 -> rsa, r = 1 -> rsb
+        const typename A::v8 Y1 = w16t_tr2<A>(scr + ad.rsb, scr + ad.rsa + 512u);       // cg 1
+#pragma unroll
+        for (int pa = 0; pa + pb < P; ++pa) {
+            acc[0] = mfma16s(S[pa], Y0, acc[0]);
+            acc[1] = mfma16s(S[pa], Y1, acc[1]);
+        }
+    }
+}
+// the same against a column tile of READY 32-wide operand planes (the e column tiles)
+template <typename A>
+__device__ __forceinline__ void w16t_small_ready(uint32_t tile, const W16TAddr& ad, const typename A::v8 (&S)[A::P], f32x4 (&acc)[2]) {
+    constexpr int P = A::P;
+#pragma unroll
+    for (int pb = 0; pb < P; ++pb) {
+        const typename A::v8 Y0 = w16t_ld<A>(tile + (uint32_t)(2 * pb) * 1024u + ad.ry);
+        const typename A::v8 Y1 = w16t_ld<A>(tile + (uint32_t)(2 * pb) * 1024u + 256u + ad.ry);
+#pragma unroll
+        for (int pa = 0; pa + pb < P; ++pa) {
+            acc[0] = mfma16s(S[pa], Y0, acc[0]);
+            acc[1] = mfma16s(S[pa], Y1, acc[1]);
+        }
+    }
+}
+// sum over the 32 lanes of a half (the samples of a tile): once per launch
+__device__ __forceinline__ float w16t_half_sum(float v) {
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+constexpr int W16T_ONES_COL = 16 + BIAS16_U;      // column of the e column tile 1 that carries the constant one of half 0
+
+template <typename A>
+struct W16T {
+    uint32_t xe;        // LDS byte addresses: e as the forward's layer-1 operand [NBUF][4 k-steps][P][64 lanes] x 16 B
+    uint32_t xa;        // H1 column tiles, ready planes [NBUF][4][2 P][64] x 16 B
+    uint32_t xb;        // [NBUF][5 column tiles]: sdf_emb 0, sdf_emb 1, grid in load layout (P planes of 2 KB), e 0, e 1 ready
+    uint32_t scr;       // this wave's plane of scratch
+};
+
+// waves 0..3 (w): d w_pts2[w][0..3] = dH2[w]^T H1, d b_pts2; d w_sdf2[:, 32 w ..] = (d logits)^T H3[w]; d w_rgb0 columns
+// {rgb_emb 0 | rgb_emb 1 | e 0 | e 1}[w] = (d rgb)^T ...; wave 3: the small rows' bias gradients.  Produces e k-step w and
+// H1 column tile w.
+template <int LAYOUT, typename A>
+__device__ __forceinline__ void w16t_role_a(const W16Args& a, const W16T<A>& lx, int w, int lane) {
+    typedef W16XL<A> L;
+    typedef typename A::v8 v8;
+    constexpr int P = A::P;
+    constexpr bool TWO_BARRIERS = L::NBUF == 1;
+    constexpr uint32_t XE_B = L::XE * 16u, XA_B = L::XA * 16u, XB_B = L::XB * 16u, CT_B = L::CT * 16u;
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t lane16 = 16u * (uint32_t)lane;
+    const W16TAddr ad = w16t_addr(lane);
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) zero_tile(acc[t]);
+    f32x4 acc_s[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acc_r[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x8 bacc[2];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) bacc[0][u] = 0.f, bacc[1][u] = 0.f;
+    int k_main = 0, k_small = 0;
+    auto act_srd = [&](const float* recs, uint32_t tile) {
+        return make_srd(recs + (size_t)tile * ACT_TILE_FLOATS, ACT_TILE_FLOATS * 4);
+    };
+    const srd_t small_srd = make_srd(a.dsmall, a.M * 32u), x_srd = make_srd(a.x, a.M * 12u);
+    auto load_small = [&](uint32_t tile, f32x8 (&v)[2]) {
+        const uint32_t off = (tile * 32u + (uint32_t)j) * 32u;
+        const float4 p = buf_load16(small_srd, off, 0), q = buf_load16(small_srd, off, 16);
+        v[0][0] = p.x, v[0][1] = p.y, v[0][2] = p.z, v[0][3] = p.w, v[0][4] = q.x, v[0][5] = q.y, v[0][6] = q.z, v[0][7] = q.w;
+    };
+    const v8* gimg = reinterpret_cast<const v8*>(a.gimg);
+    const v8* w1 = reinterpret_cast<const v8*>(a.w1_hi);
+    constexpr int W1_PLANE = RT_F1 * T16H_F1 * 64;
+    const bool recompute_x = a.gimg != nullptr && w >= 2;
+    auto dh2_srd = [&](uint32_t tile) {
+        return make_srd(a.dact + (size_t)tile * ACT_TILE_FLOATS, recompute_x ? 0 : ACT_TILE_FLOATS * 4);
+    };
+    auto load_x = [&](uint32_t tile, float (&v)[3]) {
+        const uint32_t s_raw = tile * 32u + (uint32_t)j;
+        const uint32_t off = (s_raw < a.M ? s_raw : a.M - 1) * 12u;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) v[d] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_srd, off, 4 * d, 0));
+    };
+    auto e_srd = [&](uint32_t tile) {       // (every wave issues the same loads: see w16x_role_a)
+        return make_srd(a.saved + (size_t)tile * ACT_TILE_FLOATS, w < 2 ? ACT_TILE_FLOATS * 4 : 0);
+    };
+    auto put_e = [&](uint32_t xe, const float (&xv)[3]) {
+        v8 e[P];
+        w16x_e_step<A>(w, xv[0], xv[1], xv[2], h, e);
+#pragma unroll
+        for (int p = 0; p < P; ++p) w16t_st<A>(xe + (uint32_t)((w * P + p) * 64) * 16u + lane16, e[p]);
+    };
+    f32x8 bX[2], bS[2], bH3[2], bE[2];
+    float xn[3] = {0.f, 0.f, 0.f};
+    uint32_t it = blockIdx.x, par = 0;
+    if (it < a.n_tiles) {
+        const uint32_t t0 = w16_tile(a, it);
+        load_x(t0, xn);
+        load_tile_rows(dh2_srd(t0), 1, w, lane16, bX);
+        load_small(t0, bS);
+        load_tile_rows(act_srd(a.saved, t0), 2, w, lane16, bH3);
+        load_tile_rows(e_srd(t0), 1, 2 + (w & 1), lane16, bE);
+        put_e(lx.xe, xn);
+        load_x(w16_tile(a, it + gridDim.x < a.n_tiles ? it + gridDim.x : it), xn);
+    }
+    w16x_barrier();
+#pragma clang loop unroll(disable)
+    for (; it < a.n_tiles; it += gridDim.x, par ^= (L::NBUF == 2 ? 1u : 0u)) {
+        const bool more = it + gridDim.x < a.n_tiles;
+        const uint32_t nt = more ? w16_tile(a, it + gridDim.x) : w16_tile(a, it);
+        const uint32_t xe = lx.xe + par * XE_B, xa = lx.xa + par * XA_B, xb = lx.xb + par * XB_B;
+        v8 X[P][2];
+        W16_TRACE_DECL;
+        W16_MARK(0);
+        // ---- H1 column tile w = e W1[w]^T, ReLU, planes -> XA (comes out of the product in operand layout: w16x_role_a)
+        {
+            f32x16 hacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                v8 e[P], wp[P];
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    e[p] = w16t_ld<A>(xe + (uint32_t)((t * P + p) * 64) * 16u + lane16), wp[p] = w1[p * W1_PLANE + (w * T16H_F1 + t) * 64 + lane];
+                hacc = mfma16(e[0], wp[0], hacc);
+                hacc = mfma16(e[1], wp[0], hacc);
+                if constexpr (P == 3) {
+                    hacc = mfma16(e[2], wp[0], hacc);
+                    hacc = mfma16(e[1], wp[1], hacc);
+                    hacc = mfma16(e[0], wp[1], hacc);
+                    hacc = mfma16(e[0], wp[2], hacc);
+                } else {
+                    hacc = mfma16(e[0], wp[1], hacc);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                f32x8 r;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    r[u] = __builtin_amdgcn_fmed3f(hacc[8 * m + u] * w16_acc_unscale<A>(), 0.0f, __builtin_inff());
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    w16t_st<A>(xa + (uint32_t)w * CT_B + (uint32_t)(2 * p + m) * 1024u + lane16,
+                               p == P - 1 ? next_plane<A, true>(r) : next_plane<A, false>(r));
+            }
+        }
+        W16_FENCE();
+        W16_MARK(1);
+        if (!TWO_BARRIERS) {
+            if (more) put_e(lx.xe + (par ^ 1u) * XE_B, xn);
+            load_x(w16_tile(a, it + 2 * gridDim.x < a.n_tiles ? it + 2 * gridDim.x : it), xn);
+        }
+        W16_FENCE();
+        W16_MARK(2);
+        // ---- X = dH2[w]
+        if (recompute_x) {
+            float up, down;
+            w16x_updown(bS[0], up, down);
+            v8 rp[P];
+            w16x_small_operand<A>(bS[0], N_CLASS, 3, up, h, rp);
+            const f32x16 ac = w16x_narrow<A>(gimg, L::G_RGBT + (w - 2) * 64 + lane, L::G_PLANE_RGBT, rp);
+            const float unscale = w16_acc_unscale<A>();
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) bX[q][u] = (ac[8 * q + u] * unscale) * down;
+        }
+        if (A::SCALED) {
+            float rs;
+            const float sx = w16_pick_scale(w16_block_max_bits(bX, 2), k_main, rs);
+            if (rs != 1.0f) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] *= rs;
+                bacc[0] *= rs, bacc[1] *= rs;
+            }
+            bX[0] *= sx, bX[1] *= sx;
+        }
+        bacc[0] = bacc[0] + bX[0], bacc[1] = bacc[1] + bX[1];
+        w16t_x32<A>(bX, lx.scr, ad, X);
+        W16_FENCE();
+        load_tile_rows(dh2_srd(nt), 1, w, lane16, bX);
+        W16_FENCE();
+        W16_MARK(3);
+        w16x_barrier();
+        W16_MARK(4);
+        if (TWO_BARRIERS) {
+            if (more) put_e(lx.xe, xn);
+            load_x(w16_tile(a, it + 2 * gridDim.x < a.n_tiles ? it + 2 * gridDim.x : it), xn);
+        }
+        // ---- the four H1 column tiles (ready planes)
+        {
+            const W16YReady<A> y0 = {xa + lane16}, y1 = {xa + CT_B + lane16}, y2 = {xa + 2 * CT_B + lane16}, y3 = {xa + 3 * CT_B + lane16};
+            w16t_mac2<A>(X, y0, acc[0], X, y1, acc[1]);
+            w16t_mac2<A>(X, y2, acc[2], X, y3, acc[3]);
+        }
+        W16_FENCE();
+        W16_MARK(5);
+        // ---- small rows: rows {0..3, 8..11} of a 16-row operand = (d logits 0..4, d rgb 0..2)
+        if (h != 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bS[0][u] = 0.0f;
+        }
+        if (A::SCALED) {
+            float rs;
+            const float sx = w16_pick_scale(w16_block_max_bits(bS, 1), k_small, rs);
+            if (rs != 1.0f) acc_s[0] *= rs, acc_s[1] *= rs, acc_r[0] *= rs, acc_r[1] *= rs;
+            bS[0] *= sx;
+        }
+        v8 S[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {        // slot 0 of every row: features {0..3, 8..11} by half 0, zeros by half 1
+            w16t_st<A>(lx.scr + ad.wr0, W16_PLANE(A, p == P - 1, bS[0], p));
+            S[p] = w16t_tr2<A>(lx.scr + ad.rsa, lx.scr + ad.rsb + 512u);
+        }
+        W16_FENCE();
+        w16t_small_block<A>(bH3, lx.scr, ad, S, acc_s);                                  // H3[w]
+        W16_FENCE();
+        if (w < 2) w16t_small_block<A>(bE, lx.scr, ad, S, acc_r);                        // rgb_emb (waves 0, 1)
+        else w16t_small_ready<A>(xb + (uint32_t)(3 + (w - 2)) * CT_B, ad, S, acc_r);     // e column tile w - 2 (waves 2, 3)
+        W16_FENCE();
+        load_small(nt, bS);
+        load_tile_rows(act_srd(a.saved, nt), 2, w, lane16, bH3);
+        load_tile_rows(e_srd(nt), 1, 2 + (w & 1), lane16, bE);
+        W16_FENCE();
+        W16_MARK(6);
+        if (TWO_BARRIERS) w16x_barrier();
+        W16_MARK(7);
+        W16_TRACE_SUM(7, w);
+    }
+    float* rec = a.rec;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+        flush_mapped(rec, G_W_PTS2, HID, lane, acc[ct], w16_unscale(k_main), [&](int i) { return 32 * w + i; }, [&](int c) { return 32 * ct + c; });
+    // 16 x 16 tiles: lane = column n of column group cg, rows 4 (lane >> 4) + r; the small rows sit in rows {0..3, 8..11}
+    {
+        const int n = lane & 15, rg = lane >> 4;
+        const float us = w16_unscale(k_small);
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int v = w16_small_row(4 * rg + r);         // 0..7 or -1
+                if (v >= 0 && v < N_CLASS) rec[G_W_SDF2 + v * HID + 32 * w + 16 * cg + n] = acc_s[cg][r] * us;
+                if (v >= N_CLASS) {
+                    const int col = w < 2 ? 32 * w + 16 * cg + n : (w16_e_col(w - 2, 16 * cg + n) >= 0 ? N_EMB + w16_e_col(w - 2, 16 * cg + n) : -1);
+                    if (col >= 0) rec[G_W_RGB0 + (v - N_CLASS) * N_RGB_IN + col] = acc_r[cg][r] * us;
+                }
+                // the ones column of e's second column tile: sum over the samples of every small row
+                if (w == 3 && 16 * cg + n == W16T_ONES_COL && v >= 0) {
+                    if (v < N_CLASS) rec[G_B_SDF2 + v] = acc_r[cg][r] * us;
+                    else rec[G_B_RGB0 + v - N_CLASS] = acc_r[cg][r] * us;
+                }
+            }
+    }
+    // d b_pts2: this lane's 16 features of row tile w, summed over the 32 samples of its half
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float t = w16t_half_sum(bacc[q][u]) * w16_unscale(k_main);
+            if (j == 0) rec[G_B_PTS2 + 32 * w + 16 * q + 8 * (u >> 2) + 4 * h + (u & 3)] = t;
+        }
+}
+
+// waves 4..7 (rt): d w_sdf0[rt][0..2] = dG3[rt]^T [sdf_emb | grid], d b_sdf0;  d w_pts0[rt][0..1] = dG1[rt]^T e, d b_pts0 (the
+// ones column).  Produces column tiles: rt 0, 1 -> sdf_emb 0, 1 and rt 2 -> grid, as planes in load layout; rt 3 -> e 0 and
+// e 1 from XE's operand planes (the one transposition left on the matrix pipe: 12 MFMAs per tile).
+template <int LAYOUT, typename A>
+__device__ __forceinline__ void w16t_role_b(const W16Args& a, const W16T<A>& lx, const typename A::v8 (&I)[2], int rt, int lane) {
+    typedef W16XL<A> L;
+    typedef typename A::v8 v8;
+    constexpr int P = A::P;
+    constexpr bool TWO_BARRIERS = L::NBUF == 1;
+    constexpr bool EARLY_X = TWO_BARRIERS;
+    constexpr uint32_t XE_B = L::XE * 16u, XB_B = L::XB * 16u, CT_B = L::CT * 16u;
+    static_assert(L::CT * 16 == P * (int)W16T_PLANE, "a column tile is P planes in either layout");
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t lane16 = 16u * (uint32_t)lane;
+    const W16TAddr ad = w16t_addr(lane);
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) zero_tile(acc[t]);
+    f32x8 bacc[2];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) bacc[0][u] = 0.f, bacc[1][u] = 0.f;
+    int k3 = 0, k1 = 0;
+    f32x8 bG3[2], bG1[2], bY[2];
+    auto act_srd = [&](const float* recs, uint32_t tile) {
+        return make_srd(recs + (size_t)tile * ACT_TILE_FLOATS, ACT_TILE_FLOATS * 4);
+    };
+    const uint64_t feat_bytes = (uint64_t)a.M * N_GRID * 4;
+    const srd_t feat_srd = make_srd(a.feat, feat_bytes > 0xffffffffull ? 0xffffffffu : (uint32_t)feat_bytes);
+    auto load_mine = [&](uint32_t tile) {
+        if (rt < 2) {
+            load_tile_rows(make_srd(a.saved + (size_t)tile * ACT_TILE_FLOATS, ACT_TILE_FLOATS * 4), 1, rt & 1, lane16, bY);
+        } else if (rt == 2) {
+            const uint32_t s_raw = tile * 32u + (uint32_t)j;
+            const uint32_t s_c = s_raw < a.M ? s_raw : a.M - 1;
+            const uint32_t voff = LAYOUT == MIPSF_FEAT_AOS ? s_c * (uint32_t)(N_GRID * 4) + 4u * (uint32_t)h : (s_c * 2u + (uint32_t)h) * 4u;
+            const uint32_t lstride = LAYOUT == MIPSF_FEAT_AOS ? 8u : a.M * 8u;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    bY[q][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(feat_srd, voff, (uint32_t)(8 * q + u) * lstride, 0));
+        }
+    };
+    const bool lean = a.gimg != nullptr;
+    const v8* gimg = reinterpret_cast<const v8*>(a.gimg);
+    const srd_t small_srd = make_srd(a.dsmall, a.M * 32u);
+    f32x8 bSm;
+    uint2 bMk = make_uint2(0u, 0u);
+    auto load_lean = [&](uint32_t tile) {
+        const uint32_t off = (tile * 32u + (uint32_t)j) * 32u;
+        const float4 p = buf_load16(small_srd, off, 0), q = buf_load16(small_srd, off, 16);
+        bSm[0] = p.x, bSm[1] = p.y, bSm[2] = p.z, bSm[3] = p.w, bSm[4] = q.x, bSm[5] = q.y, bSm[6] = q.z, bSm[7] = q.w;
+        if (lean) bMk = a.masks[(size_t)tile * (MASK_TILE_WORDS / 2) + 64 + lane];
+    };
+    auto g3_srd = [&](uint32_t tile) {
+        return make_srd(a.dact + (size_t)tile * ACT_TILE_FLOATS, lean ? 0 : ACT_TILE_FLOATS * 4);
+    };
+    uint32_t it = blockIdx.x, par = 0;
+    if (it < a.n_tiles) {
+        const uint32_t t0 = w16_tile(a, it);
+        load_mine(t0);
+        load_lean(t0);
+        load_tile_rows(g3_srd(t0), 2, rt, lane16, bG3);
+        load_tile_rows(act_srd(a.dact, t0), 0, rt, lane16, bG1);
+    }
+    w16x_barrier();
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    v8 X3[P][2], X1[P][2];
+    auto make_x = [&](uint32_t nt, bool with_loads) {
+        if (lean) {
+            float up, down;
+            w16x_updown(bSm, up, down);
+            v8 lp[P];
+            w16x_small_operand<A>(bSm, 0, N_CLASS, up, h, lp);
+            const f32x16 ac = w16x_narrow<A>(gimg, rt * 64 + lane, L::G_PLANE_S2T, lp);
+            const uint32_t m3[2] = {bMk.x, bMk.y};
+            const float unscale = w16_acc_unscale<A>();
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) bG3[q][u] = mask_apply(m3, rt, 8 * q + u, ac[8 * q + u] * unscale) * down;
+        }
+        if (A::SCALED) {
+            float rs;
+            const float sx = w16_pick_scale(w16_block_max_bits(bG3, 2), k3, rs);
+            if (rs != 1.0f) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[t] *= rs;
+                bacc[0] *= rs, bacc[1] *= rs;
+            }
+            bG3[0] *= sx, bG3[1] *= sx;
+        }
+        bacc[0] = bacc[0] + bG3[0], bacc[1] = bacc[1] + bG3[1];
+        w16t_x32<A>(bG3, lx.scr, ad, X3);
+        W16_FENCE();
+        if (with_loads) {
+            load_lean(nt);
+            load_tile_rows(g3_srd(nt), 2, rt, lane16, bG3);
+        }
+        W16_FENCE();
+        if (A::SCALED) {
+            float rs;
+            const float sx = w16_pick_scale(w16_block_max_bits(bG1, 2), k1, rs);
+            if (rs != 1.0f) acc[3] *= rs, acc[4] *= rs;
+            bG1[0] *= sx, bG1[1] *= sx;
+        }
+        w16t_x32<A>(bG1, lx.scr, ad, X1);
+        W16_FENCE();
+        if (with_loads) load_tile_rows(act_srd(a.dact, nt), 0, rt, lane16, bG1);
+        W16_FENCE();
+    };
+    auto load_x = [&](uint32_t nt) {
+        load_lean(nt);
+        load_tile_rows(g3_srd(nt), 2, rt, lane16, bG3);
+        load_tile_rows(act_srd(a.dact, nt), 0, rt, lane16, bG1);
+    };
+    if (EARLY_X && it < a.n_tiles) make_x(0u, false);
+#pragma clang loop unroll(disable)
+    for (; it < a.n_tiles; it += gridDim.x, par ^= (L::NBUF == 2 ? 1u : 0u)) {
+        const uint32_t nt = it + gridDim.x < a.n_tiles ? w16_tile(a, it + gridDim.x) : w16_tile(a, it);
+        const uint32_t xe = lx.xe + par * XE_B, xb = lx.xb + par * XB_B;
+        W16_TRACE_DECL;
+        W16_MARK(0);
+        // ---- this wave's column tile(s) -> XB
+        if (rt < 3) {
+            if (rt == 2) bY[0] = bY[0] * w16_grid_shift<A>(), bY[1] = bY[1] * w16_grid_shift<A>();
+            w16t_put_block<A>(bY, xb + (uint32_t)rt * CT_B, ad);
+        } else {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                v8 Y[P][2];
+#pragma unroll
+                for (int pb = 0; pb < P; ++pb) {
+                    f32x16 T = mfma16(w16t_ld<A>(xe + (uint32_t)(((2 * blk) * P + pb) * 64) * 16u + lane16), I[0], zero);
+                    T = mfma16(w16t_ld<A>(xe + (uint32_t)(((2 * blk + 1) * P + pb) * 64) * 16u + lane16), I[1], T);
+                    pack_T<A>(T, Y[pb]);
+                }
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) w16t_st<A>(xb + (uint32_t)(3 + blk) * CT_B + (uint32_t)(2 * p + m) * 1024u + lane16, Y[p][m]);
+            }
+        }
+        W16_FENCE();
+        load_mine(nt);
+        W16_FENCE();
+        W16_MARK(1);
+        if (!EARLY_X) make_x(nt, true);
+        W16_MARK(2);
+        W16_MARK(3);
+        w16x_barrier();
+        W16_MARK(4);
+        if (EARLY_X) load_x(nt);
+        {
+            const W16YTr<A> y0 = {xb + ad.rd0, xb + ad.rd1}, y1 = {xb + CT_B + ad.rd0, xb + CT_B + ad.rd1},
+                            y2 = {xb + 2 * CT_B + ad.rd0, xb + 2 * CT_B + ad.rd1};
+            const W16YReady<A> y3 = {xb + 3 * CT_B + lane16}, y4 = {xb + 4 * CT_B + lane16};
+            w16t_mac2<A>(X3, y0, acc[0], X3, y1, acc[1]);
+            w16t_mac2<A>(X3, y2, acc[2], X1, y3, acc[3]);
+            w16t_mac<A>(X1, y4, acc[4]);
+        }
+        W16_FENCE();
+        W16_MARK(5);
+        if (EARLY_X && it + gridDim.x < a.n_tiles) make_x(0u, false);
+        W16_MARK(6);
+        if (TWO_BARRIERS) w16x_barrier();
+        W16_MARK(7);
+        W16_TRACE_SUM(7, 4 + rt);
+    }
+    float* rec = a.rec;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+        flush_mapped(rec, G_W_SDF0, N_SDF_IN, lane, acc[ct], w16_unscale(k3), [&](int i) { return 32 * rt + i; }, [&](int c) { return 32 * ct + c; });
+    flush_mapped(rec, G_W_SDF0, N_SDF_IN, lane, acc[2], w16_unscale(k3) / w16_grid_shift<A>(), [&](int i) { return 32 * rt + i; },
+                 [&](int c) { return N_EMB + 2 * (8 * (c >> 4) + 4 * ((c >> 3) & 1) + (c & 3)) + ((c >> 2) & 1); });
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+        flush_mapped(rec, G_W_PTS0, N_E, lane, acc[3 + ct], w16_unscale(k1), [&](int i) { return 32 * rt + i; },
+                     [&](int c) { return w16_e_col(ct, c); });
+    // d b_pts0: the ones column of e's second column tile
+    if (j == W16T_ONES_COL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rec[G_B_PTS0 + 32 * rt + rowmap(r, h)] = acc[4][r] * w16_unscale(k1);
+    }
+    // d b_sdf0: this lane's 16 features of row tile rt, summed over the 32 samples of its half
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float t = w16t_half_sum(bacc[q][u]) * w16_unscale(k3);
+            if (j == 0) rec[G_B_SDF0 + 32 * rt + 16 * q + 8 * (u >> 2) + 4 * h + (u & 3)] = t;
+        }
+}
+
 #ifndef W16_EXCHANGE
 #define W16_EXCHANGE 1      // experiments: 0 = every wave prepares its own operands (the roles above) behind the lean record, too
+#endif
+#ifndef W16_TR
+#define W16_TR 1            // experiments: 0 = the exchange form with matrix-core transposes (rounds 3-5)
 #endif
 
 template <int LAYOUT, typename A, bool RECOMP>
@@ -1395,7 +2013,10 @@ __global__ __launch_bounds__(W16_BLOCK, 2) void decoder_wgrad16_kernel(const flo
     __shared__ h8 w1img[RECOMP ? P * W1_ENTRIES : 1];
     __shared__ h8 xch[EXCH ? L::NBUF * (L::XE + L::XA + L::XB) : 1];
     __shared__ h8 gimg[EXCH ? L::G_ENTRIES : 1];
-    static_assert(!EXCH || sizeof(h8) * (P * W1_ENTRIES + L::NBUF * (L::XE + L::XA + L::XB) + L::G_ENTRIES) <= 160 * 1024,
+    constexpr bool TRF = EXCH && W16_TR;
+    __shared__ h8 tscr[TRF ? 8 * (W16T_PLANE / 16) : 1];          // transpose-read form: one plane of scratch per wave
+    static_assert(!EXCH || sizeof(h8) * (P * W1_ENTRIES + L::NBUF * (L::XE + L::XA + L::XB) + L::G_ENTRIES + (TRF ? 8 * (W16T_PLANE / 16) : 0))
+                               <= 160 * 1024,
                   "the exchange form's images and hand-over buffers must fit the LDS of a CU");
     if constexpr (RECOMP) {
         // planes 0 and 1 of an image sit where the f16 layout has hi and lo; plane 2 (bf16 only) in the buffer's extension
@@ -1428,7 +2049,13 @@ __global__ __launch_bounds__(W16_BLOCK, 2) void decoder_wgrad16_kernel(const flo
                        RECOMP ? w1img : nullptr, RECOMP ? w1img + W1_ENTRIES : nullptr,
                        (EXCH && lean_dact) ? gimg : nullptr,
                        reinterpret_cast<const uint2*>(saved + (((size_t)M + 127) / 128) * 4 * ACT_TILE_FLOATS)};
-    if constexpr (EXCH) {
+    if constexpr (TRF) {
+        const uint32_t xb0 = w16t_lds_addr(xch);
+        const W16T<A> lx = {xb0, xb0 + 16u * L::NBUF * L::XE, xb0 + 16u * L::NBUF * (L::XE + L::XA),
+                            w16t_lds_addr(tscr) + (uint32_t)w * W16T_PLANE};
+        if (w < 4) w16t_role_a<LAYOUT, A>(a, lx, w, lane);
+        else w16t_role_b<LAYOUT, A>(a, lx, I, w - 4, lane);
+    } else if constexpr (EXCH) {
         typename A::v8* xp = reinterpret_cast<typename A::v8*>(xch);
         const W16X<A> lx = {xp, xp + L::NBUF * L::XE, xp + L::NBUF * (L::XE + L::XA)};
         if (w < 4) w16x_role_a<LAYOUT, A>(a, lx, I, w, lane);

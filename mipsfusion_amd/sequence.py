@@ -644,11 +644,7 @@ class GraphedSequence:
         rows, owner, noise = packed(self.ba_rows, n), packed(self.ba_owner, n), packed(self.ba_noise, n)
 
         accum, wait = mp.get("map_accum_step", 1), mp.get("map_wait_step", 0)
-
-        def zero_map_grads():
-            gs = [p.grad for p in self.model.parameters() if p.grad is not None]
-            if gs:
-                torch._foreach_zero_(gs)
+        zero_map_grads = self._zero_map_grads
 
         def step(k):
             if k == 0 and not self.plain_map_steps:
@@ -664,6 +660,11 @@ class GraphedSequence:
             if (k + 1) % mp["pose_accum_step"] == 0:
                 self.ba_popt.step(zero_grad=True)
         return step
+
+    def _zero_map_grads(self):
+        gs = [p.grad for p in self.model.parameters() if p.grad is not None]
+        if gs:
+            torch._foreach_zero_(gs)
 
     def _go_step(self, k):
         if k == 0:
@@ -684,6 +685,10 @@ class GraphedSequence:
     def _init_step(self, k):
         """One initialisation iteration of a sub-map (first_frame_mapping / initialize_new_localMLP, mipsfusion.py:172-190,
         206-221): mapping.sample pixels of the keyframe, its pose fixed (owner 0), map Adam step."""
+        if k == 0 and not self.plain_map_steps:
+            self._zero_map_grads()      # map_optimizer.zero_grad() at the top of every initialisation iteration (mipsfusion.py:176,
+            #                             207): a BA round whose iters is no multiple of map_accum_step leaves gradients behind;
+            #                             iterations k > 0 find them cleared by the step in front of them
         ret = self.model.forward_from_table(self.table, self.init_rows[k], self.ba_rot.detach(), self.ba_trans.detach(),
                                             self.fixed, self.init_owner, self.init_noise[k])
         backward_from_one(get_loss_from_ret(ret, self.cfg["training"]))

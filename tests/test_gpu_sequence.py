@@ -401,6 +401,30 @@ def test_graphed_ba_round_honours_map_accum_and_wait_steps():
         print("update", moved, "recorded vs literal", dist(got, want), "shipped cadence vs literal", dist(shipped, want))
         assert dist(got, want) < 0.05 * moved
         assert dist(shipped, want) > 0.3 * moved
+
+        # A switch to a NEW sub-map behind such a round: iters = 7 is no multiple of map_accum_step = 2, so the round leaves
+        # the seventh iteration's gradients in .grad.  The reference clears them at the top of every initialisation iteration
+        # (map_optimizer.zero_grad(), mipsfusion.py:176, 207); the first captured initialisation iteration must not step on them.
+        seq._fill_init_device()
+
+        def init_after_round(clear_first):
+            def run():
+                recorded()
+                assert any(float(p.grad.abs().max()) > 0 for p in table if p.grad is not None)
+                seq.model.recover_initial_param(), seq.map_opt.reset()
+                if clear_first:
+                    seq.map_opt.zero_grad(set_to_none=False)
+                    seq.plain_map_steps = True            # the literal: no clearing inside the step
+                try:
+                    seq._init_step(0)
+                finally:
+                    seq.plain_map_steps = False
+            return run
+        start = after(lambda: (seq.model.recover_initial_param(), seq.map_opt.reset()))
+        got_i, want_i = after(init_after_round(False)), after(init_after_round(True))
+        moved_i = dist(want_i, start)
+        print("first initialisation step", moved_i, "behind a partial accumulation vs cleared by hand", dist(got_i, want_i))
+        assert moved_i > 1e-3 and dist(got_i, want_i) < 0.05 * moved_i
     finally:
         torch.cuda.set_stream(prev)
 
