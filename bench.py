@@ -172,6 +172,75 @@ def log(msg):
     print(f"[bench +{time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+class BoardSampler:
+    """The board's state while a region is timed: the shader clock the SMU reports (sysfs pp_dpm_sclk, the level marked '*') and
+    the package power (hwmon power1_average / power1_input), sampled every `period` seconds from a second thread.  The decoder
+    kernels hold the board at its power cap and the clock it then delivers differs from box to box by more than most kernel
+    changes: a step time is only comparable with the board state it was measured at."""
+
+    def __init__(self, device_index=0, period=0.004):
+        import glob
+        import threading
+        self.period, self.samples, self._stop, self._glob = period, [], False, glob
+        cards = [d for d in sorted(glob.glob("/sys/class/drm/card*/device")) if os.path.exists(os.path.join(d, "pp_dpm_sclk"))]
+        mine = []
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(device_index)
+            addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+            mine = [d for d in cards if addr in os.path.realpath(d)]
+        except Exception:       # noqa: BLE001
+            pass
+        self.card = (mine or cards or [None])[0]
+        self._power_files = []
+        if self.card:
+            self._power_files = (glob.glob(os.path.join(self.card, "hwmon", "hwmon*", "power1_average")) +
+                                 glob.glob(os.path.join(self.card, "hwmon", "hwmon*", "power1_input")))
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _sclk(self):
+        try:
+            for line in open(os.path.join(self.card, "pp_dpm_sclk")):
+                if "*" in line:
+                    return float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except (OSError, ValueError, IndexError, TypeError):
+            pass
+        return None
+
+    def _power(self):
+        for f in self._power_files:
+            try:
+                return int(open(f).read()) * 1e-6
+            except (OSError, ValueError):
+                pass
+        return None
+
+    def _run(self):
+        while not self._stop:
+            self.samples.append((self._sclk(), self._power()))
+            time.sleep(self.period)
+
+    def __enter__(self):
+        if self.card:
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self.card:
+            self._thread.join(timeout=2.0)
+
+    def summary(self):
+        def med(v):
+            v = sorted(x for x in v if x is not None)
+            return None if not v else round(float(v[len(v) // 2]), 1)
+        clk, pw = [a for a, _ in self.samples], [b for _, b in self.samples]
+        lo = [x for x in clk if x is not None]
+        return {"sclk_mhz_median": med(clk), "sclk_mhz_min": round(min(lo), 1) if lo else None, "power_w_median": med(pw),
+                "samples": len(self.samples), "source": "sysfs pp_dpm_sclk / hwmon power1_*, sampled across the graph-replayed "
+                "timed region and the step_ms_stats steps" if self.card else "no sysfs card with pp_dpm_sclk visible"}
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -1070,6 +1139,9 @@ def compact_line(out):
     line["eager_ms_per_step"] = out.get("eager_ms_per_step")
     if out.get("step_ms_stats"):
         line["step_ms_stats"] = _pick(out["step_ms_stats"], ("steps", "min", "median", "p95", "max"))
+    if out.get("value_at_median_step") is not None:
+        line["value_at_median_step"] = out["value_at_median_step"]
+    line["board"] = _pick(out.get("board") or {}, ("sclk_mhz_median", "sclk_mhz_min", "power_w_median", "samples")) or None
     roof = out.get("roofline")
     if roof:
         r = _pick(roof, ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_ms", "launches", "work_per_launch", "traffic",
@@ -1131,7 +1203,12 @@ def compact_line(out):
 
 
 def emit(out):
-    """full result -> bench_detail.json + stderr; the compact line -> stdout (last line)."""
+    """full result -> bench_detail.json + stderr; the compact line -> stdout (last line).  Rank 0 only: the other ranks' results
+    go to stderr (the launcher forwards ONE line, and the detail file must be that rank's)."""
+    if int(os.environ.get("RANK", "0")) != 0:
+        sys.stderr.write(f"[bench detail rank {os.environ.get('RANK')}] " + json.dumps(out) + "\n")
+        sys.stderr.flush()
+        return
     detail = json.dumps(out)
     for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
         if os.path.isdir(d):
@@ -1265,7 +1342,7 @@ def main():
     prof = ops.profile_summary()
     ops.PROFILE = None
     log(f"eager timed region: {args.steps} steps in {eager_elapsed * 1e3:.1f} ms")
-    elapsed, step_stats = eager_elapsed, None
+    elapsed, step_stats, board = eager_elapsed, None, None
 
     # ---- graph pass (the number reported as `value`): the same K steps as hipGraph replays of pose_accum_step
     #      iterations; fresh ray batches are copied into the static input buffers before every replay
@@ -1278,6 +1355,7 @@ def main():
             loop.refill_static()
             graphed.replay()
         barrier()
+        board_sampler = BoardSampler(dev.index or 0).__enter__()
         t0 = time.perf_counter()
         for r in range(args.steps // n_inner):
             loop.refill_static()
@@ -1296,6 +1374,8 @@ def main():
             graphed.replay()
             b.record()
         torch.cuda.synchronize()
+        board_sampler.__exit__()
+        board = board_sampler.summary()
         per_step = np.array([a.elapsed_time(b) / n_inner for a, b in ev])
         step_stats = {"steps": n_rep * n_inner, "granularity": f"one replay of {n_inner} steps incl. its input refill",
                       "min": round(float(per_step.min()), 4), "median": round(float(np.median(per_step)), 4),
@@ -1369,6 +1449,8 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
         "launch": "hipGraph replay of pose_accum_step iterations" if use_graph else "eager",
         "step_ms_stats": step_stats,
+        "board": board,
+        "value_at_median_step": None if not step_stats else round(M * world / (step_stats["median"] * 1e-3), 1),
         "batches": "a fresh ray batch every step: rows gathered in-step from the HBM ray table (4 keyframes x 30 000 rays "
                    "+ current frame) by host-drawn index sets (reference samplers), indices and jitter resident in HBM",
         "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",

@@ -312,7 +312,8 @@ typedef struct mipsf_render_cfg {
     float emd_w;             /* EMD_w of JointEncoding.forward                             */
 } mipsf_render_cfg;
 
-/* z_uniform [n_uniform], z_near_offsets [n_near], z_near_nodepth [n_near]: the three torch.linspace tables
+/* z_uniform [n_uniform] (nullable when n_uniform = 0: training.n_samples_d = 0, the reference's `z_vals = z_samples` branch,
+ * scene_rep.py:166-167), z_near_offsets [n_near], z_near_nodepth [n_near]: the three torch.linspace tables
  * (computed once on the host by torch so that placement is bit-identical).  target_d nullable (then
  * n_near must be 0).  noise [N,S] U[0,1) (nullable when !perturb).  Outputs: z_vals [N,S]; xn [N*S,3]
  * normalised fp32 coordinates; counts[N,2] (uint32, written) = per-ray {#front, #band} of

@@ -1010,7 +1010,8 @@ int mipsf_sample_rays(const float* rays_o, const float* rays_d, const float* tar
                       const mipsf_render_cfg* cfg, float* z_vals, float* xn, uint32_t* counts, uint32_t N,
                       void* stream) {
     if (N == 0) return 0;
-    MIPSF_REQUIRE(cfg && rays_o && rays_d && z_uniform && z_vals && xn, "null pointer");
+    MIPSF_REQUIRE(cfg && rays_o && rays_d && z_vals && xn, "null pointer");
+    MIPSF_REQUIRE(z_uniform || cfg->n_uniform == 0, "null pointer: z_uniform with n_uniform = %u", cfg->n_uniform);
     const uint32_t S = cfg->n_uniform + cfg->n_near;
     MIPSF_REQUIRE(S >= 1 && S <= MAX_S, "samples per ray %u outside [1,%d]", S, MAX_S);
     MIPSF_REQUIRE(cfg->n_near == 0 || (target_d && z_near_offsets && z_near_nodepth),
@@ -1033,7 +1034,8 @@ int mipsf_gather_pose_place_fwd(const float* db, uint64_t n_rows, const int64_t*
                                 const float* z_near_nodepth, const mipsf_render_cfg* cfg, float* d_cam, float* rgb,
                                 float* depth, float* z_vals, float* xn, uint32_t* counts, uint32_t N, void* stream) {
     if (N == 0) return 0;
-    MIPSF_REQUIRE(cfg && db && idx && owner && z_uniform && d_cam && rgb && depth && z_vals && xn, "null pointer");
+    MIPSF_REQUIRE(cfg && db && idx && owner && d_cam && rgb && depth && z_vals && xn, "null pointer");
+    MIPSF_REQUIRE(z_uniform || cfg->n_uniform == 0, "null pointer: z_uniform with n_uniform = %u", cfg->n_uniform);
     MIPSF_REQUIRE((F == 0 || fixed_poses) && (K == 0 || (rot && trans)), "null pose pointer");
     MIPSF_REQUIRE(F + K >= 1 && F + K <= (uint32_t)PR_MAX_POSES, "number of poses %u outside [1,%d]", F + K, PR_MAX_POSES);
     const uint32_t S = cfg->n_uniform + cfg->n_near;
@@ -1079,7 +1081,9 @@ int mipsf_place_pose_bwd(const float* dxn, const float* z_vals, const mipsf_rend
     return check_launch("place_pose_bwd");
 }
 
-// render_train_kernel (S <= RT_MAX_S): RT_RPB x S x 40 bytes of dynamic LDS, above 64 KB from S = 103
+// render_train_kernel (S <= RT_MAX_S): RT_RPB x S x 40 bytes of dynamic LDS beside ~9.5 KB of static LDS (together above 64 KB
+// from S = 88, 90 KB at S = 128: inside gfx950's 160 KB).  Returns -1 -- nothing launched -- when the device does not grant the
+// dynamic size (a build for another ARCH): the caller then takes the kernel without the LDS row.
 static int launch_render_train(const float* raw, const float* z_vals, const float* target_rgb, const float* target_d,
                                const RenderCfg& rc, float* rgb, float* depth, float* depth_var, float* disp, float* acc,
                                float* weights, float* partial, uint32_t N, uint32_t S, const LossFinalize& fin, float* draw,
@@ -1092,10 +1096,10 @@ static int launch_render_train(const float* raw, const float* z_vals, const floa
     uint32_t& attr = attr_dev[device_slot()][draw ? 1 : 0];
     if (lds > 48u * 1024u && lds > attr) {        // (only the two-samples-per-lane kernels get there)
         if (hipFuncSetAttribute(fn[draw ? 1 : 0][1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            set_error("cannot raise dynamic LDS to %u bytes", lds);
-            return 4;
+            (void)hipGetLastError();
+            return -1;
         }
-        attr = lds;
+        attr = lds;       // (two threads racing here both set the attribute to a size that covers their launch: benign)
     }
     const dim3 grid((N + RT_RPB - 1) / RT_RPB), block(RT_RPB * MIPSF_WAVE);
 #define RT_LAUNCH(D, K)                                                                                                         \
@@ -1149,10 +1153,11 @@ int mipsf_render_fwd(const mipsf_render_fwd_args* a_in, void* stream) {
         MIPSF_REQUIRE(a->draw == nullptr || (ticket && loss_total && S <= RT_MAX_S),
                       "draw: the one-launch form with the objective (ticket, loss_weights, loss_total) and S <= %u", RT_MAX_S);
         if (ticket && S <= RT_MAX_S) {      // one launch, the ray read once; with `draw` also the backward of the objective
-            if (int e = launch_render_train(raw, z_vals, target_rgb, target_d, rc, rgb, depth, depth_var, disp, acc, weights, partial,
-                                            N, S, fin, a->draw, s))
-                return e;
-            return check_launch("render_fwd");
+            const int e = launch_render_train(raw, z_vals, target_rgb, target_d, rc, rgb, depth, depth_var, disp, acc, weights, partial,
+                                              N, S, fin, a->draw, s);
+            if (e > 0) return e;
+            if (e == 0) return check_launch("render_fwd");
+            MIPSF_REQUIRE(a->draw == nullptr, "draw: this device does not grant render_train_kernel's %u bytes of LDS", RT_RPB * S * 40u);
         }
         if (ticket) {       // one launch: the last workgroup finishes the losses
             constexpr int RPB = 16;
@@ -1188,10 +1193,10 @@ static int render_fwd_sums(const float* raw, const float* z_vals, const float* t
     }
     const LossFinalize fin = {counts, ticket, nullptr, nullptr, nullptr, sums};
     if (S <= RT_MAX_S) {
-        if (int e = launch_render_train(raw, z_vals, target_rgb, target_d, to_render_cfg(*cfg), rgb, depth, depth_var, disp, acc, weights,
-                                        partial, N, S, fin, nullptr, s))
-            return e;
-        return check_launch("render_fwd_sums");
+        const int e = launch_render_train(raw, z_vals, target_rgb, target_d, to_render_cfg(*cfg), rgb, depth, depth_var, disp, acc, weights,
+                                          partial, N, S, fin, nullptr, s);
+        if (e > 0) return e;
+        if (e == 0) return check_launch("render_fwd_sums");
     }
     constexpr int RPB = 16;
     hipLaunchKernelGGL((render_fwd_kernel<true, true, RPB>), dim3((N + RPB - 1) / RPB), dim3(RPB * MIPSF_WAVE), 0, s, raw, z_vals,

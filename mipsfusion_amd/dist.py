@@ -10,6 +10,15 @@ from typing import List
 import torch
 import torch.distributed as dist
 
+# Test switch (tests/test_gpu_dist.py): with one rank the collectives below are skipped -- there is nothing to exchange.  Set, a
+# one-rank process group runs them anyway, so that the RCCL entry points (all_reduce, all_gather, reduce_scatter_tensor,
+# all_gather_into_tensor) execute on the one GPU a test box has; the results must equal the skipped path's.
+FORCE_COLLECTIVES = False
+
+
+def _single(world: int) -> bool:
+    return world == 1 and not FORCE_COLLECTIVES
+
 
 def share_of(n: int, rank: int, world: int):
     """Contiguous share [begin, end) of n items for `rank` of `world` (sizes differ by at most one)."""
@@ -28,7 +37,7 @@ def rank_world(group=None):
 def all_reduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
     """In-place SUM all-reduce of a small tensor (pose gradients, prediction tables).  RCCL on GPU tensors; with the
     gloo debugging backend a GPU tensor takes a host round trip.  No-op without a process group."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or _single(dist.get_world_size(group)):
         return t
     if dist.get_backend(group) == "gloo" and t.is_cuda:
         h = t.detach().cpu()
@@ -73,7 +82,7 @@ def max_over_ranks(seconds: float, device, group=None) -> float:
 def all_gather_ragged(mine: torch.Tensor, n_total: int, world: int, group=None) -> torch.Tensor:
     """Contiguous shares of an [n_total, ...] tensor (share sizes differ by at most one, see
     inference.share_of) -> the whole tensor on every rank.  One all_gather of equal-size padded blocks."""
-    if not (dist.is_available() and dist.is_initialized()) or world == 1:
+    if not (dist.is_available() and dist.is_initialized()) or _single(world):
         return mine
     base, extra = divmod(n_total, world)
     block = base + (1 if extra else 0)
@@ -95,6 +104,6 @@ def gather_particle_results(local_rows: torch.Tensor, n_particles: int, group=No
     (mean masked |sdf| and the 7-D particle pose per particle); -> [n_particles, C] on every rank, in particle order,
     so that every rank performs the identical swarm update.  One all_gather of n_particles*C floats (64 KB at 2000 x 8)."""
     rank, world = rank_world(group)
-    if world == 1:
+    if _single(world):
         return local_rows
     return all_gather_ragged(local_rows.contiguous(), n_particles, world, group=group)

@@ -22,10 +22,19 @@ class MLP_reg(nn.Module):
         self.n_class = n_class
         self.max_class_Id = n_class - 1
         self.beta = beta
-        if (self.input_ch, self.input_ch_pos, n_hidden, n_hidden_rgb, n_hidden_sdf, n_hidden_branch, n_class) != \
-                (32, 51, 128, 64, 64, 128, 5):
-            raise ValueError("the HIP decoder is built for the reference architecture "
-                             "(grid 32, pos 48+3, hidden 128, rgb/sdf embedding 64, branch 128, 5 classes)")
+        # STATED LIMIT: the kernels are generated for ONE architecture -- the only one the reference's callers
+        # ever build (model/scene_rep.py:45 passes input_ch / input_ch_pos of its two encodings and leaves every width at its
+        # default; model/decoder.py:7-16 would accept others).  Operand images, LDS budgets and register tiles are sized by
+        # these numbers at compile time (csrc/decoder_layout.h); another width is refused here, by name, not mis-computed.
+        want = {"input_ch": 32, "input_ch_pos (+3)": 51, "n_hidden": 128, "n_hidden_rgb": 64, "n_hidden_sdf": 64,
+                "n_hidden_branch": 128, "n_class": 5}
+        got = {"input_ch": self.input_ch, "input_ch_pos (+3)": self.input_ch_pos, "n_hidden": n_hidden, "n_hidden_rgb": n_hidden_rgb,
+               "n_hidden_sdf": n_hidden_sdf, "n_hidden_branch": n_hidden_branch, "n_class": n_class}
+        bad = [f"{k} = {got[k]} (kernels: {want[k]})" for k in want if got[k] != want[k]]
+        if bad:
+            raise ValueError("mipsfusion_amd.model.MLP_reg: the HIP decoder kernels are built for the reference's architecture "
+                             "(HashGrid 16 x 2 = 32 features, Frequency 8 bins x 2 x 3 + 3 = 51, hidden 128, rgb / sdf embeddings "
+                             "64, branch 128, 5 classes; model/scene_rep.py:37-45) -- unsupported: " + "; ".join(bad))
         self.pts_linear = nn.Sequential(nn.Linear(self.input_ch_pos, n_hidden), nn.ReLU(),
                                         nn.Linear(n_hidden, n_hidden_sdf + n_hidden_rgb))
         self.rgb_linear = nn.Sequential(nn.Linear(n_hidden_rgb + self.input_ch_pos, 3))

@@ -218,7 +218,8 @@ class _RenderFn(torch.autograd.Function):
         g_total = ops._f32c(g_total).reshape(1) if (g_total is not None and loss_w is not None) else None
         if ctx.draw is not None and not ctx.draw_stale and g_total is not None and g_losses is None and g_rgb is None and g_depth is None:
             # the forward launch has written d objective / d raw for an objective gradient of exactly 1
-            if g_total.data_ptr() == ops.unit_grad(raw.device).data_ptr():
+            one = ops.unit_grad(raw.device)
+            if g_total.data_ptr() == one.data_ptr() and one._version == 0:      # (never written in place since torch.ones made it)
                 return ctx.draw, None, None, None, None, None, None, None, None, None, None     # ... and this IS that gradient
             ctx.draw_stale = True         # the kernel decides on the device (g_total == 1: returns at once), so after this call
             draw = ops.render_bwd(raw, z_vals, target_rgb, target_d, counts, losses, ctx.rc, None, None, None, ctx.N, ctx.S,
@@ -317,7 +318,7 @@ class JointEncoding(nn.Module):
         if key not in self._tables:
             tr, cam = self.config["training"], self.config["cam"]
             if guided:
-                zu = torch.linspace(cam["near"], cam["far"], tr["n_samples_d"])
+                zu = torch.linspace(cam["near"], cam["far"], max(0, tr["n_samples_d"]))
                 zoff = torch.linspace(-tr["range_d"], tr["range_d"], steps=tr["n_range_d"])
                 znd = torch.linspace(cam["near"], cam["far"], steps=tr["n_range_d"])
                 self._tables[key] = tuple(t.to(device=device, dtype=torch.float32).contiguous() for t in (zu, zoff, znd))
@@ -414,9 +415,9 @@ class JointEncoding(nn.Module):
         tr = self.config["training"]
         N = rays_o.shape[0]
         guided = target_d is not None
-        if guided and tr["n_samples_d"] <= 0:
-            raise ValueError("training.n_samples_d must be > 0 (every reference config sets it)")
-        n_uniform = tr["n_samples_d"] if guided else tr["n_samples"]
+        # (training.n_samples_d = 0 is the reference's `z_vals = z_samples` branch, scene_rep.py:166-167: the merge with an empty
+        # uniform list leaves the depth-guided samples in their own order)
+        n_uniform = max(0, tr["n_samples_d"]) if guided else tr["n_samples"]
         n_near = tr["n_range_d"] if guided else 0
         S = n_uniform + n_near
         rc = self._rc(n_uniform, n_near, emd_w)
@@ -496,9 +497,7 @@ class JointEncoding(nn.Module):
         if not self.training:
             raise RuntimeError("forward_from_table is the training branch (use forward / render_rays for evaluation)")
         tr = self.config["training"]
-        if tr["n_samples_d"] <= 0:
-            raise ValueError("training.n_samples_d must be > 0 (every reference config sets it)")
-        n_uniform, n_near = tr["n_samples_d"], tr["n_range_d"]
+        n_uniform, n_near = max(0, tr["n_samples_d"]), tr["n_range_d"]      # (0: scene_rep.py:166-167)
         S, N = n_uniform + n_near, rows.shape[0]
         rc = self._rc(n_uniform, n_near, float(EMD_w))
         if rc.perturb and noise is None:

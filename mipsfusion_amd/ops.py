@@ -567,7 +567,9 @@ _UNIT_GRAD = {}
 def unit_grad(device):
     """THE root gradient of a plain ``loss.backward()``: one cached fp32 scalar 1.0 per device (helper_functions.utils.
     backward_from_one passes it).  ``_RenderFn.backward`` recognises it by address -- the gradient of the objective is then known
-    to be exactly 1 on the host, and the gradient the forward launch has already written is returned without a launch."""
+    to be exactly 1 on the host, and the gradient the forward launch has already written is returned without a launch.  READ-ONLY:
+    a caller that scales it in place (loss scaling) turns the shortcut off for good -- the tensor's version counter is checked,
+    and the device-side check of ``MIPSF_RENDER_BWD_KEEP_IF_UNIT`` decides from then on."""
     dev = torch.device(device)
     if dev.type == "cuda" and dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())

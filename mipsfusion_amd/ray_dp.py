@@ -28,6 +28,7 @@ from typing import Callable, List, Optional, Sequence
 import torch
 import torch.distributed as dist
 
+from . import dist as _mdist
 from .dist import all_reduce_sum_, rank_world, share_of
 
 
@@ -66,7 +67,10 @@ class ShardedFlatAdam:
         self.opt = make_optimizer(self.shard)
 
     def _backend_is_gloo(self):
-        return self.world > 1 and dist.get_backend(self.group) == "gloo"
+        return not self._single() and dist.get_backend(self.group) == "gloo"
+
+    def _single(self):          # (one rank: nothing to exchange -- unless the test switch asks for the collectives anyway)
+        return self.world == 1 and not (_mdist.FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
 
     @torch.no_grad()
     def step(self):
@@ -81,7 +85,7 @@ class ShardedFlatAdam:
         else:
             g_full = g
         out = self.shard.grad
-        if self.world == 1:
+        if self._single():
             out.copy_(g_full[self.begin:self.begin + self.per])
         elif self._backend_is_gloo():
             # gloo has no reduce-scatter: all-reduce and keep the slice (CPU tests; a GPU tensor takes a host round trip)
@@ -92,7 +96,7 @@ class ShardedFlatAdam:
             dist.reduce_scatter_tensor(out, g_full, op=dist.ReduceOp.SUM, group=self.group)
         self.opt.step()
         g.zero_()
-        if self.world > 1:
+        if not self._single():
             if self._backend_is_gloo():
                 mine = self.shard.data.detach().cpu() if self.shard.is_cuda else self.shard.data.clone()
                 parts = [torch.empty_like(mine) for _ in range(self.world)]
@@ -156,7 +160,7 @@ class RayDataParallelStep:
 
     def reduce_share(self, t: torch.Tensor) -> torch.Tensor:
         """sum of a small fp64 vector over the ranks (the nine loss sums + the ray count of every share)"""
-        if self.world > 1:
+        if self.world > 1 or _mdist.FORCE_COLLECTIVES:
             all_reduce_sum_(t, self.group)
         return t
 
@@ -167,7 +171,7 @@ class RayDataParallelStep:
     def _sum_grads(self, params):
         """one all-reduce for a list of small gradients (flattened into one buffer: a collective per tensor would be ten
         latency-bound calls)"""
-        if self.world == 1:
+        if self.world == 1 and not _mdist.FORCE_COLLECTIVES:
             return
         grads = [p.grad for p in params if p.grad is not None]
         if not grads:

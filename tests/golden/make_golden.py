@@ -13,6 +13,7 @@ Files written
   scene_cfg1.npz     model/scene_rep.py:153-238 render_rays / forward (train, EMD 0.01 and 0, eval)
                      + gradients, BASELINE config 1 (256 rays x 16 samples, hash 2^10)
   scene_s75.npz      same with the reference's default S = 50 + 25 (> one wavefront), 64 rays
+  scene_nd0.npz      same with training.n_samples_d = 0 (scene_rep.py:166-167: the depth-guided samples alone), 64 rays
   adam.npz           torch.optim.Adam with the two param groups of mipsfusion.py:580-584
   quaternion.npz     geometry_helper.py:11-17 qt_to_transform_matrix (+ grads) [pytorch3d unpinned]
   ba_trace.npz       loss-per-iteration trace of a 6-iteration local-BA-style loop (mipsfusion.py:293-342)
@@ -197,6 +198,14 @@ def scene_case(cfg, n_rays, name, seed):
             if v.numel():
                 arrays[f"{tag}.g.{k}"] = v.grad
     save(name, **arrays)
+
+
+def gen_scene_nd0():
+    """training.n_samples_d = 0: the branch `z_vals = z_samples` of model/scene_rep.py:166-167 -- the depth-guided samples
+    alone, no uniform list, no sort.  No shipped configuration sets it; the reference accepts it."""
+    c = synth.config_plumbing()
+    c["training"].update(n_samples_d=0, n_range_d=16, n_samples=16)
+    scene_case(c, 64, "scene_nd0.npz", seed=10)
 
 
 # ---------------------------------------------------------------------------- adam
@@ -492,6 +501,7 @@ if __name__ == "__main__":
     c75 = synth.config_plumbing()
     c75["training"].update(n_samples_d=50, n_range_d=25, n_samples=75)
     scene_case(c75, 64, "scene_s75.npz", seed=9)
+    gen_scene_nd0()
     gen_adam()
     gen_quaternion()
     gen_ba_trace()

@@ -1,4 +1,5 @@
-"""CPU, world_size 2, gloo: the N>1 path of bench.py (submap ownership + pose all_gather + max-over-ranks timing)."""
+"""CPU, gloo, world sizes 2 and 8 (BASELINE config 4 is 8 sub-maps on 8 ranks): the N>1 path of bench.py (submap ownership +
+pose all_gather + max-over-ranks timing), the sharded global BA, the particle split and ray-data-parallel training."""
 import os
 import socket
 
@@ -40,28 +41,34 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_pose_exchange_and_ownership_world2():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 8])
+def test_pose_exchange_and_ownership(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    covered = []
     for rank, allp, t, owned, gathered, share in res:
         allp, gathered = torch.from_numpy(allp), torch.from_numpy(gathered)
         assert torch.equal(gathered, torch.arange(33, dtype=torch.float32).reshape(11, 3))
-        assert share == ((0, 6) if rank == 0 else (6, 11))
-        assert allp.shape == (2, 4, 7)
-        for src in range(2):
+        if world == 2:
+            assert share == ((0, 6) if rank == 0 else (6, 11))
+        covered += list(range(*share))
+        assert 1 <= share[1] - share[0] <= -(-11 // world)        # contiguous, ragged by at most one ray
+        assert allp.shape == (world, 4, 7)
+        for src in range(world):
             assert torch.equal(allp[src, :, :4], torch.full((4, 4), float(src)) + torch.arange(4)[:, None])
             assert torch.equal(allp[src, :, 4:], torch.full((4, 3), 10.0 * src))
-        assert t == 1.5                               # slowest rank
-        assert owned == [s for s in range(8) if s % 2 == rank]
-    assert sorted(res[0][3] + res[1][3]) == list(range(8))   # a partition of the submaps
+        assert t == 0.5 + world - 1                   # slowest rank
+        assert owned == [s for s in range(8) if s % world == rank]
+    assert covered == list(range(11))                 # the shares partition the rays in order
+    assert sorted(sum((r[3] for r in res), [])) == list(range(8))   # a partition of the submaps
 
 
 def test_single_process_is_a_noop():
@@ -76,7 +83,7 @@ def test_single_process_is_a_noop():
 # all-reduce, and the RandomOptimizer particle split.  The arithmetic core of mipsfusion_amd.global_ba is plain torch
 # and its network query is injected, so the collective logic runs here on CPU tensors with the ORACLE's sub-map models.
 def _gba_problem(seed=0, n_sub=3, n_iter=4, bs=48):
-    """Three small sub-maps (hash 2^10) with perturbed anchors, pair terms (0,1), (1,2) + one loop-closing term."""
+    """n_sub small sub-maps (hash 2^10) with perturbed anchors, pair terms (k, k + 1) + one loop-closing term (n_sub - 1, 0)."""
     import numpy as np
     from mipsfusion_amd import synth
     from oracle import path_cpu
@@ -98,7 +105,7 @@ def _gba_problem(seed=0, n_sub=3, n_iter=4, bs=48):
     batches = []
     for it in range(n_iter):
         terms = []
-        for (i, j) in ((0, 1), (1, 2)):
+        for (i, j) in [(k, k + 1) for k in range(n_sub - 1)]:
             idx = torch.randint(0, H * W, (bs,), generator=g)
             r, c = idx // W, idx % W
             rays = torch.cat([f["direction"][r, c], f["rgb"][r, c], f["depth"][r, c][:, None]], -1)
@@ -109,7 +116,7 @@ def _gba_problem(seed=0, n_sub=3, n_iter=4, bs=48):
         r, c = idx // W, idx % W
         rays = torch.cat([f["direction"][r, c], f["rgb"][r, c], f["depth"][r, c][:, None]], -1)
         mask = (torch.rand(bs // 2, 1, generator=g) > 0.3).float()
-        terms.append((2, 0, rays, anchors[2][None].clone(), 100.0, mask))          # get_SDF_dif2-style term
+        terms.append((n_sub - 1, 0, rays, anchors[n_sub - 1][None].clone(), 100.0, mask))          # get_SDF_dif2-style term
         batches.append(terms)
     return cfg, models, anchors, batches
 
@@ -124,17 +131,16 @@ def _gba_run(models, anchors, batches, trunc, owned, accum, group=None):
     return ba.result(), trace
 
 
-def _gba_worker(rank, world, port, q):
+def _gba_worker(rank, world, port, q, n_sub, P):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        torch.set_num_threads(2)
-        cfg, models, anchors, batches = _gba_problem()
-        owned = mdist.submaps_of_rank(len(models), world, rank)                 # rank 0: {0, 2}, rank 1: {1}
+        torch.set_num_threads(1 if world > 2 else 2)
+        cfg, models, anchors, batches = _gba_problem(n_sub=n_sub)
+        owned = mdist.submaps_of_rank(len(models), world, rank)                 # 3 / 2: rank 0: {0, 2}, rank 1: {1}
         poses, trace = _gba_run(models, anchors, batches, cfg["training"]["trunc"], owned, accum=2)
         # particle split (row 3): each rank contributes its share of [P, 8] rows
-        P = 11
         lo, hi = mdist.share_of(P, rank, world)
         rows = torch.arange(P * 8, dtype=torch.float32).reshape(P, 8)
         full = mdist.gather_particle_results(rows[lo:hi].clone(), P)
@@ -143,33 +149,40 @@ def _gba_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_sharded_global_ba_world2_equals_single_process_and_oracle():
-    """World-2 sharded global BA (prediction-table + (n-1)x7 pose-gradient all-reduces) == the single-process run of
-    the same class == oracle/global_ba_cpu.py's restatement of InactiveMap.global_BA_overlapping."""
+@pytest.mark.parametrize("world,n_sub,P", [(2, 3, 11), (8, 8, 2000)])
+def test_sharded_global_ba_equals_single_process_and_oracle(world, n_sub, P):
+    """Sharded global BA (prediction-table + (n-1)x7 pose-gradient all-reduces) == the single-process run of the same class ==
+    oracle/global_ba_cpu.py's restatement of InactiveMap.global_BA_overlapping; two ranks with three sub-maps, and BASELINE
+    config 4's shape: eight sub-maps, one per rank, eight anchors.  Beside it the RandomOptimizer's particle split: 11 rows over
+    2 ranks, the reference's 2000 particles over 8."""
     from oracle import global_ba_cpu
-    cfg, models, anchors, batches = _gba_problem()
+    cfg, models, anchors, batches = _gba_problem(n_sub=n_sub)
     trunc = cfg["training"]["trunc"]
     ref_poses, ref_trace = global_ba_cpu.optimise(models, anchors, batches, trunc, pose_accum_step=2)
     one_poses, one_trace = _gba_run(models, anchors, batches, trunc, owned=range(len(models)), accum=2)
     assert torch.allclose(one_poses, ref_poses, atol=1e-6) and torch.allclose(torch.tensor(one_trace),
                                                                              torch.tensor(ref_trace), rtol=1e-5)
     assert not torch.allclose(ref_poses[1:], anchors[1:], atol=1e-4), "the anchors must actually move"
-    world, port = 2, _free_port()
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_gba_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_gba_worker, args=(r, world, port, q, n_sub, P)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert res[0][4] == [0, 2] and res[1][4] == [1]
+    if world == 2:
+        assert res[0][4] == [0, 2] and res[1][4] == [1]
+    else:
+        assert [r[4] for r in res] == [[k] for k in range(8)]          # one sub-map per rank
     for rank, poses, trace, full, _ in res:
         assert torch.allclose(torch.from_numpy(poses), ref_poses, atol=2e-6), f"rank {rank} anchors"
         assert torch.allclose(torch.tensor(trace), torch.tensor(ref_trace), rtol=1e-5), f"rank {rank} loss trace"
-        assert torch.equal(torch.from_numpy(full), torch.arange(88, dtype=torch.float32).reshape(11, 8))
-    assert (res[0][1] == res[1][1]).all(), "every rank must hold bit-identical anchors (same all-reduced gradient)"
+        assert torch.equal(torch.from_numpy(full), torch.arange(P * 8, dtype=torch.float32).reshape(P, 8))
+    for r in res[1:]:
+        assert (res[0][1] == r[1]).all(), "every rank must hold bit-identical anchors (same all-reduced gradient)"
 
 
 # ------------------------------------------------------------------------ ray-data-parallel training (SURVEY 8e row 2)
@@ -208,13 +221,14 @@ def _toy_optimisers():
             lambda ps: torch.optim.Adam(ps, lr=1e-3))
 
 
-def _ray_dp_worker(rank, world, port, q, n_table):
+def _ray_dp_worker(rank, world, port, q, n_table, n_rays):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from mipsfusion_amd.ray_dp import RayDataParallelStep
         torch.manual_seed(0)
+        torch.set_num_threads(1)
         m = _ToyScene(n_table)
         pose = torch.nn.Parameter(torch.tensor([0.1, -0.2, 0.3]))
         g_opt, d_opt, p_opt = _toy_optimisers()
@@ -222,8 +236,8 @@ def _ray_dp_worker(rank, world, port, q, n_table):
         assert m.ray_share_reduce is not None
         gen = torch.Generator().manual_seed(9)
         for it in range(4):
-            x = torch.randn(11, 3, generator=gen)                 # the SAME batch on every rank ...
-            b, e = rdp.my_share(11)                               # ... of which each renders its (ragged) share
+            x = torch.randn(n_rays, 3, generator=gen)             # the SAME batch on every rank ...
+            b, e = rdp.my_share(n_rays)                               # ... of which each renders its (ragged) share
             (m.objective(x[b:e] + pose, x[b:e])).backward()
             if it == 2:                                           # the replica is reloaded between steps (recover_initial_param)
                 with torch.no_grad():
@@ -235,24 +249,26 @@ def _ray_dp_worker(rank, world, port, q, n_table):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_table", [12, 11])
-def test_ray_data_parallel_step_world2_equals_the_single_process_step(n_table):
-    """RayDataParallelStep over two gloo ranks (reduce-scatter -> sharded Adam -> all-gather; the batch's counts summed inside
-    the forward, the shares' gradients SUMMED): both ranks end with bit-identical parameters, equal to ONE process that runs
-    the same objective on the WHOLE batch and the plain optimisers -- the step mipsfusion.py:325-335 takes (n_table 11: the
-    padded path, whose private copy must follow a reload of the replica)."""
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world,n_table,n_rays", [(2, 12, 11), (2, 11, 11), (8, 16, 19), (8, 11, 19)])
+def test_ray_data_parallel_step_equals_the_single_process_step(world, n_table, n_rays):
+    """RayDataParallelStep over gloo ranks (reduce-scatter -> sharded Adam -> all-gather; the batch's counts summed inside the
+    forward, the shares' gradients SUMMED): all ranks end with bit-identical parameters, equal to ONE process that runs the same
+    objective on the WHOLE batch and the plain optimisers -- the step mipsfusion.py:325-335 takes.  Two ranks and eight; a table
+    that divides by the world size and one that does not (the padded path, whose private copy must follow a reload of the
+    replica); ragged ray shares."""
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_ray_dp_worker, args=(r, world, port, q, n_table)) for r in range(world)]
+    procs = [ctx.Process(target=_ray_dp_worker, args=(r, world, port, q, n_table, n_rays)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, t0, d0, p0), (_, t1, d1, p1) = res
-    assert (t0 == t1).all() and all((a == b).all() for a, b in zip(d0, d1)) and (p0 == p1).all(), "ranks diverged"
+    (_, t0, d0, p0) = res[0]
+    for (_, t1, d1, p1) in res[1:]:
+        assert (t0 == t1).all() and all((a == b).all() for a, b in zip(d0, d1)) and (p0 == p1).all(), "ranks diverged"
     torch.manual_seed(0)
     m = _ToyScene(n_table)
     pose = torch.nn.Parameter(torch.tensor([0.1, -0.2, 0.3]))
@@ -260,7 +276,7 @@ def test_ray_data_parallel_step_world2_equals_the_single_process_step(n_table):
     og, od, op_ = g_opt(m.embed_fn.params), d_opt(list(m.decoder.parameters())), p_opt([pose])
     gen = torch.Generator().manual_seed(9)
     for it in range(4):
-        x = torch.randn(11, 3, generator=gen)
+        x = torch.randn(n_rays, 3, generator=gen)
         m.objective(x + pose, x).backward()                       # the whole batch, one process
         if it == 2:
             with torch.no_grad():

@@ -306,10 +306,12 @@ def cfg_for(name):
     cfg = synth.config_plumbing()
     if name == "scene_s75.npz":
         cfg["training"].update(n_samples_d=50, n_range_d=25, n_samples=75)
+    if name == "scene_nd0.npz":         # scene_rep.py:166-167: no uniform samples, z_vals = the depth-guided ones
+        cfg["training"].update(n_samples_d=0, n_range_d=16, n_samples=16)
     return cfg
 
 
-@pytest.mark.parametrize("name", ["scene_cfg1.npz", "scene_s75.npz"])
+@pytest.mark.parametrize("name", ["scene_cfg1.npz", "scene_s75.npz", "scene_nd0.npz"])
 def test_scene_eval_golden(dev, name):
     g = load_golden(name)
     m = make_scene(g, cfg_for(name), dev).eval()
@@ -342,7 +344,7 @@ def assert_rays_close(a, b, tol, what, max_flipped_rays):
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "f32", "bf16x6"])
-@pytest.mark.parametrize("name", ["scene_cfg1.npz", "scene_s75.npz"])
+@pytest.mark.parametrize("name", ["scene_cfg1.npz", "scene_s75.npz", "scene_nd0.npz"])
 @pytest.mark.parametrize("tag,emd", [("emd", 0.01), ("noemd", 0.0)])
 def test_scene_train_golden(dev, name, tag, emd, precision):
     """The reference's own training step on its own fixtures.  "f32" (fp32-input MFMA) and "bf16x6" (fp32 operands carried

@@ -4,6 +4,7 @@ No compute kernel is launched here."""
 import ctypes as C
 import math
 import os
+import time
 import random
 import re
 
@@ -536,8 +537,19 @@ def test_bench_line_is_compact_and_carries_the_contract(record):
         assert line["frame"]["tracking_plus_mapping_ms_per_frame"] == out["frame"]["tracking_plus_mapping_ms_per_frame"]
     if (out.get("variants") or {}).get("unchanged_caller"):
         assert line["unchanged_caller_ms_per_step"] == out["variants"]["unchanged_caller"]["ms_per_step"]
+    # the board's state while the region was timed (round 6): carried when the run sampled it, null on the line otherwise
+    assert "board" in line and line["board"] is None
+    withb = dict(out)
+    withb["board"] = {"sclk_mhz_median": 1843.0, "sclk_mhz_min": 1712.0, "power_w_median": 1398.2, "samples": 57, "source": "x" * 400}
+    withb["step_ms_stats"] = {"steps": 200, "min": 0.63, "median": 0.6416, "p95": 0.66, "max": 0.7}
+    withb["value_at_median_step"] = 4.0e8
+    text = bench.compact_line(withb)
+    assert len(text) < bench.LINE_LIMIT
+    lb = json.loads(text)
+    assert lb["board"] == {"sclk_mhz_median": 1843.0, "sclk_mhz_min": 1712.0, "power_w_median": 1398.2, "samples": 57}
+    assert lb["value_at_median_step"] == 4.0e8
     # worst case: hundreds of kernels and variants -> optional blocks are dropped, the contract stays
-    fat = dict(out)
+    fat = dict(withb)
     fat["kernels"] = {f"kernel_with_a_long_name_{i}": {"avg_ms": 0.123456, "frac": 0.5} for i in range(400)}
     fat["variants"] = {f"variant_{i}": {"ms_per_step": 1.0} for i in range(300)}
     text = bench.compact_line(fat)
@@ -545,6 +557,17 @@ def test_bench_line_is_compact_and_carries_the_contract(record):
     line = json.loads(text)
     for k in bench.REQUIRED_LINE_KEYS:
         assert k in line, k
+    assert line["board"]["power_w_median"] == 1398.2          # (the board block is not one of the droppable ones)
+
+
+def test_board_sampler_without_a_gpu_reports_nothing_and_does_not_fail():
+    bench = _load_bench_module()
+    with bench.BoardSampler(0, period=0.001) as b:
+        time.sleep(0.01)
+    sm = b.summary()
+    assert set(sm) >= {"sclk_mhz_median", "power_w_median", "samples", "source"}
+    if b.card is None:
+        assert sm["sclk_mhz_median"] is None and sm["samples"] == 0
 
 
 def test_bench_launcher_process_keeps_its_affinity_mask():
@@ -607,3 +630,17 @@ def test_host_rng_sessions_exclude_each_other_and_ray_dp_refuses_a_model_without
     with RayDataParallelStep(m, mk, mk) as rdp:
         assert m.ray_share_reduce == rdp.reduce_share
     assert m.ray_share_reduce is None
+
+
+def test_decoder_widths_outside_the_reference_architecture_are_refused_by_name():
+    """model/decoder.py:7-16 takes any widths; every caller of the reference builds the defaults (scene_rep.py:45).  The HIP
+    kernels exist for that architecture only: another width must fail at construction with a message that names
+    the argument, not later inside a kernel."""
+    from mipsfusion_amd.model.decoder import MLP_reg
+    MLP_reg({}, input_ch=32, input_ch_pos=48)                                   # the reference's call
+    with pytest.raises(ValueError, match=r"n_hidden = 256 \(kernels: 128\)"):
+        MLP_reg({}, input_ch=32, input_ch_pos=48, n_hidden=256)
+    with pytest.raises(ValueError, match=r"n_class = 7 .*n_class|n_class = 7"):
+        MLP_reg({}, input_ch=32, input_ch_pos=48, n_class=7)
+    with pytest.raises(ValueError, match=r"input_ch = 16"):
+        MLP_reg({}, input_ch=16, input_ch_pos=48)

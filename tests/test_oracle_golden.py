@@ -32,6 +32,8 @@ def cfg_for(name):
     cfg = synth.config_plumbing()
     if name == "scene_s75.npz":
         cfg["training"].update(n_samples_d=50, n_range_d=25, n_samples=75)
+    if name == "scene_nd0.npz":         # scene_rep.py:166-167: no uniform samples, z_vals = the depth-guided ones
+        cfg["training"].update(n_samples_d=0, n_range_d=16, n_samples=16)
     return cfg
 
 
@@ -42,7 +44,7 @@ def scene_from(g, cfg):
     return m
 
 
-@pytest.mark.parametrize("name", ["scene_cfg1.npz", "scene_s75.npz"])
+@pytest.mark.parametrize("name", ["scene_cfg1.npz", "scene_s75.npz", "scene_nd0.npz"])
 def test_scene_eval_matches_reference(name):
     g = load_golden(name)
     cfg = cfg_for(name)
@@ -59,7 +61,7 @@ def test_scene_eval_matches_reference(name):
     close(nd["depth"], g["nodepth.depth"], rtol=2e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("name", ["scene_cfg1.npz", "scene_s75.npz"])
+@pytest.mark.parametrize("name", ["scene_cfg1.npz", "scene_s75.npz", "scene_nd0.npz"])
 @pytest.mark.parametrize("tag,emd", [("emd", 0.01), ("noemd", 0.0)])
 def test_scene_train_and_grads_match_reference(name, tag, emd):
     g = load_golden(name)

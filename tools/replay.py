@@ -131,7 +131,10 @@ def main():
         calls = [(n, a) for n, a in calls if re.search(only, n)]
     print(f"recorded {len(rec.calls)} calls, replaying {len(calls)}; loss {float(loss):.5f}; live tile share {live}")
     reps = int(os.environ.get("REPLAY_REPS", "20"))
-    libs = [("base", base)] + [(n, open_lib(os.path.join(ROOT, "tools", "micro", f"libv_{n}.so"))) for n in names if n != "base"]
+    # "base" (the in-tree library) is always measured first; naming it again ("base2") measures it once more in that position --
+    # the drift of the box over the run
+    libs = [("base", base)] + [(n, base if n.startswith("base") else open_lib(os.path.join(ROOT, "tools", "micro", f"libv_{n}.so")))
+                               for n in names if n != "base"]
     table_out = {}
     for lname, h in libs:
         evs = [[] for _ in calls]
