@@ -3,7 +3,7 @@
 # summarised per kernel; default program: bench.py, PMC_PASSES="1 3" restricts the passes
 TAG=$1
 shift
-if [ $# -gt 0 ]; then PROG="$GRAFT_REPO_ROOT/$1"; shift; ARGS="$@"; else PROG="$GRAFT_REPO_ROOT/bench.py"; ARGS="--steps 4 --warmup 2 --setup-iters 4 --cpu-rays 0 --no-frame-estimate"; fi
+if [ $# -gt 0 ]; then PROG="$GRAFT_REPO_ROOT/$1"; shift; ARGS="$@"; else PROG="$GRAFT_REPO_ROOT/bench.py"; ARGS="--steps 5 --warmup 5 --stats-steps 10 --setup-iters 4 --cpu-rays 0 --no-frame-estimate --no-variants"; fi
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
