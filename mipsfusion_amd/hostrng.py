@@ -157,6 +157,12 @@ def available(threads: int = 4) -> bool:
 # back -- a second thread doing the same in between (the frame loop's sample producer, a caller's own worker) would have
 # its draws overwritten or duplicated.  (Re-entrant only so that a mistaken nested session cannot deadlock its own thread; a
 # nested session's draws are lost when the outer one puts ITS state back -- draw through the session you hold.)
+# CONTRACT for callers with a producer thread (sequence.py's sample producer holds a session for a whole frame plan, including
+# bounded-queue puts that wait for the top-k stage): another thread that opens a session meanwhile WAITS for that plan to
+# finish -- milliseconds, never a deadlock as long as the stage that drains the queue opens no session itself (it does not:
+# the top-k half is generator-free).  That wait is the point: the generator's stream is ONE sequence in the reference's call
+# order, and a draw squeezed in between the producer's would change every index after it.  Code that needs draws in a fixed
+# place of the stream asks the producer for them (the frame plan) instead of opening its own session.
 _SESSION_LOCK = threading.RLock()
 
 
