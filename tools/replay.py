@@ -156,6 +156,36 @@ def main():
             table_out.setdefault((k, n), {})[lname] = us
         report_wgrad_trace(lname, h)
         report_chain_trace(lname, h, calls)
+    if os.environ.get("REPLAY_CLOCK"):
+        # the board's state under each replayed call alone: the call in a loop for REPLAY_CLOCK seconds (in-tree library), shader
+        # clock and package power sampled beside it (bench.BoardSampler: sysfs pp_dpm_sclk / hwmon) -- is the kernel at the
+        # board's power cap?  (tools/clock_probe.py does this for the decoder forward's forms.)
+        secs = float(os.environ["REPLAY_CLOCK"])
+        import time
+        print(f"board state under each call alone ({secs:.1f} s loops):")
+        with bench.BoardSampler(0, period=0.02) as b0:
+            time.sleep(1.0)
+        print(f"  {'idle':34s} {b0.summary()}")
+        for k, (n, a) in enumerate(calls):
+            fn = getattr(base, n)
+            # (the chain finds its live-tile counters cleared by the forward of the same record: alone in a loop it would
+            # process nothing after the first call -- loop the pair and say so)
+            pre = [(getattr(base, m), b) for m, b in calls[:k] if "fwd16" in m][-1:] if "bwd_chain" in n else []
+            label = n[6:] + (" (+ fwd16 in front)" if pre else "")
+            torch.cuda.synchronize()
+            t0, reps = time.perf_counter(), 0
+            with bench.BoardSampler(0, period=0.02) as bs:
+                while time.perf_counter() - t0 < secs:
+                    for _ in range(50):
+                        for pf, pa in pre:
+                            pf(*pa)
+                        fn(*a)
+                    reps += 50
+                    torch.cuda.synchronize()
+            us = (time.perf_counter() - t0) / reps * 1e6
+            sm = bs.summary()
+            print(f"  {k:2d} {label:38s} {us:8.1f} us/call  sclk median {sm['sclk_mhz_median']} min {sm['sclk_mhz_min']} MHz, "
+                  f"power median {sm['power_w_median']} W ({sm['samples']} samples)")
     w = max(len(n) for _, n in table_out) + 4
     print(" " * w + "".join(f"{l:>12s}" for l, _ in libs))
     tot = {l: 0.0 for l, _ in libs}
