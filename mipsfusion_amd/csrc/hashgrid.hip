@@ -204,6 +204,20 @@ __global__ __launch_bounds__(HG_BLOCK) void hashgrid_fwd_kernel(const float* __r
 //   * the slice is added to dparams with coalesced read-modify-writes; bins with several parts go through
 //     partial slices and a reduce kernel.  No global float atomics, no inter-workgroup communication.
 constexpr int SC_BLOCK = 1024;                      // threads of an accumulate workgroup
+// Layout of the fp64 slice in LDS.  Interleaved ([entry][2 features], round 1) puts every lane of one ds_add_f64 instruction on
+// an address = 0 (or 8) mod 16: half of the LDS banks never take part, and random entries collide twice as often as they must
+// (PMC, rounds 2-5: SQ_LDS_BANK_CONFLICT a third of the kernel's LDS cycles).  Planar ([feature][SC_MAX_SLICE entries]) spreads
+// an instruction's lanes over all banks.
+#ifndef MIPSF_SC_PLANAR
+#define MIPSF_SC_PLANAR 1
+#endif
+#if MIPSF_SC_PLANAR
+#define SC_ACC0(e) (e)
+#define SC_ACC1(e) (sc_plane1 + (e))      /* sc_plane1 = plan.max_slice: the bin counts sit behind 2 x max_slice doubles */
+#else
+#define SC_ACC0(e) (2 * (e))
+#define SC_ACC1(e) (2 * (e) + 1)
+#endif
 #ifndef MIPSF_RT_BLOCK
 #define MIPSF_RT_BLOCK 512
 #endif
@@ -689,6 +703,8 @@ __device__ __forceinline__ void scatter_item(const float* __restrict__ x, const 
                                              const ScatterPlan& plan, uint32_t* __restrict__ ws, double* __restrict__ acc,
                                              const uint4 desc, const uint32_t item_index) {
     const uint32_t item = desc.x;
+    const uint32_t sc_plane1 = plan.max_slice;
+    (void)sc_plane1;
     const uint32_t bin = item & 0xffffu, part = item >> 16;
     const bool single = desc.z == 1u;             // the bin's only work item: its slice goes straight into dparams
     uint32_t level = 0;
@@ -709,8 +725,12 @@ __device__ __forceinline__ void scatter_item(const float* __restrict__ x, const 
     // ... and the current gradient values of the slice are requested now: by the time the records are through they have
     // arrived (they used to cost a memory round trip behind the last barrier, 3 us per item)
     {   // the slice is cleared (only the entries of this level's slice: the fixed cost of an item used to include all 160 KB)
+#if MIPSF_SC_PLANAR
+        for (uint32_t e = threadIdx.x; e < count; e += SC_BLOCK) acc[SC_ACC0(e)] = 0.0, acc[SC_ACC1(e)] = 0.0;
+#else
         double2* z = reinterpret_cast<double2*>(acc);
         for (uint32_t e = threadIdx.x; e < count; e += SC_BLOCK) z[e] = make_double2(0.0, 0.0);
+#endif
     }
     float2* dst = reinterpret_cast<float2*>(dparams) + off + begin;
     constexpr uint32_t FL = SC_MAX_SLICE / SC_BLOCK;
@@ -756,8 +776,8 @@ __device__ __forceinline__ void scatter_item(const float* __restrict__ x, const 
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 if (hit >> c & 1u) {
-                    atomicAdd(&acc[2 * idx[c]], (double)sum[c][0]);
-                    atomicAdd(&acc[2 * idx[c] + 1], (double)sum[c][1]);
+                    atomicAdd(&acc[SC_ACC0(idx[c])], (double)sum[c][0]);
+                    atomicAdd(&acc[SC_ACC1(idx[c])], (double)sum[c][1]);
                 }
             }
             return;
@@ -773,8 +793,8 @@ __device__ __forceinline__ void scatter_item(const float* __restrict__ x, const 
                 v0 = (c == k) ? sum[k][0] : v0;
                 v1 = (c == k) ? sum[k][1] : v1;
             }
-            atomicAdd(&acc[2 * e], (double)v0);
-            atomicAdd(&acc[2 * e + 1], (double)v1);
+            atomicAdd(&acc[SC_ACC0(e)], (double)v0);
+            atomicAdd(&acc[SC_ACC1(e)], (double)v1);
         }
     };
     if (mode != 0) {
@@ -837,14 +857,14 @@ __device__ __forceinline__ void scatter_item(const float* __restrict__ x, const 
                         if (hit >> c & 1u) {
                             const uint32_t e = ((cell.c[0] ^ hz) & (size - 1u)) - begin;
                             const float wgt = ((1.0f - cell.f[0]) * wy) * wz;       // (the order of corner_weights)
-                            atomicAdd(&acc[2 * e], (double)(wgt * gy.x));
-                            atomicAdd(&acc[2 * e + 1], (double)(wgt * gy.y));
+                            atomicAdd(&acc[SC_ACC0(e)], (double)(wgt * gy.x));
+                            atomicAdd(&acc[SC_ACC1(e)], (double)(wgt * gy.y));
                         }
                         if (hit >> (c + 1) & 1u) {
                             const uint32_t e = (((cell.c[0] + 1u) ^ hz) & (size - 1u)) - begin;
                             const float wgt = (cell.f[0] * wy) * wz;
-                            atomicAdd(&acc[2 * e], (double)(wgt * gy.x));
-                            atomicAdd(&acc[2 * e + 1], (double)(wgt * gy.y));
+                            atomicAdd(&acc[SC_ACC0(e)], (double)(wgt * gy.x));
+                            atomicAdd(&acc[SC_ACC1(e)], (double)(wgt * gy.y));
                         }
                     }
                     continue;
@@ -857,8 +877,8 @@ __device__ __forceinline__ void scatter_item(const float* __restrict__ x, const 
                     float wgt = (c & 1) ? cell.f[0] : 1.0f - cell.f[0];
                     wgt = wgt * ((c & 2) ? cell.f[1] : 1.0f - cell.f[1]);
                     wgt = wgt * ((c & 4) ? cell.f[2] : 1.0f - cell.f[2]);
-                    atomicAdd(&acc[2 * e], (double)(wgt * gy.x));
-                    atomicAdd(&acc[2 * e + 1], (double)(wgt * gy.y));
+                    atomicAdd(&acc[SC_ACC0(e)], (double)(wgt * gy.x));
+                    atomicAdd(&acc[SC_ACC1(e)], (double)(wgt * gy.y));
                 }
             }
         }
@@ -929,18 +949,23 @@ __device__ __forceinline__ void scatter_item(const float* __restrict__ x, const 
     }
     __syncthreads();
 
-    const double2* a2 = reinterpret_cast<const double2*>(acc);
+    auto a2 = [&](uint32_t e) { return make_double2(acc[SC_ACC0(e)], acc[SC_ACC1(e)]); };
     if (single) {
 #pragma unroll
         for (uint32_t k = 0; k < FL; ++k) {
             const uint32_t e = threadIdx.x + k * SC_BLOCK;
-            if (e < count) dst[e] = plan.fresh ? make_float2((float)a2[e].x, (float)a2[e].y)
-                                               : make_float2(cur[k].x + (float)a2[e].x, cur[k].y + (float)a2[e].y);
+            if (e < count) {
+                const double2 a = a2(e);
+                dst[e] = plan.fresh ? make_float2((float)a.x, (float)a.y) : make_float2(cur[k].x + (float)a.x, cur[k].y + (float)a.y);
+            }
         }
     } else {
         float2* pdst = reinterpret_cast<float2*>(reinterpret_cast<float*>(ws) + plan.w_partial) +
                        (size_t)item_index * SC_MAX_SLICE;
-        for (uint32_t e = threadIdx.x; e < count; e += SC_BLOCK) pdst[e] = make_float2((float)a2[e].x, (float)a2[e].y);
+        for (uint32_t e = threadIdx.x; e < count; e += SC_BLOCK) {
+            const double2 a = a2(e);
+            pdst[e] = make_float2((float)a.x, (float)a.y);
+        }
     }
 }
 

@@ -1891,8 +1891,11 @@ def test_decoder_bf16x6_matches_fp32_kernel_and_oracle(dev, M, layout):
         finally:
             ops.SKIP_ZERO_TILES = keep
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1]), "short cut: same d feat / d x"
+    # (the live-tile lists are filled through atomics: which workgroup sums which tiles -- the order of the fp32 additions of
+    # the weight gradients -- changes from run to run and with the short cut; 70 000 samples: 5e-7 typically, 1.03e-6 seen in 1
+    # run of 16 on `sdf_linear.2.weight`; the gate is the one of this test's other gradient comparisons)
     for k, a, b in zip(ops.DECODER_PARAM_ORDER, res[True][2], res[False][2]):
-        assert_close(a, b, 1e-6, "short cut, grad " + k)
+        assert_close(a, b, 2e-6, "short cut, grad " + k)
     # ---- the lean records (the default of JointEncoding): the forward leaves H1 out, the chain dG3 and the rgb_emb half of dH2;
     #      the exchange form of the weight-gradient kernel (csrc/wgrad16.hip, three bf16 planes) recomputes all three with the
     #      forward's / the chain's own products in their own order.  Full record through the plain streaming kernel, full record
