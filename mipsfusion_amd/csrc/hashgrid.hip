@@ -406,7 +406,11 @@ __device__ __forceinline__ bool route_groups_hashed_pow2(const Cell& cell, uint3
             m[q] |= same ? m[p] : 0u;
             m[p] = same ? 0u : m[p];
         }
-    return cell.c[0] + 1u < (1u << shift);
+    // (cx AND cx + 1 below 2^shift.  Written as `cx + 1 < 2^shift` until round 6: a point just outside the box on the low
+    // side has cx = (uint32_t)-1, cx + 1 wraps to 0 and the "guarantee" held for a pair whose corners hash into different
+    // slices -- the second corner's contribution was added outside the LDS slice.  Found when the planar slice layout turned
+    // those stray additions into visible 1e-11-sized gradients of other entries, tests/test_gpu_configs.py.)
+    return cell.c[0] < (1u << shift) - 1u;
 }
 
 // One workgroup = one level x 4096 consecutive samples: rank the records inside the workgroup with LDS counters,

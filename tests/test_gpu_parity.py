@@ -125,6 +125,40 @@ def test_hashgrid_vs_oracle_fresh(dev):
     assert_close(dx, dx_ref, 1e-4, "dx")
 
 
+
+@pytest.mark.parametrize("log2_t", [19, 16])
+def test_hashgrid_backward_points_outside_the_box(dev, log2_t):
+    """Samples outside the bounding box (normalised coordinates below 0 or above 1: rays run past the box, scene_rep.py:134-146
+    normalises without clamping, tcnn floors and wraps).  A point just below 0 has cell coordinate (uint32_t)-1 on every level;
+    until round 6 the routing kernel's fast path for power-of-two hashed levels took `cx + 1 < 2^13` (0 after the wrap) as
+    proof that the cell's x-pairs stay inside one table slice, and the second corner of such a pair was added OUTSIDE the
+    slice's LDS image -- lost, or (planar slice layout) visible as a tiny gradient of an entry nobody touched.  Gradient
+    magnitudes spread over 2^40 like a mapping step's: a stray 1e-11 beside 1e-6 entries passes any relative gate, so the
+    check is the exact one -- an entry the oracle leaves untouched stays exactly zero, a touched one is touched."""
+    torch.manual_seed(7 + log2_t)
+    M = 60000
+    meta = _lib.make_grid_meta(16, 2, log2_t, 16, PLS)
+    ometa = tcnn_cpu.make_grid_meta(16, 2, log2_t, 16, PLS)
+    x = torch.rand(M, 3) * 1.2 - 0.1                                  # a sixth of the points outside, on either side
+    x[:2000, 0] = -torch.rand(2000) * 1e-3                            # just below zero in x: the wrapping cell coordinate
+    x[2000:3000, 1] = -torch.rand(1000) * 1e-3
+    x[3000:4000, 2] = 1.0 + torch.rand(1000) * 1e-3
+    dy = torch.randn(M, 32) * torch.exp2(-40.0 * torch.rand(M, 1))
+    params = torch.zeros(ometa.n_params)
+    dp_ref, _ = tcnn_cpu.hashgrid_backward(x, params, dy, ometa, need_dx=False)
+    for lay, d in ((_lib.FEAT_AOS, dy), (_lib.FEAT_LEVEL_MAJOR, dy.reshape(M, 16, 2).permute(1, 0, 2).contiguous())):
+        dp = torch.zeros(ometa.n_params, device=dev)
+        ops.hashgrid_bwd(x.to(dev), params.to(dev), d.to(dev), dp, meta, lay, None)
+        got = dp.cpu()
+        assert_close(got, dp_ref, 2e-5, f"dparams with points outside the box, T=2^{log2_t}")
+        touched = dp_ref != 0
+        assert float(got[~touched].abs().max()) == 0.0, "a gradient in an entry no sample touches"
+        # (an entry whose contributions cancel exactly in the oracle's fp32 order may keep a residual here and vice versa: rare)
+        assert int(((got == 0) & touched).sum()) <= 4, "a touched entry without a gradient"
+        # the same points through the forward / gather: corner indices are shared code, the features must agree too
+    feat = ops.hashgrid_fwd(x.to(dev), (torch.rand(ometa.n_params) * 2e-4 - 1e-4).to(dev), meta, _lib.FEAT_AOS)
+    assert torch.isfinite(feat).all()
+
 @pytest.mark.parametrize("sparse", [False, True])
 @pytest.mark.parametrize("log2_t,M", [(16, 1), (16, 70000), (22, 3001), (19, 40000)])
 def test_hashgrid_backward_routing_edge_sizes(dev, log2_t, M, sparse):
