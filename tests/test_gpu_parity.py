@@ -155,9 +155,20 @@ def test_hashgrid_backward_points_outside_the_box(dev, log2_t):
         assert float(got[~touched].abs().max()) == 0.0, "a gradient in an entry no sample touches"
         # (an entry whose contributions cancel exactly in the oracle's fp32 order may keep a residual here and vice versa: rare)
         assert int(((got == 0) & touched).sum()) <= 4, "a touched entry without a gradient"
-        # the same points through the forward / gather: corner indices are shared code, the features must agree too
-    feat = ops.hashgrid_fwd(x.to(dev), (torch.rand(ometa.n_params) * 2e-4 - 1e-4).to(dev), meta, _lib.FEAT_AOS)
-    assert torch.isfinite(feat).all()
+    # the same points through the gather side: corner indices bit-exact, features, d x (gather path and saved Jacobian)
+    n = 6000
+    xs, pr = x[:n].contiguous(), (torch.rand(ometa.n_params) * 2 - 1) * 0.1
+    dys = torch.randn(n, 32)
+    assert np.array_equal(ops.hashgrid_indices(xs.to(dev), meta).cpu().numpy(), tcnn_cpu.hashgrid_indices(xs, ometa).numpy().astype(np.int32))
+    assert_close(ops.hashgrid_fwd(xs.to(dev), pr.to(dev), meta), tcnn_cpu.hashgrid_forward(xs, pr, ometa), 2e-6, "features outside the box")
+    _, dx_ref = tcnn_cpu.hashgrid_backward(xs, pr, dys, ometa)
+    dxg, dpg = torch.zeros(n, 3, device=dev), torch.zeros(ometa.n_params, device=dev)
+    ops.hashgrid_bwd(xs.to(dev), pr.to(dev), dys.to(dev), dpg, meta, _lib.FEAT_AOS, dxg)
+    assert_close(dxg, dx_ref, 1e-4, "d x outside the box")
+    _, jac = ops.hashgrid_fwd(xs.to(dev), pr.to(dev), meta, _lib.FEAT_AOS, with_jac=True)
+    dxj = torch.zeros(n, 3, device=dev)
+    ops.hashgrid_dx_from_jac(jac, dys.to(dev), dxj, meta, _lib.FEAT_AOS)
+    assert torch.equal(dxj, dxg), "d x from the saved Jacobian = the gather path, outside the box too"
 
 @pytest.mark.parametrize("sparse", [False, True])
 @pytest.mark.parametrize("log2_t,M", [(16, 1), (16, 70000), (22, 3001), (19, 40000)])
