@@ -910,7 +910,11 @@ __device__ __forceinline__ void decoder16_bwd_tile(const Img bimg, const float* 
 #pragma unroll
         for (int c = 0; c < 3; ++c) mx = fmaxf(mx, fabsf(drgb[c]));
         if (mx > 0.0f && mx < 3.0e38f) {
-            const int e = __builtin_amdgcn_frexp_expf(mx);       // mx = f * 2^e, f in [0.5, 1)
+            // mx = f * 2^e, f in [0.5, 1).  A SUBNORMAL maximum (e < -126: a sample whose whole incoming gradient is below
+            // 1.2e-38 -- a softmax probability of e^-87 times a loss gradient) would ask for 2^-e > 2^127 = inf, and inf x 0
+            // = NaN would reach the grid through d feat: the exponent is held at -126 (the scaled values are then below
+            // 0.5: still exact, just not normalised).  csrc/wgrad16.hip, w16x_updown, replays this bit for bit.
+            const int e = max(__builtin_amdgcn_frexp_expf(mx), -126);
             up = ldexpf(1.0f, -e), down = ldexpf(1.0f, e);
         }
     }

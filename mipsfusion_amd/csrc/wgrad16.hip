@@ -796,7 +796,7 @@ __device__ __forceinline__ void w16x_updown(const f32x8& sm, float& up, float& d
     for (int c = 0; c < 8; ++c) mx = fmaxf(mx, fabsf(sm[c]));
     up = 1.0f, down = 1.0f;
     if (mx > 0.0f && mx < 3.0e38f) {
-        const int e = __builtin_amdgcn_frexp_expf(mx);
+        const int e = max(__builtin_amdgcn_frexp_expf(mx), -126);      // (subnormal maximum: decoder16.hip, RANGE)
         up = ldexpf(1.0f, -e), down = ldexpf(1.0f, e);
     }
 }

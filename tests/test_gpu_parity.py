@@ -1971,6 +1971,43 @@ def test_decoder_bf16x6_matches_fp32_kernel_and_oracle(dev, M, layout):
     assert torch.equal(dfm, res[True][0]) and torch.equal(dxm, res[True][1]), "frozen decoder: same d feat / d x"
 
 
+@pytest.mark.parametrize("precision", ["bf16x6", "f16x3"])
+def test_decoder_backward_with_subnormal_incoming_gradients_stays_finite(dev, precision):
+    """The chain scales every sample's incoming gradient by the power of two that brings its largest component to [0.5, 1).
+    For a sample whose WHOLE incoming gradient is subnormal (below 1.2e-38: a softmax probability of e^-87 times a loss
+    gradient) that power is above 2^127: the scale became inf and inf x 0 = NaN reached d feat -- and from there the grid --
+    until round 6.  Such samples must come out finite and tiny, their neighbours in the tile untouched, and the weight
+    gradients (which replay the scale, csrc/wgrad16.hip) must equal the run with those samples' gradients set to zero to
+    fp32 class."""
+    torch.manual_seed(11)
+    M = 4096
+    dec = MLP_reg({}, input_ch=32, input_ch_pos=48).to(dev)
+    ws = dec.ordered_parameters()
+    pk = ops.decoder_pack16(ws, precision=precision)
+    x = torch.rand(M, 3, device=dev)
+    feat = (torch.randn(M, 32, device=dev) * 0.3).contiguous()
+    out, saved = ops.decoder_fwd(None, feat, _lib.FEAT_AOS, x, None, M, save="lean", precision=precision, packed16=pk)
+    dout = torch.randn(M, 10, device=dev) * 1e-6
+    tiny = torch.zeros(M, dtype=torch.bool, device=dev)
+    tiny[5::17] = True
+    dout_t = dout.clone()
+    dout_t[tiny] = torch.randn(int(tiny.sum()), 10, device=dev) * 1e-41          # subnormal rows (incl. exact zeros in places)
+    dout_z = dout.clone()
+    dout_z[tiny] = 0.0
+    res = {}
+    for tag, d in (("tiny", dout_t), ("zero", dout_z)):
+        g = [torch.zeros_like(w) for w in ws]
+        df, dx, _ = ops.decoder_bwd(None, feat, _lib.FEAT_AOS, x, None, out, d, saved, g, M, precision=precision, packed16=pk)
+        res[tag] = (df, dx, g)
+        assert torch.isfinite(df).all() and torch.isfinite(dx).all() and all(torch.isfinite(t).all() for t in g), tag
+    df_t, dx_t, g_t = res["tiny"]
+    df_z, dx_z, g_z = res["zero"]
+    assert torch.equal(df_t[~tiny], df_z[~tiny]) and torch.equal(dx_t[~tiny], dx_z[~tiny]), "the other samples of the tiles"
+    assert float(df_t[tiny].abs().max()) < 1e-30 and float(dx_t[tiny].abs().max()) < 1e-30
+    for k, a, b in zip(ops.DECODER_PARAM_ORDER, g_t, g_z):
+        assert_close(a, b, 1e-6, "weight gradients beside subnormal samples, grad " + k)
+
+
 def test_decoder_true_error_of_every_arithmetic_against_fp64(dev):
     """What each decoder arithmetic is worth against the TRUTH (fp64 torch on the host, autograd for the backward) on
     realistic magnitudes: weights as initialised / trained, hash-grid features from tcnn's initial 1e-4 up to 0.2,
