@@ -258,7 +258,10 @@ constexpr uint32_t SC_RUN = MIPSF_SC_RUN;                   // consecutive recor
 constexpr uint32_t SC_ROUTE_UNR = 4;                // samples per thread in the routing kernel
 constexpr uint32_t SC_MAX_NS = 512;                 // slices per level (2^22-entry levels)
 constexpr uint32_t SC_MAX_BINS = 8192;
-constexpr uint32_t SC_MASKED_MAX_M = 1u << 24;    // up to here a routing record has room for the 8-bit corner mask
+#ifndef MIPSF_SC_MASKED_MAX_M
+#define MIPSF_SC_MASKED_MAX_M (1u << 24)      // (test builds lower it to run the mask-less path on small batches)
+#endif
+constexpr uint32_t SC_MASKED_MAX_M = MIPSF_SC_MASKED_MAX_M;    // up to here a routing record has room for the 8-bit corner mask
 
 struct ScatterPlan {
     uint32_t n_levels;
