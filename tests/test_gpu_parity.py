@@ -126,6 +126,46 @@ def test_hashgrid_vs_oracle_fresh(dev):
 
 
 
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_hashgrid_backward_fuzz_exact_zero_pattern(dev, seed):
+    """Randomised shapes and point sets for the routed scatter, checked the way that found the routing fault of round 6: close
+    to the oracle AND an entry the oracle never touches is exactly zero.  Table 2^10 .. 2^21, 1 .. 40 000 points mixing the box's
+    interior, both outsides, exact 0 / 1 coordinates, exact cell boundaries of a random level, one crowded cell, duplicated
+    points; gradients spread over 2^40 with dead ray tails, dead samples and dead (sample, level) pairs; both layouts."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    log2_t = [10, 14, 16, 19, 21, 12, 19, 16, 19, 17][seed]
+    M = int(torch.randint(1, 40001, (1,), generator=g)) if seed else 1
+    meta = _lib.make_grid_meta(16, 2, log2_t, 16, PLS)
+    ometa = tcnn_cpu.make_grid_meta(16, 2, log2_t, 16, PLS)
+    x = torch.rand(M, 3, generator=g)
+    kind = torch.randint(0, 8, (M,), generator=g)
+    x[kind == 1] = x[kind == 1] * 1.4 - 0.2                                          # around the box, both sides
+    x[kind == 2] = -torch.rand(int((kind == 2).sum()), 3, generator=g) * 1e-3       # just below zero
+    x[kind == 3] = torch.randint(0, 2, (int((kind == 3).sum()), 3), generator=g).float()      # corners of the box: exact 0 / 1
+    lvl = int(torch.randint(0, 16, (1,), generator=g))
+    sc = float(ometa.scales[lvl])                  # pos = scale * x + 0.5: x = (k - 0.5) / scale sits ON a cell boundary of that level
+    n4 = int((kind == 4).sum())
+    x[kind == 4] = (torch.randint(0, int(ometa.resolutions[lvl]), (n4, 3), generator=g).float() - 0.5) / sc
+    if M > 500:
+        x[100:400] = torch.tensor([0.77, 0.13, 0.52]) + torch.rand(300, 3, generator=g) * 1e-5           # one crowded cell
+        x[400:450] = x[400]                                                                                # duplicates
+    dy = torch.randn(M, 32, generator=g) * torch.exp2(-40.0 * torch.rand(M, 1, generator=g))
+    tail = torch.randint(0, 65, ((M + 63) // 64,), generator=g).repeat_interleave(64)[:M]
+    dy[(torch.arange(M) % 64) >= tail] = 0.0
+    dy[torch.rand(M, generator=g) < 0.1] = 0.0
+    dy[(torch.rand(M, 16, generator=g) < 0.1)[:, :, None].expand(M, 16, 2).reshape(M, 32)] = 0.0
+    params = torch.zeros(ometa.n_params)
+    dp_ref, _ = tcnn_cpu.hashgrid_backward(x, params, dy, ometa, need_dx=False)
+    touched = dp_ref != 0
+    for lay, d in ((_lib.FEAT_AOS, dy), (_lib.FEAT_LEVEL_MAJOR, dy.reshape(M, 16, 2).permute(1, 0, 2).contiguous())):
+        dp = torch.zeros(ometa.n_params, device=dev)
+        ops.hashgrid_bwd(x.to(dev), params.to(dev), d.to(dev), dp, meta, lay, None)
+        got = dp.cpu()
+        if float(dp_ref.abs().max()) > 0:
+            assert_close(got, dp_ref, 2e-5, f"seed {seed}: dparams T=2^{log2_t} M={M}")
+        assert float(got[~touched].abs().max()) == 0.0, f"seed {seed}: a gradient in an entry no sample touches (T=2^{log2_t}, M={M})"
+
+
 @pytest.mark.parametrize("log2_t", [19, 16])
 def test_hashgrid_backward_points_outside_the_box(dev, log2_t):
     """Samples outside the bounding box (normalised coordinates below 0 or above 1: rays run past the box, scene_rep.py:134-146
