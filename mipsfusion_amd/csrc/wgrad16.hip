@@ -1842,8 +1842,7 @@ __device__ __forceinline__ void w16t_role_b(const W16Args& a, const W16T<A>& lx,
     w16x_barrier();
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     v8 X3[P][2], X1[P][2];
-    auto make_x = [&](uint32_t nt, bool with_loads, int parts = 3) {       // parts: 1 = X3, 2 = X1
-        if (parts & 1) {
+    auto make_x = [&](uint32_t nt, bool with_loads) {
         if (lean) {
             float up, down;
             w16x_updown(bSm, up, down);
@@ -1875,8 +1874,6 @@ __device__ __forceinline__ void w16t_role_b(const W16Args& a, const W16T<A>& lx,
             load_tile_rows(g3_srd(nt), 2, rt, lane16, bG3);
         }
         W16_FENCE();
-        }
-        if (!(parts & 2)) return;
         if (A::SCALED) {
             float rs;
             const float sx = w16_pick_scale(w16_block_max_bits(bG1, 2), k1, rs);
@@ -1893,11 +1890,7 @@ __device__ __forceinline__ void w16t_role_b(const W16Args& a, const W16T<A>& lx,
         load_tile_rows(g3_srd(nt), 2, rt, lane16, bG3);
         load_tile_rows(act_srd(a.dact, nt), 0, rt, lane16, bG1);
     };
-#ifndef W16T_SPLIT_X
-#define W16T_SPLIT_X 1      // 1: X1 = dG1[rt] of a tile is made in FRONT of its first barrier (where this role has slack against role
-#endif                      // a's H1 recomputation), only X3 behind the previous tile's products; 0: both behind the products
-    constexpr bool SPLIT_X = EARLY_X && W16T_SPLIT_X;
-    if (EARLY_X && it < a.n_tiles) make_x(0u, false, SPLIT_X ? 1 : 3);
+    if (EARLY_X && it < a.n_tiles) make_x(0u, false);
 #pragma clang loop unroll(disable)
     for (; it < a.n_tiles; it += gridDim.x, par ^= (L::NBUF == 2 ? 1u : 0u)) {
         const uint32_t nt = it + gridDim.x < a.n_tiles ? w16_tile(a, it + gridDim.x) : w16_tile(a, it);
@@ -1929,7 +1922,6 @@ __device__ __forceinline__ void w16t_role_b(const W16Args& a, const W16T<A>& lx,
         W16_FENCE();
         W16_MARK(1);
         if (!EARLY_X) make_x(nt, true);
-        if (SPLIT_X) make_x(0u, false, 2);
         W16_MARK(2);
         W16_MARK(3);
         w16x_barrier();
@@ -1945,7 +1937,7 @@ __device__ __forceinline__ void w16t_role_b(const W16Args& a, const W16T<A>& lx,
         }
         W16_FENCE();
         W16_MARK(5);
-        if (EARLY_X && it + gridDim.x < a.n_tiles) make_x(0u, false, SPLIT_X ? 1 : 3);
+        if (EARLY_X && it + gridDim.x < a.n_tiles) make_x(0u, false);
         W16_MARK(6);
         if (TWO_BARRIERS) w16x_barrier();
         W16_MARK(7);
