@@ -1,4 +1,13 @@
-// Decoder weight gradients as a STREAMING kernel: no LDS, no barriers, the matrix cores do the transposes.
+// Decoder weight gradients on the 16-bit matrix cores.  THREE forms live in this file; which one a launch takes:
+//   * behind the lean records (packed16 given: H1 recomputed; the default of the Python modules), f16x3 and bf16x6:
+//       the TRANSPOSE-READ form (round 6, w16t_role_a / w16t_role_b, far below): operands several waves need are prepared
+//       once per tile and handed over through LDS, every transposition is an LDS write + ds_read_b64_tr_b16, the small-row
+//       products run on v_mfma_f32_16x16x32.  -DW16_TR=0 builds its predecessor, the EXCHANGE form with matrix-core
+//       transposes (rounds 3-5, w16x_role_a / w16x_role_b) -- kept as the A/B baseline of DESIGN.md 4.7;
+//   * full records (packed16 null) and the two-plane bf16 arithmetic: the STREAMING form described next (round 2,
+//       w16_role_a / w16_role_b): no LDS, no barriers, the matrix cores do the transposes.
+//
+// The streaming form:
 //
 //   dW[out][in] = sum over samples s of dOut[s][out] * In[s][in]
 // has the SAMPLE as reduction index, while every activation / gradient record of the decoder (`saved`, `dact`:
