@@ -449,3 +449,75 @@ def test_module_mode_embed_pos_gradient_layout(problem):
     np.testing.assert_allclose(de[24][:32], xx.grad.numpy()[:, 0], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(de[24][32:], xx.grad.numpy()[:, 1], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(de[25][:32], xx.grad.numpy()[:, 2], rtol=1e-8, atol=1e-10)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The LDS image of the transpose-read weight-gradient kernel (csrc/wgrad16.hip, w16t_addr; round 6), emulated lane by lane:
+# a 32 x 32 block in the records' load layout is written plane by plane with ds_write_b128 and read back with
+# ds_read_b64_tr_b16 as an MFMA operand.  The instruction's lane mapping is the one tools/micro/tr_probe.hip checks on the
+# device; the bank rules are MI355X_MICROARCH.md's (ds_write_b128: 8 contiguous lanes per LDS cycle, banks of 4 bytes modulo
+# 32; transposing read: 32 lanes per cycle, banks modulo 64).  Checked: the operand's elements in the order the READY operand
+# planes use (accumulator rows: k-step m, half kg, element u = sample 16 m + 8 (u >> 2) + 4 kg + (u & 3)) for both operand
+# widths, and no bank conflict in any of the three access kinds.
+def _w16t_addr(lane):
+    j, h = lane & 31, lane >> 5
+    sw = ((j >> 1) & 1) | ((((j >> 2) ^ (j >> 3)) & 1) << 1)
+    wr0, wr1 = j * 64 + ((h ^ sw) * 16), j * 64 + (((2 + h) ^ sw) * 16)
+    g, ii = lane >> 4, lane & 15
+    hh, aa, s1 = ii & 1, (ii >> 1) & 1, (ii >> 3) & 1
+    q, kg = g & 1, g >> 1
+    row0, lo = 4 * kg + (ii >> 2), (hh ^ s1) * 16 + 8 * aa
+    rd0 = row0 * 64 + 32 * (q ^ kg) + lo
+    rd1 = (row0 + 8) * 64 + 32 * (q ^ 1 ^ kg) + lo
+    base = (16 * (g >> 1) + 4 * (g & 1) + (ii >> 2)) * 64 + (hh ^ s1) * 16 + 8 * aa
+    return dict(wr0=wr0, wr1=wr1, rd0=rd0, rd1=rd1, rsa=base + 32 * (g & 1), rsb=base + 32 * (1 - (g & 1)))
+
+
+def _tr_read(lds, addrs):
+    """ds_read_b64_tr_b16: result lane i of a 16-lane group, element k = element (i & 3) of the chunk source lane 4 k + (i >> 2) addresses"""
+    out = np.zeros((64, 4), dtype=lds.dtype)
+    for lane in range(64):
+        grp, i = lane & ~15, lane & 15
+        for k in range(4):
+            out[lane, k] = lds[addrs[grp + 4 * k + (i >> 2)] // 2 + (i & 3)]
+    return out
+
+
+def _max_bank_load(addrs, lanes, n_bytes, n_banks):
+    load = {}
+    for lane in lanes:
+        for d in range(n_bytes // 4):
+            b = (addrs[lane] // 4 + d) % n_banks
+            load[b] = load.get(b, 0) + 1
+    return max(load.values())
+
+
+def test_wgrad_transpose_read_lds_layout_emulation():
+    V = (np.arange(32 * 32).reshape(32, 32) + 1).astype(np.int64)          # V[sample][feature]
+    ad = [_w16t_addr(lane) for lane in range(64)]
+    lds = np.zeros(1024, dtype=np.int64)                                    # one plane: 2 KB of 16-bit elements
+    for lane in range(64):
+        j, h = lane & 31, lane >> 5
+        for q in range(2):
+            for u in range(8):                                              # load layout: feature 16 q + 8 (u >> 2) + 4 h + (u & 3)
+                lds[ad[lane]["wr%d" % q] // 2 + u] = V[j, 16 * q + 8 * (u >> 2) + 4 * h + (u & 3)]
+    for m in range(2):                                                      # 32-wide operand (v_mfma_f32_32x32x16)
+        X = np.concatenate([_tr_read(lds, [a["rd0"] + 1024 * m for a in ad]), _tr_read(lds, [a["rd1"] + 1024 * m for a in ad])], 1)
+        for lane in range(64):
+            for u in range(8):
+                assert X[lane, u] == V[16 * m + 8 * (u >> 2) + 4 * (lane >> 5) + (u & 3), lane & 31]
+    for cg in range(2):                                                     # 16-wide operand (v_mfma_f32_16x16x32)
+        a0 = [a["rsa" if cg == 0 else "rsb"] for a in ad]
+        a1 = [a["rsb" if cg == 0 else "rsa"] + 512 for a in ad]
+        Y = np.concatenate([_tr_read(lds, a0), _tr_read(lds, a1)], 1)
+        for lane in range(64):
+            g = lane >> 4
+            for u in range(8):
+                assert Y[lane, u] == V[16 * (g >> 1) + 8 * (u >> 2) + 4 * (g & 1) + (u & 3), 16 * cg + (lane & 15)]
+    # bank conflicts: none
+    for key in ("wr0", "wr1"):
+        for g0 in range(0, 64, 8):
+            assert _max_bank_load([a[key] for a in ad], range(g0, g0 + 8), 16, 32) == 1
+    for key, off in (("rd0", 0), ("rd1", 0), ("rd0", 1024), ("rsa", 0), ("rsb", 512), ("rsb", 0), ("rsa", 512)):
+        for half in (range(0, 32), range(32, 64)):
+            assert _max_bank_load([a[key] + off for a in ad], half, 8, 64) == 1
